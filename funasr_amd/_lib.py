@@ -1,0 +1,149 @@
+"""ctypes binding of the C ABI declared in include/paraformer_hip.h.
+
+The shared library is the product: there is no Python/CPU fallback. If it is missing, ``load()`` raises with the
+build command; if no GPU is visible, every ``pf_*_create`` fails and the wrappers raise ``HipRuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparaformer_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class HipRuntimeError(RuntimeError):
+    """A pf_* entry point returned a non-zero status."""
+
+
+class pf_frontend_config(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_int32), ("frame_length", C.c_int32), ("frame_shift", C.c_int32),
+        ("n_mels", C.c_int32), ("lfr_m", C.c_int32), ("lfr_n", C.c_int32),
+        ("low_freq", C.c_float), ("high_freq", C.c_float), ("preemph", C.c_float), ("upscale", C.c_float),
+    ]
+
+
+class pf_encoder_config(C.Structure):
+    _fields_ = [
+        ("input_dim", C.c_int32), ("d_model", C.c_int32), ("n_heads", C.c_int32), ("ffn_dim", C.c_int32),
+        ("n_blocks", C.c_int32), ("tp_blocks", C.c_int32), ("kernel_size", C.c_int32), ("sanm_shift", C.c_int32),
+        ("ln_eps", C.c_float),
+    ]
+
+
+class pf_predictor_config(C.Structure):
+    _fields_ = [
+        ("d_model", C.c_int32), ("l_order", C.c_int32), ("r_order", C.c_int32),
+        ("threshold", C.c_float), ("smooth_factor", C.c_float), ("noise_threshold", C.c_float),
+        ("tail_threshold", C.c_float), ("tail_mask", C.c_int32),
+    ]
+
+
+class pf_decoder_config(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("d_model", C.c_int32), ("n_heads", C.c_int32), ("ffn_dim", C.c_int32),
+        ("n_blocks", C.c_int32), ("kernel_size", C.c_int32), ("sanm_shift", C.c_int32), ("ln_eps", C.c_float),
+    ]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_pi32 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); mirrors include/paraformer_hip.h declaration by declaration
+SIGNATURES = {
+    "pf_last_error": (C.c_char_p, []),
+    "pf_abi_version": (C.c_int, []),
+    "pf_device_count": (C.c_int, []),
+    "pf_frontend_create": (_vp, [C.POINTER(pf_frontend_config)]),
+    "pf_frontend_destroy": (None, [_vp]),
+    "pf_frontend_set_cmvn": (C.c_int, [_vp, _vp, _vp, _i32]),
+    "pf_frontend_set_tables": (C.c_int, [_vp, _vp, _vp]),
+    "pf_frontend_num_fbank_frames": (_i32, [_vp, _i64]),
+    "pf_frontend_num_frames": (_i32, [_vp, _i64]),
+    "pf_frontend_forward": (C.c_int, [_vp, _vp, _i64, _pi32, _i32, _vp, _i32, _pi32, _vp, _vp]),
+    "pf_encoder_create": (_vp, [C.POINTER(pf_encoder_config)]),
+    "pf_encoder_destroy": (None, [_vp]),
+    "pf_encoder_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "pf_encoder_missing": (C.c_int, [_vp]),
+    "pf_encoder_forward": (C.c_int, [_vp, _vp, _pi32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "pf_predictor_create": (_vp, [C.POINTER(pf_predictor_config)]),
+    "pf_predictor_destroy": (None, [_vp]),
+    "pf_predictor_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "pf_predictor_missing": (C.c_int, [_vp]),
+    "pf_predictor_alphas": (C.c_int, [_vp, _vp, _pi32, _i32, _i32, _vp, _vp, _pi32, _vp]),
+    "pf_predictor_embeds": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pf_decoder_create": (_vp, [C.POINTER(pf_decoder_config)]),
+    "pf_decoder_destroy": (None, [_vp]),
+    "pf_decoder_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "pf_decoder_missing": (C.c_int, [_vp]),
+    "pf_decoder_forward": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pf_ctc_create": (_vp, [_i32, _i32]),
+    "pf_ctc_destroy": (None, [_vp]),
+    "pf_ctc_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "pf_ctc_missing": (C.c_int, [_vp]),
+    "pf_ctc_greedy": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "pf_k_gemm_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pf_k_gemm_argmax_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pf_k_layernorm": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pf_k_fsmn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pf_k_attention_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pf_k_gemm_f32_time": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
+    # profiling hooks used by bench.py (not part of the reference boundary)
+    "pf_prof_enable": (C.c_int, [C.c_int]),
+    "pf_prof_reset": (C.c_int, []),
+    "pf_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libparaformer_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libparaformer_hip.so failed:\n" + res.stdout)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes. Raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is the only implementation of this package. "
+                f"Build it with `make -C {CSRC_DIR}` (or `python -c 'import __graft_entry__ as g; g.build()'`)."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError = ABI drift between header and library
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    msg = load().pf_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise HipRuntimeError(f"{what} failed with status {status}: {last_error()}")
+
+
+def check_handle(handle, what: str):
+    if not handle:
+        raise HipRuntimeError(f"{what} failed: {last_error()}")
+    return handle

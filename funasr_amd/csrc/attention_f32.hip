@@ -1,0 +1,160 @@
+// Flash-style scaled-dot-product attention in exact fp32 on the CDNA4 matrix cores (d_k = 128).
+//
+// Replaces the materialised  softmax((q * d_k^-0.5) k^T masked_fill -inf) masked_fill 0  @ v  of
+//   funasr/models/sanm/attention.py:270-306,322-327   (encoder self-attention, SAN-M)
+//   funasr/models/sanm/attention.py:760-813           (decoder cross-attention over the encoder memory)
+// The T x T score matrix (256 MB per layer at B=64, T=500) never reaches HBM.
+//
+// Mapping. One workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries and the
+// whole d_k = 128. Both MFMA products are issued "swapped" so that a lane always holds ONE query
+// (q = lane & 31) and the keys / output channels run over its accumulator registers:
+//     S^T[key][q] = sum_d K[key][d] * Q[q][d]      A = K tile (LDS), B = Q (64 registers per lane)
+//     O^T[d][q]   = sum_key V[key][d] * P[q][key]  A = V tile (LDS), B = P (= the S^T accumulator registers)
+// The 32x32x2 MFMA's k index is only a pairing between A and B, so the half-wave h = lane >> 5 takes
+// d in [64h, 64h+64) for S^T and, for O^T, exactly the key its own S^T register r already holds
+// (key = (r&3) + 8(r>>2) + 4h): P feeds the second product straight from registers, the online-softmax row
+// statistics are per lane (one xor-32 shuffle joins the two halves) and no LDS transpose is needed.
+// K rows are padded to 132 floats so the ds_read_b128 operand fetch is bank-conflict free; V rows are
+// read 32 consecutive floats per half-wave.
+#include "common.h"
+
+namespace pf {
+
+namespace {
+
+constexpr int DK = 128;        // head dim
+constexpr int KT = 32;         // keys per tile
+constexpr int KLD = DK + 4;    // padded K row (floats)
+
+__global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[KT * KLD + KT * DK];
+    float* Ks = smem;
+    float* Vs = smem + KT * KLD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, idx = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + idx;
+    const int qc = q < p.Tq ? q : p.Tq - 1;
+    const int klen = p.klens[b];
+
+    // Q fragment: this lane's query row, d in [64h, 64h + 64), pre-scaled like the reference (q * d_k^-0.5)
+    float qreg[64];
+    {
+        const float* qp = p.Q + ((size_t)b * p.Tq + qc) * p.ldq + head * DK + hh * 64;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + 4 * i);
+            qreg[4 * i + 0] = t.x * p.scale;
+            qreg[4 * i + 1] = t.y * p.scale;
+            qreg[4 * i + 2] = t.z * p.scale;
+            qreg[4 * i + 3] = t.w * p.scale;
+        }
+    }
+
+    floatx16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int lc4 = tid & 31, lr = tid >> 5;   // tile loader: 32 float4 per row, 8 rows per pass
+    const float* kbase = p.K + (size_t)b * p.Tk * p.ldk + head * DK + lc4 * 4;
+    const float* vbase = p.V + (size_t)b * p.Tk * p.ldv + head * DK + lc4 * 4;
+
+    const int ntiles = (klen + KT - 1) / KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * KT;
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 8 * i;
+            int kr = k0 + r;
+            kr = kr < p.Tk ? kr : p.Tk - 1;
+            const float4 kv = *reinterpret_cast<const float4*>(kbase + (size_t)kr * p.ldk);
+            const float4 vv = *reinterpret_cast<const float4*>(vbase + (size_t)kr * p.ldv);
+            *reinterpret_cast<float4*>(&Ks[r * KLD + lc4 * 4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[r * DK + lc4 * 4]) = vv;
+        }
+        __syncthreads();
+
+        // ---- S^T tile (32 keys x 32 queries)
+        floatx16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kp = &Ks[idx * KLD + hh * 64];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + 4 * i);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qreg[4 * i + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qreg[4 * i + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[4 * i + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qreg[4 * i + 3], s, 0, 0, 0);
+        }
+
+        // ---- online softmax for query (lane & 31); this lane holds keys k0 + (r&3) + 8(r>>2) + 4h
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= klen) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
+        const float alpha = expf(m_run - m_new);       // exp(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = expf(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float* vp = &Vs[krow * DK + idx];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * d], s[r], o[d], 0, 0, 0);
+        }
+    }
+
+    if (q < p.Tq) {
+        const float inv = 1.0f / l_run;
+        float* op = p.O + ((size_t)b * p.Tq + q) * p.ldo + head * DK;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 t;
+                t.x = o[d][4 * g + 0] * inv;
+                t.y = o[d][4 * g + 1] * inv;
+                t.z = o[d][4 * g + 2] * inv;
+                t.w = o[d][4 * g + 3] * inv;
+                *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hh) = t;
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
+    PF_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
+    PF_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0, "attention: strides % 4");
+    dim3 grid(ceil_div(a.Tq, 128), a.H, a.B);
+    hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pf

@@ -1,0 +1,93 @@
+// Shared helpers for the gfx950 kernels of the Paraformer / SenseVoice hot path.
+// CDNA4 only: 64-wide wavefronts, MFMA, LDS. No CUDA/compat branches on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace pf {
+
+// thread-local last error text, surfaced through pf_last_error()
+void set_error(const std::string& msg);
+const char* get_error();
+
+#define PF_HIP_TRY(expr)                                                         \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) {                                                  \
+            pf::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));    \
+            return -2;                                                           \
+        }                                                                        \
+    } while (0)
+
+#define PF_REQUIRE(cond, msg)                                                    \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            pf::set_error(std::string("invalid argument: ") + (msg));            \
+            return -1;                                                           \
+        }                                                                        \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- kernel launchers
+// (all take device pointers; `stream` is the HIP stream the caller owns)
+
+struct GemmArgs {
+    const float* A;   int lda;   // [M, K] activations, row stride lda
+    const float* W;   int ldw;   // [N, K] weights (torch Linear layout), row stride ldw
+    const float* bias;           // [N] or nullptr
+    const float* R1;  int ldr1;  // optional addend #1 (added first:  v = v + R1)
+    const float* R2;  int ldr2;  // optional addend #2 (added second: v = R2 + v)
+    float* C;         int ldc;   // [M, N]
+    int M, N, K;                 // K % 32 == 0
+    int relu;                    // apply relu after bias, before addends
+    // optional fused arg-max over N (used for vocabulary projections): when amax_val != nullptr the
+    // kernel does not write C but per-(row, column-block) partial maxima
+    float* amax_val; int* amax_idx; int amax_ld;
+};
+int launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
+
+int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
+                     int M, int D, int Dpad, float eps, hipStream_t stream);
+
+int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
+                        hipStream_t stream);
+
+struct FsmnArgs {
+    const float* in;  int ldin;   // [B*T, C] view (row stride ldin)
+    const float* w;               // [C, K] depthwise taps
+    const float* R;   int ldr;    // optional residual (added after masking), or nullptr
+    float* out;       int ldo;
+    const int* lens;              // device int32 [B]: valid rows per sequence
+    int B, T, C, K, left_pad;
+};
+int launch_fsmn(const FsmnArgs& a, hipStream_t stream);
+
+struct AttnArgs {
+    const float* Q; int ldq;      // row (b*Tq + t), head h at column h*128
+    const float* K; int ldk;      // row (b*Tk + t)
+    const float* V; int ldv;
+    float* O;       int ldo;
+    const int* klens;             // device int32 [B] valid keys per sequence (>= 1)
+    int B, H, Tq, Tk;
+    float scale;
+};
+int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
+
+}  // namespace pf

@@ -1,0 +1,196 @@
+// HBM-bound row-wise kernels of the SAN-M encoder/decoder: LayerNorm, input scale + sinusoidal PE, and the
+// FSMN memory block (depthwise conv along time).
+//
+// Reference semantics:
+//   LayerNorm            funasr/models/transformer/layer_norm.py:13-38 (nn.LayerNorm over the last dim, eps 1e-12;
+//                        SenseVoice's copy funasr/models/sense_voice/model.py:300-323 uses eps 1e-5)
+//   scale + PE           funasr/models/sanm/encoder.py:409 (x * sqrt(d_model)) and
+//                        funasr/models/transformer/embedding.py:422-432 (x + PE, positions 1-based)
+//   FSMN (encoder)       funasr/models/sanm/attention.py:216-239  mask*(conv_k(pad(mask*v)) + mask*v)
+//   FSMN (decoder)       funasr/models/sanm/attention.py:583-631 + residual at paraformer/decoder.py:106-107
+//
+// All three are pure streaming ops: one coalesced 16-B load / store per lane, wave-shuffle reductions,
+// nothing is reshaped into a GEMM.
+#include "common.h"
+
+namespace pf {
+
+namespace {
+
+// One wave per row. NV = float4 chunks per lane (D <= 256 * NV).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        int ldy, int M, int D, int Dpad, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nchunk = D >> 2;
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            v[j] = *reinterpret_cast<const float4*>(xr + 4 * c);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        } else {
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    q = wave_sum(q);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    float* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
+            const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c);
+            float4 o;
+            o.x = (v[j].x - mean) * rstd * g.x + b.x;
+            o.y = (v[j].y - mean) * rstd * g.y + b.y;
+            o.z = (v[j].z - mean) * rstd * g.z + b.z;
+            o.w = (v[j].w - mean) * rstd * g.w + b.w;
+            *reinterpret_cast<float4*>(yr + 4 * c) = o;
+        } else if (4 * c < Dpad) {
+            *reinterpret_cast<float4*>(yr + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_add_pe_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ pe, float* __restrict__ y,
+                                                           int T, int D4, float scale, size_t total4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t per_seq = (size_t)T * D4;
+    for (; i < total4; i += stride) {
+        const size_t r = i % per_seq;   // (t, d4) inside one sequence
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        const float4 p = reinterpret_cast<const float4*>(pe)[r];
+        float4 o;   // mul then add, two roundings like the reference (x * scale, then + pe)
+        o.x = __fadd_rn(__fmul_rn(a.x, scale), p.x);
+        o.y = __fadd_rn(__fmul_rn(a.y, scale), p.y);
+        o.z = __fadd_rn(__fmul_rn(a.z, scale), p.z);
+        o.w = __fadd_rn(__fmul_rn(a.w, scale), p.w);
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// FSMN memory block. Thread = 4 channels; block = (C/4 threads) x FSMN_TT consecutive frames of one sequence,
+// a register sliding window of KS + TT - 1 masked input rows (each input row is fetched once per block).
+constexpr int FSMN_TT = 8;
+template <int KS, int LP>
+__global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * FSMN_TT;
+    const int c4 = threadIdx.x;
+    if (c4 * 4 >= p.C) return;
+    const int len = p.lens[b];
+    float4 w[KS];
+    {
+        const float* wp = p.w + (size_t)c4 * 4 * KS;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            w[j].x = wp[j];
+            w[j].y = wp[KS + j];
+            w[j].z = wp[2 * KS + j];
+            w[j].w = wp[3 * KS + j];
+        }
+    }
+    float4 win[KS + FSMN_TT - 1];
+#pragma unroll
+    for (int i = 0; i < KS + FSMN_TT - 1; ++i) {
+        const int tt = t0 - LP + i;
+        if (tt >= 0 && tt < p.T && tt < len)
+            win[i] = *reinterpret_cast<const float4*>(p.in + ((size_t)b * p.T + tt) * p.ldin + c4 * 4);
+        else
+            win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < FSMN_TT; ++i) {
+        const int t = t0 + i;
+        if (t < p.T) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < len) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    acc.x = fmaf(w[j].x, win[i + j].x, acc.x);
+                    acc.y = fmaf(w[j].y, win[i + j].y, acc.y);
+                    acc.z = fmaf(w[j].z, win[i + j].z, acc.z);
+                    acc.w = fmaf(w[j].w, win[i + j].w, acc.w);
+                }
+                const float4 c = win[i + LP];   // the (masked) input row itself
+                o.x = acc.x + c.x; o.y = acc.y + c.y; o.z = acc.z + c.z; o.w = acc.w + c.w;
+            }
+            const size_t row = (size_t)b * p.T + t;
+            if (p.R) {
+                const float4 r = *reinterpret_cast<const float4*>(p.R + row * p.ldr + c4 * 4);
+                o.x = r.x + o.x; o.y = r.y + o.y; o.z = r.z + o.z; o.w = r.w + o.w;
+            }
+            *reinterpret_cast<float4*>(p.out + row * p.ldo + c4 * 4) = o;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int M,
+                     int D, int Dpad, float eps, hipStream_t stream) {
+    PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm: D must be a multiple of 4 and <= 2048");
+    PF_REQUIRE(Dpad >= D && Dpad % 4 == 0 && Dpad <= 2048 && ldy >= Dpad, "layernorm: bad Dpad/ldy");
+    PF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: strides must be multiples of 4");
+    dim3 grid(ceil_div(M, 4)), block(256);
+    const int nv = ceil_div(Dpad / 4, 64);
+    if (nv <= 2)
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);
+    else if (nv <= 3)
+        hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
+                        hipStream_t stream) {
+    PF_REQUIRE(B > 0 && T > 0 && D % 4 == 0, "scale_add_pe: D must be a multiple of 4");
+    const size_t total4 = (size_t)B * T * (D / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(scale_add_pe_kernel, dim3(blocks), dim3(256), 0, stream, x, pe, y, T, D / 4, scale, total4);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_fsmn(const FsmnArgs& a, hipStream_t stream) {
+    PF_REQUIRE(a.B > 0 && a.T > 0 && a.C % 4 == 0 && a.C <= 1024, "fsmn: C must be a multiple of 4 and <= 1024");
+    PF_REQUIRE(a.ldin % 4 == 0 && a.ldo % 4 == 0 && (a.R == nullptr || a.ldr % 4 == 0), "fsmn: strides % 4");
+    dim3 grid(ceil_div(a.T, FSMN_TT), a.B), block(a.C / 4);
+    if (a.K == 11 && a.left_pad == 5)
+        hipLaunchKernelGGL((fsmn_kernel<11, 5>), grid, block, 0, stream, a);
+    else if (a.K == 11 && a.left_pad == 10)
+        hipLaunchKernelGGL((fsmn_kernel<11, 10>), grid, block, 0, stream, a);
+    else {
+        set_error("fsmn: only kernel_size 11 with left padding 5 (offline) or 10 (sanm_shfit 5) is built");
+        return -1;
+    }
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pf

@@ -1,0 +1,102 @@
+"""Tensor-level wrappers over the single-kernel entry points (pf_k_*) of the C ABI.
+
+torch is used only as the owner of device memory and of the current HIP stream; every function launches exactly
+one gfx950 kernel from libparaformer_hip.so and raises if the library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor in GPU memory (there is no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add1=None, add2=None, out=None):
+    """out = (relu?)(a @ w.T + bias) (+ add1) (+ add2);  a [M, K] (row stride a.stride(0)), w [N, K]."""
+    lib = _lib.load()
+    _f32c(a, "a"), _f32c(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    assert a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_gemm_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias),
+                                 _ptr(add1), add1.stride(0) if add1 is not None else 0,
+                                 _ptr(add2), add2.stride(0) if add2 is not None else 0,
+                                 _ptr(out), out.stride(0), M, N, K, int(relu), _stream()), "pf_k_gemm_f32")
+    return out
+
+
+def gemm_argmax(a: torch.Tensor, w: torch.Tensor, bias=None):
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    nparts = 2 * ((N + 127) // 128)
+    ids = torch.empty(M, device=a.device, dtype=torch.int32)
+    sval = torch.empty(M, nparts, device=a.device, dtype=torch.float32)
+    sidx = torch.empty(M, nparts, device=a.device, dtype=torch.int32)
+    _lib.check(lib.pf_k_gemm_argmax_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), M, N, K,
+                                        _ptr(ids), _ptr(sval), _ptr(sidx), _stream()), "pf_k_gemm_argmax_f32")
+    return ids
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float, pad_to: int | None = None):
+    lib = _lib.load()
+    _f32c(x, "x")
+    M, D = x.shape
+    Dpad = pad_to or D
+    y = torch.empty(M, Dpad, device=x.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_layernorm(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(y), Dpad, M, D, Dpad,
+                                  float(eps), _stream()), "pf_k_layernorm")
+    return y
+
+
+def fsmn(x: torch.Tensor, w: torch.Tensor, lens: torch.Tensor, left_pad: int, residual=None):
+    """x [B, T, C] (last-dim contiguous view allowed), w [C, 1, K] or [C, K], lens int32 [B] on device."""
+    lib = _lib.load()
+    B, T, Cc = x.shape
+    assert x.stride(2) == 1 and x.stride(0) == T * x.stride(1)
+    w2 = w.reshape(Cc, -1).contiguous()
+    out = torch.empty(B, T, Cc, device=x.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_fsmn(_ptr(x), x.stride(1), _ptr(w2), _ptr(residual), Cc if residual is not None else 0,
+                             _ptr(out), Cc, _ptr(lens), B, T, Cc, w2.shape[1], left_pad, _stream()), "pf_k_fsmn")
+    return out
+
+
+def attention(q, k, v, klens, n_heads: int, scale: float):
+    """q [B, Tq, H*128], k/v [B, Tk, H*128] (row-strided views allowed), klens int32 [B] on device."""
+    lib = _lib.load()
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    out = torch.empty(B, Tq, D, device=q.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_attention_f32(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(out), D,
+                                      _ptr(klens), B, n_heads, Tq, Tk, float(scale), _stream()), "pf_k_attention_f32")
+    return out
+
+
+def gemm_time_ms(a, w, bias, out, iters: int = 20) -> float:
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_gemm_f32_time(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(out),
+                                      out.stride(0), M, N, K, iters, C.byref(ms), _stream()), "pf_k_gemm_f32_time")
+    return float(ms.value)

@@ -1,0 +1,197 @@
+/*
+ * paraformer_hip.h -- C ABI of the MI355X-native (gfx950) Paraformer / SenseVoice inference hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types. Every module of the
+ * reference's operator registry (funasr/register.py `tables`) that sits on the hot path has one opaque
+ * handle here, with `create / set_tensor / forward / destroy` entry points whose tensor contract mirrors the
+ * reference module's forward():
+ *
+ *   pf_frontend   <-> WavFrontend.forward                    funasr/frontends/wav_frontend.py:149-196
+ *   pf_encoder    <-> SANMEncoder.forward                    funasr/models/sanm/encoder.py:392-461
+ *                     SenseVoiceEncoderSmall.forward         funasr/models/sense_voice/model.py:623-655
+ *   pf_predictor  <-> CifPredictorV2.forward                 funasr/models/paraformer/cif_predictor.py:253-314
+ *   pf_decoder    <-> ParaformerSANMDecoder.forward          funasr/models/paraformer/decoder.py:397-449
+ *                     (+ log_softmax/argmax of Paraformer.inference, funasr/models/paraformer/model.py:345,642)
+ *   pf_ctc        <-> CTC.log_softmax / argmax               funasr/models/ctc/ctc.py:192-216
+ *
+ * The handle style (opaque pointer, int return codes, library-owned scratch) follows the reference's own C
+ * API for the same path, runtime/onnxruntime/include/funasrruntime.h:21-24,58-73. Tensor names accepted by
+ * `*_set_tensor` are the reference's state_dict keys relative to the module, e.g.
+ * "encoders0.0.self_attn.linear_q_k_v.weight", so a real model.pt loads without a conversion step.
+ *
+ * Conventions
+ *   - `*_dev` pointers are device (HBM) pointers, 16-byte aligned, row-major contiguous float32 unless stated.
+ *   - `*_host` pointers are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). All work is enqueued on it; a
+ *     call only synchronises where it has to return a host value (documented per function).
+ *   - return value: 0 = ok, -1 = invalid argument, -2 = HIP runtime error, -3 = missing tensor / not ready.
+ *     pf_last_error() returns a thread-local message for the last failure.
+ *   - the library never falls back to a CPU path: without a gfx950 device every create() fails with -2.
+ */
+#ifndef PARAFORMER_HIP_H_
+#define PARAFORMER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+
+const char* pf_last_error(void);
+int pf_abi_version(void);
+/* number of visible HIP devices (0 when there is no GPU); never fails */
+int pf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------ frontend */
+typedef struct pf_frontend pf_frontend;
+
+typedef struct pf_frontend_config {
+    int32_t sample_rate;      /* 16000 */
+    int32_t frame_length;     /* samples per window: 400 (25 ms)      wav_frontend.py:100,174 */
+    int32_t frame_shift;      /* samples per hop:    160 (10 ms)      wav_frontend.py:101 */
+    int32_t n_mels;           /* 80                                   wav_frontend.py:99 */
+    int32_t lfr_m;            /* 7 frames stacked                     wav_frontend.py:104 */
+    int32_t lfr_n;            /* 6 frames hop                         wav_frontend.py:105 */
+    float low_freq;           /* 20 Hz (Kaldi default) */
+    float high_freq;          /* 0 -> Nyquist */
+    float preemph;            /* 0.97 */
+    float upscale;            /* 32768: waveform * (1 << 15)          wav_frontend.py:168-169 */
+} pf_frontend_config;
+
+pf_frontend* pf_frontend_create(const pf_frontend_config* cfg);
+void pf_frontend_destroy(pf_frontend* f);
+/* CMVN rows of am.mvn (<AddShift>, <Rescale>; wav_frontend.py:15-60): y = (x + shift) * scale. n = n_mels*lfr_m */
+int pf_frontend_set_cmvn(pf_frontend* f, const float* shift_host, const float* scale_host, int32_t n);
+/* Optional: override the built-in Kaldi tables (float64 cos window, float32 mel triangles as in
+ * kaldi-native-fbank feature-window.cc:25-47, mel-computations.cc:118-210) with caller-computed ones, e.g. the
+ * float32 tables torchaudio.compliance.kaldi builds. window: [frame_length]; mel: dense [n_mels, 257]. */
+int pf_frontend_set_tables(pf_frontend* f, const float* window_host, const float* mel_host);
+/* frames after fbank (snip_edges) and after LFR for an utterance of n_samples */
+int32_t pf_frontend_num_fbank_frames(const pf_frontend* f, int64_t n_samples);
+int32_t pf_frontend_num_frames(const pf_frontend* f, int64_t n_samples);
+/* wav_dev: [B, wav_stride] float32 in [-1, 1]; n_samples_host: [B]; feats_dev: [B, T_out, n_mels*lfr_m] with
+ * T_out >= max_b frames(b), rows past an utterance's length are zero-filled (pad_sequence, :195);
+ * feat_lens_host: [B] output. Also accepts fbank_dev != NULL to export the raw [B, T_fb_max, n_mels] log-mel
+ * (T_fb_max = max_b fbank frames). Does not synchronise. */
+int pf_frontend_forward(pf_frontend* f, const float* wav_dev, int64_t wav_stride, const int32_t* n_samples_host,
+                        int32_t B, float* feats_dev, int32_t T_out, int32_t* feat_lens_host, float* fbank_dev,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------- encoder */
+typedef struct pf_encoder pf_encoder;
+
+typedef struct pf_encoder_config {
+    int32_t input_dim;        /* 560 = n_mels * lfr_m                         sanm/encoder.py:197 */
+    int32_t d_model;          /* 512  output_size */
+    int32_t n_heads;          /* 4    attention_heads (d_k must be 128) */
+    int32_t ffn_dim;          /* 2048 linear_units */
+    int32_t n_blocks;         /* 50   num_blocks: encoders0 (1) + encoders (n_blocks-1) */
+    int32_t tp_blocks;        /* 0 (Paraformer) or 20 (SenseVoiceSmall tp_encoders, sense_voice/model.py:601-612) */
+    int32_t kernel_size;      /* 11   FSMN taps */
+    int32_t sanm_shift;       /* 0    sanm_shfit */
+    float ln_eps;             /* 1e-12 (layer_norm.py:16) / 1e-5 (sense_voice/model.py:300-323) */
+} pf_encoder_config;
+
+pf_encoder* pf_encoder_create(const pf_encoder_config* cfg);
+void pf_encoder_destroy(pf_encoder* e);
+/* data may be a host or a device pointer; the tensor is copied (and repacked) into library-owned HBM */
+int pf_encoder_set_tensor(pf_encoder* e, const char* name, const float* data, int64_t numel);
+/* number of tensors still missing (0 = ready) */
+int pf_encoder_missing(const pf_encoder* e);
+/* xs_dev: [B, T, input_dim] (un-scaled features, exactly what SANMEncoder.forward receives), lens_host: [B],
+ * pe_dev: [T, input_dim] sinusoidal table (embedding.py:396-420; NULL = library computes it with libm),
+ * out_dev: [B, T, d_model]. run_blocks < 0 runs everything incl. the final norm(s); run_blocks = k >= 0 stops
+ * after k encoder blocks and returns the raw residual stream (for per-layer parity checks). No sync. */
+int pf_encoder_forward(pf_encoder* e, const float* xs_dev, const int32_t* lens_host, int32_t B, int32_t T,
+                       const float* pe_dev, float* out_dev, int32_t run_blocks, void* stream);
+
+/* ----------------------------------------------------------------------------------------------- predictor */
+typedef struct pf_predictor pf_predictor;
+
+typedef struct pf_predictor_config {
+    int32_t d_model;          /* idim 512 */
+    int32_t l_order;          /* 1 */
+    int32_t r_order;          /* 1 */
+    float threshold;          /* 1.0 (the prefix-sum/floor formulation of cif_v1 is only defined for 1.0) */
+    float smooth_factor;      /* 1.0 */
+    float noise_threshold;    /* 0.0 */
+    float tail_threshold;     /* 0.45 */
+    int32_t tail_mask;        /* 1 */
+} pf_predictor_config;
+
+pf_predictor* pf_predictor_create(const pf_predictor_config* cfg);
+void pf_predictor_destroy(pf_predictor* p);
+int pf_predictor_set_tensor(pf_predictor* p, const char* name, const float* data, int64_t numel);
+int pf_predictor_missing(const pf_predictor* p);
+/* Step 1: alphas + fire scan. hidden_dev: [B, T, d_model]; lens_host: [B];
+ * alphas_dev / peaks_dev: [B, T+1] outputs (tail-extended alphas, cif_peak); token_num_host: [B] output =
+ * number of fired tokens (= floor(sum alphas), cif_predictor.py:443-446). SYNCHRONISES the stream (the token
+ * count decides the decoder's shape, like the .item() at cif_predictor.py:311). */
+int pf_predictor_alphas(pf_predictor* p, const float* hidden_dev, const int32_t* lens_host, int32_t B, int32_t T,
+                        float* alphas_dev, float* peaks_dev, int32_t* token_num_host, void* stream);
+/* Step 2: acoustic embeddings for the scan of the last pf_predictor_alphas call: embeds_dev [B, N, d_model],
+ * rows >= token_num[b] are zero. No sync. */
+int pf_predictor_embeds(pf_predictor* p, const float* hidden_dev, int32_t B, int32_t T, int32_t N,
+                        float* embeds_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------- decoder */
+typedef struct pf_decoder pf_decoder;
+
+typedef struct pf_decoder_config {
+    int32_t vocab_size;       /* 8404 */
+    int32_t d_model;          /* 512 */
+    int32_t n_heads;          /* 4 */
+    int32_t ffn_dim;          /* 2048 */
+    int32_t n_blocks;         /* 16 = att_layer_num = num_blocks (decoders2 absent, decoder.py:363-364) */
+    int32_t kernel_size;      /* 11 */
+    int32_t sanm_shift;       /* 0 offline / 5 streaming model */
+    float ln_eps;             /* 1e-12 */
+} pf_decoder_config;
+
+pf_decoder* pf_decoder_create(const pf_decoder_config* cfg);
+void pf_decoder_destroy(pf_decoder* d);
+int pf_decoder_set_tensor(pf_decoder* d, const char* name, const float* data, int64_t numel);
+int pf_decoder_missing(const pf_decoder* d);
+/* memory_dev: [B, T, d_model] encoder output, mem_lens_host: [B]; embeds_dev: [B, N, d_model] CIF output,
+ * tok_lens_host: [B]. Outputs (each may be NULL): logits_dev [B, N, vocab] (pre-softmax, decoder.py:444),
+ * ids_dev int32 [B, N] = argmax over the vocabulary (fused into the output GEMM when logits_dev is NULL),
+ * hidden_dev [B, N, d_model] (after_norm output). No sync. */
+int pf_decoder_forward(pf_decoder* d, const float* memory_dev, const int32_t* mem_lens_host,
+                       const float* embeds_dev, const int32_t* tok_lens_host, int32_t B, int32_t T, int32_t N,
+                       float* logits_dev, int32_t* ids_dev, float* hidden_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- ctc */
+typedef struct pf_ctc pf_ctc;
+pf_ctc* pf_ctc_create(int32_t d_model, int32_t vocab_size);
+void pf_ctc_destroy(pf_ctc* c);
+int pf_ctc_set_tensor(pf_ctc* c, const char* name, const float* data, int64_t numel);   /* "ctc_lo.weight|bias" */
+int pf_ctc_missing(const pf_ctc* c);
+/* hidden_dev: [M, d_model]; ids_dev: int32 [M] frame-wise argmax; logits_dev (nullable): [M, vocab]. No sync. */
+int pf_ctc_greedy(pf_ctc* c, const float* hidden_dev, int32_t M, int32_t* ids_dev, float* logits_dev, void* stream);
+
+/* -------------------------------------------------------------------------------- single kernels (tests / bench)
+ * Thin wrappers over the individual gfx950 kernels so that parity tests and the roofline bench can drive one
+ * kernel at a time through the same ABI. All pointers are device pointers. */
+int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R1,
+                  int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc, int32_t M, int32_t N,
+                  int32_t K, int32_t relu, void* stream);
+int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t M,
+                         int32_t N, int32_t K, int32_t* ids, float* scratch_val, int32_t* scratch_idx, void* stream);
+int pf_k_layernorm(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
+                   int32_t M, int32_t D, int32_t Dpad, float eps, void* stream);
+int pf_k_fsmn(const float* in, int32_t ldin, const float* w, const float* R, int32_t ldr, float* out, int32_t ldo,
+              const int32_t* lens_dev, int32_t B, int32_t T, int32_t C, int32_t K, int32_t left_pad, void* stream);
+int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
+                       float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq,
+                       int32_t Tk, float scale, void* stream);
+/* average kernel time in milliseconds of `iters` back-to-back launches of the GEMM above, measured with
+ * hipEvents on `stream` (used by bench.py for the roofline line) */
+int pf_k_gemm_f32_time(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, float* C,
+                       int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARAFORMER_HIP_H_ */

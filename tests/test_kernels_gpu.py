@@ -1,0 +1,120 @@
+"""Kernel-level numerics of the gfx950 kernels, one kernel per test, driven through the C ABI (pf_k_*).
+
+Each kernel is compared with a plain PyTorch fp32/fp64 CPU evaluation of the same op on seeded inputs. These are
+the unit tests under the module-level parity tests (tests/test_parity_gpu.py), which use the oracle.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 512, 512), (500, 1536, 576), (333, 8404, 512),
+                                   (1000, 512, 2048), (64, 1, 64), (7, 130, 96)])
+def test_gemm_f32_matches_fp64(cuda, M, N, K):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    # asymmetric weights catch a transposed C write (cdna guide rule 16)
+    w = torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N)[:, None]
+    bias = torch.randn(N, generator=g)
+    r1 = torch.randn(M, N, generator=g)
+    r2 = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().T + bias.double()
+    out = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda)).cpu()
+    assert _rel(out, ref) < 2e-6
+    ref2 = torch.relu(ref) + r1.double() + r2.double()
+    out2 = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda), relu=True, add1=r1.to(cuda), add2=r2.to(cuda)).cpu()
+    assert _rel(out2, ref2) < 2e-6
+
+
+def test_gemm_f32_strided_and_inplace_residual(cuda):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(300, 1536, generator=g).to(cuda)
+    a = big[:, 512:1024]            # row stride 1536
+    w = torch.randn(512, 512, generator=g).to(cuda)
+    x = torch.randn(300, 512, generator=g).to(cuda)
+    ref = x.double().cpu() + a.double().cpu() @ w.double().cpu().T
+    ops.gemm(a, w, None, add2=x, out=x)   # in-place residual update
+    assert _rel(x.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,N", [(77, 8404), (300, 25055), (5, 100)])
+def test_gemm_fused_argmax(cuda, M, N):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(N)
+    a = torch.randn(M, 512, generator=g)
+    w = torch.randn(N, 512, generator=g)
+    bias = torch.randn(N, generator=g)
+    ids = ops.gemm_argmax(a.to(cuda), w.to(cuda), bias.to(cuda)).cpu().long()
+    logits = a.double() @ w.double().T + bias.double()
+    ref = logits.argmax(-1)
+    # ties are measure-zero; allow an fp32-level near-tie
+    bad = (ids != ref).nonzero().flatten()
+    for i in bad.tolist():
+        assert abs(logits[i, ids[i]] - logits[i, ref[i]]) < 1e-4 * abs(logits[i, ref[i]])
+    assert len(bad) <= 1
+
+
+@pytest.mark.parametrize("D,pad,eps", [(512, 512, 1e-12), (560, 576, 1e-12), (2048, 2048, 1e-12), (512, 512, 1e-5)])
+def test_layernorm(cuda, D, pad, eps):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(333, D, generator=g) * 3 + 0.5
+    gamma = torch.randn(D, generator=g)
+    beta = torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), eps)
+    y = ops.layernorm(x.to(cuda), gamma.to(cuda), beta.to(cuda), eps, pad_to=pad).cpu()
+    assert (y[:, :D].double() - ref).abs().max().item() < 5e-6
+    assert (y[:, D:] == 0).all()
+
+
+@pytest.mark.parametrize("left_pad", [5, 10])
+def test_fsmn(cuda, left_pad):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(11 + left_pad)
+    B, T, Cc, K = 3, 53, 512, 11
+    qkv = torch.randn(B, T, 3 * Cc, generator=g)
+    v = qkv[:, :, 2 * Cc:]
+    w = torch.randn(Cc, 1, K, generator=g) * 0.3
+    lens = torch.tensor([53, 20, 1], dtype=torch.int32)
+    res = torch.randn(B, T, Cc, generator=g)
+    mask = (torch.arange(T)[None, :] < lens[:, None]).double()[:, :, None]
+    inp = v.double() * mask
+    xp = torch.nn.functional.pad(inp.transpose(1, 2), (left_pad, K - 1 - left_pad))
+    conv = torch.nn.functional.conv1d(xp, w.double(), groups=Cc).transpose(1, 2)
+    ref = (conv + inp) * mask
+    out = ops.fsmn(qkv.to(cuda)[:, :, 2 * Cc:], w.to(cuda), lens.to(cuda), left_pad).cpu()
+    assert (out.double() - ref).abs().max().item() < 1e-5
+    out2 = ops.fsmn(qkv.to(cuda)[:, :, 2 * Cc:], w.to(cuda), lens.to(cuda), left_pad, residual=res.to(cuda)).cpu()
+    assert (out2.double() - (ref + res.double())).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,Tq,Tk,lens", [(2, 83, 83, [83, 40]), (1, 500, 500, [500]), (3, 37, 150, [150, 1, 33]),
+                                          (2, 130, 64, [64, 31])])
+def test_attention_f32(cuda, B, Tq, Tk, lens):
+    from funasr_amd import ops
+    H, dk = 4, 128
+    g = torch.Generator().manual_seed(Tq * 13 + Tk)
+    q = torch.randn(B, Tq, H * dk, generator=g)
+    kv = torch.randn(B, Tk, 2 * H * dk, generator=g)
+    k, v = kv[:, :, :H * dk], kv[:, :, H * dk:]
+    klens = torch.tensor(lens, dtype=torch.int32)
+    scale = dk ** -0.5
+    qh = q.double().view(B, Tq, H, dk).transpose(1, 2) * scale
+    kh = k.double().reshape(B, Tk, H, dk).transpose(1, 2)
+    vh = v.double().reshape(B, Tk, H, dk).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    m = (torch.arange(Tk)[None, :] >= klens[:, None])[:, None, None, :]
+    p = torch.softmax(s.masked_fill(m, float("-inf")), -1).masked_fill(m, 0.0)
+    ref = (p @ vh).transpose(1, 2).reshape(B, Tq, H * dk)
+    kvd = kv.to(cuda)
+    out = ops.attention(q.to(cuda), kvd[:, :, :H * dk], kvd[:, :, H * dk:], klens.to(cuda), H, scale).cpu()
+    assert (out.double() - ref).abs().max().item() < 2e-5
