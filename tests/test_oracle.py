@@ -1,0 +1,153 @@
+"""CPU suite: pins the oracle (oracle/paraformer_oracle.py) to the reference.
+
+Fixtures under tests/golden/ were produced by oracle/make_golden.py from the reference's own modules
+(/root/reference, imported read-only) and from the reference-vendored kaldi-native-fbank; weights are rebuilt from
+the stored seed. Bars: bit-exact for indices / integer results and pure data movement; float32-roundoff for
+tensors that go through ATen matmuls with a different blocking (stated per test).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from funasr_amd import synth
+from oracle import paraformer_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_lfr_bit_exact():
+    g = gold("lfr")
+    for T in (1, 2, 3, 5, 6, 7, 8, 13, 100):
+        out = O.apply_lfr(t(g[f"in_{T}"]), 7, 6)
+        assert np.array_equal(out.numpy(), g[f"out_{T}"]), T
+
+
+def test_load_cmvn_matches_reference_parser():
+    g = gold("frontend")
+    cmvn = O.load_cmvn(os.path.join(GOLD, "am.mvn"))
+    assert cmvn.shape == (2, 560)
+    assert np.array_equal(cmvn.numpy(), g["cmvn"])
+
+
+def test_fbank_matches_kaldi_native_fbank():
+    """kaldi-native-fbank runs its FFT in float64 and builds its tables with float scalars, torchaudio (restated by
+    the oracle) works in float32: agreement is float32-roundoff in the power domain, i.e. ~1e-4 in log-mel except
+    where a mel energy is nearly cancelled. Bar: max |d| <= 2e-3, mean |d| <= 2e-5 (log-mel values are ~5..20)."""
+    g = gold("frontend")
+    for k in ("a", "b"):
+        wave = t(g[f"pcm_{k}"].astype(np.float32) / 32768.0) * 32768.0
+        fb = O.kaldi_fbank(wave)
+        ref = t(g[f"fbank_knf_{k}"])
+        assert fb.shape == ref.shape
+        d = (fb - ref).abs()
+        assert d.max().item() <= 2e-3, d.max().item()
+        assert d.mean().item() <= 2e-5, d.mean().item()
+
+
+def test_frontend_lfr_cmvn_on_reference_fbank_bit_exact():
+    g = gold("frontend")
+    cmvn = t(g["cmvn"])
+    for k in ("a", "b"):
+        feats = O.apply_cmvn(O.apply_lfr(t(g[f"fbank_knf_{k}"]), 7, 6), cmvn)
+        assert np.array_equal(feats.numpy(), g[f"feats_{k}"])
+
+
+def test_wav_frontend_end_to_end_close_to_reference_features():
+    g = gold("frontend")
+    waves = [t(g["pcm_a"].astype(np.float32) / 32768.0), t(g["pcm_b"].astype(np.float32) / 32768.0)]
+    feats, lens = O.wav_frontend(waves, t(g["cmvn"]))
+    assert lens.tolist() == [g["feats_a"].shape[0], g["feats_b"].shape[0]]
+    assert (feats[0, : lens[0]] - t(g["feats_a"])).abs().max().item() < 5e-4
+    assert (feats[1, : lens[1]] - t(g["feats_b"])).abs().max().item() < 5e-4
+    assert (feats[1, lens[1]:] == 0).all()
+
+
+def test_positional_encoding_bit_exact():
+    g = gold("pe")
+    pe = O.sinusoidal_pe(600, 560)
+    assert np.array_equal(pe[:40].numpy(), g["head"])
+    assert np.array_equal(pe[560:600].numpy(), g["tail"])
+
+
+def test_encoder_matches_reference():
+    g = gold("encoder")
+    cfg = json.loads(str(g["cfg"]))
+    sd = synth.encoder_state_dict(cfg, seed=int(g["seed"]))
+    assert abs(sum(v.double().abs().sum() for v in sd.values()).item() - float(g["checksum"])) < 1e-6 * float(g["checksum"])
+    inter = []
+    out, olens = O.sanm_encoder(t(g["xs"]), t(g["lens"]), sd, cfg, collect=inter)
+    assert olens.tolist() == g["olens"].tolist()
+    # same ATen kernels, same op order -> expect (near) bit equality; bar 1e-5 absolute on O(1) activations
+    assert (inter[0] - t(g["block1"])).abs().max().item() < 1e-5
+    assert (inter[2] - t(g["block3"])).abs().max().item() < 1e-5
+    assert (out - t(g["out"])).abs().max().item() < 1e-5
+
+
+def test_cif_bit_exact():
+    g = gold("cif")
+    al, hid = t(g["alphas"]), t(g["hidden"])
+    fires, fire = O.cif_fires(al)
+    assert np.array_equal(fire.numpy(), g["fire_idx"])
+    assert np.array_equal(fires.numpy(), g["fires"])
+    frames, fires2, n = O.cif_frames(hid, al)
+    assert frames.shape == g["frames"].shape
+    assert np.array_equal(frames.numpy(), g["frames"])
+
+
+def test_predictor_matches_reference():
+    g = gold("predictor")
+    cfg = json.loads(str(g["cfg"]))
+    sd = synth.predictor_state_dict(cfg, seed=int(g["seed"]))
+    emb, tok, alphas, peaks = O.cif_predictor(t(g["hidden"]), t(g["lens"]), sd, cfg)
+    assert np.array_equal(tok.numpy(), g["token_num"])
+    # conv1d/linear blocking depends on the ATen thread count: alphas agree to 1 ulp, the integer results exactly
+    assert (alphas - t(g["alphas"])).abs().max().item() <= 2e-7
+    assert np.array_equal(np.floor(peaks.numpy()) >= 1, np.floor(g["peaks"]) >= 1)
+    assert (peaks - t(g["peaks"])).abs().max().item() <= 2e-6
+    assert emb.shape == g["embeds"].shape
+    assert (emb - t(g["embeds"])).abs().max().item() <= 1e-5
+
+
+def test_decoder_matches_reference():
+    g = gold("decoder")
+    cfg = json.loads(str(g["cfg"]))
+    sd = synth.decoder_state_dict(cfg, seed=int(g["seed"]))
+    logits = O.paraformer_decoder(t(g["memory"]), t(g["mem_lens"]), t(g["embeds"]), t(g["tok_lens"]), sd, cfg)
+    assert (logits - t(g["logits"])).abs().max().item() < 2e-5
+
+
+def test_pipeline_token_ids_equal_reference():
+    g = gold("pipeline")
+    cfg = json.loads(str(g["cfg"]))
+    sd = synth.paraformer_state_dict(cfg, seed=int(g["seed"]))
+    res = O.paraformer_greedy(t(g["feats"]), t(g["lens"]), sd, cfg)
+    assert res["token_num"].tolist() == g["token_num"].tolist()
+    assert np.array_equal(res["alphas"].numpy(), g["alphas"]) or (res["alphas"] - t(g["alphas"])).abs().max() < 1e-6
+    fire_ref = np.floor(g["peaks"]) >= 1            # cif_peak >= 1 marks a fire
+    assert np.array_equal(np.floor(res["peaks"].numpy()) >= 1, fire_ref)
+    for b in range(len(res["raw_ids"])):
+        n = int(g["token_num"][b])
+        assert res["raw_ids"][b] == g["raw_ids"][b, :n].tolist()
+    assert (res["enc"] - t(g["enc"])).abs().max().item() < 1e-5
+
+
+def test_sensevoice_encoder_and_ctc_match_reference():
+    g = gold("sensevoice")
+    cfg = json.loads(str(g["cfg"]))
+    sd = synth.sensevoice_state_dict(cfg, seed=int(g["seed"]))
+    out, olens = O.sanm_encoder(t(g["xs"]), t(g["lens"]), sd, cfg["encoder"], "encoder.", eps=1e-5)
+    assert olens.tolist() == g["olens"].tolist()
+    assert (out - t(g["out"])).abs().max().item() < 1e-5
+    logp = torch.log_softmax(torch.nn.functional.linear(out, sd["ctc.ctc_lo.weight"], sd["ctc.ctc_lo.bias"]), -1)
+    assert np.array_equal(logp.argmax(-1).numpy(), g["frame_ids"])
