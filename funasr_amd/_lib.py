@@ -94,6 +94,7 @@ SIGNATURES = {
     "pf_k_layernorm": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "pf_k_fsmn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pf_k_attention_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pf_k_cif": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_gemm_f32_time": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
     # profiling hooks used by bench.py (not part of the reference boundary)
     "pf_prof_enable": (C.c_int, [C.c_int]),

@@ -1,0 +1,70 @@
+"""CIF predictor on gfx950 (csrc/cif.hip + the f32 GEMM for the 3-tap conv).
+
+Host-side mirror of `CifPredictorV2` (funasr/models/paraformer/cif_predictor.py:208-314,
+`predictor_classes["CifPredictorV2"]`): same constructor keywords, state_dict keys (cif_conv1d.*, cif_output.*) and
+`forward(hidden, target_label=None, mask [B,1,T]) -> (acoustic_embeds [B,N,D], token_num [B], alphas [B,T+1],
+cif_peak [B,T+1])` for inference (no target labels). One divergence, documented in DESIGN.md: the reference raises
+IndexError (cif_predictor.py:887) when the last utterance of a batch fires no token; here such an utterance simply
+gets token_num 0 and zero rows.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .hip_module import HipModule, ParamHolder, host_i32, stream_ptr
+from .register import tables
+
+
+@tables.register("predictor_classes", "CifPredictorV2")
+class CifPredictorV2(HipModule):
+    _prefix = "pf_predictor"
+
+    def __init__(self, idim, l_order, r_order, threshold=1.0, dropout=0.1, smooth_factor=1.0, noise_threshold=0,
+                 tail_threshold=0.0, tf2torch_tensor_name_prefix_torch="predictor",
+                 tf2torch_tensor_name_prefix_tf="seq2seq/cif", tail_mask=True, **kwargs):
+        super().__init__()
+        self.idim, self.l_order, self.r_order = idim, l_order, r_order
+        self.threshold, self.smooth_factor, self.noise_threshold = threshold, smooth_factor, noise_threshold
+        self.tail_threshold, self.tail_mask = tail_threshold, tail_mask
+        self.cif_conv1d = ParamHolder((idim, idim, l_order + r_order + 1), (idim,))
+        self.cif_output = ParamHolder((1, idim), (1,))
+
+    def _make_config(self):
+        return _lib.pf_predictor_config(self.idim, self.l_order, self.r_order, float(self.threshold),
+                                        float(self.smooth_factor), float(self.noise_threshold),
+                                        float(self.tail_threshold), int(bool(self.tail_mask)))
+
+    def forward(self, hidden, target_label=None, mask=None, ignore_id=-1, mask_chunk_predictor=None,
+                target_label_length=None, lengths=None):
+        if target_label is not None or target_label_length is not None or mask_chunk_predictor is not None:
+            raise NotImplementedError("CifPredictorV2(HIP) implements the inference path (no target labels)")
+        lib, h = self._ensure_handle()
+        dev = self._handle_device
+        hid = hidden.to(device=dev, dtype=torch.float32).contiguous()
+        B, T, D = hid.shape
+        if lengths is None:
+            if mask is None:
+                lengths = [T] * B
+            else:   # [B, 1, T] validity mask as built by Paraformer.calc_predictor (paraformer/model.py:323-325)
+                lengths = mask.reshape(B, -1).to(torch.float32).sum(-1).round().to(torch.int32)
+        lens_c, lens = host_i32(lengths, B)
+        alphas = torch.empty(B, T + 1, device=dev, dtype=torch.float32)
+        peaks = torch.empty(B, T + 1, device=dev, dtype=torch.float32)
+        tok = (C.c_int32 * B)()
+        with torch.cuda.device(dev):
+            _lib.check(lib.pf_predictor_alphas(h, hid.data_ptr(), lens_c, B, T, alphas.data_ptr(), peaks.data_ptr(),
+                                               tok, stream_ptr()), "pf_predictor_alphas")
+            token_num = list(tok)
+            N = max(token_num)
+            embeds = torch.empty(B, N, D, device=dev, dtype=torch.float32)
+            if N > 0:
+                _lib.check(lib.pf_predictor_embeds(h, hid.data_ptr(), B, T, N, embeds.data_ptr(), stream_ptr()),
+                           "pf_predictor_embeds")
+        # the reference returns the floored float count (cif_predictor.py:443-446)
+        token_num_t = torch.tensor(token_num, dtype=torch.float32, device=dev)
+        if self.tail_threshold <= 0.0:
+            alphas, peaks = alphas[:, :T], peaks[:, :T]
+        return embeds, token_num_t, alphas, peaks

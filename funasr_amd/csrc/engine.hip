@@ -948,6 +948,33 @@ int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk,
     aa.klens = klens_dev; aa.B = B; aa.H = H; aa.Tq = Tq; aa.Tk = Tk; aa.scale = scale;
     return attention(aa, 4.0 * B * (double)Tq * Tk * H * 128, reinterpret_cast<hipStream_t>(stream));
 }
+int pf_k_cif(const float* alphas, const float* hidden, int32_t B, int32_t T, int32_t D, int32_t N, float* peaks,
+             int32_t* n_fires, float* embeds, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(alphas && hidden && peaks && n_fires && embeds && B > 0 && T > 0 && D > 0, "k_cif: null/empty");
+    static DevBuf al, pk, rm, ff, ln;
+    const int Te = T + 1;
+    if (al.ensure(sizeof(float) * (size_t)B * Te) || pk.ensure(sizeof(float) * (size_t)B * Te) ||
+        rm.ensure(sizeof(float) * (size_t)B * Te) || ff.ensure(sizeof(int) * (size_t)B * Te) ||
+        ln.ensure(sizeof(int) * (size_t)B)) return -2;
+    std::vector<int> lens(B, T);
+    PF_HIP_TRY(hipMemcpyAsync(ln.p, lens.data(), sizeof(int) * B, hipMemcpyHostToDevice, s));
+    PF_HIP_TRY(hipMemcpy2DAsync(al.p, sizeof(float) * Te, alphas, sizeof(float) * T, sizeof(float) * T, B,
+                                hipMemcpyDeviceToDevice, s));
+    CifScanArgs sa{};
+    sa.alphas = al.as<float>(); sa.peaks = pk.as<float>(); sa.rems = rm.as<float>(); sa.fire_flag = ff.as<int>();
+    sa.n_fires = n_fires; sa.lens = ln.as<int>(); sa.B = B; sa.T = T; sa.tail_threshold = 0.f; sa.tail_mask = 1;
+    int rc;
+    if ((rc = launch_cif_scan(sa, s))) return rc;
+    PF_HIP_TRY(hipMemcpy2DAsync(peaks, sizeof(float) * T, pk.p, sizeof(float) * Te, sizeof(float) * T, B,
+                                hipMemcpyDeviceToDevice, s));
+    CifEmitArgs ea{};
+    ea.hidden = hidden; ea.alphas = al.as<float>(); ea.rems = rm.as<float>(); ea.fire_flag = ff.as<int>();
+    ea.embeds = embeds; ea.B = B; ea.T = T; ea.D = D; ea.N = N;
+    if ((rc = launch_cif_emit(ea, s))) return rc;
+    PF_HIP_TRY(hipStreamSynchronize(s));   // `lens` is a host temporary
+    return 0;
+}
 int pf_k_gemm_f32_time(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, float* C,
                        int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t iters, float* ms_out, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -1,0 +1,48 @@
+"""CTC head on gfx950: vocabulary projection with the arg-max fused into the GEMM epilogue.
+
+Host-side mirror of `CTC` (funasr/models/ctc/ctc.py:9-216) for inference: state_dict key ctc_lo.{weight,bias},
+`log_softmax(hs_pad)`, `argmax(hs_pad)`.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .hip_module import HipModule, linear, stream_ptr
+
+
+class CTC(HipModule):
+    _prefix = "pf_ctc"
+
+    def __init__(self, odim: int, encoder_output_size: int, dropout_rate: float = 0.0, ctc_type: str = "builtin",
+                 reduce: bool = True, ignore_nan_grad: bool = True, **kwargs):
+        super().__init__()
+        self.odim, self.eprojs = odim, encoder_output_size
+        self.ctc_lo = linear(odim, encoder_output_size)
+
+    def _make_config(self):
+        return None
+
+    def _create_args(self):
+        return (self.eprojs, self.odim)
+
+    def _run(self, hs_pad, want_logits):
+        lib, h = self._ensure_handle()
+        dev = self._handle_device
+        x = hs_pad.to(device=dev, dtype=torch.float32).contiguous()
+        lead = x.shape[:-1]
+        M = x.numel() // x.shape[-1]
+        ids = torch.empty(M, device=dev, dtype=torch.int32)
+        logits = torch.empty(M, self.odim, device=dev, dtype=torch.float32) if want_logits else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.pf_ctc_greedy(h, x.data_ptr(), M, ids.data_ptr(),
+                                         logits.data_ptr() if want_logits else None, stream_ptr()), "pf_ctc_greedy")
+        return ids.view(*lead), (logits.view(*lead, self.odim) if want_logits else None)
+
+    def log_softmax(self, hs_pad):
+        _, logits = self._run(hs_pad, True)
+        return torch.log_softmax(logits, dim=-1)
+
+    def argmax(self, hs_pad):
+        ids, _ = self._run(hs_pad, False)
+        return ids

@@ -1,0 +1,151 @@
+"""Base class of the host-side mirrors: an nn.Module that only HOLDS parameters (same state_dict keys as the
+reference module, so load_pretrained_model(strict=True) -- funasr/train_utils/load_pretrained_model.py:104 -- keeps
+working) while all arithmetic is done by an opaque handle of libparaformer_hip.so.
+
+Weights are pushed to the handle lazily before the first forward after any change (load_state_dict, .to(),
+in-place edits followed by mark_dirty()). There is deliberately no CPU implementation behind forward().
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class ParamHolder(nn.Module):
+    """weight / bias container with torch-style names; never executed."""
+
+    def __init__(self, weight_shape, bias_shape=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(*weight_shape), requires_grad=False)
+        if bias_shape is not None:
+            self.bias = nn.Parameter(torch.zeros(*bias_shape), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: computation happens inside libparaformer_hip.so")
+
+
+class Holder(nn.Module):
+    """plain namespace module (children give the dotted key names)"""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: computation happens inside libparaformer_hip.so")
+
+
+def linear(out_f, in_f, bias=True):
+    return ParamHolder((out_f, in_f), (out_f,) if bias else None)
+
+
+def layer_norm(dim):
+    return ParamHolder((dim,), (dim,))
+
+
+def depthwise(channels, k):
+    return ParamHolder((channels, 1, k), None)
+
+
+class HipModule(nn.Module):
+    """Owns one C handle. Subclasses set _create / _destroy / _set_tensor names and _skip_keys."""
+
+    _prefix = ""              # e.g. "pf_encoder"
+    _skip_keys: tuple = ()    # state_dict keys the device does not need (training-only tensors)
+
+    def __init__(self):
+        super().__init__()
+        self._handle = None
+        self._dirty = True
+        self._handle_device = None
+
+    # -- lifecycle ---------------------------------------------------------------------------------------------
+    def _make_config(self):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def _device(self) -> torch.device:
+        for p in self.parameters():
+            return p.device
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    def _ensure_handle(self):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError(
+                f"{type(self).__name__} runs only on an AMD GPU through libparaformer_hip.so; parameters are on "
+                f"'{dev}'. Move the model with .to('cuda') (there is no CPU fallback by design).")
+        lib = _lib.load()
+        if self._handle is not None and self._handle_device != dev:
+            self._free()
+        if self._handle is None:
+            with torch.cuda.device(dev):
+                cfg = self._make_config()
+                create = getattr(lib, self._prefix + "_create")
+                h = create(C.byref(cfg)) if cfg is not None else create(*self._create_args())
+                self._handle = _lib.check_handle(h, self._prefix + "_create")
+            self._handle_device = dev
+            self._dirty = True
+        if self._dirty:
+            self._push_weights(lib)
+            self._dirty = False
+        return lib, self._handle
+
+    def _create_args(self):  # for handles created from scalars instead of a config struct
+        return ()
+
+    def _push_weights(self, lib):
+        set_tensor = getattr(lib, self._prefix + "_set_tensor")
+        with torch.cuda.device(self._handle_device):
+            for name, p in self.named_parameters():
+                if name in self._skip_keys or any(name.startswith(s) for s in self._skip_keys if s.endswith(".")):
+                    continue
+                t = p.detach().to(dtype=torch.float32).contiguous()
+                _lib.check(set_tensor(self._handle, name.encode(), t.data_ptr(), t.numel()),
+                           f"{self._prefix}_set_tensor({name})")
+            torch.cuda.synchronize()
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def _free(self):
+        if self._handle is not None:
+            try:
+                getattr(_lib.load(), self._prefix + "_destroy")(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def __del__(self):
+        self._free()
+
+    # -- keep the device copy coherent with nn.Module mutations ------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._dirty = True
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._dirty = True
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._dirty = True
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def host_i32(x, n=None):
+    """lengths -> (ctypes int32 array, python list). Accepts tensors (any device), lists, numpy."""
+    if isinstance(x, torch.Tensor):
+        vals = [int(v) for v in x.detach().cpu().reshape(-1).tolist()]
+    else:
+        vals = [int(v) for v in list(x)]
+    if n is not None and len(vals) != n:
+        raise ValueError(f"expected {n} lengths, got {len(vals)}")
+    return (C.c_int32 * len(vals))(*vals), vals

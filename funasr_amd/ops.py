@@ -92,6 +92,19 @@ def attention(q, k, v, klens, n_heads: int, scale: float):
     return out
 
 
+def cif(alphas: torch.Tensor, hidden: torch.Tensor, n_max: int):
+    """alphas [B, T], hidden [B, T, D] -> (peaks [B, T], n_fires int32 [B], embeds [B, n_max, D])."""
+    lib = _lib.load()
+    B, T = alphas.shape
+    D = hidden.shape[2]
+    peaks = torch.empty(B, T, device=alphas.device, dtype=torch.float32)
+    nf = torch.empty(B, device=alphas.device, dtype=torch.int32)
+    emb = torch.empty(B, n_max, D, device=alphas.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_cif(_ptr(alphas.contiguous()), _ptr(hidden.contiguous()), B, T, D, n_max, _ptr(peaks),
+                            _ptr(nf), _ptr(emb), _stream()), "pf_k_cif")
+    return peaks, nf, emb
+
+
 def gemm_time_ms(a, w, bias, out, iters: int = 20) -> float:
     lib = _lib.load()
     M, K = a.shape

@@ -1,0 +1,149 @@
+"""Paraformer on gfx950: the model-level glue of the hot path.
+
+Host-side mirror of `Paraformer` (funasr/models/paraformer/model.py:27-697, `model_classes["Paraformer"]`): it
+builds encoder / predictor / decoder BY NAME through the registry exactly like :125-150, keeps the reference's
+state_dict layout (encoder.*, predictor.*, decoder.*) and implements
+`inference(data_in, data_lengths, key, tokenizer, frontend, **kwargs) -> (results, meta_data)` (:534-697, greedy path)
+with the contract AutoModel relies on (funasr/auto/auto_model.py:812-829; executable spec tests/test_auto_model.py
+in the reference). Unlike the reference the whole batch stays in HBM between the stages, the decoder's vocabulary
+projection is fused with the arg-max, and there is exactly one device->host copy of token ids per batch.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .audio import load_audio_list
+from .register import tables
+from .tokenizer import sentence_postprocess
+
+# importing registers the classes under the reference's names
+from . import cif_predictor as _cif_predictor  # noqa: F401
+from . import paraformer_decoder as _paraformer_decoder  # noqa: F401
+from . import sanm_encoder as _sanm_encoder  # noqa: F401
+from . import wav_frontend as _wav_frontend  # noqa: F401
+
+
+@tables.register("model_classes", "Paraformer")
+class Paraformer(nn.Module):
+    def __init__(self, specaug: Optional[str] = None, specaug_conf: Optional[Dict] = None, normalize: str = None,
+                 normalize_conf: Optional[Dict] = None, encoder: str = None, encoder_conf: Optional[Dict] = None,
+                 decoder: str = None, decoder_conf: Optional[Dict] = None, ctc: str = None,
+                 ctc_conf: Optional[Dict] = None, predictor: str = None, predictor_conf: Optional[Dict] = None,
+                 ctc_weight: float = 0.5, input_size: int = 80, vocab_size: int = -1, ignore_id: int = -1,
+                 blank_id: int = 0, sos: int = 1, eos: int = 2, lsm_weight: float = 0.0,
+                 length_normalized_loss: bool = False, predictor_weight: float = 0.0, predictor_bias: int = 0,
+                 sampling_ratio: float = 0.2, share_embedding: bool = False, use_1st_decoder_loss: bool = False,
+                 **kwargs):
+        super().__init__()
+        if normalize is not None or ctc_weight > 0.0:
+            raise NotImplementedError("Paraformer(HIP): utterance-MVN `normalize` and a CTC branch are not on the "
+                                      "greedy inference path of the published Paraformer-large recipe")
+        enc_conf = dict(encoder_conf or {})
+        enc_conf.pop("input_size", None)
+        self.encoder = tables.encoder_classes.get(encoder)(input_size=input_size, **enc_conf)
+        d = self.encoder.output_size()
+        dec_conf = dict(decoder_conf or {})
+        dec_conf.pop("vocab_size", None)
+        dec_conf.pop("encoder_output_size", None)
+        self.decoder = tables.decoder_classes.get(decoder)(vocab_size=vocab_size, encoder_output_size=d, **dec_conf)
+        self.predictor = tables.predictor_classes.get(predictor)(**(predictor_conf or {}))
+        self.blank_id, self.vocab_size, self.ignore_id = blank_id, vocab_size, ignore_id
+        self.sos = sos if sos is not None else vocab_size - 1
+        self.eos = eos if eos is not None else vocab_size - 1
+        self.ctc, self.specaug, self.normalize = None, None, None
+        self.ctc_weight = ctc_weight
+        self.beam_search = None
+
+    # ------------------------------------------------------------------------------------------------ builders
+    @classmethod
+    def from_config(cls, cfg: dict) -> "Paraformer":
+        """cfg in the layout of funasr_amd.synth.PARAFORMER_LARGE (keys as in models/paraformer/template.yaml)."""
+        ec = dict(cfg["encoder"])
+        input_size = ec.pop("input_size")
+        dc = dict(cfg["decoder"])
+        vocab = dc.pop("vocab_size")
+        dc.pop("encoder_output_size", None)
+        return cls(encoder="SANMEncoder", encoder_conf=dict(ec, input_layer="pe"), decoder="ParaformerSANMDecoder",
+                   decoder_conf=dc, predictor="CifPredictorV2", predictor_conf=dict(cfg["predictor"]), ctc_weight=0.0,
+                   input_size=input_size, vocab_size=vocab)
+
+    # ------------------------------------------------------------------------------------------- device pipeline
+    def encode(self, speech: torch.Tensor, speech_lengths, **kwargs):
+        out, olens, _ = self.encoder(speech, speech_lengths)      # model.py:286-313
+        return out, olens
+
+    def calc_predictor(self, encoder_out, encoder_out_lens):
+        return self.predictor(encoder_out, None, None, ignore_id=self.ignore_id, lengths=encoder_out_lens)
+
+    def recognize_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
+        """[B, T, 560] features -> per-utterance token ids (sos/eos/blank removed), all on the current HIP stream."""
+        enc, olens = self.encode(speech, speech_lengths)
+        embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
+        tok = [int(round(v)) for v in token_num.tolist()]           # pre_token_length.round().long(), model.py:614
+        B = enc.shape[0]
+        raw: List[List[int]] = [[] for _ in range(B)]
+        if max(tok) >= 1:                                            # model.py:615-616
+            ids, _ = self.decoder.greedy(enc, olens, embeds, tok)
+            ids_host = ids.cpu()                                     # the single D2H copy of the batch
+            raw = [ids_host[b, : tok[b]].tolist() for b in range(B)]
+        drop = (self.sos, self.eos, self.blank_id)
+        out = dict(token_num=tok, raw_ids=raw, ids=[[t for t in r if t not in drop] for r in raw])
+        if return_intermediate:
+            out.update(enc=enc, olens=olens, embeds=embeds, alphas=alphas, peaks=peaks)
+        return out
+
+    # ---------------------------------------------------------------------------------------------- AutoModel API
+    def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
+        if kwargs.get("decoding_ctc_weight", 0.0) > 1e-5 or (kwargs.get("lm_weight", 0.0) > 1e-5 and kwargs.get("lm_file")):
+            raise NotImplementedError("beam search with CTC/LM rescoring (paraformer/model.py:482-532) is outside the "
+                                      "greedy hot path")
+        meta_data = {}
+        device = kwargs.get("device", None)
+        if isinstance(data_in, torch.Tensor) and kwargs.get("data_type", "sound") == "fbank":
+            speech, speech_lengths = data_in, data_lengths
+            if speech.dim() < 3:
+                speech = speech[None]
+            if speech_lengths is None:
+                speech_lengths = [speech.shape[1]] * speech.shape[0]
+        else:
+            t1 = time.perf_counter()
+            audio = load_audio_list(data_in, fs=frontend.fs, audio_fs=kwargs.get("fs", 16000))
+            t2 = time.perf_counter()
+            meta_data["load_data"] = f"{t2 - t1:0.3f}"
+            lens = [int(a.shape[0]) for a in audio]
+            wav = torch.nn.utils.rnn.pad_sequence(audio, batch_first=True)      # load_utils.py:413
+            if device is not None:
+                wav = wav.to(device)
+            speech, speech_lengths = frontend(wav, lens)
+            t3 = time.perf_counter()
+            meta_data["extract_feat"] = f"{t3 - t2:0.3f}"
+            meta_data["batch_data_time"] = (int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000)
+        res = self.recognize_features(speech, speech_lengths, return_intermediate=kwargs.get("pred_timestamp", False))
+        B = len(res["ids"])
+        if key is None:
+            key = [f"utt_{i}" for i in range(B)]
+        if isinstance(key[0], (list, tuple)):
+            key = key[0]
+        if len(key) < B:
+            key = list(key) * B
+        if max(res["token_num"]) < 1:
+            return [], meta_data
+        results = []
+        for i in range(B):
+            token_int = res["ids"][i]
+            if tokenizer is not None:
+                token = tokenizer.ids2tokens(token_int)
+                text = tokenizer.tokens2text(token)
+                if not hasattr(tokenizer, "bpemodel"):
+                    text, _ = sentence_postprocess(token)
+                results.append({"key": key[i], "text": text})
+            else:
+                results.append({"key": key[i], "token_int": token_int})
+        return results, meta_data
+
+    def forward(self, *args, **kwargs):  # pragma: no cover
+        raise NotImplementedError("training forward() is out of scope; use inference()/recognize_features()")

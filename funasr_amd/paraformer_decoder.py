@@ -1,0 +1,116 @@
+"""Paraformer SAN-M decoder on gfx950.
+
+Host-side mirror of `ParaformerSANMDecoder` (funasr/models/paraformer/decoder.py:233-449,
+`decoder_classes["ParaformerSANMDecoder"]`): same constructor keywords, state_dict keys (decoders.{i}.*,
+decoders3.0.*, after_norm.*, output_layer.*, embed.0.weight), and
+`forward(hs_pad, hlens, ys_in_pad, ys_in_lens) -> (logits [B, N, V], olens)`.
+`greedy()` is the fused route used by Paraformer.inference: the vocabulary projection and the arg-max run in one
+kernel and the [B, N, 8404] logits never reach HBM.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .hip_module import Holder, HipModule, ParamHolder, depthwise, host_i32, layer_norm, linear, stream_ptr
+from .register import tables
+
+
+def _ffn(block, d_model, ffn):
+    block.norm1 = layer_norm(d_model)
+    block.feed_forward = Holder()
+    block.feed_forward.w_1 = linear(ffn, d_model)
+    block.feed_forward.norm = layer_norm(ffn)
+    block.feed_forward.w_2 = linear(d_model, ffn, bias=False)
+
+
+def _block(d_model, ffn, kernel_size):
+    b = Holder()
+    _ffn(b, d_model, ffn)
+    b.norm2 = layer_norm(d_model)
+    b.self_attn = Holder()
+    b.self_attn.fsmn_block = depthwise(d_model, kernel_size)
+    b.norm3 = layer_norm(d_model)
+    b.src_attn = Holder()
+    b.src_attn.linear_q = linear(d_model, d_model)
+    b.src_attn.linear_k_v = linear(2 * d_model, d_model)
+    b.src_attn.linear_out = linear(d_model, d_model)
+    return b
+
+
+@tables.register("decoder_classes", "ParaformerSANMDecoder")
+class ParaformerSANMDecoder(HipModule):
+    _prefix = "pf_decoder"
+    _skip_keys = ("embed.",)      # token embedding: training / sampler only (decoder.py:314-317)
+
+    def __init__(self, vocab_size: int, encoder_output_size: int, attention_heads: int = 4, linear_units: int = 2048,
+                 num_blocks: int = 6, dropout_rate: float = 0.1, positional_dropout_rate: float = 0.1,
+                 self_attention_dropout_rate: float = 0.0, src_attention_dropout_rate: float = 0.0,
+                 input_layer: str = "embed", use_output_layer: bool = True, wo_input_layer: bool = False,
+                 pos_enc_class=None, normalize_before: bool = True, concat_after: bool = False,
+                 att_layer_num: int = 6, kernel_size: int = 21, sanm_shfit: int = 0, lora_list: List[str] = None,
+                 lora_rank: int = 8, lora_alpha: int = 16, lora_dropout: float = 0.1,
+                 chunk_multiply_factor: tuple = (1,), tf2torch_tensor_name_prefix_torch: str = "decoder",
+                 tf2torch_tensor_name_prefix_tf: str = "seq2seq/decoder", **kwargs):
+        super().__init__()
+        if num_blocks - att_layer_num > 0 or not normalize_before or concat_after or lora_list or not use_output_layer:
+            raise NotImplementedError("ParaformerSANMDecoder(HIP): only att_layer_num == num_blocks (no decoders2), "
+                                      "normalize_before, no LoRA is built")
+        if sanm_shfit is None:
+            sanm_shfit = (kernel_size - 1) // 2
+        D = encoder_output_size
+        self.vocab_size, self.d_model, self.attention_heads, self.linear_units = vocab_size, D, attention_heads, linear_units
+        self.att_layer_num, self.num_blocks, self.kernel_size, self.sanm_shfit = att_layer_num, num_blocks, kernel_size, sanm_shfit
+        if not wo_input_layer and input_layer == "embed":
+            self.embed = nn.ModuleList([ParamHolder((vocab_size, D), None)])
+        self.decoders = nn.ModuleList([_block(D, linear_units, kernel_size) for _ in range(att_layer_num)])
+        last = Holder()
+        _ffn(last, D, linear_units)
+        self.decoders3 = nn.ModuleList([last])
+        self.after_norm = layer_norm(D)
+        self.output_layer = linear(vocab_size, D)
+
+    def _make_config(self):
+        return _lib.pf_decoder_config(self.vocab_size, self.d_model, self.attention_heads, self.linear_units,
+                                      self.att_layer_num, self.kernel_size, self.sanm_shfit, 1e-12)
+
+    def _run(self, hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits: bool, want_ids: bool, want_hidden: bool = False):
+        lib, h = self._ensure_handle()
+        dev = self._handle_device
+        mem = hs_pad.to(device=dev, dtype=torch.float32).contiguous()
+        emb = ys_in_pad.to(device=dev, dtype=torch.float32).contiguous()
+        B, T, D = mem.shape
+        N = emb.shape[1]
+        mlen_c, _ = host_i32(hlens, B)
+        tlen_c, tlens = host_i32(ys_in_lens, B)
+        logits = torch.empty(B, N, self.vocab_size, device=dev, dtype=torch.float32) if want_logits else None
+        ids = torch.empty(B, N, device=dev, dtype=torch.int32) if want_ids else None
+        hid = torch.empty(B, N, D, device=dev, dtype=torch.float32) if want_hidden else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.pf_decoder_forward(h, mem.data_ptr(), mlen_c, emb.data_ptr(), tlen_c, B, T, N,
+                                              logits.data_ptr() if want_logits else None,
+                                              ids.data_ptr() if want_ids else None,
+                                              hid.data_ptr() if want_hidden else None, stream_ptr()),
+                       "pf_decoder_forward")
+        olens = torch.tensor(tlens, dtype=torch.int64, device=dev)
+        return logits, ids, hid, olens
+
+    def forward(self, hs_pad, hlens, ys_in_pad, ys_in_lens, chunk_mask=None, return_hidden: bool = False,
+                return_both: bool = False):
+        if chunk_mask is not None:
+            raise NotImplementedError("chunk_mask is a training/streaming feature")
+        logits, _, hid, olens = self._run(hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits=not return_hidden or return_both,
+                                          want_ids=False, want_hidden=return_hidden or return_both)
+        if return_both:
+            return logits, hid, olens
+        if return_hidden:
+            return hid, olens
+        return logits, olens
+
+    def greedy(self, hs_pad, hlens, ys_in_pad, ys_in_lens):
+        """int32 [B, N] arg-max token ids (== log_softmax(...).argmax(-1), paraformer/model.py:345,642)."""
+        _, ids, _, olens = self._run(hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits=False, want_ids=True)
+        return ids, olens

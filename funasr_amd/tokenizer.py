@@ -1,0 +1,131 @@
+"""Host-side id -> text glue (no GPU work).
+
+`CharTokenizer` mirrors the inference half of funasr/tokenizer/char_tokenizer.py:12-99 + BaseTokenizer.ids2tokens
+(funasr/tokenizer/abs_tokenizer.py:108-116): a token list (tokens.json / list / one-token-per-line file), ids2tokens,
+tokens2text. `sentence_postprocess` restates the no-timestamp path of funasr/utils/postprocess_utils.py:165-278:
+drop <s>/</s>/<unk>/<OOV>, join CJK characters directly, re-assemble "@@"-continued BPE pieces, put blanks between
+alphabetic words, merge spelled-out single letters into upper-case abbreviations (abbr_dispose, :57-163).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Iterable, List, Sequence, Tuple, Union
+
+from .register import tables
+
+_DROP = ("<s>", "</s>", "<unk>", "<OOV>")
+
+
+def _strip(tok: str) -> str:
+    for d in (" ",) + _DROP:
+        tok = tok.replace(d, "")
+    return tok
+
+
+def _is_cjk_token(tok: str) -> bool:
+    return "一" <= tok <= "鿿" or "0" <= tok <= "9" or tok == "@"
+
+
+def _all_cjk(tokens: Sequence[str]) -> bool:
+    toks = [_strip(t) for t in tokens]
+    return len(toks) > 0 and all(_is_cjk_token(t) for t in toks)
+
+
+def _all_alpha(tokens: Sequence[str]) -> bool:
+    toks = [_strip(t) for t in tokens]
+    if not toks:
+        return False
+    for t in toks:
+        if not t.isalpha() and t != "'":
+            return False
+        if t.isalpha() and _is_cjk_token(t):
+            return False
+    return True
+
+
+def _is_letter(tok: str) -> bool:
+    return len(tok) == 1 and tok.encode("utf-8").isalpha()
+
+
+def _merge_abbreviations(words: List[str]) -> List[str]:
+    """'a', ' ', 'b', ' ', 'c' -> 'ABC' (abbr_dispose without timestamps)."""
+    out: List[str] = []
+    i, n = 0, len(words)
+    while i < n:
+        if _is_letter(words[i]) and i + 2 < n and words[i + 1] == " " and _is_letter(words[i + 2]):
+            j = i + 2
+            while j + 2 < n and words[j + 1] == " " and _is_letter(words[j + 2]):
+                j += 2
+            out.append("".join(w.upper() for w in words[i:j + 1] if w != " "))
+            i = j + 1
+        else:
+            out.append(words[i])
+            i += 1
+    return out
+
+
+def sentence_postprocess(tokens: Iterable[Union[str, bytes]]) -> Tuple[str, List[str]]:
+    toks = [t if isinstance(t, str) else t.decode("utf-8") for t in tokens]
+    toks = [t for t in toks if t not in _DROP]
+    words: List[str] = []
+    if _all_cjk(toks):
+        words = [t.replace(" ", "") for t in toks]
+    elif _all_alpha(toks):
+        piece = ""
+        for t in toks:
+            if "@@" in t:
+                piece += t.replace("@@", "")
+            else:
+                words += [piece + t, " "]
+                piece = ""
+    else:
+        piece, blank = "", False
+        for t in toks:
+            if _all_cjk(t):
+                if blank:
+                    words.pop()
+                words.append(t)
+                blank = False
+            elif "@@" in t:
+                piece += t.replace("@@", "")
+                blank = False
+            elif _all_alpha(t):
+                words += [piece + t, " "]
+                piece, blank = "", True
+            else:
+                words.append(t)
+    words = _merge_abbreviations(words)
+    return "".join(words).strip(), [w for w in words if w != " "]
+
+
+@tables.register("tokenizer_classes", "CharTokenizer")
+class CharTokenizer:
+    def __init__(self, token_list=None, unk_symbol: str = "<unk>", space_symbol: str = "<space>", **kwargs):
+        if isinstance(token_list, (str, os.PathLike)):
+            path = str(token_list)
+            with open(path, "r", encoding="utf-8") as f:
+                self.token_list = json.load(f) if path.endswith(".json") else [ln.rstrip("\n").split()[0] for ln in f if ln.strip()]
+        elif token_list is not None:
+            self.token_list = list(token_list)
+        else:
+            self.token_list = None
+        self.unk_symbol, self.space_symbol = unk_symbol, space_symbol
+        if self.token_list is not None:
+            self.token2id = {t: i for i, t in enumerate(self.token_list)}
+
+    def get_num_vocabulary_size(self) -> int:
+        return len(self.token_list)
+
+    def ids2tokens(self, integers) -> List[str]:
+        return [self.token_list[int(i)] for i in integers]
+
+    def tokens2ids(self, tokens) -> List[int]:
+        unk = self.token2id.get(self.unk_symbol, 0)
+        return [self.token2id.get(t, unk) for t in tokens]
+
+    def tokens2text(self, tokens: Iterable[str]) -> str:
+        return "".join(t if t != self.space_symbol else " " for t in tokens)
+
+    def decode(self, ids) -> str:
+        return self.tokens2text(self.ids2tokens(ids))

@@ -1,0 +1,165 @@
+"""WavFrontend on gfx950: batched fbank + LFR + CMVN in two kernels (csrc/frontend.hip).
+
+Host-side mirror of funasr/frontends/wav_frontend.py:89-196 (`WavFrontend`, registered as "WavFrontend" /
+"wav_frontend" in `frontend_classes`), same constructor keywords, `output_size()`, and
+`forward(input [B, n], input_lengths [B]) -> (feats [B, T, n_mels*lfr_m], feats_lens [B])`.
+Differences, on purpose: the whole batch is one launch instead of a Python loop over utterances, the result stays
+in HBM, and `dither` must be 0 (the reference default of 1.0 adds Gaussian noise per sample and is therefore not
+reproducible; its own C++ runtime pins 0, runtime/onnxruntime/src/paraformer.cpp:24).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .hip_module import host_i32, stream_ptr
+from .register import tables
+
+
+def load_cmvn(cmvn_file: str) -> torch.Tensor:
+    """Kaldi-nnet am.mvn -> [2, dim] (row 0 <AddShift>, row 1 <Rescale>); format per wav_frontend.py:15-43."""
+    shift, scale = None, None
+    with open(cmvn_file, "r", encoding="utf-8") as f:
+        lines = f.readlines()
+    for i, line in enumerate(lines):
+        tok = line.split()
+        if tok and tok[0] in ("<AddShift>", "<Rescale>") and i + 1 < len(lines):
+            nxt = lines[i + 1].split()
+            if nxt and nxt[0] == "<LearnRateCoef>":
+                vals = np.array(nxt[3:len(nxt) - 1]).astype(np.float32)
+                if tok[0] == "<AddShift>":
+                    shift = vals
+                else:
+                    scale = vals
+    if shift is None or scale is None or shift.shape != scale.shape:
+        raise ValueError(f"{cmvn_file}: could not find matching <AddShift>/<Rescale> rows")
+    return torch.from_numpy(np.stack([shift, scale]))
+
+
+def kaldi_tables(n_mels: int, window_size: int, fs: float, low_freq: float = 20.0, high_freq: float = 0.0):
+    """Window and dense mel matrix in the float32 arithmetic torchaudio.compliance.kaldi uses, so that the device
+    frontend matches the reference's Python path to float32 round-off (the library's built-in tables follow
+    kaldi-native-fbank's float64-cosine / float-scalar construction instead)."""
+    import math
+
+    padded = 1 << (window_size - 1).bit_length()
+    window = torch.hamming_window(window_size, periodic=False, alpha=0.54, beta=0.46, dtype=torch.float32)
+    nyq = 0.5 * fs
+    hf = high_freq + nyq if high_freq <= 0.0 else high_freq
+    mlo = 1127.0 * math.log(1.0 + low_freq / 700.0)
+    mhi = 1127.0 * math.log(1.0 + hf / 700.0)
+    delta = (mhi - mlo) / (n_mels + 1)
+    b = torch.arange(n_mels, dtype=torch.float32).unsqueeze(1)
+    left, center, right = mlo + b * delta, mlo + (b + 1.0) * delta, mlo + (b + 2.0) * delta
+    mel = (1127.0 * (1.0 + ((fs / padded) * torch.arange(padded // 2, dtype=torch.float32)) / 700.0).log()).unsqueeze(0)
+    bins = torch.max(torch.zeros(1), torch.min((mel - left) / (center - left), (right - mel) / (right - center)))
+    return window.contiguous(), torch.nn.functional.pad(bins, (0, 1)).contiguous()
+
+
+@tables.register("frontend_classes", "wav_frontend")
+@tables.register("frontend_classes", "WavFrontend")
+class WavFrontend(nn.Module):
+    def __init__(self, cmvn_file: str = None, fs: int = 16000, window: str = "hamming", n_mels: int = 80,
+                 frame_length: int = 25, frame_shift: int = 10, filter_length_min: int = -1,
+                 filter_length_max: int = -1, lfr_m: int = 1, lfr_n: int = 1, dither: float = 0.0,
+                 snip_edges: bool = True, upsacle_samples: bool = True, cmvn: torch.Tensor = None,
+                 device=None, **kwargs):
+        super().__init__()
+        if window != "hamming":
+            raise NotImplementedError("only the hamming window of the Paraformer/SenseVoice recipes is built")
+        if not snip_edges:
+            raise NotImplementedError("snip_edges=False is not built")
+        if float(dither) != 0.0:
+            raise ValueError("dither must be 0.0: the HIP frontend is deterministic (the reference default 1.0 is "
+                             "random noise; its C++ runtime also uses 0, runtime/onnxruntime/src/paraformer.cpp:24)")
+        self.fs, self.window, self.n_mels = fs, window, n_mels
+        self.frame_length, self.frame_shift = frame_length, frame_shift
+        self.filter_length_min, self.filter_length_max = filter_length_min, filter_length_max
+        self.lfr_m, self.lfr_n = lfr_m, lfr_n
+        self.cmvn_file, self.dither, self.snip_edges, self.upsacle_samples = cmvn_file, dither, snip_edges, upsacle_samples
+        self.cmvn = cmvn if cmvn is not None else (None if cmvn_file is None else load_cmvn(cmvn_file))
+        self._device_arg = device
+        self._handle = None
+        self._handle_device = None
+
+    def output_size(self) -> int:
+        return self.n_mels * self.lfr_m
+
+    # ------------------------------------------------------------------------------------------------ internals
+    def _ensure_handle(self, dev: torch.device):
+        lib = _lib.load()
+        if self._handle is not None and self._handle_device == dev:
+            return lib, self._handle
+        if dev.type != "cuda":
+            raise RuntimeError("WavFrontend runs only on an AMD GPU through libparaformer_hip.so (no CPU fallback)")
+        self.close()
+        win = int(self.fs * self.frame_length * 0.001)
+        cfg = _lib.pf_frontend_config(self.fs, win, int(self.fs * self.frame_shift * 0.001), self.n_mels, self.lfr_m,
+                                      self.lfr_n, 20.0, 0.0, 0.97, float(1 << 15) if self.upsacle_samples else 1.0)
+        with torch.cuda.device(dev):
+            h = _lib.check_handle(lib.pf_frontend_create(C.byref(cfg)), "pf_frontend_create")
+            w, mel = kaldi_tables(self.n_mels, win, float(self.fs))
+            _lib.check(lib.pf_frontend_set_tables(h, w.data_ptr(), mel.data_ptr()), "pf_frontend_set_tables")
+            if self.cmvn is not None:
+                c = self.cmvn.to(torch.float32).contiguous().cpu()
+                dim = self.output_size()
+                _lib.check(lib.pf_frontend_set_cmvn(h, c[0, :dim].contiguous().data_ptr(),
+                                                    c[1, :dim].contiguous().data_ptr(), dim), "pf_frontend_set_cmvn")
+        self._handle, self._handle_device = h, dev
+        return lib, h
+
+    def close(self):
+        if self._handle is not None:
+            try:
+                _lib.load().pf_frontend_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def __del__(self):
+        self.close()
+
+    def _target_device(self, x: torch.Tensor) -> torch.device:
+        if x.is_cuda:
+            return x.device
+        if self._device_arg is not None:
+            return torch.device(self._device_arg)
+        if not torch.cuda.is_available():
+            raise RuntimeError("WavFrontend: no GPU visible; the HIP frontend is the only implementation")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def num_frames(self, n_samples: int) -> int:
+        win, hop = int(self.fs * self.frame_length * 0.001), int(self.fs * self.frame_shift * 0.001)
+        tf = 0 if n_samples < win else 1 + (n_samples - win) // hop
+        return (tf + self.lfr_n - 1) // self.lfr_n
+
+    def forward(self, input: torch.Tensor, input_lengths, return_fbank: bool = False, **kwargs):
+        if input.dim() == 1:
+            input = input[None, :]
+        dev = self._target_device(input)
+        lib, h = self._ensure_handle(dev)
+        wav = input.to(device=dev, dtype=torch.float32).contiguous()
+        B, n_max = wav.shape
+        lens_c, lens = host_i32(input_lengths, B)
+        T = max(self.num_frames(n) for n in lens)
+        if T <= 0:
+            raise ValueError("WavFrontend: every utterance must be at least one analysis window (25 ms) long")
+        feats = torch.empty(B, T, self.output_size(), device=dev, dtype=torch.float32)
+        out_lens = (C.c_int32 * B)()
+        fb = None
+        if return_fbank:
+            win, hop = int(self.fs * self.frame_length * 0.001), int(self.fs * self.frame_shift * 0.001)
+            tfb = max(1 + (n - win) // hop for n in lens)
+            fb = torch.zeros(B, tfb, self.n_mels, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pf_frontend_forward(h, wav.data_ptr(), wav.stride(0), lens_c, B, feats.data_ptr(), T,
+                                               out_lens, fb.data_ptr() if fb is not None else None, stream_ptr()),
+                       "pf_frontend_forward")
+        feats_lens = torch.tensor(list(out_lens), dtype=torch.int32)
+        if return_fbank:
+            return feats, feats_lens, fb
+        return feats, feats_lens

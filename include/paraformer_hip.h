@@ -186,6 +186,10 @@ int pf_k_fsmn(const float* in, int32_t ldin, const float* w, const float* R, int
 int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
                        float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq,
                        int32_t Tk, float scale, void* stream);
+/* CIF integrate-and-fire on caller-provided weights (cif_v1, cif_predictor.py:853-908): alphas [B, T], hidden
+ * [B, T, D] -> peaks [B, T] (= "fires"), n_fires int32 [B], embeds [B, N, D] (rows >= n_fires[b] zero). */
+int pf_k_cif(const float* alphas, const float* hidden, int32_t B, int32_t T, int32_t D, int32_t N, float* peaks,
+             int32_t* n_fires, float* embeds, void* stream);
 /* average kernel time in milliseconds of `iters` back-to-back launches of the GEMM above, measured with
  * hipEvents on `stream` (used by bench.py for the roofline line) */
 int pf_k_gemm_f32_time(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, float* C,

@@ -1,0 +1,237 @@
+"""Module-level parity of the HIP path (through the C ABI) against
+  (a) the committed golden fixtures produced by the REFERENCE's own modules (tests/golden, oracle/make_golden.py) and
+  (b) the CPU oracle (oracle/paraformer_oracle.py) on further seeded inputs.
+
+Bars (north_star): integer results -- CIF fire positions, token counts, arg-max token ids -- bit-exact;
+encoder / decoder activations within 1e-3 absolute of the fp32 CPU path (we assert 2e-4 or tighter where the
+measured margin allows); CIF scan bit-exact given identical alphas.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from funasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def fires_of(peaks):
+    return (torch.floor(torch.as_tensor(peaks)) >= 1)
+
+
+# ---------------------------------------------------------------------------------------------------- frontend
+def test_frontend_vs_reference_features_and_oracle(cuda):
+    from funasr_amd.wav_frontend import WavFrontend
+    from oracle import paraformer_oracle as O
+    g = gold("frontend")
+    cmvn = t(g["cmvn"])
+    fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0)
+    waves = [t(g["pcm_a"].astype(np.float32) / 32768.0), t(g["pcm_b"].astype(np.float32) / 32768.0)]
+    lens = [w.numel() for w in waves]
+    batch = torch.zeros(2, max(lens))
+    for i, w in enumerate(waves):
+        batch[i, : lens[i]] = w
+    feats, flens, fb = fe(batch.to(cuda), lens, return_fbank=True)
+    feats, fb = feats.cpu(), fb.cpu()
+    assert flens.tolist() == [g["feats_a"].shape[0], g["feats_b"].shape[0]]
+    # (a) reference features (kaldi-native-fbank + reference LFR/CMVN): float64-FFT vs float32-FFT level
+    for i, k in enumerate("ab"):
+        ref_fb = t(g[f"fbank_knf_{k}"])
+        d = (fb[i, : ref_fb.shape[0]] - ref_fb).abs()
+        assert d.max().item() <= 2e-3 and d.mean().item() <= 2e-5, (d.max().item(), d.mean().item())
+        assert (feats[i, : flens[i]] - t(g[f"feats_{k}"])).abs().max().item() < 5e-4
+    assert (feats[1, flens[1]:] == 0).all()            # pad_sequence zeros
+    # (b) the oracle (torchaudio semantics in float32): same tables, only FFT / reduction order differ
+    of, ol, ofb = O.wav_frontend(waves, cmvn, return_fbank=True)
+    assert ol.tolist() == flens.tolist()
+    for i in range(2):
+        assert (fb[i, : ofb[i].shape[0]] - ofb[i]).abs().max().item() <= 2e-3
+        assert (feats[i, : ol[i]] - of[i, : ol[i]]).abs().max().item() < 5e-4
+
+
+def test_frontend_ragged_batch_equals_single_utterance_bitwise(cuda):
+    """Utterance-level data parallelism: a clip's features do not depend on its batch neighbours."""
+    from funasr_amd.wav_frontend import WavFrontend
+    sh, sc = synth.synthetic_cmvn()
+    fe = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0)
+    lens = [16000, 7777, 400, 30011]
+    waves = [synth.speech_like(n, seed=i) for i, n in enumerate(lens)]
+    batch = torch.zeros(len(lens), max(lens))
+    for i, w in enumerate(waves):
+        batch[i, : lens[i]] = w
+    feats, flens = fe(batch.to(cuda), lens)
+    assert flens.tolist() == [fe.num_frames(n) for n in lens]
+    for i, w in enumerate(waves):
+        single, sl = fe(w[None].to(cuda), [lens[i]])
+        assert torch.equal(single[0, : sl[0]].cpu(), feats[i, : flens[i]].cpu())
+        assert (feats[i, flens[i]:] == 0).all()
+
+
+# ----------------------------------------------------------------------------------------------------- encoder
+def _encoder(cfg, sd, cuda, cls=None):
+    from funasr_amd.sanm_encoder import SANMEncoder
+    cls = cls or SANMEncoder
+    kw = dict(cfg)
+    enc = cls(input_layer="pe", **kw)
+    enc.load_state_dict(sd, strict=True)
+    return enc.to(cuda)
+
+
+def test_encoder_vs_reference_golden(cuda):
+    g = gold("encoder")
+    cfg = json.loads(str(g["cfg"]))
+    enc = _encoder(cfg, synth.encoder_state_dict(cfg, seed=int(g["seed"])), cuda)
+    out, olens, _ = enc(t(g["xs"]).to(cuda), t(g["lens"]))
+    assert olens.tolist() == g["olens"].tolist()
+    b1, _ = enc._run(t(g["xs"]).to(cuda), t(g["lens"]), run_blocks=1)
+    b3, _ = enc._run(t(g["xs"]).to(cuda), t(g["lens"]), run_blocks=3)
+    assert (b1.cpu() - t(g["block1"])).abs().max().item() < 1e-4
+    assert (b3.cpu() - t(g["block3"])).abs().max().item() < 1e-4
+    assert (out.cpu() - t(g["out"])).abs().max().item() < 1e-4     # north_star bar: 1e-3
+
+
+def test_encoder_full_depth_vs_oracle(cuda):
+    """All 50 blocks of Paraformer-large, ragged batch, every (also padded) frame compared."""
+    from oracle import paraformer_oracle as O
+    cfg = synth.PARAFORMER_LARGE["encoder"]
+    sd = synth.encoder_state_dict(cfg, seed=3)
+    enc = _encoder(cfg, sd, cuda)
+    g = torch.Generator().manual_seed(77)
+    xs = torch.randn(3, 90, 560, generator=g) * 0.7
+    lens = torch.tensor([90, 61, 8], dtype=torch.int32)
+    for b in range(3):
+        xs[b, lens[b]:] = 0
+    ref, _ = O.sanm_encoder(xs, lens, sd, cfg)
+    out, _, _ = enc(xs.to(cuda), lens)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 1e-3, err
+
+
+# --------------------------------------------------------------------------------------------------- predictor
+def test_cif_bit_exact_given_reference_alphas(cuda):
+    from funasr_amd import ops
+    g = gold("cif")
+    al, hid = t(g["alphas"]).to(cuda), t(g["hidden"]).to(cuda)
+    n_max = g["frames"].shape[1]
+    peaks, nf, emb = ops.cif(al, hid, n_max)
+    assert np.array_equal(peaks.cpu().numpy(), g["fires"])                       # bit-exact float32 "fires"
+    assert np.array_equal(fires_of(peaks.cpu()).numpy(), g["fire_idx"])          # fire positions
+    assert nf.cpu().tolist() == g["fire_idx"].sum(1).tolist()
+    assert np.array_equal(emb.cpu().numpy(), g["frames"])                        # bit-exact weighted sums
+
+
+def test_predictor_vs_reference_golden(cuda):
+    from funasr_amd.cif_predictor import CifPredictorV2
+    g = gold("predictor")
+    cfg = json.loads(str(g["cfg"]))
+    p = CifPredictorV2(**cfg)
+    p.load_state_dict(synth.predictor_state_dict(cfg, seed=int(g["seed"])), strict=True)
+    p = p.to(cuda)
+    hid, lens = t(g["hidden"]).to(cuda), t(g["lens"])
+    mask = (torch.arange(hid.shape[1])[None, :] < lens[:, None]).float()[:, None, :]
+    emb, tok, alphas, peaks = p(hid, None, mask.to(cuda))
+    assert tok.cpu().tolist() == g["token_num"].tolist()
+    assert (alphas.cpu() - t(g["alphas"])).abs().max().item() < 2e-6
+    assert torch.equal(fires_of(peaks.cpu()), fires_of(g["peaks"]))
+    assert emb.shape == g["embeds"].shape
+    assert (emb.cpu() - t(g["embeds"])).abs().max().item() < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------------- decoder
+def test_decoder_vs_reference_golden(cuda):
+    from funasr_amd.paraformer_decoder import ParaformerSANMDecoder
+    g = gold("decoder")
+    cfg = json.loads(str(g["cfg"]))
+    d = ParaformerSANMDecoder(**cfg)
+    d.load_state_dict(synth.decoder_state_dict(cfg, seed=int(g["seed"]), with_embed=True), strict=True)
+    d = d.to(cuda)
+    args = (t(g["memory"]).to(cuda), t(g["mem_lens"]), t(g["embeds"]).to(cuda), t(g["tok_lens"]))
+    logits, olens = d(*args)
+    assert olens.tolist() == g["tok_lens"].tolist()
+    assert (logits.cpu() - t(g["logits"])).abs().max().item() < 2e-4
+    ids, _ = d.greedy(*args)                                   # fused GEMM + arg-max
+    ref_ids = t(g["logits"]).argmax(-1)
+    for b in range(ids.shape[0]):
+        n = int(g["tok_lens"][b])
+        assert ids[b, :n].cpu().tolist() == ref_ids[b, :n].tolist()
+
+
+# ---------------------------------------------------------------------------------------------------- pipeline
+def test_pipeline_token_ids_equal_reference(cuda):
+    from funasr_amd.paraformer import Paraformer
+    g = gold("pipeline")
+    cfg = json.loads(str(g["cfg"]))
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=int(g["seed"])), strict=False)
+    model = model.to(cuda)
+    res = model.recognize_features(t(g["feats"]).to(cuda), t(g["lens"]), return_intermediate=True)
+    assert res["token_num"] == g["token_num"].tolist()
+    assert torch.equal(fires_of(res["peaks"].cpu()), fires_of(g["peaks"]))       # CIF fire indices bit-exact
+    assert (res["enc"].cpu() - t(g["enc"])).abs().max().item() < 1e-4
+    for b, n in enumerate(g["token_num"].tolist()):
+        assert res["raw_ids"][b] == g["raw_ids"][b, :n].tolist()
+
+
+# -------------------------------------------------------------------------------------------------- SenseVoice
+def test_sensevoice_encoder_and_ctc_vs_reference_golden(cuda):
+    from funasr_amd.ctc import CTC
+    from funasr_amd.sanm_encoder import SenseVoiceEncoderSmall
+    g = gold("sensevoice")
+    cfg = json.loads(str(g["cfg"]))
+    sd = synth.sensevoice_state_dict(cfg, seed=int(g["seed"]))
+    enc = SenseVoiceEncoderSmall(input_layer="pe", **cfg["encoder"])
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
+    enc = enc.to(cuda)
+    out, olens = enc(t(g["xs"]).to(cuda), t(g["lens"]))
+    assert olens.tolist() == g["olens"].tolist()
+    assert (out.cpu() - t(g["out"])).abs().max().item() < 1e-4
+    ctc = CTC(odim=cfg["vocab_size"], encoder_output_size=cfg["encoder"]["output_size"])
+    ctc.load_state_dict({"ctc_lo.weight": sd["ctc.ctc_lo.weight"], "ctc_lo.bias": sd["ctc.ctc_lo.bias"]})
+    ctc = ctc.to(cuda)
+    assert np.array_equal(ctc.argmax(out).cpu().numpy(), g["frame_ids"])
+
+
+# ------------------------------------------------------------------- full-size, size-independent properties
+def test_full_size_batch_independence_and_fused_argmax(cuda):
+    """BASELINE config 2 shapes (B=64 x 30 s -> T=500) on a shallow model: (1) every clip's encoder output and token
+    ids are bitwise identical whether it is decoded alone or inside the 64-clip batch (utterance DP is exact),
+    (2) fused arg-max == arg-max of the materialised logits."""
+    from funasr_amd.paraformer import Paraformer
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2, dec_blocks=1, vocab=8404)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=5), strict=False)
+    model = model.to(cuda)
+    g = torch.Generator().manual_seed(1)
+    B, T = 64, 500
+    feats = torch.randn(B, T, 560, generator=g) * 0.7
+    lens = torch.randint(100, T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = T
+    for b in range(B):
+        feats[b, lens[b]:] = 0
+    res = model.recognize_features(feats.to(cuda), lens, return_intermediate=True)
+    for b in (0, 7, 63):
+        L = int(lens[b])
+        # same padded length: everything (also the padded frames the CIF conv peeks into, cif_predictor.py:275-277)
+        # is bitwise identical, hence the same tokens
+        one = model.recognize_features(feats[b:b + 1].to(cuda), lens[b:b + 1], return_intermediate=True)
+        assert torch.equal(one["enc"][0].cpu(), res["enc"][b].cpu())
+        assert one["raw_ids"][0] == res["raw_ids"][b]
+        # truncated to its own length: valid encoder frames still bitwise identical
+        cut, _, _ = model.encoder(feats[b:b + 1, :L].to(cuda), lens[b:b + 1])
+        assert torch.equal(cut[0].cpu(), res["enc"][b, :L].cpu())
+    logits, _ = model.decoder(res["enc"], lens, res["embeds"], torch.tensor(res["token_num"]))
+    ids = logits.argmax(-1).cpu()
+    for b in range(B):
+        assert ids[b, : res["token_num"][b]].tolist() == res["raw_ids"][b]
