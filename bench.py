@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds per wall-second (RTF^-1) of the full Paraformer-large hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  [B, 480000] float32 PCM -> fbank/LFR/CMVN -> 50-block SAN-M encoder -> CIF predictor -> 16-block SAN-M decoder
+  -> fused vocabulary arg-max -> token ids on the host (one D2H copy), i.e. BASELINE.json configs[1]
+  ("Paraformer-large, batch=64 synthetic 30 s 16 kHz clips, 1 x MI355X"), random-initialised weights of the exact
+  architecture (funasr_amd/synth.py), fp32 arithmetic on the f32 MFMA path (the parity configuration).
+
+Multi-GPU (utterance-level data parallelism, weak scaling): one process per GPU, rank 0 builds the weights and
+broadcasts ONE packed arena over RCCL, every rank decodes its own 64 clips, hypotheses are gathered on rank 0
+inside the timed region. No collective touches the data path.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1 is launched through torch.distributed.run)
+prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields, incl. `roofline` and `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=2, help="clips of the same workload timed on the host oracle")
+    return ap.parse_args()
+
+
+def build_model(cfg, rank, world, device):
+    """rank 0 draws the synthetic checkpoint; with world > 1 it is shipped as one packed arena (RCCL broadcast)."""
+    from funasr_amd import synth
+    from funasr_amd.paraformer import Paraformer
+    import torch.distributed as dist
+
+    model = Paraformer.from_config(cfg)
+    names = [n for n, _ in model.named_parameters()]
+    if rank == 0:
+        sd = synth.paraformer_state_dict(cfg, seed=0)
+        model.load_state_dict(sd, strict=False)
+    model = model.to(device)
+    if world > 1:
+        params = [p for _, p in model.named_parameters()]
+        arena = torch.cat([p.detach().reshape(-1) for p in params])          # ~880 MB fp32
+        dist.broadcast(arena, src=0)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                p.copy_(arena[off:off + n].view_as(p))
+                off += n
+        del arena
+        for m in model.modules():
+            if hasattr(m, "mark_dirty"):
+                m.mark_dirty()
+    return model, names
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the HIP path is the only implementation")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)        # backend "nccl" is RCCL on ROCm
+
+    from funasr_amd import _lib, synth
+    from funasr_amd.wav_frontend import WavFrontend
+
+    lib = _lib.load()
+    cfg = synth.PARAFORMER_LARGE
+    model, _ = build_model(cfg, rank, world, device)
+    shift, scale = synth.synthetic_cmvn(560)
+    frontend = WavFrontend(cmvn=torch.stack([shift, scale]), lfr_m=7, lfr_n=6, dither=0.0, device=device)
+
+    # ---- synthetic workload, resident in HBM before the clock starts
+    B = args.batch
+    n_samples = int(args.seconds * 16000)
+    base = [synth.speech_like(n_samples, seed=1000 * rank + i) for i in range(min(B, 8))]
+    clips = [base[i % len(base)].roll(137 * (i // len(base))) for i in range(B)]   # distinct but cheap to generate
+    wav = torch.stack(clips).to(device)
+    lens = [n_samples] * B
+    N_PAD = 512
+
+    def step():
+        feats, flens = frontend(wav, lens)
+        res = model.recognize_features(feats, flens)
+        if world > 1:      # gather hypotheses on rank 0 (fixed-stride int32 ids + lengths), the path's only exchange
+            ids = torch.full((B, N_PAD), -1, dtype=torch.int32)
+            for b, r in enumerate(res["raw_ids"]):
+                ids[b, : len(r)] = torch.tensor(r[:N_PAD], dtype=torch.int32)
+            ids = ids.to(device)
+            out = [torch.empty_like(ids) for _ in range(world)] if rank == 0 else None
+            dist.gather(ids, out, dst=0)
+        return res
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    sync()
+    lib.pf_prof_reset()
+    lib.pf_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    dt = time.perf_counter() - t0
+    lib.pf_prof_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    audio_s = world * B * args.seconds * args.steps
+    value = audio_s / dt
+    # ---- roofline of the dominant kernel (f32 MFMA GEMM), from hipEvents recorded around every launch in the
+    #      timed region on the launch stream
+    kinds = {0: "gemm_f32_mfma", 1: "attention_f32", 2: "fsmn", 3: "layernorm", 4: "fbank"}
+    prof = {}
+    for k, name in kinds.items():
+        ms, work, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        lib.pf_prof_read(k, C.byref(ms), C.byref(work), C.byref(n))
+        prof[name] = dict(ms_per_step=ms.value / args.steps, work_per_step=work.value / args.steps,
+                          launches_per_step=n.value / args.steps)
+    gemm = prof["gemm_f32_mfma"]
+    ach = gemm["work_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12 if gemm["ms_per_step"] > 0 else 0.0
+    roofline = dict(bound="mfma", kernel="gemm_f32_mfma_kernel", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    flops_per_launch=gemm["work_per_step"] / max(gemm["launches_per_step"], 1),
+                    avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
+                    launches_per_step=gemm["launches_per_step"])
+    kernels = {k: dict(ms_per_step=round(v["ms_per_step"], 3), launches=v["launches_per_step"]) for k, v in prof.items()}
+    attn = prof["attention_f32"]
+    if attn["ms_per_step"] > 0:
+        kernels["attention_f32"]["tflops"] = round(attn["work_per_step"] / (attn["ms_per_step"] * 1e-3) / 1e12, 2)
+    for nm in ("fsmn", "layernorm", "fbank"):
+        if prof[nm]["ms_per_step"] > 0:
+            kernels[nm]["GBps"] = round(prof[nm]["work_per_step"] / (prof[nm]["ms_per_step"] * 1e-3) / 1e9, 1)
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(cfg, clips[: args.cpu_clips], shift, scale, res, args)
+
+    line = {
+        "metric": "audio-seconds/sec (RTF^-1) Paraformer-large 30s@bs64", "value": round(value, 1),
+        "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Paraformer-large (50 enc + 16 dec blocks, vocab 8404, random-init), "
+                               f"{B} x {args.seconds:g} s 16 kHz clips per GPU, wav in HBM -> token ids on host",
+                   "clips_per_gpu": B, "clip_seconds": args.seconds, "parallelism": f"utterance-dp{world}",
+                   "tokens_per_clip": round(sum(res["token_num"]) / len(res["token_num"]), 1)},
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(cfg, clips, shift, scale, gpu_res, args):
+    """The oracle (CPU port of the reference path, same ATen kernels the reference uses) timed on the host cores on
+    a bounded sample of the same workload; doubles as an end-of-run parity check of the token ids."""
+    from funasr_amd import synth
+    from oracle import paraformer_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.paraformer_state_dict(cfg, seed=0)
+    cmvn = torch.stack([shift, scale])
+    match = True
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i, w in enumerate(clips):                      # bs = 1, what AutoModel does on device="cpu"
+            feats, flens = O.wav_frontend([w], cmvn)
+            r = O.paraformer_greedy(feats, flens, sd, cfg)
+            match = match and (r["raw_ids"][0] == gpu_res["raw_ids"][i])
+    dt = time.perf_counter() - t0
+    secs = sum(w.numel() for w in clips) / 16000.0
+    return {"value": round(secs / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"{len(clips)} x {secs / len(clips):g} s clips of the same batch, batch_size 1, fp32, "
+                      f"torch {torch.__version__} CPU, {cores} threads", "token_ids_match_gpu": bool(match)}
+
+
+if __name__ == "__main__":
+    main()
