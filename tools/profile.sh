@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes for HBM traffic of the
+# bench workload. Outputs under gpurun_out/prof_$TAG; tools/summarize_prof.py condenses them into profiles/.
+# usage: tools/profile.sh TAG [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH > "$OUT/stats.log" 2>&1
+echo "stats rc=$?" >> "$OUT/stats.log"
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
+echo "pmc_fetch rc=$?" >> "$OUT/pmc_fetch.log"
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/pmc_write.log" 2>&1
+echo "pmc_write rc=$?" >> "$OUT/pmc_write.log"
+cd - > /dev/null
+python tools/summarize_prof.py "$OUT" "$TAG" > "$OUT/summary.md" 2>&1
+# keep the merged-back payload small: per-dispatch traces can be tens of MB
+find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
+find "$OUT" -name '*counter_collection.csv' -size +8M -delete
+tail -40 "$OUT/summary.md"

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output of tools/profile.sh into one markdown summary (per-kernel time table from
+--kernel-trace --stats, per-kernel HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE PMC passes).
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are reported in KiB
+(x1024); on gfx950 FETCH_SIZE under-counts wide coalesced reads by exactly 2x, so the read side is doubled
+("corrected"); WRITE_SIZE is taken as reported (uncalibrated)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.split("(")[0]
+    for pre in ("void ", "pf::(anonymous namespace)::", "pf::"):
+        name = name.replace(pre, "")
+    return name[:70]
+
+
+def stats_table(root):
+    f = find(os.path.join(root, "stats"), "*kernel_stats.csv")
+    rows = []
+    if not f:
+        return rows
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            rows.append(r)
+    return rows
+
+
+def pmc_table(root, sub, counter):
+    f = find(os.path.join(root, sub), "*counter_collection.csv")
+    agg = defaultdict(lambda: [0.0, 0])
+    if not f:
+        return agg
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if r.get("Counter_Name") != counter:
+                continue
+            k = short(r.get("Kernel_Name", "?"))
+            agg[k][0] += float(r.get("Counter_Value", 0.0))
+            agg[k][1] += 1
+    return agg
+
+
+def main():
+    root, tag = sys.argv[1], sys.argv[2]
+    print(f"# rocprofv3 summary `{tag}`  (python bench.py --steps 3 --warmup 1 --no-cpu-baseline)\n")
+    rows = stats_table(root)
+    print("## kernel time (rocprofv3 --kernel-trace --stats)\n")
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for r in rows[:24]:
+        name = short(r.get("Name", r.get("KernelName", "?")))
+        calls = r.get("Calls", "?")
+        tot = float(r.get("TotalDurationNs", 0)) / 1e6
+        avg = float(r.get("AverageNs", 0)) / 1e3
+        pct = r.get("Percentage", "?")
+        print(f"| {name} | {calls} | {tot:.2f} | {avg:.1f} | {pct} |")
+    fetch = pmc_table(root, "pmc_fetch", "FETCH_SIZE")
+    write = pmc_table(root, "pmc_write", "WRITE_SIZE")
+    print("\n## HBM traffic per launch (separate --pmc passes; KiB counters x1024; FETCH_SIZE doubled per the gfx950 note)\n")
+    print("| kernel | launches | read MB/launch (corrected) | write MB/launch |")
+    print("|---|---|---|---|")
+    keys = sorted(set(fetch) | set(write), key=lambda k: -(fetch[k][0] if k in fetch else 0))
+    for k in keys[:24]:
+        fr = fetch[k][0] * 1024 * 2 / max(fetch[k][1], 1) / 1e6 if k in fetch else float("nan")
+        wr = write[k][0] * 1024 / max(write[k][1], 1) / 1e6 if k in write else float("nan")
+        n = fetch[k][1] if k in fetch else write[k][1]
+        print(f"| {k} | {n} | {fr:.3f} | {wr:.3f} |")
+
+
+if __name__ == "__main__":
+    main()
