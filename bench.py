@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=2, help="clips of the same workload timed on the host oracle")
+    ap.add_argument("--cpu-clips", type=int, default=64, help="max clips of the same workload timed on the host "
+                    "oracle (stops after ~20 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap on host threads for the CPU baseline (0 = all usable)")
     return ap.parse_args()
 
@@ -62,7 +63,7 @@ def build_model(cfg, rank, world, device):
     model = Paraformer.from_config(cfg)
     names = [n for n, _ in model.named_parameters()]
     if rank == 0:
-        sd = synth.paraformer_state_dict(cfg, seed=0)
+        sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
         model.load_state_dict(sd, strict=False)
     model = model.to(device)
     if world > 1:
@@ -188,7 +189,7 @@ def main():
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         trace("cpu baseline (oracle on host cores) ...")
-        cpu_baseline = run_cpu_baseline(cfg, clips[: args.cpu_clips], shift, scale, res, args)
+        cpu_baseline = run_cpu_baseline(cfg, clips, shift, scale, res, args)
         trace("cpu baseline done")
 
     line = {
@@ -232,7 +233,7 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu_res, args):
 
     cores = min(host_cores(), args.cpu_threads) if args.cpu_threads > 0 else host_cores()
     torch.set_num_threads(cores)
-    sd = synth.paraformer_state_dict(cfg, seed=0)
+    sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
     cmvn = torch.stack([shift, scale])
 
     def run(w):
@@ -245,20 +246,25 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu_res, args):
         probe = time.perf_counter() - t0
         rate = 3.0 / probe                                   # audio-s per wall-s on a short clip (optimistic for 30 s)
         trace(f"cpu probe: 3 s clip in {probe:.2f} s on {cores} threads")
-        budget_s = 25.0
+        budget_s = 20.0
         full = clips[0].numel() / 16000.0
-        n_full = int(min(len(clips), (budget_s * rate) // full))
+        n_full = int(min(len(clips), args.cpu_clips, (budget_s * rate) // full))
         match = None
         if n_full >= 1:
             sample = clips[:n_full]
         else:                                                # host too slow for one whole clip inside the budget
             sample = [clips[0][: max(16000, int(budget_s * rate * 0.7) * 16000)]]
         t0 = time.perf_counter()
+        done = 0
         for i, w in enumerate(sample):
             r = run(w)
+            done += 1
             if n_full >= 1:
                 ok = r["raw_ids"][0] == gpu_res["raw_ids"][i]
                 match = ok if match is None else (match and ok)
+            if time.perf_counter() - t0 > budget_s:
+                break
+        sample = sample[:done]
         dt = time.perf_counter() - t0
     secs = sum(w.numel() for w in sample) / 16000.0
     return {"value": round(secs / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",

@@ -60,6 +60,7 @@ struct GemmArgs {
     // optional fused arg-max over N (used for vocabulary projections): when amax_val != nullptr the
     // kernel does not write C but per-(row, column-block) partial maxima
     float* amax_val; int* amax_idx; int amax_ld;
+    int vec_epilogue;            // set by the launcher: all epilogue operands allow aligned float4 access
 };
 int launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 

@@ -6,132 +6,136 @@
 // funasr/models/paraformer/cif_predictor.py:277 cif_conv1d (as a 3-tap im2col GEMM),
 // funasr/models/paraformer/decoder.py:444 output_layer, funasr/models/ctc/ctc.py:192 ctc_lo).
 //
-// Design (gfx950): v_mfma_f32_32x32x2_f32 is an exact f32 fma chain at the f32 vector rate
-// (157 TFLOP/s peak), which is what the parity bar (encoder activations <= 1e-3, CIF fire indices equal
-// to the fp32 CPU path) needs. 128x128x32 block tile, 4 waves in a 2x2 grid, each wave owns 2x2 MFMA
-// tiles of 32x32. Both operands are K-contiguous in HBM (torch Linear layout), so one 16-B global load
-// per lane feeds one 16-B LDS store; LDS rows are padded to 36 floats (144 B) which makes every
-// ds_read_b128 lane group hit 16 distinct 16-B slots. The two half-waves of an MFMA operand take K
-// offsets {0..15} and {16..31} of the tile (the MFMA k index is only a pairing between A and B, so any
-// bijection applied to both is legal) which turns the operand fetch into 4 x ds_read_b128 per row.
-// The next K tile is prefetched into registers while the current one is multiplied.
+// Design (gfx950). v_mfma_f32_32x32x2_f32 is an exact f32 fma chain at the f32 vector rate (157 TFLOP/s peak),
+// which is what the parity bar (encoder activations <= 1e-3, CIF fire indices equal to the fp32 CPU path) needs.
+//   * 128 x 128 x 32 block tile, 4 waves in a 2 x 2 grid, each wave owns 2 x 2 MFMA tiles of 32 x 32
+//     (64 accumulator registers); 64 MFMAs = 4096 matrix-pipe cycles per wave per K tile against
+//     16 ds_read_b128 and 8 LDS-DMA pieces, i.e. the kernel is matrix-pipe bound by construction.
+//   * Both operands are K-contiguous in HBM (torch Linear layout) and go HBM -> LDS directly with
+//     global_load_lds_dwordx4 (no staging registers), double buffered: the DMA of K tile t+1 is in flight while
+//     tile t is multiplied, one workgroup barrier per K tile. 2 x 32 KB of LDS per workgroup -> two workgroups
+//     (2 waves per SIMD) per CU, so one workgroup's barrier/epilogue is covered by the other's MFMAs.
+//   * LDS image: rows of 32 floats (128 B), 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7). The DMA
+//     writes lane-linear, so the permutation is applied to the per-lane SOURCE address (each row is still one
+//     full 128-B line) and again on the read; every 16-lane ds_read_b128 group then hits 16 distinct slots.
+//   * The two half-waves of an MFMA operand take K offsets {0..15} and {16..31} of the tile (the MFMA k index is
+//     only a pairing between A and B, so any bijection applied to both is legal): operand fetch = ds_read_b128.
+//   * XCD-aware block order: consecutive workgroup ids round-robin over the 8 XCDs, so XCD x gets the row
+//     panels x, x+8, ... and walks all column blocks of a panel back to back: the A panel is fetched from HBM
+//     once and re-read from that XCD's L2.
 #include "common.h"
 
 namespace pf {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDSS = 36;
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE_FLOATS = BM * BK;                 // one operand tile
+constexpr int BUF_FLOATS = 2 * TILE_FLOATS;          // A tile + B tile
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDSS];
-    float* As = smem;
-    float* Bs = smem + BM * LDSS;
+constexpr int MODE_ARGMAX = 4;   // MODE bit 0: + R1, bit 1: + R2; 4: fused arg-max instead of a C store
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int nM, int nN) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS];   // 64 KB, the only LDS object
+
+    // ---- XCD-aware tile order
+    const int L = blockIdx.x;
+    const int xcd = L & 7, j = L >> 3;
+    const int mblk = (j / nN) * 8 + xcd, nblk = j % nN;
+    if (mblk >= nM) return;
+    const int m0 = mblk * BM, n0 = nblk * BN;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int hh = lane >> 5, idx = lane & 31;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    const int lc4 = tid & 7, lr = tid >> 3;
-    const float* aptr[4];
-    const float* wptr[4];
+    // ---- LDS-DMA source addresses: wave w stages rows [32w, 32w+32) of both tiles, 4 pieces of 8 rows each;
+    //      lane l of a piece lands at row (l >> 3), physical chunk (l & 7)
+    const float* asrc[4];
+    const float* wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int row = m0 + lr + 32 * i;
+        const int r = wave * 32 + i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int row = m0 + r;
         row = row < p.M ? row : p.M - 1;
-        aptr[i] = p.A + (size_t)row * p.lda + lc4 * 4;
-        int col = n0 + lr + 32 * i;
+        asrc[i] = p.A + (size_t)row * p.lda + c * 4;
+        int col = n0 + r;
         col = col < p.N ? col : p.N - 1;
-        wptr[i] = p.W + (size_t)col * p.ldw + lc4 * 4;
+        wsrc[i] = p.W + (size_t)col * p.ldw + c * 4;
     }
+    const int nk = p.K / BK;
 
-    float4 ra[4], rb[4];
+    auto stage = [&](int buf, int kt) {
+        float* base = smem + buf * BUF_FLOATS + wave * 32 * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const float4*>(aptr[i]);
-        rb[i] = *reinterpret_cast<const float4*>(wptr[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<float4*>(&As[(lr + 32 * i) * LDSS + lc4 * 4]) = ra[i];
-        *reinterpret_cast<float4*>(&Bs[(lr + 32 * i) * LDSS + lc4 * 4]) = rb[i];
-    }
-    __syncthreads();
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt * BK), (lds_ptr_t)(base + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt * BK), (lds_ptr_t)(base + TILE_FLOATS + i * 8 * BK),
+                                             16, 0, 0);
+        }
+    };
 
     floatx16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    const float* ap = &As[(wr * 64 + idx) * LDSS + hh * 16];
-    const float* bp = &Bs[(wc * 64 + idx) * LDSS + hh * 16];
-
-    for (int k0 = 0; k0 < p.K; k0 += BK) {
-        const bool has_next = (k0 + BK) < p.K;
-        if (has_next) {
+    // per-lane read offsets (floats): row * 32 + physical chunk * 4
+    const int f = (idx >> 1) & 7;
+    int coff[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const float4*>(aptr[i] + k0 + BK);
-                rb[i] = *reinterpret_cast<const float4*>(wptr[i] + k0 + BK);
-            }
-        }
+    for (int s4 = 0; s4 < 4; ++s4) coff[s4] = ((hh * 4 + s4) ^ f) * 4;
+    const int arow = (wr * 64 + idx) * BK;
+    const int brow = TILE_FLOATS + (wc * 64 + idx) * BK;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                       // tile kt landed for every wave; buffer (kt+1)&1 is free again
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const float* sb = smem + (kt & 1) * BUF_FLOATS;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const float4 a0 = *reinterpret_cast<const float4*>(ap + s4 * 4);
-            const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDSS + s4 * 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(bp + s4 * 4);
-            const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDSS + s4 * 4);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
-            const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
-            const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        if (has_next) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<float4*>(&As[(lr + 32 * i) * LDSS + lc4 * 4]) = ra[i];
-                *reinterpret_cast<float4*>(&Bs[(lr + 32 * i) * LDSS + lc4 * 4]) = rb[i];
-            }
-            __syncthreads();
+            const float4 a0 = *reinterpret_cast<const float4*>(sb + arow + coff[s4]);
+            const float4 a1 = *reinterpret_cast<const float4*>(sb + arow + 32 * BK + coff[s4]);
+            const float4 b0 = *reinterpret_cast<const float4*>(sb + brow + coff[s4]);
+            const float4 b1 = *reinterpret_cast<const float4*>(sb + brow + 32 * BK + coff[s4]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
         }
     }
 
     // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (p.amax_val == nullptr) {
+    if constexpr (MODE == MODE_ARGMAX) {
+        // fused row arg-max over this wave's 64 columns: one partial per (row, 2 * nblk + wc)
+        float bv[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + idx;
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.R1) v = v + p.R1[(size_t)row * p.ldr1 + col];
-                    if (p.R2) v = p.R2[(size_t)row * p.ldr2 + col] + v;
-                    p.C[(size_t)row * p.ldc + col] = v;
-                }
-            }
+        for (int jj = 0; jj < 2; ++jj) {
+            const int col = n0 + wc * 64 + jj * 32 + idx;
+            bv[jj] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
         }
-    } else {
-        // fused row arg-max over this wave's 64 columns: one partial per (row, 2 * blockIdx.x + wc)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -140,10 +144,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
                 float best = -INFINITY;
                 int besti = 0x7fffffff;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + wc * 64 + j * 32 + idx;
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int col = n0 + wc * 64 + jj * 32 + idx;
                     if (col < p.N) {
-                        float v = acc[i][j][r] + (p.bias ? p.bias[col] : 0.f);
+                        const float v = acc[i][jj][r] + bv[jj];
                         if (v > best) { best = v; besti = col; }
                     }
                 }
@@ -154,9 +158,82 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
                     if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
                 }
                 if (idx == 0 && row < p.M) {
-                    const size_t o = (size_t)row * p.amax_ld + 2 * blockIdx.x + wc;
+                    const size_t o = (size_t)row * p.amax_ld + 2 * nblk + wc;
                     p.amax_val[o] = best;
                     p.amax_idx[o] = besti;
+                }
+            }
+        }
+    } else {
+        constexpr bool HAS_R1 = (MODE & 1) != 0, HAS_R2 = (MODE & 2) != 0;
+        // The accumulator tile goes through a wave-private LDS slab (32 rows x 64 columns per pass, row stride 68
+        // floats) so that every global access of the epilogue is a float4 of a 256-B row segment: one
+        // instruction touches 4 rows x 256 B instead of 2 rows x 128 B, and bias / residual loads are issued
+        // in bulk instead of one dependent load per element.
+        constexpr int ELD = 68;
+        __syncthreads();                                       // every wave is done reading the operand tiles
+        float* slab = smem + wave * (32 * ELD);
+        const int c4 = lane & 15, rsub = lane >> 4;
+        const int col = n0 + wc * 64 + c4 * 4;
+        const bool vec_ok = p.vec_epilogue != 0;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            if (vec_ok && col + 3 < p.N) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+            else {
+                if (col + 0 < p.N) bias4.x = p.bias[col + 0];
+                if (col + 1 < p.N) bias4.y = p.bias[col + 1];
+                if (col + 2 < p.N) bias4.z = p.bias[col + 2];
+                if (col + 3 < p.N) bias4.w = p.bias[col + 3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[((r & 3) + 8 * (r >> 2) + 4 * hh) * ELD + jj * 32 + idx] = acc[i][jj][r];
+            // (same wave wrote and reads the slab: DS operations of one wave execute in order)
+            float4 v[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const float4*>(slab + (it * 4 + rsub) * ELD + c4 * 4);
+            const int row0 = m0 + wr * 64 + i * 32 + rsub;
+            if (vec_ok && col + 3 < p.N) {
+                float4 r1[8], r2[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = row0 + it * 4;
+                    const int rr = row < p.M ? row : p.M - 1;
+                    if constexpr (HAS_R1) r1[it] = *reinterpret_cast<const float4*>(p.R1 + (size_t)rr * p.ldr1 + col);
+                    if constexpr (HAS_R2) r2[it] = *reinterpret_cast<const float4*>(p.R2 + (size_t)rr * p.ldr2 + col);
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = row0 + it * 4;
+                    float4 o;
+                    o.x = v[it].x + bias4.x; o.y = v[it].y + bias4.y; o.z = v[it].z + bias4.z; o.w = v[it].w + bias4.w;
+                    if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    if constexpr (HAS_R1) { o.x = o.x + r1[it].x; o.y = o.y + r1[it].y; o.z = o.z + r1[it].z; o.w = o.w + r1[it].w; }
+                    if constexpr (HAS_R2) { o.x = r2[it].x + o.x; o.y = r2[it].y + o.y; o.z = r2[it].z + o.z; o.w = r2[it].w + o.w; }
+                    if (row < p.M) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = o;
+                }
+            } else {
+                // ragged right edge / unaligned leading dimensions: element-wise
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = row0 + it * 4;
+                    if (row >= p.M) continue;
+                    const float vv[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+                    const float bb[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e >= p.N) continue;
+                        float o = vv[e] + bb[e];
+                        if (p.relu) o = fmaxf(o, 0.f);
+                        if constexpr (HAS_R1) o = o + p.R1[(size_t)row * p.ldr1 + col + e];
+                        if constexpr (HAS_R2) o = p.R2[(size_t)row * p.ldr2 + col + e] + o;
+                        p.C[(size_t)row * p.ldc + col + e] = o;
+                    }
                 }
             }
         }
@@ -170,9 +247,28 @@ int launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.K % BK == 0, "gemm: K must be a multiple of 32 (pad the operand)");
     PF_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm: row strides must be multiples of 4 floats");
     PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
-    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM));
-    if (a.amax_val) PF_REQUIRE(a.amax_ld >= 2 * (int)grid.x, "gemm: amax_ld too small");
-    hipLaunchKernelGGL(gemm_f32_mfma_kernel, grid, dim3(256), 0, stream, a);
+    const int nM = ceil_div(a.M, BM), nN = ceil_div(a.N, BN);
+    if (a.amax_val) PF_REQUIRE(a.amax_ld >= 2 * nN, "gemm: amax_ld too small");
+    const int nMpad = (nM + 7) / 8 * 8;
+    GemmArgs g = a;
+    g.vec_epilogue = 0;
+    if (!a.amax_val) {
+        PF_REQUIRE(a.C != nullptr, "gemm: null output");
+        bool ok = a.N % 4 == 0 && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0;
+        if (a.bias) ok = ok && ((uintptr_t)a.bias & 15) == 0;
+        if (a.R1) ok = ok && a.ldr1 % 4 == 0 && ((uintptr_t)a.R1 & 15) == 0;
+        if (a.R2) ok = ok && a.ldr2 % 4 == 0 && ((uintptr_t)a.R2 & 15) == 0;
+        g.vec_epilogue = ok ? 1 : 0;
+    }
+    const dim3 grid((unsigned)nMpad * nN), block(256);
+    const int mode = a.amax_val ? MODE_ARGMAX : ((a.R1 ? 1 : 0) | (a.R2 ? 2 : 0));
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(gemm_f32_mfma_kernel<0>, grid, block, 0, stream, g, nM, nN); break;
+        case 1: hipLaunchKernelGGL(gemm_f32_mfma_kernel<1>, grid, block, 0, stream, g, nM, nN); break;
+        case 2: hipLaunchKernelGGL(gemm_f32_mfma_kernel<2>, grid, block, 0, stream, g, nM, nN); break;
+        case 3: hipLaunchKernelGGL(gemm_f32_mfma_kernel<3>, grid, block, 0, stream, g, nM, nN); break;
+        default: hipLaunchKernelGGL(gemm_f32_mfma_kernel<MODE_ARGMAX>, grid, block, 0, stream, g, nM, nN); break;
+    }
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

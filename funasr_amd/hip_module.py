@@ -110,15 +110,19 @@ class HipModule(nn.Module):
         self._dirty = True
 
     def _free(self):
-        if self._handle is not None:
+        h = self.__dict__.get("_handle")
+        if h is not None:
             try:
-                getattr(_lib.load(), self._prefix + "_destroy")(self._handle)
+                getattr(_lib.load(), self._prefix + "_destroy")(h)
             except Exception:
                 pass
-            self._handle = None
+            self.__dict__["_handle"] = None      # not nn.Module.__setattr__: it is unusable at interpreter exit
 
     def __del__(self):
-        self._free()
+        try:
+            self._free()
+        except Exception:
+            pass
 
     # -- keep the device copy coherent with nn.Module mutations ------------------------------------------------------
     def _apply(self, fn, *args, **kwargs):

@@ -113,15 +113,19 @@ class WavFrontend(nn.Module):
         return lib, h
 
     def close(self):
-        if self._handle is not None:
+        h = self.__dict__.get("_handle")
+        if h is not None:
             try:
-                _lib.load().pf_frontend_destroy(self._handle)
+                _lib.load().pf_frontend_destroy(h)
             except Exception:
                 pass
-            self._handle = None
+            self.__dict__["_handle"] = None      # not nn.Module.__setattr__: it is unusable at interpreter exit
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _target_device(self, x: torch.Tensor) -> torch.device:
         if x.is_cuda:

@@ -18,9 +18,9 @@ def find(root, pattern):
 
 
 def short(name):
-    name = name.split("(")[0]
-    for pre in ("void ", "pf::(anonymous namespace)::", "pf::"):
+    for pre in ("void ", "pf::(anonymous namespace)::", "(anonymous namespace)::"):
         name = name.replace(pre, "")
+    name = name.split("(")[0].replace("pf::", "")
     return name[:70]
 
 
