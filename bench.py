@@ -67,19 +67,9 @@ def build_model(cfg, rank, world, device):
         model.load_state_dict(sd, strict=False)
     model = model.to(device)
     if world > 1:
-        params = [p for _, p in model.named_parameters()]
-        arena = torch.cat([p.detach().reshape(-1) for p in params])          # ~880 MB fp32
-        dist.broadcast(arena, src=0)
-        off = 0
-        with torch.no_grad():
-            for p in params:
-                n = p.numel()
-                p.copy_(arena[off:off + n].view_as(p))
-                off += n
-        del arena
-        for m in model.modules():
-            if hasattr(m, "mark_dirty"):
-                m.mark_dirty()
+        from funasr_amd import dp
+        nbytes = dp.broadcast_model(model, src=0)          # ONE packed fp32 arena over RCCL (~880 MB)
+        trace(f"rank {rank}: weight arena broadcast, {nbytes / 1e6:.0f} MB")
     return model, names
 
 
@@ -97,7 +87,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)        # backend "nccl" is RCCL on ROCm
 
-    from funasr_amd import _lib, synth
+    from funasr_amd import _lib, dp, synth
     from funasr_amd.wav_frontend import WavFrontend
 
     lib = _lib.load()
@@ -120,13 +110,8 @@ def main():
     def step():
         feats, flens = frontend(wav, lens)
         res = model.recognize_features(feats, flens)
-        if world > 1:      # gather hypotheses on rank 0 (fixed-stride int32 ids + lengths), the path's only exchange
-            ids = torch.full((B, N_PAD), -1, dtype=torch.int32)
-            for b, r in enumerate(res["raw_ids"]):
-                ids[b, : len(r)] = torch.tensor(r[:N_PAD], dtype=torch.int32)
-            ids = ids.to(device)
-            out = [torch.empty_like(ids) for _ in range(world)] if rank == 0 else None
-            dist.gather(ids, out, dst=0)
+        if world > 1:      # gather hypotheses on rank 0 (fixed-stride int32 ids + counts), the path's only exchange
+            dp.gather_hypotheses(res["raw_ids"], N_PAD, dst=0, device=device)
         return res
 
     def sync():

@@ -1,0 +1,302 @@
+"""`AutoModel` for environments where the `funasr` package itself cannot be imported (it needs omegaconf, hydra,
+torchaudio, kaldiio, ... -- none of them present in the build image).
+
+Mirrors the dispatch half of funasr/auto/auto_model.py that sits on the hot path:
+  * `build_model` (:522-675): local model directory -> `config.yaml` (merged with the constructor kwargs, kwargs win)
+    -> tokenizer / frontend / model looked up BY NAME in the registry (:591-646) -> `model.pt` loaded with the
+    reference's state-dict conventions (funasr/train_utils/load_pretrained_model.py:39-104: `state_dict` /
+    `model_state_dict` / `model` wrappers stripped, `module.` prefixes dropped, strict load) -> `.to(device)`, `.eval()`;
+  * `generate` / `inference` (:689-850): `prepare_data_iterator` (:347-415; wav path, wav.scp / jsonl file lists,
+    lists of paths / arrays / tensors, raw PCM bytes), the batch loop calling
+    `model.inference(data_in=..., key=..., tokenizer=..., frontend=..., **kwargs)` under `torch.no_grad()` (:812-814),
+    RTF bookkeeping from `meta_data["batch_data_time"]` (:823-833).
+Model directory format (funasr/download/download_model_from_hub.py:80-97): `config.yaml`, `model.pt`, `tokens.json`,
+`am.mvn`. No hub download (no network): `model` must be a local directory.
+VAD / punctuation / speaker pipelines (`inference_with_vad`, :852-1254) are outside the hot path and raise.
+
+When the real package is importable, use `funasr.AutoModel` itself after `funasr_amd.install()`.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import logging
+import os
+import random
+import string
+import time
+from typing import Any, Dict, List, Tuple
+
+import torch
+
+from . import paraformer as _paraformer  # noqa: F401  (registers the model classes)
+from . import sense_voice as _sense_voice  # noqa: F401
+from .register import tables
+
+
+def deep_update(dst: dict, src: dict) -> dict:
+    """funasr/utils/misc.py deep_update: recursive dict merge, `src` wins."""
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            deep_update(dst[k], v)
+        else:
+            dst[k] = v
+    return dst
+
+
+def _rand_key() -> str:
+    chars = string.ascii_letters + string.digits
+    return "rand_key_" + "".join(random.choice(chars) for _ in range(13))
+
+
+def prepare_data_iterator(data_in, input_len=None, data_type=None, key=None) -> Tuple[List[str], List[Any]]:
+    """funasr/auto/auto_model.py:347-415 for sound inputs."""
+    filelist = (".scp", ".txt", ".json", ".jsonl", ".text")
+    key_list: List[str] = []
+    data_list: List[Any] = []
+    if isinstance(data_in, str) and (data_in.startswith("http://") or data_in.startswith("https://")):
+        raise NotImplementedError("URL inputs need a network; pass a local path")
+    if isinstance(data_in, str) and os.path.exists(data_in):
+        ext = os.path.splitext(data_in)[1].lower()
+        if ext in filelist:
+            with open(data_in, encoding="utf-8") as fin:
+                for line in fin:
+                    if not line.strip():
+                        continue
+                    k = _rand_key()
+                    if data_in.endswith(".jsonl"):
+                        obj = json.loads(line.strip())
+                        data, k = obj["source"], obj.get("key", k)
+                    else:
+                        parts = line.strip().split(maxsplit=1)
+                        data = parts[1] if len(parts) > 1 else parts[0]
+                        k = parts[0] if len(parts) > 1 else k
+                    data_list.append(data)
+                    key_list.append(k)
+        else:
+            k = key if key is not None else os.path.splitext(os.path.basename(data_in))[0]
+            data_list, key_list = [data_in], [k]
+    elif isinstance(data_in, str):
+        raise FileNotFoundError(f"Audio file not found: {data_in!r}. Pass a valid local file path, numpy array, "
+                                f"torch.Tensor, or bytes.")
+    elif isinstance(data_in, (list, tuple)):
+        data_list = list(data_in)
+        for d in data_in:
+            if isinstance(d, str) and os.path.exists(d):
+                key_list.append(os.path.splitext(os.path.basename(d))[0])
+            else:
+                key_list.append(key if isinstance(key, str) else _rand_key())
+    else:
+        data_list = [data_in]
+        key_list = [key if key is not None else _rand_key()]
+    return key_list, data_list
+
+
+def _load_yaml(path: str) -> dict:
+    import yaml
+
+    with open(path, "r", encoding="utf-8") as f:
+        return yaml.safe_load(f) or {}
+
+
+def load_model_dir(model_dir: str) -> dict:
+    """config.yaml + the file conventions of download_model_from_hub.py:80-97."""
+    cfg_path = os.path.join(model_dir, "config.yaml")
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError(f"{model_dir}: no config.yaml (expected a FunASR model directory)")
+    kwargs = _load_yaml(cfg_path)
+    conf_json = os.path.join(model_dir, "configuration.json")
+    metas = {}
+    if os.path.exists(conf_json):
+        with open(conf_json, "r", encoding="utf-8") as f:
+            metas = (json.load(f) or {}).get("file_path_metas", {}) or {}
+
+    def resolve(meta_key: str, default_name: str):
+        name = metas.get(meta_key, default_name)
+        if isinstance(name, dict):
+            return None
+        p = os.path.join(model_dir, name)
+        return p if os.path.exists(p) else None
+
+    init_param = resolve("init_param", "model.pt")
+    if init_param:
+        kwargs["init_param"] = init_param
+    tokens = resolve("tokenizer_conf.token_list", "tokens.json") if "tokenizer_conf" not in metas else None
+    tokens = tokens or (os.path.join(model_dir, "tokens.json") if os.path.exists(os.path.join(model_dir, "tokens.json")) else None)
+    if tokens:
+        kwargs.setdefault("tokenizer_conf", {})
+        kwargs["tokenizer_conf"] = dict(kwargs["tokenizer_conf"] or {}, token_list=tokens)
+    mvn = os.path.join(model_dir, "am.mvn")
+    if os.path.exists(mvn):
+        kwargs.setdefault("frontend_conf", {})
+        kwargs["frontend_conf"] = dict(kwargs["frontend_conf"] or {}, cmvn_file=mvn)
+    bpe = os.path.join(model_dir, "chn_jpn_yue_eng_ko_spectok.bpe.model")
+    if os.path.exists(bpe):
+        kwargs.setdefault("tokenizer_conf", {})
+        kwargs["tokenizer_conf"] = dict(kwargs["tokenizer_conf"] or {}, bpemodel=bpe)
+    kwargs["model_path"] = model_dir
+    return kwargs
+
+
+def load_pretrained_model(path: str, model: torch.nn.Module, ignore_init_mismatch: bool = True, **kwargs) -> None:
+    """funasr/train_utils/load_pretrained_model.py:14-114 without scope maps: wrapper keys stripped (:45-47), `module.`
+    prefix dropped, shape-mismatched tensors skipped with a log line (:94-97), then a strict load (:104)."""
+    src = torch.load(path, map_location="cpu", weights_only=False)
+    for k in ("state_dict", "model_state_dict", "model"):
+        if isinstance(src, dict) and k in src and isinstance(src[k], dict):
+            src = src[k]
+    dst = model.state_dict()
+    out = {}
+    for k, v in dst.items():
+        cand = k
+        if cand not in src and ("module." + cand) in src:
+            cand = "module." + cand
+        if cand in src:
+            if ignore_init_mismatch and tuple(src[cand].shape) != tuple(v.shape):
+                logging.info("ignore_init_mismatch: %s %s vs %s", k, tuple(src[cand].shape), tuple(v.shape))
+                out[k] = v
+            else:
+                out[k] = src[cand]
+        else:
+            logging.warning("Miss key in ckpt: model: %s", k)
+            out[k] = v
+    model.load_state_dict(out, strict=True)
+
+
+class AutoModel:
+    def __init__(self, **kwargs):
+        for k in ("vad_model", "punc_model", "spk_model"):
+            if kwargs.get(k) is not None:
+                raise NotImplementedError(f"{k}: VAD / punctuation / speaker pipelines are outside the HIP hot path")
+        log_level = getattr(logging, str(kwargs.get("log_level", "WARNING")).upper(), logging.WARNING)
+        logging.getLogger().setLevel(log_level)
+        model, kwargs = self.build_model(**kwargs)
+        self.kwargs = kwargs
+        self.model = model
+        self.model_path = kwargs.get("model_path")
+        self._base_kwargs = copy.deepcopy({k: v for k, v in kwargs.items() if k not in ("tokenizer", "frontend")})
+
+    # --------------------------------------------------------------------------------------------- build_model
+    @staticmethod
+    def build_model(**kwargs) -> Tuple[torch.nn.Module, Dict[str, Any]]:
+        model_arg = kwargs.get("model")
+        if isinstance(model_arg, str) and os.path.isdir(model_arg):
+            file_kwargs = load_model_dir(model_arg)
+            user = {k: v for k, v in kwargs.items() if k != "model"}
+            kwargs = deep_update(file_kwargs, user)                       # constructor kwargs win (:728,782)
+        elif isinstance(model_arg, str) and model_arg not in tables.model_classes:
+            raise FileNotFoundError(f"model={model_arg!r}: not a local model directory and not a registered model "
+                                    f"class; hub download is not available (no network)")
+        torch.manual_seed(kwargs.get("seed", 0))
+        device = kwargs.get("device", "cuda")
+        if str(device).startswith("cuda") and not torch.cuda.is_available():
+            # the reference silently falls back to cpu + batch_size 1 (:551-561); there is no CPU implementation of
+            # this path, so keep the plumbing working and let inference() raise a clear error instead
+            logging.warning("no GPU visible: the model is built on cpu, inference needs an AMD GPU")
+            device = "cpu"
+        kwargs["device"] = device
+        if device == "cpu":
+            kwargs["batch_size"] = 1
+        # tokenizer (:591-601)
+        tokenizer = kwargs.get("tokenizer")
+        vocab_size = -1
+        if isinstance(tokenizer, str):
+            tok_cls = tables.tokenizer_classes.get(tokenizer)
+            if tok_cls is None:
+                raise KeyError(f"tokenizer {tokenizer!r} is not registered: {sorted(tables.tokenizer_classes)}")
+            tokenizer = tok_cls(**(kwargs.get("tokenizer_conf") or {}))
+            kwargs["token_list"] = getattr(tokenizer, "token_list", None)
+            vocab_size = len(kwargs["token_list"]) if kwargs["token_list"] is not None else -1
+            if vocab_size == -1 and hasattr(tokenizer, "get_vocab_size"):
+                vocab_size = tokenizer.get_vocab_size()
+        kwargs["tokenizer"] = tokenizer
+        # frontend (:626-634)
+        frontend = kwargs.get("frontend")
+        kwargs["input_size"] = kwargs.get("input_size")
+        if isinstance(frontend, str):
+            fe_cls = tables.frontend_classes.get(frontend)
+            if fe_cls is None:
+                raise KeyError(f"frontend {frontend!r} is not registered: {sorted(tables.frontend_classes)}")
+            fconf = dict(kwargs.get("frontend_conf") or {})
+            if float(fconf.get("dither", 0.0) or 0.0) != 0.0:
+                logging.warning("frontend_conf.dither=%s overridden to 0.0 (deterministic HIP frontend)", fconf["dither"])
+            fconf["dither"] = 0.0
+            frontend = fe_cls(device=None if device == "cpu" else device, **fconf)
+            kwargs["input_size"] = frontend.output_size()
+        kwargs["frontend"] = frontend
+        # model (:636-646)
+        name = kwargs.get("model")
+        model_class = tables.model_classes.get(name)
+        if model_class is None:
+            raise KeyError(f"model class {name!r} is not registered in model_classes: {sorted(tables.model_classes)}")
+        model_conf = dict(kwargs.get("model_conf") or {})
+        build_kwargs = {k: v for k, v in kwargs.items() if k not in ("model", "model_conf", "tokenizer", "frontend")}
+        deep_update(build_kwargs, model_conf)
+        if vocab_size > 0 or "vocab_size" not in build_kwargs:
+            build_kwargs["vocab_size"] = vocab_size
+        model = model_class(**build_kwargs)
+        init_param = kwargs.get("init_param")
+        if init_param is not None and os.path.exists(init_param):
+            load_pretrained_model(init_param, model, ignore_init_mismatch=kwargs.get("ignore_init_mismatch", True))
+        elif init_param is not None:
+            logging.warning("init_param %s does not exist: model keeps its initial weights", init_param)
+        if kwargs.get("fp16", False) or kwargs.get("bf16", False):
+            raise NotImplementedError("fp16/bf16 storage of the parameters is not built: the HIP path computes in fp32")
+        model.to(device)
+        model.eval()
+        return model, kwargs
+
+    # ------------------------------------------------------------------------------------------------- generate
+    def generate(self, input, input_len=None, progress_callback=None, **cfg):
+        return self.inference(input, input_len=input_len, progress_callback=progress_callback, **cfg)
+
+    def inference(self, input, input_len=None, model=None, kwargs=None, key=None, progress_callback=None, **cfg):
+        if kwargs is None:                                                   # _reset_runtime_configs (:1318-1359)
+            keep = {k: self.kwargs[k] for k in ("tokenizer", "frontend") if k in self.kwargs}
+            self.kwargs = dict(copy.deepcopy(self._base_kwargs), **keep)
+            kwargs = self.kwargs
+        kwargs.pop("cache", None)
+        deep_update(kwargs, cfg)
+        model = self.model if model is None else model
+        batch_size = int(kwargs.get("batch_size", 1))
+        key_list, data_list = prepare_data_iterator(input, input_len=input_len, data_type=kwargs.get("data_type"), key=key)
+        results_all: List[dict] = []
+        speed_stats: Dict[str, Any] = {}
+        time_speech_total, time_escape_total = 0.0, 0.0
+        call_kwargs = {k: v for k, v in kwargs.items() if k not in ("model", "key", "data_in")}
+        n = len(data_list)
+        for beg in range(0, n, batch_size):
+            end = min(n, beg + batch_size)
+            batch = {"data_in": data_list[beg:end], "key": key_list[beg:end]}
+            if end - beg == 1 and kwargs.get("data_type") == "fbank":
+                batch["data_in"] = data_list[beg]
+                batch["data_lengths"] = input_len
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                res = model.inference(**batch, **call_kwargs)
+            results, meta = (res[0] if len(res) > 0 else [{"text": ""}]), (res[1] if len(res) > 1 else {})
+            dt = time.perf_counter() - t1
+            results_all.extend(results)
+            batch_data_time = meta.get("batch_data_time", -1)
+            speed_stats.update(load_data=meta.get("load_data", 0.0), extract_feat=meta.get("extract_feat", 0.0),
+                               forward=f"{dt:0.3f}", batch_size=f"{len(results)}",
+                               rtf=f"{dt / batch_data_time:0.3f}" if batch_data_time else "nan")
+            if progress_callback:
+                try:
+                    progress_callback(end, n)
+                except Exception as e:  # noqa: BLE001 - same tolerance as the reference (:835-839)
+                    logging.error("progress_callback error: %s", e)
+            time_speech_total += batch_data_time
+            time_escape_total += dt
+        self.speed_stats = dict(speed_stats, rtf_avg=(time_escape_total / time_speech_total) if time_speech_total else None)
+        try:
+            device = next(model.parameters()).device
+            if device.type == "cuda":
+                with torch.cuda.device(device):
+                    torch.cuda.empty_cache()                                   # :846-849
+        except StopIteration:
+            pass
+        return results_all
+
+    def inference_with_vad(self, *a, **k):
+        raise NotImplementedError("inference_with_vad (VAD segmentation pipeline) is outside the HIP hot path")

@@ -1,0 +1,104 @@
+"""Utterance-level data parallelism over the GPUs of one node: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The path shards over independent clips with NO data-path collective (the reference forks one process
+per GPU over a split wav.scp and concatenates the outputs, examples/aishell/paraformer/run.sh:135-190). The only
+exchanges are
+  * start-up: ONE broadcast of a packed fp32 weight arena (880 MB for Paraformer-large) instead of ~950 small ones
+    (xGMI is point-to-point: few large messages, not many small ones), and
+  * per batch: a gather of fixed-stride int32 hypotheses [B, n_pad] (+ lengths) on rank 0 -- KBs, latency-bound.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:
+    """Length-sorted round-robin deal (like the length sort of auto_model.py:917-918): rank r gets the clips at
+    positions r, r+world, ... of the descending-length order, so every rank sees the same length mix."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    return order[rank::world]
+
+
+def pack_arena(params: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Flatten parameters into one contiguous fp32 arena (same device as the first parameter)."""
+    return torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
+
+
+def unpack_arena(arena: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(arena[off:off + n].view_as(p))
+            off += n
+    if off != arena.numel():
+        raise ValueError(f"arena holds {arena.numel()} elements, parameters need {off}")
+
+
+def broadcast_model(model: torch.nn.Module, src: int = 0) -> int:
+    """Ship rank `src`'s weights to every rank as ONE packed arena; returns the arena size in bytes. Handles created
+    from the parameters (HipModule) are marked dirty so the device copy is refreshed before the next forward."""
+    params = [p for _, p in model.named_parameters()]
+    if not params:
+        return 0
+    arena = pack_arena(params)
+    dist.broadcast(arena, src=src)
+    unpack_arena(arena, params)
+    for m in model.modules():
+        if hasattr(m, "mark_dirty"):
+            m.mark_dirty()
+    return arena.numel() * 4
+
+
+def pack_hypotheses(ids: Sequence[Sequence[int]], n_pad: int, device=None) -> torch.Tensor:
+    """[B, 1 + n_pad] int32: column 0 = token count, then the ids, -1 padded (fixed stride so one gather suffices)."""
+    out = torch.full((len(ids), 1 + n_pad), -1, dtype=torch.int32)
+    for b, r in enumerate(ids):
+        r = list(r)[:n_pad]
+        out[b, 0] = len(r)
+        if r:
+            out[b, 1:1 + len(r)] = torch.tensor(r, dtype=torch.int32)
+    return out if device is None else out.to(device)
+
+
+def unpack_hypotheses(t: torch.Tensor) -> List[List[int]]:
+    t = t.cpu()
+    return [t[b, 1:1 + int(t[b, 0])].tolist() for b in range(t.shape[0])]
+
+
+def gather_hypotheses(ids: Sequence[Sequence[int]], n_pad: int, dst: int = 0, device=None):
+    """Every rank contributes the same number of clips B. Returns on `dst` a list (one entry per rank) of per-clip id
+    lists, elsewhere None."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = pack_hypotheses(ids, n_pad, device)
+    bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [unpack_hypotheses(b) for b in bufs]
+
+
+def recognize_sharded(decode: Callable[[List[int]], List[List[int]]], lengths: Sequence[int], n_pad: int = 512,
+                      dst: int = 0, device=None):
+    """Decode a corpus of len(lengths) clips across all ranks. `decode(indices)` returns the token ids of the clips
+    `indices` (this rank's shard, in that order). Shards are padded to equal size with repeats of their last clip so
+    the gather is fixed-stride. Returns on `dst` the hypotheses in corpus order, elsewhere None."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    shards = [shard_indices(lengths, world, r) for r in range(world)]
+    width = max(len(s) for s in shards)
+    mine = shards[rank]
+    hyps = decode(list(mine)) if mine else []
+    while len(hyps) < width:                      # pad with an empty hypothesis
+        hyps = list(hyps) + [[]]
+    gathered = gather_hypotheses(hyps, n_pad, dst=dst, device=device)
+    if gathered is None:
+        return None
+    out: List[List[int]] = [[] for _ in range(len(lengths))]
+    for r, shard in enumerate(shards):
+        for k, i in enumerate(shard):
+            out[i] = gathered[r][k]
+    return out

@@ -1,0 +1,70 @@
+"""Builds a FunASR-format model directory (config.yaml, model.pt, tokens.json, am.mvn) around a tiny synthetic
+Paraformer so that the AutoModel plumbing can be exercised without the hub."""
+import json
+import os
+import shutil
+import wave
+
+import numpy as np
+import torch
+import yaml
+
+from funasr_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VOCAB = ["<blank>", "<s>", "</s>"] + list("的一是了我不人在他有这个上们来到时大地为子中你说生国年着就那和要她出也得里后自以会") + \
+        ["hello", "wor@@", "ld", "a", "b", "<unk>"]
+
+
+def tiny_cfg():
+    return synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2, dec_blocks=2, vocab=len(VOCAB))
+
+
+def make_model_dir(path: str, seed: int = 21) -> dict:
+    os.makedirs(path, exist_ok=True)
+    cfg = tiny_cfg()
+    ec, dc, pc = cfg["encoder"], cfg["decoder"], cfg["predictor"]
+    conf = {
+        "model": "Paraformer",
+        "model_conf": {"ctc_weight": 0.0, "lsm_weight": 0.1, "length_normalized_loss": True, "predictor_weight": 1.0,
+                       "predictor_bias": 1, "sampling_ratio": 0.75},
+        "encoder": "SANMEncoder",
+        "encoder_conf": {"output_size": ec["output_size"], "attention_heads": ec["attention_heads"],
+                         "linear_units": ec["linear_units"], "num_blocks": ec["num_blocks"], "dropout_rate": 0.1,
+                         "positional_dropout_rate": 0.1, "attention_dropout_rate": 0.1, "input_layer": "pe",
+                         "pos_enc_class": "SinusoidalPositionEncoder", "normalize_before": True,
+                         "kernel_size": ec["kernel_size"], "sanm_shfit": ec["sanm_shfit"],
+                         "selfattention_layer_type": "sanm"},
+        "decoder": "ParaformerSANMDecoder",
+        "decoder_conf": {"attention_heads": dc["attention_heads"], "linear_units": dc["linear_units"],
+                         "num_blocks": dc["num_blocks"], "dropout_rate": 0.1, "positional_dropout_rate": 0.1,
+                         "self_attention_dropout_rate": 0.1, "src_attention_dropout_rate": 0.1,
+                         "att_layer_num": dc["att_layer_num"], "kernel_size": dc["kernel_size"],
+                         "sanm_shfit": dc["sanm_shfit"]},
+        "predictor": "CifPredictorV2",
+        "predictor_conf": {"idim": pc["idim"], "threshold": 1.0, "l_order": 1, "r_order": 1, "tail_threshold": 0.45},
+        "frontend": "WavFrontend",
+        "frontend_conf": {"fs": 16000, "window": "hamming", "n_mels": 80, "frame_length": 25, "frame_shift": 10,
+                          "lfr_m": 7, "lfr_n": 6},
+        "tokenizer": "CharTokenizer",
+        "tokenizer_conf": {"unk_symbol": "<unk>", "split_with_space": True},
+    }
+    with open(os.path.join(path, "config.yaml"), "w", encoding="utf-8") as f:
+        yaml.safe_dump(conf, f, allow_unicode=True)
+    sd = synth.paraformer_state_dict(cfg, seed=seed, cif_bias=0.3)
+    sd["decoder.embed.0.weight"] = torch.zeros(len(VOCAB), dc["encoder_output_size"])
+    torch.save({"state_dict": sd}, os.path.join(path, "model.pt"))          # wrapped like a training checkpoint
+    with open(os.path.join(path, "tokens.json"), "w", encoding="utf-8") as f:
+        json.dump(VOCAB, f, ensure_ascii=False)
+    shutil.copy(os.path.join(HERE, "golden", "am.mvn"), os.path.join(path, "am.mvn"))
+    return dict(cfg=cfg, sd=sd)
+
+
+def write_wav(path: str, x: torch.Tensor, fs: int = 16000) -> np.ndarray:
+    pcm = (x.clamp(-1, 1) * 32767.0).round().to(torch.int16).numpy()
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(fs)
+        f.writeframes(pcm.tobytes())
+    return pcm

@@ -1,0 +1,91 @@
+"""Utterance-level data parallelism (funasr_amd/dp.py) at world_size 2 on the gloo backend: sharding covers the corpus
+exactly once, the packed-arena weight broadcast reproduces rank 0's parameters bit for bit, and the fixed-stride
+hypothesis gather returns every clip's ids in corpus order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from funasr_amd import dp
+
+
+def test_shard_indices_partition_and_balance():
+    lengths = [480000, 16000, 32000, 8000, 90000, 90000, 1234, 77777, 5, 31000, 64000]
+    for world in (1, 2, 3, 8):
+        shards = [dp.shard_indices(lengths, world, r) for r in range(world)]
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(len(lengths)))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+        # descending-length deal: the r-th longest clip goes to rank r
+        order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+        for r in range(min(world, len(lengths))):
+            assert shards[r][0] == order[r]
+
+
+def test_pack_unpack_hypotheses_roundtrip():
+    ids = [[5, 6, 7], [], [1] * 40, [8403]]
+    t = dp.pack_hypotheses(ids, n_pad=32)
+    assert t.shape == (4, 33) and t.dtype == torch.int32
+    back = dp.unpack_hypotheses(t)
+    assert back == [[5, 6, 7], [], [1] * 32, [8403]]          # truncated to n_pad like bench.py
+
+
+def _fake_decode_factory(lengths):
+    def decode(indices):
+        return [[(i * 7 + k) % 8404 for k in range(lengths[i] % 13)] for i in indices]
+    return decode
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                          # different weights per rank before the broadcast
+        model = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.LayerNorm(19), torch.nn.Linear(19, 5, bias=False))
+        ref = None
+        if rank == 0:
+            ref = [p.detach().clone() for p in model.parameters()]
+        nbytes = dp.broadcast_model(model, src=0)
+        assert nbytes == 4 * sum(p.numel() for p in model.parameters())
+        flat = dp.pack_arena(list(model.parameters()))
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert all(torch.equal(both[0], b) for b in both), "weights differ across ranks after the arena broadcast"
+        if rank == 0:
+            assert all(torch.equal(a, b) for a, b in zip(ref, model.parameters()))
+        lengths = [480000, 16000, 32000, 8000, 90000, 90000, 1234, 77777, 401, 31000, 64000]
+        hyps = dp.recognize_sharded(_fake_decode_factory(lengths), lengths, n_pad=16, dst=0)
+        if rank == 0:
+            expect = _fake_decode_factory(lengths)(list(range(len(lengths))))
+            assert hyps == expect
+        else:
+            assert hyps is None
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, f"fail: {e!r}"))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world_size_2_gloo_broadcast_shard_gather():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res == [(0, "ok"), (1, "ok")], res
+    assert all(p.exitcode == 0 for p in procs)
