@@ -53,6 +53,11 @@ class pf_decoder_config(C.Structure):
     ]
 
 
+class pf_stream_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_streams", "chunk_left", "chunk_cur", "chunk_right", "enc_look_back",
+                                          "dec_look_back", "max_frames", "max_tokens", "use_graph")]
+
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _pi32 = C.POINTER(C.c_int32)
 
@@ -89,6 +94,14 @@ SIGNATURES = {
     "pf_ctc_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "pf_ctc_missing": (C.c_int, [_vp]),
     "pf_ctc_greedy": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "pf_stream_create": (_vp, [_vp, _vp, _vp, C.POINTER(pf_stream_config)]),
+    "pf_stream_destroy": (None, [_vp]),
+    "pf_stream_set_pe": (C.c_int, [_vp, _vp, _i32]),
+    "pf_stream_reset": (C.c_int, [_vp, _vp]),
+    "pf_stream_step": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pi32, _pi32, _vp, _vp]),
+    "pf_stream_peek": (C.c_int, [_vp, _vp, _vp, _pi32]),
+    "pf_frontend_fbank": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "pf_frontend_lfr_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "pf_k_gemm_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pf_k_gemm_argmax_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_layernorm": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),

@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs p) {
     const int b = blockIdx.z, head = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + idx;
     const int qc = q < p.Tq ? q : p.Tq - 1;
-    const int klen = p.klens[b];
+    // keys: [0, n1) from source 1 (K, V; rows b*Tk + t), then n2 keys from the optional source 2 (K2, V2; rows
+    // b*T2 + t) -- the streaming step attends over [cached K/V ring | this chunk's K/V] without staging them
+    // into one buffer (funasr/models/sanm/attention.py:343-347 `torch.cat((cache["k"], k_h))`)
+    const int n1 = p.K2 ? p.n1_dev[b * p.n1_stride] : p.klens[b];
+    const int klen = p.K2 ? n1 + p.n2 : n1;
 
     // Q fragment: this lane's query row, d in [64h, 64h + 64), pre-scaled like the reference (q * d_k^-0.5)
     float qreg[64];
@@ -62,6 +66,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs p) {
     const int lc4 = tid & 31, lr = tid >> 5;   // tile loader: 32 float4 per row, 8 rows per pass
     const float* kbase = p.K + (size_t)b * p.Tk * p.ldk + head * DK + lc4 * 4;
     const float* vbase = p.V + (size_t)b * p.Tk * p.ldv + head * DK + lc4 * 4;
+    const float* kbase2 = p.K2 ? p.K2 + (size_t)b * p.T2 * p.ldk2 + head * DK + lc4 * 4 : nullptr;
+    const float* vbase2 = p.K2 ? p.V2 + (size_t)b * p.T2 * p.ldv2 + head * DK + lc4 * 4 : nullptr;
 
     const int ntiles = (klen + KT - 1) / KT;
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -71,9 +77,18 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs p) {
         for (int i = 0; i < 4; ++i) {
             const int r = lr + 8 * i;
             int kr = k0 + r;
-            kr = kr < p.Tk ? kr : p.Tk - 1;
-            const float4 kv = *reinterpret_cast<const float4*>(kbase + (size_t)kr * p.ldk);
-            const float4 vv = *reinterpret_cast<const float4*>(vbase + (size_t)kr * p.ldv);
+            kr = kr < klen ? kr : klen - 1;          // rows past the last valid key only feed masked (-inf) scores
+            const float* ksrc;
+            const float* vsrc;
+            if (kr < n1) {
+                ksrc = kbase + (size_t)kr * p.ldk;
+                vsrc = vbase + (size_t)kr * p.ldv;
+            } else {
+                ksrc = kbase2 + (size_t)(kr - n1) * p.ldk2;
+                vsrc = vbase2 + (size_t)(kr - n1) * p.ldv2;
+            }
+            const float4 kv = *reinterpret_cast<const float4*>(ksrc);
+            const float4 vv = *reinterpret_cast<const float4*>(vsrc);
             *reinterpret_cast<float4*>(&Ks[r * KLD + lc4 * 4]) = kv;
             *reinterpret_cast<float4*>(&Vs[r * DK + lc4 * 4]) = vv;
         }

@@ -85,9 +85,14 @@ struct AttnArgs {
     const float* K; int ldk;      // row (b*Tk + t)
     const float* V; int ldv;
     float* O;       int ldo;
-    const int* klens;             // device int32 [B] valid keys per sequence (>= 1)
+    const int* klens;             // device int32 [B] valid keys per sequence (>= 1); unused with a second source
     int B, H, Tq, Tk;
     float scale;
+    // optional second key/value source (streaming): keys [0, n1[b]) come from (K, V), the next n2 from (K2, V2)
+    const float* K2; int ldk2;    // row (b*T2 + t)
+    const float* V2; int ldv2;
+    int T2, n2;
+    const int* n1_dev; int n1_stride;   // device int32, element b * n1_stride (stride 0 = one value for all)
 };
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
 

@@ -18,6 +18,7 @@
 #include "cif.h"
 #include "common.h"
 #include "frontend.h"
+#include "stream.h"
 
 namespace pf {
 
@@ -295,8 +296,15 @@ static int encoder_default_pe(Encoder* e, int T, hipStream_t s) {
     return 0;
 }
 
+// per-layer streaming context: attention additionally sees the cached K/V ring of this layer and the first
+// `append_rows` K/V rows of the window are appended to it afterwards (attention.py:343-361)
+struct EncChunkCtx {
+    float* ring; int cap; const StreamDev* st; int append_rows;
+    const int* lens;     // device [B]: every window row is valid in a chunk
+};
+
 static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float* x, int B, int T,
-                         hipStream_t s) {
+                         hipStream_t s, const EncChunkCtx* cc = nullptr) {
     // EncoderLayerSANM.forward (sanm/encoder.py:72-148), normalize_before, no concat_after
     const pf_encoder_config& c = e->cfg;
     const int M = B * T, D = c.d_model, F = c.ffn_dim;
@@ -305,7 +313,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
     float* mem = e->mem.as<float>();
     float* ctx = e->ctx.as<float>();
     float* ffn = e->ffn.as<float>();
-    const int* lens = e->lens.as<int>();
+    const int* lens = cc ? cc->lens : e->lens.as<int>();
     int rc;
     // norm1 -> fused QKV projection
     if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
@@ -322,7 +330,19 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
     aa.Q = qkv; aa.ldq = 3 * D; aa.K = qkv + D; aa.ldk = 3 * D; aa.V = qkv + 2 * D; aa.ldv = 3 * D;
     aa.O = ctx; aa.ldo = D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
     aa.scale = powf((float)(D / c.n_heads), -0.5f);
+    if (cc && cc->cap > 0) {
+        // keys = [ring rows 0 .. enc_valid) | this window's K/V], no padding mask (forward_chunk passes mask=None)
+        aa.K = cc->ring; aa.ldk = 2 * D; aa.V = cc->ring + D; aa.ldv = 2 * D; aa.Tk = cc->cap;
+        aa.K2 = qkv + D; aa.ldk2 = 3 * D; aa.V2 = qkv + 2 * D; aa.ldv2 = 3 * D; aa.T2 = T; aa.n2 = T;
+        aa.n1_dev = &cc->st->enc_valid; aa.n1_stride = 0;
+    }
     if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s))) return rc;
+    if (cc && cc->cap > 0 && cc->append_rows > 0) {
+        RingAppendArgs ra{};
+        ra.src = qkv + D; ra.ldsrc = 3 * D; ra.src_T = T; ra.r0 = 0; ra.rows = cc->append_rows; ra.cols = 2 * D;
+        ra.ring = cc->ring; ra.cap = cc->cap; ra.S = B; ra.st = cc->st;
+        if ((rc = launch_ring_append(ra, s))) return rc;
+    }
     // out projection + fsmn memory (+ residual when in == out, encoder.py:120-137)
     const float* resid = (w.in_dim == D) ? x_in : nullptr;
     if ((rc = gemm_simple(ctx, D, w.out_w, D, w.out_b, x, D, M, D, D, 0, mem, D, resid, ld_in, s))) return rc;
@@ -412,6 +432,190 @@ struct Ctc {
     TensorTable tt;
     DevBuf pval, pidx;
 };
+
+
+// PositionwiseFeedForwardDecoderSANM (sanm/positionwise_feed_forward.py:12-33): w_2(LN(relu(w_1 x))), w_2 bias-free
+static int dec_ffn(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s) {
+    const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
+    float* t1 = d->t1.as<float>();
+    float* ffn = d->ffn.as<float>();
+    float* ffn2 = d->ffn2.as<float>();
+    int rc;
+    if ((rc = layernorm(x, D, w.n1g, w.n1b, t1, D, M, D, D, d->cfg.ln_eps, s))) return rc;
+    if ((rc = gemm_simple(t1, D, w.w1, D, w.b1, ffn, F, M, F, D, 1, nullptr, 0, nullptr, 0, s))) return rc;
+    if ((rc = layernorm(ffn, F, w.fng, w.fnb, ffn2, F, M, F, F, d->cfg.ln_eps, s))) return rc;
+    return gemm_simple(ffn2, F, w.w2, F, nullptr, out, D, M, D, F, 0, nullptr, 0, nullptr, 0, s);
+}
+
+
+// ================================================================================================ streaming
+// A lock-step batch of S independent streams (the reference handles exactly one: "batch_size must be set 1",
+// paraformer_streaming/model.py:705). All per-stream state lives in HBM; the steady-state step is captured in a
+// hipGraph keyed by (n_frames, is_final, tail_chunk) and replayed.
+struct Stream {
+    Encoder* e = nullptr; Predictor* p = nullptr; Decoder* d = nullptr;
+    pf_stream_config cfg{};
+    int S = 1, keep = 5, Wmax = 0, Nmax = 0, enc_cap = 0, dec_cap = 0, pe_rows = 0;
+    DevBuf dev_state, cache_feats, feats_in, win, enc_ring, dec_ring, dec_fsmn, cif_hidden, cif_alpha, dec_valid, dec_wp,
+        n_fired, pe, lensW, enc_out, embeds, ids, alphas;
+    int32_t* h_ids = nullptr; int32_t* h_n = nullptr;       // pinned
+    hipStream_t stream = nullptr;                            // the step runs (and is captured) on its own stream
+    hipEvent_t ev = nullptr;
+    int start_idx = 0;                                       // host mirror of StreamDev.start_idx
+    std::map<int, hipGraphExec_t> graphs;
+    std::map<int, int> seen;
+    bool use_graph = true;
+    ~Stream() {
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        if (h_ids) (void)hipHostFree(h_ids);
+        if (h_n) (void)hipHostFree(h_n);
+        if (ev) (void)hipEventDestroy(ev);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static int stream_reset(Stream* st, hipStream_t s) {
+    auto zero = [&](DevBuf& b) -> int {
+        if (b.p && b.cap) PF_HIP_TRY(hipMemsetAsync(b.p, 0, b.cap, s));
+        return 0;
+    };
+    int rc = 0;
+    rc |= zero(st->dev_state); rc |= zero(st->cache_feats); rc |= zero(st->enc_ring); rc |= zero(st->dec_ring);
+    rc |= zero(st->dec_fsmn); rc |= zero(st->cif_hidden); rc |= zero(st->cif_alpha); rc |= zero(st->dec_valid);
+    rc |= zero(st->dec_wp); rc |= zero(st->n_fired);
+    st->start_idx = 0;
+    return rc ? -2 : 0;
+}
+
+// enqueue one chunk on `s` (no host synchronisation, no allocation after the first call with this shape)
+static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t s) {
+    Encoder* e = st->e; Predictor* p = st->p; Decoder* d = st->d;
+    const pf_encoder_config& ec = e->cfg;
+    const int S = st->S, D = ec.d_model, F = ec.ffn_dim, Din = ec.input_dim, Dpad = round_up(Din, 32);
+    const int W = tail ? st->keep : st->keep + n;
+    const int M = S * W, Nmax = st->Nmax;
+    const StreamDev* dev = st->dev_state.as<StreamDev>();
+    int rc;
+    // ---- workspaces of the three handles (grow-only; the first eager call with a shape allocates)
+    {
+        const size_t Mz = (size_t)S * st->Wmax;
+        const int Fbuf = F > Din ? F : Din;
+        if (e->x.ensure(sizeof(float) * Mz * D) || e->xn.ensure(sizeof(float) * Mz * (Dpad > D ? Dpad : D)) ||
+            e->qkv.ensure(sizeof(float) * Mz * 3 * D) || e->mem.ensure(sizeof(float) * Mz * D) ||
+            e->ctx.ensure(sizeof(float) * Mz * D) || e->ffn.ensure(sizeof(float) * Mz * Fbuf))
+            return -2;
+    }
+    if ((rc = launch_fill_int(st->lensW.as<int>(), S, W, s))) return rc;
+    // ---- window: [cached rows | x * sqrt(d) + PE]  (scama/encoder.py:496-503)
+    StreamEmbedArgs ea{};
+    ea.feats = tail ? nullptr : st->feats_in.as<float>(); ea.pe = st->pe.as<float>();
+    ea.cache_feats = st->cache_feats.as<float>(); ea.win = st->win.as<float>(); ea.st = dev; ea.S = S; ea.n = n;
+    ea.keep = st->keep; ea.Din = Din; ea.pe_rows = st->pe_rows; ea.tail = tail; ea.scale = (float)sqrt((double)D);
+    if ((rc = launch_stream_embed(ea, s))) return rc;
+    // ---- encoder blocks on the window
+    const int append_rows = W - st->cfg.chunk_right > 0 ? W - st->cfg.chunk_right : 0;
+    float* x = e->x.as<float>();
+    const size_t ring_layer = (size_t)S * st->enc_cap * 2 * D;
+    for (size_t l = 0; l < e->layers.size(); ++l) {
+        EncChunkCtx cc{st->enc_cap > 0 ? st->enc_ring.as<float>() + l * ring_layer : nullptr, st->enc_cap, dev, append_rows,
+                       st->lensW.as<int>()};
+        if (l == 0) rc = encoder_block(e, e->layers[0], st->win.as<float>(), Din, x, S, W, s, &cc);
+        else rc = encoder_block(e, e->layers[l], x, D, x, S, W, s, &cc);
+        if (rc) return rc;
+    }
+    StreamAdvanceArgs adv{};
+    adv.st = st->dev_state.as<StreamDev>(); adv.n_frames = tail ? st->keep : n;   // the tail chunk re-feeds `keep` rows (embedding.py:478)
+    adv.enc_rows = append_rows; adv.enc_cap = st->enc_cap;
+    if ((rc = launch_stream_advance_enc(adv, s))) return rc;
+    float* enc_out = st->enc_out.as<float>();
+    if ((rc = layernorm(x, D, e->tt.get("after_norm.weight"), e->tt.get("after_norm.bias"), enc_out, D, M, D, D,
+                        ec.ln_eps, s))) return rc;
+    // ---- predictor chunk (cif_predictor.py:316-392)
+    const pf_predictor_config& pc = p->cfg;
+    const int taps = pc.l_order + pc.r_order + 1;
+    if (p->col.ensure(sizeof(float) * (size_t)S * st->Wmax * taps * D) || p->conv.ensure(sizeof(float) * (size_t)S * st->Wmax * D))
+        return -2;
+    if ((rc = launch_im2col(enc_out, p->col.as<float>(), S, W, D, pc.l_order, pc.r_order, s))) return rc;
+    if ((rc = gemm_simple(p->col.as<float>(), taps * D, p->tt.get("cif_conv1d.weight"), taps * D,
+                          p->tt.get("cif_conv1d.bias"), p->conv.as<float>(), D, M, D, taps * D, 1, nullptr, 0, nullptr,
+                          0, s))) return rc;
+    AlphaArgs aa{};
+    aa.conv = p->conv.as<float>(); aa.w = p->tt.get("cif_output.weight"); aa.bias = p->tt.get("cif_output.bias");
+    aa.lens = st->lensW.as<int>(); aa.alphas = st->alphas.as<float>(); aa.B = S; aa.T = W; aa.D = D; aa.T_ext = st->Wmax + 1;
+    aa.smooth = pc.smooth_factor; aa.noise = pc.noise_threshold;
+    if ((rc = launch_alpha(aa, s))) return rc;
+    CifChunkArgs ca{};
+    ca.hidden = enc_out; ca.alphas = st->alphas.as<float>(); ca.ld_alpha = st->Wmax + 1;
+    ca.cif_hidden = st->cif_hidden.as<float>(); ca.cif_alpha = st->cif_alpha.as<float>();
+    ca.embeds = st->embeds.as<float>(); ca.n_fired = st->n_fired.as<int>(); ca.S = S; ca.W = W; ca.D = D; ca.Nmax = Nmax;
+    ca.lo = st->cfg.chunk_left; ca.hi = is_final ? W : st->cfg.chunk_left + st->cfg.chunk_cur;
+    ca.is_final = is_final; ca.tail_threshold = pc.tail_threshold; ca.threshold = pc.threshold;
+    if ((rc = launch_cif_chunk(ca, s))) return rc;
+    // ---- decoder chunk on Nmax token rows per stream; rows >= n_fired are padding, streams with n_fired == 0 keep
+    //      their caches (the reference does not call the decoder then, paraformer_streaming/model.py:589-590)
+    const pf_decoder_config& dc = d->cfg;
+    const int V = dc.vocab_size, Mq = S * Nmax, Mk = M;
+    if (d->x.ensure(sizeof(float) * (size_t)Mq * D) || d->t1.ensure(sizeof(float) * (size_t)Mq * D) ||
+        d->t2.ensure(sizeof(float) * (size_t)Mq * D) || d->ffn.ensure(sizeof(float) * (size_t)Mq * dc.ffn_dim) ||
+        d->ffn2.ensure(sizeof(float) * (size_t)Mq * dc.ffn_dim) || d->q.ensure(sizeof(float) * (size_t)Mq * D) ||
+        d->kv.ensure(sizeof(float) * (size_t)S * st->Wmax * 2 * D) || d->ctx.ensure(sizeof(float) * (size_t)Mq * D) ||
+        d->hid.ensure(sizeof(float) * (size_t)Mq * D))
+        return -2;
+    float* dx = d->x.as<float>();
+    float* t1 = d->t1.as<float>();
+    float* t2 = d->t2.as<float>();
+    PF_HIP_TRY(hipMemcpyAsync(dx, st->embeds.p, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
+    const size_t dring_layer = (size_t)S * st->dec_cap * 2 * D;
+    const size_t dfsmn_layer = (size_t)S * (dc.kernel_size - 1) * D;
+    for (int l = 0; l < dc.n_blocks; ++l) {
+        const DecLayerW& w = d->layers[l];
+        if ((rc = dec_ffn(d, w, dx, t2, Mq, s))) return rc;
+        if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
+        DecFsmnChunkArgs fa{};
+        fa.in = t1; fa.resid = dx; fa.out = dx; fa.w = w.fsmn_w; fa.state = st->dec_fsmn.as<float>() + l * dfsmn_layer;
+        fa.n_valid = st->n_fired.as<int>(); fa.S = S; fa.N = Nmax; fa.C = D;
+        if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
+        if ((rc = layernorm(dx, D, w.n3g, w.n3b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
+        if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
+        if ((rc = gemm_simple(enc_out, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
+                              nullptr, 0, s))) return rc;
+        AttnArgs at{};
+        at.Q = d->q.as<float>(); at.ldq = D; at.O = d->ctx.as<float>(); at.ldo = D; at.B = S; at.H = dc.n_heads;
+        at.Tq = Nmax; at.scale = powf((float)(D / dc.n_heads), -0.5f);
+        if (st->dec_cap > 0) {
+            float* ring = st->dec_ring.as<float>() + l * dring_layer;
+            at.K = ring; at.ldk = 2 * D; at.V = ring + D; at.ldv = 2 * D; at.Tk = st->dec_cap;
+            at.K2 = d->kv.as<float>(); at.ldk2 = 2 * D; at.V2 = d->kv.as<float>() + D; at.ldv2 = 2 * D; at.T2 = W; at.n2 = W;
+            at.n1_dev = st->dec_valid.as<int>(); at.n1_stride = 1;
+        } else {
+            at.K = d->kv.as<float>(); at.ldk = 2 * D; at.V = d->kv.as<float>() + D; at.ldv = 2 * D; at.Tk = W;
+            at.klens = st->lensW.as<int>();
+        }
+        if ((rc = attention(at, 4.0 * S * (double)Nmax * W * D, s))) return rc;
+        if (st->dec_cap > 0) {
+            RingAppendArgs ra{};
+            ra.src = d->kv.as<float>(); ra.ldsrc = 2 * D; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
+            ra.ring = st->dec_ring.as<float>() + l * dring_layer; ra.cap = st->dec_cap; ra.S = S; ra.st = nullptr;
+            ra.wp_dev = st->dec_wp.as<int>(); ra.gate_dev = st->n_fired.as<int>();
+            if ((rc = launch_ring_append(ra, s))) return rc;
+        }
+        if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, dx, D, Mq, D, D, 0, nullptr, 0, dx, D, s))) return rc;
+    }
+    if (st->dec_cap > 0) {
+        StreamAdvanceArgs ad{};
+        ad.dec_valid = st->dec_valid.as<int>(); ad.dec_wp = st->dec_wp.as<int>(); ad.gate = st->n_fired.as<int>();
+        ad.S = S; ad.dec_rows = W; ad.dec_cap = st->dec_cap;
+        if ((rc = launch_stream_advance_dec(ad, s))) return rc;
+    }
+    if ((rc = dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
+    if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), d->hid.as<float>(), D, Mq,
+                        D, D, dc.ln_eps, s))) return rc;
+    if ((rc = vocab_project(d->hid.as<float>(), Mq, D, d->tt.get("output_layer.weight"), d->tt.get("output_layer.bias"),
+                            V, nullptr, st->ids.as<int32_t>(), d->pval, d->pidx, s))) return rc;
+    PF_HIP_TRY(hipMemcpyAsync(st->h_ids, st->ids.p, sizeof(int32_t) * (size_t)Mq, hipMemcpyDeviceToHost, s));
+    PF_HIP_TRY(hipMemcpyAsync(st->h_n, st->n_fired.p, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, s));
+    return 0;
+}
 
 }  // namespace pf
 
@@ -552,6 +756,7 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     LfrArgs l{};
     l.fbank = fb; l.max_frames = max_fr; l.n_frames = f->nfr.as<int>(); l.out = feats; l.T_out = T_out;
     l.n_mels = f->cfg.n_mels; l.lfr_m = f->cfg.lfr_m; l.lfr_n = f->cfg.lfr_n;
+    l.left = (f->cfg.lfr_m - 1) / 2; l.rows_override = 0;
     l.cmvn_shift = f->has_cmvn ? f->cmvn_shift.as<float>() : nullptr;
     l.cmvn_scale = f->has_cmvn ? f->cmvn_scale.as<float>() : nullptr;
     return launch_lfr_cmvn(l, B, s);
@@ -808,19 +1013,6 @@ int pf_decoder_missing(const pf_decoder* dh) {
     return d ? d->tt.missing() : -1;
 }
 
-// PositionwiseFeedForwardDecoderSANM (sanm/positionwise_feed_forward.py:12-33): w_2(LN(relu(w_1 x))), w_2 bias-free
-static int dec_ffn(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s) {
-    const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
-    float* t1 = d->t1.as<float>();
-    float* ffn = d->ffn.as<float>();
-    float* ffn2 = d->ffn2.as<float>();
-    int rc;
-    if ((rc = layernorm(x, D, w.n1g, w.n1b, t1, D, M, D, D, d->cfg.ln_eps, s))) return rc;
-    if ((rc = gemm_simple(t1, D, w.w1, D, w.b1, ffn, F, M, F, D, 1, nullptr, 0, nullptr, 0, s))) return rc;
-    if ((rc = layernorm(ffn, F, w.fng, w.fnb, ffn2, F, M, F, F, d->cfg.ln_eps, s))) return rc;
-    return gemm_simple(ffn2, F, w.w2, F, nullptr, out, D, M, D, F, 0, nullptr, 0, nullptr, 0, s);
-}
-
 int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_lens, const float* embeds,
                        const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids,
                        float* hidden_out, void* stream) {
@@ -908,6 +1100,207 @@ int pf_ctc_greedy(pf_ctc* ch, const float* hidden, int32_t M, int32_t* ids, floa
     if (c->tt.missing(&first)) { set_error("ctc: tensor not set: " + first); return -3; }
     return vocab_project(hidden, M, c->d_model, c->tt.get("ctc_lo.weight"), c->tt.get("ctc_lo.bias"), c->vocab, logits,
                          ids, c->pval, c->pidx, s);
+}
+
+// ---------------------------------------------------------------------------------------------------- streaming
+pf_stream* pf_stream_create(pf_encoder* eh, pf_predictor* ph, pf_decoder* dh, const pf_stream_config* cfg) {
+    if (!eh || !ph || !dh || !cfg) { set_error("stream: null argument"); return nullptr; }
+    if (check_device()) return nullptr;
+    Encoder* e = reinterpret_cast<Encoder*>(eh);
+    Predictor* p = reinterpret_cast<Predictor*>(ph);
+    Decoder* d = reinterpret_cast<Decoder*>(dh);
+    const pf_stream_config& c = *cfg;
+    const int K = d->cfg.kernel_size;
+    const int dec_left = (K - 1) / 2 + (d->cfg.sanm_shift > 0 ? d->cfg.sanm_shift : 0);
+    if (c.n_streams < 1 || c.chunk_left < 0 || c.chunk_cur < 1 || c.chunk_right < 0 || c.enc_look_back < 0 ||
+        c.dec_look_back < 0 || c.max_frames < c.chunk_cur || c.max_tokens < 1 || c.max_tokens > 24 ||
+        e->cfg.tp_blocks != 0 || e->cfg.d_model != 512 || d->cfg.d_model != 512 || p->cfg.d_model != 512 ||
+        dec_left != K - 1) {
+        set_error("stream: unsupported config (d_model 512, look_back >= 0 (finite), max_tokens <= 24, causal decoder "
+                  "FSMN i.e. sanm_shfit == (kernel_size-1)/2 as in paraformer_streaming/template.yaml:62)");
+        return nullptr;
+    }
+    int rc;
+    if (!e->resolved && (rc = encoder_resolve(e))) return nullptr;
+    if (!d->resolved && (rc = decoder_resolve(d))) return nullptr;
+    { std::string first; if (p->tt.missing(&first)) { set_error("predictor: tensor not set: " + first); return nullptr; } }
+    std::unique_ptr<Stream> st(new Stream());
+    st->e = e; st->p = p; st->d = d; st->cfg = c;
+    st->S = c.n_streams; st->keep = c.chunk_left + c.chunk_right; st->Wmax = st->keep + c.max_frames;
+    st->Nmax = c.max_tokens; st->enc_cap = c.enc_look_back * c.chunk_cur; st->dec_cap = c.dec_look_back * c.chunk_cur;
+    st->use_graph = c.use_graph != 0;
+    const int S = st->S, D = 512, Din = e->cfg.input_dim;
+    const size_t L = e->layers.size(), Ld = (size_t)d->cfg.n_blocks;
+    bool bad = false;
+    bad |= st->dev_state.ensure(sizeof(StreamDev)) != 0;
+    bad |= st->cache_feats.ensure(sizeof(float) * (size_t)S * (st->keep > 0 ? st->keep : 1) * Din) != 0;
+    bad |= st->feats_in.ensure(sizeof(float) * (size_t)S * c.max_frames * Din) != 0;
+    bad |= st->win.ensure(sizeof(float) * (size_t)S * st->Wmax * Din) != 0;
+    bad |= st->enc_ring.ensure(sizeof(float) * (L * S * (st->enc_cap > 0 ? st->enc_cap : 1) * 2 * D)) != 0;
+    bad |= st->dec_ring.ensure(sizeof(float) * (Ld * S * (st->dec_cap > 0 ? st->dec_cap : 1) * 2 * D)) != 0;
+    bad |= st->dec_fsmn.ensure(sizeof(float) * (Ld * S * (K - 1) * D)) != 0;
+    bad |= st->cif_hidden.ensure(sizeof(float) * (size_t)S * D) != 0;
+    bad |= st->cif_alpha.ensure(sizeof(float) * (size_t)S) != 0;
+    bad |= st->dec_valid.ensure(sizeof(int) * (size_t)S) != 0;
+    bad |= st->dec_wp.ensure(sizeof(int) * (size_t)S) != 0;
+    bad |= st->n_fired.ensure(sizeof(int) * (size_t)S) != 0;
+    bad |= st->lensW.ensure(sizeof(int) * (size_t)S) != 0;
+    bad |= st->enc_out.ensure(sizeof(float) * (size_t)S * st->Wmax * D) != 0;
+    bad |= st->embeds.ensure(sizeof(float) * (size_t)S * st->Nmax * D) != 0;
+    bad |= st->ids.ensure(sizeof(int32_t) * (size_t)S * st->Nmax) != 0;
+    bad |= st->alphas.ensure(sizeof(float) * (size_t)S * (st->Wmax + 1)) != 0;
+    if (bad) return nullptr;
+    if (hipHostMalloc((void**)&st->h_ids, sizeof(int32_t) * (size_t)S * st->Nmax) != hipSuccess ||
+        hipHostMalloc((void**)&st->h_n, sizeof(int32_t) * (size_t)S) != hipSuccess ||
+        hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&st->ev, hipEventDisableTiming) != hipSuccess) {
+        set_error("stream: pinned buffer / stream creation failed");
+        return nullptr;
+    }
+    // default position table (libm); the Python mirror replaces it with the torch-evaluated one for bit-exactness
+    {
+        const int rows = 4096, half = Din / 2;
+        std::vector<float> tab((size_t)rows * Din);
+        const float inc = logf(10000.0f) / (float)(half - 1);
+        for (int t = 0; t < rows; ++t)
+            for (int i = 0; i < half; ++i) {
+                const float sc = (float)(t + 1) * expf((float)i * (-inc));
+                tab[(size_t)t * Din + i] = sinf(sc);
+                tab[(size_t)t * Din + half + i] = cosf(sc);
+            }
+        if (st->pe.ensure(sizeof(float) * tab.size())) return nullptr;
+        if (hipMemcpy(st->pe.p, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        st->pe_rows = rows;
+    }
+    if (stream_reset(st.get(), st->stream) || hipStreamSynchronize(st->stream) != hipSuccess) return nullptr;
+    return reinterpret_cast<pf_stream*>(st.release());
+}
+
+void pf_stream_destroy(pf_stream* s) { delete reinterpret_cast<Stream*>(s); }
+
+int pf_stream_set_pe(pf_stream* sh, const float* pe, int32_t rows) {
+    Stream* st = reinterpret_cast<Stream*>(sh);
+    PF_REQUIRE(st && pe && rows > 0, "stream_set_pe: null/empty");
+    PF_HIP_TRY(hipStreamSynchronize(st->stream));
+    const size_t bytes = sizeof(float) * (size_t)rows * st->e->cfg.input_dim;
+    const void* old = st->pe.p;
+    if (st->pe.ensure(bytes)) return -2;
+    if (st->pe.p != old) {                     // the table moved: captured graphs hold the old pointer
+        for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+        st->graphs.clear();
+    }
+    PF_HIP_TRY(hipMemcpy(st->pe.p, pe, bytes, hipMemcpyDefault));
+    st->pe_rows = rows;
+    return 0;
+}
+
+int pf_stream_reset(pf_stream* sh, void* stream) {
+    Stream* st = reinterpret_cast<Stream*>(sh);
+    PF_REQUIRE(st, "stream_reset: null");
+    int rc = stream_reset(st, st->stream);
+    if (rc) return rc;
+    PF_HIP_TRY(hipStreamSynchronize(st->stream));
+    return 0;
+}
+
+int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t is_final, int32_t tail_chunk,
+                   int32_t* ids_host, int32_t* n_tokens_host, float* enc_out, void* stream) {
+    Stream* st = reinterpret_cast<Stream*>(sh);
+    hipStream_t us = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(st && ids_host && n_tokens_host, "stream_step: null argument");
+    const int n = tail_chunk ? 0 : n_frames;
+    PF_REQUIRE(tail_chunk || (feats && n >= 1 && n <= st->cfg.max_frames), "stream_step: n_frames out of range");
+    PF_REQUIRE(!tail_chunk || st->keep > 0, "stream_step: a tail chunk needs chunk_left + chunk_right > 0");
+    PF_REQUIRE(st->start_idx + n <= st->pe_rows, "stream_step: position table exhausted (pf_stream_set_pe with more rows)");
+    const int S = st->S, Din = st->e->cfg.input_dim, D = 512;
+    const int W = tail_chunk ? st->keep : st->keep + n;
+    hipStream_t s = st->stream;
+    // order after whatever produced `feats` on the caller's stream
+    PF_HIP_TRY(hipEventRecord(st->ev, us));
+    PF_HIP_TRY(hipStreamWaitEvent(s, st->ev, 0));
+    if (!tail_chunk)
+        PF_HIP_TRY(hipMemcpyAsync(st->feats_in.p, feats, sizeof(float) * (size_t)S * n * Din, hipMemcpyDeviceToDevice, s));
+    const int key = n | (is_final ? 1 << 10 : 0) | (tail_chunk ? 1 << 11 : 0);
+    int rc;
+    const bool graphable = st->use_graph && !g_prof_on;
+    if (graphable && st->seen[key] >= 1) {
+        auto it = st->graphs.find(key);
+        if (it == st->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            PF_HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = stream_enqueue(st, n, is_final, tail_chunk, s);
+            hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (ce != hipSuccess) { set_error(std::string("stream: graph capture failed: ") + hipGetErrorString(ce)); return -2; }
+            hipGraphExec_t exec = nullptr;
+            PF_HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            it = st->graphs.emplace(key, exec).first;
+        }
+        PF_HIP_TRY(hipGraphLaunch(it->second, s));
+    } else {
+        if ((rc = stream_enqueue(st, n, is_final, tail_chunk, s))) return rc;
+        st->seen[key] += 1;
+    }
+    if (enc_out)
+        PF_HIP_TRY(hipMemcpyAsync(enc_out, st->enc_out.p, sizeof(float) * (size_t)S * W * D, hipMemcpyDeviceToDevice, s));
+    PF_HIP_TRY(hipStreamSynchronize(s));
+    st->start_idx += tail_chunk ? st->keep : n;
+    memcpy(ids_host, st->h_ids, sizeof(int32_t) * (size_t)S * st->Nmax);
+    memcpy(n_tokens_host, st->h_n, sizeof(int32_t) * (size_t)S);
+    return 0;
+}
+
+int pf_stream_peek(pf_stream* sh, float* cif_alpha_host, float* cif_hidden_host, int32_t* start_idx_host) {
+    Stream* st = reinterpret_cast<Stream*>(sh);
+    PF_REQUIRE(st, "stream_peek: null");
+    PF_HIP_TRY(hipStreamSynchronize(st->stream));
+    if (cif_alpha_host) PF_HIP_TRY(hipMemcpy(cif_alpha_host, st->cif_alpha.p, sizeof(float) * st->S, hipMemcpyDeviceToHost));
+    if (cif_hidden_host) PF_HIP_TRY(hipMemcpy(cif_hidden_host, st->cif_hidden.p, sizeof(float) * (size_t)st->S * 512, hipMemcpyDeviceToHost));
+    if (start_idx_host) {
+        StreamDev d{};
+        PF_HIP_TRY(hipMemcpy(&d, st->dev_state.p, sizeof(StreamDev), hipMemcpyDeviceToHost));
+        *start_idx_host = d.start_idx;
+    }
+    return 0;
+}
+
+// LFR + CMVN over an explicit frame buffer (WavFrontendOnline.apply_lfr + apply_cmvn, wav_frontend.py:331-380): the
+// caller has already put the left context (splice cache) in front, so row i stacks frames [lfr_n*i, lfr_n*i + lfr_m),
+// frames past the end repeat the last one (final flush). frames_dev [T, n_mels] -> out_dev [rows, n_mels*lfr_m].
+int pf_frontend_lfr_cmvn(pf_frontend* fh, const float* frames_dev, int32_t T, int32_t rows, float* out_dev, void* stream) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(f && frames_dev && out_dev && T > 0 && rows >= 0, "frontend_lfr_cmvn: null/empty");
+    if (rows == 0) return 0;
+    if (f->nfr.ensure(sizeof(int32_t))) return -2;
+    int rc;
+    if ((rc = launch_fill_int(f->nfr.as<int>(), 1, T, s))) return rc;
+    LfrArgs l{};
+    l.fbank = frames_dev; l.max_frames = T; l.n_frames = f->nfr.as<int>(); l.out = out_dev; l.T_out = rows;
+    l.n_mels = f->cfg.n_mels; l.lfr_m = f->cfg.lfr_m; l.lfr_n = f->cfg.lfr_n; l.left = 0; l.rows_override = rows;
+    l.cmvn_shift = f->has_cmvn ? f->cmvn_shift.as<float>() : nullptr;
+    l.cmvn_scale = f->has_cmvn ? f->cmvn_scale.as<float>() : nullptr;
+    return launch_lfr_cmvn(l, 1, s);
+}
+
+// log-mel only: wav_dev [n] -> fbank_dev [T_fb, n_mels] with T_fb = pf_frontend_num_fbank_frames(n)
+int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, float* fbank_dev, void* stream) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(f && wav_dev && fbank_dev, "frontend_fbank: null");
+    const int nfr = pf_frontend_num_fbank_frames(fh, n_samples);
+    if (nfr <= 0) return 0;
+    if (f->nfr.ensure(sizeof(int32_t))) return -2;
+    int rc;
+    if ((rc = launch_fill_int(f->nfr.as<int>(), 1, nfr, s))) return rc;
+    FbankArgs a{};
+    a.wav = wav_dev; a.wav_stride = (size_t)n_samples; a.n_frames = f->nfr.as<int>(); a.fbank = fbank_dev; a.max_frames = nfr;
+    a.frame_len = f->cfg.frame_length; a.frame_shift = f->cfg.frame_shift; a.n_mels = f->cfg.n_mels;
+    a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
+    a.twiddle = f->twiddle.as<float2>(); a.mel_weight = f->mel_w.as<float>(); a.mel_offset = f->mel_off.as<int>();
+    a.mel_len = f->mel_len.as<int>();
+    return launch_fbank(a, 1, nfr, s);
 }
 
 // -------------------------------------------------------------------------------------------- single kernels

@@ -30,6 +30,8 @@ struct LfrArgs {
     int n_mels, lfr_m, lfr_n;
     const float* cmvn_shift;     // device [n_mels * lfr_m] or nullptr
     const float* cmvn_scale;
+    int left;                    // frames of left context the row index is shifted by: (lfr_m-1)/2 offline, 0 online
+    int rows_override;           // > 0: emit exactly this many rows (online LFR decides the count on the host)
 };
 int launch_lfr_cmvn(const LfrArgs& a, int B, hipStream_t stream);
 

@@ -137,11 +137,11 @@ __global__ __launch_bounds__(256) void lfr_cmvn_kernel(LfrArgs p) {
     if (i >= (size_t)p.T_out * D4) return;
     const int t = (int)(i / D4), c = (int)(i % D4) * 4;
     const int nfr = p.n_frames[b];
-    const int T = (nfr + p.lfr_n - 1) / p.lfr_n;
+    const int T = p.rows_override > 0 ? p.rows_override : (nfr + p.lfr_n - 1) / p.lfr_n;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t < T) {
         const int j = c / p.n_mels, m = c % p.n_mels;      // n_mels % 4 == 0: a float4 never straddles frames
-        int src = p.lfr_n * t + j - (p.lfr_m - 1) / 2;
+        int src = p.lfr_n * t + j - p.left;
         src = src < 0 ? 0 : (src > nfr - 1 ? nfr - 1 : src);
         const float4 v = *reinterpret_cast<const float4*>(p.fbank + ((size_t)b * p.max_frames + src) * p.n_mels + m);
         if (p.cmvn_shift) {

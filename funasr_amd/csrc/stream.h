@@ -1,0 +1,71 @@
+// Kernel argument blocks of the streaming (chunked) Paraformer step (see stream.hip).
+#pragma once
+#include "common.h"
+
+namespace pf {
+
+// device-resident step state shared by all streams of a lock-step batch; advanced ON DEVICE so that a captured
+// hipGraph of the steady-state step can be replayed without patching kernel arguments
+struct StreamDev {
+    int start_idx;      // absolute position of the next feature frame (StreamSinusoidalPositionEncoder cache)
+    int enc_valid;      // valid rows in the encoder K/V rings (<= capacity)
+    int enc_wp;         // next write row of the encoder K/V rings
+    int step;           // chunks processed
+};
+
+struct StreamEmbedArgs {
+    const float* feats;        // [S, n, Din] un-scaled online features (nullptr for a tail chunk)
+    const float* pe;           // [pe_rows, Din] sinusoidal table, row = absolute position (0-based)
+    float* cache_feats;        // [S, keep, Din] last `keep` rows of the previous window (in/out)
+    float* win;                // [S, W, Din] output window
+    const StreamDev* st;
+    int S, n, keep, Din, pe_rows, tail;
+    float scale;
+};
+int launch_stream_embed(const StreamEmbedArgs& a, hipStream_t stream);
+
+struct RingAppendArgs {
+    const float* src; int ldsrc;     // rows (s * src_T + r0 + i), `cols` floats each
+    int src_T, r0, rows, cols;
+    float* ring;                     // [S, cap, cols]
+    int cap, S;
+    const StreamDev* st;             // uniform mode: write pointer = st->enc_wp
+    const int* wp_dev;               // per-stream mode (st == nullptr): write pointer wp_dev[s]
+    const int* gate_dev;             // per-stream mode: stream s is skipped when gate_dev[s] < 1
+};
+int launch_ring_append(const RingAppendArgs& a, hipStream_t stream);
+
+struct StreamAdvanceArgs {
+    StreamDev* st; int n_frames, enc_rows, enc_cap;
+    int* dec_valid; int* dec_wp; const int* gate; int S, dec_rows, dec_cap;
+};
+int launch_stream_advance_enc(const StreamAdvanceArgs& a, hipStream_t stream);
+int launch_stream_advance_dec(const StreamAdvanceArgs& a, hipStream_t stream);
+
+struct CifChunkArgs {
+    const float* hidden;       // [S, W, D] encoder window output
+    const float* alphas; int ld_alpha;   // [S, ld_alpha] raw alphas of the window (alpha_kernel)
+    float* cif_hidden;         // [S, D] carried un-fired remainder (in/out)
+    float* cif_alpha;          // [S]    carried weight (in/out)
+    float* embeds;             // [S, Nmax, D] fired frames, rows >= n zero-filled
+    int* n_fired;              // [S]
+    int S, W, D, Nmax;
+    int lo, hi;                // window frames outside [lo, hi) get alpha 0 (cif_predictor.py:343-346)
+    int is_final; float tail_threshold, threshold;
+};
+int launch_cif_chunk(const CifChunkArgs& a, hipStream_t stream);
+
+struct DecFsmnChunkArgs {
+    const float* in;           // [S, N, C] LN2 output of this chunk's tokens
+    const float* resid;        // [S, N, C] layer input (residual)
+    float* out;                // [S, N, C]
+    const float* w;            // [C, K]
+    float* state;              // [S, K-1, C] left context carried across chunks (in/out)
+    const int* n_valid;        // [S] tokens fired this chunk
+    int S, N, C;
+};
+int launch_dec_fsmn_chunk(const DecFsmnChunkArgs& a, hipStream_t stream);
+
+int launch_fill_int(int* p, int n, int value, hipStream_t stream);
+
+}  // namespace pf

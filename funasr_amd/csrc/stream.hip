@@ -1,0 +1,281 @@
+// Kernels of the streaming (chunked, stateful) Paraformer step. All of them are tiny and latency-bound: the whole
+// step is meant to be captured once in a hipGraph and replayed, so every step-varying scalar lives in device
+// memory (StreamDev) and is advanced by a kernel instead of being passed as a launch argument.
+//
+// Reference semantics:
+//   window = [last 5 rows of the previous window | x * sqrt(d) + PE(start_idx ..)]   funasr/models/scama/encoder.py:480-503,
+//                                                                                    funasr/models/transformer/embedding.py:468-482
+//   K/V caches ("last look_back * chunk rows")                                       funasr/models/sanm/attention.py:343-361, :829-841
+//   sequential integrate-and-fire with carried remainder                              funasr/models/paraformer/cif_predictor.py:343-392
+//   causal decoder FSMN with carried left context                                     funasr/models/sanm/attention.py:606-625
+#include "stream.h"
+
+namespace pf {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------- window / PE
+__global__ __launch_bounds__(256) void stream_embed_kernel(StreamEmbedArgs p) {
+    const int D4 = p.Din >> 2;
+    const int W = p.tail ? p.keep : p.keep + p.n;
+    const int total = p.S * W * D4;
+    const int start = p.st->start_idx;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = i % D4, row = (i / D4) % W, s = i / (D4 * W);
+        float4 v;
+        if (p.tail) {
+            // tail chunk: the cached window itself is scaled a second time, no new position (encoder.py:496-502)
+            const float4 c = reinterpret_cast<const float4*>(p.cache_feats)[(s * p.keep + row) * D4 + c4];
+            v.x = __fmul_rn(c.x, p.scale); v.y = __fmul_rn(c.y, p.scale);
+            v.z = __fmul_rn(c.z, p.scale); v.w = __fmul_rn(c.w, p.scale);
+        } else if (row < p.keep) {
+            v = reinterpret_cast<const float4*>(p.cache_feats)[(s * p.keep + row) * D4 + c4];
+        } else {
+            const int t = row - p.keep;
+            int pos = start + t;
+            pos = pos < p.pe_rows ? pos : p.pe_rows - 1;
+            const float4 a = reinterpret_cast<const float4*>(p.feats)[(s * p.n + t) * D4 + c4];
+            const float4 e = reinterpret_cast<const float4*>(p.pe)[pos * D4 + c4];
+            v.x = __fadd_rn(__fmul_rn(a.x, p.scale), e.x); v.y = __fadd_rn(__fmul_rn(a.y, p.scale), e.y);
+            v.z = __fadd_rn(__fmul_rn(a.z, p.scale), e.z); v.w = __fadd_rn(__fmul_rn(a.w, p.scale), e.w);
+        }
+        reinterpret_cast<float4*>(p.win)[(s * W + row) * D4 + c4] = v;
+    }
+}
+
+// second pass (separate launch: every window row must have been read first): cache <- last `keep` rows of the window
+__global__ __launch_bounds__(256) void stream_keep_kernel(const float* win, float* cache, int S, int W, int keep, int D4) {
+    const int total = S * keep * D4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = i % D4, row = (i / D4) % keep, s = i / (D4 * keep);
+        reinterpret_cast<float4*>(cache)[i] = reinterpret_cast<const float4*>(win)[(s * W + (W - keep) + row) * D4 + c4];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- K/V rings
+__global__ __launch_bounds__(256) void ring_append_kernel(RingAppendArgs p) {
+    const int C4 = p.cols >> 2;
+    const int skip = p.rows > p.cap ? p.rows - p.cap : 0;      // only the newest `cap` rows can survive
+    const int rows = p.rows - skip;
+    const int total = p.S * rows * C4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = i % C4, r = (i / C4) % rows, s = i / (C4 * rows);
+        int wp;
+        if (p.st) wp = p.st->enc_wp;
+        else {
+            if (p.gate_dev[s] < 1) continue;
+            wp = p.wp_dev[s];
+        }
+        const int dst = (wp + skip + r) % p.cap;
+        const float4 v = *reinterpret_cast<const float4*>(p.src + (size_t)(s * p.src_T + p.r0 + skip + r) * p.ldsrc + c4 * 4);
+        reinterpret_cast<float4*>(p.ring)[((size_t)s * p.cap + dst) * C4 + c4] = v;
+    }
+}
+
+__global__ void stream_advance_enc_kernel(StreamAdvanceArgs p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        StreamDev s = *p.st;
+        s.start_idx += p.n_frames;
+        if (p.enc_cap > 0) {
+            const int v = s.enc_valid + p.enc_rows;
+            s.enc_valid = v < p.enc_cap ? v : p.enc_cap;
+            s.enc_wp = (s.enc_wp + p.enc_rows) % p.enc_cap;
+        }
+        s.step += 1;
+        *p.st = s;
+    }
+}
+
+__global__ void stream_advance_dec_kernel(StreamAdvanceArgs p) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.S || p.dec_cap <= 0) return;
+    if (p.gate[s] < 1) return;                    // the reference skips the decoder when no token fired (:589-590)
+    const int v = p.dec_valid[s] + p.dec_rows;
+    p.dec_valid[s] = v < p.dec_cap ? v : p.dec_cap;
+    p.dec_wp[s] = (p.dec_wp[s] + p.dec_rows) % p.dec_cap;
+}
+
+// ------------------------------------------------------------------------------------------- CIF, one chunk
+// One wave per stream; lane l owns channels [8l, 8l+8) (+512 per extra pass). The integrate/fire decisions are
+// wave-uniform scalars evaluated in float32 exactly in the reference's order (cif_predictor.py:360-383):
+//   if alpha + integrate < thr:  integrate += alpha; frames += alpha * h
+//   else: frames += (thr - integrate) * h; emit(frames); integrate += alpha; integrate -= thr; frames = integrate * h
+template <int CPL>   // channels per lane
+__global__ __launch_bounds__(64) void cif_chunk_kernel(CifChunkArgs p) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int c0 = lane * CPL;
+    float frames[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) frames[j] = 0.f;
+    float integrate = 0.f;
+    int n = 0;
+    const int T = 1 + p.W + (p.is_final ? 1 : 0);
+    for (int t = 0; t < T; ++t) {
+        float a;
+        float h[CPL];
+        if (t == 0) {
+            a = p.cif_alpha[s];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) h[j] = p.cif_hidden[(size_t)s * p.D + c0 + j];
+        } else if (t <= p.W) {
+            const int w = t - 1;
+            a = (w >= p.lo && w < p.hi) ? p.alphas[(size_t)s * p.ld_alpha + w] : 0.f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) h[j] = p.hidden[((size_t)s * p.W + w) * p.D + c0 + j];
+        } else {
+            a = p.tail_threshold;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) h[j] = 0.f;
+        }
+        if (__fadd_rn(a, integrate) < p.threshold) {
+            integrate = __fadd_rn(integrate, a);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) frames[j] = __fadd_rn(frames[j], __fmul_rn(a, h[j]));
+        } else {
+            const float rest = __fsub_rn(p.threshold, integrate);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) frames[j] = __fadd_rn(frames[j], __fmul_rn(rest, h[j]));
+            if (n < p.Nmax) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) p.embeds[((size_t)s * p.Nmax + n) * p.D + c0 + j] = frames[j];
+            }
+            ++n;
+            integrate = __fadd_rn(integrate, a);
+            integrate = __fsub_rn(integrate, p.threshold);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) frames[j] = __fmul_rn(integrate, h[j]);
+        }
+    }
+    for (int k = n < p.Nmax ? n : p.Nmax; k < p.Nmax; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) p.embeds[((size_t)s * p.Nmax + k) * p.D + c0 + j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+        p.cif_hidden[(size_t)s * p.D + c0 + j] = integrate > 0.f ? __fdiv_rn(frames[j], integrate) : frames[j];
+    if (lane == 0) {
+        p.cif_alpha[s] = integrate;
+        p.n_fired[s] = n < p.Nmax ? n : p.Nmax;
+    }
+}
+
+// -------------------------------------------------------------------------- decoder FSMN with carried context
+// thread = (stream, 4 channels); sequence = [state (K-1 rows) | this chunk's n tokens]; out[k] = resid[k] +
+// (sum_j w[j] * seq[k + j] + in[k]); new state = last K-1 rows of the sequence. Rows >= n are padding.
+template <int KS, int NMAX>
+__global__ __launch_bounds__(128) void dec_fsmn_chunk_kernel(DecFsmnChunkArgs p) {
+    const int s = blockIdx.y;
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 * 4 >= p.C) return;
+    int n = p.n_valid[s];
+    n = n < p.N ? n : p.N;
+    float4 w[KS];
+    {
+        const float* wp = p.w + (size_t)c4 * 4 * KS;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            w[j].x = wp[j]; w[j].y = wp[KS + j]; w[j].z = wp[2 * KS + j]; w[j].w = wp[3 * KS + j];
+        }
+    }
+    float4 seq[KS - 1 + NMAX];
+#pragma unroll
+    for (int i = 0; i < KS - 1; ++i)
+        seq[i] = *reinterpret_cast<const float4*>(p.state + ((size_t)s * (KS - 1) + i) * p.C + c4 * 4);
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        seq[KS - 1 + k] = (k < p.N) ? *reinterpret_cast<const float4*>(p.in + ((size_t)s * p.N + k) * p.C + c4 * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        if (k < p.N) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                acc.x = fmaf(w[j].x, seq[k + j].x, acc.x);
+                acc.y = fmaf(w[j].y, seq[k + j].y, acc.y);
+                acc.z = fmaf(w[j].z, seq[k + j].z, acc.z);
+                acc.w = fmaf(w[j].w, seq[k + j].w, acc.w);
+            }
+            const float4 x = seq[KS - 1 + k];
+            const float4 r = *reinterpret_cast<const float4*>(p.resid + ((size_t)s * p.N + k) * p.C + c4 * 4);
+            float4 o;
+            o.x = r.x + (acc.x + x.x); o.y = r.y + (acc.y + x.y); o.z = r.z + (acc.z + x.z); o.w = r.w + (acc.w + x.w);
+            *reinterpret_cast<float4*>(p.out + ((size_t)s * p.N + k) * p.C + c4 * 4) = o;
+        }
+    }
+    // new state: rows [n, n + KS - 1) of the sequence (n is wave-divergent only across streams = blocks)
+#pragma unroll
+    for (int i = 0; i < KS - 1; ++i) {
+        float4 v = seq[i];
+#pragma unroll
+        for (int k = 1; k <= NMAX; ++k)
+            if (n == k) v = seq[i + k];
+        *reinterpret_cast<float4*>(p.state + ((size_t)s * (KS - 1) + i) * p.C + c4 * 4) = v;
+    }
+}
+
+__global__ void fill_int_kernel(int* p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+int launch_stream_embed(const StreamEmbedArgs& a, hipStream_t stream) {
+    PF_REQUIRE(a.Din % 4 == 0 && a.S > 0 && a.keep >= 0, "stream_embed: bad shape");
+    const int W = a.tail ? a.keep : a.keep + a.n;
+    PF_REQUIRE(W > 0, "stream_embed: empty window");
+    const int total = a.S * W * (a.Din / 4);
+    hipLaunchKernelGGL(stream_embed_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, a);
+    if (a.keep > 0 && W >= a.keep) {
+        const int t2 = a.S * a.keep * (a.Din / 4);
+        hipLaunchKernelGGL(stream_keep_kernel, dim3(ceil_div(t2, 256)), dim3(256), 0, stream, a.win, a.cache_feats, a.S, W,
+                           a.keep, a.Din / 4);
+    }
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_ring_append(const RingAppendArgs& a, hipStream_t stream) {
+    if (a.rows <= 0 || a.cap <= 0) return 0;
+    PF_REQUIRE(a.cols % 4 == 0 && a.ldsrc % 4 == 0, "ring_append: cols % 4");
+    const int rows = a.rows > a.cap ? a.cap : a.rows;
+    const int total = a.S * rows * (a.cols / 4);
+    hipLaunchKernelGGL(ring_append_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_stream_advance_enc(const StreamAdvanceArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(stream_advance_enc_kernel, dim3(1), dim3(64), 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_stream_advance_dec(const StreamAdvanceArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(stream_advance_dec_kernel, dim3(ceil_div(a.S, 64)), dim3(64), 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_cif_chunk(const CifChunkArgs& a, hipStream_t stream) {
+    PF_REQUIRE(a.D == 512, "cif_chunk: d_model 512 is built (8 channels per lane)");
+    hipLaunchKernelGGL(cif_chunk_kernel<8>, dim3(a.S), dim3(64), 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_dec_fsmn_chunk(const DecFsmnChunkArgs& a, hipStream_t stream) {
+    PF_REQUIRE(a.C % 4 == 0 && a.N <= 24, "dec_fsmn_chunk: N <= 24 tokens per chunk");
+    dim3 grid(ceil_div(a.C / 4, 128), a.S), block(128);
+    hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 24>), grid, block, 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_fill_int(int* p, int n, int value, hipStream_t stream) {
+    hipLaunchKernelGGL(fill_int_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, p, n, value);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pf

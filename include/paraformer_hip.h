@@ -171,6 +171,48 @@ int pf_ctc_missing(const pf_ctc* c);
 /* hidden_dev: [M, d_model]; ids_dev: int32 [M] frame-wise argmax; logits_dev (nullable): [M, vocab]. No sync. */
 int pf_ctc_greedy(pf_ctc* c, const float* hidden_dev, int32_t M, int32_t* ids_dev, float* logits_dev, void* stream);
 
+/* ----------------------------------------------------------------------------------------------- streaming
+ * Chunked online decoding (ParaformerStreaming, funasr/models/paraformer_streaming/model.py:552-763): one handle =
+ * a lock-step batch of n_streams independent streams (the reference: exactly 1) with all caches in HBM
+ * (encoder K/V rings funasr/models/sanm/attention.py:343-361, overlap window funasr/models/scama/encoder.py:480-494,
+ * CIF remainder cif_predictor.py:347-392, decoder FSMN / cross-attention caches attention.py:606-625,829-841).
+ * The steady-state step is captured in a hipGraph per (n_frames, is_final, tail_chunk) and replayed. */
+typedef struct pf_stream pf_stream;
+
+typedef struct pf_stream_config {
+    int32_t n_streams;        /* streams advanced together (>= 1) */
+    int32_t chunk_left;       /* chunk_size[0] = 0 */
+    int32_t chunk_cur;        /* chunk_size[1] = 10 LFR frames = 600 ms */
+    int32_t chunk_right;      /* chunk_size[2] = 5 look-ahead frames */
+    int32_t enc_look_back;    /* encoder_chunk_look_back (chunks), 4 */
+    int32_t dec_look_back;    /* decoder_chunk_look_back (chunks), 1 */
+    int32_t max_frames;       /* most feature frames a step may bring (>= chunk_cur) */
+    int32_t max_tokens;       /* token rows decoded per stream per step (<= 24) */
+    int32_t use_graph;        /* 1: capture + replay the step as a hipGraph */
+} pf_stream_config;
+
+/* the three handles must outlive the stream and carry all their tensors */
+pf_stream* pf_stream_create(pf_encoder* e, pf_predictor* p, pf_decoder* d, const pf_stream_config* cfg);
+void pf_stream_destroy(pf_stream* s);
+/* sinusoidal position table, row r = position r+1 (StreamSinusoidalPositionEncoder, embedding.py:468-482); host or
+ * device pointer, [rows, input_dim]. Default: 4096 rows computed with libm. */
+int pf_stream_set_pe(pf_stream* s, const float* pe, int32_t rows);
+int pf_stream_reset(pf_stream* s, void* stream);
+/* One chunk for every stream. feats_dev: [n_streams, n_frames, input_dim] un-scaled online features (ignored for a
+ * tail chunk, which re-feeds the cached window, model.py:715-720). Outputs: ids_host int32 [n_streams, max_tokens]
+ * (raw arg-max ids incl. sos/eos/blank), n_tokens_host int32 [n_streams]; optional enc_out_dev
+ * [n_streams, W, d_model] (W = chunk_left + chunk_right + n_frames, or chunk_left + chunk_right for a tail chunk).
+ * SYNCHRONISES (returns host values). */
+int pf_stream_step(pf_stream* s, const float* feats_dev, int32_t n_frames, int32_t is_final, int32_t tail_chunk,
+                   int32_t* ids_host, int32_t* n_tokens_host, float* enc_out_dev, void* stream);
+/* debug / parity: carried CIF state and position counter (any pointer may be NULL) */
+int pf_stream_peek(pf_stream* s, float* cif_alpha_host, float* cif_hidden_host, int32_t* start_idx_host);
+
+/* online frontend pieces (WavFrontendOnline, wav_frontend.py:395-505): log-mel of one buffer, and LFR + CMVN over a
+ * frame buffer that already carries its left context */
+int pf_frontend_fbank(pf_frontend* f, const float* wav_dev, int64_t n_samples, float* fbank_dev, void* stream);
+int pf_frontend_lfr_cmvn(pf_frontend* f, const float* frames_dev, int32_t T, int32_t rows, float* out_dev, void* stream);
+
 /* -------------------------------------------------------------------------------- single kernels (tests / bench)
  * Thin wrappers over the individual gfx950 kernels so that parity tests and the roofline bench can drive one
  * kernel at a time through the same ABI. All pointers are device pointers. */

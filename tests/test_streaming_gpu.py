@@ -1,0 +1,136 @@
+"""Streaming (chunked) Paraformer through the C ABI (pf_stream_*, pf_frontend_fbank / pf_frontend_lfr_cmvn) against the
+golden fixture recorded from the REFERENCE's own ParaformerStreaming + WavFrontendOnline (tests/golden/streaming.npz,
+oracle/make_golden_streaming.py): per 600 ms chunk the online features, the encoder window, the carried CIF state and
+the token ids; incl. the final flush and the < 960-sample tail chunk. Token ids / counts bit-exact, activations 1e-3."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from funasr_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load():
+    g = np.load(os.path.join(GOLD, "streaming.npz"), allow_pickle=False)
+    cfg = json.loads(bytes(g["config"]).decode())
+    sd = synth.paraformer_state_dict(cfg, seed=int(g["seed"]), cif_bias=float(g["cif_bias"]))
+    wav = torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0)
+    return g, cfg, sd, wav
+
+
+def build(cfg, sd, dev):
+    from funasr_amd.paraformer_streaming import ParaformerStreaming
+    model = ParaformerStreaming.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    return model.to(dev)
+
+
+def frontend(dev):
+    from funasr_amd.paraformer_streaming import WavFrontendOnline
+    return WavFrontendOnline(cmvn_file=os.path.join(GOLD, "am.mvn"), lfr_m=7, lfr_n=6, dither=0.0, device=dev)
+
+
+def test_online_frontend_matches_reference_chunks(cuda):
+    g, cfg, sd, wav = load()
+    fe = frontend(cuda)
+    n1, stride = int(g["n1"]), 9600
+    cache = {}
+    k = 0
+    audio = wav[:n1]
+    for i in range(len(audio) // stride):
+        f, lens = fe(audio[i * stride:(i + 1) * stride][None], None, cache=cache, is_final=False)
+        ref = torch.from_numpy(g[f"feats_{k}"])
+        assert tuple(f.shape) == tuple(ref.shape) and int(lens[0]) == ref.shape[1]
+        assert (f.cpu() - ref).abs().max().item() < 5e-4, k
+        k += 1
+    audio = torch.cat((audio[(len(audio) // stride) * stride:], wav[n1:]))
+    n = len(audio) // stride + 1
+    for i in range(n):
+        piece = audio[i * stride:(i + 1) * stride]
+        fin = i == n - 1
+        if fin and len(piece) < 960:
+            break
+        f, lens = fe(piece[None], None, cache=cache, is_final=fin)
+        ref = torch.from_numpy(g[f"feats_{k}"])
+        assert tuple(f.shape) == tuple(ref.shape)
+        assert (f.cpu() - ref).abs().max().item() < 5e-4, k
+        k += 1
+    assert k == int(g["n_chunks"]) - 1                      # every chunk but the tail one goes through the frontend
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_stream_steps_match_reference_given_reference_features(cuda, use_graph):
+    from funasr_amd.paraformer_streaming import StreamBatch
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    sb = StreamBatch(model, 1, [0, 10, 5], 4, 1, use_graph=use_graph)
+    for i in range(int(g["n_chunks"])):
+        fin, tail, start_idx = (int(v) for v in g[f"flags_{i}"])
+        feats = None if tail else torch.from_numpy(g[f"feats_{i}"]).to(cuda)
+        ids, enc = sb.step(feats, is_final=bool(fin), tail_chunk=bool(tail), return_enc=True)
+        ref = torch.from_numpy(g[f"enc_{i}"])
+        assert tuple(enc.shape) == tuple(ref.shape), i
+        err = (enc.cpu() - ref).abs().max().item()
+        assert err < 1e-3, (i, err)
+        got = [t for t in ids[0] if t not in (0, 1, 2)]
+        assert got == g[f"tokens_{i}"].tolist(), (i, got, g[f"tokens_{i}"].tolist())
+        st = sb.peek()
+        assert st["start_idx"] == start_idx
+        assert abs(st["cif_alphas"][0] - float(g[f"cif_alphas_{i}"][0])) < 1e-4, i
+        assert (st["cif_hidden"][0] - torch.from_numpy(g[f"cif_hidden_{i}"])).abs().max().item() < 1e-3, i
+    sb.close()
+
+
+def test_graph_replay_equals_eager_bitwise_and_streams_are_independent(cuda):
+    from funasr_amd.paraformer_streaming import StreamBatch
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    gen = torch.Generator().manual_seed(5)
+    runs = {}
+    for name, S, graph in (("eager1", 1, False), ("graph1", 1, True), ("graph3", 3, True)):
+        sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=graph)
+        out = []
+        for rep in range(2):                                 # second pass after reset(): state fully cleared
+            gen.manual_seed(5)
+            for i in range(int(g["n_chunks"])):
+                fin, tail, _ = (int(v) for v in g[f"flags_{i}"])
+                feats = None
+                if not tail:
+                    f0 = torch.from_numpy(g[f"feats_{i}"])
+                    others = [f0 * 0.5 + 0.1 * torch.randn(f0.shape, generator=gen) for _ in range(S - 1)]
+                    feats = torch.cat([f0] + others, 0).to(cuda)
+                ids, enc = sb.step(feats, is_final=bool(fin), tail_chunk=bool(tail), return_enc=True)
+                out.append((rep, ids[0], enc[0].cpu()))
+            sb.reset()
+        runs[name] = out
+        sb.close()
+    n = int(g["n_chunks"])
+    for name in ("graph1", "graph3"):
+        for a, b in zip(runs["eager1"], runs[name]):
+            assert a[1] == b[1], name
+            assert torch.equal(a[2], b[2]), name
+    for a, b in zip(runs["eager1"][:n], runs["eager1"][n:]):  # reset() reproduces the session
+        assert a[1] == b[1] and torch.equal(a[2], b[2])
+
+
+def test_streaming_inference_api_two_calls_equals_reference_tokens(cuda):
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    fe = frontend(cuda)
+    n1 = int(g["n1"])
+    cache = {}
+    kw = dict(chunk_size=[0, 10, 5], encoder_chunk_look_back=4, decoder_chunk_look_back=1)
+    r1, meta = model.inference([wav[:n1]], key=["utt"], tokenizer=None, frontend=fe, cache=cache, is_final=False, **kw)
+    assert "batch_data_time" in meta
+    r2, _ = model.inference([wav[n1:]], key=["utt"], tokenizer=None, frontend=fe, cache=cache, is_final=True, **kw)
+    ref = [g[f"tokens_{i}"].tolist() for i in range(int(g["n_chunks"]))]
+    assert r1[0]["token_int"] == sum(ref[:5], [])
+    assert r2[0]["token_int"] == sum(ref[5:], [])
+    # the final call re-initialised the cache: the same audio again gives the same tokens
+    r3, _ = model.inference([wav], key=["utt"], tokenizer=None, frontend=fe, cache=cache, is_final=True, **kw)
+    assert r3[0]["token_int"] == sum(ref, [])
