@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (dry run of the N>1 code "
+                    "path with every rank on cuda:0 of a single-GPU box)")
     ap.add_argument("--cpu-clips", type=int, default=64, help="max clips of the same workload timed on the host "
                     "oracle (stops after ~20 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap on host threads for the CPU baseline (0 = all usable)")
@@ -80,12 +82,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP path is the only implementation")
+    if args.dist_backend == "gloo":
+        local_rank = 0                                       # dry run: all ranks share the one visible GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)        # backend "nccl" is RCCL on ROCm
+        if args.dist_backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)    # backend "nccl" is RCCL on ROCm
 
     from funasr_amd import _lib, dp, synth
     from funasr_amd.wav_frontend import WavFrontend
@@ -120,6 +127,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def max_over_ranks(x: float) -> float:
+        tt = torch.tensor([x], dtype=torch.float64, device="cpu" if args.dist_backend == "gloo" else device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     trace("workload resident in HBM")
     for i in range(args.warmup):
         res = step()
@@ -136,9 +148,7 @@ def main():
     lib.pf_prof_enable(0)
     trace(f"timed region done: {dt:.3f} s for {args.steps} steps")
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = max_over_ranks(dt)
 
     if rank != 0:
         if world > 1:
@@ -159,7 +169,7 @@ def main():
     gemm = prof["gemm_f32_mfma"]
     ach = gemm["work_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12 if gemm["ms_per_step"] > 0 else 0.0
     roofline = dict(bound="mfma", kernel="gemm_f32_mfma_kernel", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic("gemm_f32_mfma_kernel"),
                     flops_per_launch=gemm["work_per_step"] / max(gemm["launches_per_step"], 1),
                     avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
                     launches_per_step=gemm["launches_per_step"])
@@ -191,6 +201,27 @@ def main():
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, written by
+    tools/summarize_prof.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, with
+    the guide's gfx950 corrections). null when no summary is present: PMC passes are not run inside the timed bench."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            t = json.load(f)
+        rows = [v for k, v in t["kernels"].items() if k.startswith(kernel)]
+        n = sum(r["launches"] for r in rows)
+        if n == 0:
+            return None
+        b = sum((r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in rows) / n
+        return {"bytes_per_launch": round(b), "source": os.path.basename(files[-1])}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def host_cores() -> int:
@@ -233,7 +264,7 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu_res, args):
         trace(f"cpu probe: 3 s clip in {probe:.2f} s on {cores} threads")
         budget_s = 20.0
         full = clips[0].numel() / 16000.0
-        n_full = int(min(len(clips), args.cpu_clips, (budget_s * rate) // full))
+        n_full = int(min(len(clips), args.cpu_clips)) if (budget_s * rate) // full >= 1 else 0   # loop stops at budget_s
         match = None
         if n_full >= 1:
             sample = clips[:n_full]

@@ -102,6 +102,7 @@ SIGNATURES = {
     "pf_stream_peek": (C.c_int, [_vp, _vp, _vp, _pi32]),
     "pf_frontend_fbank": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "pf_frontend_lfr_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "pf_set_skinny_max_m": (C.c_int, [_i32]),
     "pf_k_gemm_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pf_k_gemm_argmax_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_layernorm": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),

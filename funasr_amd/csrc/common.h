@@ -63,6 +63,9 @@ struct GemmArgs {
     int vec_epilogue;            // set by the launcher: all epilogue operands allow aligned float4 access
 };
 int launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
+// small-M weight-streaming variant (gemm_skinny.hip); same contract, no fused arg-max
+bool gemm_skinny_applicable(const GemmArgs& a);
+int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);
 
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
                      int M, int D, int Dpad, float eps, hipStream_t stream);

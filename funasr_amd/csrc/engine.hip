@@ -144,7 +144,18 @@ static int upload_lens(DevBuf& buf, const int32_t* host, int B, hipStream_t s) {
 }
 
 // Instrumented launch helpers ---------------------------------------------------------------------------
+// Kernel choice is by CALLER, never by batch size, so that a clip's (or a stream's) result does not depend on what
+// else is in the batch: the offline path always takes the 128 x 128 tile kernel, the streaming step always the small-M
+// weight-streaming kernel (whose K slicing depends on K only). g_skinny_max_m is a test hook for pf_k_gemm_f32.
+static int g_skinny_max_m = 0;
+static thread_local bool g_stream_mode = false;
+struct StreamModeScope {
+    bool prev;
+    StreamModeScope() : prev(g_stream_mode) { g_stream_mode = true; }
+    ~StreamModeScope() { g_stream_mode = prev; }
+};
 static int gemm(const GemmArgs& a, hipStream_t s) {
+    if ((g_stream_mode || a.M <= g_skinny_max_m) && gemm_skinny_applicable(a)) return launch_gemm_skinny(a, s);
     ProfScope ps(PROF_GEMM, 2.0 * a.M * (double)a.N * a.K, s);
     return launch_gemm_f32(a, s);
 }
@@ -418,6 +429,12 @@ static int vocab_project(const float* hidden, int M, int D, const float* W, cons
         return 0;
     }
     if (!ids) return 0;
+    if (g_stream_mode && D % 16 == 0) {
+        // small M (streaming): weight-streaming GEMM into a scratch logits block, then a row arg-max
+        if (pval.ensure(sizeof(float) * (size_t)M * V)) return -2;
+        if ((rc = gemm_simple(hidden, D, W, D, bias, pval.as<float>(), V, M, V, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
+        return launch_argmax_rows(pval.as<float>(), V, M, V, ids, s);
+    }
     const int nparts = 2 * ceil_div(V, 128);
     if (pval.ensure(sizeof(float) * (size_t)M * nparts) || pidx.ensure(sizeof(int) * (size_t)M * nparts)) return -2;
     GemmArgs g{};
@@ -495,6 +512,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     const int W = tail ? st->keep : st->keep + n;
     const int M = S * W, Nmax = st->Nmax;
     const StreamDev* dev = st->dev_state.as<StreamDev>();
+    StreamModeScope small_m_kernels;
     int rc;
     // ---- workspaces of the three handles (grow-only; the first eager call with a shape allocates)
     {
@@ -1304,6 +1322,9 @@ int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, 
 }
 
 // -------------------------------------------------------------------------------------------- single kernels
+/* test hook: pf_k_gemm_f32 takes the small-M kernel for M <= m (default 0 = always the tile kernel) */
+int pf_set_skinny_max_m(int32_t m) { g_skinny_max_m = m; return 0; }
+
 int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R1,
                   int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                   int32_t relu, void* stream) {

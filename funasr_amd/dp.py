@@ -39,15 +39,22 @@ def unpack_arena(arena: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
         raise ValueError(f"arena holds {arena.numel()} elements, parameters need {off}")
 
 
+def _collective_device(t: torch.Tensor) -> torch.Tensor:
+    """RCCL ("nccl") moves device tensors; gloo (CPU tests, single-GPU dry runs) needs host tensors."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        return t.cpu()
+    return t
+
+
 def broadcast_model(model: torch.nn.Module, src: int = 0) -> int:
     """Ship rank `src`'s weights to every rank as ONE packed arena; returns the arena size in bytes. Handles created
     from the parameters (HipModule) are marked dirty so the device copy is refreshed before the next forward."""
     params = [p for _, p in model.named_parameters()]
     if not params:
         return 0
-    arena = pack_arena(params)
+    arena = _collective_device(pack_arena(params))
     dist.broadcast(arena, src=src)
-    unpack_arena(arena, params)
+    unpack_arena(arena.to(params[0].device), params)
     for m in model.modules():
         if hasattr(m, "mark_dirty"):
             m.mark_dirty()
@@ -74,7 +81,7 @@ def gather_hypotheses(ids: Sequence[Sequence[int]], n_pad: int, dst: int = 0, de
     """Every rank contributes the same number of clips B. Returns on `dst` a list (one entry per rank) of per-clip id
     lists, elsewhere None."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    mine = pack_hypotheses(ids, n_pad, device)
+    mine = _collective_device(pack_hypotheses(ids, n_pad, device))
     bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
     dist.gather(mine, bufs, dst=dst)
     if rank != dst:

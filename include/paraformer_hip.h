@@ -216,6 +216,9 @@ int pf_frontend_lfr_cmvn(pf_frontend* f, const float* frames_dev, int32_t T, int
 /* -------------------------------------------------------------------------------- single kernels (tests / bench)
  * Thin wrappers over the individual gfx950 kernels so that parity tests and the roofline bench can drive one
  * kernel at a time through the same ABI. All pointers are device pointers. */
+/* test hook: pf_k_gemm_f32 takes the small-M weight-streaming kernel (the streaming step's GEMM) for M <= m;
+ * default 0 = the 128x128 tile kernel (the offline path's GEMM) */
+int pf_set_skinny_max_m(int32_t m);
 int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R1,
                   int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc, int32_t M, int32_t N,
                   int32_t K, int32_t relu, void* stream);

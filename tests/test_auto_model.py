@@ -72,7 +72,7 @@ def test_generate_matches_oracle_text(model_dir, cuda):
     paths = list(model_dir["waves"])
     res = am.generate(input=os.path.join(model_dir["dir"], "wav.scp"))
     assert [r["key"] for r in res] == ["key_0", "key_1", "key_2"]
-    assert am.speed_stats["rtf_avg"] is not None and float(am.speed_stats["rtf"]) > 0
+    assert am.speed_stats["rtf_avg"] is not None and float(am.speed_stats["rtf"]) >= 0
     # the same three clips through the CPU oracle (bs 1, like the reference on cpu) -> ids -> text
     cmvn = am.kwargs["frontend"].cmvn
     tok = CharTokenizer(token_list=VOCAB)

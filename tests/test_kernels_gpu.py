@@ -15,9 +15,21 @@ def _rel(a, b):
     return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
 
 
+@pytest.fixture(params=["tile", "small_m"])
+def gemm_path(request):
+    """the 128x128 tile kernel (gemm_f32.hip) and the small-M weight-streaming kernel (gemm_skinny.hip) share one
+    contract; run every GEMM test through both"""
+    from funasr_amd import _lib
+    lib = _lib.load()
+    lib.pf_set_skinny_max_m(0 if request.param == "tile" else 1 << 30)
+    yield request.param
+    lib.pf_set_skinny_max_m(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 512, 512), (500, 1536, 576), (333, 8404, 512),
-                                   (1000, 512, 2048), (64, 1, 64), (7, 130, 96)])
-def test_gemm_f32_matches_fp64(cuda, M, N, K):
+                                   (1000, 512, 2048), (64, 1, 64), (7, 130, 96), (15, 1536, 576), (20, 8404, 512),
+                                   (960, 2048, 512)])
+def test_gemm_f32_matches_fp64(cuda, gemm_path, M, N, K):
     from funasr_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g)
@@ -34,7 +46,7 @@ def test_gemm_f32_matches_fp64(cuda, M, N, K):
     assert _rel(out2, ref2) < 2e-6
 
 
-def test_gemm_f32_strided_and_inplace_residual(cuda):
+def test_gemm_f32_strided_and_inplace_residual(cuda, gemm_path):
     from funasr_amd import ops
     g = torch.Generator().manual_seed(5)
     big = torch.randn(300, 1536, generator=g).to(cuda)

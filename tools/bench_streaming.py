@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Streaming step benchmark (BASELINE configs[4]: Paraformer-large-streaming, chunk 600 ms, hipGraph-captured step).
+
+Times `pf_stream_step` for S lock-step streams on synthetic online features (random-init Paraformer-large online
+architecture: 50 encoder blocks, 16 decoder blocks with sanm_shfit 5, vocab 8404), eager vs hipGraph replay.
+Prints one JSON line per configuration: chunks/s, audio-seconds/s (= S * 0.6 s per step), step latency."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, nargs="+", default=[1, 16, 64])
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    args = ap.parse_args()
+    from funasr_amd import synth
+    from funasr_amd.paraformer_streaming import ParaformerStreaming, StreamBatch
+    import copy
+
+    dev = torch.device("cuda:0")
+    cfg = copy.deepcopy(synth.PARAFORMER_LARGE)
+    cfg["decoder"]["sanm_shfit"] = 5
+    model = ParaformerStreaming.from_config(cfg)
+    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
+    model = model.to(dev)
+    for S in args.streams:
+        for graph in (False, True):
+            sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=graph, pe_rows=16384)
+            g = torch.Generator().manual_seed(S)
+            feats = (torch.randn(S, 10, 560, generator=g) * 0.8).to(dev)
+            ntok = 0
+            for _ in range(args.warmup):
+                sb.step(feats)
+            torch.cuda.synchronize()
+            lat = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                t1 = time.perf_counter()
+                ids = sb.step(feats)
+                lat.append(time.perf_counter() - t1)
+                ntok += sum(len(r) for r in ids)
+            dt = time.perf_counter() - t0
+            lat.sort()
+            print(json.dumps({"metric": "streaming chunks/s (600 ms chunk, Paraformer-large-online)", "streams": S,
+                              "hipgraph": graph, "steps": args.steps, "chunks_per_s": round(S * args.steps / dt, 1),
+                              "audio_s_per_s": round(S * args.steps * 0.6 / dt, 1),
+                              "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3),
+                              "tokens_per_chunk": round(ntok / (S * args.steps), 2), "dtype": "f32"}), flush=True)
+            sb.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,11 +70,23 @@ def main():
     print("| kernel | launches | read MB/launch (corrected) | write MB/launch |")
     print("|---|---|---|---|")
     keys = sorted(set(fetch) | set(write), key=lambda k: -(fetch[k][0] if k in fetch else 0))
+    traffic = {}
     for k in keys[:24]:
         fr = fetch[k][0] * 1024 * 2 / max(fetch[k][1], 1) / 1e6 if k in fetch else float("nan")
         wr = write[k][0] * 1024 / max(write[k][1], 1) / 1e6 if k in write else float("nan")
         n = fetch[k][1] if k in fetch else write[k][1]
         print(f"| {k} | {n} | {fr:.3f} | {wr:.3f} |")
+        if k in fetch and k in write:
+            traffic[k] = dict(launches=n, read_bytes_per_launch=fr * 1e6, write_bytes_per_launch=wr * 1e6)
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_traffic.json")
+    try:
+        with open(out, "w") as f:
+            json.dump(dict(tag=tag, note="FETCH_SIZE KiB x1024 x2 (gfx950 under-count of wide reads), WRITE_SIZE KiB x1024; "
+                                        "separate rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
+                           kernels=traffic), f, indent=1)
+    except OSError:
+        pass
 
 
 if __name__ == "__main__":
