@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand-mode measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (dry run of the N>1 code "
                     "path with every rank on cuda:0 of a single-GPU box)")
     ap.add_argument("--cpu-clips", type=int, default=64, help="max clips of the same workload timed on the host "
@@ -181,6 +182,40 @@ def main():
         if prof[nm]["ms_per_step"] > 0:
             kernels[nm]["GBps"] = round(prof[nm]["work_per_step"] / (prof[nm]["ms_per_step"] * 1e-3) / 1e9, 1)
 
+    # ---- secondary measurement (N = 1 only): the bf16-operand throughput mode of the encoder on the same batch,
+    #      with its token agreement against the fp32 parity mode measured, not assumed
+    bf16_mode = None
+    if world == 1 and not args.no_bf16:
+        try:
+            model.encoder.set_precision("bf16")
+            for _ in range(max(1, args.warmup)):
+                res16 = step()
+            torch.cuda.synchronize()
+            lib.pf_prof_reset()
+            lib.pf_prof_enable(1)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                res16 = step()
+            torch.cuda.synchronize()
+            dt16 = time.perf_counter() - t1
+            lib.pf_prof_enable(0)
+            ms, work, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+            lib.pf_prof_read(0, C.byref(ms), C.byref(work), C.byref(n))
+            same = sum(1 for a, b in zip(res["raw_ids"], res16["raw_ids"]) if a == b)
+            same_n = sum(1 for a, b in zip(res["token_num"], res16["token_num"]) if a == b)
+            tok = sum(len(a) for a in res["raw_ids"])
+            diff = sum(sum(1 for x, y in zip(a, b) if x != y) + abs(len(a) - len(b)) for a, b in zip(res["raw_ids"], res16["raw_ids"]))
+            bf16_mode = {"value": round(B * args.seconds * args.steps / dt16, 1), "unit": "audio-s/s",
+                         "ms_per_step": round(dt16 / args.steps * 1e3, 2), "dtype": "bf16 operands (encoder GEMMs + attention), "
+                         "fp32 accumulate/residual/LN/softmax; predictor + decoder fp32",
+                         "gemm_tflops_all_launches": round(work.value / (ms.value * 1e-3) / 1e12, 1) if ms.value > 0 else None,
+                         "clips_with_identical_token_ids_vs_fp32": f"{same}/{B}",
+                         "clips_with_identical_token_count_vs_fp32": f"{same_n}/{B}",
+                         "token_positions_differing": f"{diff}/{tok}"}
+            trace(f"bf16-operand mode: {bf16_mode['value']} audio-s/s, identical ids {same}/{B}")
+        finally:
+            model.encoder.set_precision("fp32")
+
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         trace("cpu baseline (oracle on host cores) ...")
@@ -196,7 +231,7 @@ def main():
                                f"{B} x {args.seconds:g} s 16 kHz clips per GPU, wav in HBM -> token ids on host",
                    "clips_per_gpu": B, "clip_seconds": args.seconds, "parallelism": f"utterance-dp{world}",
                    "tokens_per_clip": round(sum(res["token_num"]) / len(res["token_num"]), 1)},
-        "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels, "bf16_mode": bf16_mode,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pf_encoder_destroy": (None, [_vp]),
     "pf_encoder_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "pf_encoder_missing": (C.c_int, [_vp]),
+    "pf_encoder_set_precision": (C.c_int, [_vp, _i32]),
     "pf_encoder_forward": (C.c_int, [_vp, _vp, _pi32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "pf_predictor_create": (_vp, [C.POINTER(pf_predictor_config)]),
     "pf_predictor_destroy": (None, [_vp]),
@@ -104,10 +105,14 @@ SIGNATURES = {
     "pf_frontend_lfr_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "pf_set_skinny_max_m": (C.c_int, [_i32]),
     "pf_k_gemm_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pf_k_gemm_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pf_k_gemm_bf16_time": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
+    "pf_k_cast_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "pf_k_gemm_argmax_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_layernorm": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "pf_k_fsmn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pf_k_attention_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pf_k_attention_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "pf_k_cif": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_gemm_f32_time": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
     # profiling hooks used by bench.py (not part of the reference boundary)

@@ -45,6 +45,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// fp32 -> bf16, round to nearest even (finite inputs)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned int u = __builtin_bit_cast(unsigned int, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+    return __builtin_bit_cast(float, (unsigned int)h << 16);
+}
+
 // ---------------------------------------------------------------- kernel launchers
 // (all take device pointers; `stream` is the HIP stream the caller owns)
 
@@ -61,14 +71,19 @@ struct GemmArgs {
     // kernel does not write C but per-(row, column-block) partial maxima
     float* amax_val; int* amax_idx; int amax_ld;
     int vec_epilogue;            // set by the launcher: all epilogue operands allow aligned float4 access
+    int ab_bf16;                 // A and W hold bf16 (lda / ldw in ELEMENTS); fp32 accumulate and epilogue
+    int c_bf16;                  // C is written as bf16 (ldc in elements)
 };
 int launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 // small-M weight-streaming variant (gemm_skinny.hip); same contract, no fused arg-max
 bool gemm_skinny_applicable(const GemmArgs& a);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);
 
+int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t stream);
+
+// out_bf16: y is a bf16 buffer (ldy in elements)
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
-                     int M, int D, int Dpad, float eps, hipStream_t stream);
+                     int M, int D, int Dpad, float eps, hipStream_t stream, int out_bf16 = 0);
 
 int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
                         hipStream_t stream);
@@ -80,6 +95,7 @@ struct FsmnArgs {
     float* out;       int ldo;
     const int* lens;              // device int32 [B]: valid rows per sequence
     int B, T, C, K, left_pad;
+    int in_bf16;                  // `in` holds bf16 (ldin in elements)
 };
 int launch_fsmn(const FsmnArgs& a, hipStream_t stream);
 
@@ -98,5 +114,7 @@ struct AttnArgs {
     const int* n1_dev; int n1_stride;   // device int32, element b * n1_stride (stride 0 = one value for all)
 };
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
+// bf16 Q/K/V in, bf16 O out (strides in elements), fp32 softmax statistics and accumulators
+int launch_attention_bf16(const AttnArgs& a, hipStream_t stream);
 
 }  // namespace pf

@@ -72,7 +72,10 @@ struct Tensor {
 
 struct TensorTable {
     std::map<std::string, Tensor> t;
-    ~TensorTable() { for (auto& kv : t) if (kv.second.d) (void)hipFree(kv.second.d); }
+    ~TensorTable() {
+        for (auto& kv : t) if (kv.second.d) (void)hipFree(kv.second.d);
+        for (auto& kv : b16) if (kv.second) (void)hipFree(kv.second);
+    }
     int add(const std::string& name, int64_t numel) {
         Tensor x; x.numel = numel;
         PF_HIP_TRY(hipMalloc((void**)&x.d, sizeof(float) * (size_t)numel));
@@ -123,6 +126,27 @@ struct TensorTable {
         return n;
     }
     const float* get(const std::string& name) const { return t.at(name).d; }
+    // bf16 copy of a (repacked) tensor for the bf16-operand mode, made on first use and dropped when the fp32
+    // master changes
+    std::map<std::string, unsigned short*> b16;
+    void drop_bf16() {
+        for (auto& kv : b16) if (kv.second) (void)hipFree(kv.second);
+        b16.clear();
+    }
+    const unsigned short* get_bf16(const std::string& name, hipStream_t s) {
+        auto it = b16.find(name);
+        if (it != b16.end()) return it->second;
+        const Tensor& x = t.at(name);
+        const size_t n = x.kind == 1 ? (size_t)x.rows * x.cols_pad : (size_t)x.numel;
+        unsigned short* p = nullptr;
+        if (n % 4 != 0 || hipMalloc((void**)&p, sizeof(unsigned short) * n) != hipSuccess) {
+            set_error("bf16 copy of " + name + " failed");
+            return nullptr;
+        }
+        if (launch_cast_bf16(x.d, p, n, s)) { (void)hipFree(p); return nullptr; }
+        b16[name] = p;
+        return p;
+    }
 };
 
 static int check_device() {
@@ -243,6 +267,8 @@ static int frontend_default_tables(Frontend* f) {
 struct EncLayerW {
     const float *n1g, *n1b, *qkv_w, *qkv_b, *fsmn_w, *out_w, *out_b, *n2g, *n2b, *w1, *b1, *w2, *b2;
     int in_dim, in_pad;
+    const unsigned short *qkv_w16 = nullptr, *out_w16 = nullptr, *w1_16 = nullptr, *w2_16 = nullptr;   // bf16 mode
+    std::string prefix;
 };
 
 struct Encoder {
@@ -252,6 +278,8 @@ struct Encoder {
     bool resolved = false;
     DevBuf x, xn, qkv, mem, ctx, ffn, lens, pe;
     int pe_T = 0;
+    int precision = 0;               // 0: fp32 MFMA everywhere (parity mode); 1: bf16 operands for GEMMs + attention
+    DevBuf xn16, qkv16, ctx16, ffn16;
 };
 
 static void enc_layer_names(std::vector<std::pair<std::string, int>>& out, const pf_encoder_config& c) {
@@ -271,7 +299,8 @@ static int encoder_resolve(Encoder* e) {
     for (auto& nm : names) {
         const std::string& p = nm.first;
         EncLayerW w;
-        w.in_dim = nm.second; w.in_pad = round_up(nm.second, 32);
+        w.prefix = p;
+        w.in_dim = nm.second; w.in_pad = round_up(nm.second, 64);
         w.n1g = e->tt.get(p + "norm1.weight"); w.n1b = e->tt.get(p + "norm1.bias");
         w.qkv_w = e->tt.get(p + "self_attn.linear_q_k_v.weight"); w.qkv_b = e->tt.get(p + "self_attn.linear_q_k_v.bias");
         w.fsmn_w = e->tt.get(p + "self_attn.fsmn_block.weight");
@@ -326,6 +355,52 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
     float* ffn = e->ffn.as<float>();
     const int* lens = cc ? cc->lens : e->lens.as<int>();
     int rc;
+    if (e->precision == 1 && !cc) {
+        // ---- bf16-operand mode: LN writes bf16, GEMMs and attention take bf16 operands with fp32 accumulation, the
+        //      residual stream x, the FSMN memory and every epilogue stay fp32
+        unsigned short* xn16 = e->xn16.as<unsigned short>();
+        unsigned short* qkv16 = e->qkv16.as<unsigned short>();
+        unsigned short* ctx16 = e->ctx16.as<unsigned short>();
+        unsigned short* ffn16 = e->ffn16.as<unsigned short>();
+        auto gemm16 = [&](const unsigned short* A, int lda, const unsigned short* W, int ldw, const float* bias, void* C,
+                          int ldc, int N, int K, int relu, const float* R1, int ldr1, const float* R2, int ldr2, int c16) {
+            GemmArgs g{};
+            g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = reinterpret_cast<const float*>(W); g.ldw = ldw;
+            g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = reinterpret_cast<float*>(C); g.ldc = ldc;
+            g.M = M; g.N = N; g.K = K; g.relu = relu; g.ab_bf16 = 1; g.c_bf16 = c16;
+            ProfScope ps(PROF_GEMM, 2.0 * M * (double)N * K, s);
+            return launch_gemm_f32(g, s);
+        };
+        {
+            ProfScope ps(PROF_LN, 6.0 * M * (double)w.in_dim, s);
+            if ((rc = launch_layernorm(x_in, ld_in, w.n1g, w.n1b, reinterpret_cast<float*>(xn16), w.in_pad, M, w.in_dim,
+                                       w.in_pad, c.ln_eps, s, 1))) return rc;
+        }
+        if ((rc = gemm16(xn16, w.in_pad, w.qkv_w16, w.in_pad, w.qkv_b, qkv16, 3 * D, 3 * D, w.in_pad, 0, nullptr, 0, nullptr, 0, 1)))
+            return rc;
+        FsmnArgs fa{};
+        fa.in = reinterpret_cast<const float*>(qkv16 + 2 * D); fa.ldin = 3 * D; fa.in_bf16 = 1; fa.w = w.fsmn_w; fa.R = nullptr;
+        fa.out = mem; fa.ldo = D; fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size;
+        fa.left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
+        if ((rc = fsmn(fa, s))) return rc;
+        AttnArgs aa{};
+        aa.Q = reinterpret_cast<const float*>(qkv16); aa.ldq = 3 * D; aa.K = reinterpret_cast<const float*>(qkv16 + D);
+        aa.ldk = 3 * D; aa.V = reinterpret_cast<const float*>(qkv16 + 2 * D); aa.ldv = 3 * D;
+        aa.O = reinterpret_cast<float*>(ctx16); aa.ldo = D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
+        aa.scale = powf((float)(D / c.n_heads), -0.5f);
+        {
+            ProfScope ps(PROF_ATTN, 4.0 * B * (double)T * T * D, s);
+            if ((rc = launch_attention_bf16(aa, s))) return rc;
+        }
+        const float* resid16 = (w.in_dim == D) ? x_in : nullptr;
+        if ((rc = gemm16(ctx16, D, w.out_w16, D, w.out_b, x, D, D, D, 0, mem, D, resid16, ld_in, 0))) return rc;
+        {
+            ProfScope ps(PROF_LN, 6.0 * M * (double)D, s);
+            if ((rc = launch_layernorm(x, D, w.n2g, w.n2b, reinterpret_cast<float*>(xn16), D, M, D, D, c.ln_eps, s, 1))) return rc;
+        }
+        if ((rc = gemm16(xn16, D, w.w1_16, D, w.b1, ffn16, F, F, D, 1, nullptr, 0, nullptr, 0, 1))) return rc;
+        return gemm16(ffn16, F, w.w2_16, F, w.b2, x, D, D, F, 0, nullptr, 0, x, D, 0);
+    }
     // norm1 -> fused QKV projection
     if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
     if ((rc = gemm_simple(xn, w.in_pad, w.qkv_w, w.in_pad, w.qkv_b, qkv, 3 * D, M, 3 * D, w.in_pad, 0, nullptr, 0,
@@ -508,7 +583,7 @@ static int stream_reset(Stream* st, hipStream_t s) {
 static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t s) {
     Encoder* e = st->e; Predictor* p = st->p; Decoder* d = st->d;
     const pf_encoder_config& ec = e->cfg;
-    const int S = st->S, D = ec.d_model, F = ec.ffn_dim, Din = ec.input_dim, Dpad = round_up(Din, 32);
+    const int S = st->S, D = ec.d_model, F = ec.ffn_dim, Din = ec.input_dim, Dpad = round_up(Din, 64);
     const int W = tail ? st->keep : st->keep + n;
     const int M = S * W, Nmax = st->Nmax;
     const StreamDev* dev = st->dev_state.as<StreamDev>();
@@ -799,7 +874,7 @@ pf_encoder* pf_encoder_create(const pf_encoder_config* cfg) {
     int rc = 0;
     for (auto& nm : names) {
         const std::string& p = nm.first;
-        const int in = nm.second, in_pad = round_up(in, 32);
+        const int in = nm.second, in_pad = round_up(in, 64);
         rc |= e->tt.add(p + "norm1.weight", in);
         rc |= e->tt.add(p + "norm1.bias", in);
         rc |= (in_pad == in) ? e->tt.add(p + "self_attn.linear_q_k_v.weight", (int64_t)3 * D * in)
@@ -829,7 +904,16 @@ int pf_encoder_set_tensor(pf_encoder* eh, const char* name, const float* data, i
     Encoder* e = reinterpret_cast<Encoder*>(eh);
     PF_REQUIRE(e && name && data, "encoder_set_tensor: null");
     e->resolved = false;
+    e->tt.drop_bf16();
     return e->tt.set(name, data, numel);
+}
+/* 0 = fp32 MFMA (parity mode, default), 1 = bf16 operands for the GEMMs and the attention (fp32 accumulate, fp32
+ * residual stream / LayerNorm statistics / softmax / FSMN): the throughput mode of BASELINE configs[1] */
+int pf_encoder_set_precision(pf_encoder* eh, int32_t mode) {
+    Encoder* e = reinterpret_cast<Encoder*>(eh);
+    PF_REQUIRE(e && (mode == 0 || mode == 1), "encoder_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+    e->precision = mode;
+    return 0;
 }
 int pf_encoder_missing(const pf_encoder* eh) {
     const Encoder* e = reinterpret_cast<const Encoder*>(eh);
@@ -846,8 +930,21 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
     if (!e->resolved && (rc = encoder_resolve(e))) return rc;
     const pf_encoder_config& c = e->cfg;
     const size_t M = (size_t)B * T;
-    const int D = c.d_model, F = c.ffn_dim, Din = c.input_dim, Dpad = round_up(Din, 32);
+    const int D = c.d_model, F = c.ffn_dim, Din = c.input_dim, Dpad = round_up(Din, 64);
     const int Fbuf = F > Din ? F : Din;
+    if (e->precision == 1) {
+        if (e->xn16.ensure(sizeof(unsigned short) * M * (Dpad > D ? Dpad : D)) || e->qkv16.ensure(sizeof(unsigned short) * M * 3 * D) ||
+            e->ctx16.ensure(sizeof(unsigned short) * M * D) || e->ffn16.ensure(sizeof(unsigned short) * M * F))
+            return -2;
+        for (auto& w : e->layers) {
+            if (w.qkv_w16) continue;
+            w.qkv_w16 = e->tt.get_bf16(w.prefix + "self_attn.linear_q_k_v.weight", s);
+            w.out_w16 = e->tt.get_bf16(w.prefix + "self_attn.linear_out.weight", s);
+            w.w1_16 = e->tt.get_bf16(w.prefix + "feed_forward.w_1.weight", s);
+            w.w2_16 = e->tt.get_bf16(w.prefix + "feed_forward.w_2.weight", s);
+            if (!w.qkv_w16 || !w.out_w16 || !w.w1_16 || !w.w2_16) return -2;
+        }
+    }
     if (e->x.ensure(sizeof(float) * M * D) || e->xn.ensure(sizeof(float) * M * (Dpad > D ? Dpad : D)) ||
         e->qkv.ensure(sizeof(float) * M * 3 * D) || e->mem.ensure(sizeof(float) * M * D) ||
         e->ctx.ensure(sizeof(float) * M * D) || e->ffn.ensure(sizeof(float) * M * Fbuf))
@@ -1331,6 +1428,44 @@ int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, cons
     return gemm_simple(A, lda, W, ldw, bias, C, ldc, M, N, K, relu, R1, ldr1, R2, ldr2,
                        reinterpret_cast<hipStream_t>(stream));
 }
+/* bf16-operand GEMM (throughput mode): A [M,K] bf16, W [N,K] bf16, fp32 accumulate, fp32 bias/residuals, C fp32 or
+ * bf16 (c_bf16); strides in elements */
+int pf_k_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const float* R1,
+                   int32_t ldr1, const float* R2, int32_t ldr2, void* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+                   int32_t relu, int32_t c_bf16, void* stream) {
+    GemmArgs g{};
+    g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = reinterpret_cast<const float*>(W); g.ldw = ldw;
+    g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = reinterpret_cast<float*>(C); g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.relu = relu; g.ab_bf16 = 1; g.c_bf16 = c_bf16;
+    return launch_gemm_f32(g, reinterpret_cast<hipStream_t>(stream));
+}
+int pf_k_gemm_bf16_time(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, void* C, int32_t ldc,
+                        int32_t M, int32_t N, int32_t K, int32_t c_bf16, int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(iters > 0 && ms_out, "gemm_time: iters > 0");
+    GemmArgs g{};
+    g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = reinterpret_cast<const float*>(W); g.ldw = ldw;
+    g.bias = bias; g.C = reinterpret_cast<float*>(C); g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.ab_bf16 = 1; g.c_bf16 = c_bf16;
+    int rc;
+    for (int i = 0; i < 3; ++i) if ((rc = launch_gemm_f32(g, s))) return rc;
+    hipEvent_t a, b;
+    PF_HIP_TRY(hipEventCreate(&a));
+    PF_HIP_TRY(hipEventCreate(&b));
+    PF_HIP_TRY(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if ((rc = launch_gemm_f32(g, s))) return rc;
+    PF_HIP_TRY(hipEventRecord(b, s));
+    PF_HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    PF_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_out = ms / iters;
+    return 0;
+}
+/* fp32 -> bf16 (round to nearest even), n elements */
+int pf_k_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
+    return launch_cast_bf16(x, reinterpret_cast<unsigned short*>(y), (size_t)n, reinterpret_cast<hipStream_t>(stream));
+}
 int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t M,
                          int32_t N, int32_t K, int32_t* ids, float* sval, int32_t* sidx, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1361,6 +1496,15 @@ int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk,
     aa.Q = Q; aa.ldq = ldq; aa.K = K; aa.ldk = ldk; aa.V = V; aa.ldv = ldv; aa.O = O; aa.ldo = ldo;
     aa.klens = klens_dev; aa.B = B; aa.H = H; aa.Tq = Tq; aa.Tk = Tk; aa.scale = scale;
     return attention(aa, 4.0 * B * (double)Tq * Tk * H * 128, reinterpret_cast<hipStream_t>(stream));
+}
+int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                        int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
+                        void* stream) {
+    AttnArgs aa{};
+    aa.Q = reinterpret_cast<const float*>(Q); aa.ldq = ldq; aa.K = reinterpret_cast<const float*>(K); aa.ldk = ldk;
+    aa.V = reinterpret_cast<const float*>(V); aa.ldv = ldv; aa.O = reinterpret_cast<float*>(O); aa.ldo = ldo;
+    aa.klens = klens_dev; aa.B = B; aa.H = H; aa.Tq = Tq; aa.Tk = Tk; aa.scale = scale;
+    return launch_attention_bf16(aa, reinterpret_cast<hipStream_t>(stream));
 }
 int pf_k_cif(const float* alphas, const float* hidden, int32_t B, int32_t T, int32_t D, int32_t N, float* peaks,
              int32_t* n_fires, float* embeds, void* stream) {

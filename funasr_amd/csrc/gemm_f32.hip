@@ -23,22 +23,36 @@
 //   * XCD-aware block order: consecutive workgroup ids round-robin over the 8 XCDs, so XCD x gets the row
 //     panels x, x+8, ... and walks all column blocks of a panel back to back: the A panel is fetched from HBM
 //     once and re-read from that XCD's L2.
+//
+// The same kernel is instantiated for bf16 OPERANDS (throughput mode, v_mfma_f32_32x32x16_bf16, fp32 accumulate,
+// fp32 bias / residual epilogue, fp32 or bf16 output): an LDS row is 128 B either way (32 floats or 64 bf16), so
+// staging, swizzle and read addressing are byte-identical; only the MFMA and the K extent of a tile differ.
 #include "common.h"
 
 namespace pf {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int TILE_FLOATS = BM * BK;                 // one operand tile
-constexpr int BUF_FLOATS = 2 * TILE_FLOATS;          // A tile + B tile
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;                        // one LDS row = one 128-B line of an operand row
+constexpr int TILE_FLOATS = BM * ROW_BYTES / 4;       // one operand tile (4096 floats = 16 KB)
+constexpr int BUF_FLOATS = 2 * TILE_FLOATS;           // A tile + B tile
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {
+    unsigned int u = __builtin_bit_cast(unsigned int, f);
+    u += 0x7fffu + ((u >> 16) & 1u);                  // round to nearest even (inputs are finite)
+    return (unsigned short)(u >> 16);
+}
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int MODE_ARGMAX = 4;   // MODE bit 0: + R1, bit 1: + R2; 4: fused arg-max instead of a C store
 
-template <int MODE>
+template <int MODE, bool BF16>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int nM, int nN) {
+    constexpr int ES = BF16 ? 2 : 4;                  // operand element size
+    constexpr int BK = ROW_BYTES / ES;                // k extent of one tile: 32 floats / 64 bf16
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS];   // 64 KB, the only LDS object
 
     // ---- XCD-aware tile order
@@ -56,28 +70,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
 
     // ---- LDS-DMA source addresses: wave w stages rows [32w, 32w+32) of both tiles, 4 pieces of 8 rows each;
     //      lane l of a piece lands at row (l >> 3), physical chunk (l & 7)
-    const float* asrc[4];
-    const float* wsrc[4];
+    const char* asrc[4];
+    const char* wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = wave * 32 + i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         int row = m0 + r;
         row = row < p.M ? row : p.M - 1;
-        asrc[i] = p.A + (size_t)row * p.lda + c * 4;
+        asrc[i] = reinterpret_cast<const char*>(p.A) + ((size_t)row * p.lda) * ES + c * 16;
         int col = n0 + r;
         col = col < p.N ? col : p.N - 1;
-        wsrc[i] = p.W + (size_t)col * p.ldw + c * 4;
+        wsrc[i] = reinterpret_cast<const char*>(p.W) + ((size_t)col * p.ldw) * ES + c * 16;
     }
     const int nk = p.K / BK;
 
     auto stage = [&](int buf, int kt) {
-        float* base = smem + buf * BUF_FLOATS + wave * 32 * BK;
+        float* base = smem + buf * BUF_FLOATS + wave * 32 * 32;          // 32 rows x 32 floats (= 128 B) per wave
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt * BK), (lds_ptr_t)(base + i * 8 * BK), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt * BK), (lds_ptr_t)(base + TILE_FLOATS + i * 8 * BK),
-                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt * ROW_BYTES), (lds_ptr_t)(base + i * 8 * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt * ROW_BYTES),
+                                             (lds_ptr_t)(base + TILE_FLOATS + i * 8 * 32), 16, 0, 0);
         }
     };
 
@@ -94,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
     int coff[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) coff[s4] = ((hh * 4 + s4) ^ f) * 4;
-    const int arow = (wr * 64 + idx) * BK;
-    const int brow = TILE_FLOATS + (wc * 64 + idx) * BK;
+    const int arow = (wr * 64 + idx) * 32;
+    const int brow = TILE_FLOATS + (wc * 64 + idx) * 32;
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -105,9 +119,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const float4 a0 = *reinterpret_cast<const float4*>(sb + arow + coff[s4]);
-            const float4 a1 = *reinterpret_cast<const float4*>(sb + arow + 32 * BK + coff[s4]);
+            const float4 a1 = *reinterpret_cast<const float4*>(sb + arow + 32 * 32 + coff[s4]);
             const float4 b0 = *reinterpret_cast<const float4*>(sb + brow + coff[s4]);
-            const float4 b1 = *reinterpret_cast<const float4*>(sb + brow + 32 * BK + coff[s4]);
+            const float4 b1 = *reinterpret_cast<const float4*>(sb + brow + 32 * 32 + coff[s4]);
+            if constexpr (BF16) {
+                // one 16-B chunk = 8 bf16 = the whole K=16 operand of a 32x32x16 MFMA for this half-wave
+                const bf16x8 xa0 = __builtin_bit_cast(bf16x8, a0), xa1 = __builtin_bit_cast(bf16x8, a1);
+                const bf16x8 xb0 = __builtin_bit_cast(bf16x8, b0), xb1 = __builtin_bit_cast(bf16x8, b1);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][1], 0, 0, 0);
+                continue;
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
@@ -215,7 +239,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
                     if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
                     if constexpr (HAS_R1) { o.x = o.x + r1[it].x; o.y = o.y + r1[it].y; o.z = o.z + r1[it].z; o.w = o.w + r1[it].w; }
                     if constexpr (HAS_R2) { o.x = r2[it].x + o.x; o.y = r2[it].y + o.y; o.z = r2[it].z + o.z; o.w = r2[it].w + o.w; }
-                    if (row < p.M) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = o;
+                    if (row < p.M) {
+                        if (p.c_bf16) {
+                            uint2 pk;
+                            pk.x = (unsigned)f32_to_bf16_rn(o.x) | ((unsigned)f32_to_bf16_rn(o.y) << 16);
+                            pk.y = (unsigned)f32_to_bf16_rn(o.z) | ((unsigned)f32_to_bf16_rn(o.w) << 16);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)row * p.ldc + col) = pk;
+                        } else {
+                            *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = o;
+                        }
+                    }
                 }
             } else {
                 // ragged right edge / unaligned leading dimensions: element-wise
@@ -232,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
                         if (p.relu) o = fmaxf(o, 0.f);
                         if constexpr (HAS_R1) o = o + p.R1[(size_t)row * p.ldr1 + col + e];
                         if constexpr (HAS_R2) o = p.R2[(size_t)row * p.ldr2 + col + e] + o;
-                        p.C[(size_t)row * p.ldc + col + e] = o;
+                        if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)row * p.ldc + col + e] = f32_to_bf16_rn(o);
+                        else p.C[(size_t)row * p.ldc + col + e] = o;
                     }
                 }
             }
@@ -244,8 +278,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
 
 int launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
-    PF_REQUIRE(a.K % BK == 0, "gemm: K must be a multiple of 32 (pad the operand)");
-    PF_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm: row strides must be multiples of 4 floats");
+    const int bk = a.ab_bf16 ? 64 : 32, align = a.ab_bf16 ? 8 : 4;
+    PF_REQUIRE(a.K % bk == 0, "gemm: K must be a multiple of 32 (fp32) / 64 (bf16): pad the operand");
+    PF_REQUIRE(a.lda % align == 0 && a.ldw % align == 0, "gemm: operand row strides must be multiples of 16 bytes");
     PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
     const int nM = ceil_div(a.M, BM), nN = ceil_div(a.N, BN);
     if (a.amax_val) PF_REQUIRE(a.amax_ld >= 2 * nN, "gemm: amax_ld too small");
@@ -262,13 +297,19 @@ int launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
     }
     const dim3 grid((unsigned)nMpad * nN), block(256);
     const int mode = a.amax_val ? MODE_ARGMAX : ((a.R1 ? 1 : 0) | (a.R2 ? 2 : 0));
+#define PF_LAUNCH_GEMM(MODE_)                                                                                      \
+    do {                                                                                                           \
+        if (a.ab_bf16) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, true>), grid, block, 0, stream, g, nM, nN);  \
+        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, false>), grid, block, 0, stream, g, nM, nN);           \
+    } while (0)
     switch (mode) {
-        case 0: hipLaunchKernelGGL(gemm_f32_mfma_kernel<0>, grid, block, 0, stream, g, nM, nN); break;
-        case 1: hipLaunchKernelGGL(gemm_f32_mfma_kernel<1>, grid, block, 0, stream, g, nM, nN); break;
-        case 2: hipLaunchKernelGGL(gemm_f32_mfma_kernel<2>, grid, block, 0, stream, g, nM, nN); break;
-        case 3: hipLaunchKernelGGL(gemm_f32_mfma_kernel<3>, grid, block, 0, stream, g, nM, nN); break;
-        default: hipLaunchKernelGGL(gemm_f32_mfma_kernel<MODE_ARGMAX>, grid, block, 0, stream, g, nM, nN); break;
+        case 0: PF_LAUNCH_GEMM(0); break;
+        case 1: PF_LAUNCH_GEMM(1); break;
+        case 2: PF_LAUNCH_GEMM(2); break;
+        case 3: PF_LAUNCH_GEMM(3); break;
+        default: PF_LAUNCH_GEMM(MODE_ARGMAX); break;
     }
+#undef PF_LAUNCH_GEMM
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

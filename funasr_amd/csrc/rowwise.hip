@@ -18,7 +18,7 @@ namespace pf {
 namespace {
 
 // One wave per row. NV = float4 chunks per lane (D <= 256 * NV).
-template <int NV>
+template <int NV, bool OUT_BF16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
@@ -54,20 +54,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     q = wave_sum(q);
     const float rstd = 1.0f / sqrtf(q / (float)D + eps);
     float* yr = y + (size_t)row * ldy;
+    unsigned short* yb = reinterpret_cast<unsigned short*>(y) + (size_t)row * ldy;     // bf16 view (ldy in elements)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane + 64 * j;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < nchunk) {
             const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
             const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c);
-            float4 o;
             o.x = (v[j].x - mean) * rstd * g.x + b.x;
             o.y = (v[j].y - mean) * rstd * g.y + b.y;
             o.z = (v[j].z - mean) * rstd * g.z + b.z;
             o.w = (v[j].w - mean) * rstd * g.w + b.w;
-            *reinterpret_cast<float4*>(yr + 4 * c) = o;
-        } else if (4 * c < Dpad) {
-            *reinterpret_cast<float4*>(yr + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (4 * c < Dpad) {
+            if constexpr (OUT_BF16) {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(o.x) | ((unsigned)f32_to_bf16(o.y) << 16);
+                pk.y = (unsigned)f32_to_bf16(o.z) | ((unsigned)f32_to_bf16(o.w) << 16);
+                *reinterpret_cast<uint2*>(yb + 4 * c) = pk;
+            } else {
+                *reinterpret_cast<float4*>(yr + 4 * c) = o;
+            }
         }
     }
 }
@@ -94,6 +102,15 @@ __global__ __launch_bounds__(256) void scale_add_pe_kernel(const float* __restri
 // FSMN memory block. Thread = 4 channels; block = (C/4 threads) x FSMN_TT consecutive frames of one sequence,
 // a register sliding window of KS + TT - 1 masked input rows (each input row is fetched once per block).
 constexpr int FSMN_TT = 8;
+__device__ __forceinline__ float4 load4(const float* base, size_t off, bool bf16) {
+    if (!bf16) return *reinterpret_cast<const float4*>(base + off);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+    float4 v;
+    v.x = bf16_to_f32((unsigned short)(u.x & 0xffffu)); v.y = bf16_to_f32((unsigned short)(u.x >> 16));
+    v.z = bf16_to_f32((unsigned short)(u.y & 0xffffu)); v.w = bf16_to_f32((unsigned short)(u.y >> 16));
+    return v;
+}
+
 template <int KS, int LP>
 __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
     const int b = blockIdx.y;
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
     for (int i = 0; i < KS + FSMN_TT - 1; ++i) {
         const int tt = t0 - LP + i;
         if (tt >= 0 && tt < p.T && tt < len)
-            win[i] = *reinterpret_cast<const float4*>(p.in + ((size_t)b * p.T + tt) * p.ldin + c4 * 4);
+            win[i] = load4(p.in, ((size_t)b * p.T + tt) * p.ldin + c4 * 4, p.in_bf16 != 0);
         else
             win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -148,21 +165,44 @@ __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
     }
 }
 
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        pk.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        reinterpret_cast<uint2*>(y)[i] = pk;
+    }
+}
+
 }  // namespace
 
+int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t stream) {
+    PF_REQUIRE(n % 4 == 0, "cast_bf16: n % 4");
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, stream, x, y, n4);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int M,
-                     int D, int Dpad, float eps, hipStream_t stream) {
+                     int D, int Dpad, float eps, hipStream_t stream, int out_bf16) {
     PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm: D must be a multiple of 4 and <= 2048");
     PF_REQUIRE(Dpad >= D && Dpad % 4 == 0 && Dpad <= 2048 && ldy >= Dpad, "layernorm: bad Dpad/ldy");
     PF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: strides must be multiples of 4");
+    PF_REQUIRE(((uintptr_t)y & 15) == 0, "layernorm: output must be 16-B aligned");
     dim3 grid(ceil_div(M, 4)), block(256);
     const int nv = ceil_div(Dpad / 4, 64);
-    if (nv <= 2)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);
-    else if (nv <= 3)
-        hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);
+#define PF_LN(NV_)                                                                                                 \
+    do {                                                                                                          \
+        if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV_, true>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps); \
+        else hipLaunchKernelGGL((layernorm_kernel<NV_, false>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);         \
+    } while (0)
+    if (nv <= 2) PF_LN(2);
+    else if (nv <= 3) PF_LN(3);
+    else PF_LN(8);
+#undef PF_LN
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -113,3 +113,50 @@ def gemm_time_ms(a, w, bias, out, iters: int = 20) -> float:
     _lib.check(lib.pf_k_gemm_f32_time(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(out),
                                       out.stride(0), M, N, K, iters, C.byref(ms), _stream()), "pf_k_gemm_f32_time")
     return float(ms.value)
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 (round to nearest even) on the device; returns a torch.bfloat16 tensor of the same shape."""
+    lib = _lib.load()
+    _f32c(x, "x")
+    xc = x.contiguous()
+    y = torch.empty(xc.shape, device=x.device, dtype=torch.bfloat16)
+    _lib.check(lib.pf_k_cast_bf16(_ptr(xc), _ptr(y), xc.numel(), _stream()), "pf_k_cast_bf16")
+    return y
+
+
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add1=None, add2=None, out_bf16=False):
+    """a [M, K] bf16, w [N, K] bf16 -> fp32 (or bf16) [M, N]; fp32 accumulate / bias / residuals."""
+    lib = _lib.load()
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    _lib.check(lib.pf_k_gemm_bf16(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias),
+                                  _ptr(add1), add1.stride(0) if add1 is not None else 0,
+                                  _ptr(add2), add2.stride(0) if add2 is not None else 0,
+                                  _ptr(out), out.stride(0), M, N, K, int(relu), int(out_bf16), _stream()), "pf_k_gemm_bf16")
+    return out
+
+
+def gemm_bf16_time_ms(a, w, bias, out, iters: int = 20) -> float:
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_gemm_bf16_time(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0),
+                                       M, N, K, int(out.dtype == torch.bfloat16), iters, C.byref(ms), _stream()),
+               "pf_k_gemm_bf16_time")
+    return float(ms.value)
+
+
+def attention_bf16(q, k, v, klens, n_heads: int, scale: float):
+    """bf16 q [B, Tq, H*128], k/v [B, Tk, H*128] (row-strided views allowed) -> bf16 [B, Tq, H*128]."""
+    lib = _lib.load()
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    assert q.dtype == torch.bfloat16 and q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    out = torch.empty(B, Tq, D, device=q.device, dtype=torch.bfloat16)
+    _lib.check(lib.pf_k_attention_bf16(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(out), D,
+                                       _ptr(klens), B, n_heads, Tq, Tk, float(scale), _stream()), "pf_k_attention_bf16")
+    return out

@@ -71,6 +71,17 @@ class _SANMEncoderBase(HipModule):
     def output_size(self) -> int:
         return self._output_size
 
+    def set_precision(self, mode: str = "fp32"):
+        """"fp32": exact fp32 MFMA (default, the parity configuration). "bf16": bf16 operands for the GEMMs and the
+        attention with fp32 accumulation / residual stream / LayerNorm / softmax -- the throughput mode."""
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self._precision = mode
+        if self._handle is not None:
+            _lib.check(_lib.load().pf_encoder_set_precision(self._handle, 1 if mode == "bf16" else 0),
+                       "pf_encoder_set_precision")
+        return self
+
     def _make_config(self):
         return _lib.pf_encoder_config(self._input_size, self._output_size, self.attention_heads, self.linear_units,
                                       self.num_blocks, self.tp_blocks, self.kernel_size, self.sanm_shfit, self.ln_eps)
@@ -82,6 +93,8 @@ class _SANMEncoderBase(HipModule):
 
     def _run(self, xs_pad: torch.Tensor, ilens, run_blocks: int = -1):
         lib, h = self._ensure_handle()
+        _lib.check(lib.pf_encoder_set_precision(h, 1 if getattr(self, "_precision", "fp32") == "bf16" else 0),
+                   "pf_encoder_set_precision")
         dev = self._handle_device
         xs = xs_pad.to(device=dev, dtype=torch.float32).contiguous()
         B, T, Din = xs.shape

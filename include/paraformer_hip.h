@@ -100,6 +100,10 @@ void pf_encoder_destroy(pf_encoder* e);
 int pf_encoder_set_tensor(pf_encoder* e, const char* name, const float* data, int64_t numel);
 /* number of tensors still missing (0 = ready) */
 int pf_encoder_missing(const pf_encoder* e);
+/* 0 = fp32 MFMA everywhere (default; the parity configuration: activations <= 1e-3, CIF indices equal to the CPU
+ * reference). 1 = bf16 OPERANDS for the GEMMs and the attention with fp32 accumulation; residual stream, LayerNorm
+ * statistics, softmax and FSMN stay fp32 (the reference's own bf16=True casts the whole module, auto_model.py:665-668). */
+int pf_encoder_set_precision(pf_encoder* e, int32_t mode);
 /* xs_dev: [B, T, input_dim] (un-scaled features, exactly what SANMEncoder.forward receives), lens_host: [B],
  * pe_dev: [T, input_dim] sinusoidal table (embedding.py:396-420; NULL = library computes it with libm),
  * out_dev: [B, T, d_model]. run_blocks < 0 runs everything incl. the final norm(s); run_blocks = k >= 0 stops
@@ -222,6 +226,15 @@ int pf_set_skinny_max_m(int32_t m);
 int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R1,
                   int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc, int32_t M, int32_t N,
                   int32_t K, int32_t relu, void* stream);
+/* bf16-operand GEMM of the throughput mode: A [M,K] bf16, W [N,K] bf16 (strides in elements), fp32 accumulate on
+ * v_mfma_f32_32x32x16_bf16, fp32 bias / residuals, C fp32 (c_bf16 = 0) or bf16 (1). K % 64 == 0. */
+int pf_k_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const float* R1,
+                   int32_t ldr1, const float* R2, int32_t ldr2, void* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+                   int32_t relu, int32_t c_bf16, void* stream);
+int pf_k_gemm_bf16_time(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, void* C, int32_t ldc,
+                        int32_t M, int32_t N, int32_t K, int32_t c_bf16, int32_t iters, float* ms_out, void* stream);
+/* fp32 -> bf16 (round to nearest even), n % 4 == 0 */
+int pf_k_cast_bf16(const float* x, void* y, int64_t n, void* stream);
 int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t M,
                          int32_t N, int32_t K, int32_t* ids, float* scratch_val, int32_t* scratch_idx, void* stream);
 int pf_k_layernorm(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
@@ -231,6 +244,10 @@ int pf_k_fsmn(const float* in, int32_t ldin, const float* w, const float* R, int
 int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
                        float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq,
                        int32_t Tk, float scale, void* stream);
+/* bf16 twin of pf_k_attention_f32: Q/K/V/O bf16, strides in elements */
+int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
+                        int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
+                        void* stream);
 /* CIF integrate-and-fire on caller-provided weights (cif_v1, cif_predictor.py:853-908): alphas [B, T], hidden
  * [B, T, D] -> peaks [B, T] (= "fires"), n_fires int32 [B], embeds [B, N, D] (rows >= n_fires[b] zero). */
 int pf_k_cif(const float* alphas, const float* hidden, int32_t B, int32_t T, int32_t D, int32_t N, float* peaks,

@@ -46,6 +46,26 @@ def test_gemm_f32_matches_fp64(cuda, gemm_path, M, N, K):
     assert _rel(out2, ref2) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (500, 1536, 576), (333, 2048, 512), (1000, 512, 2048), (70, 130, 192)])
+def test_gemm_bf16_operands_fp32_accumulate(cuda, M, N, K):
+    """bf16-operand mode: against fp64 on the SAME bf16-rounded operands only the fp32 accumulation differs."""
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N)[:, None]
+    bias = torch.randn(N, generator=g)
+    r2 = torch.randn(M, N, generator=g)
+    ab = ops.cast_bf16(a.to(cuda))
+    wb = ops.cast_bf16(w.to(cuda))
+    assert torch.equal(ab.cpu(), a.to(torch.bfloat16)) and torch.equal(wb.cpu(), w.to(torch.bfloat16))   # RNE like torch
+    ref = ab.cpu().double() @ wb.cpu().double().T + bias.double()
+    out = ops.gemm_bf16(ab, wb, bias.to(cuda)).cpu()
+    assert _rel(out, ref) < 2e-6
+    out2 = ops.gemm_bf16(ab, wb, bias.to(cuda), relu=True, add2=r2.to(cuda), out_bf16=True).cpu()
+    ref2 = (torch.relu(ref) + r2.double())
+    assert torch.equal(out2, ref2.float().to(torch.bfloat16)) or _rel(out2.float(), ref2) < 4e-3   # one bf16 rounding
+
+
 def test_gemm_f32_strided_and_inplace_residual(cuda, gemm_path):
     from funasr_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -130,3 +150,27 @@ def test_attention_f32(cuda, B, Tq, Tk, lens):
     kvd = kv.to(cuda)
     out = ops.attention(q.to(cuda), kvd[:, :, :H * dk], kvd[:, :, H * dk:], klens.to(cuda), H, scale).cpu()
     assert (out.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,Tq,Tk,lens", [(2, 100, 100, [100, 37]), (1, 500, 500, [500]), (3, 40, 300, [300, 1, 129])])
+def test_attention_bf16(cuda, B, Tq, Tk, lens):
+    """bf16-operand attention against fp64 softmax attention on the same bf16-rounded Q/K/V: the differences are the
+    bf16 rounding of P (2^-9 relative) and of the output."""
+    from funasr_amd import ops
+    H, dk = 4, 128
+    g = torch.Generator().manual_seed(B * 1000 + Tq)
+    q = (torch.randn(B, Tq, H * dk, generator=g)).to(torch.bfloat16)
+    k = (torch.randn(B, Tk, H * dk, generator=g)).to(torch.bfloat16)
+    v = (torch.randn(B, Tk, H * dk, generator=g)).to(torch.bfloat16)
+    kl = torch.tensor(lens, dtype=torch.int32)
+    scale = dk ** -0.5
+    out = ops.attention_bf16(q.to(cuda), k.to(cuda), v.to(cuda), kl.to(cuda), H, scale).cpu().double()
+    qh = q.double().view(B, Tq, H, dk).transpose(1, 2) * scale
+    kh = k.double().view(B, Tk, H, dk).transpose(1, 2)
+    vh = v.double().view(B, Tk, H, dk).transpose(1, 2)
+    sc = qh @ kh.transpose(-1, -2)
+    mask = torch.arange(Tk)[None, :] >= kl[:, None]
+    sc = sc.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, Tq, H * dk)
+    err = (out - ref).abs()
+    assert err.max().item() < 3e-2 and err.mean().item() < 3e-3, (err.max().item(), err.mean().item())
