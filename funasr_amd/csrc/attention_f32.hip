@@ -161,13 +161,152 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs p) {
     }
 }
 
+// ---- offline variant: K/V tiles go HBM -> LDS with global_load_lds_dwordx4 (no staging registers), double buffered:
+// the DMA of tile t+1 is in flight under the 128 MFMAs of tile t, one barrier per tile. K rows are 512 B; the DMA
+// writes lane-linear, so the 16-B chunk permutation that makes the ds_read_b128 operand fetch conflict-free
+// (chunk c of key r at c ^ (r & 15)) is applied to the per-lane SOURCE address and again on the read.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+constexpr int TILE_F = KT * DK;                 // floats per K (or V) tile: 16 KB
+constexpr int STAGE_F = 2 * TILE_F;             // K tile + V tile
+
+__global__ __launch_bounds__(256, 2) void attention_f32_dma_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_F];     // 64 KB, the only LDS object
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, idx = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + idx;
+    const int qc = q < p.Tq ? q : p.Tq - 1;
+    const int klen = p.klens[b];
+
+    float qreg[64];
+    {
+        const float* qp = p.Q + ((size_t)b * p.Tq + qc) * p.ldq + head * DK + hh * 64;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + 4 * i);
+            qreg[4 * i + 0] = t.x * p.scale;
+            qreg[4 * i + 1] = t.y * p.scale;
+            qreg[4 * i + 2] = t.z * p.scale;
+            qreg[4 * i + 3] = t.w * p.scale;
+        }
+    }
+
+    floatx16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // DMA pieces: a piece = 2 keys x 512 B; wave w stages pieces 4w .. 4w+3 of both tiles
+    const float* kbase = p.K + (size_t)b * p.Tk * p.ldk + head * DK;
+    const float* vbase = p.V + (size_t)b * p.Tk * p.ldv + head * DK;
+    const int cp = lane & 31;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 4 * 2 * DK * 4);
+    auto stage = [&](int buf, int k0) {
+        // issued from inline asm (common.h: glds16): the compiler must not drain the prefetch before the MFMAs
+        const unsigned base = lds_base + (unsigned)buf * (STAGE_F * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 2 + (lane >> 5);          // key row inside the tile
+            int kr = k0 + r;
+            kr = kr < klen ? kr : klen - 1;                           // rows past the last valid key feed masked scores only
+            const float* ks = kbase + (size_t)kr * p.ldk + ((cp ^ (r & 15)) * 4);
+            const float* vs = vbase + (size_t)kr * p.ldv + cp * 4;
+            glds16(ks, base + i * 2 * DK * 4);
+            glds16(vs, base + TILE_F * 4 + i * 2 * DK * 4);
+        }
+    };
+
+    const int ntiles = (klen + KT - 1) / KT;
+    stage(0, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * KT;
+        glds_wait_all();                      // this wave's pieces of tile kt have landed ...
+        __syncthreads();                      // ... and everybody else's; the other buffer is free again
+        if (kt + 1 < ntiles) stage((kt + 1) & 1, k0 + KT);
+        const float* Ks = smem + (kt & 1) * STAGE_F;
+        const float* Vs = Ks + TILE_F;
+
+        // ---- S^T tile (32 keys x 32 queries); this lane's K row idx, d chunks [16h, 16h+16) permuted by idx & 15
+        floatx16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kp = Ks + idx * DK;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 kf = *reinterpret_cast<const float4*>(kp + (((hh * 16 + i) ^ (idx & 15)) * 4));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qreg[4 * i + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qreg[4 * i + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[4 * i + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qreg[4 * i + 3], s, 0, 0, 0);
+        }
+
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= klen) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = expf(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float* vp = Vs + krow * DK + idx;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * d], s[r], o[d], 0, 0, 0);
+        }
+    }
+
+    if (q < p.Tq) {
+        const float inv = 1.0f / l_run;
+        float* op = p.O + ((size_t)b * p.Tq + q) * p.ldo + head * DK;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 t;
+                t.x = o[d][4 * g + 0] * inv;
+                t.y = o[d][4 * g + 1] * inv;
+                t.z = o[d][4 * g + 2] * inv;
+                t.w = o[d][4 * g + 3] * inv;
+                *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hh) = t;
+            }
+    }
+}
+
 }  // namespace
 
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
     PF_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0, "attention: strides % 4");
     dim3 grid(ceil_div(a.Tq, 128), a.H, a.B);
-    hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, stream, a);
+    // the K/V ring form of the streaming step (two sources, a few dozen keys) keeps the register-staged loader; the
+    // offline form (one source) takes the LDS-DMA double-buffered kernel. Both do the same arithmetic in the same order.
+    const bool dma_ok = a.K2 == nullptr && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.V & 15) == 0;
+    if (dma_ok) hipLaunchKernelGGL(attention_f32_dma_kernel, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(256), 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

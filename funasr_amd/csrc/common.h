@@ -55,6 +55,25 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
     return __builtin_bit_cast(float, (unsigned int)h << 16);
 }
 
+// ---------------------------------------------------------------- LDS-DMA issued behind the compiler's back
+// hipcc cannot prove that a ds_read does not alias an LDS-DMA in flight (SIInsertWaitcnts only separates them with
+// alias-scope metadata HIP does not attach), so with __builtin_amdgcn_global_load_lds it puts `s_waitcnt vmcnt(0)` in
+// front of the first ds_read of every k-step: the prefetch of tile t+1 is drained before tile t is multiplied and the
+// double buffer overlaps nothing. Issued from inline asm the DMA is invisible to that pass; the kernel then owns the
+// ordering: glds_wait_all() by every wave, then the workgroup barrier, then the ds_reads (cdna guide 5.7, item 1).
+// lds_byte_addr must be wave-uniform (readfirstlane it); each lane lands 16 bytes at lds_byte_addr + 16 * lane.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // ---------------------------------------------------------------- kernel launchers
 // (all take device pointers; `stream` is the HIP stream the caller owns)
 

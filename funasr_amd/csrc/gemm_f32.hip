@@ -85,13 +85,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
     }
     const int nk = p.K / BK;
 
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 32 * ROW_BYTES);
     auto stage = [&](int buf, int kt) {
-        float* base = smem + buf * BUF_FLOATS + wave * 32 * 32;          // 32 rows x 32 floats (= 128 B) per wave
+        // 32 rows x 128 B per wave and operand; issued from inline asm (common.h: glds16) so that the prefetch really
+        // stays in flight under the MFMAs of the current tile
+        const unsigned base = lds_base + (unsigned)buf * (BUF_FLOATS * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + kt * ROW_BYTES), (lds_ptr_t)(base + i * 8 * 32), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + kt * ROW_BYTES),
-                                             (lds_ptr_t)(base + TILE_FLOATS + i * 8 * 32), 16, 0, 0);
+            glds16(asrc[i] + kt * ROW_BYTES, base + i * 8 * ROW_BYTES);
+            glds16(wsrc[i] + kt * ROW_BYTES, base + TILE_FLOATS * 4 + i * 8 * ROW_BYTES);
         }
     };
 
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
 
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                       // tile kt landed for every wave; buffer (kt+1)&1 is free again
+        glds_wait_all();                       // this wave's pieces of tile kt have landed ...
+        __syncthreads();                       // ... and so have everybody else's; buffer (kt+1)&1 is free again
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const float* sb = smem + (kt & 1) * BUF_FLOATS;
 #pragma unroll
