@@ -259,3 +259,43 @@ def test_bf16_operand_mode_stays_close_to_fp32_mode(cuda):
     d = (out - ref).abs()[m]
     scale = ref.abs()[m].mean().item()
     assert d.mean().item() < 0.02 * scale and d.max().item() < 0.25 * max(scale, 1.0), (d.mean().item(), d.max().item(), scale)
+
+
+def test_edge_cases_short_silent_and_zero_token_utterances(cuda):
+    """Edge cases of the offline path: (1) an utterance shorter than one 25 ms window is rejected like the reference's
+    fbank would produce no frame; (2) one-frame utterances and a batch where some clips fire no token at all: those
+    clips come back empty, their neighbours are unaffected (bitwise) -- where the reference raises IndexError for a
+    zero-token LAST utterance (cif_predictor.py:887) this path returns an empty hypothesis; (3) a 60 s clip (T = 1000)."""
+    from funasr_amd.paraformer import Paraformer
+    from funasr_amd.wav_frontend import WavFrontend
+    from oracle import paraformer_oracle as O
+    sh, sc = synth.synthetic_cmvn()
+    fe = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0)
+    with pytest.raises(Exception, match="25 ms|window"):
+        fe(torch.zeros(1, 399).to(cuda), [399])
+    feats, flens = fe(torch.zeros(2, 400).to(cuda), [400, 400])           # exactly one window -> one LFR frame
+    assert flens.tolist() == [1, 1] and feats.shape[1] == 1
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2, dec_blocks=1, vocab=97)
+    sd = synth.paraformer_state_dict(cfg, seed=5, cif_bias=-6.0)          # alpha ~ 0.002: almost nothing fires
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(cuda)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 40, 560, generator=g) * 0.7
+    lens = torch.tensor([40, 3, 25], dtype=torch.int32)
+    for b in range(3):
+        x[b, lens[b]:] = 0
+    res = model.recognize_features(x.to(cuda), lens, return_intermediate=True)
+    ref = O.paraformer_greedy(x[:1], lens[:1], sd, cfg)
+    assert res["token_num"][0] == int(ref["token_num"][0]) and res["raw_ids"][0] == ref["raw_ids"][0]
+    assert all(len(r) == n for r, n in zip(res["raw_ids"], res["token_num"]))
+    one = model.recognize_features(x[:1].to(cuda), lens[:1], return_intermediate=True)
+    assert torch.equal(one["enc"][0], res["enc"][0]) and one["raw_ids"][0] == res["raw_ids"][0]
+    # tail threshold 0.45 + tiny alphas: floor(sum) can be 0 -> empty hypothesis, no exception
+    assert min(res["token_num"]) >= 0
+    # long clip: T = 1000 frames
+    xl = torch.randn(1, 1000, 560, generator=g) * 0.7
+    rl = model.recognize_features(xl.to(cuda), [1000], return_intermediate=True)
+    refl = O.paraformer_greedy(xl, torch.tensor([1000], dtype=torch.int32), sd, cfg)
+    assert (rl["enc"].cpu() - refl["enc"]).abs().max().item() < 1e-3
+    assert rl["raw_ids"] == refl["raw_ids"]

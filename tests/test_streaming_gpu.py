@@ -134,3 +134,28 @@ def test_streaming_inference_api_two_calls_equals_reference_tokens(cuda):
     # the final call re-initialised the cache: the same audio again gives the same tokens
     r3, _ = model.inference([wav], key=["utt"], tokenizer=None, frontend=fe, cache=cache, is_final=True, **kw)
     assert r3[0]["token_int"] == sum(ref, [])
+
+
+@pytest.mark.parametrize("chunk,enc_lb,dec_lb", [([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1)])
+def test_stream_other_chunk_geometries_vs_streaming_oracle(cuda, chunk, enc_lb, dec_lb):
+    """chunk_size / look-back settings other than the golden session's, against the (reference-pinned) streaming oracle
+    on random online features: token ids and counts equal, encoder window within 1e-3."""
+    from funasr_amd.paraformer_streaming import StreamBatch
+    from oracle import streaming_oracle as S
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    sb = StreamBatch(model, 1, chunk, enc_lb, dec_lb)
+    st = S.model_init(cfg, tuple(chunk), enc_lb, dec_lb)
+    gen = torch.Generator().manual_seed(chunk[1] * 10 + enc_lb)
+    for i in range(6):
+        fin = i == 5
+        n = chunk[1] if not fin else chunk[1] + 2           # the final flush of the online frontend brings extra frames
+        feats = torch.randn(1, n, 560, generator=gen) * 0.7
+        trace = []
+        with torch.no_grad():
+            oids = S.generate_chunk(feats.clone(), st, sd, cfg, fin, trace)
+        ids, enc = sb.step(feats.to(cuda), is_final=fin, return_enc=True)
+        assert (enc.cpu() - trace[0]["enc"]).abs().max().item() < 1e-3, i
+        assert [t for t in ids[0] if t not in (0, 1, 2)] == oids, (i, ids[0], oids)
+        assert len(ids[0]) == trace[0]["n"], i
+    sb.close()
