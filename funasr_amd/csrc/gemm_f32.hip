@@ -33,10 +33,10 @@ namespace pf {
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
+constexpr int BN = 128;
 constexpr int ROW_BYTES = 128;                        // one LDS row = one 128-B line of an operand row
-constexpr int TILE_FLOATS = BM * ROW_BYTES / 4;       // one operand tile (4096 floats = 16 KB)
-constexpr int BUF_FLOATS = 2 * TILE_FLOATS;           // A tile + B tile
+constexpr int TILE_FLOATS = 128 * ROW_BYTES / 4;      // a 128-row operand tile (4096 floats = 16 KB)
+constexpr int BUF_FLOATS = 2 * TILE_FLOATS;           // A tile + B tile (the A tile of the 64-row variant is half used)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {
@@ -49,8 +49,12 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int MODE_ARGMAX = 4;   // MODE bit 0: + R1, bit 1: + R2; 4: fused arg-max instead of a C store
 
-template <int MODE, bool BF16>
+// TM = 32-row MFMA tiles per wave in M: 2 -> the 128 x 128 block tile; 1 -> a 64 x 128 block tile, chosen by the
+// launcher when the 128-row grid would leave most CUs idle (decoder-sized problems: twice the workgroups, same
+// per-element fma chain, so the choice never changes a bit of the result)
+template <int MODE, bool BF16, int TM>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int nM, int nN) {
+    constexpr int BM = 64 * TM;
     constexpr int ES = BF16 ? 2 : 4;                  // operand element size
     constexpr int BK = ROW_BYTES / ES;                // k extent of one tile: 32 floats / 64 bf16
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF_FLOATS];   // 64 KB, the only LDS object
@@ -70,36 +74,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
 
     // ---- LDS-DMA source addresses: wave w stages rows [32w, 32w+32) of both tiles, 4 pieces of 8 rows each;
     //      lane l of a piece lands at row (l >> 3), physical chunk (l & 7)
-    const char* asrc[4];
+    const char* asrc[2 * TM];
     const char* wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = wave * 32 + i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int row = m0 + r;
-        row = row < p.M ? row : p.M - 1;
-        asrc[i] = reinterpret_cast<const char*>(p.A) + ((size_t)row * p.lda) * ES + c * 16;
         int col = n0 + r;
         col = col < p.N ? col : p.N - 1;
         wsrc[i] = reinterpret_cast<const char*>(p.W) + ((size_t)col * p.ldw) * ES + c * 16;
     }
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) {
+        const int r = wave * (16 * TM) + i * 8 + (lane >> 3);           // wave w stages A rows [16 TM w, 16 TM (w+1))
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int row = m0 + r;
+        row = row < p.M ? row : p.M - 1;
+        asrc[i] = reinterpret_cast<const char*>(p.A) + ((size_t)row * p.lda) * ES + c * 16;
+    }
     const int nk = p.K / BK;
 
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 32 * ROW_BYTES);
+    const unsigned lds_a = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * (16 * TM) * ROW_BYTES);
+    const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + TILE_FLOATS * 4 + (unsigned)wave * 32 * ROW_BYTES);
     auto stage = [&](int buf, int kt) {
-        // 32 rows x 128 B per wave and operand; issued from inline asm (common.h: glds16) so that the prefetch really
-        // stays in flight under the MFMAs of the current tile
-        const unsigned base = lds_base + (unsigned)buf * (BUF_FLOATS * 4);
+        // issued from inline asm (common.h: glds16) so that the prefetch really stays in flight under the MFMAs of
+        // the current tile
+        const unsigned off = (unsigned)buf * (BUF_FLOATS * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(asrc[i] + kt * ROW_BYTES, base + i * 8 * ROW_BYTES);
-            glds16(wsrc[i] + kt * ROW_BYTES, base + TILE_FLOATS * 4 + i * 8 * ROW_BYTES);
-        }
+        for (int i = 0; i < 2 * TM; ++i) glds16(asrc[i] + kt * ROW_BYTES, lds_a + off + i * 8 * ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(wsrc[i] + kt * ROW_BYTES, lds_b + off + i * 8 * ROW_BYTES);
     };
 
-    floatx16 acc[2][2];
+    floatx16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
     int coff[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) coff[s4] = ((hh * 4 + s4) ^ f) * 4;
-    const int arow = (wr * 64 + idx) * 32;
+    const int arow = (wr * (32 * TM) + idx) * 32;
     const int brow = TILE_FLOATS + (wc * 64 + idx) * 32;
 
     stage(0, 0);
@@ -121,36 +130,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
         const float* sb = smem + (kt & 1) * BUF_FLOATS;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const float4 a0 = *reinterpret_cast<const float4*>(sb + arow + coff[s4]);
-            const float4 a1 = *reinterpret_cast<const float4*>(sb + arow + 32 * 32 + coff[s4]);
-            const float4 b0 = *reinterpret_cast<const float4*>(sb + brow + coff[s4]);
-            const float4 b1 = *reinterpret_cast<const float4*>(sb + brow + 32 * 32 + coff[s4]);
+            float4 av[TM], bv[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(sb + arow + i * 32 * 32 + coff[s4]);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) bv[jj] = *reinterpret_cast<const float4*>(sb + brow + jj * 32 * 32 + coff[s4]);
             if constexpr (BF16) {
                 // one 16-B chunk = 8 bf16 = the whole K=16 operand of a 32x32x16 MFMA for this half-wave
-                const bf16x8 xa0 = __builtin_bit_cast(bf16x8, a0), xa1 = __builtin_bit_cast(bf16x8, a1);
-                const bf16x8 xb0 = __builtin_bit_cast(bf16x8, b0), xb1 = __builtin_bit_cast(bf16x8, b1);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa0, xb1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa1, xb1, acc[1][1], 0, 0, 0);
-                continue;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i]),
+                                                                            __builtin_bit_cast(bf16x8, bv[jj]), acc[i][jj], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float ae = e == 0 ? av[i].x : (e == 1 ? av[i].y : (e == 2 ? av[i].z : av[i].w));
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const float be = e == 0 ? bv[jj].x : (e == 1 ? bv[jj].y : (e == 2 ? bv[jj].z : bv[jj].w));
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[i][jj], 0, 0, 0);
+                        }
+                    }
+                }
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
         }
     }
 
@@ -164,10 +170,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
             bv[jj] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int row = m0 + wr * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float best = -INFINITY;
                 int besti = 0x7fffffff;
 #pragma unroll
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
             float4 v[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const float4*>(slab + (it * 4 + rsub) * ELD + c4 * 4);
-            const int row0 = m0 + wr * 64 + i * 32 + rsub;
+            const int row0 = m0 + wr * (32 * TM) + i * 32 + rsub;
             if (vec_ok && col + 3 < p.N) {
                 float4 r1[8], r2[8];
 #pragma unroll
@@ -285,7 +291,11 @@ int launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.K % bk == 0, "gemm: K must be a multiple of 32 (fp32) / 64 (bf16): pad the operand");
     PF_REQUIRE(a.lda % align == 0 && a.ldw % align == 0, "gemm: operand row strides must be multiples of 16 bytes");
     PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: operands must be 16-B aligned");
-    const int nM = ceil_div(a.M, BM), nN = ceil_div(a.N, BN);
+    // 64-row block tiles when the 128-row grid cannot even give every CU its two workgroups (2 x 256 CUs)
+    const int nN = ceil_div(a.N, BN);
+    const bool half_tile = ceil_div(a.M, 128) * nN < 512;
+    const int BMr = half_tile ? 64 : 128;
+    const int nM = ceil_div(a.M, BMr);
     if (a.amax_val) PF_REQUIRE(a.amax_ld >= 2 * nN, "gemm: amax_ld too small");
     const int nMpad = (nM + 7) / 8 * 8;
     GemmArgs g = a;
@@ -300,10 +310,15 @@ int launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
     }
     const dim3 grid((unsigned)nMpad * nN), block(256);
     const int mode = a.amax_val ? MODE_ARGMAX : ((a.R1 ? 1 : 0) | (a.R2 ? 2 : 0));
-#define PF_LAUNCH_GEMM(MODE_)                                                                                      \
-    do {                                                                                                           \
-        if (a.ab_bf16) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, true>), grid, block, 0, stream, g, nM, nN);  \
-        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, false>), grid, block, 0, stream, g, nM, nN);           \
+#define PF_LAUNCH_GEMM(MODE_)                                                                                          \
+    do {                                                                                                               \
+        if (a.ab_bf16) {                                                                                               \
+            if (half_tile) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, true, 1>), grid, block, 0, stream, g, nM, nN);  \
+            else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, true, 2>), grid, block, 0, stream, g, nM, nN);             \
+        } else {                                                                                                       \
+            if (half_tile) hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, false, 1>), grid, block, 0, stream, g, nM, nN); \
+            else hipLaunchKernelGGL((gemm_f32_mfma_kernel<MODE_, false, 2>), grid, block, 0, stream, g, nM, nN);            \
+        }                                                                                                              \
     } while (0)
     switch (mode) {
         case 0: PF_LAUNCH_GEMM(0); break;
