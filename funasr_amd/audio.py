@@ -2,8 +2,8 @@
 
 Mirrors the subset of `load_audio_text_image_video` the ASR path uses (funasr/utils/load_utils.py:48-179): local WAV
 paths (decoded with the stdlib `wave` module instead of torchaudio/soundfile/ffmpeg), numpy arrays, tensors, raw
-16-bit PCM bytes, and lists of those; a missing file raises FileNotFoundError like :95-112. Resampling is not built
-(the reference uses torchaudio.transforms.Resample, :176-178): a sample-rate mismatch raises.
+16-bit PCM bytes, and lists of those; a missing file raises FileNotFoundError like :95-112. A sample-rate mismatch is
+resampled on the host with a polyphase FIR (scipy) where the reference uses torchaudio.transforms.Resample (:176-178).
 """
 from __future__ import annotations
 
@@ -55,10 +55,23 @@ def load_audio(item, fs: int = 16000, audio_fs: int = 16000) -> torch.Tensor:
     if x.dim() > 1:
         x = x.reshape(-1, x.shape[-1]).mean(0) if x.shape[0] <= 8 else x.reshape(-1)
     if audio_fs != fs:
-        raise NotImplementedError(f"audio is {audio_fs} Hz but the frontend expects {fs} Hz; resample upstream")
+        x = resample(x.to(torch.float32), audio_fs, fs)
     if x.dtype in (torch.int16,):
         x = x.to(torch.float32) / 32768.0
     return x.to(torch.float32)
+
+
+def resample(x: torch.Tensor, src_fs: int, dst_fs: int) -> torch.Tensor:
+    """Host-side band-limited resampling (the reference calls torchaudio.transforms.Resample, load_utils.py:176-178;
+    torchaudio is not a dependency here): polyphase FIR from scipy. Not bit-identical to torchaudio's kernel -- audio that
+    is already at the frontend rate (the hot path) never passes through here."""
+    from math import gcd
+
+    from scipy.signal import resample_poly
+
+    g = gcd(int(src_fs), int(dst_fs))
+    y = resample_poly(x.numpy().astype(np.float64), int(dst_fs) // g, int(src_fs) // g)
+    return torch.from_numpy(np.ascontiguousarray(y.astype(np.float32)))
 
 
 def load_audio_list(data_in, fs: int = 16000, audio_fs: int = 16000) -> List[torch.Tensor]:

@@ -129,3 +129,37 @@ class CharTokenizer:
 
     def decode(self, ids) -> str:
         return self.tokens2text(self.ids2tokens(ids))
+
+
+@tables.register("tokenizer_classes", "SentencepiecesTokenizer")
+class SentencepiecesTokenizer:
+    """SenseVoiceSmall's tokenizer (funasr/tokenizer/sentencepiece_tokenizer.py:11-104): a thin wrapper over the
+    `sentencepiece` package around the model directory's `*.bpe.model`; host-side only."""
+
+    def __init__(self, bpemodel, **kwargs):
+        import sentencepiece as spm
+
+        self.bpemodel = str(bpemodel)
+        self.sp = spm.SentencePieceProcessor()
+        self.sp.load(self.bpemodel)
+
+    def text2tokens(self, line: str) -> List[str]:
+        return self.sp.EncodeAsPieces(line)
+
+    def tokens2text(self, tokens: Iterable[str]) -> str:
+        return self.sp.DecodePieces(list(tokens))
+
+    def encode(self, line: str, **kwargs) -> List[int]:
+        return self.sp.EncodeAsIds(line)
+
+    def decode(self, ids, **kwargs) -> str:
+        return self.sp.DecodeIds([int(i) for i in ids])
+
+    def get_vocab_size(self) -> int:
+        return self.sp.GetPieceSize()
+
+    def ids2tokens(self, ids) -> List[str]:
+        return [self.sp.IdToPiece(int(i)) for i in ids]
+
+    def tokens2ids(self, tokens) -> List[int]:
+        return [self.sp.PieceToId(t) for t in tokens]

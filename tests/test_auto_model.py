@@ -88,3 +88,40 @@ def test_generate_matches_oracle_text(model_dir, cuda):
     res2 = am.generate(input=[paths[0], x1, torch.from_numpy(x1)], batch_size=3)
     assert res2[0]["text"] == res[0]["text"] and res2[1]["text"] == res[1]["text"] == res2[2]["text"]
     assert am.kwargs["batch_size"] == 2 or am.kwargs["batch_size"] == 3
+
+
+def test_audio_inputs_resample_and_bytes(tmp_path):
+    """load_audio handles the input kinds of load_audio_text_image_video (load_utils.py:48-179) that the ASR path sees."""
+    import wave as _wave
+    from funasr_amd.audio import load_audio, load_audio_list
+    x = synth.speech_like(8000, seed=1)
+    p8 = str(tmp_path / "a8k.wav")
+    pcm = write_wav(p8, x, fs=8000)
+    y = load_audio(p8, fs=16000)                                  # 8 kHz file -> 16 kHz
+    assert abs(y.numel() - 16000) <= 1 and y.dtype == torch.float32
+    raw = pcm.tobytes()                                            # headerless 16-bit PCM bytes
+    z = load_audio(raw, fs=16000, audio_fs=16000)
+    assert z.numel() == 8000 and torch.allclose(z, torch.from_numpy(pcm.astype(np.float32) / 32768.0))
+    stereo = np.stack([pcm, pcm // 2]).astype(np.int16)
+    with _wave.open(str(tmp_path / "st.wav"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes(stereo.T.copy().tobytes())
+    m = load_audio(str(tmp_path / "st.wav"))
+    assert m.numel() == 8000                                       # channel mean (load_utils.py:126-127)
+    assert len(load_audio_list([p8, x.numpy()], fs=8000, audio_fs=8000)) == 2
+    with pytest.raises(FileNotFoundError):
+        load_audio("/nope.wav")
+
+
+def test_sentencepiece_tokenizer_registered(tmp_path):
+    import sentencepiece as spm
+    from funasr_amd.register import tables
+    corpus = tmp_path / "c.txt"
+    corpus.write_text("\n".join(["hello world this is a test", "speech recognition on amd gpus", "paraformer and sensevoice"] * 20))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "m"), vocab_size=40, model_type="bpe",
+                                   minloglevel=2)
+    cls = tables.tokenizer_classes.get("SentencepiecesTokenizer")
+    tok = cls(bpemodel=str(tmp_path / "m.model"))
+    ids = tok.encode("hello world")
+    assert tok.decode(ids) == "hello world" and tok.get_vocab_size() == 40
+    assert tok.tokens2text(tok.ids2tokens(ids)) == "hello world"
