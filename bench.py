@@ -187,7 +187,7 @@ def main():
     bf16_mode = None
     if world == 1 and not args.no_bf16:
         try:
-            model.encoder.set_precision("bf16")
+            model.set_precision("bf16")
             for _ in range(max(1, args.warmup)):
                 res16 = step()
             torch.cuda.synchronize()
@@ -206,15 +206,15 @@ def main():
             tok = sum(len(a) for a in res["raw_ids"])
             diff = sum(sum(1 for x, y in zip(a, b) if x != y) + abs(len(a) - len(b)) for a, b in zip(res["raw_ids"], res16["raw_ids"]))
             bf16_mode = {"value": round(B * args.seconds * args.steps / dt16, 1), "unit": "audio-s/s",
-                         "ms_per_step": round(dt16 / args.steps * 1e3, 2), "dtype": "bf16 operands (encoder GEMMs + attention), "
-                         "fp32 accumulate/residual/LN/softmax; predictor + decoder fp32",
+                         "ms_per_step": round(dt16 / args.steps * 1e3, 2), "dtype": "bf16 operands (encoder + decoder GEMMs and attention), "
+                         "fp32 accumulate/residual/LN/softmax/FSMN; CIF predictor fp32",
                          "gemm_tflops_all_launches": round(work.value / (ms.value * 1e-3) / 1e12, 1) if ms.value > 0 else None,
                          "clips_with_identical_token_ids_vs_fp32": f"{same}/{B}",
                          "clips_with_identical_token_count_vs_fp32": f"{same_n}/{B}",
                          "token_positions_differing": f"{diff}/{tok}"}
             trace(f"bf16-operand mode: {bf16_mode['value']} audio-s/s, identical ids {same}/{B}")
         finally:
-            model.encoder.set_precision("fp32")
+            model.set_precision("fp32")
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:

@@ -89,6 +89,7 @@ SIGNATURES = {
     "pf_decoder_destroy": (None, [_vp]),
     "pf_decoder_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "pf_decoder_missing": (C.c_int, [_vp]),
+    "pf_decoder_set_precision": (C.c_int, [_vp, _i32]),
     "pf_decoder_forward": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_ctc_create": (_vp, [_i32, _i32]),
     "pf_ctc_destroy": (None, [_vp]),

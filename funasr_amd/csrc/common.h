@@ -100,9 +100,9 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);
 
 int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t stream);
 
-// out_bf16: y is a bf16 buffer (ldy in elements)
+// out_bf16 / in_bf16: y / x is a bf16 buffer (ldy / ldx in elements); statistics are always fp32
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
-                     int M, int D, int Dpad, float eps, hipStream_t stream, int out_bf16 = 0);
+                     int M, int D, int Dpad, float eps, hipStream_t stream, int out_bf16 = 0, int in_bf16 = 0);
 
 int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
                         hipStream_t stream);

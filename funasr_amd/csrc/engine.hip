@@ -459,6 +459,8 @@ struct Decoder {
     DecLayerW last;          // decoders3.0 (FFN only)
     bool resolved = false;
     DevBuf x, t1, t2, ffn, ffn2, q, kv, ctx, mem_lens, tok_lens, pval, pidx, hid;
+    int precision = 0;       // 0 fp32, 1 bf16 operands (GEMMs + cross-attention), fp32 residual / LN statistics / FSMN
+    DevBuf t16, ffn16, ffn2_16, q16, kv16, ctx16, mem16, hid16;
 };
 
 static int decoder_resolve(Decoder* d) {
@@ -539,6 +541,93 @@ static int dec_ffn(Decoder* d, const DecLayerW& w, const float* x, float* out, i
     return gemm_simple(ffn2, F, w.w2, F, nullptr, out, D, M, D, F, 0, nullptr, 0, nullptr, 0, s);
 }
 
+
+// bf16-operand decoder (throughput mode): every GEMM and the cross-attention take bf16 operands with fp32
+// accumulation; the token stream x, the FSMN and the LayerNorm statistics stay fp32. Expects x = embeds and the
+// length arrays already staged by pf_decoder_forward.
+static int decoder_forward_bf16(Decoder* d, const float* memory, int B, int T, int N, int32_t* ids, float* hidden_out,
+                                hipStream_t s) {
+    const pf_decoder_config& c = d->cfg;
+    const int D = c.d_model, F = c.ffn_dim, V = c.vocab_size, Mq = B * N, Mk = B * T;
+    typedef unsigned short u16;
+    if (d->t16.ensure(sizeof(u16) * (size_t)Mq * D) || d->ffn16.ensure(sizeof(u16) * (size_t)Mq * F) ||
+        d->ffn2_16.ensure(sizeof(u16) * (size_t)Mq * F) || d->q16.ensure(sizeof(u16) * (size_t)Mq * D) ||
+        d->kv16.ensure(sizeof(u16) * (size_t)Mk * 2 * D) || d->ctx16.ensure(sizeof(u16) * (size_t)Mq * D) ||
+        d->mem16.ensure(sizeof(u16) * (size_t)Mk * D) || d->hid16.ensure(sizeof(u16) * (size_t)Mq * D))
+        return -2;
+    u16* t16 = d->t16.as<u16>(); u16* ffn16 = d->ffn16.as<u16>(); u16* ffn2_16 = d->ffn2_16.as<u16>();
+    u16* q16 = d->q16.as<u16>(); u16* kv16 = d->kv16.as<u16>(); u16* ctx16 = d->ctx16.as<u16>();
+    u16* mem16 = d->mem16.as<u16>();
+    float* x = d->x.as<float>(); float* t1 = d->t1.as<float>(); float* t2 = d->t2.as<float>();
+    int rc;
+    if ((rc = launch_cast_bf16(memory, mem16, (size_t)Mk * D, s))) return rc;
+    auto w16 = [&](const std::string& name) { return d->tt.get_bf16(name, s); };
+    auto gemm16 = [&](const u16* A, int lda, const u16* W, int ldw, const float* bias, void* C, int ldc, int M, int Nn, int K,
+                      int relu, const float* R2, int ldr2, int c16) {
+        if (!W) return -2;
+        GemmArgs g{};
+        g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = reinterpret_cast<const float*>(W); g.ldw = ldw;
+        g.bias = bias; g.R2 = R2; g.ldr2 = ldr2; g.C = reinterpret_cast<float*>(C); g.ldc = ldc;
+        g.M = M; g.N = Nn; g.K = K; g.relu = relu; g.ab_bf16 = 1; g.c_bf16 = c16;
+        ProfScope ps(PROF_GEMM, 2.0 * M * (double)Nn * K, s);
+        return launch_gemm_f32(g, s);
+    };
+    auto ffn_bf16 = [&](const std::string& p, const DecLayerW& w, const float* xin, float* out) {
+        int r;
+        if ((r = launch_layernorm(xin, D, w.n1g, w.n1b, reinterpret_cast<float*>(t16), D, Mq, D, D, c.ln_eps, s, 1, 0))) return r;
+        if ((r = gemm16(t16, D, w16(p + "feed_forward.w_1.weight"), D, w.b1, ffn16, F, Mq, F, D, 1, nullptr, 0, 1))) return r;
+        if ((r = launch_layernorm(reinterpret_cast<const float*>(ffn16), F, w.fng, w.fnb, reinterpret_cast<float*>(ffn2_16), F,
+                                  Mq, F, F, c.ln_eps, s, 1, 1))) return r;
+        return gemm16(ffn2_16, F, w16(p + "feed_forward.w_2.weight"), F, nullptr, out, D, Mq, D, F, 0, nullptr, 0, 0);
+    };
+    const int left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
+    for (int l = 0; l < c.n_blocks; ++l) {
+        const DecLayerW& w = d->layers[l];
+        const std::string p = "decoders." + std::to_string(l) + ".";
+        if ((rc = ffn_bf16(p, w, x, t2))) return rc;
+        if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;
+        FsmnArgs fa{};
+        fa.in = t1; fa.ldin = D; fa.w = w.fsmn_w; fa.R = x; fa.ldr = D; fa.out = x; fa.ldo = D;
+        fa.lens = d->tok_lens.as<int>(); fa.B = B; fa.T = N; fa.C = D; fa.K = c.kernel_size; fa.left_pad = left_pad;
+        if ((rc = fsmn(fa, s))) return rc;
+        if ((rc = launch_layernorm(x, D, w.n3g, w.n3b, reinterpret_cast<float*>(t16), D, Mq, D, D, c.ln_eps, s, 1, 0))) return rc;
+        if ((rc = gemm16(t16, D, w16(p + "src_attn.linear_q.weight"), D, w.q_b, q16, D, Mq, D, D, 0, nullptr, 0, 1))) return rc;
+        if ((rc = gemm16(mem16, D, w16(p + "src_attn.linear_k_v.weight"), D, w.kv_b, kv16, 2 * D, Mk, 2 * D, D, 0, nullptr, 0, 1)))
+            return rc;
+        AttnArgs aa{};
+        aa.Q = reinterpret_cast<const float*>(q16); aa.ldq = D; aa.K = reinterpret_cast<const float*>(kv16); aa.ldk = 2 * D;
+        aa.V = reinterpret_cast<const float*>(kv16 + D); aa.ldv = 2 * D; aa.O = reinterpret_cast<float*>(ctx16); aa.ldo = D;
+        aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tq = N; aa.Tk = T;
+        aa.scale = powf((float)(D / c.n_heads), -0.5f);
+        {
+            ProfScope ps(PROF_ATTN, 4.0 * B * (double)N * T * D, s);
+            if ((rc = launch_attention_bf16(aa, s))) return rc;
+        }
+        if ((rc = gemm16(ctx16, D, w16(p + "src_attn.linear_out.weight"), D, w.o_b, x, D, Mq, D, D, 0, x, D, 0))) return rc;
+    }
+    if ((rc = ffn_bf16("decoders3.0.", d->last, x, t2))) return rc;
+    u16* hid16 = d->hid16.as<u16>();
+    if (hidden_out) {
+        if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), hidden_out, D, Mq, D, D,
+                            c.ln_eps, s))) return rc;
+    }
+    if (!ids) return 0;
+    if ((rc = launch_layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"),
+                               reinterpret_cast<float*>(hid16), D, Mq, D, D, c.ln_eps, s, 1, 0))) return rc;
+    const u16* ow = w16("output_layer.weight");
+    if (!ow) return -2;
+    const int nparts = 2 * ceil_div(V, 128);
+    if (d->pval.ensure(sizeof(float) * (size_t)Mq * nparts) || d->pidx.ensure(sizeof(int) * (size_t)Mq * nparts)) return -2;
+    GemmArgs g{};
+    g.A = reinterpret_cast<const float*>(hid16); g.lda = D; g.W = reinterpret_cast<const float*>(ow); g.ldw = D;
+    g.bias = d->tt.get("output_layer.bias"); g.M = Mq; g.N = V; g.K = D; g.ab_bf16 = 1;
+    g.amax_val = d->pval.as<float>(); g.amax_idx = d->pidx.as<int>(); g.amax_ld = nparts;
+    {
+        ProfScope ps(PROF_GEMM, 2.0 * Mq * (double)V * D, s);
+        if ((rc = launch_gemm_f32(g, s))) return rc;
+    }
+    return launch_argmax_reduce(d->pval.as<float>(), d->pidx.as<int>(), nparts, nparts, ids, nullptr, Mq, s);
+}
 
 // ================================================================================================ streaming
 // A lock-step batch of S independent streams (the reference handles exactly one: "batch_size must be set 1",
@@ -1121,7 +1210,15 @@ int pf_decoder_set_tensor(pf_decoder* dh, const char* name, const float* data, i
     Decoder* d = reinterpret_cast<Decoder*>(dh);
     PF_REQUIRE(d && name && data, "decoder_set_tensor: null");
     d->resolved = false;
+    d->tt.drop_bf16();
     return d->tt.set(name, data, numel);
+}
+/* same modes as pf_encoder_set_precision; the bf16 mode serves the fused arg-max route (logits_dev == NULL) */
+int pf_decoder_set_precision(pf_decoder* dh, int32_t mode) {
+    Decoder* d = reinterpret_cast<Decoder*>(dh);
+    PF_REQUIRE(d && (mode == 0 || mode == 1), "decoder_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+    d->precision = mode;
+    return 0;
 }
 int pf_decoder_missing(const pf_decoder* dh) {
     const Decoder* d = reinterpret_cast<const Decoder*>(dh);
@@ -1156,6 +1253,7 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     float* t2 = d->t2.as<float>();
     PF_HIP_TRY(hipMemcpyAsync(x, embeds, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     const int left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
+    if (d->precision == 1 && !logits) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
     for (int l = 0; l < c.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
         // DecoderLayerSANM.forward (paraformer/decoder.py:78-121)

@@ -26,6 +26,11 @@ constexpr int FRAMES_PER_BLOCK = 4;
 
 __device__ __forceinline__ int bitrev9(int i) { return (int)(__brev((unsigned)i) >> 23); }
 
+// Every wave works on its own LDS slice, and the DS operations of one wave are executed in program order: a write
+// followed by a read of another lane's element needs no workgroup barrier, only that the compiler keeps the order
+// (it must: the addresses may alias) -- 15 s_barriers per frame across 4 unrelated waves were pure stall.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
     // per wave: re[512], im[512]  (pw[257] aliases re after the FFT, raw samples alias im before it)
     __shared__ float lds[FRAMES_PER_BLOCK][2 * NFFT];
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
         const int i = lane + 64 * j;
         if (i < p.frame_len) im[i] = x[j] - mean;
     }
-    __syncthreads();
+    wave_sync();
     // ---- pre-emphasis (feature-window.cc:204-215) + window, stored bit-reversed for the DIT FFT
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -69,10 +74,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
         }
         re[bitrev9(i)] = v;
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int j = 0; j < 8; ++j) im[lane + 64 * j] = 0.f;
-    __syncthreads();
+    wave_sync();
 
     // ---- 512-point radix-2 decimation-in-time FFT, twiddle table tw[k] = exp(-2 pi i k / 512)
 #pragma unroll 1
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
             re[i0] = ar + tr; im[i0] = ai + ti;
             re[i1] = ar - tr; im[i1] = ai - ti;
         }
-        __syncthreads();
+        wave_sync();
     }
 
     // ---- power spectrum: |X|^2 computed as abs() then square like torchaudio's spectrum.abs().pow(2)
@@ -108,13 +113,13 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
             pw[j] = mag * mag;
         }
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int k = lane + 64 * j;
         if (k < NBIN) re[k] = pw[j];
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- mel projection over the sparse triangles + log floor (feature-fbank.cc:95-106)
     float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;

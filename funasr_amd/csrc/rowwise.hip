@@ -17,24 +17,32 @@ namespace pf {
 
 namespace {
 
+__device__ __forceinline__ float4 load4(const float* base, size_t off, bool bf16) {
+    if (!bf16) return *reinterpret_cast<const float4*>(base + off);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+    float4 v;
+    v.x = bf16_to_f32((unsigned short)(u.x & 0xffffu)); v.y = bf16_to_f32((unsigned short)(u.x >> 16));
+    v.z = bf16_to_f32((unsigned short)(u.y & 0xffffu)); v.w = bf16_to_f32((unsigned short)(u.y >> 16));
+    return v;
+}
+
 // One wave per row. NV = float4 chunks per lane (D <= 256 * NV).
 template <int NV, bool OUT_BF16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        int ldy, int M, int D, int Dpad, float eps) {
+                                                        int ldy, int M, int D, int Dpad, float eps, int in_bf16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nchunk = D >> 2;
-    const float* xr = x + (size_t)row * ldx;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane + 64 * j;
         if (c < nchunk) {
-            v[j] = *reinterpret_cast<const float4*>(xr + 4 * c);
+            v[j] = load4(x, (size_t)row * ldx + 4 * c, in_bf16 != 0);
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         } else {
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -102,15 +110,6 @@ __global__ __launch_bounds__(256) void scale_add_pe_kernel(const float* __restri
 // FSMN memory block. Thread = 4 channels; block = (C/4 threads) x FSMN_TT consecutive frames of one sequence,
 // a register sliding window of KS + TT - 1 masked input rows (each input row is fetched once per block).
 constexpr int FSMN_TT = 8;
-__device__ __forceinline__ float4 load4(const float* base, size_t off, bool bf16) {
-    if (!bf16) return *reinterpret_cast<const float4*>(base + off);
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
-    float4 v;
-    v.x = bf16_to_f32((unsigned short)(u.x & 0xffffu)); v.y = bf16_to_f32((unsigned short)(u.x >> 16));
-    v.z = bf16_to_f32((unsigned short)(u.y & 0xffffu)); v.w = bf16_to_f32((unsigned short)(u.y >> 16));
-    return v;
-}
-
 template <int KS, int LP>
 __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
     const int b = blockIdx.y;
@@ -187,7 +186,7 @@ int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t st
 }
 
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int M,
-                     int D, int Dpad, float eps, hipStream_t stream, int out_bf16) {
+                     int D, int Dpad, float eps, hipStream_t stream, int out_bf16, int in_bf16) {
     PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm: D must be a multiple of 4 and <= 2048");
     PF_REQUIRE(Dpad >= D && Dpad % 4 == 0 && Dpad <= 2048 && ldy >= Dpad, "layernorm: bad Dpad/ldy");
     PF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: strides must be multiples of 4");
@@ -196,8 +195,8 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     const int nv = ceil_div(Dpad / 4, 64);
 #define PF_LN(NV_)                                                                                                 \
     do {                                                                                                          \
-        if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV_, true>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps); \
-        else hipLaunchKernelGGL((layernorm_kernel<NV_, false>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps);         \
+        if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV_, true>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16); \
+        else hipLaunchKernelGGL((layernorm_kernel<NV_, false>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16);         \
     } while (0)
     if (nv <= 2) PF_LN(2);
     else if (nv <= 3) PF_LN(3);

@@ -71,6 +71,13 @@ class Paraformer(nn.Module):
                    decoder_conf=dc, predictor="CifPredictorV2", predictor_conf=dict(cfg["predictor"]), ctc_weight=0.0,
                    input_size=input_size, vocab_size=vocab)
 
+    def set_precision(self, mode: str = "fp32"):
+        """"fp32": exact-fp32 MFMA everywhere (parity mode). "bf16": bf16 operands for the encoder's and the decoder's
+        GEMMs and attention (fp32 accumulate / residual / LN / softmax / FSMN); the CIF predictor stays fp32."""
+        self.encoder.set_precision(mode)
+        self.decoder.set_precision(mode)
+        return self
+
     # ------------------------------------------------------------------------------------------- device pipeline
     def encode(self, speech: torch.Tensor, speech_lengths, **kwargs):
         out, olens, _ = self.encoder(speech, speech_lengths)      # model.py:286-313

@@ -73,12 +73,21 @@ class ParaformerSANMDecoder(HipModule):
         self.after_norm = layer_norm(D)
         self.output_layer = linear(vocab_size, D)
 
+    def set_precision(self, mode: str = "fp32"):
+        """"fp32" (default, parity) or "bf16" (bf16 operands for the GEMMs + cross-attention on the greedy route)."""
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self._precision = mode
+        return self
+
     def _make_config(self):
         return _lib.pf_decoder_config(self.vocab_size, self.d_model, self.attention_heads, self.linear_units,
                                       self.att_layer_num, self.kernel_size, self.sanm_shfit, 1e-12)
 
     def _run(self, hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits: bool, want_ids: bool, want_hidden: bool = False):
         lib, h = self._ensure_handle()
+        _lib.check(lib.pf_decoder_set_precision(h, 1 if getattr(self, "_precision", "fp32") == "bf16" else 0),
+                   "pf_decoder_set_precision")
         dev = self._handle_device
         mem = hs_pad.to(device=dev, dtype=torch.float32).contiguous()
         emb = ys_in_pad.to(device=dev, dtype=torch.float32).contiguous()

@@ -158,6 +158,9 @@ pf_decoder* pf_decoder_create(const pf_decoder_config* cfg);
 void pf_decoder_destroy(pf_decoder* d);
 int pf_decoder_set_tensor(pf_decoder* d, const char* name, const float* data, int64_t numel);
 int pf_decoder_missing(const pf_decoder* d);
+/* 0 = fp32 (default), 1 = bf16 operands for the GEMMs and the cross-attention (see pf_encoder_set_precision); applies
+ * to the fused arg-max route (logits_dev == NULL) */
+int pf_decoder_set_precision(pf_decoder* d, int32_t mode);
 /* memory_dev: [B, T, d_model] encoder output, mem_lens_host: [B]; embeds_dev: [B, N, d_model] CIF output,
  * tok_lens_host: [B]. Outputs (each may be NULL): logits_dev [B, N, vocab] (pre-softmax, decoder.py:444),
  * ids_dev int32 [B, N] = argmax over the vocabulary (fused into the output GEMM when logits_dev is NULL),

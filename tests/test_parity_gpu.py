@@ -299,3 +299,34 @@ def test_edge_cases_short_silent_and_zero_token_utterances(cuda):
     refl = O.paraformer_greedy(xl, torch.tensor([1000], dtype=torch.int32), sd, cfg)
     assert (rl["enc"].cpu() - refl["enc"]).abs().max().item() < 1e-3
     assert rl["raw_ids"] == refl["raw_ids"]
+
+
+def test_bf16_operand_decoder_stays_close_to_fp32_decoder(cuda):
+    """bf16-operand decoder (all GEMMs + cross-attention, fused arg-max route) against the fp32 decoder of the same
+    weights: final hidden states within a few percent, most arg-max ids unchanged even with random-init weights."""
+    from funasr_amd.paraformer_decoder import ParaformerSANMDecoder
+    cfg = synth.PARAFORMER_LARGE["decoder"]
+    sd = synth.decoder_state_dict(cfg, seed=4, with_embed=True)
+    kw = {k: v for k, v in cfg.items()}
+    dec = ParaformerSANMDecoder(**kw)
+    dec.load_state_dict(sd, strict=True)
+    dec = dec.to(cuda)
+    g = torch.Generator().manual_seed(11)
+    B, T, N = 3, 90, 14
+    mem = torch.randn(B, T, 512, generator=g) * 0.8
+    emb = torch.randn(B, N, 512, generator=g) * 0.8
+    mlen, tlen = [90, 61, 75], [14, 9, 11]
+    _, ids32, hid32, _ = dec._run(mem.to(cuda), mlen, emb.to(cuda), tlen, want_logits=False, want_ids=True, want_hidden=True)
+    dec.set_precision("bf16")
+    _, ids16, hid16, _ = dec._run(mem.to(cuda), mlen, emb.to(cuda), tlen, want_logits=False, want_ids=True, want_hidden=True)
+    dec.set_precision("fp32")
+    _, ids32b, hid32b, _ = dec._run(mem.to(cuda), mlen, emb.to(cuda), tlen, want_logits=False, want_ids=True, want_hidden=True)
+    assert torch.equal(hid32, hid32b) and torch.equal(ids32, ids32b)
+    valid = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        valid[b, : tlen[b]] = True
+    d = (hid16 - hid32).abs().cpu()[valid]
+    scale = hid32.abs().cpu()[valid].mean().item()
+    assert d.mean().item() < 0.03 * scale, (d.mean().item(), scale)
+    same = (ids16.cpu()[valid] == ids32.cpu()[valid]).float().mean().item()
+    assert same >= 0.7, same
