@@ -208,7 +208,8 @@ static int attention(const AttnArgs& a, double flops, hipStream_t s) {
 // ================================================================================================ frontend
 struct Frontend {
     pf_frontend_config cfg;
-    DevBuf window, twiddle, mel_w, mel_off, mel_len, cmvn_shift, cmvn_scale;
+    DevBuf window, twiddle, mel_w, mel_off, mel_len, mel_compact, mel_coff, cmvn_shift, cmvn_scale;
+    int mel_nnz = 0;
     DevBuf fbank, nfr;
     bool has_cmvn = false;
     int feat_dim() const { return cfg.n_mels * cfg.lfr_m; }
@@ -226,6 +227,17 @@ static int frontend_upload_tables(Frontend* f, const std::vector<float>& window,
         off[m] = first < 0 ? 0 : first;
         len[m] = first < 0 ? 0 : last - first + 1;
     }
+    std::vector<float> cw;
+    std::vector<int> coff(nm);
+    for (int m = 0; m < nm; ++m) {
+        coff[m] = (int)cw.size();
+        for (int k = 0; k < len[m]; ++k) cw.push_back(mel[(size_t)m * NB + off[m] + k]);
+    }
+    if (cw.empty()) cw.push_back(0.f);
+    f->mel_nnz = (int)cw.size();
+    if (f->mel_compact.ensure(sizeof(float) * cw.size()) || f->mel_coff.ensure(sizeof(int) * nm)) return -2;
+    PF_HIP_TRY(hipMemcpy(f->mel_compact.p, cw.data(), sizeof(float) * cw.size(), hipMemcpyHostToDevice));
+    PF_HIP_TRY(hipMemcpy(f->mel_coff.p, coff.data(), sizeof(int) * nm, hipMemcpyHostToDevice));
     if (f->window.ensure(sizeof(float) * window.size())) return -2;
     if (f->mel_w.ensure(sizeof(float) * mel.size())) return -2;
     if (f->mel_off.ensure(sizeof(int) * nm) || f->mel_len.ensure(sizeof(int) * nm)) return -2;
@@ -927,7 +939,8 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.frame_len = f->cfg.frame_length; a.frame_shift = f->cfg.frame_shift; a.n_mels = f->cfg.n_mels;
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
     a.twiddle = f->twiddle.as<float2>(); a.mel_weight = f->mel_w.as<float>(); a.mel_offset = f->mel_off.as<int>();
-    a.mel_len = f->mel_len.as<int>();
+    a.mel_len = f->mel_len.as<int>(); a.mel_compact = f->mel_compact.as<float>(); a.mel_coff = f->mel_coff.as<int>();
+    a.mel_nnz = f->mel_nnz;
     int rc;
     {
         double bytes = 0;
@@ -1512,7 +1525,8 @@ int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, 
     a.frame_len = f->cfg.frame_length; a.frame_shift = f->cfg.frame_shift; a.n_mels = f->cfg.n_mels;
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
     a.twiddle = f->twiddle.as<float2>(); a.mel_weight = f->mel_w.as<float>(); a.mel_offset = f->mel_off.as<int>();
-    a.mel_len = f->mel_len.as<int>();
+    a.mel_len = f->mel_len.as<int>(); a.mel_compact = f->mel_compact.as<float>(); a.mel_coff = f->mel_coff.as<int>();
+    a.mel_nnz = f->mel_nnz;
     return launch_fbank(a, 1, nfr, s);
 }
 

@@ -18,6 +18,9 @@ struct FbankArgs {
     const float* mel_weight;     // device dense [n_mels, 257]
     const int* mel_offset;       // device [n_mels] first non-zero fft bin
     const int* mel_len;          // device [n_mels] number of non-zero bins
+    const float* mel_compact;    // device [mel_nnz]: the non-zero weights of all triangles back to back
+    const int* mel_coff;         // device [n_mels] start of mel m inside mel_compact
+    int mel_nnz;
 };
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream);
 

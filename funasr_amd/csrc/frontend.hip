@@ -23,6 +23,7 @@ namespace {
 constexpr int NFFT = 512;
 constexpr int NBIN = NFFT / 2 + 1;   // 257
 constexpr int FRAMES_PER_BLOCK = 4;
+constexpr int MAX_NNZ = 2048;        // non-zero mel weights (80 triangles over 256 bins: ~510)
 
 __device__ __forceinline__ int bitrev9(int i) { return (int)(__brev((unsigned)i) >> 23); }
 
@@ -34,6 +35,13 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
     // per wave: re[512], im[512]  (pw[257] aliases re after the FFT, raw samples alias im before it)
     __shared__ float lds[FRAMES_PER_BLOCK][2 * NFFT];
+    // twiddles and the compacted mel triangles are read by every frame: staged once per workgroup (one barrier),
+    // so that the 36 twiddle fetches and the ~40-step triangle walk of a lane hit LDS instead of dependent global loads
+    __shared__ float2 tw_s[NFFT / 2];
+    __shared__ float cw_s[MAX_NNZ];
+    for (int i = threadIdx.x; i < NFFT / 2; i += 256) tw_s[i] = p.twiddle[i];
+    for (int i = threadIdx.x; i < p.mel_nnz; i += 256) cw_s[i] = p.mel_compact[i];
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
     const int nfr = p.n_frames[b];
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
             const int pos = k & (half - 1);
             const int i0 = (grp << st) + pos;
             const int i1 = i0 + half;
-            const float2 t = p.twiddle[pos * tstep];
+            const float2 t = tw_s[pos * tstep];
             const float xr = re[i1], xi = im[i1];
             const float tr = xr * t.x - xi * t.y;
             const float ti = xr * t.y + xi * t.x;
@@ -125,9 +133,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
     float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
     for (int m = lane; m < p.n_mels; m += 64) {
         const int off = p.mel_offset[m], len = p.mel_len[m];
-        const float* mw = p.mel_weight + (size_t)m * NBIN;
+        const float* mw = cw_s + p.mel_coff[m];
         float e = 0.f;
-        for (int k = 0; k < len; ++k) e = fmaf(mw[off + k], re[off + k], e);
+#pragma unroll 4
+        for (int k = 0; k < len; ++k) e = fmaf(mw[k], re[off + k], e);
         e = fmaxf(e, 1.1920928955078125e-07f);
         if (valid) out[m] = logf(e);
     }
@@ -168,6 +177,7 @@ __global__ __launch_bounds__(256) void lfr_cmvn_kernel(LfrArgs p) {
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream) {
     PF_REQUIRE(a.frame_len <= 448 && a.frame_len > 0, "fbank: frame length must be <= 448 samples");
     PF_REQUIRE(a.n_mels <= 128, "fbank: n_mels <= 128");
+    PF_REQUIRE(a.mel_nnz <= MAX_NNZ && a.mel_compact && a.mel_coff, "fbank: mel filterbank too dense for the LDS copy");
     if (max_frames_in_batch <= 0) return 0;
     dim3 grid(ceil_div(max_frames_in_batch, FRAMES_PER_BLOCK), B);
     hipLaunchKernelGGL(fbank_kernel, grid, dim3(256), 0, stream, a);

@@ -3,33 +3,38 @@
 //
 // With M << 128 the 128 x 128 tile kernel burns a full tile of MFMA work per 16 useful rows and exposes one long
 // serial K loop on a handful of CUs (27-110 us per GEMM regardless of M). Here the problem is treated as what it is:
-// a weight-streaming pass. v_mfma_f32_16x16x4_f32 (exact f32, 16-row tiles), one wave = 16 rows x 32 columns, no LDS
-// and no barriers: every lane fetches its own operands as 16-B loads (A: row l&15, 4 consecutive k; W: column l&15,
-// the same 4 k -- the MFMA k index is only a pairing, so the four floats of a load feed four MFMAs), weights are read
-// exactly once per 16-row tile, and K is split over blockIdx.y so that even a 15-row problem spreads its weight
-// stream over ~100+ CUs. Split-K partials are summed in a fixed order by a second tiny kernel that also applies the
-// epilogue (deterministic: hipGraph replay == eager launch, bit for bit).
+// a weight-streaming pass. v_mfma_f32_16x16x4_f32 (exact f32, 16-row tiles); one workgroup = 16*RM rows x 32 columns,
+// its 4 waves split K four ways (intra-workgroup split-K): no LDS staging and no barriers in the main loop, every
+// lane fetches its own operands as 16-B loads (A: row l&15, 4 consecutive k; W: column l&15, the same 4 k -- the MFMA
+// k index is only a pairing, so the four floats of a load feed four MFMAs). The four partial tiles meet in LDS and are
+// summed in a FIXED order (wave 0 + 1 + 2 + 3) by the epilogue, which also applies bias / ReLU / residuals and writes
+// 128-B row segments: one launch per GEMM (the streaming step is launch-latency bound), deterministic, and a row's
+// fma chain depends on K only -- never on how many rows or streams are in the batch (hipGraph replay == eager, a
+// stream's result is bitwise independent of its neighbours).
 #include "common.h"
 
 namespace pf {
 
 namespace {
 
-constexpr int SK_BN = 128;   // columns per block (4 waves x 32)
+constexpr int SK_BN = 32;    // columns per workgroup
+constexpr int SK_LD = 33;    // padded row of the LDS partial tiles
 
-// part == nullptr: single K slice, epilogue in-kernel. Otherwise raw partial sums to part[slice][M][N].
-// RM = 16-row MFMA tiles per wave (1, 2 or 4): more rows per wave re-use each weight load; a row's own fma chain
-// (k order, K slicing) is the same for every RM, so the choice changes speed only, never a bit of the result.
+// RM = 16-row MFMA tiles per workgroup in M (1, 2 or 4): more rows re-use each weight load; a row's own fma chain is
+// the same for every RM, so the choice changes speed only, never a bit of the result.
 template <int RM>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, int k_per_slice, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+    __shared__ float red[4][RM * 16][SK_LD];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.z * (16 * RM);
-    const int n0 = blockIdx.x * SK_BN + wave * 32;
-    if (n0 >= p.N) return;
-    const int kb = blockIdx.y * k_per_slice;
-    int ke = kb + k_per_slice;
+    const int m0 = blockIdx.y * (16 * RM);
+    const int n0 = blockIdx.x * SK_BN;
+    // this wave's quarter of K (in 16-wide steps)
+    const int steps = p.K >> 4;
+    const int spw = (steps + 3) >> 2;
+    const int kb = wave * spw * 16;
+    int ke = kb + spw * 16;
     ke = ke < p.K ? ke : p.K;
 
     const float* ap[RM];
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, int k_per_
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
+#pragma unroll 4
     for (int k = kb; k < ke; k += 16) {
         float4 a[RM];
 #pragma unroll
@@ -83,37 +88,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, int k_per_
 
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + j * 16 + i16;
-        if (col >= p.N) continue;
-        const float bv = (!part && p.bias) ? p.bias[col] : 0.f;
+    for (int i = 0; i < RM; ++i)
 #pragma unroll
-        for (int i = 0; i < RM; ++i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + i * 16 + kq * 4 + r;
-                if (row >= p.M) continue;
-                if (part) {
-                    part[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[i][j][r];
-                } else {
-                    float v = acc[i][j][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.R1) v = v + p.R1[(size_t)row * p.ldr1 + col];
-                    if (p.R2) v = p.R2[(size_t)row * p.ldr2 + col] + v;
-                    p.C[(size_t)row * p.ldc + col] = v;
-                }
-            }
-        }
-    }
-}
+            for (int r = 0; r < 4; ++r) red[wave][i * 16 + kq * 4 + r][j * 16 + i16] = acc[i][j][r];
+    __syncthreads();
 
-// fixed-order sum of the K slices + epilogue
-__global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(GemmArgs p, const float* __restrict__ part, int slices) {
-    const size_t total = (size_t)p.M * p.N;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int row = (int)(i / p.N), col = (int)(i % p.N);
-        float v = part[i];
-        for (int s = 1; s < slices; ++s) v += part[(size_t)s * total + i];
+    // fixed-order sum of the four K quarters + epilogue; consecutive threads -> consecutive columns of a row
+#pragma unroll
+    for (int e = 0; e < RM * 2; ++e) {
+        const int t = threadIdx.x + 256 * e;
+        const int lr = t >> 5, lc = t & 31;
+        const int row = m0 + lr, col = n0 + lc;
+        if (row >= p.M || col >= p.N) continue;
+        float v = ((red[0][lr][lc] + red[1][lr][lc]) + red[2][lr][lc]) + red[3][lr][lc];
         if (p.bias) v += p.bias[col];
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.R1) v = v + p.R1[(size_t)row * p.ldr1 + col];
@@ -121,12 +110,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(GemmArgs p, con
         p.C[(size_t)row * p.ldc + col] = v;
     }
 }
-
-struct Scratch {
-    float* p = nullptr;
-    size_t cap = 0;
-};
-Scratch g_part;   // split-K partials; grows outside of graph capture (first eager call with a shape)
 
 }  // namespace
 
@@ -137,38 +120,10 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm_skinny: row strides must be multiples of 4 floats");
     PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && a.C, "gemm_skinny: operands must be 16-B aligned");
     const int RM = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
-    const int nN = ceil_div(a.N, SK_BN), nM = ceil_div(a.M, 16 * RM);
-    // K slicing is a function of K ONLY (a row's summation order must not depend on how many other rows are in the
-    // batch): 128 k per slice -> 4 slices for K = 512, 16 for K = 2048; even a 15-row problem then streams its
-    // weights from >= 16-64 workgroups
-    const int kps = 128;
-    const int slices = ceil_div(a.K, kps);
-    dim3 grid(nN, slices, nM), block(256);
-    auto launch = [&](float* part) {
-        if (RM == 1) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, block, 0, stream, a, kps, part);
-        else if (RM == 2) hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, block, 0, stream, a, kps, part);
-        else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, block, 0, stream, a, kps, part);
-    };
-    if (slices == 1) {
-        launch(nullptr);
-        PF_HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    const size_t need = sizeof(float) * (size_t)slices * a.M * a.N;
-    if (need > g_part.cap) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &cs);
-        PF_REQUIRE(cs == hipStreamCaptureStatusNone, "gemm_skinny: split-K scratch must be sized by an eager call first");
-        PF_HIP_TRY(hipDeviceSynchronize());
-        if (g_part.p) PF_HIP_TRY(hipFree(g_part.p));
-        g_part.p = nullptr; g_part.cap = 0;
-        PF_HIP_TRY(hipMalloc((void**)&g_part.p, need + need / 4));
-        g_part.cap = need + need / 4;
-    }
-    launch(g_part.p);
-    const size_t total = (size_t)a.M * a.N;
-    const int rb = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    hipLaunchKernelGGL(gemm_skinny_reduce_kernel, dim3(rb), dim3(256), 0, stream, a, (const float*)g_part.p, slices);
+    dim3 grid(ceil_div(a.N, SK_BN), ceil_div(a.M, 16 * RM)), block(256);
+    if (RM == 1) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, block, 0, stream, a);
+    else if (RM == 2) hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, block, 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
