@@ -201,6 +201,8 @@ def main():
             lib.pf_prof_enable(0)
             ms, work, n = C.c_double(0), C.c_double(0), C.c_int64(0)
             lib.pf_prof_read(0, C.byref(ms), C.byref(work), C.byref(n))
+            from funasr_amd.metrics import micro_error_rate
+            ter, _, _ = micro_error_rate(res["raw_ids"], res16["raw_ids"])
             same = sum(1 for a, b in zip(res["raw_ids"], res16["raw_ids"]) if a == b)
             same_n = sum(1 for a, b in zip(res["token_num"], res16["token_num"]) if a == b)
             tok = sum(len(a) for a in res["raw_ids"])
@@ -211,7 +213,8 @@ def main():
                          "gemm_tflops_all_launches": round(work.value / (ms.value * 1e-3) / 1e12, 1) if ms.value > 0 else None,
                          "clips_with_identical_token_ids_vs_fp32": f"{same}/{B}",
                          "clips_with_identical_token_count_vs_fp32": f"{same_n}/{B}",
-                         "token_positions_differing": f"{diff}/{tok}"}
+                         "token_positions_differing": f"{diff}/{tok}",
+                         "token_error_rate_vs_fp32_mode": round(ter, 4)}
             trace(f"bf16-operand mode: {bf16_mode['value']} audio-s/s, identical ids {same}/{B}")
         finally:
             model.set_precision("fp32")
@@ -307,10 +310,12 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu_res, args):
             sample = [clips[0][: max(16000, int(budget_s * rate * 0.7) * 16000)]]
         t0 = time.perf_counter()
         done = 0
+        cpu_ids = []
         for i, w in enumerate(sample):
             r = run(w)
             done += 1
             if n_full >= 1:
+                cpu_ids.append(r["raw_ids"][0])
                 ok = r["raw_ids"][0] == gpu_res["raw_ids"][i]
                 match = ok if match is None else (match and ok)
             if time.perf_counter() - t0 > budget_s:
@@ -318,10 +323,14 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu_res, args):
         sample = sample[:done]
         dt = time.perf_counter() - t0
     secs = sum(w.numel() for w in sample) / 16000.0
+    ter_cpu = None
+    if cpu_ids:                      # the metric's "CER vs CPU ref" on what can be compared here: token ids, micro-averaged
+        from funasr_amd.metrics import micro_error_rate
+        ter_cpu = round(micro_error_rate(cpu_ids, gpu_res["raw_ids"][: len(cpu_ids)])[0], 6)
     return {"value": round(secs / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
             "sample": f"{len(sample)} x {secs / len(sample):g} s clip(s) of the same batch, batch_size 1, fp32, "
                       f"torch {torch.__version__} CPU ATen kernels, {cores} threads, {dt:.1f} s of CPU work",
-            "token_ids_match_gpu": match}
+            "token_ids_match_gpu": match, "token_error_rate_gpu_vs_cpu_ref": ter_cpu}
 
 
 if __name__ == "__main__":

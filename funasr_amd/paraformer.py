@@ -139,6 +139,12 @@ class Paraformer(nn.Module):
             key = list(key) * B
         if max(res["token_num"]) < 1:
             return [], meta_data
+        ibest_writer = None
+        if kwargs.get("output_dir") is not None:                        # model.py:571-575
+            if not hasattr(self, "writer"):
+                from .datadir_writer import DatadirWriter
+                self.writer = DatadirWriter(kwargs.get("output_dir"))
+            ibest_writer = self.writer["1best_recog"]
         results = []
         for i in range(B):
             token_int = res["ids"][i]
@@ -148,6 +154,9 @@ class Paraformer(nn.Module):
                 if not hasattr(tokenizer, "bpemodel"):
                     text, _ = sentence_postprocess(token)
                 results.append({"key": key[i], "text": text})
+                if ibest_writer is not None:                             # model.py:688-692
+                    ibest_writer["token"][key[i]] = " ".join(token)
+                    ibest_writer["text"][key[i]] = text
             else:
                 results.append({"key": key[i], "token_int": token_int})
         return results, meta_data

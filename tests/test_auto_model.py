@@ -125,3 +125,17 @@ def test_sentencepiece_tokenizer_registered(tmp_path):
     ids = tok.encode("hello world")
     assert tok.decode(ids) == "hello world" and tok.get_vocab_size() == 40
     assert tok.tokens2text(tok.ids2tokens(ids)) == "hello world"
+
+
+def test_metrics_and_datadir_writer(tmp_path):
+    from funasr_amd.datadir_writer import DatadirWriter
+    from funasr_amd.metrics import cer, edit_distance, micro_error_rate
+    assert edit_distance("kitten", "sitting") == 3 and edit_distance([], [1, 2]) == 2 and edit_distance([1, 2, 3], [1, 2, 3]) == 0
+    rate, edits, total = micro_error_rate([[1, 2, 3, 4], [5, 6]], [[1, 2, 4], [5, 6, 7]])
+    assert (edits, total) == (2, 6) and abs(rate - 2 / 6) < 1e-12
+    assert cer(["欢迎 大家，来体验!"], ["欢迎大家来体验"]) == 0.0 and cer(["abc"], ["ABD"]) == 1 / 3
+    with DatadirWriter(str(tmp_path / "out")) as w:
+        w["1best_recog"]["text"]["utt1"] = "你好"
+        w["1best_recog"]["token"]["utt1"] = "你 好"
+    assert (tmp_path / "out" / "1best_recog" / "text").read_text(encoding="utf-8") == "utt1 你好\n"
+    assert (tmp_path / "out" / "1best_recog" / "token").read_text(encoding="utf-8") == "utt1 你 好\n"

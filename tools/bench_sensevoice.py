@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2]: SenseVoiceSmall encoder-only (50 + 20 SAN-M blocks, CTC head 25055), batch 128 x 10 s clips on one
+MI355X: wav (resident in HBM) -> fbank/LFR/CMVN -> 4 query frames + encoder -> CTC GEMM with fused arg-max -> ids on host.
+Random-init weights of the exact architecture. Prints one JSON line (audio-seconds/s, ms per step, CPU-oracle check)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-clips", type=int, default=4)
+    args = ap.parse_args()
+    from funasr_amd import synth
+    from funasr_amd.sense_voice import SenseVoiceSmall
+    from funasr_amd.wav_frontend import WavFrontend
+
+    dev = torch.device("cuda:0")
+    cfg = synth.SENSEVOICE_SMALL
+    sd = synth.sensevoice_state_dict(cfg, seed=0)
+    model = SenseVoiceSmall.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev)
+    sh, sc = synth.synthetic_cmvn(560)
+    cmvn = torch.stack([sh, sc])
+    fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0, device=dev)
+    n = int(args.seconds * 16000)
+    base = [synth.speech_like(n, seed=500 + i) for i in range(8)]
+    clips = [base[i % 8].roll(97 * (i // 8)) for i in range(args.batch)]
+    wav = torch.stack(clips).to(dev)
+    lens = [n] * args.batch
+
+    def step(precision=None):
+        feats, flens = fe(wav, lens)
+        return model.recognize_features(feats, flens, "auto", "woitn")
+
+    out = {}
+    for mode in ("fp32", "bf16"):
+        model.encoder.set_precision(mode)
+        for _ in range(args.warmup):
+            res = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[mode] = dict(value=round(args.batch * args.seconds * args.steps / dt, 1), ms_per_step=round(dt / args.steps * 1e3, 2),
+                         res=res)
+    model.encoder.set_precision("fp32")
+    from oracle import paraformer_oracle as O
+    ok = True
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(args.cpu_clips):
+            f, fl = O.wav_frontend([clips[i]], cmvn)
+            ref = O.sensevoice_greedy(f, fl, sd, cfg)
+            ok = ok and ref["ids"][0] == out["fp32"]["res"]["ids"][i]
+    cpu_dt = time.perf_counter() - t0
+    from funasr_amd.metrics import micro_error_rate
+    ter = micro_error_rate(out["fp32"]["res"]["ids"], out["bf16"]["res"]["ids"])[0]
+    print(json.dumps({"metric": "audio-seconds/sec SenseVoiceSmall encoder+CTC, 10 s clips @ bs128", "value": out["fp32"]["value"],
+                      "unit": "audio-s/s", "ms_per_step": out["fp32"]["ms_per_step"], "dtype": "f32", "n_gpus": 1,
+                      "config": {"workload": f"SenseVoiceSmall (70 SAN-M blocks, CTC 25055, random-init), {args.batch} x {args.seconds:g} s"},
+                      "ids_equal_cpu_oracle": bool(ok), "cpu_oracle_audio_s_per_s": round(args.cpu_clips * args.seconds / cpu_dt, 1),
+                      "bf16_mode": {"value": out["bf16"]["value"], "ms_per_step": out["bf16"]["ms_per_step"],
+                                    "token_error_rate_vs_fp32_mode": round(ter, 4)}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
