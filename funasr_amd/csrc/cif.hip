@@ -65,8 +65,58 @@ __global__ __launch_bounds__(256) void alpha_kernel(AlphaArgs p) {
     }
 }
 
-// one lane per utterance: exact reference scan
+// One wave per utterance: the exact reference scan. The recurrence is serial by definition (a sequential-order float64
+// prefix sum rounded to float32 per step, cif_predictor.py:835-846), so it runs on lane 0 -- but out of LDS: the wave
+// first stages the alphas with coalesced loads and afterwards writes peaks / remainders / fire flags back coalesced,
+// instead of one dependent global round trip per frame (0.2 ms -> ~10 us at T = 500).
+constexpr int CIF_MAX_T = 4096;     // frames per utterance that fit the LDS staging (4 arrays x 16 KB)
 __global__ __launch_bounds__(64) void cif_scan_kernel(CifScanArgs p) {
+    __shared__ float s_al[CIF_MAX_T], s_pk[CIF_MAX_T], s_rm[CIF_MAX_T];
+    __shared__ int s_ff[CIF_MAX_T];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int Te = p.T + 1;
+    float* al = p.alphas + (size_t)b * Te;
+    const int len = p.lens[b];
+    for (int t = lane; t < Te; t += 64) {
+        float a = t < p.T ? al[t] : 0.f;
+        if (p.tail_threshold > 0.f) {
+            // tail_process_fn: with tail_mask the threshold lands on index len (mask_2 - mask_1), else on index T
+            const bool hit = p.tail_mask ? (t == len) : (t == p.T);
+            if (hit) a = __fadd_rn(a, p.tail_threshold);
+        }
+        s_al[t] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double cs = 0.0;
+        float prev_floor = 0.f;
+        int n = 0;
+#pragma unroll 4
+        for (int t = 0; t < Te; ++t) {
+            cs += (double)s_al[t];
+            const float ps = (float)cs;
+            const float fl = floorf(ps);
+            const bool fire = (fl - prev_floor) > 0.f;
+            const float fires = __fsub_rn(__fadd_rn(fire ? 1.f : 0.f, ps), fl);
+            s_pk[t] = fires;
+            s_rm[t] = __fsub_rn(fires, floorf(fires));
+            s_ff[t] = fire ? 1 : 0;
+            n += fire ? 1 : 0;
+            prev_floor = fl;
+        }
+        p.n_fires[b] = n;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < Te; t += 64) {
+        al[t] = s_al[t];
+        p.peaks[(size_t)b * Te + t] = s_pk[t];
+        p.rems[(size_t)b * Te + t] = s_rm[t];
+        p.fire_flag[(size_t)b * Te + t] = s_ff[t];
+    }
+}
+
+// fallback for very long utterances (T >= CIF_MAX_T): one lane per utterance straight from HBM
+__global__ __launch_bounds__(64) void cif_scan_long_kernel(CifScanArgs p) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= p.B) return;
     const int Te = p.T + 1;
@@ -81,7 +131,6 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(CifScanArgs p) {
     for (int t = 0; t < Te; ++t) {
         float a = t < p.T ? al[t] : 0.f;
         if (p.tail_threshold > 0.f) {
-            // tail_process_fn: with tail_mask the threshold lands on index len (mask_2 - mask_1), else on index T
             const bool hit = p.tail_mask ? (t == len) : (t == p.T);
             if (hit) a = __fadd_rn(a, p.tail_threshold);
         }
@@ -100,33 +149,57 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(CifScanArgs p) {
     p.n_fires[b] = n;
 }
 
-// one thread per (utterance, channel)
+// one thread per (utterance, channel). The per-frame scalars (alpha, remainder, fire flag) are staged in LDS once per
+// workgroup; the channel loads of 8 consecutive frames are issued together (they do not depend on the running sum), so
+// the serial float64 accumulation no longer waits on one HBM round trip per frame.
 __global__ __launch_bounds__(256) void cif_emit_kernel(CifEmitArgs p) {
+    __shared__ float s_al[CIF_MAX_T], s_rm[CIF_MAX_T];
+    __shared__ int s_ff[CIF_MAX_T];
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    if (c >= p.D) return;
     const int Te = p.T + 1;
+    const bool staged = Te <= CIF_MAX_T;
     const float* al = p.alphas + (size_t)b * Te;
     const float* rm = p.rems + (size_t)b * Te;
     const int* ff = p.fire_flag + (size_t)b * Te;
+    if (staged) {
+        for (int t = threadIdx.x; t < Te; t += 256) {
+            s_al[t] = al[t];
+            s_rm[t] = rm[t];
+            s_ff[t] = ff[t];
+        }
+        __syncthreads();
+    }
+    if (c >= p.D) return;
     const float* h = p.hidden + (size_t)b * p.T * p.D + c;
     float* out = p.embeds + (size_t)b * p.N * p.D + c;
     double acc = 0.0;
     float prevP = 0.f, prev_remh = 0.f;
     int k = 0;
-    for (int t = 0; t < Te; ++t) {
-        const float hv = t < p.T ? h[(size_t)t * p.D] : 0.f;
-        const float prod = __fmul_rn(al[t], hv);
-        acc += (double)prod;
-        const float P = (float)acc;
-        if (ff[t]) {
-            const float remh = __fmul_rn(rm[t], hv);
-            // frames - shift_frames + shift_remain_frames - remain_frames, left to right (cif_predictor.py:896)
-            const float v = __fsub_rn(__fadd_rn(__fsub_rn(P, prevP), prev_remh), remh);
-            if (k < p.N) out[(size_t)k * p.D] = v;
-            prevP = P;
-            prev_remh = remh;
-            ++k;
+    for (int t0 = 0; t0 < Te; t0 += 8) {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j;
+            hv[j] = t < p.T ? h[(size_t)t * p.D] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j;
+            if (t >= Te) break;
+            const float a = staged ? s_al[t] : al[t];
+            const float prod = __fmul_rn(a, hv[j]);
+            acc += (double)prod;
+            const float P = (float)acc;
+            if (staged ? s_ff[t] : ff[t]) {
+                const float remh = __fmul_rn(staged ? s_rm[t] : rm[t], hv[j]);
+                // frames - shift_frames + shift_remain_frames - remain_frames, left to right (cif_predictor.py:896)
+                const float v = __fsub_rn(__fadd_rn(__fsub_rn(P, prevP), prev_remh), remh);
+                if (k < p.N) out[(size_t)k * p.D] = v;
+                prevP = P;
+                prev_remh = remh;
+                ++k;
+            }
         }
     }
     for (; k < p.N; ++k) out[(size_t)k * p.D] = 0.f;
@@ -199,7 +272,8 @@ int launch_alpha(const AlphaArgs& a, hipStream_t stream) {
 }
 
 int launch_cif_scan(const CifScanArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(cif_scan_kernel, dim3(ceil_div(a.B, 64)), dim3(64), 0, stream, a);
+    if (a.T + 1 <= CIF_MAX_T) hipLaunchKernelGGL(cif_scan_kernel, dim3(a.B), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(cif_scan_long_kernel, dim3(ceil_div(a.B, 64)), dim3(64), 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -208,8 +208,8 @@ static int attention(const AttnArgs& a, double flops, hipStream_t s) {
 // ================================================================================================ frontend
 struct Frontend {
     pf_frontend_config cfg;
-    DevBuf window, twiddle, mel_w, mel_off, mel_len, mel_compact, mel_coff, cmvn_shift, cmvn_scale;
-    int mel_nnz = 0;
+    DevBuf window, twiddle, piece_w, piece_k0, mel_first, mel_count, cmvn_shift, cmvn_scale;
+    int n_pieces = 0;
     DevBuf fbank, nfr;
     bool has_cmvn = false;
     int feat_dim() const { return cfg.n_mels * cfg.lfr_m; }
@@ -218,33 +218,36 @@ struct Frontend {
 static float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
 
 static int frontend_upload_tables(Frontend* f, const std::vector<float>& window, const std::vector<float>& mel) {
+    // the mel triangles (dense [n_mels, 257]) are cut into pieces of <= 8 consecutive fft bins: a lane of the fbank
+    // kernel owns <= 2 pieces (weights in registers), a mel bin is the fixed-order sum of its pieces
     const int nm = f->cfg.n_mels, NB = 257;
-    std::vector<int> off(nm), len(nm);
+    std::vector<float> pw;
+    std::vector<int> pk0, first(nm), count(nm);
     for (int m = 0; m < nm; ++m) {
-        int first = -1, last = -1;
+        int lo = -1, hi = -1;
         for (int k = 0; k < NB; ++k)
-            if (mel[(size_t)m * NB + k] != 0.f) { if (first < 0) first = k; last = k; }
-        off[m] = first < 0 ? 0 : first;
-        len[m] = first < 0 ? 0 : last - first + 1;
+            if (mel[(size_t)m * NB + k] != 0.f) { if (lo < 0) lo = k; hi = k; }
+        first[m] = (int)pk0.size();
+        if (lo >= 0) {
+            for (int k0 = lo; k0 <= hi; k0 += 8) {
+                pk0.push_back(k0);
+                for (int t = 0; t < 8; ++t) pw.push_back((k0 + t <= hi) ? mel[(size_t)m * NB + k0 + t] : 0.f);
+            }
+        }
+        count[m] = (int)pk0.size() - first[m];
     }
-    std::vector<float> cw;
-    std::vector<int> coff(nm);
-    for (int m = 0; m < nm; ++m) {
-        coff[m] = (int)cw.size();
-        for (int k = 0; k < len[m]; ++k) cw.push_back(mel[(size_t)m * NB + off[m] + k]);
-    }
-    if (cw.empty()) cw.push_back(0.f);
-    f->mel_nnz = (int)cw.size();
-    if (f->mel_compact.ensure(sizeof(float) * cw.size()) || f->mel_coff.ensure(sizeof(int) * nm)) return -2;
-    PF_HIP_TRY(hipMemcpy(f->mel_compact.p, cw.data(), sizeof(float) * cw.size(), hipMemcpyHostToDevice));
-    PF_HIP_TRY(hipMemcpy(f->mel_coff.p, coff.data(), sizeof(int) * nm, hipMemcpyHostToDevice));
-    if (f->window.ensure(sizeof(float) * window.size())) return -2;
-    if (f->mel_w.ensure(sizeof(float) * mel.size())) return -2;
-    if (f->mel_off.ensure(sizeof(int) * nm) || f->mel_len.ensure(sizeof(int) * nm)) return -2;
+    if (pk0.empty()) { pk0.push_back(0); pw.resize(8, 0.f); }
+    if (pk0.size() > 128) { set_error("frontend: mel filterbank needs more than 128 eight-bin pieces"); return -1; }
+    f->n_pieces = (int)pk0.size();
+    if (f->window.ensure(sizeof(float) * window.size()) || f->piece_w.ensure(sizeof(float) * pw.size()) ||
+        f->piece_k0.ensure(sizeof(int) * pk0.size()) || f->mel_first.ensure(sizeof(int) * nm) ||
+        f->mel_count.ensure(sizeof(int) * nm))
+        return -2;
     PF_HIP_TRY(hipMemcpy(f->window.p, window.data(), sizeof(float) * window.size(), hipMemcpyHostToDevice));
-    PF_HIP_TRY(hipMemcpy(f->mel_w.p, mel.data(), sizeof(float) * mel.size(), hipMemcpyHostToDevice));
-    PF_HIP_TRY(hipMemcpy(f->mel_off.p, off.data(), sizeof(int) * nm, hipMemcpyHostToDevice));
-    PF_HIP_TRY(hipMemcpy(f->mel_len.p, len.data(), sizeof(int) * nm, hipMemcpyHostToDevice));
+    PF_HIP_TRY(hipMemcpy(f->piece_w.p, pw.data(), sizeof(float) * pw.size(), hipMemcpyHostToDevice));
+    PF_HIP_TRY(hipMemcpy(f->piece_k0.p, pk0.data(), sizeof(int) * pk0.size(), hipMemcpyHostToDevice));
+    PF_HIP_TRY(hipMemcpy(f->mel_first.p, first.data(), sizeof(int) * nm, hipMemcpyHostToDevice));
+    PF_HIP_TRY(hipMemcpy(f->mel_count.p, count.data(), sizeof(int) * nm, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -857,21 +860,21 @@ int pf_prof_read(int kind, double* total_ms, double* total_work, int64_t* launch
 pf_frontend* pf_frontend_create(const pf_frontend_config* cfg) {
     if (!cfg) { set_error("frontend: null config"); return nullptr; }
     if (check_device()) return nullptr;
-    if (cfg->frame_length <= 0 || cfg->frame_length > 448 || cfg->frame_shift <= 0 || cfg->n_mels <= 0 ||
+    if (cfg->frame_length <= 0 || cfg->frame_length > 512 || cfg->frame_shift <= 0 || cfg->n_mels <= 0 ||
         cfg->n_mels > 128 || cfg->n_mels % 4 || cfg->lfr_m <= 0 || cfg->lfr_n <= 0) {
-        set_error("frontend: unsupported config (frame_length <= 448, n_mels % 4 == 0, n_mels <= 128)");
+        set_error("frontend: unsupported config (frame_length <= 512, n_mels % 4 == 0, n_mels <= 128)");
         return nullptr;
     }
     std::unique_ptr<Frontend> f(new Frontend());
     f->cfg = *cfg;
-    std::vector<float> tw(512);
-    for (int k = 0; k < 256; ++k) {
+    std::vector<float> tw(1024);                       // exp(-2 pi i k / 512), k = 0 .. 511
+    for (int k = 0; k < 512; ++k) {
         const double a = 6.283185307179586476925286766559005 * k / 512.0;
         tw[2 * k] = (float)cos(a);
         tw[2 * k + 1] = (float)(-sin(a));
     }
-    if (f->twiddle.ensure(sizeof(float) * 512)) return nullptr;
-    if (hipMemcpy(f->twiddle.p, tw.data(), sizeof(float) * 512, hipMemcpyHostToDevice) != hipSuccess) {
+    if (f->twiddle.ensure(sizeof(float) * 1024)) return nullptr;
+    if (hipMemcpy(f->twiddle.p, tw.data(), sizeof(float) * 1024, hipMemcpyHostToDevice) != hipSuccess) {
         set_error("frontend: twiddle upload failed");
         return nullptr;
     }
@@ -938,9 +941,8 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.wav = wav; a.wav_stride = (size_t)wav_stride; a.n_frames = f->nfr.as<int>(); a.fbank = fb; a.max_frames = max_fr;
     a.frame_len = f->cfg.frame_length; a.frame_shift = f->cfg.frame_shift; a.n_mels = f->cfg.n_mels;
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
-    a.twiddle = f->twiddle.as<float2>(); a.mel_weight = f->mel_w.as<float>(); a.mel_offset = f->mel_off.as<int>();
-    a.mel_len = f->mel_len.as<int>(); a.mel_compact = f->mel_compact.as<float>(); a.mel_coff = f->mel_coff.as<int>();
-    a.mel_nnz = f->mel_nnz;
+    a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
+    a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     int rc;
     {
         double bytes = 0;
@@ -1524,9 +1526,8 @@ int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, 
     a.wav = wav_dev; a.wav_stride = (size_t)n_samples; a.n_frames = f->nfr.as<int>(); a.fbank = fbank_dev; a.max_frames = nfr;
     a.frame_len = f->cfg.frame_length; a.frame_shift = f->cfg.frame_shift; a.n_mels = f->cfg.n_mels;
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
-    a.twiddle = f->twiddle.as<float2>(); a.mel_weight = f->mel_w.as<float>(); a.mel_offset = f->mel_off.as<int>();
-    a.mel_len = f->mel_len.as<int>(); a.mel_compact = f->mel_compact.as<float>(); a.mel_coff = f->mel_coff.as<int>();
-    a.mel_nnz = f->mel_nnz;
+    a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
+    a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     return launch_fbank(a, 1, nfr, s);
 }
 

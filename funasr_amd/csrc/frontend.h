@@ -14,13 +14,13 @@ struct FbankArgs {
     float in_scale;              // 32768 (wav_frontend.py:168-169)
     float preemph;               // 0.97
     const float* window;         // device [frame_len]
-    const float2* twiddle;       // device [256] (cos, -sin)(2 pi k / 512)
-    const float* mel_weight;     // device dense [n_mels, 257]
-    const int* mel_offset;       // device [n_mels] first non-zero fft bin
-    const int* mel_len;          // device [n_mels] number of non-zero bins
-    const float* mel_compact;    // device [mel_nnz]: the non-zero weights of all triangles back to back
-    const int* mel_coff;         // device [n_mels] start of mel m inside mel_compact
-    int mel_nnz;
+    const float2* twiddle;       // device [512] (cos, -sin)(2 pi k / 512)
+    // the triangles cut into pieces of <= 8 consecutive bins (a lane owns <= 2 pieces, weights in registers)
+    const float* piece_w;        // device [n_pieces, 8] weights (zero padded)
+    const int* piece_k0;         // device [n_pieces] first fft bin of the piece (k0 + 7 <= 256: clamped, pad weights are 0)
+    const int* mel_first;        // device [n_mels] first piece of mel m
+    const int* mel_count;        // device [n_mels] pieces of mel m
+    int n_pieces;                // <= 128
 };
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream);
 

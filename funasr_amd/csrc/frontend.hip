@@ -22,123 +22,202 @@ namespace {
 
 constexpr int NFFT = 512;
 constexpr int NBIN = NFFT / 2 + 1;   // 257
-constexpr int FRAMES_PER_BLOCK = 4;
-constexpr int MAX_NNZ = 2048;        // non-zero mel weights (80 triangles over 256 bins: ~510)
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int MAX_PIECES = 128;
 
-__device__ __forceinline__ int bitrev9(int i) { return (int)(__brev((unsigned)i) >> 23); }
+// forward radix-4 butterfly (W_4 = -i) on 4 complex values held by one lane, followed by the stage twiddles
+__device__ __forceinline__ void bfly4(float2 (&v)[4], const float2 (&tw)[3]) {
+    const float2 a = v[0], b = v[1], c = v[2], d = v[3];
+    const float2 s02 = make_float2(a.x + c.x, a.y + c.y), d02 = make_float2(a.x - c.x, a.y - c.y);
+    const float2 s13 = make_float2(b.x + d.x, b.y + d.y), d13 = make_float2(b.x - d.x, b.y - d.y);
+    v[0] = make_float2(s02.x + s13.x, s02.y + s13.y);
+    const float2 y1 = make_float2(d02.x + d13.y, d02.y - d13.x);      // a - i b - c + i d
+    const float2 y2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+    const float2 y3 = make_float2(d02.x - d13.y, d02.y + d13.x);      // a + i b - c - i d
+    v[1] = make_float2(y1.x * tw[0].x - y1.y * tw[0].y, y1.x * tw[0].y + y1.y * tw[0].x);
+    v[2] = make_float2(y2.x * tw[1].x - y2.y * tw[1].y, y2.x * tw[1].y + y2.y * tw[1].x);
+    v[3] = make_float2(y3.x * tw[2].x - y3.y * tw[2].y, y3.x * tw[2].y + y3.y * tw[2].x);
+}
 
-// Every wave works on its own LDS slice, and the DS operations of one wave are executed in program order: a write
-// followed by a read of another lane's element needs no workgroup barrier, only that the compiler keeps the order
-// (it must: the addresses may alias) -- 15 s_barriers per frame across 4 unrelated waves were pure stall.
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
-
-__global__ __launch_bounds__(256) void fbank_kernel(FbankArgs p) {
-    // per wave: re[512], im[512]  (pw[257] aliases re after the FFT, raw samples alias im before it)
-    __shared__ float lds[FRAMES_PER_BLOCK][2 * NFFT];
-    // twiddles and the compacted mel triangles are read by every frame: staged once per workgroup (one barrier),
-    // so that the 36 twiddle fetches and the ~40-step triangle walk of a lane hit LDS instead of dependent global loads
-    __shared__ float2 tw_s[NFFT / 2];
-    __shared__ float cw_s[MAX_NNZ];
-    for (int i = threadIdx.x; i < NFFT / 2; i += 256) tw_s[i] = p.twiddle[i];
-    for (int i = threadIdx.x; i < p.mel_nnz; i += 256) cw_s[i] = p.mel_compact[i];
-    __syncthreads();
+// One PERSISTENT wave per stream of frames. The 512-point real FFT is a 256-point complex FFT of z[n] = x[2n] + i x[2n+1]
+// (radix-4, decimation in frequency, 4 stages) followed by the real-input split: lane l holds z[l + 64 j] in registers,
+// the butterflies of every stage are lane-local, and between stages the wave regroups its 256 values through its own
+// 2 KB LDS slice (3 exchanges of 4 x 8 B per lane instead of 9 radix-2 passes over LDS). No workgroup barriers: a wave
+// only ever touches its own slice and its DS operations execute in order. Everything that does not change from frame to
+// frame lives in registers for the life of the wave: window coefficients, stage twiddles, and the weights of the (at
+// most two) mel-triangle pieces this lane accumulates.
+__global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_frames) {
+    __shared__ float2 zs[WAVES_PER_BLOCK][NFFT / 2];          // exchange buffer / spectrum Z in natural order
+    __shared__ float ps[WAVES_PER_BLOCK][NBIN + 7];           // power spectrum (+ zero tail for clamped piece reads)
+    __shared__ float part[WAVES_PER_BLOCK][MAX_PIECES];       // partial sums of the mel pieces
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int nfr = p.n_frames[b];
-    int f = blockIdx.x * FRAMES_PER_BLOCK + wave;
-    const bool valid = f < nfr;
-    if (!valid) f = nfr > 0 ? nfr - 1 : 0;
-    float* re = lds[wave];
-    float* im = lds[wave] + NFFT;
-    const bool any = nfr > 0;
+    float2* z = zs[wave];
+    float* pw = ps[wave];
+    float* pt = part[wave];
 
-    // ---- load + scale, DC removal (feature-window.cc:186-196)
-    const float* w = p.wav + (size_t)b * p.wav_stride + (size_t)f * p.frame_shift;
-    float x[7];
-    float s = 0.f;
+    // ---- per-lane constants
+    float win_e[4], win_o[4];                                  // window at samples 2n, 2n+1 for n = lane + 64 j
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int i = lane + 64 * j;
-        x[j] = (any && i < p.frame_len) ? w[i] * p.in_scale : 0.f;
-        s += x[j];
+    for (int j = 0; j < 4; ++j) {
+        const int i0 = 2 * (lane + 64 * j);
+        win_e[j] = i0 < p.frame_len ? p.window[i0] : 0.f;
+        win_o[j] = i0 + 1 < p.frame_len ? p.window[i0 + 1] : 0.f;
     }
-    s = wave_sum(s);
-    const float mean = s / (float)p.frame_len;
+    float2 tw0[3], tw1[3], tw2[3];                             // W_256^{r lane}, W_64^{r (lane&15)}, W_16^{r (lane&3)}
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int i = lane + 64 * j;
-        if (i < p.frame_len) im[i] = x[j] - mean;
+    for (int r = 1; r <= 3; ++r) {
+        tw0[r - 1] = p.twiddle[(2 * r * lane) & 511];
+        tw1[r - 1] = p.twiddle[(8 * r * (lane & 15)) & 511];
+        tw2[r - 1] = p.twiddle[(32 * r * (lane & 3)) & 511];
     }
-    wave_sync();
-    // ---- pre-emphasis (feature-window.cc:204-215) + window, stored bit-reversed for the DIT FFT
+    const float2 one[3] = {make_float2(1.f, 0.f), make_float2(1.f, 0.f), make_float2(1.f, 0.f)};
+    float2 twx[4];                                             // W_512^{k} for the real-input split, k = lane + 64 j
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = lane + 64 * j;
-        float v = 0.f;
-        if (i < p.frame_len) {
-            const float cur = im[i];
-            const float prev = im[i > 0 ? i - 1 : 0];
-            v = __fsub_rn(cur, __fmul_rn(p.preemph, prev)) * p.window[i];
-        }
-        re[bitrev9(i)] = v;
+    for (int j = 0; j < 4; ++j) twx[j] = p.twiddle[lane + 64 * j];
+    float pwgt[2][8];
+    int pk0[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pc = lane + 64 * q;
+        pk0[q] = pc < p.n_pieces ? p.piece_k0[pc] : 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pwgt[q][t] = pc < p.n_pieces ? p.piece_w[pc * 8 + t] : 0.f;
     }
-    wave_sync();
+    int mfirst[2], mcount[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) im[lane + 64 * j] = 0.f;
-    wave_sync();
+    for (int q = 0; q < 2; ++q) {
+        const int m = lane + 64 * q;
+        mfirst[q] = m < p.n_mels ? p.mel_first[m] : 0;
+        mcount[q] = m < p.n_mels ? p.mel_count[m] : 0;
+    }
+    for (int t = lane; t < 8; t += 64) pw[NBIN - 1 + t] = 0.f;   // zero tail (bins 257..263 never written)
 
-    // ---- 512-point radix-2 decimation-in-time FFT, twiddle table tw[k] = exp(-2 pi i k / 512)
-#pragma unroll 1
-    for (int st = 1; st <= 9; ++st) {
-        const int half = 1 << (st - 1);
-        const int tstep = NFFT >> st;
+    const int wave_id = blockIdx.x * WAVES_PER_BLOCK + wave, n_waves = gridDim.x * WAVES_PER_BLOCK;
+    // raw samples of frame g (2n, 2n+1 for n = lane + 64 j); issued one frame ahead so that the HBM/L2 round trip of
+    // the next frame overlaps the FFT of the current one
+    auto fetch = [&](int g, float (&re)[4], float (&ro)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { re[j] = 0.f; ro[j] = 0.f; }
+        if (g >= total_frames) return;
+        const int b = g / p.max_frames, f = g - b * p.max_frames;
+        if (f >= p.n_frames[b]) return;
+        const float* w = p.wav + (size_t)b * p.wav_stride + (size_t)f * p.frame_shift;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int k = lane + 64 * j;            // butterfly id 0..255
-            const int grp = k >> (st - 1);
-            const int pos = k & (half - 1);
-            const int i0 = (grp << st) + pos;
-            const int i1 = i0 + half;
-            const float2 t = tw_s[pos * tstep];
-            const float xr = re[i1], xi = im[i1];
-            const float tr = xr * t.x - xi * t.y;
-            const float ti = xr * t.y + xi * t.x;
-            const float ar = re[i0], ai = im[i0];
-            re[i0] = ar + tr; im[i0] = ai + ti;
-            re[i1] = ar - tr; im[i1] = ai - ti;
+            const int i0 = 2 * (lane + 64 * j);
+            if (i0 < p.frame_len) re[j] = w[i0];
+            if (i0 + 1 < p.frame_len) ro[j] = w[i0 + 1];
         }
-        wave_sync();
-    }
-
-    // ---- power spectrum: |X|^2 computed as abs() then square like torchaudio's spectrum.abs().pow(2)
-    float pw[5];
+    };
+    float ne[4], no[4];
+    fetch(wave_id, ne, no);
+    for (int g = wave_id; g < total_frames; g += n_waves) {
+        const int b = g / p.max_frames, f = g - b * p.max_frames;
+        float xe[4], xo[4];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int k = lane + 64 * j;
-        if (k < NBIN) {
-            const float a = re[k], c = im[k];
-            const float mag = sqrtf(a * a + c * c);
-            pw[j] = mag * mag;
+        for (int j = 0; j < 4; ++j) { xe[j] = ne[j]; xo[j] = no[j]; }
+        fetch(g + n_waves, ne, no);
+        if (f >= p.n_frames[b]) continue;                      // wave-uniform
+
+        // ---- scale; DC removal (feature-window.cc:186-196)
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xe[j] = xe[j] * p.in_scale;
+            xo[j] = xo[j] * p.in_scale;
+            s += xe[j] + xo[j];
         }
-    }
-    wave_sync();
+        s = wave_sum(s);
+        const float mean = s / (float)p.frame_len;
+        // ---- pre-emphasis y[i] = x[i] - 0.97 x[i-1], x[-1] := x[0] (:204-215), then the window
+        float prev_lane[4];                                    // x[2n - 1] = odd sample of n - 1 (lane - 1, same j)
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int k = lane + 64 * j;
-        if (k < NBIN) re[k] = pw[j];
-    }
-    wave_sync();
+        for (int j = 0; j < 4; ++j) {
+            const int i0 = 2 * (lane + 64 * j);
+            xe[j] = i0 < p.frame_len ? xe[j] - mean : 0.f;
+            xo[j] = i0 + 1 < p.frame_len ? xo[j] - mean : 0.f;
+            prev_lane[j] = __shfl(xo[j], (lane + 63) & 63, 64);   // lane 0 receives lane 63's odd sample of the SAME j
+        }
+        float2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // for lane 0 the predecessor of sample 128 j is lane 63's odd sample of j - 1; sample 0 precedes itself
+            float pe = prev_lane[j];
+            if (lane == 0) pe = j == 0 ? xe[0] : prev_lane[j - 1];
+            const float ye = __fsub_rn(xe[j], __fmul_rn(p.preemph, pe));
+            const float yo = __fsub_rn(xo[j], __fmul_rn(p.preemph, xe[j]));
+            v[j] = make_float2(ye * win_e[j], yo * win_o[j]);
+        }
 
-    // ---- mel projection over the sparse triangles + log floor (feature-fbank.cc:95-106)
-    float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
-    for (int m = lane; m < p.n_mels; m += 64) {
-        const int off = p.mel_offset[m], len = p.mel_len[m];
-        const float* mw = cw_s + p.mel_coff[m];
-        float e = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < len; ++k) e = fmaf(mw[k], re[off + k], e);
-        e = fmaxf(e, 1.1920928955078125e-07f);
-        if (valid) out[m] = logf(e);
+        // ---- 256-point complex FFT, radix-4 DIF; position p = 64 d3 + 16 d2 + 4 d1 + d0
+        bfly4(v, tw0);                                         // over d3; lane = p & 63
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[64 * r + lane] = v[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = z[64 * (lane >> 4) + 16 * r + (lane & 15)];
+        bfly4(v, tw1);                                         // over d2
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[64 * (lane >> 4) + 16 * r + (lane & 15)] = v[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = z[64 * (lane >> 4) + 16 * ((lane >> 2) & 3) + 4 * r + (lane & 3)];
+        bfly4(v, tw2);                                         // over d1
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[64 * (lane >> 4) + 16 * ((lane >> 2) & 3) + 4 * r + (lane & 3)] = v[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = z[4 * lane + r];
+        bfly4(v, one);                                         // over d0 (no twiddles)
+        __builtin_amdgcn_wave_barrier();
+        // element (lane, r) is Z[digit-reversed position]: natural order into LDS
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- real-input split X[k] = E + W_512^k O,  E = (Z[k] + conj Z[256-k]) / 2,  O = -i (Z[k] - conj Z[256-k]) / 2
+        //      and the power spectrum, computed as abs() then square like torchaudio's spectrum.abs().pow(2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane + 64 * j;
+            const float2 zk = z[k], zc = z[(256 - k) & 255];
+            const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+            const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+            const float xr = er + (twx[j].x * orr - twx[j].y * oi);
+            const float xi = ei + (twx[j].x * oi + twx[j].y * orr);
+            const float mag = sqrtf(xr * xr + xi * xi);
+            pw[k] = mag * mag;
+            if (k == 0) {                                      // bin 256: W_512^256 = -1
+                const float x256 = er - orr;
+                const float m2 = fabsf(x256);
+                pw[256] = m2 * m2;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- mel projection: this lane's (<= 2) triangle pieces, then the pieces of its (<= 2) mel bins in fixed order
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float e = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) e = fmaf(pwgt[q][t], pw[pk0[q] + t], e);
+            pt[lane + 64 * q] = e;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = lane + 64 * q;
+            if (m < p.n_mels) {
+                float e = 0.f;
+                for (int c = 0; c < mcount[q]; ++c) e += pt[mfirst[q] + c];
+                e = fmaxf(e, 1.1920928955078125e-07f);         // feature-fbank.cc:102-106
+                out[m] = logf(e);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -175,12 +254,18 @@ __global__ __launch_bounds__(256) void lfr_cmvn_kernel(LfrArgs p) {
 }  // namespace
 
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream) {
-    PF_REQUIRE(a.frame_len <= 448 && a.frame_len > 0, "fbank: frame length must be <= 448 samples");
+    PF_REQUIRE(a.frame_len <= 512 && a.frame_len > 0, "fbank: frame length must be <= 512 samples");
     PF_REQUIRE(a.n_mels <= 128, "fbank: n_mels <= 128");
-    PF_REQUIRE(a.mel_nnz <= MAX_NNZ && a.mel_compact && a.mel_coff, "fbank: mel filterbank too dense for the LDS copy");
+    PF_REQUIRE(a.n_pieces <= MAX_PIECES && a.piece_w && a.piece_k0 && a.mel_first && a.mel_count,
+               "fbank: mel filterbank needs more than 128 eight-bin pieces");
+    PF_REQUIRE(a.max_frames >= max_frames_in_batch, "fbank: max_frames");
     if (max_frames_in_batch <= 0) return 0;
-    dim3 grid(ceil_div(max_frames_in_batch, FRAMES_PER_BLOCK), B);
-    hipLaunchKernelGGL(fbank_kernel, grid, dim3(256), 0, stream, a);
+    const long long total = (long long)B * a.max_frames;
+    PF_REQUIRE(total < (1ll << 31), "fbank: batch too large");
+    // persistent waves: enough workgroups to fill every CU several times over, each wave strides over the frames
+    long long blocks = (total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks > 256 * 4) blocks = 256 * 4;      // 4 workgroups x 4 waves per CU = the 128-VGPR occupancy
+    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
