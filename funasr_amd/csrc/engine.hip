@@ -46,6 +46,9 @@ struct ProfScope {
 enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_FSMN = 2, PROF_LN = 3, PROF_FBANK = 4, PROF_KINDS = 5 };
 
 // ------------------------------------------------------------------------------------------------ utilities
+// bumped whenever a workspace moves: captured hipGraphs hold raw workspace pointers and must be re-captured then
+static unsigned long long g_ws_epoch = 0;
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -56,6 +59,7 @@ struct DevBuf {
         size_t want = bytes + bytes / 8;
         PF_HIP_TRY(hipMalloc(&p, want));
         cap = want;
+        ++g_ws_epoch;
         return 0;
     }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
@@ -660,6 +664,7 @@ struct Stream {
     int start_idx = 0;                                       // host mirror of StreamDev.start_idx
     std::map<int, hipGraphExec_t> graphs;
     std::map<int, int> seen;
+    unsigned long long graph_epoch = 0;                      // g_ws_epoch the graphs were captured under
     bool use_graph = true;
     ~Stream() {
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
@@ -1451,6 +1456,14 @@ int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t 
     const int key = n | (is_final ? 1 << 10 : 0) | (tail_chunk ? 1 << 11 : 0);
     int rc;
     const bool graphable = st->use_graph && !g_prof_on;
+    if (st->graph_epoch != g_ws_epoch) {
+        // a workspace of the encoder / predictor / decoder handles moved since the capture (e.g. an offline batch grew
+        // it): the graphs hold stale pointers -- drop them, run this step eagerly, capture again next time
+        for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+        st->graphs.clear();
+        st->seen.clear();
+        st->graph_epoch = g_ws_epoch;
+    }
     if (graphable && st->seen[key] >= 1) {
         auto it = st->graphs.find(key);
         if (it == st->graphs.end()) {
@@ -1469,6 +1482,7 @@ int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t 
     } else {
         if ((rc = stream_enqueue(st, n, is_final, tail_chunk, s))) return rc;
         st->seen[key] += 1;
+        st->graph_epoch = g_ws_epoch;                        // allocations of this eager pass are accounted for
     }
     if (enc_out)
         PF_HIP_TRY(hipMemcpyAsync(enc_out, st->enc_out.p, sizeof(float) * (size_t)S * W * D, hipMemcpyDeviceToDevice, s));

@@ -159,3 +159,24 @@ def test_stream_other_chunk_geometries_vs_streaming_oracle(cuda, chunk, enc_lb, 
         assert [t for t in ids[0] if t not in (0, 1, 2)] == oids, (i, ids[0], oids)
         assert len(ids[0]) == trace[0]["n"], i
     sb.close()
+
+
+def test_graphs_survive_workspace_growth_by_an_offline_batch(cuda):
+    """The captured step holds raw workspace pointers of the shared encoder/decoder handles; an offline batch that grows
+    those workspaces in between must not leave the graph with stale pointers (it is re-captured)."""
+    from funasr_amd.paraformer_streaming import StreamBatch
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    sb = StreamBatch(model, 1, [0, 10, 5], 4, 1, use_graph=True)
+    ref = StreamBatch(model, 1, [0, 10, 5], 4, 1, use_graph=False)
+    gen = torch.Generator().manual_seed(0)
+    for i in range(6):
+        f = torch.from_numpy(g[f"feats_{i}"]).to(cuda)
+        a, ea = sb.step(f, return_enc=True)
+        b, eb = ref.step(f, return_enc=True)
+        assert a == b and torch.equal(ea, eb), i
+        if i == 2:      # a big offline batch through the same handles: every workspace is re-allocated
+            x = torch.randn(4, 300, 560, generator=gen).to(cuda)
+            model.recognize_features(x, [300, 250, 100, 280])
+    sb.close()
+    ref.close()
