@@ -86,22 +86,36 @@ class Paraformer(nn.Module):
     def calc_predictor(self, encoder_out, encoder_out_lens):
         return self.predictor(encoder_out, None, None, ignore_id=self.ignore_id, lengths=encoder_out_lens)
 
-    def recognize_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
-        """[B, T, 560] features -> per-utterance token ids (sos/eos/blank removed), all on the current HIP stream."""
+    def enqueue_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
+        """[B, T, 560] features -> everything up to the fused arg-max ENQUEUED on the current HIP stream. The only host
+        synchronisation inside is the CIF token count (it sizes the decoder, like the .item() at cif_predictor.py:311).
+        `collect()` brings the ids to the host; a serving loop enqueues batch i+1 before collecting batch i, so the
+        GPU never waits for the host-side post-processing."""
         enc, olens = self.encode(speech, speech_lengths)
         embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
         tok = [int(round(v)) for v in token_num.tolist()]           # pre_token_length.round().long(), model.py:614
-        B = enc.shape[0]
-        raw: List[List[int]] = [[] for _ in range(B)]
+        ids = None
         if max(tok) >= 1:                                            # model.py:615-616
             ids, _ = self.decoder.greedy(enc, olens, embeds, tok)
-            ids_host = ids.cpu()                                     # the single D2H copy of the batch
+        pending = dict(tok=tok, ids=ids, B=enc.shape[0])
+        if return_intermediate:
+            pending["extra"] = dict(enc=enc, olens=olens, embeds=embeds, alphas=alphas, peaks=peaks)
+        return pending
+
+    def collect(self, pending: dict) -> dict:
+        tok, B = pending["tok"], pending["B"]
+        raw: List[List[int]] = [[] for _ in range(B)]
+        if pending["ids"] is not None:
+            ids_host = pending["ids"].cpu()                          # the single D2H copy of the batch
             raw = [ids_host[b, : tok[b]].tolist() for b in range(B)]
         drop = (self.sos, self.eos, self.blank_id)
         out = dict(token_num=tok, raw_ids=raw, ids=[[t for t in r if t not in drop] for r in raw])
-        if return_intermediate:
-            out.update(enc=enc, olens=olens, embeds=embeds, alphas=alphas, peaks=peaks)
+        out.update(pending.get("extra", {}))
         return out
+
+    def recognize_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
+        """[B, T, 560] features -> per-utterance token ids (sos/eos/blank removed), all on the current HIP stream."""
+        return self.collect(self.enqueue_features(speech, speech_lengths, return_intermediate))
 
     # ---------------------------------------------------------------------------------------------- AutoModel API
     def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
