@@ -139,3 +139,30 @@ def test_metrics_and_datadir_writer(tmp_path):
         w["1best_recog"]["token"]["utt1"] = "你 好"
     assert (tmp_path / "out" / "1best_recog" / "text").read_text(encoding="utf-8") == "utt1 你好\n"
     assert (tmp_path / "out" / "1best_recog" / "token").read_text(encoding="utf-8") == "utt1 你 好\n"
+
+
+def test_progress_callback_called_like_the_reference_spec():
+    """The reference's executable spec of the AutoModel -> model boundary (tests/test_auto_model.py:43-71 there): a model
+    object exposing only parameters()/eval()/inference(data_in=..., **kw) -> (results, {"batch_data_time": 1}) is driven in
+    batches of `batch_size`, and the progress callback sees (items done, total) after every batch."""
+    class DummyModel:
+        def __init__(self):
+            self.param = torch.nn.Parameter(torch.zeros(1))
+
+        def parameters(self):
+            return iter([self.param])
+
+        def eval(self):
+            pass
+
+        def inference(self, data_in=None, **kwargs):
+            return [{"text": str(d)} for d in data_in], {"batch_data_time": 1}
+
+    am = AutoModel.__new__(AutoModel)
+    am.model = DummyModel()
+    am.kwargs = {"batch_size": 2, "disable_pbar": True}
+    am._base_kwargs = dict(am.kwargs)
+    progress = []
+    res = AutoModel.inference(am, ["a", "b", "c"], progress_callback=lambda idx, total: progress.append((idx, total)))
+    assert progress == [(2, 3), (3, 3)]
+    assert [r["text"] for r in res] == ["a", "b", "c"]
