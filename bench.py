@@ -189,8 +189,10 @@ def main():
                           launches_per_step=n.value / args.steps)
     gemm = prof["gemm_f32_mfma"]
     ach = gemm["work_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12 if gemm["ms_per_step"] > 0 else 0.0
+    pmc = pmc_traffic("gemm_f32_mfma_kernel")
     roofline = dict(bound="mfma", kernel="gemm_f32_mfma_kernel", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic("gemm_f32_mfma_kernel"),
+                    unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc[0] if pmc else None,
+                    traffic_unit="HBM bytes per launch (PMC)", traffic_source=pmc[1] if pmc else None,
                     flops_per_launch=gemm["work_per_step"] / max(gemm["launches_per_step"], 1),
                     avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
                     launches_per_step=gemm["launches_per_step"])
@@ -276,7 +278,7 @@ def pmc_traffic(kernel: str):
         if n == 0:
             return None
         b = sum((r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in rows) / n
-        return {"bytes_per_launch": round(b), "source": os.path.basename(files[-1])}
+        return round(b), os.path.basename(files[-1])
     except (OSError, KeyError, ValueError):
         return None
 
