@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-operand-mode measurement")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="precision of the MAIN timed region "
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"], help="precision of the MAIN timed region "
                     "(default fp32 = the parity mode the headline is quoted on; bf16 is for profiling the throughput mode)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (dry run of the N>1 code "
                     "path with every rank on cuda:0 of a single-GPU box)")
@@ -180,7 +180,7 @@ def main():
     value = audio_s / dt
     # ---- roofline of the dominant kernel (f32 MFMA GEMM), from hipEvents recorded around every launch in the
     #      timed region on the launch stream
-    kinds = {0: "gemm_f32_mfma", 1: "attention_f32", 2: "fsmn", 3: "layernorm", 4: "fbank"}
+    kinds = {0: "gemm_f32_mfma", 1: "attention_f32", 2: "fsmn", 3: "layernorm", 4: "fbank", 5: "gemm_bf16x3"}
     prof = {}
     for k, name in kinds.items():
         ms, work, n = C.c_double(0), C.c_double(0), C.c_int64(0)
@@ -197,6 +197,9 @@ def main():
                     avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
                     launches_per_step=gemm["launches_per_step"])
     kernels = {k: dict(ms_per_step=round(v["ms_per_step"], 3), launches=v["launches_per_step"]) for k, v in prof.items()}
+    for nm in ("gemm_f32_mfma", "gemm_bf16x3"):
+        if prof[nm]["ms_per_step"] > 0:
+            kernels[nm]["tflops"] = round(prof[nm]["work_per_step"] / (prof[nm]["ms_per_step"] * 1e-3) / 1e12, 2)
     attn = prof["attention_f32"]
     if attn["ms_per_step"] > 0:
         kernels["attention_f32"]["tflops"] = round(attn["work_per_step"] / (attn["ms_per_step"] * 1e-3) / 1e12, 2)

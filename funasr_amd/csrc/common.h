@@ -55,6 +55,24 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
     return __builtin_bit_cast(float, (unsigned int)h << 16);
 }
 
+// fp32 -> three bf16 with x = hi + mid + lo exactly (each difference below is exact in fp32; 8 + 8 + 8 significand bits)
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = f32_to_bf16(x);
+    const float r1 = x - bf16_to_f32(h);
+    m = f32_to_bf16(r1);
+    const float r2 = r1 - bf16_to_f32(m);
+    l = f32_to_bf16(r2);
+}
+// four consecutive values -> the three planes at p, p + plane, p + 2 plane (8-B stores)
+__device__ __forceinline__ void store_split3x4(unsigned short* p, size_t plane, const float (&o)[4]) {
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(o[e], h[e], m[e], l[e]);
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(p + plane) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+    *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+
 // ---------------------------------------------------------------- LDS-DMA issued behind the compiler's back
 // hipcc cannot prove that a ds_read does not alias an LDS-DMA in flight (SIInsertWaitcnts only separates them with
 // alias-scope metadata HIP does not attach), so with __builtin_amdgcn_global_load_lds it puts `s_waitcnt vmcnt(0)` in
@@ -100,9 +118,28 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);
 
 int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t stream);
 
-// out_bf16 / in_bf16: y / x is a bf16 buffer (ldy / ldx in elements); statistics are always fp32
+// fp32-accurate GEMM with both operands as three bf16 planes (gemm_split3.hip): x = hi + mid + lo, the planes of a
+// matrix are `*_plane` ELEMENTS apart, row strides in elements
+struct Gemm3Args {
+    const unsigned short* A; int lda; size_t a_plane;   // [3][M, K]
+    const unsigned short* W; int ldw; size_t w_plane;   // [3][N, K]
+    const float* bias;
+    const float* R1; int ldr1;                          // v = v + R1, then v = R2 + v (as GemmArgs)
+    const float* R2; int ldr2;
+    float* C; int ldc;                                  // fp32 output ...
+    unsigned short* C3; int ldc3; size_t c_plane;       // ... or (C3 != nullptr) three bf16 planes of the result
+    int M, N, K;                                        // K % 32 == 0, N % 4 == 0
+    int relu;
+};
+int launch_gemm_split3(const Gemm3Args& a, hipStream_t stream);
+// fp32 [M, N] -> three bf16 planes [M, ldy]; columns N..ldy-1 are written as zero
+int launch_split3(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, hipStream_t stream);
+
+// out_mode 1 / in_bf16: y / x is a bf16 buffer (ldy / ldx in elements); out_mode 2: y receives the three bf16 planes
+// of the result (split3), `plane` elements apart; statistics are always fp32
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
-                     int M, int D, int Dpad, float eps, hipStream_t stream, int out_bf16 = 0, int in_bf16 = 0);
+                     int M, int D, int Dpad, float eps, hipStream_t stream, int out_mode = 0, int in_bf16 = 0,
+                     size_t plane = 0);
 
 int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
                         hipStream_t stream);

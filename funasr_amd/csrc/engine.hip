@@ -43,7 +43,7 @@ struct ProfScope {
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(b, s); g_prof.push_back({a, b, kind, work}); } }
 };
-enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_FSMN = 2, PROF_LN = 3, PROF_FBANK = 4, PROF_KINDS = 5 };
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_FSMN = 2, PROF_LN = 3, PROF_FBANK = 4, PROF_GEMM3 = 5, PROF_KINDS = 6 };
 
 // ------------------------------------------------------------------------------------------------ utilities
 // bumped whenever a workspace moves: captured hipGraphs hold raw workspace pointers and must be re-captured then
@@ -136,6 +136,23 @@ struct TensorTable {
     void drop_bf16() {
         for (auto& kv : b16) if (kv.second) (void)hipFree(kv.second);
         b16.clear();
+    }
+    // the three bf16 planes [3][rows, cols] of a [rows, cols] weight (gemm_split3.hip); shares the b16 cache under a
+    // suffixed key, so it is dropped with it
+    const unsigned short* get_split3(const std::string& name, int rows, int cols, hipStream_t s) {
+        const std::string key = name + "#split3";
+        auto it = b16.find(key);
+        if (it != b16.end()) return it->second;
+        const Tensor& x = t.at(name);
+        const size_t n = x.kind == 1 ? (size_t)x.rows * x.cols_pad : (size_t)x.numel;
+        unsigned short* p = nullptr;
+        if (n != (size_t)rows * cols || cols % 8 != 0 || hipMalloc((void**)&p, sizeof(unsigned short) * 3 * n) != hipSuccess) {
+            set_error("split3 planes of " + name + " failed");
+            return nullptr;
+        }
+        if (launch_split3(x.d, cols, p, cols, n, rows, cols, s)) { (void)hipFree(p); return nullptr; }
+        b16[key] = p;
+        return p;
     }
     const unsigned short* get_bf16(const std::string& name, hipStream_t s) {
         auto it = b16.find(name);
@@ -287,6 +304,7 @@ struct EncLayerW {
     const float *n1g, *n1b, *qkv_w, *qkv_b, *fsmn_w, *out_w, *out_b, *n2g, *n2b, *w1, *b1, *w2, *b2;
     int in_dim, in_pad;
     const unsigned short *qkv_w16 = nullptr, *out_w16 = nullptr, *w1_16 = nullptr, *w2_16 = nullptr;   // bf16 mode
+    const unsigned short *qkv_w3 = nullptr, *out_w3 = nullptr, *w1_3 = nullptr, *w2_3 = nullptr;       // bf16x3 mode
     std::string prefix;
 };
 
@@ -297,8 +315,10 @@ struct Encoder {
     bool resolved = false;
     DevBuf x, xn, qkv, mem, ctx, ffn, lens, pe;
     int pe_T = 0;
-    int precision = 0;               // 0: fp32 MFMA everywhere (parity mode); 1: bf16 operands for GEMMs + attention
-    DevBuf xn16, qkv16, ctx16, ffn16;
+    // 0: fp32 MFMA everywhere; 1: bf16 operands for GEMMs + attention (throughput mode, bf16-class error);
+    // 2: fp32 results from bf16x3 split operands on the bf16 MFMA (gemm_split3.hip), everything else as in mode 0
+    int precision = 0;
+    DevBuf xn16, qkv16, ctx16, ffn16;   // mode 1: bf16 activations; mode 2: xn16 / ctx16 / ffn16 hold three planes each
 };
 
 static void enc_layer_names(std::vector<std::pair<std::string, int>>& out, const pf_encoder_config& c) {
@@ -419,6 +439,50 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         }
         if ((rc = gemm16(xn16, D, w.w1_16, D, w.b1, ffn16, F, F, D, 1, nullptr, 0, nullptr, 0, 1))) return rc;
         return gemm16(ffn16, F, w.w2_16, F, w.b2, x, D, D, F, 0, nullptr, 0, x, D, 0);
+    }
+    if (e->precision == 2 && !cc) {
+        // ---- fp32-accurate mode on the bf16 matrix cores: every GEMM operand is three bf16 planes (x = hi + mid + lo
+        //      exactly), produced by LayerNorm, by the relu epilogue of w_1 and by one split pass over the attention
+        //      output; FSMN, attention, residuals and LayerNorm statistics are the fp32 kernels of mode 0
+        unsigned short* xn3 = e->xn16.as<unsigned short>();
+        unsigned short* ctx3 = e->ctx16.as<unsigned short>();
+        unsigned short* ffn3 = e->ffn16.as<unsigned short>();
+        auto gemm3 = [&](const unsigned short* A, int lda, const unsigned short* W, const float* bias, float* C, int ldc,
+                         unsigned short* C3, int N, int K, int relu, const float* R1, int ldr1, const float* R2, int ldr2) {
+            Gemm3Args g{};
+            g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)N * K;
+            g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
+            g.C3 = C3; g.ldc3 = N; g.c_plane = (size_t)M * N; g.M = M; g.N = N; g.K = K; g.relu = relu;
+            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
+            return launch_gemm_split3(g, s);
+        };
+        {
+            ProfScope ps(PROF_LN, 10.0 * M * (double)w.in_dim, s);
+            if ((rc = launch_layernorm(x_in, ld_in, w.n1g, w.n1b, reinterpret_cast<float*>(xn3), w.in_pad, M, w.in_dim,
+                                       w.in_pad, c.ln_eps, s, 2, 0, (size_t)M * w.in_pad))) return rc;
+        }
+        if ((rc = gemm3(xn3, w.in_pad, w.qkv_w3, w.qkv_b, qkv, 3 * D, nullptr, 3 * D, w.in_pad, 0, nullptr, 0, nullptr, 0)))
+            return rc;
+        FsmnArgs fa{};
+        fa.in = qkv + 2 * D; fa.ldin = 3 * D; fa.w = w.fsmn_w; fa.R = nullptr; fa.ldr = 0; fa.out = mem; fa.ldo = D;
+        fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size;
+        fa.left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
+        if ((rc = fsmn(fa, s))) return rc;
+        AttnArgs aa{};
+        aa.Q = qkv; aa.ldq = 3 * D; aa.K = qkv + D; aa.ldk = 3 * D; aa.V = qkv + 2 * D; aa.ldv = 3 * D;
+        aa.O = ctx; aa.ldo = D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
+        aa.scale = powf((float)(D / c.n_heads), -0.5f);
+        if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s))) return rc;
+        if ((rc = launch_split3(ctx, D, ctx3, D, (size_t)M * D, M, D, s))) return rc;
+        const float* resid3 = (w.in_dim == D) ? x_in : nullptr;
+        if ((rc = gemm3(ctx3, D, w.out_w3, w.out_b, x, D, nullptr, D, D, 0, mem, D, resid3, ld_in))) return rc;
+        {
+            ProfScope ps(PROF_LN, 10.0 * M * (double)D, s);
+            if ((rc = launch_layernorm(x, D, w.n2g, w.n2b, reinterpret_cast<float*>(xn3), D, M, D, D, c.ln_eps, s, 2, 0,
+                                       (size_t)M * D))) return rc;
+        }
+        if ((rc = gemm3(xn3, D, w.w1_3, w.b1, nullptr, 0, ffn3, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
+        return gemm3(ffn3, F, w.w2_3, w.b2, x, D, nullptr, D, F, 0, nullptr, 0, x, D);
     }
     // norm1 -> fused QKV projection
     if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
@@ -1020,7 +1084,7 @@ int pf_encoder_set_tensor(pf_encoder* eh, const char* name, const float* data, i
  * residual stream / LayerNorm statistics / softmax / FSMN): the throughput mode of BASELINE configs[1] */
 int pf_encoder_set_precision(pf_encoder* eh, int32_t mode) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);
-    PF_REQUIRE(e && (mode == 0 || mode == 1), "encoder_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+    PF_REQUIRE(e && mode >= 0 && mode <= 2, "encoder_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 operands) or 2 (fp32 via bf16x3)");
     e->precision = mode;
     return 0;
 }
@@ -1052,6 +1116,19 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
             w.w1_16 = e->tt.get_bf16(w.prefix + "feed_forward.w_1.weight", s);
             w.w2_16 = e->tt.get_bf16(w.prefix + "feed_forward.w_2.weight", s);
             if (!w.qkv_w16 || !w.out_w16 || !w.w1_16 || !w.w2_16) return -2;
+        }
+    }
+    if (e->precision == 2) {
+        if (e->xn16.ensure(sizeof(unsigned short) * 3 * M * (Dpad > D ? Dpad : D)) ||
+            e->ctx16.ensure(sizeof(unsigned short) * 3 * M * D) || e->ffn16.ensure(sizeof(unsigned short) * 3 * M * F))
+            return -2;
+        for (auto& w : e->layers) {
+            if (w.qkv_w3) continue;
+            w.qkv_w3 = e->tt.get_split3(w.prefix + "self_attn.linear_q_k_v.weight", 3 * D, w.in_pad, s);
+            w.out_w3 = e->tt.get_split3(w.prefix + "self_attn.linear_out.weight", D, D, s);
+            w.w1_3 = e->tt.get_split3(w.prefix + "feed_forward.w_1.weight", F, D, s);
+            w.w2_3 = e->tt.get_split3(w.prefix + "feed_forward.w_2.weight", D, F, s);
+            if (!w.qkv_w3 || !w.out_w3 || !w.w1_3 || !w.w2_3) return -2;
         }
     }
     if (e->x.ensure(sizeof(float) * M * D) || e->xn.ensure(sizeof(float) * M * (Dpad > D ? Dpad : D)) ||
@@ -1236,7 +1313,7 @@ int pf_decoder_set_tensor(pf_decoder* dh, const char* name, const float* data, i
 /* same modes as pf_encoder_set_precision; the bf16 mode serves the fused arg-max route (logits_dev == NULL) */
 int pf_decoder_set_precision(pf_decoder* dh, int32_t mode) {
     Decoder* d = reinterpret_cast<Decoder*>(dh);
-    PF_REQUIRE(d && (mode == 0 || mode == 1), "decoder_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+    PF_REQUIRE(d && mode >= 0 && mode <= 2, "decoder_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 operands) or 2 (fp32 via bf16x3)");
     d->precision = mode;
     return 0;
 }
@@ -1580,6 +1657,39 @@ int pf_k_gemm_bf16_time(const void* A, int32_t lda, const void* W, int32_t ldw, 
     PF_HIP_TRY(hipEventCreate(&b));
     PF_HIP_TRY(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) if ((rc = launch_gemm_f32(g, s))) return rc;
+    PF_HIP_TRY(hipEventRecord(b, s));
+    PF_HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    PF_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_out = ms / iters;
+    return 0;
+}
+int pf_k_split3(const float* x, int32_t ldx, void* y3, int32_t ldy, int64_t plane, int32_t M, int32_t N, void* stream) {
+    return launch_split3(x, ldx, reinterpret_cast<unsigned short*>(y3), ldy, (size_t)plane, M, N,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+/* iters > 0 with ms_out: additionally times `iters` back-to-back launches (after 3 warm-up launches) */
+int pf_k_gemm_split3(const void* A3, int32_t lda, int64_t a_plane, const void* W3, int32_t ldw, int64_t w_plane,
+                     const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C,
+                     int32_t ldc, void* C3, int32_t ldc3, int64_t c_plane, int32_t M, int32_t N, int32_t K,
+                     int32_t relu, int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Gemm3Args g{};
+    g.A = reinterpret_cast<const unsigned short*>(A3); g.lda = lda; g.a_plane = (size_t)a_plane;
+    g.W = reinterpret_cast<const unsigned short*>(W3); g.ldw = ldw; g.w_plane = (size_t)w_plane;
+    g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
+    g.C3 = reinterpret_cast<unsigned short*>(C3); g.ldc3 = ldc3; g.c_plane = (size_t)c_plane;
+    g.M = M; g.N = N; g.K = K; g.relu = relu;
+    int rc;
+    if (iters <= 0 || !ms_out) return launch_gemm_split3(g, s);
+    for (int i = 0; i < 3; ++i) if ((rc = launch_gemm_split3(g, s))) return rc;
+    hipEvent_t a, b;
+    PF_HIP_TRY(hipEventCreate(&a));
+    PF_HIP_TRY(hipEventCreate(&b));
+    PF_HIP_TRY(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if ((rc = launch_gemm_split3(g, s))) return rc;
     PF_HIP_TRY(hipEventRecord(b, s));
     PF_HIP_TRY(hipEventSynchronize(b));
     float ms = 0.f;

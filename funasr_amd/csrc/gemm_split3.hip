@@ -1,0 +1,248 @@
+// fp32-accurate GEMM on the bf16 matrix cores: C = epilogue(A[M,K] * W[N,K]^T) with both operands held as THREE bf16
+// planes (x = hi + mid + lo exactly: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); 8 + 8 + 8 significand
+// bits cover fp32's 24) and six v_mfma_f32_32x32x16_bf16 products per operand pair:
+//     hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid      (dropped: mid*lo, lo*mid, lo*lo <= 2^-26 |a||w|)
+// Every bf16 x bf16 product is exact in fp32 and the sums are carried in fp32, so the result has fp32-class error
+// (measured against float64 in tests/test_kernels_gpu.py next to the v_mfma_f32_32x32x2_f32 kernel) while the
+// matrix pipe runs at the bf16 rate: 2.5 PFLOP/s / 6 products = 417 TFLOP/s of fp32-equivalent work per GPU against
+// 157 TFLOP/s for the fp32 MFMA. Same call sites as gemm_f32.hip (the dense Linear layers of the SAN-M blocks:
+// funasr/models/sanm/attention.py:256,306, funasr/models/transformer/positionwise_feed_forward.py:32).
+//
+// Design (gfx950).
+//   * 256 x 128 x 32 block tile, 8 waves in a 4 x 2 grid, each wave owns 2 x 2 MFMA tiles of 32 x 32; per 16-deep
+//     k-step a wave issues 12 ds_read_b128 and 24 MFMAs (768 matrix-pipe cycles): matrix-pipe bound by construction.
+//   * The six planes of a K tile (3 x 256 + 3 x 128 rows of 64 B) go HBM -> LDS with global_load_lds_dwordx4,
+//     72 pieces of 1 KB, 9 per wave, double buffered (2 x 72 KB of LDS, one workgroup = 2 waves per SIMD per CU).
+//   * LDS image: rows of 32 bf16 (64 B); 16-B chunk c of row r is stored at chunk c ^ ((r >> 2) & 3), applied to the
+//     per-lane DMA source address and again on the read: the 16-lane groups of a ds_read_b128 hit 16 distinct slots.
+//   * XCD-aware block order as in gemm_f32.hip.
+// The planes are produced by the kernels that write the activations (LayerNorm, the relu epilogue of this kernel,
+// split3_kernel below) and once per weight at load time.
+#include "common.h"
+
+namespace pf {
+
+namespace {
+
+constexpr int BM = 256, BN = 128;
+constexpr int ROWB = 64;                               // bytes per LDS row = 32 bf16 of one plane row
+constexpr int A_PLANE_B = BM * ROWB;                   // 16 KB
+constexpr int B_PLANE_B = BN * ROWB;                   // 8 KB
+constexpr int STAGE_B = 3 * (A_PLANE_B + B_PLANE_B);   // 72 KB
+constexpr int PPW = STAGE_B / 1024 / 8;                // 1-KB DMA pieces per wave per stage (9)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MODE, bool OUT3>
+__global__ __launch_bounds__(512, 1) void gemm_split3_kernel(Gemm3Args p, int nM, int nN) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE_B
+
+    const int L = blockIdx.x;
+    const int xcd = L & 7, j8 = L >> 3;
+    const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
+    if (mblk >= nM) return;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int hh = lane >> 5, idx = lane & 31;
+
+    // ---- DMA sources: piece q = 9 * wave + i of a stage; pieces 0..47 are the A planes (16 rows each), 48..71 the W
+    //      planes; lane l of a piece lands at row (l >> 2), physical chunk (l & 3)
+    const unsigned short* src[PPW];
+    {
+        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);          // (row >> 2) & 3 with row = 16 * piece + (lane >> 2)
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave * PPW + i;
+            if (q < 48) {
+                int row = m0 + (q & 15) * 16 + (lane >> 2);
+                row = row < p.M ? row : p.M - 1;
+                src[i] = p.A + (size_t)(q >> 4) * p.a_plane + (size_t)row * p.lda + chunk * 8;
+            } else {
+                const int qq = q - 48;
+                int col = n0 + (qq & 7) * 16 + (lane >> 2);
+                col = col < p.N ? col : p.N - 1;
+                src[i] = p.W + (size_t)(qq >> 3) * p.w_plane + (size_t)col * p.ldw + chunk * 8;
+            }
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * (PPW * 1024));
+    auto stage = [&](int buf, int kt) {
+        const unsigned dst = lds0 + (unsigned)buf * STAGE_B;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) glds16(src[i] + kt * 32, dst + i * 1024);
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    // per-lane read offsets (bytes)
+    const int f = (idx >> 2) & 3;
+    const int aoff = (wr * 64 + idx) * ROWB;
+    const int boff = 3 * A_PLANE_B + (wc * 64 + idx) * ROWB;
+    int coff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) coff[s] = ((2 * s + hh) ^ f) * 16;
+
+    const int nk = p.K / 32;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        glds_wait_all();
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const unsigned char* sb = smem + (kt & 1) * STAGE_B;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + pl * A_PLANE_B + aoff + i * 32 * ROWB + coff[s]));
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    b[jj][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[s]));
+            }
+            // product-major order: consecutive MFMAs write four different accumulators
+#define PF_PROD(PA, PB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                    \
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[jj][PB], acc[i][jj], 0, 0, 0)
+            PF_PROD(1, 1);
+            PF_PROD(0, 2);
+            PF_PROD(2, 0);
+            PF_PROD(0, 1);
+            PF_PROD(1, 0);
+            PF_PROD(0, 0);
+#undef PF_PROD
+        }
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)):
+    //      through a wave-private LDS slab so that every global access is a 16-B piece of a 256-B row segment
+    constexpr bool HAS_R1 = (MODE & 1) != 0, HAS_R2 = (MODE & 2) != 0;
+    constexpr int ELD = 68;
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ELD);
+    const int c4 = lane & 15, rsub = lane >> 4;
+    const int col = n0 + wc * 64 + c4 * 4;
+    const bool colok = col + 3 < p.N;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && colok) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * hh) * ELD + jj * 32 + idx] = acc[i][jj][r];
+        float4 v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const float4*>(slab + (it * 4 + rsub) * ELD + c4 * 4);
+        const int row0 = m0 + wr * 64 + i * 32 + rsub;
+        if (!colok) continue;
+        float4 r1[8], r2[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = row0 + it * 4;
+            const int rr = row < p.M ? row : p.M - 1;
+            if constexpr (HAS_R1) r1[it] = *reinterpret_cast<const float4*>(p.R1 + (size_t)rr * p.ldr1 + col);
+            if constexpr (HAS_R2) r2[it] = *reinterpret_cast<const float4*>(p.R2 + (size_t)rr * p.ldr2 + col);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = row0 + it * 4;
+            float o[4] = {v[it].x + bias4.x, v[it].y + bias4.y, v[it].z + bias4.z, v[it].w + bias4.w};
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            if constexpr (HAS_R1) { o[0] = o[0] + r1[it].x; o[1] = o[1] + r1[it].y; o[2] = o[2] + r1[it].z; o[3] = o[3] + r1[it].w; }
+            if constexpr (HAS_R2) { o[0] = r2[it].x + o[0]; o[1] = r2[it].y + o[1]; o[2] = r2[it].z + o[2]; o[3] = r2[it].w + o[3]; }
+            if (row >= p.M) continue;
+            if constexpr (OUT3) {
+                store_split3x4(p.C3 + (size_t)row * p.ldc3 + col, p.c_plane, o);
+            } else {
+                *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// fp32 [M, N] (row stride ldx) -> three bf16 planes [M, ldy] (plane stride `plane` elements); columns N..ldy are zero
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ y,
+                                                     int ldy, size_t plane, int M, int N) {
+    const int c4n = ldy >> 2;
+    const size_t total = (size_t)M * c4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / c4n), c = (int)(i % c4n) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < N) {
+            const float4 t = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < N) v[e] = x[(size_t)row * ldx + c + e];
+        }
+        store_split3x4(y + (size_t)row * ldy + c, plane, v);
+    }
+}
+
+template <int MODE, bool OUT3>
+int launch_one(const Gemm3Args& a, int nM, int nN, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split3_kernel<MODE, OUT3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B));
+        configured = true;
+    }
+    const int nMpad = (nM + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_split3_kernel<MODE, OUT3>), dim3((unsigned)nMpad * nN), dim3(512), 2 * STAGE_B, stream, a, nM, nN);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int launch_split3(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, hipStream_t stream) {
+    PF_REQUIRE(M > 0 && N > 0 && ldy >= N && ldy % 4 == 0, "split3: ldy must cover N and be a multiple of 4");
+    PF_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && plane % 4 == 0, "split3: alignment");
+    const size_t total = (size_t)M * (ldy >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, y, ldy, plane, M, N);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_split3(const Gemm3Args& a, hipStream_t stream) {
+    PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_split3: empty problem");
+    PF_REQUIRE(a.K % 32 == 0, "gemm_split3: K must be a multiple of 32 (pad the planes with zeros)");
+    PF_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_plane % 8 == 0 && a.w_plane % 8 == 0, "gemm_split3: operand strides % 8");
+    PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_split3: operands must be 16-B aligned");
+    PF_REQUIRE(a.N % 4 == 0, "gemm_split3: N % 4");
+    if (a.C3) PF_REQUIRE(a.ldc3 % 4 == 0 && a.c_plane % 4 == 0 && ((uintptr_t)a.C3 & 7) == 0, "gemm_split3: plane output alignment");
+    else PF_REQUIRE(a.C && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_split3: output alignment");
+    if (a.bias) PF_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm_split3: bias alignment");
+    if (a.R1) PF_REQUIRE(a.ldr1 % 4 == 0 && ((uintptr_t)a.R1 & 15) == 0, "gemm_split3: R1 alignment");
+    if (a.R2) PF_REQUIRE(a.ldr2 % 4 == 0 && ((uintptr_t)a.R2 & 15) == 0, "gemm_split3: R2 alignment");
+    const int nM = ceil_div(a.M, BM), nN = ceil_div(a.N, BN);
+    const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
+    if (a.C3) {
+        PF_REQUIRE(mode == 0, "gemm_split3: the plane output has no residual form");
+        return launch_one<0, true>(a, nM, nN, stream);
+    }
+    switch (mode) {
+        case 0: return launch_one<0, false>(a, nM, nN, stream);
+        case 1: return launch_one<1, false>(a, nM, nN, stream);
+        case 2: return launch_one<2, false>(a, nM, nN, stream);
+        default: return launch_one<3, false>(a, nM, nN, stream);
+    }
+}
+
+}  // namespace pf

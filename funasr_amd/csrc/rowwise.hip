@@ -27,11 +27,13 @@ __device__ __forceinline__ float4 load4(const float* base, size_t off, bool bf16
 }
 
 // One wave per row. NV = float4 chunks per lane (D <= 256 * NV).
-template <int NV, bool OUT_BF16>
+// OUT: 0 fp32, 1 bf16, 2 three bf16 planes (split3) `plane` elements apart
+template <int NV, int OUT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                        int ldy, int M, int D, int Dpad, float eps, int in_bf16) {
+                                                        int ldy, int M, int D, int Dpad, float eps, int in_bf16,
+                                                        size_t plane) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -76,7 +78,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             o.w = (v[j].w - mean) * rstd * g.w + b.w;
         }
         if (4 * c < Dpad) {
-            if constexpr (OUT_BF16) {
+            if constexpr (OUT == 2) {
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                store_split3x4(yb + 4 * c, plane, ov);
+            } else if constexpr (OUT == 1) {
                 uint2 pk;
                 pk.x = (unsigned)f32_to_bf16(o.x) | ((unsigned)f32_to_bf16(o.y) << 16);
                 pk.y = (unsigned)f32_to_bf16(o.z) | ((unsigned)f32_to_bf16(o.w) << 16);
@@ -186,7 +191,7 @@ int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t st
 }
 
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int M,
-                     int D, int Dpad, float eps, hipStream_t stream, int out_bf16, int in_bf16) {
+                     int D, int Dpad, float eps, hipStream_t stream, int out_mode, int in_bf16, size_t plane) {
     PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm: D must be a multiple of 4 and <= 2048");
     PF_REQUIRE(Dpad >= D && Dpad % 4 == 0 && Dpad <= 2048 && ldy >= Dpad, "layernorm: bad Dpad/ldy");
     PF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: strides must be multiples of 4");
@@ -195,8 +200,9 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     const int nv = ceil_div(Dpad / 4, 64);
 #define PF_LN(NV_)                                                                                                 \
     do {                                                                                                          \
-        if (out_bf16) hipLaunchKernelGGL((layernorm_kernel<NV_, true>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16); \
-        else hipLaunchKernelGGL((layernorm_kernel<NV_, false>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16);         \
+        if (out_mode == 2) hipLaunchKernelGGL((layernorm_kernel<NV_, 2>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane); \
+        else if (out_mode == 1) hipLaunchKernelGGL((layernorm_kernel<NV_, 1>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane); \
+        else hipLaunchKernelGGL((layernorm_kernel<NV_, 0>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane);         \
     } while (0)
     if (nv <= 2) PF_LN(2);
     else if (nv <= 3) PF_LN(3);

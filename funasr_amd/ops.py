@@ -150,6 +150,41 @@ def gemm_bf16_time_ms(a, w, bias, out, iters: int = 20) -> float:
     return float(ms.value)
 
 
+def split3(x: torch.Tensor, kpad: int = 32) -> torch.Tensor:
+    """fp32 [M, N] -> bf16 planes [3, M, Npad] with x = hi + mid + lo exactly (columns N..Npad-1 zero)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    ld = (N + kpad - 1) // kpad * kpad
+    y = torch.empty(3, M, ld, device=x.device, dtype=torch.bfloat16)
+    _lib.check(lib.pf_k_split3(_ptr(x), x.stride(0), _ptr(y), ld, M * ld, M, N, _stream()), "pf_k_split3")
+    return y
+
+
+def gemm_split3(a3: torch.Tensor, w3: torch.Tensor, bias=None, relu=False, add1=None, add2=None, out_planes=False,
+                time_iters: int = 0):
+    """a3 [3, M, K], w3 [3, N, K] bf16 planes (ops.split3) -> fp32 [M, N] (or its planes [3, M, N]); fp32-class accuracy
+    from six bf16 MFMA products per operand pair. With time_iters > 0 returns (out, ms per launch)."""
+    lib = _lib.load()
+    assert a3.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and a3.is_contiguous() and w3.is_contiguous()
+    _, M, K = a3.shape
+    N = w3.shape[1]
+    assert w3.shape[2] == K
+    ms = C.c_float(0)
+    if out_planes:
+        out = torch.empty(3, M, N, device=a3.device, dtype=torch.bfloat16)
+        c, ldc, c3, ldc3, cpl = None, 0, out, N, M * N
+    else:
+        out = torch.empty(M, N, device=a3.device, dtype=torch.float32)
+        c, ldc, c3, ldc3, cpl = out, N, None, 0, 0
+    _lib.check(lib.pf_k_gemm_split3(_ptr(a3), K, M * K, _ptr(w3), K, N * K, _ptr(bias),
+                                    _ptr(add1), add1.stride(0) if add1 is not None else 0,
+                                    _ptr(add2), add2.stride(0) if add2 is not None else 0,
+                                    _ptr(c), ldc, _ptr(c3), ldc3, cpl, M, N, K, int(relu), int(time_iters),
+                                    C.byref(ms), _stream()), "pf_k_gemm_split3")
+    return (out, float(ms.value)) if time_iters > 0 else out
+
+
 def attention_bf16(q, k, v, klens, n_heads: int, scale: float):
     """bf16 q [B, Tq, H*128], k/v [B, Tk, H*128] (row-strided views allowed) -> bf16 [B, Tq, H*128]."""
     lib = _lib.load()

@@ -236,6 +236,15 @@ int pf_k_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, const
                    int32_t relu, int32_t c_bf16, void* stream);
 int pf_k_gemm_bf16_time(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, void* C, int32_t ldc,
                         int32_t M, int32_t N, int32_t K, int32_t c_bf16, int32_t iters, float* ms_out, void* stream);
+/* fp32-accurate GEMM on the bf16 matrix cores (gemm_split3.hip): both operands as three bf16 planes
+ * (x = hi + mid + lo exactly; plane p of a matrix starts `*_plane` elements after plane p-1), six bf16 MFMA products
+ * per operand pair, fp32 accumulate / bias / residuals. Output fp32 C, or (C3 != NULL) the three planes of the result.
+ * K % 32 == 0 (planes zero-padded), N % 4 == 0, strides in elements. */
+int pf_k_split3(const float* x, int32_t ldx, void* y3, int32_t ldy, int64_t plane, int32_t M, int32_t N, void* stream);
+int pf_k_gemm_split3(const void* A3, int32_t lda, int64_t a_plane, const void* W3, int32_t ldw, int64_t w_plane,
+                     const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C,
+                     int32_t ldc, void* C3, int32_t ldc3, int64_t c_plane, int32_t M, int32_t N, int32_t K,
+                     int32_t relu, int32_t iters, float* ms_out, void* stream);
 /* fp32 -> bf16 (round to nearest even), n % 4 == 0 */
 int pf_k_cast_bf16(const float* x, void* y, int64_t n, void* stream);
 int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t M,

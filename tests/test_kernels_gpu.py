@@ -66,6 +66,56 @@ def test_gemm_bf16_operands_fp32_accumulate(cuda, M, N, K):
     assert torch.equal(out2, ref2.float().to(torch.bfloat16)) or _rel(out2.float(), ref2) < 4e-3   # one bf16 rounding
 
 
+def test_split3_planes_are_exact(cuda):
+    """x = hi + mid + lo exactly (three bf16 planes carry fp32's 24 significand bits), padding columns are zero."""
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(257, 560, generator=g) * torch.pow(10.0, torch.rand(257, 560, generator=g) * 12 - 6)
+    x[0, :8] = torch.tensor([0.0, 1.0, -1.0, 3.0e-5, 65504.0, 1.0e-20, -7.25, 0.1])
+    p = ops.split3(x.to(cuda)).cpu()
+    assert p.shape == (3, 257, 576) and torch.count_nonzero(p[:, :, 560:]) == 0
+    s = (p[0, :, :560].float() + p[1, :, :560].float()) + p[2, :, :560].float()
+    assert torch.equal(s, x)
+    assert torch.equal(p[0, :, :560], x.to(torch.bfloat16))        # hi = round-to-nearest-even bf16
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (500, 1536, 576), (333, 2048, 512), (1000, 512, 2048), (70, 132, 192)])
+def test_gemm_split3_fp32_class_accuracy(cuda, M, N, K):
+    """bf16x3 operands, six MFMA products: error against fp64 is in the class of the fp32 MFMA kernel's."""
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * torch.linspace(0.5, 1.5, N)[:, None]
+    bias = torch.randn(N, generator=g)
+    r1 = torch.randn(M, N, generator=g)
+    r2 = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().T + bias.double()
+    a3, w3 = ops.split3(a.to(cuda)), ops.split3(w.to(cuda))
+    out = ops.gemm_split3(a3, w3, bias.to(cuda)).cpu()
+    f32 = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda)).cpu()
+    e3, e32 = _rel(out, ref), _rel(f32, ref)
+    assert e3 < 2e-6 and e3 < 3 * e32 + 1e-7, (e3, e32)
+    # epilogue forms: relu, residuals, and the plane output (its planes sum to the fp32 result bit for bit)
+    out2 = ops.gemm_split3(a3, w3, bias.to(cuda), relu=True, add1=r1.to(cuda), add2=r2.to(cuda)).cpu()
+    ref2 = torch.relu(ref) + r1.double() + r2.double()
+    assert _rel(out2, ref2) < 2e-6
+    out1 = ops.gemm_split3(a3, w3, None, add1=r1.to(cuda)).cpu()
+    assert _rel(out1, (a.double() @ w.double().T) + r1.double()) < 2e-6
+    o3 = ops.gemm_split3(a3, w3, bias.to(cuda), relu=True, out_planes=True).cpu()
+    o = ops.gemm_split3(a3, w3, bias.to(cuda), relu=True).cpu()
+    assert torch.equal((o3[0].float() + o3[1].float()) + o3[2].float(), o)
+
+
+def test_gemm_split3_rows_do_not_depend_on_the_batch(cuda):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(1000, 512, generator=g).to(cuda)
+    w3 = ops.split3(torch.randn(1536, 512, generator=g).to(cuda))
+    full = ops.gemm_split3(ops.split3(a), w3)
+    part = ops.gemm_split3(ops.split3(a[300:437].contiguous()), w3)
+    assert torch.equal(full[300:437], part)
+
+
 def test_gemm_f32_strided_and_inplace_residual(cuda, gemm_path):
     from funasr_amd import ops
     g = torch.Generator().manual_seed(5)

@@ -31,6 +31,13 @@ def fires_of(peaks):
     return (torch.floor(torch.as_tensor(peaks)) >= 1)
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def f32_mode(request):
+    """the two fp32-accurate GEMM routes: v_mfma_f32_32x32x2_f32 (gemm_f32.hip) and three-bf16-plane operands with six
+    bf16 MFMA products (gemm_split3.hip). Both must meet every fp32 parity bar."""
+    return request.param
+
+
 # ---------------------------------------------------------------------------------------------------- frontend
 def test_frontend_vs_reference_features_and_oracle(cuda):
     from funasr_amd.wav_frontend import WavFrontend
@@ -89,10 +96,10 @@ def _encoder(cfg, sd, cuda, cls=None):
     return enc.to(cuda)
 
 
-def test_encoder_vs_reference_golden(cuda):
+def test_encoder_vs_reference_golden(cuda, f32_mode):
     g = gold("encoder")
     cfg = json.loads(str(g["cfg"]))
-    enc = _encoder(cfg, synth.encoder_state_dict(cfg, seed=int(g["seed"])), cuda)
+    enc = _encoder(cfg, synth.encoder_state_dict(cfg, seed=int(g["seed"])), cuda).set_precision(f32_mode)
     out, olens, _ = enc(t(g["xs"]).to(cuda), t(g["lens"]))
     assert olens.tolist() == g["olens"].tolist()
     b1, _ = enc._run(t(g["xs"]).to(cuda), t(g["lens"]), run_blocks=1)
@@ -102,12 +109,12 @@ def test_encoder_vs_reference_golden(cuda):
     assert (out.cpu() - t(g["out"])).abs().max().item() < 1e-4     # north_star bar: 1e-3
 
 
-def test_encoder_full_depth_vs_oracle(cuda):
+def test_encoder_full_depth_vs_oracle(cuda, f32_mode):
     """All 50 blocks of Paraformer-large, ragged batch, every (also padded) frame compared."""
     from oracle import paraformer_oracle as O
     cfg = synth.PARAFORMER_LARGE["encoder"]
     sd = synth.encoder_state_dict(cfg, seed=3)
-    enc = _encoder(cfg, sd, cuda)
+    enc = _encoder(cfg, sd, cuda).set_precision(f32_mode)
     g = torch.Generator().manual_seed(77)
     xs = torch.randn(3, 90, 560, generator=g) * 0.7
     lens = torch.tensor([90, 61, 8], dtype=torch.int32)
@@ -169,13 +176,13 @@ def test_decoder_vs_reference_golden(cuda):
 
 
 # ---------------------------------------------------------------------------------------------------- pipeline
-def test_pipeline_token_ids_equal_reference(cuda):
+def test_pipeline_token_ids_equal_reference(cuda, f32_mode):
     from funasr_amd.paraformer import Paraformer
     g = gold("pipeline")
     cfg = json.loads(str(g["cfg"]))
     model = Paraformer.from_config(cfg)
     model.load_state_dict(synth.paraformer_state_dict(cfg, seed=int(g["seed"])), strict=False)
-    model = model.to(cuda)
+    model = model.to(cuda).set_precision(f32_mode)
     res = model.recognize_features(t(g["feats"]).to(cuda), t(g["lens"]), return_intermediate=True)
     assert res["token_num"] == g["token_num"].tolist()
     assert torch.equal(fires_of(res["peaks"].cpu()), fires_of(g["peaks"]))       # CIF fire indices bit-exact
@@ -204,7 +211,7 @@ def test_sensevoice_encoder_and_ctc_vs_reference_golden(cuda):
 
 
 # ------------------------------------------------------------------- full-size, size-independent properties
-def test_full_size_batch_independence_and_fused_argmax(cuda):
+def test_full_size_batch_independence_and_fused_argmax(cuda, f32_mode):
     """BASELINE config 2 shapes (B=64 x 30 s -> T=500) on a shallow model: (1) every clip's encoder output and token
     ids are bitwise identical whether it is decoded alone or inside the 64-clip batch (utterance DP is exact),
     (2) fused arg-max == arg-max of the materialised logits."""
@@ -212,7 +219,7 @@ def test_full_size_batch_independence_and_fused_argmax(cuda):
     cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2, dec_blocks=1, vocab=8404)
     model = Paraformer.from_config(cfg)
     model.load_state_dict(synth.paraformer_state_dict(cfg, seed=5), strict=False)
-    model = model.to(cuda)
+    model = model.to(cuda).set_precision(f32_mode)
     g = torch.Generator().manual_seed(1)
     B, T = 64, 500
     feats = torch.randn(B, T, 560, generator=g) * 0.7

@@ -19,4 +19,8 @@ for name, N, K in (("qkv", 1536, 512), ("out", 512, 512), ("ffn1", 2048, 512), (
     fl = 2.0 * m * N * K
     ms = min(ops.gemm_time_ms(a, w, b, out, 20) for _ in range(3))
     ms16 = min(ops.gemm_bf16_time_ms(ab, wb, b, ob, 20) for _ in range(3))
-    print(f"{name:9s} M={m} N={N} K={K}: f32 {ms*1e3:7.1f} us {fl/ms/1e9:6.1f} TF | bf16 {ms16*1e3:7.1f} us {fl/ms16/1e9:7.1f} TF", flush=True)
+    a3, w3 = ops.split3(a), ops.split3(w)
+    ms3 = min(ops.gemm_split3(a3, w3, b, time_iters=20)[1] for _ in range(3))
+    ms3p = min(ops.gemm_split3(a3, w3, b, relu=True, out_planes=True, time_iters=20)[1] for _ in range(3))
+    print(f"{name:9s} M={m} N={N} K={K}: f32 {ms*1e3:7.1f} us {fl/ms/1e9:6.1f} TF | bf16 {ms16*1e3:7.1f} us {fl/ms16/1e9:7.1f} TF"
+          f" | bf16x3 {ms3*1e3:7.1f} us {fl/ms3/1e9:6.1f} TF-equiv ({6*fl/ms3/1e9:6.0f} raw), plane-out {fl/ms3p/1e9:6.1f}", flush=True)
