@@ -146,17 +146,15 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(AttnArgs p) {
 
     if (q < p.Tq) {
         const float inv = 1.0f / l_run;
-        float* op = p.O + ((size_t)b * p.Tq + q) * p.ldo + head * DK;
+        const size_t orow = ((size_t)b * p.Tq + q) * p.ldo + head * DK;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 t;
-                t.x = o[d][4 * g + 0] * inv;
-                t.y = o[d][4 * g + 1] * inv;
-                t.z = o[d][4 * g + 2] * inv;
-                t.w = o[d][4 * g + 3] * inv;
-                *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hh) = t;
+                const float t[4] = {o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+                const size_t off = orow + d * 32 + 8 * g + 4 * hh;
+                if (p.O3) store_split3x4(p.O3 + off, p.o_plane, t);      // the out-projection's operand planes (bf16x3 mode)
+                else *reinterpret_cast<float4*>(p.O + off) = make_float4(t[0], t[1], t[2], t[3]);
             }
     }
 }
@@ -281,17 +279,15 @@ __global__ __launch_bounds__(256, 2) void attention_f32_dma_kernel(AttnArgs p) {
 
     if (q < p.Tq) {
         const float inv = 1.0f / l_run;
-        float* op = p.O + ((size_t)b * p.Tq + q) * p.ldo + head * DK;
+        const size_t orow = ((size_t)b * p.Tq + q) * p.ldo + head * DK;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 t;
-                t.x = o[d][4 * g + 0] * inv;
-                t.y = o[d][4 * g + 1] * inv;
-                t.z = o[d][4 * g + 2] * inv;
-                t.w = o[d][4 * g + 3] * inv;
-                *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * hh) = t;
+                const float t[4] = {o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+                const size_t off = orow + d * 32 + 8 * g + 4 * hh;
+                if (p.O3) store_split3x4(p.O3 + off, p.o_plane, t);      // the out-projection's operand planes (bf16x3 mode)
+                else *reinterpret_cast<float4*>(p.O + off) = make_float4(t[0], t[1], t[2], t[3]);
             }
     }
 }
@@ -301,6 +297,8 @@ __global__ __launch_bounds__(256, 2) void attention_f32_dma_kernel(AttnArgs p) {
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
     PF_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0, "attention: strides % 4");
+    PF_REQUIRE(a.O || a.O3, "attention: null output");
+    if (a.O3) PF_REQUIRE(a.o_plane % 4 == 0 && ((uintptr_t)a.O3 & 7) == 0, "attention: plane output alignment");
     dim3 grid(ceil_div(a.Tq, 128), a.H, a.B);
     // the K/V ring form of the streaming step (two sources, a few dozen keys) keeps the register-staged loader; the
     // offline form (one source) takes the LDS-DMA double-buffered kernel. Both do the same arithmetic in the same order.

@@ -63,14 +63,28 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
     const float r2 = r1 - bf16_to_f32(m);
     l = f32_to_bf16(r2);
 }
+// two values -> three packed bf16 pairs (low half = first value) with v_cvt_pk_bf16_f32 (round to nearest even)
+typedef __bf16 pf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pf_floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const pf_floatx2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pf_bf16x2));
+}
+__device__ __forceinline__ void split3_pk(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(a, b);
+    float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = cvt_pk_bf16(ra, rb);
+    ra -= __builtin_bit_cast(float, m << 16); rb -= __builtin_bit_cast(float, m & 0xffff0000u);
+    l = cvt_pk_bf16(ra, rb);
+}
 // four consecutive values -> the three planes at p, p + plane, p + 2 plane (8-B stores)
 __device__ __forceinline__ void store_split3x4(unsigned short* p, size_t plane, const float (&o)[4]) {
-    unsigned short h[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split3(o[e], h[e], m[e], l[e]);
-    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    *reinterpret_cast<uint2*>(p + plane) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-    *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pk(o[0], o[1], h0, m0, l0);
+    split3_pk(o[2], o[3], h1, m1, l1);
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + plane) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2(l0, l1);
 }
 
 // ---------------------------------------------------------------- LDS-DMA issued behind the compiler's back
@@ -168,6 +182,8 @@ struct AttnArgs {
     const float* V2; int ldv2;
     int T2, n2;
     const int* n1_dev; int n1_stride;   // device int32, element b * n1_stride (stride 0 = one value for all)
+    // fp32 kernels only: write the three bf16 planes of the result (split3; same ldo, `o_plane` elements apart) instead of O
+    unsigned short* O3; size_t o_plane;
 };
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
 // bf16 Q/K/V in, bf16 O out (strides in elements), fp32 softmax statistics and accumulators

@@ -470,10 +470,10 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         if ((rc = fsmn(fa, s))) return rc;
         AttnArgs aa{};
         aa.Q = qkv; aa.ldq = 3 * D; aa.K = qkv + D; aa.ldk = 3 * D; aa.V = qkv + 2 * D; aa.ldv = 3 * D;
-        aa.O = ctx; aa.ldo = D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
+        aa.O = nullptr; aa.O3 = ctx3; aa.o_plane = (size_t)M * D; aa.ldo = D;       // straight into the out-projection's planes
+        aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
         aa.scale = powf((float)(D / c.n_heads), -0.5f);
         if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s))) return rc;
-        if ((rc = launch_split3(ctx, D, ctx3, D, (size_t)M * D, M, D, s))) return rc;
         const float* resid3 = (w.in_dim == D) ? x_in : nullptr;
         if ((rc = gemm3(ctx3, D, w.out_w3, w.out_b, x, D, nullptr, D, D, 0, mem, D, resid3, ld_in))) return rc;
         {
@@ -612,12 +612,35 @@ struct Ctc {
 
 
 // PositionwiseFeedForwardDecoderSANM (sanm/positionwise_feed_forward.py:12-33): w_2(LN(relu(w_1 x))), w_2 bias-free
-static int dec_ffn(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s) {
+static int gemm3_simple(const unsigned short* A3, int lda, int M, const unsigned short* W3, const float* bias, float* C,
+                        int ldc, int N, int K, int relu, hipStream_t s) {
+    if (!W3) return -2;
+    Gemm3Args g{};
+    g.A = A3; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W3; g.ldw = K; g.w_plane = (size_t)N * K;
+    g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = relu;
+    ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
+    return launch_gemm_split3(g, s);
+}
+
+// w1_3 != nullptr (bf16x3 mode): norm1 writes the three planes and w_1 runs on the bf16 matrix cores
+static int dec_ffn(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s,
+                   const unsigned short* w1_3 = nullptr) {
     const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
     float* t1 = d->t1.as<float>();
     float* ffn = d->ffn.as<float>();
     float* ffn2 = d->ffn2.as<float>();
     int rc;
+    if (w1_3) {
+        unsigned short* t3 = d->t16.as<unsigned short>();
+        {
+            ProfScope ps(PROF_LN, 10.0 * M * (double)D, s);
+            if ((rc = launch_layernorm(x, D, w.n1g, w.n1b, reinterpret_cast<float*>(t3), D, M, D, D, d->cfg.ln_eps, s, 2, 0,
+                                       (size_t)M * D))) return rc;
+        }
+        if ((rc = gemm3_simple(t3, D, M, w1_3, w.b1, ffn, F, F, D, 1, s))) return rc;
+        if ((rc = layernorm(ffn, F, w.fng, w.fnb, ffn2, F, M, F, F, d->cfg.ln_eps, s))) return rc;
+        return gemm_simple(ffn2, F, w.w2, F, nullptr, out, D, M, D, F, 0, nullptr, 0, nullptr, 0, s);
+    }
     if ((rc = layernorm(x, D, w.n1g, w.n1b, t1, D, M, D, D, d->cfg.ln_eps, s))) return rc;
     if ((rc = gemm_simple(t1, D, w.w1, D, w.b1, ffn, F, M, F, D, 1, nullptr, 0, nullptr, 0, s))) return rc;
     if ((rc = layernorm(ffn, F, w.fng, w.fnb, ffn2, F, M, F, F, d->cfg.ln_eps, s))) return rc;
@@ -1351,10 +1374,24 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     PF_HIP_TRY(hipMemcpyAsync(x, embeds, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     const int left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
     if (d->precision == 1 && !logits) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
+    // bf16x3 mode: the two GEMMs that are large at every batch size (w_1: N = ffn_dim; linear_k_v: M = B * T) take
+    // three-plane operands on the bf16 matrix cores; the D x D projections and w_2 keep the fp32 MFMA tiles
+    const bool x3 = d->precision == 2;
+    const unsigned short* mem3 = nullptr;
+    if (x3) {
+        if (d->t16.ensure(sizeof(unsigned short) * 3 * (size_t)Mq * D) || d->mem16.ensure(sizeof(unsigned short) * 3 * (size_t)Mk * D))
+            return -2;
+        if ((rc = launch_split3(memory, D, d->mem16.as<unsigned short>(), D, (size_t)Mk * D, Mk, D, s))) return rc;
+        mem3 = d->mem16.as<unsigned short>();
+    }
+    auto w3 = [&](const std::string& name, int rows, int cols) { return x3 ? d->tt.get_split3(name, rows, cols, s) : nullptr; };
     for (int l = 0; l < c.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
+        const std::string lp = "decoders." + std::to_string(l) + ".";
         // DecoderLayerSANM.forward (paraformer/decoder.py:78-121)
-        if ((rc = dec_ffn(d, w, x, t2, Mq, s))) return rc;                                    // tgt = FFN(norm1(tgt))
+        const unsigned short* w1_3 = w3(lp + "feed_forward.w_1.weight", F, D);
+        if (x3 && !w1_3) return -2;
+        if ((rc = dec_ffn(d, w, x, t2, Mq, s, w1_3))) return rc;                              // tgt = FFN(norm1(tgt))
         if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;   // norm2
         FsmnArgs fa{};                                                                        // x = residual + fsmn
         fa.in = t1; fa.ldin = D; fa.w = w.fsmn_w; fa.R = x; fa.ldr = D; fa.out = x; fa.ldo = D;
@@ -1363,8 +1400,11 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
         if ((rc = layernorm(x, D, w.n3g, w.n3b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;    // norm3
         if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s)))
             return rc;
-        if ((rc = gemm_simple(memory, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
-                              nullptr, 0, s))) return rc;
+        if (x3) {
+            if ((rc = gemm3_simple(mem3, D, Mk, w3(lp + "src_attn.linear_k_v.weight", 2 * D, D), w.kv_b, d->kv.as<float>(),
+                                   2 * D, 2 * D, D, 0, s))) return rc;
+        } else if ((rc = gemm_simple(memory, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
+                                     nullptr, 0, s))) return rc;
         AttnArgs aa{};
         aa.Q = d->q.as<float>(); aa.ldq = D; aa.K = d->kv.as<float>(); aa.ldk = 2 * D;
         aa.V = d->kv.as<float>() + D; aa.ldv = 2 * D; aa.O = d->ctx.as<float>(); aa.ldo = D;
@@ -1375,7 +1415,11 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
             return rc;                                                                        // x = residual + att
     }
     // decoders3: FFN only, no residual (decoder.py:438, DecoderLayerSANM with self_attn = src_attn = None)
-    if ((rc = dec_ffn(d, d->last, x, t2, Mq, s))) return rc;
+    {
+        const unsigned short* w1_3 = w3("decoders3.0.feed_forward.w_1.weight", F, D);
+        if (x3 && !w1_3) return -2;
+        if ((rc = dec_ffn(d, d->last, x, t2, Mq, s, w1_3))) return rc;
+    }
     float* hid = hidden_out ? hidden_out : d->hid.as<float>();
     if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), hid, D, Mq, D, D,
                         c.ln_eps, s))) return rc;

@@ -96,32 +96,41 @@ __global__ __launch_bounds__(512, 1) void gemm_split3_kernel(Gemm3Args p, int nM
     for (int kt = 0; kt < nk; ++kt) {
         glds_wait_all();
         __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        // the DMA pieces of K tile kt+1 are issued one per group of four MFMAs: each piece costs the wave tens of issue
+        // cycles, which the matrix pipe covers when they sit between MFMAs instead of in front of them
+        const bool nxt = kt + 1 < nk;
+        const unsigned dst = lds0 + (unsigned)((kt + 1) & 1) * STAGE_B;
+        const int koff = (kt + 1) * 32;
         const unsigned char* sb = smem + (kt & 1) * STAGE_B;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2][3], b[2][3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    a[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + pl * A_PLANE_B + aoff + i * 32 * ROWB + coff[s]));
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    b[jj][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[s]));
-            }
-            // product-major order: consecutive MFMAs write four different accumulators
+#define PF_PIECE(I) do { if (nxt) glds16(src[I] + koff, dst + (I) * 1024); } while (0)
 #define PF_PROD(PA, PB)                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                    \
         acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[jj][PB], acc[i][jj], 0, 0, 0)
-            PF_PROD(1, 1);
-            PF_PROD(0, 2);
-            PF_PROD(2, 0);
-            PF_PROD(0, 1);
-            PF_PROD(1, 0);
-            PF_PROD(0, 0);
+#define PF_LOAD(S)                                                                                                    \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                                \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+            a[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + pl * A_PLANE_B + aoff + i * 32 * ROWB + coff[S]));   \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                              \
+            b[jj][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[S])); \
+    }
+        bf16x8 a[2][3], b[2][3];
+        PF_LOAD(0)
+        PF_PROD(1, 1); PF_PIECE(0);
+        PF_PROD(0, 2); PF_PIECE(1);
+        PF_PROD(2, 0); PF_PIECE(2);
+        PF_PROD(0, 1); PF_PIECE(3);
+        PF_PROD(1, 0); PF_PIECE(4);
+        PF_PROD(0, 0); PF_PIECE(5);
+        PF_LOAD(1)
+        PF_PROD(1, 1); PF_PIECE(6);
+        PF_PROD(0, 2); PF_PIECE(7);
+        PF_PROD(2, 0); PF_PIECE(8);
+        PF_PROD(0, 1);
+        PF_PROD(1, 0);
+        PF_PROD(0, 0);
 #undef PF_PROD
-        }
+#undef PF_LOAD
+#undef PF_PIECE
     }
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)):

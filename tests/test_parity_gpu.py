@@ -157,13 +157,13 @@ def test_predictor_vs_reference_golden(cuda):
 
 
 # ----------------------------------------------------------------------------------------------------- decoder
-def test_decoder_vs_reference_golden(cuda):
+def test_decoder_vs_reference_golden(cuda, f32_mode):
     from funasr_amd.paraformer_decoder import ParaformerSANMDecoder
     g = gold("decoder")
     cfg = json.loads(str(g["cfg"]))
     d = ParaformerSANMDecoder(**cfg)
     d.load_state_dict(synth.decoder_state_dict(cfg, seed=int(g["seed"]), with_embed=True), strict=True)
-    d = d.to(cuda)
+    d = d.to(cuda).set_precision(f32_mode)
     args = (t(g["memory"]).to(cuda), t(g["mem_lens"]), t(g["embeds"]).to(cuda), t(g["tok_lens"]))
     logits, olens = d(*args)
     assert olens.tolist() == g["tok_lens"].tolist()
