@@ -25,15 +25,27 @@ namespace pf {
 namespace {
 
 constexpr int BM = 256, BN = 128;
-constexpr int ROWB = 64;                               // bytes per LDS row = 32 bf16 of one plane row
-constexpr int A_PLANE_B = BM * ROWB;                   // 16 KB
-constexpr int B_PLANE_B = BN * ROWB;                   // 8 KB
-constexpr int STAGE_B = 3 * (A_PLANE_B + B_PLANE_B);   // 72 KB
-constexpr int PPW = STAGE_B / 1024 / 8;                // 1-KB DMA pieces per wave per stage (9)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MODE, bool OUT3>
-__global__ __launch_bounds__(512, 1) void gemm_split3_kernel(Gemm3Args p, int nM, int nN) {
+// KS = k extent of one LDS stage (32: 64-B rows, one workgroup per CU; 16: 32-B rows, two workgroups per CU)
+template <int KS> struct Geo {
+    static constexpr int ROWB = KS * 2;                         // bytes per LDS row of one plane
+    static constexpr int CPR = ROWB / 16;                       // 16-B chunks per row
+    static constexpr int RPB = 256 / ROWB;                      // rows per 256-B bank row
+    static constexpr int RPP = 1024 / ROWB;                     // rows per 1-KB DMA piece
+    static constexpr int A_PLANE_B = BM * ROWB, B_PLANE_B = BN * ROWB;
+    static constexpr int STAGE_B = 3 * (A_PLANE_B + B_PLANE_B);
+    static constexpr int NPIECE = STAGE_B / 1024;               // 72 / 36
+    static constexpr int A_PIECES = 3 * BM / RPP;               // pieces of the A planes (48 / 24)
+    static constexpr int PPW = (NPIECE + 7) / 8;                // pieces per wave (9 / 5, the last partly idle for KS = 16)
+    static constexpr int STEPS = KS / 16;
+};
+
+template <int MODE, bool OUT3, int KS>
+__global__ __launch_bounds__(512, KS == 16 ? 4 : 2) void gemm_split3_kernel(Gemm3Args p, int nM, int nN) {
+    typedef Geo<KS> G;
+    constexpr int ROWB = G::ROWB, CPR = G::CPR, RPP = G::RPP, PPW = G::PPW, STAGE_B = G::STAGE_B;
+    constexpr int A_PLANE_B = G::A_PLANE_B, B_PLANE_B = G::B_PLANE_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE_B
 
     const int L = blockIdx.x;
@@ -48,31 +60,33 @@ __global__ __launch_bounds__(512, 1) void gemm_split3_kernel(Gemm3Args p, int nM
     const int wr = wave >> 1, wc = wave & 1;
     const int hh = lane >> 5, idx = lane & 31;
 
-    // ---- DMA sources: piece q = 9 * wave + i of a stage; pieces 0..47 are the A planes (16 rows each), 48..71 the W
-    //      planes; lane l of a piece lands at row (l >> 2), physical chunk (l & 3)
+    // ---- DMA sources: a stage is NPIECE pieces of 1 KB (RPP rows of one plane), A planes first, then the W planes,
+    //      laid out linearly in LDS; wave w issues pieces w, w + 8, ...; lane l of a piece lands at row l / CPR,
+    //      physical chunk l % CPR, and fetches the logical chunk that the read-side swizzle expects there
     const unsigned short* src[PPW];
     {
-        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);          // (row >> 2) & 3 with row = 16 * piece + (lane >> 2)
+        const int prow = lane / CPR;
+        const int chunk = (lane % CPR) ^ ((prow / G::RPB) & (CPR - 1));
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int q = wave * PPW + i;
-            if (q < 48) {
-                int row = m0 + (q & 15) * 16 + (lane >> 2);
+            const int q = wave + 8 * i;
+            if (q < G::A_PIECES) {
+                int row = m0 + (q % (BM / RPP)) * RPP + prow;
                 row = row < p.M ? row : p.M - 1;
-                src[i] = p.A + (size_t)(q >> 4) * p.a_plane + (size_t)row * p.lda + chunk * 8;
+                src[i] = p.A + (size_t)(q / (BM / RPP)) * p.a_plane + (size_t)row * p.lda + chunk * 8;
             } else {
-                const int qq = q - 48;
-                int col = n0 + (qq & 7) * 16 + (lane >> 2);
+                const int qq = (q < G::NPIECE ? q : G::NPIECE - 1) - G::A_PIECES;
+                int col = n0 + (qq % (BN / RPP)) * RPP + prow;
                 col = col < p.N ? col : p.N - 1;
-                src[i] = p.W + (size_t)(qq >> 3) * p.w_plane + (size_t)col * p.ldw + chunk * 8;
+                src[i] = p.W + (size_t)(qq / (BN / RPP)) * p.w_plane + (size_t)col * p.ldw + chunk * 8;
             }
         }
     }
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * (PPW * 1024));
-    auto stage = [&](int buf, int kt) {
-        const unsigned dst = lds0 + (unsigned)buf * STAGE_B;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) glds16(src[i] + kt * 32, dst + i * 1024);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
+    const bool last_piece_ok = wave + 8 * (PPW - 1) < G::NPIECE;           // wave-uniform
+    auto piece = [&](int i, int buf, int kt) {
+        if (i == PPW - 1 && !last_piece_ok) return;
+        glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * 8192);
     };
 
     floatx16 acc[2][2];
@@ -83,26 +97,26 @@ __global__ __launch_bounds__(512, 1) void gemm_split3_kernel(Gemm3Args p, int nM
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    // per-lane read offsets (bytes)
-    const int f = (idx >> 2) & 3;
+    // per-lane read offsets (bytes): row idx of a 32-row MFMA operand, chunk (2 s + h | h) ^ swizzle(row)
+    const int f = (idx / G::RPB) & (CPR - 1);
     const int aoff = (wr * 64 + idx) * ROWB;
     const int boff = 3 * A_PLANE_B + (wc * 64 + idx) * ROWB;
-    int coff[2];
+    int coff[G::STEPS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) coff[s] = ((2 * s + hh) ^ f) * 16;
+    for (int st = 0; st < G::STEPS; ++st) coff[st] = ((G::STEPS * st + hh) ^ f) * 16;
 
-    const int nk = p.K / 32;
-    stage(0, 0);
+    const int nk = p.K / KS;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) piece(i, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         glds_wait_all();
         __syncthreads();
         // the DMA pieces of K tile kt+1 are issued one per group of four MFMAs: each piece costs the wave tens of issue
         // cycles, which the matrix pipe covers when they sit between MFMAs instead of in front of them
         const bool nxt = kt + 1 < nk;
-        const unsigned dst = lds0 + (unsigned)((kt + 1) & 1) * STAGE_B;
-        const int koff = (kt + 1) * 32;
+        const int nb = (kt + 1) & 1;
         const unsigned char* sb = smem + (kt & 1) * STAGE_B;
-#define PF_PIECE(I) do { if (nxt) glds16(src[I] + koff, dst + (I) * 1024); } while (0)
+#define PF_PIECE(I) do { if ((I) < PPW && nxt) piece((I) < PPW ? (I) : 0, nb, kt + 1); } while (0)
 #define PF_PROD(PA, PB)                                                                                               \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                    \
         acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[jj][PB], acc[i][jj], 0, 0, 0)
@@ -121,13 +135,15 @@ __global__ __launch_bounds__(512, 1) void gemm_split3_kernel(Gemm3Args p, int nM
         PF_PROD(0, 1); PF_PIECE(3);
         PF_PROD(1, 0); PF_PIECE(4);
         PF_PROD(0, 0); PF_PIECE(5);
-        PF_LOAD(1)
-        PF_PROD(1, 1); PF_PIECE(6);
-        PF_PROD(0, 2); PF_PIECE(7);
-        PF_PROD(2, 0); PF_PIECE(8);
-        PF_PROD(0, 1);
-        PF_PROD(1, 0);
-        PF_PROD(0, 0);
+        if constexpr (G::STEPS == 2) {
+            PF_LOAD(G::STEPS - 1)
+            PF_PROD(1, 1); PF_PIECE(6);
+            PF_PROD(0, 2); PF_PIECE(7);
+            PF_PROD(2, 0); PF_PIECE(8);
+            PF_PROD(0, 1);
+            PF_PROD(1, 0);
+            PF_PROD(0, 0);
+        }
 #undef PF_PROD
 #undef PF_LOAD
 #undef PF_PIECE
@@ -203,18 +219,26 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     }
 }
 
-template <int MODE, bool OUT3>
-int launch_one(const Gemm3Args& a, int nM, int nN, hipStream_t stream) {
+template <int MODE, bool OUT3, int KS>
+int launch_ks(const Gemm3Args& a, int nM, int nN, hipStream_t stream) {
+    constexpr int LDS_B = 2 * Geo<KS>::STAGE_B;
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split3_kernel<MODE, OUT3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B));
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split3_kernel<MODE, OUT3, KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         configured = true;
     }
     const int nMpad = (nM + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_split3_kernel<MODE, OUT3>), dim3((unsigned)nMpad * nN), dim3(512), 2 * STAGE_B, stream, a, nM, nN);
+    hipLaunchKernelGGL((gemm_split3_kernel<MODE, OUT3, KS>), dim3((unsigned)nMpad * nN), dim3(512), LDS_B, stream, a, nM, nN);
     PF_HIP_TRY(hipGetLastError());
     return 0;
+}
+// KS = 16 (32-B rows, two workgroups per CU so that one's epilogue / barrier sits under the other's MFMAs) measured
+// 165 TF-equivalent against 180 for KS = 32 on the encoder shapes: the half-line DMA rows and twice the barriers cost
+// more than the overlap returns
+template <int MODE, bool OUT3>
+int launch_one(const Gemm3Args& a, int nM, int nN, hipStream_t stream) {
+    return launch_ks<MODE, OUT3, 32>(a, nM, nN, stream);
 }
 
 }  // namespace
