@@ -57,6 +57,8 @@ class Paraformer(nn.Module):
         self.ctc, self.specaug, self.normalize = None, None, None
         self.ctc_weight = ctc_weight
         self.beam_search = None
+        if kwargs.get("precision"):                      # model_conf: {precision: fp32 | bf16x3 | bf16}
+            self.set_precision(kwargs["precision"])
 
     # ------------------------------------------------------------------------------------------------ builders
     @classmethod
@@ -72,8 +74,10 @@ class Paraformer(nn.Module):
                    input_size=input_size, vocab_size=vocab)
 
     def set_precision(self, mode: str = "fp32"):
-        """"fp32": exact-fp32 MFMA everywhere (parity mode). "bf16": bf16 operands for the encoder's and the decoder's
-        GEMMs and attention (fp32 accumulate / residual / LN / softmax / FSMN); the CIF predictor stays fp32."""
+        """"fp32": exact-fp32 MFMA everywhere (default). "bf16x3": the same fp32 results with the large GEMMs on the bf16
+        matrix cores from three-plane split operands (meets the fp32 parity bars; for large batches). "bf16": bf16 operands
+        for the encoder's and the decoder's GEMMs and attention (fp32 accumulate / residual / LN / softmax / FSMN), bf16-class
+        error. The CIF predictor is fp32 in every mode."""
         self.encoder.set_precision(mode)
         self.decoder.set_precision(mode)
         return self

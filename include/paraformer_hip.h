@@ -102,7 +102,11 @@ int pf_encoder_set_tensor(pf_encoder* e, const char* name, const float* data, in
 int pf_encoder_missing(const pf_encoder* e);
 /* 0 = fp32 MFMA everywhere (default; the parity configuration: activations <= 1e-3, CIF indices equal to the CPU
  * reference). 1 = bf16 OPERANDS for the GEMMs and the attention with fp32 accumulation; residual stream, LayerNorm
- * statistics, softmax and FSMN stay fp32 (the reference's own bf16=True casts the whole module, auto_model.py:665-668). */
+ * statistics, softmax and FSMN stay fp32 (the reference's own bf16=True casts the whole module, auto_model.py:665-668).
+ * 2 = fp32 results from the bf16 matrix cores: every GEMM operand is held as three bf16 planes (x = hi + mid + lo
+ * exactly) and multiplied with six bf16 MFMA products, fp32 accumulate (gemm_split3.hip); everything else is mode 0.
+ * Meets the same parity bars as mode 0 (tests/test_parity_gpu.py, fixture f32_mode); intended for large batches
+ * (256-row tiles). */
 int pf_encoder_set_precision(pf_encoder* e, int32_t mode);
 /* xs_dev: [B, T, input_dim] (un-scaled features, exactly what SANMEncoder.forward receives), lens_host: [B],
  * pe_dev: [T, input_dim] sinusoidal table (embedding.py:396-420; NULL = library computes it with libm),
@@ -158,8 +162,8 @@ pf_decoder* pf_decoder_create(const pf_decoder_config* cfg);
 void pf_decoder_destroy(pf_decoder* d);
 int pf_decoder_set_tensor(pf_decoder* d, const char* name, const float* data, int64_t numel);
 int pf_decoder_missing(const pf_decoder* d);
-/* 0 = fp32 (default), 1 = bf16 operands for the GEMMs and the cross-attention (see pf_encoder_set_precision); applies
- * to the fused arg-max route (logits_dev == NULL) */
+/* 0 = fp32 (default), 1 = bf16 operands for the GEMMs and the cross-attention (see pf_encoder_set_precision; applies
+ * to the fused arg-max route, logits_dev == NULL), 2 = w_1 and linear_k_v on the three-plane split GEMM (fp32 results) */
 int pf_decoder_set_precision(pf_decoder* d, int32_t mode);
 /* memory_dev: [B, T, d_model] encoder output, mem_lens_host: [B]; embeds_dev: [B, N, d_model] CIF output,
  * tok_lens_host: [B]. Outputs (each may be NULL): logits_dev [B, N, vocab] (pre-softmax, decoder.py:444),
