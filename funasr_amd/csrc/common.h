@@ -188,5 +188,7 @@ struct AttnArgs {
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
 // bf16 Q/K/V in, bf16 O out (strides in elements), fp32 softmax statistics and accumulators
 int launch_attention_bf16(const AttnArgs& a, hipStream_t stream);
+// fp32 in / fp32 (or plane) out like launch_attention_f32, both products on the bf16 MFMA from three-plane split operands
+int launch_attention_split3(const AttnArgs& a, hipStream_t stream);
 
 }  // namespace pf

@@ -221,9 +221,10 @@ static int fsmn(const FsmnArgs& a, hipStream_t s) {
     ProfScope ps(PROF_FSMN, (a.R ? 12.0 : 8.0) * a.B * (double)a.T * a.C, s);
     return launch_fsmn(a, s);
 }
-static int attention(const AttnArgs& a, double flops, hipStream_t s) {
+static int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3 = false) {
     ProfScope ps(PROF_ATTN, flops, s);
-    return launch_attention_f32(a, s);
+    static const bool no_x3 = getenv("PF_ATTN_F32") != nullptr;     // A/B switch for measurements
+    return (x3 && !no_x3) ? launch_attention_split3(a, s) : launch_attention_f32(a, s);
 }
 
 // ================================================================================================ frontend
@@ -473,7 +474,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         aa.O = nullptr; aa.O3 = ctx3; aa.o_plane = (size_t)M * D; aa.ldo = D;       // straight into the out-projection's planes
         aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
         aa.scale = powf((float)(D / c.n_heads), -0.5f);
-        if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s))) return rc;
+        if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s, true))) return rc;
         const float* resid3 = (w.in_dim == D) ? x_in : nullptr;
         if ((rc = gemm3(ctx3, D, w.out_w3, w.out_b, x, D, nullptr, D, D, 0, mem, D, resid3, ld_in))) return rc;
         {
@@ -1410,7 +1411,7 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
         aa.V = d->kv.as<float>() + D; aa.ldv = 2 * D; aa.O = d->ctx.as<float>(); aa.ldo = D;
         aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tq = N; aa.Tk = T;
         aa.scale = powf((float)(D / c.n_heads), -0.5f);
-        if ((rc = attention(aa, 4.0 * B * (double)N * T * D, s))) return rc;
+        if ((rc = attention(aa, 4.0 * B * (double)N * T * D, s, x3))) return rc;
         if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, x, D, Mq, D, D, 0, nullptr, 0, x, D, s)))
             return rc;                                                                        // x = residual + att
     }
@@ -1777,6 +1778,15 @@ int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk,
     aa.Q = Q; aa.ldq = ldq; aa.K = K; aa.ldk = ldk; aa.V = V; aa.ldv = ldv; aa.O = O; aa.ldo = ldo;
     aa.klens = klens_dev; aa.B = B; aa.H = H; aa.Tq = Tq; aa.Tk = Tk; aa.scale = scale;
     return attention(aa, 4.0 * B * (double)Tq * Tk * H * 128, reinterpret_cast<hipStream_t>(stream));
+}
+/* fp32 Q/K/V -> fp32 O with both products on the bf16 MFMA from three-plane split operands (attention_split3.hip) */
+int pf_k_attention_split3(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv, float* O,
+                          int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
+                          void* stream) {
+    AttnArgs aa{};
+    aa.Q = Q; aa.ldq = ldq; aa.K = K; aa.ldk = ldk; aa.V = V; aa.ldv = ldv; aa.O = O; aa.ldo = ldo; aa.klens = klens_dev;
+    aa.B = B; aa.H = H; aa.Tq = Tq; aa.Tk = Tk; aa.scale = scale;
+    return launch_attention_split3(aa, reinterpret_cast<hipStream_t>(stream));
 }
 int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                         int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,

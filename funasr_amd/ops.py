@@ -92,6 +92,29 @@ def attention(q, k, v, klens, n_heads: int, scale: float):
     return out
 
 
+def attention_split3(q, k, v, klens, n_heads: int, scale: float, time_iters: int = 0):
+    """Same contract as attention(); both products on the bf16 MFMA from three-plane split operands (fp32-class)."""
+    lib = _lib.load()
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    out = torch.empty(B, Tq, D, device=q.device, dtype=torch.float32)
+    def run():
+        _lib.check(lib.pf_k_attention_split3(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(out), D,
+                                             _ptr(klens), B, n_heads, Tq, Tk, float(scale), _stream()), "pf_k_attention_split3")
+    run()
+    if time_iters <= 0:
+        return out
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(time_iters):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    return out, a.elapsed_time(b) / time_iters
+
+
 def cif(alphas: torch.Tensor, hidden: torch.Tensor, n_max: int):
     """alphas [B, T], hidden [B, T, D] -> (peaks [B, T], n_fires int32 [B], embeds [B, n_max, D])."""
     lib = _lib.load()

@@ -260,6 +260,10 @@ int pf_k_fsmn(const float* in, int32_t ldin, const float* w, const float* R, int
 int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
                        float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq,
                        int32_t Tk, float scale, void* stream);
+/* same contract, both products on the bf16 MFMA from three-plane split operands (fp32-class results; mode bf16x3) */
+int pf_k_attention_split3(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
+                          float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq,
+                          int32_t Tk, float scale, void* stream);
 /* bf16 twin of pf_k_attention_f32: Q/K/V/O bf16, strides in elements */
 int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                         int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,

@@ -200,6 +200,10 @@ def test_attention_f32(cuda, B, Tq, Tk, lens):
     kvd = kv.to(cuda)
     out = ops.attention(q.to(cuda), kvd[:, :, :H * dk], kvd[:, :, H * dk:], klens.to(cuda), H, scale).cpu()
     assert (out.double() - ref).abs().max().item() < 2e-5
+    # the bf16x3 form (three-plane split operands on the bf16 MFMA) meets the same bar
+    out3 = ops.attention_split3(q.to(cuda), kvd[:, :, :H * dk], kvd[:, :, H * dk:], klens.to(cuda), H, scale).cpu()
+    e3, e32 = (out3.double() - ref).abs().max().item(), (out.double() - ref).abs().max().item()
+    assert e3 < 2e-5 and e3 < 3 * e32 + 1e-6, (e3, e32)
 
 
 @pytest.mark.parametrize("B,Tq,Tk,lens", [(2, 100, 100, [100, 37]), (1, 500, 500, [500]), (3, 40, 300, [300, 1, 129])])
