@@ -1411,7 +1411,9 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
         aa.V = d->kv.as<float>() + D; aa.ldv = 2 * D; aa.O = d->ctx.as<float>(); aa.ldo = D;
         aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tq = N; aa.Tk = T;
         aa.scale = powf((float)(D / c.n_heads), -0.5f);
-        if ((rc = attention(aa, 4.0 * B * (double)N * T * D, s, x3))) return rc;
+        // cross-attention keeps the fp32 MFMA kernel in every fp32-accurate mode: with Tq = tokens (~120) one 128-query
+        // block per (utterance, head) is the better shape (102 us vs 111 us for the 256-query split kernel)
+        if ((rc = attention(aa, 4.0 * B * (double)N * T * D, s))) return rc;
         if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, x, D, Mq, D, D, 0, nullptr, 0, x, D, s)))
             return rc;                                                                        // x = residual + att
     }

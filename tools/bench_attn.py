@@ -7,10 +7,11 @@ from funasr_amd import ops
 
 dev = torch.device("cuda:0")
 B, T, H, dk = 64, 500, 4, 128
+Tq = int(sys.argv[1]) if len(sys.argv) > 1 else T          # 120 = the decoder's cross-attention (queries = tokens)
 qkv = torch.randn(B, T, 3 * H * dk, device=dev)
-q, k, v = qkv[:, :, :512], qkv[:, :, 512:1024], qkv[:, :, 1024:]
+q, k, v = qkv[:, :Tq, :512].contiguous(), qkv[:, :, 512:1024], qkv[:, :, 1024:]
 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
-fl = 4.0 * B * T * T * H * dk
+fl = 4.0 * B * Tq * T * H * dk
 ref = ops.attention(q, k, v, lens, H, dk ** -0.5)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
