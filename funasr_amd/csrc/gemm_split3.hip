@@ -1,7 +1,8 @@
 // fp32-accurate GEMM on the bf16 matrix cores: C = epilogue(A[M,K] * W[N,K]^T) with both operands held as THREE bf16
 // planes (x = hi + mid + lo exactly: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); 8 + 8 + 8 significand
 // bits cover fp32's 24) and six v_mfma_f32_32x32x16_bf16 products per operand pair:
-//     hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid      (dropped: mid*lo, lo*mid, lo*lo <= 2^-26 |a||w|)
+//     hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid      (dropped: mid*lo, lo*mid <= 2^-24 |a||w| each,
+//                                                              lo*lo <= 2^-32: the size of fp32's own product rounding)
 // Every bf16 x bf16 product is exact in fp32 and the sums are carried in fp32, so the result has fp32-class error
 // (measured against float64 in tests/test_kernels_gpu.py next to the v_mfma_f32_32x32x2_f32 kernel) while the
 // matrix pipe runs at the bf16 rate: 2.5 PFLOP/s / 6 products = 417 TFLOP/s of fp32-equivalent work per GPU against
