@@ -43,6 +43,13 @@ class SenseVoiceSmall(nn.Module):
         self.textnorm_dict = {"withitn": 14, "woitn": 15}
         self.embed = nn.Embedding(7 + len(self.lid_dict) + len(self.textnorm_dict), input_size)
         self.embed.weight.requires_grad_(False)
+        if kwargs.get("precision"):                      # model_conf: {precision: fp32 | bf16x3 | bf16}
+            self.set_precision(kwargs["precision"])
+
+    def set_precision(self, mode: str = "fp32"):
+        """Arithmetic mode of the encoder (see SANMEncoder.set_precision); the CTC projection + arg-max stay fp32."""
+        self.encoder.set_precision(mode)
+        return self
 
     @classmethod
     def from_config(cls, cfg: dict) -> "SenseVoiceSmall":

@@ -192,7 +192,7 @@ def test_pipeline_token_ids_equal_reference(cuda, f32_mode):
 
 
 # -------------------------------------------------------------------------------------------------- SenseVoice
-def test_sensevoice_encoder_and_ctc_vs_reference_golden(cuda):
+def test_sensevoice_encoder_and_ctc_vs_reference_golden(cuda, f32_mode):
     from funasr_amd.ctc import CTC
     from funasr_amd.sanm_encoder import SenseVoiceEncoderSmall
     g = gold("sensevoice")
@@ -200,7 +200,7 @@ def test_sensevoice_encoder_and_ctc_vs_reference_golden(cuda):
     sd = synth.sensevoice_state_dict(cfg, seed=int(g["seed"]))
     enc = SenseVoiceEncoderSmall(input_layer="pe", **cfg["encoder"])
     enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
-    enc = enc.to(cuda)
+    enc = enc.to(cuda).set_precision(f32_mode)
     out, olens = enc(t(g["xs"]).to(cuda), t(g["lens"]))
     assert olens.tolist() == g["olens"].tolist()
     assert (out.cpu() - t(g["out"])).abs().max().item() < 1e-4
@@ -268,7 +268,7 @@ def test_bf16_operand_mode_stays_close_to_fp32_mode(cuda):
     assert d.mean().item() < 0.02 * scale and d.max().item() < 0.25 * max(scale, 1.0), (d.mean().item(), d.max().item(), scale)
 
 
-def test_edge_cases_short_silent_and_zero_token_utterances(cuda):
+def test_edge_cases_short_silent_and_zero_token_utterances(cuda, f32_mode):
     """Edge cases of the offline path: (1) an utterance shorter than one 25 ms window is rejected like the reference's
     fbank would produce no frame; (2) one-frame utterances and a batch where some clips fire no token at all: those
     clips come back empty, their neighbours are unaffected (bitwise) -- where the reference raises IndexError for a
@@ -286,7 +286,7 @@ def test_edge_cases_short_silent_and_zero_token_utterances(cuda):
     sd = synth.paraformer_state_dict(cfg, seed=5, cif_bias=-6.0)          # alpha ~ 0.002: almost nothing fires
     model = Paraformer.from_config(cfg)
     model.load_state_dict(sd, strict=False)
-    model = model.to(cuda)
+    model = model.to(cuda).set_precision(f32_mode)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(3, 40, 560, generator=g) * 0.7
     lens = torch.tensor([40, 3, 25], dtype=torch.int32)
