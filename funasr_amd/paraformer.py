@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .audio import load_audio_list
 from .register import tables
+from .timestamps import cif_timestamps
 from .tokenizer import sentence_postprocess
 
 # importing registers the classes under the reference's names
@@ -169,9 +170,18 @@ class Paraformer(nn.Module):
             if tokenizer is not None:
                 token = tokenizer.ids2tokens(token_int)
                 text = tokenizer.tokens2text(token)
-                if not hasattr(tokenizer, "bpemodel"):
-                    text, _ = sentence_postprocess(token)
-                results.append({"key": key[i], "text": text})
+                if kwargs.get("pred_timestamp", False):
+                    # model.py:668-681. The reference hands (cif_peak, alphas) to the (us_alphas, us_peaks) parameters of
+                    # ts_prediction_lfr6_standard in THAT order; kept, so that the timestamps are the reference's.
+                    _, stamps = cif_timestamps(res["peaks"][i].cpu(), res["alphas"][i].cpu(), list(token),
+                                               vad_offset=kwargs.get("begin_time", 0), upsample_rate=1)
+                    if not hasattr(tokenizer, "bpemodel"):
+                        text, stamps, _ = sentence_postprocess(token, stamps)
+                    results.append({"key": key[i], "text": text, "timestamp": stamps})
+                else:
+                    if not hasattr(tokenizer, "bpemodel"):
+                        text, _ = sentence_postprocess(token)
+                    results.append({"key": key[i], "text": text})
                 if ibest_writer is not None:                             # model.py:688-692
                     ibest_writer["token"][key[i]] = " ".join(token)
                     ibest_writer["text"][key[i]] = text

@@ -1,0 +1,84 @@
+"""Token timestamps from the CIF weights (host side, no GPU work).
+
+Restates `ts_prediction_lfr6_standard` (funasr/utils/timestamp_tools.py:37-122), the function Paraformer.inference
+calls when `pred_timestamp=True` (funasr/models/paraformer/model.py:668-676): a token lasts from its CIF fire to the
+next one, fires are shifted by `force_time_shift` frames, one (upsampled) LFR frame is 60 ms / upsample_rate, long gaps
+and the two ends of the utterance become `<sil>` spans. When the number of fires does not match the number of tokens
+the alphas are rescaled to sum to len(tokens) + 1 and integrated again sequentially in fp32
+(`cif_wo_hidden`, timestamp_tools.py:12-34) -- the arithmetic below keeps the reference's dtypes and order so that the
+millisecond values come out identical.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+_EDGE_FRAMES = 5          # shorter leading / trailing gaps are not reported as silence
+_MAX_TOKEN_FRAMES = 12    # a token is cut after this many frames, the rest of the gap is silence
+_FIRE = 1.0 - 1e-4
+
+
+def _refire(alphas: torch.Tensor, n_fires: int) -> torch.Tensor:
+    """alphas rescaled to sum to n_fires, then integrate-and-fire at 1 - 1e-4; returns the running integral per frame
+    (the value BEFORE the threshold is taken off), fp32 like the reference loop."""
+    a = (alphas / (alphas.sum() / n_fires)).to(torch.float32).cpu().numpy()
+    thr = np.float32(_FIRE)
+    acc = np.float32(0.0)
+    out = np.empty(a.shape[0], dtype=np.float32)
+    for t in range(a.shape[0]):
+        acc = np.float32(acc + a[t])
+        out[t] = acc
+        if acc >= thr:
+            acc = np.float32(acc - thr)
+    return torch.from_numpy(out)
+
+
+def cif_timestamps(us_alphas: torch.Tensor, us_peaks: torch.Tensor, char_list: Sequence[str], vad_offset: float = 0.0,
+                   force_time_shift: float = -1.5, sil_in_str: bool = True, upsample_rate: int = 3
+                   ) -> Tuple[str, List[List[int]]]:
+    """-> ("tok beg end;..." with seconds, [[beg_ms, end_ms] per non-silence token])."""
+    if not len(char_list):
+        return "", []
+    frame_s = 10.0 * 6 / 1000 / upsample_rate
+    alphas, peaks = (us_alphas[0], us_peaks[0]) if us_alphas.dim() == 2 else (us_alphas, us_peaks)   # batch of one
+    tokens = list(char_list[:-1]) if char_list[-1] == "</s>" else list(char_list)
+    fires = torch.where(peaks >= _FIRE)[0].cpu().numpy() + force_time_shift
+    if len(fires) != len(tokens) + 1:
+        peaks = _refire(alphas, len(tokens) + 1)
+        fires = torch.where(peaks >= _FIRE)[0].cpu().numpy() + force_time_shift
+    n_frames = peaks.shape[0]
+
+    names: List[str] = []
+    spans: List[List[float]] = []
+    if fires[0] > _EDGE_FRAMES:
+        names.append("<sil>")
+        spans.append([0.0, fires[0] * frame_s])
+    for i in range(len(fires) - 1):
+        names.append(tokens[i])
+        if fires[i + 1] - fires[i] <= _MAX_TOKEN_FRAMES:
+            spans.append([fires[i] * frame_s, fires[i + 1] * frame_s])
+        else:
+            cut = fires[i] + _MAX_TOKEN_FRAMES
+            spans.append([fires[i] * frame_s, cut * frame_s])
+            names.append("<sil>")
+            spans.append([cut * frame_s, fires[i + 1] * frame_s])
+    if n_frames - fires[-1] > _EDGE_FRAMES:
+        end = (n_frames + fires[-1]) * 0.5
+        spans[-1][1] = end * frame_s
+        names.append("<sil>")
+        spans.append([end * frame_s, n_frames * frame_s])
+    elif spans:
+        spans[-1][1] = n_frames * frame_s
+    if vad_offset:                                        # segment start inside the recording, milliseconds
+        for sp in spans:
+            sp[0] += vad_offset / 1000.0
+            sp[1] += vad_offset / 1000.0
+    text = "".join("{} {} {};".format(nm, str(sp[0] + 0.0005)[:5], str(sp[1] + 0.0005)[:5])
+                   for nm, sp in zip(names, spans) if sil_in_str or nm != "<sil>")
+    ms = [[int(sp[0] * 1000), int(sp[1] * 1000)] for nm, sp in zip(names, spans) if nm != "<sil>"]
+    return text, ms
+
+
+ts_prediction_lfr6_standard = cif_timestamps       # the reference's name, for code that imports it

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import json
 import os
-from typing import Iterable, List, Sequence, Tuple, Union
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
 
 from .register import tables
 
@@ -48,9 +48,18 @@ def _is_letter(tok: str) -> bool:
     return len(tok) == 1 and tok.encode("utf-8").isalpha()
 
 
-def _merge_abbreviations(words: List[str]) -> List[str]:
-    """'a', ' ', 'b', ' ', 'c' -> 'ABC' (abbr_dispose without timestamps)."""
+def _merge_abbreviations(words: List[str], spans: Optional[List[List[int]]] = None):
+    """'a', ' ', 'b', ' ', 'c' -> 'ABC' (abbr_dispose, postprocess_utils.py:68-163). With `spans` (one [begin, end] per
+    non-blank word) the merged word runs from its first letter's begin to its last letter's end and the merged span
+    list is returned as well."""
     out: List[str] = []
+    out_spans: List[List[int]] = []
+    # span index of every position: a blank shares the index of the word that follows it
+    idx, k = [], 0
+    for w in words:
+        idx.append(k)
+        if w != " ":
+            k += 1
     i, n = 0, len(words)
     while i < n:
         if _is_letter(words[i]) and i + 2 < n and words[i + 1] == " " and _is_letter(words[i + 2]):
@@ -58,45 +67,77 @@ def _merge_abbreviations(words: List[str]) -> List[str]:
             while j + 2 < n and words[j + 1] == " " and _is_letter(words[j + 2]):
                 j += 2
             out.append("".join(w.upper() for w in words[i:j + 1] if w != " "))
+            if spans is not None and idx[j] < len(spans):
+                out_spans.append([spans[idx[i]][0], spans[idx[j]][1]])
             i = j + 1
         else:
             out.append(words[i])
+            if spans is not None and words[i] != " " and idx[i] < len(spans):
+                out_spans.append([spans[idx[i]][0], spans[idx[i]][1]])
             i += 1
-    return out
+    return (out, out_spans) if spans is not None else out
 
 
-def sentence_postprocess(tokens: Iterable[Union[str, bytes]]) -> Tuple[str, List[str]]:
+def sentence_postprocess(tokens: Iterable[Union[str, bytes]], time_stamp: Optional[List[List[int]]] = None):
+    """-> (sentence, words) or, with one [begin_ms, end_ms] per token, (sentence, spans, words): the spans of "@@"
+    continued pieces are merged into their word, words are joined by blanks (postprocess_utils.py:165-278)."""
     toks = [t if isinstance(t, str) else t.decode("utf-8") for t in tokens]
     toks = [t for t in toks if t not in _DROP]
+    ts = time_stamp
     words: List[str] = []
+    spans: List[List[int]] = []
     if _all_cjk(toks):
         words = [t.replace(" ", "") for t in toks]
+        if ts is not None:
+            spans = ts
     elif _all_alpha(toks):
-        piece = ""
-        for t in toks:
+        piece, begin = "", None
+        for i, t in enumerate(toks):
+            if ts is not None and begin is None:
+                begin = ts[i][0]
             if "@@" in t:
                 piece += t.replace("@@", "")
             else:
                 words += [piece + t, " "]
                 piece = ""
+                if ts is not None:
+                    spans.append([begin, ts[i][1]])
+                    begin = None
     else:
-        piece, blank = "", False
-        for t in toks:
+        # mixed script. `fresh`: the next token starts a new span (False while "@@" pieces are pending); a token that
+        # is neither CJK, a piece nor alphabetic joins the words but gets no span -- as in the reference
+        piece, blank, fresh, begin, end = "", False, True, -1, -1
+        for i, t in enumerate(toks):
+            if ts is not None and fresh:
+                begin, end = ts[i][0], ts[i][1]
             if _all_cjk(t):
                 if blank:
                     words.pop()
                 words.append(t)
                 blank = False
+                if ts is not None:
+                    spans.append([begin, end])
+                    fresh, begin = True, end
             elif "@@" in t:
                 piece += t.replace("@@", "")
                 blank = False
+                if ts is not None:
+                    fresh, end = False, ts[i][1]
             elif _all_alpha(t):
                 words += [piece + t, " "]
                 piece, blank = "", True
+                if ts is not None:
+                    end = ts[i][1]
+                    spans.append([begin, end])
+                    fresh, begin = True, end
             else:
                 words.append(t)
-    words = _merge_abbreviations(words)
-    return "".join(words).strip(), [w for w in words if w != " "]
+    if ts is None:
+        words = _merge_abbreviations(words)
+        return "".join(words).strip(), [w for w in words if w != " "]
+    words, spans = _merge_abbreviations(words, spans)
+    real = [w for w in words if w != " "]
+    return " ".join(real).strip(), spans, real
 
 
 @tables.register("tokenizer_classes", "CharTokenizer")

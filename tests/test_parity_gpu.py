@@ -191,6 +191,39 @@ def test_pipeline_token_ids_equal_reference(cuda, f32_mode):
         assert res["raw_ids"][b] == g["raw_ids"][b, :n].tolist()
 
 
+def test_pred_timestamp_follows_the_reference_call(cuda):
+    """Paraformer.inference(pred_timestamp=True) (paraformer/model.py:668-681): per utterance the reference calls
+    ts_prediction_lfr6_standard(pre_peak_index[i], alphas[i], tokens, vad_offset=begin_time, upsample_rate=1) -- cif_peak
+    in the `us_alphas` slot, alphas in the `us_peaks` slot -- and post-processes tokens and spans together. The two host
+    functions are pinned to the reference in tests/test_timestamps.py; here the wiring is checked on the oracle's outputs."""
+    from funasr_amd.paraformer import Paraformer
+    from funasr_amd.timestamps import cif_timestamps
+    from funasr_amd.tokenizer import CharTokenizer, sentence_postprocess
+    from oracle import paraformer_oracle as O
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2, dec_blocks=1, vocab=64)
+    sd = synth.paraformer_state_dict(cfg, seed=21, cif_bias=-0.5)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(cuda)
+    chars = ["<blank>", "<s>", "</s>"] + list("天地玄黄宇宙洪荒日月盈昃辰宿列张寒来暑往秋收冬藏") + ["he@@", "llo", "a", "b", "ok", "world"]
+    chars += [f"w{i}" for i in range(64 - len(chars))]
+    tok = CharTokenizer(token_list=chars)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 60, 560, generator=g) * 0.7
+    lens = torch.tensor([60, 41], dtype=torch.int32)
+    x[1, 41:] = 0
+    res, meta = model.inference(x.to(cuda), data_lengths=lens, key=["u0", "u1"], tokenizer=tok, data_type="fbank",
+                                pred_timestamp=True, begin_time=500)
+    ref = O.paraformer_greedy(x, lens, sd, cfg)
+    assert [r["key"] for r in res] == ["u0", "u1"]
+    for i, r in enumerate(res):
+        tokens = tok.ids2tokens(ref["ids"][i])
+        _, stamps = cif_timestamps(ref["peaks"][i], ref["alphas"][i], list(tokens), vad_offset=500, upsample_rate=1)
+        text, stamps, _ = sentence_postprocess(tokens, stamps)
+        assert r["text"] == text and r["timestamp"] == stamps and len(stamps) > 0
+        assert all(b >= 500 and e >= b for b, e in r["timestamp"])
+
+
 # -------------------------------------------------------------------------------------------------- SenseVoice
 def test_sensevoice_encoder_and_ctc_vs_reference_golden(cuda, f32_mode):
     from funasr_amd.ctc import CTC
