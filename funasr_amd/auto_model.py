@@ -12,7 +12,12 @@ Mirrors the dispatch half of funasr/auto/auto_model.py that sits on the hot path
     RTF bookkeeping from `meta_data["batch_data_time"]` (:823-833).
 Model directory format (funasr/download/download_model_from_hub.py:80-97): `config.yaml`, `model.pt`, `tokens.json`,
 `am.mvn`. No hub download (no network): `model` must be a local directory.
-VAD / punctuation / speaker pipelines (`inference_with_vad`, :852-1254) are outside the hot path and raise.
+`inference_with_vad` (:852-1254), ASR half: a VAD model -- any object that follows the FunASR model contract and returns
+`[{"key", "value": [[beg_ms, end_ms], ...]}]`, e.g. the reference's own FsmnVADStreaming -- cuts each recording into
+segments; the segments are sorted by length, packed into batches under the reference's `batch_size_s` /
+`batch_size_threshold_s` policy, decoded by the HIP path, put back in order and merged (texts joined, per-token
+timestamps shifted by the segment start). Punctuation and speaker models are outside the hot path and raise. The
+FSMN-VAD network itself is not built yet: `vad_model` must be an object, not a hub name.
 
 When the real package is importable, use `funasr.AutoModel` itself after `funasr_amd.install()`.
 """
@@ -165,9 +170,15 @@ def load_pretrained_model(path: str, model: torch.nn.Module, ignore_init_mismatc
 
 class AutoModel:
     def __init__(self, **kwargs):
-        for k in ("vad_model", "punc_model", "spk_model"):
+        for k in ("punc_model", "spk_model"):
             if kwargs.get(k) is not None:
-                raise NotImplementedError(f"{k}: VAD / punctuation / speaker pipelines are outside the HIP hot path")
+                raise NotImplementedError(f"{k}: punctuation / speaker pipelines are outside the HIP hot path")
+        vad_model = kwargs.pop("vad_model", None)
+        self.vad_kwargs = dict(kwargs.pop("vad_kwargs", None) or {})
+        if isinstance(vad_model, str):
+            raise NotImplementedError("vad_model by name: the FSMN-VAD network is not built on the HIP path yet; pass a "
+                                      "VAD model OBJECT (FunASR model contract: inference(...) -> [{'key', 'value': segments}])")
+        self.vad_model = vad_model
         log_level = getattr(logging, str(kwargs.get("log_level", "WARNING")).upper(), logging.WARNING)
         logging.getLogger().setLevel(log_level)
         model, kwargs = self.build_model(**kwargs)
@@ -248,7 +259,9 @@ class AutoModel:
 
     # ------------------------------------------------------------------------------------------------- generate
     def generate(self, input, input_len=None, progress_callback=None, **cfg):
-        return self.inference(input, input_len=input_len, progress_callback=progress_callback, **cfg)
+        if self.vad_model is None:                                          # :689-712
+            return self.inference(input, input_len=input_len, progress_callback=progress_callback, **cfg)
+        return self.inference_with_vad(input, input_len=input_len, **cfg)
 
     def inference(self, input, input_len=None, model=None, kwargs=None, key=None, progress_callback=None, **cfg):
         if kwargs is None:                                                   # _reset_runtime_configs (:1318-1359)
@@ -298,5 +311,91 @@ class AutoModel:
             pass
         return results_all
 
-    def inference_with_vad(self, *a, **k):
-        raise NotImplementedError("inference_with_vad (VAD segmentation pipeline) is outside the HIP hot path")
+    # --------------------------------------------------------------------------------------- inference_with_vad
+    @staticmethod
+    def plan_vad_batches(durations_ms: List[int], batch_size_ms: int, threshold_ms: int) -> List[Tuple[int, int]]:
+        """The reference's packing of length-sorted VAD segments (:946-966) as [begin, end) index ranges: a segment joins
+        the open batch while it is not the last one, is shorter than `threshold_ms` and (longest so far) x (count) stays
+        under `batch_size_ms`; otherwise the batch -- INCLUDING this segment -- is decoded and a new one is opened."""
+        plan, beg, end, longest = [], 0, 1, 0
+        n = len(durations_ms)
+        for j, d in enumerate(durations_ms):
+            if j < n - 1 and d < threshold_ms and max(longest, d) * (j + 1 - beg) < batch_size_ms:
+                longest = max(longest, d)
+                end += 1
+                continue
+            plan.append((beg, end))
+            beg, end, longest = end, end + 1, d
+        return plan
+
+    def inference_with_vad(self, input, input_len=None, **cfg):
+        """VAD -> length-sorted dynamic batches -> ASR -> merge (funasr/auto/auto_model.py:852-1254 without the
+        punctuation and speaker branches). Returns one dict per recording: key, text, [timestamp], [sentence_info]."""
+        if self.vad_model is None:
+            raise RuntimeError("inference_with_vad needs AutoModel(vad_model=<VAD model object>)")
+        from .audio import load_audio_list
+        vad_kwargs = dict(copy.deepcopy({k: v for k, v in self.vad_kwargs.items() if k not in ("tokenizer", "frontend")}),
+                          **{k: self.vad_kwargs[k] for k in ("tokenizer", "frontend") if k in self.vad_kwargs})
+        vad_kwargs.setdefault("device", self.kwargs.get("device", "cuda"))
+        res = self.inference(input, input_len=input_len, model=self.vad_model, kwargs=vad_kwargs, **cfg)      # step 1
+        if cfg.get("merge_vad", False):
+            from .vad_utils import merge_vad
+            for r in res:
+                r["value"] = merge_vad(r["value"], self.kwargs.get("merge_length_s", 15) * 1000)
+        keep = {k: self.kwargs[k] for k in ("tokenizer", "frontend") if k in self.kwargs}                       # step 2
+        kwargs = dict(copy.deepcopy(self._base_kwargs), **keep)
+        deep_update(kwargs, cfg)
+        batch_size = max(int(kwargs.get("batch_size_s", 300)) * 1000, 1)
+        threshold_ms = int(kwargs.get("batch_size_threshold_s", 60)) * 1000
+        kwargs["batch_size"] = batch_size
+        key_list, data_list = prepare_data_iterator(input, input_len=input_len, data_type=kwargs.get("data_type"))
+        fs = getattr(kwargs.get("frontend"), "fs", 16000)
+        out: List[dict] = []
+        for i, vad_res in enumerate(res):
+            key, segments = vad_res["key"], vad_res["value"]
+            speech = load_audio_list([data_list[i]], fs=fs, audio_fs=kwargs.get("fs", 16000))[0]
+            n = len(segments)
+            order = sorted(range(n), key=lambda j: segments[j][1] - segments[j][0])       # stable, ascending duration
+            if n == 0:
+                out.append({"key": key, "text": "", "timestamp": []})
+                continue
+            durs = [segments[j][1] - segments[j][0] for j in order]
+            bs = max(batch_size, durs[0])
+            if kwargs["device"] == "cpu":
+                bs = 0
+            decoded: List[dict] = []
+            for beg, end in self.plan_vad_batches(durs, bs, threshold_ms):
+                idx = order[beg:end]
+                # slice_padding_audio_samples (funasr/utils/vad_utils.py:28-51): 16 samples per millisecond
+                clips = [speech[int(segments[j][0] * 16): min(int(segments[j][1] * 16), len(speech))] for j in idx]
+                results = self.inference(clips, input_len=None, model=self.model, kwargs=kwargs, **cfg)
+                if len(results) < 1:
+                    continue
+                decoded.extend(results)
+            if len(decoded) != n:
+                out.append({"key": key, "text": "", "timestamp": []})
+                continue
+            restored = [None] * n
+            for pos, j in enumerate(order):
+                restored[j] = decoded[pos]
+            merged: Dict[str, Any] = {}
+            for j in range(n):                                                            # :1005-1038
+                for k, v in restored[j].items():
+                    if k.startswith("timestamp"):
+                        merged.setdefault(k, [])
+                        for t in v:
+                            t[0] = int(t[0]) + int(segments[j][0])
+                            t[1] = int(t[1]) + int(segments[j][0])
+                        merged[k].extend(v)
+                    elif "text" in k:
+                        merged[k] = v if k not in merged else merged[k] + " " + v
+                    elif k != "key":
+                        merged[k] = v if k not in merged else merged[k] + v
+            if not len(merged.get("text", "").strip()):
+                continue
+            if kwargs.get("sentence_timestamp", False):
+                from .vad_utils import vad_segment_sentences
+                merged["sentence_info"] = vad_segment_sentences(restored, segments)
+            merged["key"] = key
+            out.append(merged)
+        return out

@@ -86,10 +86,25 @@ def main():
             s2, ts2, w2 = sentence_postprocess(list(toks), [list(x) for x in ms])
             case["sentence_ts"], case["spans_ts"], case["words_ts"] = s2, ts2, w2
         cases.append(case)
+    # merge_vad (funasr/utils/vad_utils.py:54-89) and the sentence records of _vad_segment_sentences (auto_model.py:71-105)
+    from funasr.utils.vad_utils import merge_vad
+    merge_cases = []
+    for mi in range(24):
+        n = int(rng.integers(0, 12))
+        t, segs = int(rng.integers(0, 500)), []
+        for _ in range(n):
+            d = int(rng.integers(200, 9000))
+            segs.append([t, t + d])
+            t += d + int(rng.integers(50, 3000))
+        mx = int(rng.choice([5000, 15000, 30000]))
+        mn = int(rng.choice([0, 0, 1000]))
+        merge_cases.append(dict(segments=segs, max_length=mx, min_length=mn,
+                                merged=merge_vad([list(x) for x in segs], max_length=mx, min_length=mn)))
     out = os.path.join(os.path.dirname(HERE), "tests", "golden", "timestamps.json")
     with open(out, "w", encoding="utf-8") as f:
         json.dump(dict(generator="oracle/make_golden_timestamps.py", reference="funasr/utils/timestamp_tools.py:37-122, "
-                       "funasr/utils/postprocess_utils.py:165-278", cases=cases), f, ensure_ascii=False)
+                       "funasr/utils/postprocess_utils.py:165-278, funasr/utils/vad_utils.py:54-89", cases=cases, merge_vad=merge_cases),
+                  f, ensure_ascii=False)
     n_ts = sum(1 for c in cases if "spans_ts" in c)
     print(f"wrote {out}: {len(cases)} cases, {n_ts} with timestamped post-processing, "
           f"{sum(1 for i in range(len(cases)) if i % 5 == 4)} through the refire branch")

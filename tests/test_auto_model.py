@@ -90,6 +90,52 @@ def test_generate_matches_oracle_text(model_dir, cuda):
     assert am.kwargs["batch_size"] == 2 or am.kwargs["batch_size"] == 3
 
 
+@pytest.mark.gpu
+def test_generate_with_vad_segments_on_the_hip_path(model_dir, cuda):
+    """inference_with_vad (auto_model.py:852-1254) with a stand-in VAD model: a long recording is cut at the VAD's
+    segments, decoded in length-sorted batches by the HIP path and merged; every segment's text and (shifted)
+    timestamps equal decoding that segment alone."""
+    class FixedVAD:
+        def __init__(self, segments):
+            self.segments = segments
+
+        def parameters(self):
+            return iter(())
+
+        def inference(self, data_in, key=None, **kwargs):
+            return [{"key": key[0], "value": [list(s) for s in self.segments]}], {"batch_data_time": 1.0}
+
+    paths = list(model_dir["waves"])
+    clips = [torch.from_numpy(model_dir["waves"][p].astype(np.float32) / 32768.0) for p in paths]
+    gap = torch.zeros(8000)
+    long = torch.cat([clips[0], gap, clips[1], gap, gap, clips[2], gap])
+    segs, t = [], 0
+    for c, g in zip(clips, (1, 2, 1)):
+        segs.append([t // 16, (t + c.numel()) // 16])
+        t += c.numel() + g * 8000
+    am = AutoModel(model=model_dir["dir"], device="cuda:0", vad_model=FixedVAD(segs))
+    single = AutoModel(model=model_dir["dir"], device="cuda:0")
+    texts, stamps = [], []
+    for (b, e) in segs:
+        r = single.generate(input=long[b * 16: e * 16], pred_timestamp=True)[0]
+        texts.append(r["text"])
+        stamps += [[x + b, y + b] for x, y in r["timestamp"]]
+    # budget 0 s: every segment is its own ASR batch -> identical to decoding the segments one by one
+    out = am.generate(input=long, pred_timestamp=True, batch_size_s=0)
+    assert len(out) == 1 and out[0]["text"] == " ".join(texts)
+    assert out[0]["timestamp"] == stamps and len(stamps) > 0
+    # default budget (300 s): one batch of the three segments in ascending-duration order. A padded batch is not the
+    # same computation as three single decodes in the reference either (the CIF conv peeks into the padded frames,
+    # cif_predictor.py:275-277, and the timestamp function gets rows of the batch tensors, paraformer/model.py:669), so
+    # the expectation is that very batch decoded directly, restored to recording order and shifted
+    out2 = am.generate(input=long, pred_timestamp=True)
+    order = sorted(range(len(segs)), key=lambda j: segs[j][1] - segs[j][0])
+    direct = single.generate(input=[long[segs[j][0] * 16: segs[j][1] * 16] for j in order], pred_timestamp=True, batch_size=3)
+    by_seg = {j: direct[pos] for pos, j in enumerate(order)}
+    assert out2[0]["text"] == " ".join(by_seg[j]["text"] for j in range(len(segs)))
+    assert out2[0]["timestamp"] == [[x + segs[j][0], y + segs[j][0]] for j in range(len(segs)) for x, y in by_seg[j]["timestamp"]]
+
+
 def test_audio_inputs_resample_and_bytes(tmp_path):
     """load_audio handles the input kinds of load_audio_text_image_video (load_utils.py:48-179) that the ASR path sees."""
     import wave as _wave
