@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Golden vectors for the FSMN-VAD decision logic, produced by the REFERENCE's own class
+(funasr/models/fsmn_vad_streaming/model.py `FsmnVADStreaming.forward`) with the network replaced by injected scores:
+the reference computes the frame energies from the waveform, classifies frames, runs its window detector and start /
+end point state machine, drops history and reports segments exactly as in production; only the FSMN's output is given.
+TEST INFRASTRUCTURE: run in the build container (needs /root/reference); writes tests/golden/vad_decision.npz.
+
+Scenarios: speech / silence patterns with blips, long pauses and over-long speech; offline (one final block; several
+blocks with the last one final) and streaming-event reporting in small blocks; option variants (no look-ahead
+extension, single-utterance mode with start-silence timeout, energy and SNR thresholds that actually bite, short
+maximum segment length, different end-silence times).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_import  # noqa: E402
+
+SHIFT, FLEN = 160, 400
+
+
+def pattern(rng, n_frames, kind):
+    """-> (p_sil [n], amplitude per frame [n])"""
+    p = np.empty(n_frames, np.float32)
+    amp = np.empty(n_frames, np.float32)
+    t, speech = 0, bool(rng.random() < 0.3)
+    while t < n_frames:
+        if speech:
+            d = int(rng.integers(3, 40)) if kind == "blips" else int(rng.integers(30, 900 if kind == "long" else 300))
+        else:
+            d = int(rng.integers(2, 30)) if kind == "blips" else int(rng.integers(10, 250))
+        e = min(n_frames, t + d)
+        if speech:
+            p[t:e] = np.clip(0.08 + 0.1 * rng.standard_normal(e - t), 1e-4, 0.6)
+            amp[t:e] = 0.05 + 0.2 * rng.random(e - t)
+        else:
+            p[t:e] = np.clip(0.92 + 0.1 * rng.standard_normal(e - t), 0.3, 1 - 1e-4)
+            amp[t:e] = 1e-4 * (1 + 20 * rng.random()) * (1 + rng.random(e - t))
+        t, speech = e, not speech
+    return p, amp
+
+
+def main():
+    ref_import.install()
+    import funasr.models.fsmn_vad_streaming.encoder  # noqa: F401  (registers FSMN)
+    from funasr.models.fsmn_vad_streaming.model import FsmnVADStreaming
+    rng = np.random.default_rng(77)
+    enc_conf = dict(input_dim=400, input_affine_dim=140, fsmn_layers=4, linear_dim=250, proj_dim=128, lorder=20, rorder=0,
+                    lstride=1, rstride=0, output_affine_dim=140, output_dim=248)
+    variants = [dict(), dict(do_extend=0), dict(detect_mode=0, max_start_silence_time=1200), dict(decibel_thres=-45.0),
+                dict(snr_thres=5.0), dict(max_single_segment_time=3000), dict(max_end_silence_time=300),
+                dict(max_end_silence_time=1500, lookahead_time_end_point=200, lookback_time_start_point=100),
+                dict(speech_noise_thres=0.3, window_size_ms=100, sil_to_speech_time_thres=60, speech_to_sil_time_thres=60)]
+    cases, all_p, all_db = [], [], []
+    for ci in range(72):
+        opts = variants[ci % len(variants)]
+        kind = ("normal", "blips", "long")[ci % 3]
+        n = int(rng.integers(40, 2500 if kind == "long" else 1200))
+        p_sil, amp = pattern(rng, n, kind)
+        n_samp = (n - 1) * SHIFT + FLEN
+        env = np.concatenate([np.repeat(amp, SHIFT), np.full(FLEN - SHIFT, amp[-1], np.float32)])[:n_samp]
+        wave = rng.standard_normal(n_samp).astype(np.float32) * env.astype(np.float32)
+        mode = ("offline_one", "offline_blocks", "stream_events")[(ci // 3) % 3]
+        if mode == "offline_one":
+            blocks = [n]
+        elif mode == "offline_blocks":
+            blocks, left = [], n
+            while left > 0:
+                b = min(left, int(rng.integers(50, 700)))
+                blocks.append(b)
+                left -= b
+        else:
+            blocks, left = [], n
+            while left > 0:
+                b = min(left, int(rng.integers(1, 40)))
+                blocks.append(b)
+                left -= b
+        model = FsmnVADStreaming(encoder="FSMN", encoder_conf=enc_conf, **opts)
+        feed = {}
+
+        class Injected(torch.nn.Module):                    # stands in for the FSMN: returns the scores of this block
+            def forward(self, feats, cache=None):
+                return feed["scores"]
+        model.encoder = Injected()
+        cache = {}
+        model.init_cache(cache)
+        outs, decibels, f0 = [], [], 0
+        for bi, b in enumerate(blocks):
+            final = bi == len(blocks) - 1
+            span = wave[f0 * SHIFT: (f0 + b - 1) * SHIFT + FLEN]
+            frames = span[np.arange(0, span.shape[0] - FLEN + 1, SHIFT)[:, None] + np.arange(FLEN)]
+            decibels += (10 * np.log10(np.sum(np.square(frames), axis=1) + 0.000001)).tolist()      # as ComputeDecibel does
+            sc = torch.zeros(1, b, 2)
+            sc[0, :, 0] = torch.from_numpy(p_sil[f0: f0 + b])
+            sc[0, :, 1] = 1 - sc[0, :, 0]
+            feed["scores"] = sc
+            seg = model.forward(feats=torch.zeros(1, b, 400), waveform=torch.from_numpy(span)[None], cache=cache,
+                                is_final=final, is_streaming_input=(mode == "stream_events"))
+            outs.append([list(map(int, s)) for s in (seg[0] if len(seg) else [])])
+            f0 += b
+        cases.append(dict(options=opts, kind=kind, mode=mode, blocks=blocks, segments_per_block=outs, n=n))
+        all_p.append(p_sil.astype(np.float32))
+        all_db.append(np.asarray(decibels, dtype=np.float64))
+    out = os.path.join(os.path.dirname(HERE), "tests", "golden", "vad_decision.npz")
+    meta = dict(generator="oracle/make_golden_vad.py",
+                reference="funasr/models/fsmn_vad_streaming/model.py FsmnVADStreaming.forward with injected scores", cases=cases)
+    np.savez_compressed(out, p_sil=np.concatenate(all_p), decibel=np.concatenate(all_db), meta=json.dumps(meta))
+    nseg = sum(len(s) for c in cases for s in c["segments_per_block"])
+    print(f"wrote {out}: {len(cases)} cases, {nseg} reported segments/events, {os.path.getsize(out) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
