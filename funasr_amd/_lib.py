@@ -53,6 +53,11 @@ class pf_decoder_config(C.Structure):
     ]
 
 
+class pf_vad_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("input_dim", "input_affine_dim", "fsmn_layers", "linear_dim", "proj_dim", "lorder",
+                                          "rorder", "lstride", "rstride", "output_affine_dim", "output_dim")]
+
+
 class pf_stream_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_streams", "chunk_left", "chunk_cur", "chunk_right", "enc_look_back",
                                           "dec_look_back", "max_frames", "max_tokens", "use_graph")]
@@ -91,6 +96,12 @@ SIGNATURES = {
     "pf_decoder_missing": (C.c_int, [_vp]),
     "pf_decoder_set_precision": (C.c_int, [_vp, _i32]),
     "pf_decoder_forward": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pf_vad_create": (_vp, [C.POINTER(pf_vad_config)]),
+    "pf_vad_destroy": (None, [_vp]),
+    "pf_vad_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "pf_vad_missing": (C.c_int, [_vp]),
+    "pf_vad_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _pi32, _i32, _vp, _vp, _i32, _vp]),
+    "pf_vad_frame_decibel": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "pf_ctc_create": (_vp, [_i32, _i32]),
     "pf_ctc_destroy": (None, [_vp]),
     "pf_ctc_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),

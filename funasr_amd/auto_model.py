@@ -16,8 +16,8 @@ Model directory format (funasr/download/download_model_from_hub.py:80-97): `conf
 `[{"key", "value": [[beg_ms, end_ms], ...]}]`, e.g. the reference's own FsmnVADStreaming -- cuts each recording into
 segments; the segments are sorted by length, packed into batches under the reference's `batch_size_s` /
 `batch_size_threshold_s` policy, decoded by the HIP path, put back in order and merged (texts joined, per-token
-timestamps shifted by the segment start). Punctuation and speaker models are outside the hot path and raise. The
-FSMN-VAD network itself is not built yet: `vad_model` must be an object, not a hub name.
+timestamps shifted by the segment start). Punctuation and speaker models are outside the hot path and raise. `vad_model` may also be a local FSMN-VAD model directory: the network runs on the GPU (funasr_amd/fsmn_vad.py), its
+decision logic on the host (funasr_amd/vad_decision.py).
 
 When the real package is importable, use `funasr.AutoModel` itself after `funasr_amd.install()`.
 """
@@ -34,7 +34,9 @@ from typing import Any, Dict, List, Tuple
 
 import torch
 
+from . import fsmn_vad as _fsmn_vad  # noqa: F401  (registers FSMN / FsmnVADStreaming)
 from . import paraformer as _paraformer  # noqa: F401  (registers the model classes)
+from . import paraformer_streaming as _paraformer_streaming  # noqa: F401  (WavFrontendOnline)
 from . import sense_voice as _sense_voice  # noqa: F401
 from .register import tables
 
@@ -176,8 +178,11 @@ class AutoModel:
         vad_model = kwargs.pop("vad_model", None)
         self.vad_kwargs = dict(kwargs.pop("vad_kwargs", None) or {})
         if isinstance(vad_model, str):
-            raise NotImplementedError("vad_model by name: the FSMN-VAD network is not built on the HIP path yet; pass a "
-                                      "VAD model OBJECT (FunASR model contract: inference(...) -> [{'key', 'value': segments}])")
+            # a local FSMN-VAD model directory (config.yaml: FsmnVADStreaming / FSMN / WavFrontendOnline, model.pt,
+            # am.mvn) or a registered class name with its configuration in vad_kwargs (:463-476)
+            vk = dict(self.vad_kwargs, model=vad_model)
+            vk.setdefault("device", kwargs.get("device", "cuda"))
+            vad_model, self.vad_kwargs = self.build_model(**vk)
         self.vad_model = vad_model
         log_level = getattr(logging, str(kwargs.get("log_level", "WARNING")).upper(), logging.WARNING)
         logging.getLogger().setLevel(log_level)

@@ -191,4 +191,11 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t stream);
 // fp32 in / fp32 (or plane) out like launch_attention_f32, both products on the bf16 MFMA from three-plane split operands
 int launch_attention_split3(const AttnArgs& a, hipStream_t stream);
 
+// FSMN-VAD row kernels (vad.hip)
+int launch_vad_fsmn(const float* x, int ldx, const float* w, const float* cache_in, float* cache_out, float* y, int ldy,
+                    int B, int T, int C, int L, int S, hipStream_t stream);
+int launch_vad_softmax_sil(const float* x, int ldx, int M, int N, const int* ids, int n_ids, float* p_sil, float* probs,
+                           int ldp, hipStream_t stream);
+int launch_frame_decibel(const float* wav, int n_frames, int flen, int shift, float* out, hipStream_t stream);
+
 }  // namespace pf

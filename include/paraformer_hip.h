@@ -174,6 +174,28 @@ int pf_decoder_forward(pf_decoder* d, const float* memory_dev, const int32_t* me
                        float* logits_dev, int32_t* ids_dev, float* hidden_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- ctc */
+/* ---- FSMN-VAD network (funasr/models/fsmn_vad_streaming/encoder.py:288-378 FSMN.forward), reduced to what the decision
+ * logic reads: the summed posterior of the silence pdfs per frame (model.py:783-795), and the frame energies
+ * (ComputeDecibel, model.py:513-530). Tensor names as in the reference state_dict below `encoder.`:
+ * in_linear1|in_linear2|out_linear1|out_linear2 ".linear.weight|bias", "fsmn.<i>.linear.linear.weight",
+ * "fsmn.<i>.fsmn_block.conv_left.weight" ([proj, 1, lorder, 1]), "fsmn.<i>.affine.linear.weight|bias". */
+typedef struct pf_vad pf_vad;
+typedef struct pf_vad_config {
+    int32_t input_dim, input_affine_dim, fsmn_layers, linear_dim, proj_dim, lorder, rorder, lstride, rstride,
+        output_affine_dim, output_dim;
+} pf_vad_config;
+pf_vad* pf_vad_create(const pf_vad_config* cfg);
+void pf_vad_destroy(pf_vad* v);
+int pf_vad_set_tensor(pf_vad* v, const char* name, const float* data, int64_t numel);
+int pf_vad_missing(const pf_vad* v);
+/* feats_dev [B, T, input_dim]; cache_dev [B, fsmn_layers, (lorder-1)*lstride, proj_dim]: left context of the memory
+ * blocks, read and updated in place (NULL = zero left context); p_sil_dev [B, T]; probs_dev [B, T, output_dim] or NULL;
+ * small_m != 0: weight-streaming GEMMs (chunks of a few frames). No sync. */
+int pf_vad_forward(pf_vad* v, const float* feats_dev, int32_t B, int32_t T, float* cache_dev, const int32_t* sil_ids_host,
+                   int32_t n_sil, float* p_sil_dev, float* probs_dev, int32_t small_m, void* stream);
+int pf_vad_frame_decibel(const float* wav_dev, int32_t n_frames, int32_t frame_len, int32_t frame_shift, float* out_dev,
+                         void* stream);
+
 typedef struct pf_ctc pf_ctc;
 pf_ctc* pf_ctc_create(int32_t d_model, int32_t vocab_size);
 void pf_ctc_destroy(pf_ctc* c);

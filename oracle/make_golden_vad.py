@@ -110,6 +110,33 @@ def main():
     meta = dict(generator="oracle/make_golden_vad.py",
                 reference="funasr/models/fsmn_vad_streaming/model.py FsmnVADStreaming.forward with injected scores", cases=cases)
     np.savez_compressed(out, p_sil=np.concatenate(all_p), decibel=np.concatenate(all_db), meta=json.dumps(meta))
+    # ---- the network: the reference's FSMN class on seeded weights, whole utterance and chunked with its cache dict
+    from funasr.models.fsmn_vad_streaming.encoder import FSMN
+    from oracle import vad_oracle
+    enc_cfg = dict(enc_conf)
+    sd = vad_oracle.synthetic_state_dict(enc_cfg, seed=5)
+    ref = FSMN(**enc_cfg)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    tg = torch.Generator().manual_seed(6)
+    feats = torch.randn(2, 137, 400, generator=tg)
+    with torch.no_grad():
+        whole = ref(feats, cache=None)                                  # zero left context
+        rc, parts = {}, []
+        for a, b in ((0, 1), (1, 9), (9, 60), (60, 137)):
+            parts.append(ref(feats[:1, a:b], cache=rc))
+        chunked = torch.cat(parts, dim=1)
+    mine = vad_oracle.fsmn_forward(feats, sd, enc_cfg)
+    oc, oparts = {}, []
+    for a, b in ((0, 1), (1, 9), (9, 60), (60, 137)):
+        oparts.append(vad_oracle.fsmn_forward(feats[:1, a:b], sd, enc_cfg, cache=oc))
+    err = max((mine - whole).abs().max().item(), (torch.cat(oparts, 1) - chunked).abs().max().item())
+    assert err < 1e-6, f"oracle restatement differs from the reference FSMN by {err}"
+    enc_out = os.path.join(os.path.dirname(HERE), "tests", "golden", "vad_encoder.npz")
+    np.savez_compressed(enc_out, cfg=json.dumps(enc_cfg), seed=5, feats=feats.numpy(), probs_whole=whole.numpy(),
+                        probs_chunked=chunked.numpy(), chunks=np.array([[0, 1], [1, 9], [9, 60], [60, 137]]))
+    print(f"wrote {enc_out}: oracle vs reference FSMN max |d| = {err:.2e}; chunked vs whole (reference) "
+          f"{(chunked - whole[:1]).abs().max().item():.2e}")
     nseg = sum(len(s) for c in cases for s in c["segments_per_block"])
     print(f"wrote {out}: {len(cases)} cases, {nseg} reported segments/events, {os.path.getsize(out) / 1e6:.2f} MB")
 

@@ -68,3 +68,41 @@ def write_wav(path: str, x: torch.Tensor, fs: int = 16000) -> np.ndarray:
         f.setframerate(fs)
         f.writeframes(pcm.tobytes())
     return pcm
+
+
+def write_mvn(path: str, shift: torch.Tensor, scale: torch.Tensor) -> None:
+    """Kaldi-nnet am.mvn (<AddShift> / <Rescale> rows, the format funasr/frontends/wav_frontend.py:15-43 parses)"""
+    d = shift.numel()
+    row = lambda v: " ".join(f"{float(x):.6g}" for x in v.tolist())                  # noqa: E731
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(f"<Nnet> \n<Splice> {d} {d}\n[ 0 ]\n<AddShift> {d} {d} \n<LearnRateCoef> 0 [ {row(shift)} ]\n"
+                f"<Rescale> {d} {d} \n<LearnRateCoef> 0 [ {row(scale)} ]\n</Nnet> \n")
+
+
+VAD_ENCODER_CONF = dict(input_dim=400, input_affine_dim=140, fsmn_layers=4, linear_dim=250, proj_dim=128, lorder=20, rorder=0,
+                        lstride=1, rstride=0, output_affine_dim=140, output_dim=248)
+
+
+def make_vad_model_dir(path: str, encoder_sd: dict) -> None:
+    """FSMN-VAD model directory in the hub layout: config.yaml (FsmnVADStreaming / FSMN / WavFrontendOnline), model.pt with
+    `encoder.`-prefixed keys, am.mvn for the 400-dim LFR(5, 1) features"""
+    os.makedirs(path, exist_ok=True)
+    conf = {
+        "model": "FsmnVADStreaming",
+        "model_conf": {"sample_rate": 16000, "detect_mode": 1, "max_end_silence_time": 800, "max_start_silence_time": 3000,
+                       "window_size_ms": 200, "sil_to_speech_time_thres": 150, "speech_to_sil_time_thres": 150,
+                       "speech_2_noise_ratio": 1.0, "do_extend": 1, "lookback_time_start_point": 200,
+                       "lookahead_time_end_point": 100, "max_single_segment_time": 60000, "snr_thres": -100.0,
+                       "noise_frame_num_used_for_snr": 100, "decibel_thres": -100.0, "speech_noise_thres": 0.6,
+                       "fe_prior_thres": 0.0001, "silence_pdf_num": 1, "sil_pdf_ids": [0], "frame_in_ms": 10,
+                       "frame_length_ms": 25},
+        "encoder": "FSMN",
+        "encoder_conf": dict(VAD_ENCODER_CONF),
+        "frontend": "WavFrontendOnline",
+        "frontend_conf": {"fs": 16000, "window": "hamming", "n_mels": 80, "frame_length": 25, "frame_shift": 10,
+                          "dither": 0.0, "lfr_m": 5, "lfr_n": 1},
+    }
+    with open(os.path.join(path, "config.yaml"), "w", encoding="utf-8") as f:
+        yaml.safe_dump(conf, f)
+    torch.save({"encoder." + k: v for k, v in encoder_sd.items()}, os.path.join(path, "model.pt"))
+    write_mvn(os.path.join(path, "am.mvn"), torch.full((400,), -8.0), torch.full((400,), 0.25))

@@ -56,11 +56,13 @@ def test_build_from_model_dir_on_cpu_and_loud_failure(model_dir):
         am.generate(input=list(model_dir["waves"])[0])
 
 
-def test_unknown_model_and_vad_pipeline_raise(model_dir):
+def test_unknown_model_and_unbuilt_pipelines_raise(model_dir):
     with pytest.raises(FileNotFoundError):
         AutoModel(model="iic/not-a-local-dir", device="cpu")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):                         # hub names need the network: local directories only
         AutoModel(model=model_dir["dir"], vad_model="fsmn-vad", device="cpu")
+    with pytest.raises(NotImplementedError):
+        AutoModel(model=model_dir["dir"], punc_model="ct-punc", device="cpu")
 
 
 @pytest.mark.gpu
@@ -134,6 +136,30 @@ def test_generate_with_vad_segments_on_the_hip_path(model_dir, cuda):
     by_seg = {j: direct[pos] for pos, j in enumerate(order)}
     assert out2[0]["text"] == " ".join(by_seg[j]["text"] for j in range(len(segs)))
     assert out2[0]["timestamp"] == [[x + segs[j][0], y + segs[j][0]] for j in range(len(segs)) for x, y in by_seg[j]["timestamp"]]
+
+
+@pytest.mark.gpu
+def test_vad_model_directory_end_to_end(model_dir, cuda, tmp_path):
+    """AutoModel(model=<Paraformer dir>, vad_model=<FSMN-VAD dir>): the VAD network + decision logic cut a recording
+    with three bursts, the ASR decodes the cuts; the VAD alone (AutoModel(model=<VAD dir>)) reports the same segments."""
+    from tests._model_dir import VAD_ENCODER_CONF, make_vad_model_dir
+    from tests.test_vad_gpu import _energy_tracking_weights
+    vad_dir = str(tmp_path / "vad")
+    make_vad_model_dir(vad_dir, _energy_tracking_weights(VAD_ENCODER_CONF))
+    fs = 16000
+    long = 1e-4 * torch.randn(26 * fs, generator=torch.Generator().manual_seed(8))
+    for i, (a, b) in enumerate([(1.0, 5.5), (8.0, 11.0), (15.0, 24.0)]):
+        seg = synth.speech_like(int((b - a) * fs), seed=70 + i)
+        long[int(a * fs): int(a * fs) + seg.numel()] += seg
+    vad = AutoModel(model=vad_dir, device="cuda:0")
+    segs = vad.generate(input=long)[0]["value"]
+    assert len(segs) == 3 and all(abs(s[0] / 1000 - a) < 0.5 and abs(s[1] / 1000 - b) < 1.2
+                                   for s, (a, b) in zip(segs, [(1.0, 5.5), (8.0, 11.0), (15.0, 24.0)])), segs
+    am = AutoModel(model=model_dir["dir"], device="cuda:0", vad_model=vad_dir)
+    out = am.generate(input=long, batch_size_s=0)                              # one ASR batch per segment
+    single = AutoModel(model=model_dir["dir"], device="cuda:0")
+    texts = [single.generate(input=long[b * 16: min(e * 16, long.numel())])[0]["text"] for b, e in segs]
+    assert len(out) == 1 and out[0]["text"] == " ".join(texts)
 
 
 def test_audio_inputs_resample_and_bytes(tmp_path):

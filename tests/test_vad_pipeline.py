@@ -141,6 +141,6 @@ def test_merge_vad_option_and_missing_vad_model():
     merged = merge_vad([list(s) for s in segs["r"]], 5000)
     assert sorted(x for c in asr.calls for x in c) == sorted((e - b) * 16 for b, e in merged)
     assert out[0]["key"] == "r" and out[0]["text"]
-    with pytest.raises(NotImplementedError, match="FSMN-VAD"):
-        AutoModel(model="Paraformer", vad_model="fsmn-vad")
+    with pytest.raises(FileNotFoundError):
+        AutoModel(model="Paraformer", vad_model="fsmn-vad")             # not a local directory, not a registered class
     assert vad_segment_sentences([{"text": "<|zh|>"}], [[0, 10]]) == []
