@@ -58,6 +58,15 @@ class pf_vad_config(C.Structure):
                                           "rorder", "lstride", "rstride", "output_affine_dim", "output_dim")]
 
 
+class pf_vad_options(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("sample_rate", "detect_mode", "max_end_silence_time", "max_start_silence_time",
+                                          "window_size_ms", "sil_to_speech_time_thres", "speech_to_sil_time_thres", "do_extend",
+                                          "lookback_time_start_point", "lookahead_time_end_point", "max_single_segment_time",
+                                          "noise_frame_num_used_for_snr", "frame_in_ms", "frame_length_ms")] + \
+               [(n, C.c_double) for n in ("speech_2_noise_ratio", "snr_thres", "decibel_thres", "speech_noise_thres",
+                                           "fe_prior_thres")]
+
+
 class pf_stream_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_streams", "chunk_left", "chunk_cur", "chunk_right", "enc_look_back",
                                           "dec_look_back", "max_frames", "max_tokens", "use_graph")]
@@ -102,6 +111,11 @@ SIGNATURES = {
     "pf_vad_missing": (C.c_int, [_vp]),
     "pf_vad_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _pi32, _i32, _vp, _vp, _i32, _vp]),
     "pf_vad_frame_decibel": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "pf_vad_decision_create": (_vp, [C.POINTER(pf_vad_options)]),
+    "pf_vad_decision_destroy": (None, [_vp]),
+    "pf_vad_decision_set_thresholds": (None, [_vp, C.c_double, C.c_double]),
+    "pf_vad_decision_state": (C.c_int, [_vp]),
+    "pf_vad_decision_push": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32]),
     "pf_ctc_create": (_vp, [_i32, _i32]),
     "pf_ctc_destroy": (None, [_vp]),
     "pf_ctc_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),

@@ -7,9 +7,9 @@ Host-side mirrors, registered under the reference's names:
     fp32 GEMM kernels, the memory blocks / softmax / frame energies in csrc/vad.hip. The left-context cache of the memory
     blocks lives in HBM (`cache["fsmn_ctx"]`, [1, layers, (lorder-1)*lstride, proj_dim]).
   * `FsmnVADStreaming` (model_classes; funasr/models/fsmn_vad_streaming/model.py:367-1115): `inference()` with the
-    reference's chunking (`chunk_size` ms per block, default 60 s), its dynamic end-silence schedule for long recordings
-    (:1005-1019) and both reporting conventions; segments come from `vad_decision.VadDecision`, which is pinned to the
-    reference's state machine. Output `[{"key": ..., "value": [[beg_ms, end_ms], ...]}]`, the contract
+    reference's chunking (`chunk_size` ms per block, default 60 s) and its dynamic end-silence schedule for long
+    recordings (:1005-1019); segments come from the decision logic of `vad_decision` (native host code, pinned to the
+    reference's state machine). Output `[{"key": ..., "value": [[beg_ms, end_ms], ...]}]`, the contract
     `AutoModel.inference_with_vad` consumes.
 For a whole recording the network runs ONCE over all frames (fbank / LFR(5,1) / CMVN through the offline frontend kernel,
 then the FSMN): frame t of the score stream is fbank frame t and its energy is that of samples [160 t, 160 t + 400), the
@@ -27,7 +27,7 @@ from . import _lib
 from .audio import load_audio_list
 from .hip_module import Holder, HipModule, ParamHolder, linear, stream_ptr
 from .register import tables
-from .vad_decision import IN_SPEECH, VadDecision, VadOptions
+from .vad_decision import IN_SPEECH, NativeVadDecision, VadOptions
 
 # (speech accumulated in ms, end-silence in ms): funasr/models/fsmn_vad_streaming/model.py:22-41
 STREAMING_SILENCE_SCHEDULE = [(5000, 2000), (10000, 1500), (15000, 1000), (30000, 800), (45000, 400), (float("inf"), 100)]
@@ -148,7 +148,7 @@ class FsmnVADStreaming(torch.nn.Module):
         cache["frontend"] = {}
         cache["encoder"] = {}
         cache["prev_samples"] = torch.empty(0)
-        cache["decision"] = VadDecision(self.vad_opts, speech_noise_thres=kwargs.get("speech_noise_thres"))
+        cache["decision"] = NativeVadDecision(self.vad_opts, speech_noise_thres=kwargs.get("speech_noise_thres"))
         cache["samples_seen"] = 0                 # of the current recording, incl. what is still waiting for a full frame
         cache["frames_done"] = 0
         cache["pending"] = torch.empty(0)         # waveform tail that has not produced a frame yet (streaming input)
@@ -165,11 +165,12 @@ class FsmnVADStreaming(torch.nn.Module):
             feats, flens = frontend(w[None], [int(w.numel())])
         T = int(flens[0]) if feats.numel() else 0
         if T <= 0:
-            return [], []
+            import numpy as np
+            return np.zeros(0, np.float32), np.zeros(0, np.float32)
         p_sil = self.encoder.silence_posterior(feats[:, :T], enc_cache, self.vad_opts.sil_pdf_ids)[0]
         o = self.vad_opts
         db = frame_decibel(w, T, int(o.frame_length_ms * o.sample_rate / 1000), int(o.frame_in_ms * o.sample_rate / 1000))
-        return p_sil.cpu().tolist(), db.cpu().tolist()
+        return p_sil.cpu().numpy(), db.cpu().numpy()
 
     def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, cache: dict = None,
                   **kwargs):
@@ -203,7 +204,7 @@ class FsmnVADStreaming(torch.nn.Module):
         p_sil, db = self._scores(frontend, wav, None)
         meta["extract_feat"] = f"{time.perf_counter() - t2:0.3f}"
         meta["batch_data_time"] = len(p_sil) * frontend.frame_shift * frontend.lfr_n / 1000
-        dec: VadDecision = cache["decision"]
+        dec: NativeVadDecision = cache["decision"]
         dynamic = kwargs.get("dynamic_silence", kwargs.get("max_end_silence_time") is None)
         schedule = kwargs.get("silence_schedule", DEFAULT_SILENCE_SCHEDULE)
         to_sil = self.vad_opts.speech_to_sil_time_thres

@@ -10,7 +10,7 @@ reporting conventions (`forward` :861-905: complete `[beg, end]` pairs offline, 
 streaming). The waveform buffers of the reference only ever influence the decision through their LENGTHS, so this
 version carries sample counts instead of samples.
 
-Pinned to the reference by tests/golden/vad_decision.json (oracle/make_golden_vad.py drives the reference's own class with
+Pinned to the reference by tests/golden/vad_decision.npz (oracle/make_golden_vad.py drives the reference's own class with
 injected network scores, offline and chunked).
 """
 from __future__ import annotations
@@ -312,3 +312,66 @@ class VadDecision:
                 out.append([seg.start_ms, seg.end_ms])
                 self.reported += 1
         return out
+
+
+class NativeVadDecision:
+    """The same logic in native host code (csrc/vad_decision.hip, C ABI `pf_vad_decision_*`): ~100x the frame rate of the
+    Python loop above, which stays as the readable restatement. Same interface, same golden vectors."""
+
+    def __init__(self, opts: Optional[VadOptions] = None, speech_noise_thres: Optional[float] = None, **kwargs):
+        import ctypes as C
+        from . import _lib
+        self.o = opts if opts is not None else VadOptions(**kwargs)
+        o = self.o
+        if len(o.sil_pdf_ids) != o.silence_pdf_num:
+            raise ValueError("VadOptions: len(sil_pdf_ids) must equal silence_pdf_num")
+        self._C, self._lib = C, _lib.load()
+        c = _lib.pf_vad_options(o.sample_rate, o.detect_mode, o.max_end_silence_time, o.max_start_silence_time, o.window_size_ms,
+                                o.sil_to_speech_time_thres, o.speech_to_sil_time_thres, int(o.do_extend),
+                                o.lookback_time_start_point, o.lookahead_time_end_point, o.max_single_segment_time,
+                                o.noise_frame_num_used_for_snr, o.frame_in_ms, o.frame_length_ms, float(o.speech_2_noise_ratio),
+                                float(o.snr_thres), float(o.decibel_thres),
+                                float(o.speech_noise_thres if speech_noise_thres is None else speech_noise_thres),
+                                float(o.fe_prior_thres))
+        self._h = _lib.check_handle(self._lib.pf_vad_decision_create(C.byref(c)), "pf_vad_decision_create")
+        self._max_end_sil_ms = float(o.max_end_silence_time - o.speech_to_sil_time_thres)
+        self._speech_noise_thres = float(c.speech_noise_thres)
+        self._out = (C.c_int32 * 512)()
+
+    def __del__(self):
+        h = self.__dict__.get("_h")
+        if h is not None:
+            try:
+                self._lib.pf_vad_decision_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def state(self) -> int:
+        return int(self._lib.pf_vad_decision_state(self._h))
+
+    def _sync(self):
+        self._lib.pf_vad_decision_set_thresholds(self._h, self._max_end_sil_ms, self._speech_noise_thres)
+
+    max_end_sil_ms = property(lambda self: self._max_end_sil_ms,
+                              lambda self, v: (setattr(self, "_max_end_sil_ms", float(v)), self._sync())[1])
+    speech_noise_thres = property(lambda self: self._speech_noise_thres,
+                                  lambda self, v: (setattr(self, "_speech_noise_thres", float(v)), self._sync())[1])
+
+    def push(self, sil_scores, decibels, is_final: bool = False, streaming_events: bool = False) -> List[List[int]]:
+        import numpy as np
+        from . import _lib
+        p = np.ascontiguousarray(sil_scores, dtype=np.float32)
+        d = np.ascontiguousarray(decibels, dtype=np.float32)
+        if p.shape != d.shape or p.ndim != 1:
+            raise RuntimeError(f"VAD score frames and energies are not aligned: {p.shape} vs {d.shape}")
+        if p.size == 0:
+            return []
+        cap = len(self._out) // 2
+        m = self._lib.pf_vad_decision_push(self._h, p.ctypes.data, d.ctypes.data, int(p.size), int(is_final),
+                                           int(streaming_events), self._out, cap)
+        _lib.check(0 if m >= 0 else m, "pf_vad_decision_push")
+        if m > cap:
+            raise RuntimeError(f"pf_vad_decision_push: {m} segments in one block (capacity {cap})")
+        return [[int(self._out[2 * i]), int(self._out[2 * i + 1])] for i in range(m)]

@@ -196,6 +196,26 @@ int pf_vad_forward(pf_vad* v, const float* feats_dev, int32_t B, int32_t T, floa
 int pf_vad_frame_decibel(const float* wav_dev, int32_t n_frames, int32_t frame_len, int32_t frame_shift, float* out_dev,
                          void* stream);
 
+/* ---- FSMN-VAD decision logic in native host code (no device work): silence posteriors + frame energies -> speech
+ * segments; restates what FsmnVADStreaming.forward does after the network (model.py:552-905,1117-1302). Options = the
+ * post-processing section of the model's config.yaml (VADXOptions, model.py:71-173). */
+typedef struct pf_vad_decision pf_vad_decision;
+typedef struct pf_vad_options {
+    int32_t sample_rate, detect_mode, max_end_silence_time, max_start_silence_time, window_size_ms,
+        sil_to_speech_time_thres, speech_to_sil_time_thres, do_extend, lookback_time_start_point,
+        lookahead_time_end_point, max_single_segment_time, noise_frame_num_used_for_snr, frame_in_ms, frame_length_ms;
+    double speech_2_noise_ratio, snr_thres, decibel_thres, speech_noise_thres, fe_prior_thres;
+} pf_vad_options;
+pf_vad_decision* pf_vad_decision_create(const pf_vad_options* opts);
+void pf_vad_decision_destroy(pf_vad_decision* d);
+/* the per-block dynamic end-silence schedule of FsmnVADStreaming.inference (model.py:1005-1019) */
+void pf_vad_decision_set_thresholds(pf_vad_decision* d, double max_end_sil_ms, double speech_noise_thres);
+int pf_vad_decision_state(const pf_vad_decision* d);   /* 1 start point not detected, 2 in speech, 3 end point detected */
+/* next block of frames (host arrays). Returns the number of reportable segments (written as [beg_ms, end_ms] pairs up to
+ * `capacity`; with streaming_events a started segment is [beg, -1] and closed later by [-1, end]); -1 on error. */
+int pf_vad_decision_push(pf_vad_decision* d, const float* sil_scores, const float* decibels, int32_t n_frames,
+                         int32_t is_final, int32_t streaming_events, int32_t* segments_out, int32_t capacity);
+
 typedef struct pf_ctc pf_ctc;
 pf_ctc* pf_ctc_create(int32_t d_model, int32_t vocab_size);
 void pf_ctc_destroy(pf_ctc* c);
