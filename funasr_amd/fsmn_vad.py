@@ -149,9 +149,8 @@ class FsmnVADStreaming(torch.nn.Module):
         cache["encoder"] = {}
         cache["prev_samples"] = torch.empty(0)
         cache["decision"] = NativeVadDecision(self.vad_opts, speech_noise_thres=kwargs.get("speech_noise_thres"))
-        cache["samples_seen"] = 0                 # of the current recording, incl. what is still waiting for a full frame
         cache["frames_done"] = 0
-        cache["pending"] = torch.empty(0)         # waveform tail that has not produced a frame yet (streaming input)
+        cache["wave"], cache["wave_start"] = None, 0   # waveform history behind the frame energies (streaming input)
         return cache
 
     # ------------------------------------------------------------------------------------------------- one block
@@ -196,9 +195,9 @@ class FsmnVADStreaming(torch.nn.Module):
             return [{"key": k0, "value": []}], meta
         if len(audio) != 1:
             raise AssertionError("batch_size must be set 1")
-        if streaming_input or not is_final:
-            raise NotImplementedError("FsmnVADStreaming(HIP): chunk-by-chunk streaming input is not built yet; pass the "
-                                      "whole recording (is_final=True), the mode AutoModel.inference_with_vad uses")
+        if streaming_input or not is_final or len(cache.get("prev_samples", ())) or cache.get("frames_done", 0):
+            rest = {k: v for k, v in kwargs.items() if k not in ("is_final", "is_streaming_input", "chunk_size")}
+            return self._inference_chunked(audio[0], k0, frontend, cache, chunk_ms, is_final, streaming_input, meta, **rest)
         wav = audio[0]
         t2 = time.perf_counter()
         p_sil, db = self._scores(frontend, wav, None)
@@ -246,6 +245,67 @@ class FsmnVADStreaming(torch.nn.Module):
                 from .datadir_writer import DatadirWriter
                 self.writer = DatadirWriter(kwargs.get("output_dir"))
             self.writer["1best_recog"]["text"][k0] = segments
+        return [{"key": k0, "value": segments}], meta
+
+    def _inference_chunked(self, samples: torch.Tensor, k0: str, frontend, cache: dict, chunk_ms: int, is_final: bool,
+                           streaming_input: bool, meta: dict, **kwargs):
+        """Streaming input (model.py:985-1087): the samples of this call (after what the previous call left over) go
+        through the ONLINE frontend, the network (left context in HBM) and the decision logic `chunk_size` ms at a time;
+        a started segment is reported as [beg, -1] and closed later by [-1, end]."""
+        if not hasattr(frontend, "init_cache"):
+            raise ValueError("streaming VAD input needs the online frontend (frontend: WavFrontendOnline in config.yaml)")
+        dev = next(self.encoder.parameters()).device
+        o = self.vad_opts
+        hop, flen = int(o.frame_in_ms * o.sample_rate / 1000), int(o.frame_length_ms * o.sample_rate / 1000)
+        audio = torch.cat((cache["prev_samples"].to(samples.dtype), samples.cpu())) if len(cache["prev_samples"]) else samples.cpu()
+        stride = int(chunk_ms * frontend.fs / 1000)
+        n = int(len(audio) // stride + int(is_final))
+        m = int(len(audio) % stride * (1 - int(is_final)))
+        dec: NativeVadDecision = cache["decision"]
+        dynamic = kwargs.get("dynamic_silence", kwargs.get("max_end_silence_time") is None)
+        schedule = kwargs.get("silence_schedule", DEFAULT_SILENCE_SCHEDULE)
+        acc_ms, in_speech = cache.get("_dynamic_accumulated_ms", 0), cache.get("_dynamic_in_speech", False)
+        segments: List[List[int]] = []
+        t2 = time.perf_counter()
+        for i in range(n):
+            final_i = is_final and i == n - 1
+            chunk = audio[i * stride: (i + 1) * stride].to(dev)
+            if dynamic:
+                if dec.state == IN_SPEECH or in_speech:
+                    acc_ms += chunk_ms
+                    in_speech = True
+                for limit_ms, silence_ms in schedule:
+                    if acc_ms <= limit_ms:
+                        dec.max_end_sil_ms = max(silence_ms - o.speech_to_sil_time_thres, 0)
+                        dec.speech_noise_thres = 0.5
+                        break
+                cache["_dynamic_accumulated_ms"], cache["_dynamic_in_speech"] = acc_ms, in_speech
+            # waveform history for the frame energies: samples from absolute index `wave_start` on
+            cache["wave"] = chunk if cache.get("wave") is None else torch.cat((cache["wave"], chunk))
+            feats, flens = frontend(chunk[None], [int(chunk.numel())], cache=cache["frontend"], is_final=final_i)
+            meta["batch_data_time"] = float(flens.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000
+            if feats.numel() == 0 or feats.dim() != 3:
+                continue
+            T = feats.shape[1]
+            first = cache["frames_done"]                                       # absolute index of the first new frame
+            lo = first * hop - cache.get("wave_start", 0)
+            db = frame_decibel(cache["wave"][lo:], T, flen, hop)
+            p_sil = self.encoder.silence_posterior(feats, cache["encoder"], o.sil_pdf_ids)[0]
+            got = dec.push(p_sil.cpu().numpy(), db.cpu().numpy(), is_final=final_i, streaming_events=streaming_input)
+            cache["frames_done"] = first + T
+            keep_from = cache["frames_done"] * hop - cache.get("wave_start", 0)   # the next frame starts here
+            keep_from = min(max(keep_from, 0), cache["wave"].numel())
+            cache["wave"] = cache["wave"][keep_from:]
+            cache["wave_start"] = cache.get("wave_start", 0) + keep_from
+            if got:
+                segments.extend(got)
+                if dynamic:
+                    acc_ms, in_speech = 0, False
+                    cache["_dynamic_accumulated_ms"], cache["_dynamic_in_speech"] = 0, False
+        meta["extract_feat"] = f"{time.perf_counter() - t2:0.3f}"
+        cache["prev_samples"] = audio[-m:] if m > 0 else torch.empty(0)
+        if is_final:
+            self.init_cache(cache)
         return [{"key": k0, "value": segments}], meta
 
     def forward(self, *a, **k):  # pragma: no cover

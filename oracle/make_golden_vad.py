@@ -137,6 +137,54 @@ def main():
                         probs_chunked=chunked.numpy(), chunks=np.array([[0, 1], [1, 9], [9, 60], [60, 137]]))
     print(f"wrote {enc_out}: oracle vs reference FSMN max |d| = {err:.2e}; chunked vs whole (reference) "
           f"{(chunked - whole[:1]).abs().max().item():.2e}")
+    # ---- end to end: the reference's FsmnVADStreaming.inference with ITS WavFrontendOnline (only torchaudio's kaldi.fbank is
+    #      the oracle's restatement, pinned to kaldi-native-fbank in tests/test_oracle.py), a hand-wired network whose
+    #      silence posterior follows the frame level, on a seeded 70 s recording: whole recording (60 s blocks, dynamic
+    #      end-silence schedule) and streaming input in 200 ms chunks fed over several calls
+    import tempfile
+    import torchaudio.compliance.kaldi as kaldi
+    from oracle import paraformer_oracle as O
+    from funasr_amd import synth
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from _model_dir import write_mvn
+    from test_vad_gpu import _energy_tracking_weights
+
+    def fbank(waveform, num_mel_bins=80, frame_length=25, frame_shift=10, dither=0.0, energy_floor=0.0,
+              window_type="hamming", sample_frequency=16000, **kw):
+        assert dither == 0.0 and window_type == "hamming" and energy_floor == 0.0
+        return O.kaldi_fbank(waveform[0], num_mel_bins, float(frame_length), float(frame_shift), float(sample_frequency))
+    kaldi.fbank = fbank
+    import funasr.frontends.wav_frontend as wf
+    wf.kaldi.fbank = fbank
+    tmp = tempfile.mkdtemp()
+    write_mvn(os.path.join(tmp, "am.mvn"), torch.full((400,), -8.0), torch.full((400,), 0.25))
+    fe = wf.WavFrontendOnline(cmvn_file=os.path.join(tmp, "am.mvn"), fs=16000, window="hamming", n_mels=80, frame_length=25,
+                              frame_shift=10, dither=0.0, lfr_m=5, lfr_n=1)
+    fs, total = 16000, 70 * 16000
+    wav = 1e-4 * torch.randn(total, generator=torch.Generator().manual_seed(3))
+    bursts = [(1.0, 4.2), (6.0, 6.3), (9.5, 21.0), (30.0, 58.0), (59.2, 61.0), (66.0, 69.8)]
+    for i, (a, b) in enumerate(bursts):
+        seg = synth.speech_like(int((b - a) * fs), seed=50 + i)
+        wav[int(a * fs): int(a * fs) + seg.numel()] += seg
+    vm = FsmnVADStreaming(encoder="FSMN", encoder_conf=enc_conf)
+    vm.encoder.load_state_dict(_energy_tracking_weights(enc_conf), strict=True)
+    vm.eval()
+    with torch.no_grad():
+        offline, _ = vm.inference([wav], key=["rec"], frontend=fe, device="cpu")
+        cache, calls, events, pos = {}, [7000, 16000, 3300, 200000, 50000, 400000, 123456], [], 0
+        ci = 0
+        while pos < total:
+            n = calls[ci % len(calls)]
+            ci += 1
+            chunk = wav[pos: pos + n]
+            pos += n
+            res, _ = vm.inference([chunk], key=["rec"], frontend=fe, device="cpu", cache=cache, chunk_size=200,
+                                  is_final=pos >= total)
+            events.append(dict(samples=int(chunk.numel()), final=bool(pos >= total), value=res[0]["value"]))
+    e2e = dict(bursts=bursts, offline=offline[0]["value"], streaming_calls=events)
+    with open(os.path.join(os.path.dirname(HERE), "tests", "golden", "vad_e2e.json"), "w") as f:
+        json.dump(e2e, f)
+    print(f"e2e: offline {offline[0]['value']}; streaming {sum(len(e['value']) for e in events)} events over {len(events)} calls")
     nseg = sum(len(s) for c in cases for s in c["segments_per_block"])
     print(f"wrote {out}: {len(cases)} cases, {nseg} reported segments/events, {os.path.getsize(out) / 1e6:.2f} MB")
 

@@ -138,7 +138,41 @@ def test_vad_inference_equals_cpu_pipeline(cuda):
             want += segs
             acc, in_sp = 0, False
     assert got == want, (got, want)
+    # ... and those of the REFERENCE's own FsmnVADStreaming.inference (its online frontend, its network class, its state
+    # machine) on the same recording and weights (tests/golden/vad_e2e.json, oracle/make_golden_vad.py)
+    with open(os.path.join(GOLD, "vad_e2e.json")) as f:
+        e2e = json.load(f)
+    assert got == e2e["offline"], (got, e2e["offline"])
     # sanity of the hand-wired network: every long burst is found, the gaps are silence
     for a, b in [(9.5, 21.0), (30.0, 58.0)]:
         assert any(s[0] <= a * 1000 + 400 and s[1] >= min(b, s[1] / 1000) * 1000 - 400 for s in got)
     assert model.encoder.silence_posterior(fe(wav[None].to(cuda), [total])[0][:, 300:310]).mean().item() < 0.5   # inside a burst
+
+
+@pytest.mark.gpu
+def test_vad_streaming_input_equals_reference_events(cuda):
+    """the same recording fed in 13 calls of arbitrary length with chunk_size = 200 ms and streaming reporting: the
+    events of every call ([beg, -1] / [-1, end]) equal the reference's (per-chunk dynamic end-silence schedule, online
+    frontend with its LFR look-ahead and final flush, network left context carried in HBM)"""
+    from funasr_amd.fsmn_vad import FsmnVADStreaming
+    from funasr_amd.paraformer_streaming import WavFrontendOnline
+    _, cfg = _enc_gold()
+    with open(os.path.join(GOLD, "vad_e2e.json")) as f:
+        e2e = json.load(f)
+    model = FsmnVADStreaming(encoder="FSMN", encoder_conf=cfg)
+    model.encoder.load_state_dict(_energy_tracking_weights(cfg), strict=True)
+    model = model.to(cuda)
+    fs, total = 16000, 70 * 16000
+    wav = 1e-4 * torch.randn(total, generator=torch.Generator().manual_seed(3))
+    for i, (a, b) in enumerate(e2e["bursts"]):
+        seg = synth.speech_like(int((b - a) * fs), seed=50 + i)
+        wav[int(a * fs): int(a * fs) + seg.numel()] += seg
+    cmvn = torch.zeros(2, 400); cmvn[0] = -8.0; cmvn[1] = 0.25
+    fe = WavFrontendOnline(cmvn=cmvn, lfr_m=5, lfr_n=1, dither=0.0, device=cuda)
+    cache, pos = {}, 0
+    for ci, call in enumerate(e2e["streaming_calls"]):
+        chunk = wav[pos: pos + call["samples"]]
+        pos += call["samples"]
+        res, _ = model.inference([chunk], key=["rec"], frontend=fe, cache=cache, chunk_size=200, is_final=call["final"])
+        assert res[0]["value"] == call["value"], (ci, res[0]["value"], call["value"])
+    assert pos == total and len(cache["prev_samples"]) == 0 and cache["frames_done"] == 0      # re-initialised after the final call
