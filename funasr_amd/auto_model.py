@@ -125,7 +125,9 @@ def load_model_dir(model_dir: str) -> dict:
         p = os.path.join(model_dir, name)
         return p if os.path.exists(p) else None
 
-    init_param = resolve("init_param", "model.pt")
+    # a `model.arena` beside (or instead of) model.pt is preferred: one mapped blob instead of ~950 pickled tensors
+    init_param = resolve("init_param", "model.arena") if "init_param" not in metas else None
+    init_param = init_param or resolve("init_param", "model.pt")
     if init_param:
         kwargs["init_param"] = init_param
     tokens = resolve("tokenizer_conf.token_list", "tokens.json") if "tokenizer_conf" not in metas else None
@@ -147,7 +149,12 @@ def load_model_dir(model_dir: str) -> dict:
 
 def load_pretrained_model(path: str, model: torch.nn.Module, ignore_init_mismatch: bool = True, **kwargs) -> None:
     """funasr/train_utils/load_pretrained_model.py:14-114 without scope maps: wrapper keys stripped (:45-47), `module.`
-    prefix dropped, shape-mismatched tensors skipped with a log line (:94-97), then a strict load (:104)."""
+    prefix dropped, shape-mismatched tensors skipped with a log line (:94-97), then a strict load (:104). A path ending in
+    `.arena` is a one-file weight arena (funasr_amd/arena_file.py): one mapped blob, one copy, strict names and shapes."""
+    if str(path).endswith(".arena"):
+        from .arena_file import load_arena
+        load_arena(model, path, strict=True)
+        return
     src = torch.load(path, map_location="cpu", weights_only=False)
     for k in ("state_dict", "model_state_dict", "model"):
         if isinstance(src, dict) and k in src and isinstance(src[k], dict):
