@@ -110,7 +110,7 @@ SIGNATURES = {
     "pf_vad_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "pf_vad_missing": (C.c_int, [_vp]),
     "pf_vad_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _pi32, _i32, _vp, _vp, _i32, _vp]),
-    "pf_vad_frame_decibel": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "pf_vad_frame_decibel": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "pf_vad_decision_create": (_vp, [C.POINTER(pf_vad_options)]),
     "pf_vad_decision_destroy": (None, [_vp]),
     "pf_vad_decision_set_thresholds": (None, [_vp, C.c_double, C.c_double]),

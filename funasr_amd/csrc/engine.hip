@@ -1584,8 +1584,11 @@ int pf_vad_forward(pf_vad* vh, const float* feats, int32_t B, int32_t T, float* 
     return launch_vad_softmax_sil(cc, ldo, M, c.output_dim, sil_ids_host, n_sil, p_sil, probs, c.output_dim, s);
 }
 /* 10 log10(sum(x^2) + 1e-6) of n_frames frames of frame_len samples, frame_shift apart (ComputeDecibel, model.py:513-530) */
-int pf_vad_frame_decibel(const float* wav, int32_t n_frames, int32_t frame_len, int32_t frame_shift, float* out, void* stream) {
+int pf_vad_frame_decibel(const float* wav, int64_t n_samples, int32_t n_frames, int32_t frame_len, int32_t frame_shift,
+                         float* out, void* stream) {
     PF_REQUIRE(wav && out, "vad_frame_decibel: null");
+    PF_REQUIRE(n_frames > 0 && (int64_t)(n_frames - 1) * frame_shift + frame_len <= n_samples,
+               "vad_frame_decibel: the frames reach past the end of the waveform");
     return launch_frame_decibel(wav, n_frames, frame_len, frame_shift, out, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -123,7 +123,7 @@ def frame_decibel(wav: torch.Tensor, n_frames: int, frame_len: int = 400, frame_
         raise RuntimeError("VAD score frames and waveform samples are not aligned")
     out = torch.empty(n_frames, device=w.device, dtype=torch.float32)
     with torch.cuda.device(w.device):
-        _lib.check(lib.pf_vad_frame_decibel(w.data_ptr(), n_frames, frame_len, frame_shift, out.data_ptr(), stream_ptr()),
+        _lib.check(lib.pf_vad_frame_decibel(w.data_ptr(), w.numel(), n_frames, frame_len, frame_shift, out.data_ptr(), stream_ptr()),
                    "pf_vad_frame_decibel")
     return out
 

@@ -193,8 +193,8 @@ int pf_vad_missing(const pf_vad* v);
  * small_m != 0: weight-streaming GEMMs (chunks of a few frames). No sync. */
 int pf_vad_forward(pf_vad* v, const float* feats_dev, int32_t B, int32_t T, float* cache_dev, const int32_t* sil_ids_host,
                    int32_t n_sil, float* p_sil_dev, float* probs_dev, int32_t small_m, void* stream);
-int pf_vad_frame_decibel(const float* wav_dev, int32_t n_frames, int32_t frame_len, int32_t frame_shift, float* out_dev,
-                         void* stream);
+int pf_vad_frame_decibel(const float* wav_dev, int64_t n_samples, int32_t n_frames, int32_t frame_len, int32_t frame_shift,
+                         float* out_dev, void* stream);
 
 /* ---- FSMN-VAD decision logic in native host code (no device work): silence posteriors + frame energies -> speech
  * segments; restates what FsmnVADStreaming.forward does after the network (model.py:552-905,1117-1302). Options = the
