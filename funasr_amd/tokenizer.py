@@ -67,8 +67,10 @@ def _merge_abbreviations(words: List[str], spans: Optional[List[List[int]]] = No
             while j + 2 < n and words[j + 1] == " " and _is_letter(words[j + 2]):
                 j += 2
             out.append("".join(w.upper() for w in words[i:j + 1] if w != " "))
-            if spans is not None and idx[j] < len(spans):
-                out_spans.append([spans[idx[i]][0], spans[idx[j]][1]])
+            if spans is not None:
+                begin = spans[idx[i]][0]        # IndexError, like the reference (:130), when tokens without a span
+                if idx[j] < len(spans):         # (neither CJK, alphabetic nor a piece) pushed the words past the spans
+                    out_spans.append([begin, spans[idx[j]][1]])
             i = j + 1
         else:
             out.append(words[i])

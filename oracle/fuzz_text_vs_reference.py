@@ -1,0 +1,72 @@
+"""Fuzz the host-side text path against the REFERENCE functions (build container only; TEST INFRASTRUCTURE):
+sentence_postprocess with/without timestamps (40k calls), merge_vad (3k), ts_prediction_lfr6_standard (3k), incl. the
+error behaviour. Prints mismatch counts; 0/0/0 at the time of the round-1 commit."""
+import sys, random
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from oracle import ref_import
+ref_import.install()
+from funasr.utils.timestamp_tools import ts_prediction_lfr6_standard
+from funasr.utils.postprocess_utils import sentence_postprocess as ref_pp
+from funasr.utils.vad_utils import merge_vad as ref_merge
+from funasr_amd.timestamps import cif_timestamps
+from funasr_amd.tokenizer import sentence_postprocess
+from funasr_amd.vad_utils import merge_vad
+rng = random.Random(1)
+cjk = list("今天天气真不错我们一起去公园散步吧欢迎大家来体验语音识别模型")
+alpha = ["hel@@", "lo", "wor@@", "ld", "the", "quick", "a", "i", "b", "m", "c", "don't", "re@@", "cog@@", "tion", "x", "y", "z", "ok", "U", "S", "A"]
+other = ["3d", "<unk>", "</s>", "<s>", "1", "2", "@", "'", "a1", ",", "。", "mp3", "你好", "ab"]
+bad = 0
+for trial in range(20000):
+    n = rng.randint(0, 14)
+    kind = rng.random()
+    toks = []
+    for _ in range(n):
+        r = rng.random()
+        if kind < 0.25: toks.append(rng.choice(cjk))
+        elif kind < 0.5: toks.append(rng.choice(alpha))
+        else: toks.append(rng.choice(cjk) if r < 0.4 else rng.choice(alpha) if r < 0.8 else rng.choice(other))
+    try: want = ref_pp(list(toks))
+    except Exception as e: want = ("EXC", type(e).__name__)
+    try: got = sentence_postprocess(list(toks))
+    except Exception as e: got = ("EXC", type(e).__name__)
+    if tuple(want) != tuple(got):
+        bad += 1
+        if bad < 6: print("PP", toks, want, got)
+    ts = [[100 * i, 100 * i + rng.randint(10, 99)] for i in range(len(toks))]
+    try: want = ref_pp(list(toks), [list(t) for t in ts])
+    except Exception as e: want = ("EXC", type(e).__name__)
+    try: got = sentence_postprocess(list(toks), [list(t) for t in ts])
+    except Exception as e: got = ("EXC", type(e).__name__)
+    if tuple(want) != tuple(got):
+        bad += 1
+        if bad < 12: print("PPTS", toks, want, got)
+print("postprocess mismatches:", bad)
+bad = 0
+for trial in range(3000):
+    n = rng.randint(0, 10); t = rng.randint(0, 400); segs = []
+    for _ in range(n):
+        d = rng.randint(100, 9000); segs.append([t, t + d]); t += d + rng.randint(0, 3000)
+    mx, mn = rng.choice([3000, 15000, 30000]), rng.choice([0, 500, 2000])
+    if ref_merge([list(s) for s in segs], mx, mn) != merge_vad([list(s) for s in segs], mx, mn): bad += 1
+print("merge_vad mismatches:", bad)
+bad = 0
+nprng = np.random.default_rng(3)
+for trial in range(3000):
+    n = rng.randint(1, 12)
+    T = rng.randint(n + 2, 120)
+    a = torch.from_numpy(nprng.random(T).astype(np.float32)) * 0.4
+    p = torch.from_numpy(nprng.random(T).astype(np.float32)) * 0.9
+    k = rng.choice([n + 1, n + 1, n, n + 2, 0])
+    idx = nprng.choice(T, size=min(k, T), replace=False)
+    p[idx] = 1.0 + torch.from_numpy(nprng.random(len(idx)).astype(np.float32)) * 0.5
+    toks = [rng.choice(cjk + alpha) for _ in range(n)] + (["</s>"] if rng.random() < 0.2 else [])
+    kw = dict(vad_offset=rng.choice([0.0, 500.0]), upsample_rate=rng.choice([1, 3]), sil_in_str=rng.random() < 0.8)
+    try: want = ts_prediction_lfr6_standard(a.clone(), p.clone(), list(toks), **kw)
+    except Exception as e: want = ("EXC", type(e).__name__)
+    try: got = cif_timestamps(a.clone(), p.clone(), list(toks), **kw)
+    except Exception as e: got = ("EXC", type(e).__name__)
+    if want != got:
+        bad += 1
+        if bad < 5: print("TS", toks, kw, want, got)
+print("timestamp mismatches:", bad)
