@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Shape fuzz on the GPU: random batch sizes / frame counts / ragged lengths through the HIP pipeline in both
+fp32-accurate modes against the CPU oracle (token ids, CIF fire positions, encoder error). Not part of the test run."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from funasr_amd import synth                      # noqa: E402
+from funasr_amd.paraformer import Paraformer      # noqa: E402
+from oracle import paraformer_oracle as O         # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+worst, bad = {"fp32": 0.0, "bf16x3": 0.0}, 0
+for ci in range(n_cases):
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=int(torch.randint(1, 4, (1,), generator=g)),
+                     dec_blocks=int(torch.randint(1, 3, (1,), generator=g)), vocab=int(torch.randint(30, 300, (1,), generator=g)))
+    sd = synth.paraformer_state_dict(cfg, seed=500 + ci, cif_bias=float(torch.rand(1, generator=g)) * 0.8 - 0.2)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev)
+    B = int(torch.randint(1, 9, (1,), generator=g))
+    T = int(torch.randint(3, 300, (1,), generator=g))
+    lens = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = T
+    x = torch.randn(B, T, 560, generator=g) * 0.7
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    try:
+        ref = O.paraformer_greedy(x, lens, sd, cfg)
+    except IndexError:
+        continue
+    for mode in ("fp32", "bf16x3"):
+        model.set_precision(mode)
+        res = model.recognize_features(x.to(dev), lens, return_intermediate=True)
+        err = (res["enc"].cpu() - ref["enc"]).abs().max().item()
+        worst[mode] = max(worst[mode], err)
+        same = res["raw_ids"] == ref["raw_ids"] and res["token_num"] == ref["token_num"].tolist() and \
+            torch.equal(torch.floor(res["peaks"].cpu()) >= 1, torch.floor(ref["peaks"]) >= 1)
+        if not same or err > 1e-3:
+            bad += 1
+            print(f"case {ci} mode {mode} B={B} T={T} lens={lens.tolist()} err={err:.2e} same={same}")
+print(f"{n_cases} cases: max encoder |d| {worst}, failures {bad}")
