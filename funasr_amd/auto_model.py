@@ -34,6 +34,7 @@ from typing import Any, Dict, List, Tuple
 
 import torch
 
+from . import ct_transformer as _ct_transformer  # noqa: F401  (registers CTTransformer)
 from . import fsmn_vad as _fsmn_vad  # noqa: F401  (registers FSMN / FsmnVADStreaming)
 from . import paraformer as _paraformer  # noqa: F401  (registers the model classes)
 from . import paraformer_streaming as _paraformer_streaming  # noqa: F401  (WavFrontendOnline)

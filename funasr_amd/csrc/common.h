@@ -191,6 +191,12 @@ int launch_attention_bf16(const AttnArgs& a, hipStream_t stream);
 // fp32 in / fp32 (or plane) out like launch_attention_f32, both products on the bf16 MFMA from three-plane split operands
 int launch_attention_split3(const AttnArgs& a, hipStream_t stream);
 
+// small heads (d_k <= 64) on short sequences: plain fp32 FMAs, one wave per query (attention_small.hip)
+bool attention_small_applicable(const AttnArgs& a, int dk);
+int launch_attention_small(const AttnArgs& a, int dk, hipStream_t stream);
+// out[i] = table[ids[i]] (embedding lookup; ids clamped to [0, rows))
+int launch_gather_rows(const float* table, int ld, int rows, const int* ids, float* out, int n, int D, hipStream_t stream);
+
 // FSMN-VAD row kernels (vad.hip)
 int launch_vad_fsmn(const float* x, int ldx, const float* w, const float* cache_in, float* cache_out, float* y, int ldy,
                     int B, int T, int C, int L, int S, hipStream_t stream);

@@ -221,8 +221,9 @@ static int fsmn(const FsmnArgs& a, hipStream_t s) {
     ProfScope ps(PROF_FSMN, (a.R ? 12.0 : 8.0) * a.B * (double)a.T * a.C, s);
     return launch_fsmn(a, s);
 }
-static int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3 = false) {
+static int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3 = false, int dk = 128) {
     ProfScope ps(PROF_ATTN, flops, s);
+    if (dk != 128) return launch_attention_small(a, dk, s);      // CT-Transformer sized heads
     static const bool no_x3 = getenv("PF_ATTN_F32") != nullptr;     // A/B switch for measurements
     return (x3 && !no_x3) ? launch_attention_split3(a, s) : launch_attention_f32(a, s);
 }
@@ -395,6 +396,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
     float* ffn = e->ffn.as<float>();
     const int* lens = cc ? cc->lens : e->lens.as<int>();
     int rc;
+    if (e->precision != 0 && D / c.n_heads != 128) { set_error("encoder: the bf16 / bf16x3 modes need d_model / n_heads == 128"); return -1; }
     if (e->precision == 1 && !cc) {
         // ---- bf16-operand mode: LN writes bf16, GEMMs and attention take bf16 operands with fp32 accumulation, the
         //      residual stream x, the FSMN memory and every epilogue stay fp32
@@ -506,7 +508,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         aa.K2 = qkv + D; aa.ldk2 = 3 * D; aa.V2 = qkv + 2 * D; aa.ldv2 = 3 * D; aa.T2 = T; aa.n2 = T;
         aa.n1_dev = &cc->st->enc_valid; aa.n1_stride = 0;
     }
-    if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s))) return rc;
+    if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s, false, D / c.n_heads))) return rc;
     if (cc && cc->cap > 0 && cc->append_rows > 0) {
         RingAppendArgs ra{};
         ra.src = qkv + D; ra.ldsrc = 3 * D; ra.src_T = T; ra.r0 = 0; ra.rows = cc->append_rows; ra.cols = 2 * D;
@@ -1057,10 +1059,12 @@ pf_encoder* pf_encoder_create(const pf_encoder_config* cfg) {
     if (!cfg) { set_error("encoder: null config"); return nullptr; }
     if (check_device()) return nullptr;
     const pf_encoder_config& c = *cfg;
-    if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model / c.n_heads != 128 || c.d_model % c.n_heads ||
+    const int dk = (c.n_heads > 0 && c.d_model > 0) ? c.d_model / c.n_heads : 0;
+    if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads || !(dk == 128 || (dk <= 64 && dk % 4 == 0)) ||
         c.input_dim % 4 || c.ffn_dim % 32 || c.d_model % 32 || c.n_blocks < 1 || c.tp_blocks < 0 ||
         c.kernel_size != 11) {
-        set_error("encoder: unsupported config (need d_model/n_heads == 128, kernel_size == 11, dims % 32 == 0)");
+        set_error("encoder: unsupported config (need d_model/n_heads == 128, or <= 64 for the small-head kernel; "
+                  "kernel_size == 11, dims % 32 == 0)");
         return nullptr;
     }
     std::unique_ptr<Encoder> e(new Encoder());
@@ -1922,6 +1926,21 @@ int pf_k_attention_split3(const float* Q, int32_t ldq, const float* K, int32_t l
     aa.Q = Q; aa.ldq = ldq; aa.K = K; aa.ldk = ldk; aa.V = V; aa.ldv = ldv; aa.O = O; aa.ldo = ldo; aa.klens = klens_dev;
     aa.B = B; aa.H = H; aa.Tq = Tq; aa.Tk = Tk; aa.scale = scale;
     return launch_attention_split3(aa, reinterpret_cast<hipStream_t>(stream));
+}
+/* small heads (d_k <= 64): Q/K/V rows hold H heads of d_k columns (attention_small.hip) */
+int pf_k_attention_small(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv, float* O,
+                         int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t d_k, int32_t Tq, int32_t Tk,
+                         float scale, void* stream) {
+    AttnArgs aa{};
+    aa.Q = Q; aa.ldq = ldq; aa.K = K; aa.ldk = ldk; aa.V = V; aa.ldv = ldv; aa.O = O; aa.ldo = ldo; aa.klens = klens_dev;
+    aa.B = B; aa.H = H; aa.Tq = Tq; aa.Tk = Tk; aa.scale = scale;
+    return launch_attention_small(aa, d_k, reinterpret_cast<hipStream_t>(stream));
+}
+/* out[i, :] = table[ids[i], :] (embedding lookup), ids int32 on the device, clamped to [0, rows) */
+int pf_k_gather_rows(const float* table, int32_t ld, int32_t rows, const int32_t* ids_dev, float* out, int32_t n, int32_t D,
+                     void* stream) {
+    PF_REQUIRE(table && ids_dev && out, "gather_rows: null");
+    return launch_gather_rows(table, ld, rows, ids_dev, out, n, D, reinterpret_cast<hipStream_t>(stream));
 }
 int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                         int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,

@@ -115,6 +115,30 @@ def attention_split3(q, k, v, klens, n_heads: int, scale: float, time_iters: int
     return out, a.elapsed_time(b) / time_iters
 
 
+def attention_small(q, k, v, klens, n_heads: int, scale: float):
+    """q [B, Tq, H*dk], k/v [B, Tk, H*dk] with dk <= 64 (row-strided views allowed) -> [B, Tq, H*dk]; fp32 FMAs."""
+    lib = _lib.load()
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and D % n_heads == 0
+    out = torch.empty(B, Tq, D, device=q.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_attention_small(_ptr(q), q.stride(1), _ptr(k), k.stride(1), _ptr(v), v.stride(1), _ptr(out), D,
+                                        _ptr(klens), B, n_heads, D // n_heads, Tq, Tk, float(scale), _stream()),
+               "pf_k_attention_small")
+    return out
+
+
+def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """table [rows, D] fp32, ids int32 [n] (device) -> [n, D]: the embedding lookup of the punctuation model."""
+    lib = _lib.load()
+    t = _f32c(table, "table").contiguous()
+    i = ids.to(device=t.device, dtype=torch.int32).contiguous()
+    out = torch.empty(i.numel(), t.shape[1], device=t.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_gather_rows(_ptr(t), t.stride(0), t.shape[0], _ptr(i), _ptr(out), i.numel(), t.shape[1], _stream()),
+               "pf_k_gather_rows")
+    return out
+
+
 def cif(alphas: torch.Tensor, hidden: torch.Tensor, n_max: int):
     """alphas [B, T], hidden [B, T, D] -> (peaks [B, T], n_fires int32 [B], embeds [B, n_max, D])."""
     lib = _lib.load()

@@ -170,6 +170,14 @@ class CharTokenizer:
     def tokens2text(self, tokens: Iterable[str]) -> str:
         return "".join(t if t != self.space_symbol else " " for t in tokens)
 
+    def text2tokens(self, line) -> List[str]:
+        """char_tokenizer.py:72-94 without seg_dict / non-linguistic symbols: a string is cut into characters (blanks
+        dropped); a LIST of words (what the punctuation model passes) stays a list of words"""
+        return [t for t in line if t != " "]
+
+    def encode(self, text, **kwargs) -> List[int]:
+        return self.tokens2ids(self.text2tokens(text))
+
     def decode(self, ids) -> str:
         return self.tokens2text(self.ids2tokens(ids))
 

@@ -302,6 +302,13 @@ int pf_k_fsmn(const float* in, int32_t ldin, const float* w, const float* R, int
 int pf_k_attention_f32(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
                        float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq,
                        int32_t Tk, float scale, void* stream);
+/* small heads (d_k <= 64, multiple of 4; the CT-Transformer's 8 x 32), Tk <= 1024: rows hold H heads of d_k columns */
+int pf_k_attention_small(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
+                         float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t d_k,
+                         int32_t Tq, int32_t Tk, float scale, void* stream);
+/* embedding lookup: out[i, :] = table[ids_dev[i], :] (ids clamped to [0, rows)); D % 4 == 0 */
+int pf_k_gather_rows(const float* table, int32_t ld, int32_t rows, const int32_t* ids_dev, float* out, int32_t n,
+                     int32_t D, void* stream);
 /* same contract, both products on the bf16 MFMA from three-plane split operands (fp32-class results; mode bf16x3) */
 int pf_k_attention_split3(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
                           float* O, int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq,
