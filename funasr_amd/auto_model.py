@@ -16,7 +16,8 @@ Model directory format (funasr/download/download_model_from_hub.py:80-97): `conf
 `[{"key", "value": [[beg_ms, end_ms], ...]}]`, e.g. the reference's own FsmnVADStreaming -- cuts each recording into
 segments; the segments are sorted by length, packed into batches under the reference's `batch_size_s` /
 `batch_size_threshold_s` policy, decoded by the HIP path, put back in order and merged (texts joined, per-token
-timestamps shifted by the segment start). Punctuation and speaker models are outside the hot path and raise. `vad_model` may also be a local FSMN-VAD model directory: the network runs on the GPU (funasr_amd/fsmn_vad.py), its
+timestamps shifted by the segment start); with a `punc_model` (CT-Transformer directory or object) the joined text is
+punctuated once per recording and `sentence_timestamp` cuts it into sentence records. The speaker branch raises. `vad_model` may also be a local FSMN-VAD model directory: the network runs on the GPU (funasr_amd/fsmn_vad.py), its
 decision logic on the host (funasr_amd/vad_decision.py).
 
 When the real package is importable, use `funasr.AutoModel` itself after `funasr_amd.install()`.
@@ -84,9 +85,6 @@ def prepare_data_iterator(data_in, input_len=None, data_type=None, key=None) -> 
         else:
             k = key if key is not None else os.path.splitext(os.path.basename(data_in))[0]
             data_list, key_list = [data_in], [k]
-    elif isinstance(data_in, str):
-        raise FileNotFoundError(f"Audio file not found: {data_in!r}. Pass a valid local file path, numpy array, "
-                                f"torch.Tensor, or bytes.")
     elif isinstance(data_in, (list, tuple)):
         data_list = list(data_in)
         for d in data_in:
@@ -94,7 +92,7 @@ def prepare_data_iterator(data_in, input_len=None, data_type=None, key=None) -> 
                 key_list.append(os.path.splitext(os.path.basename(d))[0])
             else:
                 key_list.append(key if isinstance(key, str) else _rand_key())
-    else:
+    else:       # raw text (punctuation models), samples, features; a missing wav path is reported by audio.load_audio
         data_list = [data_in]
         key_list = [key if key is not None else _rand_key()]
     return key_list, data_list
@@ -180,9 +178,15 @@ def load_pretrained_model(path: str, model: torch.nn.Module, ignore_init_mismatc
 
 class AutoModel:
     def __init__(self, **kwargs):
-        for k in ("punc_model", "spk_model"):
-            if kwargs.get(k) is not None:
-                raise NotImplementedError(f"{k}: punctuation / speaker pipelines are outside the HIP hot path")
+        if kwargs.get("spk_model") is not None:
+            raise NotImplementedError("spk_model: the speaker pipeline is outside the HIP hot path")
+        punc_model = kwargs.pop("punc_model", None)
+        self.punc_kwargs = dict(kwargs.pop("punc_kwargs", None) or {})
+        if isinstance(punc_model, str):                                  # CT-Transformer model directory (:478-490)
+            pk = dict(self.punc_kwargs, model=punc_model)
+            pk.setdefault("device", kwargs.get("device", "cuda"))
+            punc_model, self.punc_kwargs = self.build_model(**pk)
+        self.punc_model = punc_model
         vad_model = kwargs.pop("vad_model", None)
         self.vad_kwargs = dict(kwargs.pop("vad_kwargs", None) or {})
         if isinstance(vad_model, str):
@@ -272,7 +276,7 @@ class AutoModel:
 
     # ------------------------------------------------------------------------------------------------- generate
     def generate(self, input, input_len=None, progress_callback=None, **cfg):
-        if self.vad_model is None:                                          # :689-712
+        if getattr(self, "vad_model", None) is None:                        # :689-712
             return self.inference(input, input_len=input_len, progress_callback=progress_callback, **cfg)
         return self.inference_with_vad(input, input_len=input_len, **cfg)
 
@@ -406,9 +410,41 @@ class AutoModel:
                         merged[k] = v if k not in merged else merged[k] + v
             if not len(merged.get("text", "").strip()):
                 continue
-            if kwargs.get("sentence_timestamp", False):
+            # punctuation (:1057-1075): the recording's text, joined without blanks between CJK chunks, goes through the
+            # punc model once; its text replaces the joined ASR text, its punc_array drives the sentence records
+            punc_res, punc_array, punc_text = None, None, None
+            punc_model = getattr(self, "punc_model", None)
+            if punc_model is not None and "timestamps" not in merged:
+                from .vad_utils import join_vad_texts
+                pk = dict(copy.deepcopy({k: v for k, v in self.punc_kwargs.items() if k not in ("tokenizer", "frontend")}),
+                          **{k: self.punc_kwargs[k] for k in ("tokenizer", "frontend") if k in self.punc_kwargs})
+                pk.setdefault("device", self.kwargs.get("device", "cuda"))
+                raw_text = copy.copy(merged["text"])
+                punc_text = join_vad_texts(item.get("text", "") for item in restored)
+                punc_res = self.inference(punc_text, model=punc_model, kwargs=pk, **cfg)
+                if kwargs.get("return_raw_text", False):
+                    merged["raw_text"] = raw_text
+                punc_array = punc_res[0].get("punc_array")
+                merged["text"] = punc_res[0]["text"]
+            stamps = merged.get("timestamp", [])
+            misaligned = False
+            if punc_res is not None and punc_array is not None and len(punc_array) != len(stamps):
+                punc_array, misaligned = None, True
+            if kwargs.get("sentence_timestamp", False):                                   # :1198-1234
+                from .timestamps import timestamp_sentence
                 from .vad_utils import vad_segment_sentences
-                merged["sentence_info"] = vad_segment_sentences(restored, segments)
+                if punc_model is None and not stamps:
+                    merged["sentence_info"] = vad_segment_sentences(restored, segments)
+                elif punc_res is None:
+                    logging.warning("punc_model is required for sentence_timestamp, skipping sentence segmentation.")
+                    merged["sentence_info"] = []
+                elif misaligned:
+                    logging.warning("punctuation timestamps could not be aligned, falling back to VAD segments.")
+                    merged["sentence_info"] = vad_segment_sentences(restored, segments)
+                else:
+                    merged["sentence_info"] = timestamp_sentence(punc_array, stamps, punc_text,
+                                                                 return_raw_text=kwargs.get("return_raw_text", False),
+                                                                 english=kwargs.get("en_post_proc", False))
             merged["key"] = key
             out.append(merged)
         return out

@@ -82,3 +82,61 @@ def cif_timestamps(us_alphas: torch.Tensor, us_peaks: torch.Tensor, char_list: S
 
 
 ts_prediction_lfr6_standard = cif_timestamps       # the reference's name, for code that imports it
+
+
+def _ascii_letter(ch: str) -> bool:
+    return "a" <= ch <= "z" or "A" <= ch <= "Z"
+
+
+def timestamp_sentence(punc_id_list, timestamp_postprocessed, text_postprocessed, return_raw_text: bool = False,
+                       english: bool = False) -> List[dict]:
+    """Cut a punctuated recording into sentence records {text, start, end, timestamp[, raw_text]} at every punctuation
+    mark (ids > 1 of the CT-Transformer's punc_array). Restates `timestamp_sentence` / `timestamp_sentence_en`
+    (funasr/utils/timestamp_tools.py:125-222 / :223-316): words are glued without blanks except around ASCII words, marks
+    are `，。？、` (`,.?,` for English); the English variant strips the leading blank and restarts the sentence clock on
+    the first word after a mark, the Chinese one on the first word that has a timestamp."""
+    from itertools import zip_longest
+    marks = [",", ".", "?", ","] if english else ["，", "。", "？", "、"]
+    res: List[dict] = []
+    if text_postprocessed is None or timestamp_postprocessed is None:
+        return res
+    if len(timestamp_postprocessed) == 0 or len(text_postprocessed) == 0:
+        return res
+    if punc_id_list is None or len(punc_id_list) == 0:
+        return [{"text": text_postprocessed.split(), "start": timestamp_postprocessed[0][0],
+                 "end": timestamp_postprocessed[-1][1], "timestamp": timestamp_postprocessed}]
+    sent, raw, stamps = "", "", []
+    start, end = timestamp_postprocessed[0][0], timestamp_postprocessed[0][1]
+    fresh = True
+    for punc_id, stamp, word in zip_longest(punc_id_list, timestamp_postprocessed, text_postprocessed.split(), fillvalue=None):
+        if not english and start is None and stamp is not None:
+            start = stamp[0]
+        if word is not None:
+            if _ascii_letter(word[0]) or (len(sent) and _ascii_letter(sent[-1])):
+                sent += " " + word
+            else:
+                sent += word
+            raw += word + " "
+        stamps.append(stamp)
+        punc_id = int(punc_id) if punc_id is not None else 1
+        end = stamp[1] if stamp is not None else end
+        if english:
+            sent = sent[1:] if sent[0] == " " else sent
+            if fresh:
+                start = stamp[0] if stamp is not None else start
+                fresh = False
+        else:
+            raw = raw[:-1] if raw and raw[-1] == " " else raw
+        if punc_id > 1:
+            sent += marks[punc_id - 2]
+            if english:
+                fresh = True
+                raw = raw[:-1] if raw[-1] == " " else raw
+            rec = {"text": sent, "start": start, "end": end, "timestamp": stamps}
+            if return_raw_text:
+                rec["raw_text"] = raw
+            res.append(rec)
+            sent, raw, stamps = "", "", []
+            if not english:
+                start = None
+    return res

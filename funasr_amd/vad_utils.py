@@ -46,3 +46,17 @@ def vad_segment_sentences(decoded: List[dict], segments: List[List[int]]) -> Lis
         sentences.append({"start": stamps[0][0] if stamps else seg[0], "end": stamps[-1][1] if stamps else seg[1],
                           "text": text, "sentence": text, "timestamp": stamps})
     return sentences
+
+
+def join_vad_texts(texts) -> str:
+    """`_join_vad_texts` (funasr/auto/auto_model.py:56-68): rich tags removed, chunks joined by a blank unless both sides
+    of the seam are CJK characters."""
+    cleaned = [re.sub(r"<\|[^|]*\|>", "", t).strip() for t in texts]
+    cleaned = [t for t in cleaned if t]
+    if not cleaned:
+        return ""
+    joined = cleaned[0]
+    for t in cleaned[1:]:
+        cjk_seam = "㐀" <= joined[-1] <= "鿿" and "㐀" <= t[0] <= "鿿"
+        joined += ("" if cjk_seam else " ") + t
+    return joined

@@ -1,7 +1,7 @@
 """Fuzz the host-side text path against the REFERENCE functions (build container only; TEST INFRASTRUCTURE):
 sentence_postprocess with/without timestamps (40k calls), merge_vad (3k), ts_prediction_lfr6_standard (3k), incl. the
 error behaviour. Prints mismatch counts; 0/0/0 at the time of the round-1 commit."""
-import sys, random
+import sys, random, copy
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from oracle import ref_import
@@ -70,3 +70,55 @@ for trial in range(3000):
         bad += 1
         if bad < 5: print("TS", toks, kw, want, got)
 print("timestamp mismatches:", bad)
+from funasr.utils.timestamp_tools import timestamp_sentence as ref_ts, timestamp_sentence_en as ref_ts_en
+from funasr_amd.timestamps import timestamp_sentence
+bad = 0
+for trial in range(6000):
+    n = rng.randint(0, 16)
+    words = [rng.choice(cjk + ["hello", "world", "a", "GPU", "ok"]) for _ in range(n)]
+    nts = max(0, n + rng.choice([0, 0, 0, -1, 1]))
+    ts = [[100 * i, 100 * i + rng.randint(10, 99)] for i in range(nts)]
+    npc = max(0, n + rng.choice([0, 0, 0, -1, 1, -n]))
+    pids = [rng.choice([1, 1, 1, 2, 3, 4, 5]) for _ in range(npc)]
+    pid_arg = rng.choice([pids, torch.tensor(pids) if pids else pids, None if not pids else pids])
+    text = " ".join(words) if rng.random() < 0.95 else None
+    raw = rng.random() < 0.5
+    for en, ref_fn in ((False, ref_ts), (True, ref_ts_en)):
+        try: want = ref_fn(copy.deepcopy(pid_arg), copy.deepcopy(ts), text, return_raw_text=raw)
+        except Exception as e: want = ("EXC", type(e).__name__)
+        try: got = timestamp_sentence(copy.deepcopy(pid_arg), copy.deepcopy(ts), text, return_raw_text=raw, english=en)
+        except Exception as e: got = ("EXC", type(e).__name__)
+        if want != got:
+            bad += 1
+            if bad < 6: print("TSENT", en, words, ts, pids, raw, want, got)
+print("timestamp_sentence mismatches:", bad)
+
+# _join_vad_texts / _vad_segment_sentences live in funasr/auto/auto_model.py, whose import pulls the whole package: lift
+# the two function definitions out of the reference source with ast and run them as they stand
+import ast, re
+_src = open("/root/reference/funasr/auto/auto_model.py", encoding="utf-8").read()
+_ns = {"re": re}
+for node in ast.parse(_src).body:
+    if isinstance(node, ast.FunctionDef) and node.name in ("_join_vad_texts", "_vad_segment_sentences"):
+        exec(compile(ast.Module([node], []), "auto_model.py", "exec"), _ns)
+from funasr_amd.vad_utils import join_vad_texts, vad_segment_sentences
+bad = 0
+pieces = ["今天", "天气 ", " hello", "world", "<|zh|>", "<|NEUTRAL|><|Speech|>", "ok。", "", "  ", "3d", "、好", "㐀", "鿿x", "<|en|>the cat"]
+for trial in range(5000):
+    n = rng.randint(0, 6)
+    texts = ["".join(rng.choice(pieces) for _ in range(rng.randint(0, 3))) for _ in range(n)]
+    if _ns["_join_vad_texts"](list(texts)) != join_vad_texts(list(texts)):
+        bad += 1
+        if bad < 6: print("JOIN", texts)
+    segs, t = [], 0
+    for _ in range(n):
+        t += rng.randint(10, 900); b = t; t += rng.randint(50, 5000); segs.append([b, t])
+    rd = [{"text": x} for x in texts]
+    try: want = _ns["_vad_segment_sentences"](copy.deepcopy(rd), copy.deepcopy(segs))
+    except Exception as e: want = ("EXC", type(e).__name__)
+    try: got = vad_segment_sentences(copy.deepcopy(rd), copy.deepcopy(segs))
+    except Exception as e: got = ("EXC", type(e).__name__)
+    if want != got:
+        bad += 1
+        if bad < 6: print("SEGS", texts, want, got)
+print("join_vad_texts / vad_segment_sentences mismatches:", bad)

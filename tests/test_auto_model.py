@@ -37,8 +37,13 @@ def test_prepare_data_iterator_forms(model_dir):
     assert k == ["key_0", "key_1", "key_2"] and data == paths
     k, data = prepare_data_iterator([paths[1], np.zeros(16000, dtype=np.float32)])
     assert k[0] == "utt1" and k[1].startswith("rand_key_") and len(data) == 2
+    # a string that is not a path is raw text for a punctuation model (auto_model.py:403-409); a missing wav path is
+    # reported when the audio is loaded
+    k, data = prepare_data_iterator("/nonexistent/a.wav")
+    assert data == ["/nonexistent/a.wav"] and k[0].startswith("rand_key_")
+    from funasr_amd.audio import load_audio
     with pytest.raises(FileNotFoundError):
-        prepare_data_iterator("/nonexistent/a.wav")
+        load_audio("/nonexistent/a.wav")
 
 
 def test_build_from_model_dir_on_cpu_and_loud_failure(model_dir):
@@ -61,8 +66,10 @@ def test_unknown_model_and_unbuilt_pipelines_raise(model_dir):
         AutoModel(model="iic/not-a-local-dir", device="cpu")
     with pytest.raises(FileNotFoundError):                         # hub names need the network: local directories only
         AutoModel(model=model_dir["dir"], vad_model="fsmn-vad", device="cpu")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):
         AutoModel(model=model_dir["dir"], punc_model="ct-punc", device="cpu")
+    with pytest.raises(NotImplementedError):
+        AutoModel(model=model_dir["dir"], spk_model="cam++", device="cpu")
 
 
 @pytest.mark.gpu

@@ -95,6 +95,7 @@ class _FakeASR:
 def _auto(vad, asr, **kw):
     m = AutoModel.__new__(AutoModel)
     m.model, m.vad_model, m.vad_kwargs = asr, vad, {}
+    m.punc_model, m.punc_kwargs = None, {}
     m.kwargs = dict(device="cuda", batch_size=1, **kw)
     m._base_kwargs = dict(m.kwargs)
     return m
@@ -125,10 +126,46 @@ def test_inference_with_vad_sorts_batches_restores_and_merges():
     ts = out[0]["timestamp"]
     assert ts[0] == [1000, 1100] and ts[-1][1] <= 33000 and all(ts[i][0] <= ts[i + 1][0] for i in range(len(ts) - 1))
     assert len(ts) == len(expect)
-    # sentence records: one per non-empty segment, spanning its own tokens
-    info = out[0]["sentence_info"]
-    assert [s["start"] for s in info] == [1000, 5000, 7000, 21000, 30000]
-    assert info[2]["end"] == 20000 and info[2]["timestamp"][0] == [7000, 7100]
+    # token timestamps but no punctuation model: the reference has nothing to cut sentences with (auto_model.py:1204-1208)
+    assert out[0]["sentence_info"] == []
+
+
+class _FakePunc:
+    """marks a comma after every 3rd word and a period after every 7th; one punc id per word, like CTTransformer"""
+    def parameters(self):
+        return iter(())
+
+    def inference(self, data_in, key=None, **kwargs):
+        words = data_in[0].split()
+        ids = [3 if (i + 1) % 7 == 0 else 2 if (i + 1) % 3 == 0 else 1 for i in range(len(words))]
+        ids[-1] = 3
+        text = "".join(w + {1: " ", 2: ", ", 3: ". "}[p] for w, p in zip(words, ids)).strip()
+        return [{"key": key[0], "text": text, "punc_array": torch.tensor(ids)}], {}
+
+
+def test_punctuation_branch_and_sentence_records():
+    from funasr_amd.timestamps import timestamp_sentence
+    wav = torch.arange(40 * 16000, dtype=torch.float32)
+    segs = [[1000, 2000], [5000, 6500], [20000, 20400]]
+    asr = _FakeASR()
+    am = _auto(_FakeVAD([segs]), asr, batch_size_s=300)
+    am.punc_model, am.punc_kwargs = _FakePunc(), {}
+    out = am.generate(wav, sentence_timestamp=True, return_raw_text=True, en_post_proc=True)[0]
+    words = [f"t{b}" for b, e in segs for _ in range(max((e - b) // 100, 1))]
+    assert out["raw_text"] == " ".join(words)
+    assert out["text"].endswith(".") and out["text"].count(",") + out["text"].count(".") == sum(1 for i in range(len(words)) if (i + 1) % 3 == 0 or (i + 1) % 7 == 0 or i == len(words) - 1)
+    ids = [3 if (i + 1) % 7 == 0 else 2 if (i + 1) % 3 == 0 else 1 for i in range(len(words))]
+    ids[-1] = 3
+    assert out["sentence_info"] == timestamp_sentence(ids, out["timestamp"], " ".join(words), return_raw_text=True, english=True)
+    assert out["sentence_info"][0]["start"] == 1000 and out["sentence_info"][-1]["end"] == out["timestamp"][-1][1]
+    # an ASR model without timestamps: sentence records fall back to the VAD segments when there is no punc model either
+    class NoStampASR(_FakeASR):
+        def inference(self, data_in, key=None, **kwargs):
+            res, meta = super().inference(data_in, key=key, **kwargs)
+            return [{k: v for k, v in r.items() if k != "timestamp"} for r in res], meta
+    am2 = _auto(_FakeVAD([segs]), NoStampASR(), batch_size_s=300)
+    info = am2.generate(wav, sentence_timestamp=True)[0]["sentence_info"]
+    assert [(s["start"], s["end"]) for s in info] == [tuple(s) for s in segs]
 
 
 def test_merge_vad_option_and_missing_vad_model():
