@@ -167,6 +167,27 @@ def test_vad_model_directory_end_to_end(model_dir, cuda, tmp_path):
     single = AutoModel(model=model_dir["dir"], device="cuda:0")
     texts = [single.generate(input=long[b * 16: min(e * 16, long.numel())])[0]["text"] for b, e in segs]
     assert len(out) == 1 and out[0]["text"] == " ".join(texts)
+    # the whole long-form chain from three model directories: VAD -> ASR (with token timestamps) -> CT-Transformer.
+    # The text is what the punctuation model makes of the joined segment texts, the sentence records are cut at its marks
+    from funasr_amd.timestamps import timestamp_sentence
+    from funasr_amd.vad_utils import join_vad_texts
+    from tests.test_punctuation import _punc_dir
+    punc_dir, _ = _punc_dir(tmp_path)
+    full = AutoModel(model=model_dir["dir"], device="cuda:0", vad_model=vad_dir, punc_model=punc_dir)
+    res = full.generate(input=long, batch_size_s=0, pred_timestamp=True, sentence_timestamp=True, return_raw_text=True)[0]
+    stamped = [single.generate(input=long[b * 16: min(e * 16, long.numel())], pred_timestamp=True)[0] for b, e in segs]
+    punc_in = join_vad_texts(r["text"] for r in stamped)
+    punc = AutoModel(model=punc_dir, device="cuda:0").generate(input=punc_in)[0]
+    # with token timestamps the ASR text is one blank-separated word per stamp (sentence_postprocess with time_stamp)
+    assert res["raw_text"] == " ".join(r["text"] for r in stamped) and res["raw_text"].replace(" ", "") == " ".join(texts).replace(" ", "")
+    assert res["text"] == punc["text"] and res["text"] != res["raw_text"]
+    stamps = [[x + b, y + b] for r, (b, e) in zip(stamped, segs) for x, y in r["timestamp"]]
+    assert res["timestamp"] == stamps
+    if len(punc["punc_array"]) == len(stamps):
+        assert res["sentence_info"] == timestamp_sentence(punc["punc_array"], stamps, punc_in, return_raw_text=True)
+        assert res["sentence_info"] and res["sentence_info"][-1]["end"] == stamps[-1][1]
+    else:                                                                       # misaligned: VAD-segment records
+        assert [s["start"] for s in res["sentence_info"]] == [b for b, e in segs]
 
 
 def test_audio_inputs_resample_and_bytes(tmp_path):

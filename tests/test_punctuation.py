@@ -91,3 +91,34 @@ def test_small_head_attention_kernel(cuda):
     tab = torch.randn(50, 256, generator=g).to(cuda)
     ids = torch.tensor([3, 0, 49, 7, 7], dtype=torch.int32)
     assert torch.equal(ops.gather_rows(tab, ids.to(cuda)).cpu(), tab.cpu()[ids.long()])
+
+
+def _punc_dir(tmp_path):
+    from oracle import punc_oracle
+    from tests._model_dir import make_punc_model_dir
+    g, vocab, enc = _gold()
+    sd = punc_oracle.synthetic_state_dict(len(vocab), enc, seed=int(g["seed"]))
+    d = str(tmp_path / "punc")
+    make_punc_model_dir(d, vocab, enc, sd, punc_oracle.PUNC_LIST)
+    return d, g
+
+
+def test_punc_model_directory_builds(tmp_path):
+    from funasr_amd.auto_model import AutoModel
+    d, _ = _punc_dir(tmp_path)
+    am = AutoModel(model=d, device="cpu")
+    assert type(am.model).__name__ == "CTTransformer" and am.kwargs["tokenizer"].encode(["<unk>"]) is not None
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        am.generate(input="今天天气不错")
+
+
+@pytest.mark.gpu
+def test_automodel_punctuates_raw_text_like_the_reference(cuda, tmp_path):
+    """AutoModel(model=<ct-punc dir>).generate(input="raw text") -- the reference's documented use of the punctuation
+    model -- gives the text / punc_array the reference class gave for the same weights (tests/golden/punc.npz)"""
+    from funasr_amd.auto_model import AutoModel
+    d, g = _punc_dir(tmp_path)
+    am = AutoModel(model=d, device="cuda:0")
+    for c in json.loads(str(g["e2e"])):
+        r = am.generate(input=c["text"])
+        assert len(r) == 1 and r[0]["text"] == c["out"] and r[0]["punc_array"].tolist() == c["punc_array"]
