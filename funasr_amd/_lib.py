@@ -38,6 +38,13 @@ class pf_encoder_config(C.Structure):
     ]
 
 
+class pf_predictor_v3_config(C.Structure):
+    _fields_ = [
+        ("upsample_times", C.c_int32), ("upsample_type", C.c_int32), ("use_cif1_cnn", C.c_int32),
+        ("smooth_factor2", C.c_float), ("noise_threshold2", C.c_float),
+    ]
+
+
 class pf_predictor_config(C.Structure):
     _fields_ = [
         ("d_model", C.c_int32), ("l_order", C.c_int32), ("r_order", C.c_int32),
@@ -99,6 +106,8 @@ SIGNATURES = {
     "pf_predictor_missing": (C.c_int, [_vp]),
     "pf_predictor_alphas": (C.c_int, [_vp, _vp, _pi32, _i32, _i32, _vp, _vp, _pi32, _vp]),
     "pf_predictor_embeds": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pf_predictor_create_v3": (_vp, [C.POINTER(pf_predictor_config), C.POINTER(pf_predictor_v3_config)]),
+    "pf_predictor_timestamp": (C.c_int, [_vp, _vp, _pi32, _pi32, _i32, _i32, _vp, _vp, _vp]),
     "pf_decoder_create": (_vp, [C.POINTER(pf_decoder_config)]),
     "pf_decoder_destroy": (None, [_vp]),
     "pf_decoder_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
@@ -145,6 +154,7 @@ SIGNATURES = {
     "pf_k_gather_rows": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "pf_k_attention_split3": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "pf_k_attention_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pf_k_lstm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pf_k_cif": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_gemm_f32_time": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
     # profiling hooks used by bench.py (not part of the reference boundary)

@@ -35,6 +35,7 @@ from typing import Any, Dict, List, Tuple
 
 import torch
 
+from . import bicif_paraformer as _bicif_paraformer  # noqa: F401  (registers BiCifParaformer / CifPredictorV3)
 from . import ct_transformer as _ct_transformer  # noqa: F401  (registers CTTransformer)
 from . import fsmn_vad as _fsmn_vad  # noqa: F401  (registers FSMN / FsmnVADStreaming)
 from . import paraformer as _paraformer  # noqa: F401  (registers the model classes)

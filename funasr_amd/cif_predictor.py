@@ -14,7 +14,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .hip_module import HipModule, ParamHolder, host_i32, stream_ptr
+from .hip_module import Holder, HipModule, ParamHolder, host_i32, stream_ptr
 from .register import tables
 
 
@@ -68,3 +68,72 @@ class CifPredictorV2(HipModule):
         if self.tail_threshold <= 0.0:
             alphas, peaks = alphas[:, :T], peaks[:, :T]
         return embeds, token_num_t, alphas, peaks
+
+
+@tables.register("predictor_classes", "CifPredictorV3")
+class CifPredictorV3(CifPredictorV2):
+    """Host-side mirror of `CifPredictorV3` (funasr/models/bicif_paraformer/cif_predictor.py:121-384), the predictor of
+    BiCifParaformer / SeACo-Paraformer: same state_dict keys (cif_conv1d.*, cif_output.*, upsample_cnn.*, blstm.*,
+    cif_output2.*). `forward` is V2's contract computed with V3's sequential fp32 integrate-and-fire (`cif`, :39-86; the
+    fifth return value, the training-only token_num2, is None); `get_upsample_timestamp(hidden, mask, token_num)` returns
+    (None, None, us_alphas, us_cif_peak): the upsampled pair of :301-352 (the re-downsampled pair is unused at inference).
+    `cnn_attn` upsampling is not built."""
+    _create_name = "pf_predictor_create_v3"
+
+    def __init__(self, idim, l_order, r_order, threshold=1.0, dropout=0.1, smooth_factor=1.0, noise_threshold=0,
+                 tail_threshold=0.0, tf2torch_tensor_name_prefix_torch="predictor",
+                 tf2torch_tensor_name_prefix_tf="seq2seq/cif", smooth_factor2=1.0, noise_threshold2=0, upsample_times=5,
+                 upsample_type="cnn", use_cif1_cnn=True, tail_mask=True, **kwargs):
+        super().__init__(idim, l_order, r_order, threshold=threshold, dropout=dropout, smooth_factor=smooth_factor,
+                         noise_threshold=noise_threshold, tail_threshold=tail_threshold, tail_mask=True)
+        if upsample_type not in ("cnn", "cnn_blstm"):
+            raise NotImplementedError(f"CifPredictorV3(HIP): upsample_type {upsample_type!r} is not built (cnn, cnn_blstm)")
+        self.upsample_times, self.upsample_type, self.use_cif1_cnn = int(upsample_times), upsample_type, bool(use_cif1_cnn)
+        self.smooth_factor2, self.noise_threshold2 = smooth_factor2, noise_threshold2
+        self.upsample_cnn = ParamHolder((idim, idim, self.upsample_times), (idim,))
+        if upsample_type == "cnn_blstm":
+            self.blstm = Holder()
+            for sfx in ("", "_reverse"):
+                for name, shape in (("weight_ih_l0", (4 * idim, idim)), ("weight_hh_l0", (4 * idim, idim)),
+                                    ("bias_ih_l0", (4 * idim,)), ("bias_hh_l0", (4 * idim,))):
+                    self.blstm.register_parameter(name + sfx, torch.nn.Parameter(torch.zeros(*shape), requires_grad=False))
+            self.cif_output2 = ParamHolder((1, 2 * idim), (1,))
+        else:
+            self.cif_output2 = ParamHolder((1, idim), (1,))
+
+    def _make_config(self):
+        return None
+
+    def _create_args(self):
+        self._cfg_pair = (super()._make_config(),
+                          _lib.pf_predictor_v3_config(self.upsample_times, 1 if self.upsample_type == "cnn_blstm" else 0,
+                                                      int(self.use_cif1_cnn), float(self.smooth_factor2),
+                                                      float(self.noise_threshold2)))
+        return C.byref(self._cfg_pair[0]), C.byref(self._cfg_pair[1])
+
+    def forward(self, hidden, target_label=None, mask=None, ignore_id=-1, mask_chunk_predictor=None,
+                target_label_length=None, lengths=None):
+        embeds, token_num, alphas, peaks = super().forward(hidden, target_label, mask, ignore_id, mask_chunk_predictor,
+                                                           target_label_length, lengths)
+        return embeds, token_num, alphas, peaks, None
+
+    def get_upsample_timestamp(self, hidden, mask=None, token_num=None, lengths=None):
+        lib, h = self._ensure_handle()
+        dev = self._handle_device
+        hid = hidden.to(device=dev, dtype=torch.float32).contiguous()
+        B, T, D = hid.shape
+        if lengths is None:
+            lengths = [T] * B if mask is None else mask.reshape(B, -1).to(torch.float32).sum(-1).round().to(torch.int32)
+        lens_c, _ = host_i32(lengths, B)
+        if token_num is None:
+            raise NotImplementedError("get_upsample_timestamp(HIP) needs the token counts (the reference's inference call)")
+        tok_c, _ = host_i32(token_num, B)
+        U = self.upsample_times
+        us_alphas = torch.empty(B, U * T, device=dev, dtype=torch.float32)
+        us_peaks = torch.empty(B, U * T, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pf_predictor_timestamp(h, hid.data_ptr(), lens_c, tok_c, B, T, us_alphas.data_ptr(),
+                                                  us_peaks.data_ptr(), stream_ptr()), "pf_predictor_timestamp")
+        self._keep = (lens_c, tok_c)                      # read by an async copy: alive until the next call
+        # the re-downsampled pair (ds_alphas, ds_cif_peak) of the reference is not used at inference
+        return None, None, us_alphas, us_peaks

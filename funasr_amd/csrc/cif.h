@@ -41,6 +41,16 @@ struct CifEmitArgs {
 };
 int launch_cif_emit(const CifEmitArgs& a, hipStream_t stream);
 
+// CifPredictorV3's sequential fp32 integrate-and-fire (`cif`, funasr/models/bicif_paraformer/cif_predictor.py:39-86).
+// Scan: same arguments as launch_cif_scan plus `curs` [B, T+1] (the weight a frame contributes to the token being
+// integrated: alpha, or 1 - integrate on a fire), `rems` = alpha - cur, `peaks` = the running integral before the
+// threshold is taken off, `n_tok` [B] = floor(sum alphas) (the reference's token_num; n_fires counts the fires).
+// Needs T + 1 <= 4096.
+int launch_cif_scan_loop(const CifScanArgs& a, float* curs, int* n_tok, hipStream_t stream);
+// Emit: frame += cur * hidden (product and sum rounded separately, like the reference's two tensor ops); a fire emits the
+// frame and restarts it at rem * hidden. `a.alphas` = curs of the scan.
+int launch_cif_emit_loop(const CifEmitArgs& a, hipStream_t stream);
+
 // reduce per-row partial (max, argmax) pairs to token ids; rows >= n_valid[b] get `pad_id`
 int launch_argmax_reduce(const float* pval, const int* pidx, int ld, int nparts, int* ids, float* best,
                          int M, hipStream_t stream);

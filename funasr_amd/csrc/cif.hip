@@ -149,6 +149,94 @@ __global__ __launch_bounds__(64) void cif_scan_long_kernel(CifScanArgs p) {
     p.n_fires[b] = n;
 }
 
+// CifPredictorV3: the reference integrates in a Python loop over frames, all in fp32 (bicif_paraformer/cif_predictor.py:39-86)
+__global__ __launch_bounds__(64) void cif_scan_loop_kernel(CifScanArgs p, float* __restrict__ curs, int* __restrict__ n_tok) {
+    __shared__ float s_al[CIF_MAX_T], s_pk[CIF_MAX_T], s_rm[CIF_MAX_T];
+    __shared__ int s_ff[CIF_MAX_T];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int Te = p.T + 1;
+    float* al = p.alphas + (size_t)b * Te;
+    const int len = p.lens[b];
+    for (int t = lane; t < Te; t += 64) {
+        float a = t < p.T ? al[t] : 0.f;
+        if (p.tail_threshold > 0.f) {
+            const bool hit = p.tail_mask ? (t == len) : (t == p.T);
+            if (hit) a = __fadd_rn(a, p.tail_threshold);
+        }
+        s_al[t] = a;
+        al[t] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float integrate = 0.f;
+        double total = 0.0;
+        int n = 0;
+#pragma unroll 4
+        for (int t = 0; t < Te; ++t) {
+            const float a = s_al[t];
+            total += (double)a;
+            const float completion = __fsub_rn(1.0f, integrate);
+            integrate = __fadd_rn(integrate, a);
+            s_pk[t] = integrate;
+            const bool fire = integrate >= 1.0f;
+            if (fire) integrate = __fsub_rn(integrate, 1.0f);
+            const float cur = fire ? completion : a;
+            s_al[t] = cur;
+            s_rm[t] = __fsub_rn(a, cur);
+            s_ff[t] = fire ? 1 : 0;
+            n += fire ? 1 : 0;
+        }
+        p.n_fires[b] = n;
+        n_tok[b] = (int)floorf((float)total);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < Te; t += 64) {
+        curs[(size_t)b * Te + t] = s_al[t];
+        p.peaks[(size_t)b * Te + t] = s_pk[t];
+        p.rems[(size_t)b * Te + t] = s_rm[t];
+        p.fire_flag[(size_t)b * Te + t] = s_ff[t];
+    }
+}
+
+__global__ __launch_bounds__(256) void cif_emit_loop_kernel(CifEmitArgs p) {
+    __shared__ float s_cur[CIF_MAX_T], s_rm[CIF_MAX_T];
+    __shared__ int s_ff[CIF_MAX_T];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const int Te = p.T + 1;
+    for (int t = threadIdx.x; t < Te; t += 256) {
+        s_cur[t] = p.alphas[(size_t)b * Te + t];
+        s_rm[t] = p.rems[(size_t)b * Te + t];
+        s_ff[t] = p.fire_flag[(size_t)b * Te + t];
+    }
+    __syncthreads();
+    if (c >= p.D) return;
+    const float* h = p.hidden + (size_t)b * p.T * p.D + c;
+    float* out = p.embeds + (size_t)b * p.N * p.D + c;
+    float frame = 0.f;
+    int k = 0;
+    for (int t0 = 0; t0 < Te; t0 += 8) {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j;
+            hv[j] = t < p.T ? h[(size_t)t * p.D] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + j;
+            if (t >= Te) break;
+            frame = __fadd_rn(frame, __fmul_rn(s_cur[t], hv[j]));
+            if (s_ff[t]) {
+                if (k < p.N) out[(size_t)k * p.D] = frame;
+                ++k;
+                frame = __fmul_rn(s_rm[t], hv[j]);
+            }
+        }
+    }
+    for (; k < p.N; ++k) out[(size_t)k * p.D] = 0.f;
+}
+
 // one thread per (utterance, channel). The per-frame scalars (alpha, remainder, fire flag) are staged in LDS once per
 // workgroup; the channel loads of 8 consecutive frames are issued together (they do not depend on the running sum), so
 // the serial float64 accumulation no longer waits on one HBM round trip per frame.
@@ -274,6 +362,24 @@ int launch_alpha(const AlphaArgs& a, hipStream_t stream) {
 int launch_cif_scan(const CifScanArgs& a, hipStream_t stream) {
     if (a.T + 1 <= CIF_MAX_T) hipLaunchKernelGGL(cif_scan_kernel, dim3(a.B), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(cif_scan_long_kernel, dim3(ceil_div(a.B, 64)), dim3(64), 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_cif_scan_loop(const CifScanArgs& a, float* curs, int* n_tok, hipStream_t stream) {
+    PF_REQUIRE(a.alphas && a.peaks && a.rems && a.fire_flag && a.n_fires && a.lens && curs && n_tok && a.B > 0 && a.T > 0,
+               "cif_scan_loop: null/empty argument");
+    PF_REQUIRE(a.T + 1 <= CIF_MAX_T, "cif_scan_loop: at most 4095 encoder frames per utterance");
+    hipLaunchKernelGGL(cif_scan_loop_kernel, dim3((unsigned)a.B), dim3(64), 0, stream, a, curs, n_tok);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_cif_emit_loop(const CifEmitArgs& a, hipStream_t stream) {
+    PF_REQUIRE(a.hidden && a.alphas && a.rems && a.fire_flag && a.embeds && a.B > 0 && a.T > 0 && a.D > 0 && a.N > 0,
+               "cif_emit_loop: null/empty argument");
+    PF_REQUIRE(a.T + 1 <= CIF_MAX_T, "cif_emit_loop: at most 4095 encoder frames per utterance");
+    hipLaunchKernelGGL(cif_emit_loop_kernel, dim3((unsigned)ceil_div(a.D, 256), (unsigned)a.B), dim3(256), 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

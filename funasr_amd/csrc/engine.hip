@@ -16,6 +16,7 @@
 
 #include "../../include/paraformer_hip.h"
 #include "cif.h"
+#include "lstm.h"
 #include "common.h"
 #include "frontend.h"
 #include "stream.h"
@@ -70,7 +71,8 @@ struct Tensor {
     int64_t numel = 0;       // expected element count of the SOURCE tensor
     bool set = false;
     // optional repack description
-    int kind = 0;            // 0 plain copy, 1 pad rows [rows, cols] -> [rows, cols_pad], 2 conv [O, I, K] -> [O, K*I]
+    int kind = 0;            // 0 plain copy, 1 pad rows [rows, cols] -> [rows, cols_pad], 2 conv [O, I, K] -> [O, K*I],
+                             // 3 upsampling conv, 4 tiled vector, 5 LSTM weight_hh (see add_upsample / add_tiled / add_lstm_hh)
     int rows = 0, cols = 0, cols_pad = 0, taps = 0;
 };
 
@@ -96,6 +98,25 @@ struct TensorTable {
         PF_HIP_TRY(hipMalloc((void**)&x.d, sizeof(float) * (size_t)x.numel));
         t[name] = x; return 0;
     }
+    // ConvTranspose1d(I, O, k = stride = U) weight [I][O][U] -> the [U * O, I] operand of one GEMM whose output row
+    // (b, t) holds the U upsampled frames of input frame t back to back: dst[(j * O + o) * I + i] = src[(i * O + o) * U + j]
+    int add_upsample(const std::string& name, int in_c, int out_c, int U) {
+        Tensor x; x.numel = (int64_t)in_c * out_c * U; x.kind = 3; x.rows = out_c; x.cols = in_c; x.taps = U;
+        PF_HIP_TRY(hipMalloc((void**)&x.d, sizeof(float) * (size_t)x.numel));
+        t[name] = x; return 0;
+    }
+    // a [n] vector stored `reps` times back to back (the bias of the upsampling GEMM)
+    int add_tiled(const std::string& name, int n, int reps) {
+        Tensor x; x.numel = n; x.kind = 4; x.rows = reps; x.cols = n;
+        PF_HIP_TRY(hipMalloc((void**)&x.d, sizeof(float) * (size_t)n * reps));
+        t[name] = x; return 0;
+    }
+    // LSTM weight_hh [4H][H] (gates i, f, g, o stacked) -> [unit][k][4 gates] (lstm.hip)
+    int add_lstm_hh(const std::string& name, int H) {
+        Tensor x; x.numel = (int64_t)4 * H * H; x.kind = 5; x.rows = H;
+        PF_HIP_TRY(hipMalloc((void**)&x.d, sizeof(float) * (size_t)x.numel));
+        t[name] = x; return 0;
+    }
     int set(const char* name, const float* data, int64_t numel) {
         auto it = t.find(name);
         if (it == t.end()) { set_error(std::string("unknown tensor name: ") + name); return -1; }
@@ -110,6 +131,29 @@ struct TensorTable {
         } else if (x.kind == 1) {
             PF_HIP_TRY(hipMemcpy2D(x.d, sizeof(float) * x.cols_pad, data, sizeof(float) * x.cols,
                                    sizeof(float) * x.cols, x.rows, hipMemcpyDefault));
+        } else if (x.kind >= 3) {
+            std::vector<float> src((size_t)numel);
+            PF_HIP_TRY(hipMemcpy(src.data(), data, sizeof(float) * (size_t)numel, hipMemcpyDefault));
+            std::vector<float> dst;
+            if (x.kind == 3) {
+                const int O = x.rows, I = x.cols, U = x.taps;
+                dst.resize((size_t)numel);
+                for (int i = 0; i < I; ++i)
+                    for (int o = 0; o < O; ++o)
+                        for (int j = 0; j < U; ++j)
+                            dst[((size_t)j * O + o) * I + i] = src[((size_t)i * O + o) * U + j];
+            } else if (x.kind == 4) {
+                dst.resize((size_t)x.cols * x.rows);
+                for (int r = 0; r < x.rows; ++r) std::copy(src.begin(), src.end(), dst.begin() + (size_t)r * x.cols);
+            } else {
+                const int H = x.rows;
+                dst.resize((size_t)numel);
+                for (int g = 0; g < 4; ++g)
+                    for (int u = 0; u < H; ++u)
+                        for (int k = 0; k < H; ++k)
+                            dst[((size_t)u * H + k) * 4 + g] = src[((size_t)g * H + u) * H + k];
+            }
+            PF_HIP_TRY(hipMemcpy(x.d, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice));
         } else {
             // [O, I, K] -> [O, K*I]: dst[o][k*I + i] = src[o][i][k]; done on the host (load-time only)
             std::vector<float> src((size_t)numel), dst((size_t)numel);
@@ -531,6 +575,12 @@ struct Predictor {
     TensorTable tt;
     DevBuf col, conv, lens, alphas, peaks, rems, flags, nfires;
     int last_B = 0, last_T = 0;
+    // CifPredictorV3 (bicif_paraformer/cif_predictor.py:121-384): sequential fp32 CIF + the upsampled timestamp head
+    bool v3 = false;
+    pf_predictor_v3_config c3{};
+    DevBuf curs, ntok, up, x_tm, pre, lstm_out, h_a, h_b, cell, tok_dev, ulens, pack;
+    bool packed = false;                 // pack = both directions' re-laid weight_hh, then bias_ih, bias_hh back to back
+    std::vector<int32_t> ul_host;
 };
 
 // ================================================================================================= decoder
@@ -1220,10 +1270,47 @@ pf_predictor* pf_predictor_create(const pf_predictor_config* cfg) {
     if (rc) return nullptr;
     return reinterpret_cast<pf_predictor*>(p.release());
 }
+pf_predictor* pf_predictor_create_v3(const pf_predictor_config* cfg, const pf_predictor_v3_config* cfg3) {
+    if (!cfg3) { set_error("predictor_v3: null config"); return nullptr; }
+    const pf_predictor_v3_config& c3 = *cfg3;
+    if (c3.upsample_times < 1 || c3.upsample_times > 8 || (c3.upsample_type != 0 && c3.upsample_type != 1)) {
+        set_error("predictor_v3: unsupported config (upsample_times 1..8; upsample_type 0 = cnn, 1 = cnn_blstm)");
+        return nullptr;
+    }
+    if (cfg && !cfg->tail_mask && cfg->tail_threshold > 0.f) {
+        set_error("predictor_v3: the reference always applies the tail threshold through the mask (tail_mask = 1)");
+        return nullptr;
+    }
+    pf_predictor* ph = pf_predictor_create(cfg);
+    if (!ph) return nullptr;
+    Predictor* p = reinterpret_cast<Predictor*>(ph);
+    p->v3 = true;
+    p->c3 = c3;
+    const int D = p->cfg.d_model, U = c3.upsample_times;
+    int rc = 0;
+    rc |= p->tt.add_upsample("upsample_cnn.weight", D, D, U);
+    rc |= p->tt.add_tiled("upsample_cnn.bias", D, U);
+    if (c3.upsample_type == 1) {
+        for (const char* sfx : {"", "_reverse"}) {
+            const std::string s(sfx);
+            rc |= p->tt.add("blstm.weight_ih_l0" + s, (int64_t)4 * D * D);
+            rc |= p->tt.add_lstm_hh("blstm.weight_hh_l0" + s, D);
+            rc |= p->tt.add("blstm.bias_ih_l0" + s, (int64_t)4 * D);
+            rc |= p->tt.add("blstm.bias_hh_l0" + s, (int64_t)4 * D);
+        }
+        rc |= p->tt.add("cif_output2.weight", 2 * D);
+    } else {
+        rc |= p->tt.add("cif_output2.weight", D);
+    }
+    rc |= p->tt.add("cif_output2.bias", 1);
+    if (rc) { pf_predictor_destroy(ph); return nullptr; }
+    return ph;
+}
 void pf_predictor_destroy(pf_predictor* p) { delete reinterpret_cast<Predictor*>(p); }
 int pf_predictor_set_tensor(pf_predictor* ph, const char* name, const float* data, int64_t numel) {
     Predictor* p = reinterpret_cast<Predictor*>(ph);
     PF_REQUIRE(p && name && data, "predictor_set_tensor: null");
+    p->packed = false;
     return p->tt.set(name, data, numel);
 }
 int pf_predictor_missing(const pf_predictor* ph) {
@@ -1263,10 +1350,17 @@ int pf_predictor_alphas(pf_predictor* ph, const float* hidden, const int32_t* le
     sa.alphas = p->alphas.as<float>(); sa.peaks = p->peaks.as<float>(); sa.rems = p->rems.as<float>();
     sa.fire_flag = p->flags.as<int>(); sa.n_fires = p->nfires.as<int>(); sa.lens = p->lens.as<int>(); sa.B = B;
     sa.T = T; sa.tail_threshold = c.tail_threshold; sa.tail_mask = c.tail_mask;
-    if ((rc = launch_cif_scan(sa, s))) return rc;
+    if (p->v3) {
+        if (p->curs.ensure(sizeof(float) * (size_t)B * Te) || p->ntok.ensure(sizeof(int) * (size_t)B)) return -2;
+        if ((rc = launch_cif_scan_loop(sa, p->curs.as<float>(), p->ntok.as<int>(), s))) return rc;
+    } else if ((rc = launch_cif_scan(sa, s))) {
+        return rc;
+    }
     if (alphas) PF_HIP_TRY(hipMemcpyAsync(alphas, p->alphas.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
     if (peaks) PF_HIP_TRY(hipMemcpyAsync(peaks, p->peaks.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
-    PF_HIP_TRY(hipMemcpyAsync(token_num, p->nfires.p, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    // V3 reports floor(sum alphas) (cif_predictor.py:383), V2's count of fires is the same number by construction
+    PF_HIP_TRY(hipMemcpyAsync(token_num, p->v3 ? p->ntok.p : p->nfires.p, sizeof(int32_t) * (size_t)B,
+                              hipMemcpyDeviceToHost, s));
     PF_HIP_TRY(hipStreamSynchronize(s));
     p->last_B = B; p->last_T = T;
     return 0;
@@ -1281,7 +1375,108 @@ int pf_predictor_embeds(pf_predictor* ph, const float* hidden, int32_t B, int32_
     CifEmitArgs ea{};
     ea.hidden = hidden; ea.alphas = p->alphas.as<float>(); ea.rems = p->rems.as<float>();
     ea.fire_flag = p->flags.as<int>(); ea.embeds = embeds; ea.B = B; ea.T = T; ea.D = p->cfg.d_model; ea.N = N;
+    if (p->v3) {
+        if (N <= 0) return 0;
+        ea.alphas = p->curs.as<float>();
+        return launch_cif_emit_loop(ea, s);
+    }
     return launch_cif_emit(ea, s);
+}
+
+// one direction-pair of torch.nn.LSTM on a time-major input: gates-major input projections by the fp32 MFMA GEMM
+// (W_ih . X_tm^T, one GEMM per direction), then the per-step recurrence (lstm.hip)
+struct LstmW { const float* w_ih[2]; const float* w_hh; const float* b_ih; const float* b_hh; };
+static int lstm_forward(const LstmW& w, const float* x_tm, int T, int B, int D, int H, int ndir, float* out, int out_layout,
+                        DevBuf& pre, DevBuf& h_a, DevBuf& h_b, DevBuf& cell, hipStream_t s) {
+    const size_t cols = (size_t)T * B, ldp = (cols + 3) / 4 * 4;
+    const int Bs = (B + 63) / 64 * 64;
+    const size_t state = sizeof(float) * (size_t)ndir * H * Bs;
+    if (pre.ensure(sizeof(float) * (size_t)ndir * 4 * H * ldp) || h_a.ensure(state) || h_b.ensure(state) || cell.ensure(state))
+        return -2;
+    int rc;
+    for (int d = 0; d < ndir; ++d)
+        if ((rc = gemm_simple(w.w_ih[d], D, x_tm, D, nullptr, pre.as<float>() + (size_t)d * 4 * H * ldp, (int)ldp, 4 * H,
+                              (int)cols, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
+    LstmStepArgs a{};
+    a.pre = pre.as<float>(); a.whh = w.w_hh; a.b_ih = w.b_ih; a.b_hh = w.b_hh; a.h_a = h_a.as<float>();
+    a.h_b = h_b.as<float>(); a.c = cell.as<float>(); a.out = out; a.ld_pre = ldp; a.T = T; a.B = B; a.Bs = Bs; a.H = H;
+    a.ndir = ndir; a.out_layout = out_layout;
+    return launch_lstm_steps(a, s);
+}
+
+int pf_predictor_timestamp(pf_predictor* ph, const float* hidden, const int32_t* lens_host, const int32_t* token_num_host,
+                           int32_t B, int32_t T, float* us_alphas, float* us_peaks, void* stream) {
+    Predictor* p = reinterpret_cast<Predictor*>(ph);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(p && hidden && lens_host && token_num_host && us_alphas && us_peaks && B > 0 && T > 0,
+               "predictor_timestamp: null/empty argument");
+    PF_REQUIRE(p->v3, "predictor_timestamp: the handle was not made by pf_predictor_create_v3");
+    for (int b = 0; b < B; ++b) PF_REQUIRE(lens_host[b] >= 1 && lens_host[b] <= T, "predictor_timestamp: lens out of range");
+    std::string first;
+    if (p->tt.missing(&first)) { set_error("predictor: tensor not set: " + first); return -3; }
+    const pf_predictor_config& c = p->cfg;
+    const int D = c.d_model, U = p->c3.upsample_times, taps = c.l_order + c.r_order + 1, Tu = T * U;
+    const size_t M = (size_t)B * T;
+    int rc;
+    if ((rc = upload_lens(p->lens, lens_host, B, s))) return rc;
+    if (p->tok_dev.ensure(sizeof(int) * (size_t)B)) return -2;
+    PF_HIP_TRY(hipMemcpyAsync(p->tok_dev.p, token_num_host, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, s));
+    const float* src = hidden;
+    if (p->c3.use_cif1_cnn) {                                   // the head sees relu(cif_conv1d(hidden)) instead (:317-320)
+        if (p->col.ensure(sizeof(float) * M * taps * D) || p->conv.ensure(sizeof(float) * M * D)) return -2;
+        if ((rc = launch_im2col(hidden, p->col.as<float>(), B, T, D, c.l_order, c.r_order, s))) return rc;
+        if ((rc = gemm_simple(p->col.as<float>(), taps * D, p->tt.get("cif_conv1d.weight"), taps * D,
+                              p->tt.get("cif_conv1d.bias"), p->conv.as<float>(), D, (int)M, D, taps * D, 1, nullptr, 0,
+                              nullptr, 0, s))) return rc;
+        src = p->conv.as<float>();
+    }
+    // ConvTranspose1d(k = stride = U) == one GEMM: row (b, t) of the output holds frames U t .. U t + U - 1
+    if (p->up.ensure(sizeof(float) * M * U * D)) return -2;
+    if ((rc = gemm_simple(src, D, p->tt.get("upsample_cnn.weight"), D, p->tt.get("upsample_cnn.bias"), p->up.as<float>(),
+                          U * D, (int)M, U * D, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
+    if (p->c3.upsample_type == 1) {
+        const int Bs = (B + 63) / 64 * 64;
+        if (p->x_tm.ensure(sizeof(float) * (size_t)Tu * B * D) || p->lstm_out.ensure(sizeof(float) * (size_t)Tu * 2 * D * Bs))
+            return -2;
+        if ((rc = launch_rows_bt_to_tb(p->up.as<float>(), p->x_tm.as<float>(), B, Tu, D, s))) return rc;
+        // the two directions' recurrent weights / biases live back to back so that one launch serves both
+        LstmW w{};
+        w.w_ih[0] = p->tt.get("blstm.weight_ih_l0"); w.w_ih[1] = p->tt.get("blstm.weight_ih_l0_reverse");
+        const size_t hh = (size_t)4 * D * D, bb = (size_t)4 * D;
+        if (p->pack.ensure(sizeof(float) * (2 * hh + 4 * bb))) return -2;
+        float* pack = p->pack.as<float>();
+        float* bi = pack + 2 * hh;
+        float* bh = bi + 2 * bb;
+        if (!p->packed) {
+            PF_HIP_TRY(hipMemcpyAsync(pack, p->tt.get("blstm.weight_hh_l0"), sizeof(float) * hh, hipMemcpyDeviceToDevice, s));
+            PF_HIP_TRY(hipMemcpyAsync(pack + hh, p->tt.get("blstm.weight_hh_l0_reverse"), sizeof(float) * hh, hipMemcpyDeviceToDevice, s));
+            PF_HIP_TRY(hipMemcpyAsync(bi, p->tt.get("blstm.bias_ih_l0"), sizeof(float) * bb, hipMemcpyDeviceToDevice, s));
+            PF_HIP_TRY(hipMemcpyAsync(bi + bb, p->tt.get("blstm.bias_ih_l0_reverse"), sizeof(float) * bb, hipMemcpyDeviceToDevice, s));
+            PF_HIP_TRY(hipMemcpyAsync(bh, p->tt.get("blstm.bias_hh_l0"), sizeof(float) * bb, hipMemcpyDeviceToDevice, s));
+            PF_HIP_TRY(hipMemcpyAsync(bh + bb, p->tt.get("blstm.bias_hh_l0_reverse"), sizeof(float) * bb, hipMemcpyDeviceToDevice, s));
+            p->packed = true;
+        }
+        w.w_hh = pack; w.b_ih = bi; w.b_hh = bh;
+        if ((rc = lstm_forward(w, p->x_tm.as<float>(), Tu, B, D, D, 2, p->lstm_out.as<float>(), 1, p->pre, p->h_a, p->h_b,
+                               p->cell, s))) return rc;
+        UsAlphaArgs ua{};
+        ua.out_t = p->lstm_out.as<float>(); ua.w = p->tt.get("cif_output2.weight"); ua.bias = p->tt.get("cif_output2.bias");
+        ua.lens = p->lens.as<int>(); ua.alphas = us_alphas; ua.B = B; ua.Bs = Bs; ua.T = Tu; ua.C = 2 * D; ua.U = U;
+        ua.smooth = p->c3.smooth_factor2; ua.noise = p->c3.noise_threshold2;
+        if ((rc = launch_us_alpha_t(ua, s))) return rc;
+    } else {
+        // plain `cnn` head: the row-major upsampled frames go straight through the one-wave-per-row dot kernel
+        p->ul_host.resize(B);
+        for (int b = 0; b < B; ++b) p->ul_host[b] = lens_host[b] * U;
+        DevBuf& ulens = p->ulens;
+        if ((rc = upload_lens(ulens, p->ul_host.data(), B, s))) return rc;
+        AlphaArgs aa{};
+        aa.conv = p->up.as<float>(); aa.w = p->tt.get("cif_output2.weight"); aa.bias = p->tt.get("cif_output2.bias");
+        aa.lens = ulens.as<int>(); aa.alphas = us_alphas; aa.B = B; aa.T = Tu; aa.D = D; aa.T_ext = Tu;
+        aa.smooth = p->c3.smooth_factor2; aa.noise = p->c3.noise_threshold2;
+        if ((rc = launch_alpha(aa, s))) return rc;
+    }
+    return launch_us_scale_scan(us_alphas, us_peaks, p->tok_dev.as<int>(), B, Tu, (float)((double)c.threshold - 1e-4), s);
 }
 
 // --------------------------------------------------------------------------------------------------- decoder
@@ -1941,6 +2136,34 @@ int pf_k_gather_rows(const float* table, int32_t ld, int32_t rows, const int32_t
                      void* stream) {
     PF_REQUIRE(table && ids_dev && out, "gather_rows: null");
     return launch_gather_rows(table, ld, rows, ids_dev, out, n, D, reinterpret_cast<hipStream_t>(stream));
+}
+/* torch.nn.LSTM (one layer, ndir directions, zero initial state) on caller-provided device tensors in torch's layouts:
+ * x [B, T, D], w_ih [ndir][4H][D], w_hh [ndir][4H][H], b_ih / b_hh [ndir][4H] -> out [B, T, ndir * H]. Test hook of
+ * lstm.hip: the weight re-layout happens on the host here, so the call synchronises. */
+int pf_k_lstm(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int32_t B, int32_t T,
+              int32_t D, int32_t H, int32_t ndir, float* out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && out && B > 0 && T > 0 && D > 0 && H > 0 && (ndir == 1 || ndir == 2),
+               "k_lstm: null/empty argument");
+    if (check_device()) return -2;
+    const size_t hh = (size_t)4 * H * H;
+    std::vector<float> src(hh * ndir), dst(hh * ndir);
+    PF_HIP_TRY(hipMemcpy(src.data(), w_hh, sizeof(float) * src.size(), hipMemcpyDeviceToHost));
+    for (int d = 0; d < ndir; ++d)
+        for (int g = 0; g < 4; ++g)
+            for (int u = 0; u < H; ++u)
+                for (int k = 0; k < H; ++k)
+                    dst[d * hh + ((size_t)u * H + k) * 4 + g] = src[d * hh + ((size_t)g * H + u) * H + k];
+    DevBuf whh, x_tm, pre, h_a, h_b, cell;
+    if (whh.ensure(sizeof(float) * dst.size()) || x_tm.ensure(sizeof(float) * (size_t)B * T * D)) return -2;
+    PF_HIP_TRY(hipMemcpyAsync(whh.p, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice, s));
+    int rc;
+    if ((rc = launch_rows_bt_to_tb(x, x_tm.as<float>(), B, T, D, s))) return rc;
+    LstmW w{};
+    w.w_ih[0] = w_ih; w.w_ih[1] = w_ih + (size_t)4 * H * D; w.w_hh = whh.as<float>(); w.b_ih = b_ih; w.b_hh = b_hh;
+    if ((rc = lstm_forward(w, x_tm.as<float>(), T, B, D, H, ndir, out, 0, pre, h_a, h_b, cell, s))) return rc;
+    PF_HIP_TRY(hipStreamSynchronize(s));
+    return 0;
 }
 int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                         int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,

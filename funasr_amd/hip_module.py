@@ -82,7 +82,7 @@ class HipModule(nn.Module):
         if self._handle is None:
             with torch.cuda.device(dev):
                 cfg = self._make_config()
-                create = getattr(lib, self._prefix + "_create")
+                create = getattr(lib, getattr(self, "_create_name", None) or self._prefix + "_create")
                 h = create(C.byref(cfg)) if cfg is not None else create(*self._create_args())
                 self._handle = _lib.check_handle(h, self._prefix + "_create")
             self._handle_device = dev

@@ -139,6 +139,20 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def lstm(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor, b_ih: torch.Tensor, b_hh: torch.Tensor) -> torch.Tensor:
+    """One layer of torch.nn.LSTM (batch_first, zero initial state): x [B, T, D], w_ih [ndir, 4H, D], w_hh [ndir, 4H, H],
+    b_ih / b_hh [ndir, 4H] (the layer's state_dict entries stacked over directions) -> [B, T, ndir * H]."""
+    lib = _lib.load()
+    xc = _f32c(x, "x").contiguous()
+    B, T, D = xc.shape
+    ndir, H = w_hh.shape[0], w_hh.shape[2]
+    ws = [_f32c(t, "w").contiguous() for t in (w_ih, w_hh, b_ih, b_hh)]
+    out = torch.empty(B, T, ndir * H, device=xc.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_lstm(_ptr(xc), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), B, T, D, H, ndir, _ptr(out),
+                             _stream()), "pf_k_lstm")
+    return out
+
+
 def cif(alphas: torch.Tensor, hidden: torch.Tensor, n_max: int):
     """alphas [B, T], hidden [B, T, D] -> (peaks [B, T], n_fires int32 [B], embeds [B, n_max, D])."""
     lib = _lib.load()

@@ -30,6 +30,8 @@ from . import wav_frontend as _wav_frontend  # noqa: F401
 
 @tables.register("model_classes", "Paraformer")
 class Paraformer(nn.Module):
+    _always_timestamps = False      # BiCifParaformer / SeACo return token timestamps on every call
+
     def __init__(self, specaug: Optional[str] = None, specaug_conf: Optional[Dict] = None, normalize: str = None,
                  normalize_conf: Optional[Dict] = None, encoder: str = None, encoder_conf: Optional[Dict] = None,
                  decoder: str = None, decoder_conf: Optional[Dict] = None, ctc: str = None,
@@ -148,7 +150,8 @@ class Paraformer(nn.Module):
             t3 = time.perf_counter()
             meta_data["extract_feat"] = f"{t3 - t2:0.3f}"
             meta_data["batch_data_time"] = (int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000)
-        res = self.recognize_features(speech, speech_lengths, return_intermediate=kwargs.get("pred_timestamp", False))
+        want_stamps = self._always_timestamps or kwargs.get("pred_timestamp", False)
+        res = self.recognize_features(speech, speech_lengths, return_intermediate=want_stamps)
         B = len(res["ids"])
         if key is None:
             key = [f"utt_{i}" for i in range(B)]
@@ -170,14 +173,12 @@ class Paraformer(nn.Module):
             if tokenizer is not None:
                 token = tokenizer.ids2tokens(token_int)
                 text = tokenizer.tokens2text(token)
-                if kwargs.get("pred_timestamp", False):
-                    # model.py:668-681. The reference hands (cif_peak, alphas) to the (us_alphas, us_peaks) parameters of
-                    # ts_prediction_lfr6_standard in THAT order; kept, so that the timestamps are the reference's.
-                    _, stamps = cif_timestamps(res["peaks"][i].cpu(), res["alphas"][i].cpu(), list(token),
-                                               vad_offset=kwargs.get("begin_time", 0), upsample_rate=1)
-                    if not hasattr(tokenizer, "bpemodel"):
-                        text, stamps, _ = sentence_postprocess(token, stamps)
+                if want_stamps:
+                    stamps = self._token_timestamps(res, i, token, kwargs)
+                    text, stamps = self._postprocess(tokenizer, token, text, stamps)
                     results.append({"key": key[i], "text": text, "timestamp": stamps})
+                    if ibest_writer is not None and self._always_timestamps:     # bicif_paraformer/model.py:396
+                        ibest_writer["timestamp"][key[i]] = stamps
                 else:
                     if not hasattr(tokenizer, "bpemodel"):
                         text, _ = sentence_postprocess(token)
@@ -188,6 +189,18 @@ class Paraformer(nn.Module):
             else:
                 results.append({"key": key[i], "token_int": token_int})
         return results, meta_data
+
+    def _token_timestamps(self, res: dict, i: int, token, kwargs):
+        # model.py:668-681. The reference hands (cif_peak, alphas) to the (us_alphas, us_peaks) parameters of
+        # ts_prediction_lfr6_standard in THAT order; kept, so that the timestamps are the reference's.
+        _, stamps = cif_timestamps(res["peaks"][i].cpu(), res["alphas"][i].cpu(), list(token),
+                                   vad_offset=kwargs.get("begin_time", 0), upsample_rate=1)
+        return stamps
+
+    def _postprocess(self, tokenizer, token, text, stamps):
+        if not hasattr(tokenizer, "bpemodel"):
+            text, stamps, _ = sentence_postprocess(token, stamps)
+        return text, stamps
 
     def forward(self, *args, **kwargs):  # pragma: no cover
         raise NotImplementedError("training forward() is out of scope; use inference()/recognize_features()")

@@ -144,6 +144,30 @@ int pf_predictor_alphas(pf_predictor* p, const float* hidden_dev, const int32_t*
 int pf_predictor_embeds(pf_predictor* p, const float* hidden_dev, int32_t B, int32_t T, int32_t N,
                         float* embeds_dev, void* stream);
 
+/* CifPredictorV3 (funasr/models/bicif_paraformer/cif_predictor.py:121-384), the predictor of BiCifParaformer and
+ * SeACo-Paraformer ("paraformer-zh"): the same first head as V2 but integrated by the sequential fp32 loop `cif`
+ * (:39-86), plus a second head on a `upsample_times` x finer time axis that gives the token timestamps
+ * (`get_upsample_timestamp`, :301-352). A handle made by pf_predictor_create_v3 answers pf_predictor_alphas /
+ * pf_predictor_embeds with V3's arithmetic (token_num = floor(sum alphas), :383) and accepts pf_predictor_timestamp.
+ * Extra tensors: upsample_cnn.weight [d, d, U] / .bias [d]; cif_output2.weight [d or 2d] / .bias [1]; for
+ * upsample_type 1 blstm.weight_ih_l0[_reverse] [4d, d], blstm.weight_hh_l0[_reverse] [4d, d], blstm.bias_ih_l0[_reverse],
+ * blstm.bias_hh_l0[_reverse] [4d] (torch.nn.LSTM's state_dict, gates i, f, g, o). */
+typedef struct pf_predictor_v3_config {
+    int32_t upsample_times;   /* 3 */
+    int32_t upsample_type;    /* 0 "cnn", 1 "cnn_blstm" ("cnn_attn" is not built) */
+    int32_t use_cif1_cnn;     /* 0: the second head reads the encoder output, 1: relu(cif_conv1d(.)) */
+    float smooth_factor2;     /* 0.25 */
+    float noise_threshold2;   /* 0.01 */
+} pf_predictor_v3_config;
+pf_predictor* pf_predictor_create_v3(const pf_predictor_config* cfg, const pf_predictor_v3_config* cfg3);
+/* hidden_dev [B, T, d_model], lens_host [B], token_num_host [B] (the rounded token counts of pf_predictor_alphas) ->
+ * us_alphas_dev, us_peaks_dev [B, U * T]: the upsampled weights rescaled to sum to token_num per utterance and their
+ * running integral at threshold 1 - 1e-4 (`cif_wo_hidden`, :89-118), the two inputs of ts_prediction_lfr6_standard
+ * (funasr/utils/timestamp_tools.py:37). No sync. */
+int pf_predictor_timestamp(pf_predictor* p, const float* hidden_dev, const int32_t* lens_host,
+                           const int32_t* token_num_host, int32_t B, int32_t T, float* us_alphas_dev, float* us_peaks_dev,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------------- decoder */
 typedef struct pf_decoder pf_decoder;
 
@@ -317,6 +341,10 @@ int pf_k_attention_split3(const float* Q, int32_t ldq, const float* K, int32_t l
 int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, const void* V, int32_t ldv, void* O,
                         int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
                         void* stream);
+/* torch.nn.LSTM (one layer, ndir = 1 | 2, zero initial state) on device tensors in torch's layouts: x [B, T, D],
+ * w_ih [ndir][4H][D], w_hh [ndir][4H][H], b_ih / b_hh [ndir][4H] -> out [B, T, ndir * H]. Synchronises (lstm.hip). */
+int pf_k_lstm(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int32_t B, int32_t T,
+              int32_t D, int32_t H, int32_t ndir, float* out, void* stream);
 /* CIF integrate-and-fire on caller-provided weights (cif_v1, cif_predictor.py:853-908): alphas [B, T], hidden
  * [B, T, D] -> peaks [B, T] (= "fires"), n_fires int32 [B], embeds [B, N, D] (rows >= n_fires[b] zero). */
 int pf_k_cif(const float* alphas, const float* hidden, int32_t B, int32_t T, int32_t D, int32_t N, float* peaks,

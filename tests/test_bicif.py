@@ -85,3 +85,68 @@ def test_oracle_end_to_end_equals_reference_inference():
     got = _texts_and_stamps(res["ids"], res["us_alphas"], res["us_peaks"], res["olens"], vocab)
     for (text, stamps), w in zip(got, want):
         assert text == w["text"] and stamps == w["timestamp"]
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_lstm_kernel_equals_torch(cuda):
+    from funasr_amd import ops
+    torch.manual_seed(5)
+    for B, T, D, H, bid in ((3, 11, 64, 32, True), (70, 5, 32, 64, False), (1, 40, 64, 128, True), (64, 3, 32, 36, True)):
+        ref = torch.nn.LSTM(D, H, 1, batch_first=True, bidirectional=bid)
+        x = torch.randn(B, T, D)
+        with torch.no_grad():
+            want, _ = ref(x)
+        sd = ref.state_dict()
+        sfx = ("", "_reverse") if bid else ("",)
+        stack = lambda n: torch.stack([sd[f"{n}_l0{s}"] for s in sfx]).to(cuda)
+        got = ops.lstm(x.to(cuda), stack("weight_ih"), stack("weight_hh"), stack("bias_ih"), stack("bias_hh")).cpu()
+        assert got.shape == want.shape and (got - want).abs().max().item() < 2e-5, (B, T, D, H, bid)
+
+
+@pytest.mark.gpu
+def test_predictor_v3_on_the_gpu_equals_reference_golden(cuda):
+    from funasr_amd.cif_predictor import CifPredictorV3
+    from oracle import bicif_oracle as BO
+    g = _gold()
+    for name in json.loads(str(g["variants"])):
+        cfg = json.loads(str(g[f"{name}_cfg"]))
+        sd = BO.predictor_v3_state_dict(cfg, seed=int(g[f"{name}_seed"]), cif_bias=-0.6)
+        pred = CifPredictorV3(**cfg)
+        pred.load_state_dict(sd, strict=True)
+        pred = pred.to(cuda)
+        hidden, lens = _t(g, f"{name}_hidden").to(cuda), _t(g, f"{name}_lens")
+        emb, tok, alphas, peaks, _ = pred(hidden, lengths=lens)
+        assert tok.tolist() == g[f"{name}_token_num"].tolist(), name
+        want = _t(g, f"{name}_embeds")
+        assert emb.shape == want.shape and (emb.cpu() - want).abs().max().item() < 5e-5, name
+        assert (alphas.cpu() - _t(g, f"{name}_alphas")).abs().max().item() < 5e-6
+        assert _fires(peaks.cpu(), 1.0) == _fires(_t(g, f"{name}_peaks"), 1.0)
+        _, _, usa, usp = pred.get_upsample_timestamp(hidden, None, tok.round().long(), lengths=lens)
+        assert (usa.cpu() - _t(g, f"{name}_us_alphas")).abs().max().item() < 1e-5, name
+        assert _fires(usp.cpu()) == _fires(_t(g, f"{name}_us_peaks")), name
+        assert (usp.cpu() - _t(g, f"{name}_us_peaks")).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_bicif_paraformer_text_and_timestamps_equal_reference_inference(cuda):
+    """the HIP BiCifParaformer on the features the reference model decoded (oracle/make_golden_bicif.py): same text, same
+    token timestamps, in fp32 and in the bf16x3 mode; a single utterance decodes like its row of the batch"""
+    from funasr_amd.bicif_paraformer import BiCifParaformer
+    from funasr_amd.tokenizer import CharTokenizer
+    g = _gold()
+    cfg, sd, vocab, want = _e2e_setup(g)
+    model = BiCifParaformer.from_config(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if not k.startswith("decoder.embed")], (missing, unexpected)
+    model = model.to(cuda)
+    tok = CharTokenizer(token_list=vocab, unk_symbol="<unk>")
+    feats, lens = _t(g, "e2e_feats").to(cuda), _t(g, "e2e_lens")
+    for mode in ("fp32", "bf16x3"):
+        model.set_precision(mode)
+        res, _ = model.inference(feats, data_lengths=lens, key=[w["key"] for w in want], tokenizer=tok, data_type="fbank")
+        for r, w in zip(res, want):
+            assert r["key"] == w["key"] and r["text"] == w["text"] and r["timestamp"] == w["timestamp"], (mode, r, w)
+    model.set_precision("fp32")
+    one, _ = model.inference(feats[:1], data_lengths=lens[:1], key=["utt0"], tokenizer=tok, data_type="fbank")
+    assert one[0]["text"] == want[0]["text"] and one[0]["timestamp"] == want[0]["timestamp"]
