@@ -11,8 +11,8 @@
 //     accumulators of a lane.
 // One launch per time step (both directions in the same launch, grid = H/4 x ndir x ceil(B/64) workgroups of 4 waves; wave =
 // hidden unit, lane = utterance): no inter-workgroup synchronisation inside a kernel, the step order is the stream order.
-// The step is bound by the fp32 vector rate (B * 4H * H FMAs per direction) and by launch latency, not by HBM: the 4 MB of
-// W_hh per direction stay in L2 across steps.
+// The step is bound by the fp32 vector rate (B * 4H * H FMAs per direction), one L2 round trip and the launch latency, not
+// by HBM: W_hh (4 MB per direction) and the state come from the L2 / Infinity Cache every step.
 #include "common.h"
 #include "lstm.h"
 
@@ -20,14 +20,24 @@ namespace pf {
 
 namespace {
 
-constexpr int LSTM_KC = 128;      // k-rows of the state staged in LDS per pass (128 x 64 floats = 32 KB)
+constexpr int LSTM_MAX_H = 512;   // hidden units whose W_hh slice (4 units x H x 4 gates) fits the 32 KB LDS block
+constexpr int LSTM_KC = 64;       // k-rows of the state staged in LDS per pass (64 x 64 floats = 16 KB)
+constexpr int LSTM_HREG = LSTM_MAX_H * 16 / 256;   // float4 registers per thread holding the whole state tile
+constexpr int LSTM_WREG = LSTM_MAX_H * 4 / 256;    // float4 registers per thread holding the W_hh slice
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Everything a step reads is requested from L2 at once, before any arithmetic: the workgroup's W_hh slice (4 units, 32 KB at
+// H = 512) and its [H][64] tile of the previous state (128 KB) are loaded into registers with coalesced 16-byte loads, so
+// the step pays ONE memory latency instead of one per k-chunk (the first version streamed W through dependent scalar loads:
+// 22 us per step at H = 512). W goes to LDS once and is read back as a wave-uniform broadcast, the state
+// tile passes through LDS in 64-row chunks.
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
+    __shared__ float4 s_w[4 * LSTM_MAX_H];
     __shared__ float s_h[LSTM_KC * 64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int dir = blockIdx.y;
     const int u = blockIdx.x * 4 + wave;
     const int b0 = blockIdx.z * 64;
@@ -35,6 +45,20 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
     const int H = p.H;
     const int t = dir == 0 ? p.step : p.T - 1 - p.step;
     const bool valid = b < p.B;
+    const float* hp = p.h_prev + (size_t)dir * H * p.Bs + b0;
+    const float4* wsrc = reinterpret_cast<const float4*>(p.whh) + ((size_t)dir * H + (size_t)blockIdx.x * 4) * H;
+    float4 wreg[LSTM_WREG], hreg[LSTM_HREG];
+#pragma unroll
+    for (int j = 0; j < LSTM_WREG; ++j) {
+        const int q = tid + 256 * j;
+        wreg[j] = q < 4 * H ? wsrc[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < LSTM_HREG; ++j) {
+        const int q = tid + 256 * j;                  // float4 q of the [H][64] tile: row q / 16, columns 4 (q % 16) ..
+        hreg[j] = q < 16 * H ? *reinterpret_cast<const float4*>(hp + (size_t)(q >> 4) * p.Bs + (q & 15) * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -42,26 +66,27 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
         const float x = valid ? p.pre[n * p.ld_pre + (size_t)t * p.B + b] : 0.f;
         acc[g] = x + (p.b_ih[n] + p.b_hh[n]);
     }
-    const float* hp = p.h_prev + (size_t)dir * H * p.Bs + b0;
-    const float4* w4 = reinterpret_cast<const float4*>(p.whh) + ((size_t)dir * H + u) * H;
-    for (int kc = 0; kc < H; kc += LSTM_KC) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < LSTM_KC * 16; i += 256) {
-            const int r = i >> 4, c4 = i & 15;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kc + r < H) v = *reinterpret_cast<const float4*>(hp + (size_t)(kc + r) * p.Bs + c4 * 4);
-            *reinterpret_cast<float4*>(s_h + r * 64 + c4 * 4) = v;
-        }
-        __syncthreads();
-        const int kn = min(LSTM_KC, H - kc);
+#pragma unroll
+    for (int j = 0; j < LSTM_WREG; ++j) s_w[tid + 256 * j] = wreg[j];
+    const float4* wl = s_w + wave * H;
+    // chunk c holds tile rows [64 c, 64 c + 64) = float4s [1024 c, 1024 c + 1024) = registers 4 c .. 4 c + 3 of every thread
+#pragma unroll
+    for (int c = 0; c < LSTM_MAX_H / LSTM_KC; ++c) {
+        if (c * LSTM_KC < H) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) reinterpret_cast<float4*>(s_h)[tid + 256 * j] = hreg[4 * c + j];
+            __syncthreads();
+            const int kn = min(LSTM_KC, H - c * LSTM_KC);
 #pragma unroll 8
-        for (int k = 0; k < kn; ++k) {
-            const float hv = s_h[k * 64 + lane];
-            const float4 w = w4[kc + k];
-            acc[0] = fmaf(w.x, hv, acc[0]);
-            acc[1] = fmaf(w.y, hv, acc[1]);
-            acc[2] = fmaf(w.z, hv, acc[2]);
-            acc[3] = fmaf(w.w, hv, acc[3]);
+            for (int k = 0; k < kn; ++k) {
+                const float hv = s_h[k * 64 + lane];
+                const float4 w = wl[c * LSTM_KC + k];
+                acc[0] = fmaf(w.x, hv, acc[0]);
+                acc[1] = fmaf(w.y, hv, acc[1]);
+                acc[2] = fmaf(w.z, hv, acc[2]);
+                acc[3] = fmaf(w.w, hv, acc[3]);
+            }
         }
     }
     const float ig = sigmoidf_(acc[0]), fg = sigmoidf_(acc[1]), gg = tanhf(acc[2]), og = sigmoidf_(acc[3]);
@@ -152,8 +177,9 @@ __global__ __launch_bounds__(64) void us_scale_scan_kernel(float* __restrict__ a
 }  // namespace
 
 int launch_lstm_steps(const LstmStepArgs& a, hipStream_t stream) {
-    PF_REQUIRE(a.H > 0 && a.H % 4 == 0 && a.B > 0 && a.T > 0 && a.Bs % 64 == 0 && a.Bs >= a.B && (a.ndir == 1 || a.ndir == 2),
-               "lstm: need H % 4 == 0, ndir 1 or 2, state stride a multiple of 64");
+    PF_REQUIRE(a.H > 0 && a.H % 4 == 0 && a.H <= LSTM_MAX_H && a.B > 0 && a.T > 0 && a.Bs % 64 == 0 && a.Bs >= a.B &&
+                   (a.ndir == 1 || a.ndir == 2),
+               "lstm: need H % 4 == 0, H <= 512, ndir 1 or 2, state stride a multiple of 64");
     PF_REQUIRE(a.pre && a.whh && a.b_ih && a.b_hh && a.h_a && a.h_b && a.c && a.out, "lstm: null argument");
     const size_t state = sizeof(float) * (size_t)a.ndir * a.H * a.Bs;
     PF_HIP_TRY(hipMemsetAsync(a.h_a, 0, state, stream));
