@@ -40,6 +40,7 @@ from . import ct_transformer as _ct_transformer  # noqa: F401  (registers CTTran
 from . import fsmn_vad as _fsmn_vad  # noqa: F401  (registers FSMN / FsmnVADStreaming)
 from . import paraformer as _paraformer  # noqa: F401  (registers the model classes)
 from . import paraformer_streaming as _paraformer_streaming  # noqa: F401  (WavFrontendOnline)
+from . import seaco_paraformer as _seaco_paraformer  # noqa: F401  (registers SeacoParaformer)
 from . import sense_voice as _sense_voice  # noqa: F401
 from .register import tables
 

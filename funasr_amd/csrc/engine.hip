@@ -1485,8 +1485,10 @@ pf_decoder* pf_decoder_create(const pf_decoder_config* cfg) {
     if (check_device()) return nullptr;
     const pf_decoder_config& c = *cfg;
     if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads || c.d_model / c.n_heads != 128 ||
-        c.ffn_dim % 32 || c.d_model % 32 || c.n_blocks < 1 || c.kernel_size != 11 || c.vocab_size <= 0) {
-        set_error("decoder: unsupported config (need d_model/n_heads == 128, kernel_size == 11, dims % 32 == 0)");
+        c.ffn_dim % 32 || c.d_model % 32 || c.n_blocks < 1 || (c.kernel_size != 11 && c.kernel_size != 21) ||
+        (c.kernel_size == 21 && c.sanm_shift > 0) || c.vocab_size < 0) {
+        set_error("decoder: unsupported config (need d_model/n_heads == 128, kernel_size 11 or 21 (21: sanm_shfit 0), "
+                  "dims % 32 == 0; vocab_size 0 = no output layer)");
         return nullptr;
     }
     std::unique_ptr<Decoder> d(new Decoder());
@@ -1520,8 +1522,10 @@ pf_decoder* pf_decoder_create(const pf_decoder_config* cfg) {
     add_ffn("decoders3.0.");
     rc |= d->tt.add("after_norm.weight", D);
     rc |= d->tt.add("after_norm.bias", D);
-    rc |= d->tt.add("output_layer.weight", (int64_t)c.vocab_size * D);
-    rc |= d->tt.add("output_layer.bias", c.vocab_size);
+    if (c.vocab_size > 0) {          // SeACo's bias decoder has no output layer (use_output_layer: false)
+        rc |= d->tt.add("output_layer.weight", (int64_t)c.vocab_size * D);
+        rc |= d->tt.add("output_layer.bias", c.vocab_size);
+    }
     if (rc) return nullptr;
     return reinterpret_cast<pf_decoder*>(d.release());
 }
@@ -1573,6 +1577,8 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     float* t2 = d->t2.as<float>();
     PF_HIP_TRY(hipMemcpyAsync(x, embeds, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     const int left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
+    if (V == 0) PF_REQUIRE(!logits && !ids && hidden_out && d->precision != 1,
+                           "decoder_forward: a decoder without output layer returns hidden states only (fp32 / bf16x3)");
     if (d->precision == 1 && !logits) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
     // bf16x3 mode: the two GEMMs that are large at every batch size (w_1: N = ffn_dim; linear_k_v: M = B * T) take
     // three-plane operands on the bf16 matrix cores; the D x D projections and w_2 keep the fp32 MFMA tiles
@@ -1625,6 +1631,7 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     float* hid = hidden_out ? hidden_out : d->hid.as<float>();
     if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), hid, D, Mq, D, D,
                         c.ln_eps, s))) return rc;
+    if (V == 0) return 0;
     return vocab_project(hid, Mq, D, d->tt.get("output_layer.weight"), d->tt.get("output_layer.bias"), V, logits, ids,
                          d->pval, d->pidx, s);
 }

@@ -230,8 +230,11 @@ int launch_fsmn(const FsmnArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((fsmn_kernel<11, 5>), grid, block, 0, stream, a);
     else if (a.K == 11 && a.left_pad == 10)
         hipLaunchKernelGGL((fsmn_kernel<11, 10>), grid, block, 0, stream, a);
+    else if (a.K == 21 && a.left_pad == 10)          // SeACo's bias decoder (seaco_paraformer/template.yaml: kernel_size 21)
+        hipLaunchKernelGGL((fsmn_kernel<21, 10>), grid, block, 0, stream, a);
     else {
-        set_error("fsmn: only kernel_size 11 with left padding 5 (offline) or 10 (sanm_shfit 5) is built");
+        set_error("fsmn: built for kernel_size 11 with left padding 5 (offline) or 10 (sanm_shfit 5) and kernel_size 21 "
+                  "with left padding 10");
         return -1;
     }
     PF_HIP_TRY(hipGetLastError());

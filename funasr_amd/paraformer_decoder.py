@@ -56,8 +56,8 @@ class ParaformerSANMDecoder(HipModule):
                  chunk_multiply_factor: tuple = (1,), tf2torch_tensor_name_prefix_torch: str = "decoder",
                  tf2torch_tensor_name_prefix_tf: str = "seq2seq/decoder", **kwargs):
         super().__init__()
-        if num_blocks - att_layer_num > 0 or not normalize_before or concat_after or lora_list or not use_output_layer:
-            raise NotImplementedError("ParaformerSANMDecoder(HIP): only att_layer_num == num_blocks (no decoders2), "
+        if num_blocks - att_layer_num > 0 or not normalize_before or concat_after or lora_list:
+            raise NotImplementedError("ParaformerSANMDecoder(HIP): only att_layer_num >= num_blocks (no decoders2), "
                                       "normalize_before, no LoRA is built")
         if sanm_shfit is None:
             sanm_shfit = (kernel_size - 1) // 2
@@ -71,7 +71,8 @@ class ParaformerSANMDecoder(HipModule):
         _ffn(last, D, linear_units)
         self.decoders3 = nn.ModuleList([last])
         self.after_norm = layer_norm(D)
-        self.output_layer = linear(vocab_size, D)
+        # SeACo's bias decoder is built with use_output_layer false: forward() returns the hidden states (decoder.py:332-335)
+        self.output_layer = linear(vocab_size, D) if use_output_layer else None
 
     def set_precision(self, mode: str = "fp32"):
         """"fp32" (default, parity), "bf16" (bf16 operands for the GEMMs + cross-attention on the greedy route) or
@@ -82,7 +83,7 @@ class ParaformerSANMDecoder(HipModule):
         return self
 
     def _make_config(self):
-        return _lib.pf_decoder_config(self.vocab_size, self.d_model, self.attention_heads, self.linear_units,
+        return _lib.pf_decoder_config(self.vocab_size if self.output_layer is not None else 0, self.d_model, self.attention_heads, self.linear_units,
                                       self.att_layer_num, self.kernel_size, self.sanm_shfit, 1e-12)
 
     def _run(self, hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits: bool, want_ids: bool, want_hidden: bool = False):
@@ -112,6 +113,9 @@ class ParaformerSANMDecoder(HipModule):
                 return_both: bool = False):
         if chunk_mask is not None:
             raise NotImplementedError("chunk_mask is a training/streaming feature")
+        if self.output_layer is None:
+            _, _, hid, olens = self._run(hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits=False, want_ids=False, want_hidden=True)
+            return hid, olens
         logits, _, hid, olens = self._run(hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits=not return_hidden or return_both,
                                           want_ids=False, want_hidden=return_hidden or return_both)
         if return_both:

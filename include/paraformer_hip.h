@@ -172,12 +172,12 @@ int pf_predictor_timestamp(pf_predictor* p, const float* hidden_dev, const int32
 typedef struct pf_decoder pf_decoder;
 
 typedef struct pf_decoder_config {
-    int32_t vocab_size;       /* 8404 */
+    int32_t vocab_size;       /* 8404; 0 = no output layer (SeACo's bias decoder): forward returns hidden states only */
     int32_t d_model;          /* 512 */
     int32_t n_heads;          /* 4 */
     int32_t ffn_dim;          /* 2048 */
     int32_t n_blocks;         /* 16 = att_layer_num = num_blocks (decoders2 absent, decoder.py:363-364) */
-    int32_t kernel_size;      /* 11 */
+    int32_t kernel_size;      /* 11; 21 (with sanm_shift 0) for SeACo's bias decoder */
     int32_t sanm_shift;       /* 0 offline / 5 streaming model */
     float ln_eps;             /* 1e-12 */
 } pf_decoder_config;

@@ -349,6 +349,8 @@ def paraformer_decoder(memory: Tensor, mem_lens: Tensor, embeds: Tensor, tok_len
     p = prefix + "decoders3.0."
     x = _dec_ffn(_ln(x, sd, p + "norm1", eps), sd, p, eps)
     hidden = _ln(x, sd, prefix + "after_norm", eps)
+    if prefix + "output_layer.weight" not in sd:          # use_output_layer false (SeACo's bias decoder, decoder.py:332-335)
+        return hidden
     logits = F.linear(hidden, sd[prefix + "output_layer.weight"], sd[prefix + "output_layer.bias"])
     return (logits, hidden) if return_hidden else logits
 

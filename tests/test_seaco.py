@@ -1,0 +1,106 @@
+"""SeACo-Paraformer (SURVEY §8 f rank 2, the `paraformer-zh` model): the CPU oracle against goldens made by the reference
+class (oracle/make_golden_seaco.py), and the HIP path against both."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seaco.npz")
+
+
+def _setup():
+    from oracle import seaco_oracle as SO
+    g = np.load(GOLD, allow_pickle=False)
+    cfg = json.loads(str(g["cfg"]))
+    sd = SO.seaco_state_dict(cfg, int(g["seed"]), int(g["no_bias"]))
+    return g, cfg, sd, json.loads(str(g["vocab"])), json.loads(str(g["hw_list"]))
+
+
+def test_oracle_equals_reference_inference_with_and_without_hotwords():
+    from oracle import seaco_oracle as SO
+    from tests.test_bicif import _texts_and_stamps
+    g, cfg, sd, vocab, hw_list = _setup()
+    feats, lens = torch.from_numpy(g["feats"]), torch.from_numpy(g["lens"])
+    for name, hw in (("plain", None), ("hot", hw_list)):
+        res = SO.seaco_greedy(feats, lens, hw, sd, cfg, int(g["no_bias"]))
+        got = _texts_and_stamps(res["ids"], res["us_alphas"], res["us_peaks"], res["olens"], vocab)
+        for (text, stamps), w in zip(got, json.loads(str(g[name]))):
+            assert text == w["text"] and stamps == w["timestamp"], name
+    assert json.loads(str(g["plain"])) != json.loads(str(g["hot"]))
+
+
+class _Frontend:
+    cmvn_file = None
+
+
+def test_hotword_list_parsing(tmp_path):
+    from funasr_amd.seaco_paraformer import SeacoParaformer, seg_tokenize
+    from funasr_amd.tokenizer import CharTokenizer
+    g, cfg, sd, vocab, hw_list = _setup()
+    tok = CharTokenizer(token_list=vocab, unk_symbol="<unk>")
+    seg = {ch: ch for ch in vocab[3:-10]}
+    seg.update({"hello": "hel@@ lo", "world": "wor@@ ld", "the": "the"})
+    assert seg_tokenize(["我们"], seg) == ["我", "们"] and seg_tokenize(["Hello"], seg) == ["hel@@", "lo"]
+    assert seg_tokenize(["x1"], seg) == ["<unk>"] and seg_tokenize(["我x"], seg) == ["<unk>"]
+    m = SeacoParaformer.__new__(SeacoParaformer)
+    m.sos = 1
+    fe = _Frontend()
+    assert m.generate_hotwords_list(None, tokenizer=tok, frontend=fe) is None
+    with open(tmp_path / "seg_dict", "w", encoding="utf-8") as f:
+        f.write("".join(f"{k} {v}\n" for k, v in seg.items()))
+    fe.cmvn_file = str(tmp_path / "am.mvn")
+    assert m.generate_hotwords_list(str(g["hotwords"]), tokenizer=tok, frontend=fe) == hw_list
+    (tmp_path / "hot.txt").write_text("\n".join(str(g["hotwords"]).split()) + "\n", encoding="utf-8")
+    assert m.generate_hotwords_list(str(tmp_path / "hot.txt"), tokenizer=tok, frontend=fe) == hw_list
+    fe.cmvn_file = None                                           # no seg_dict: a hotword is one token (or <unk>)
+    assert m.generate_hotwords_list("我 hello", tokenizer=tok, frontend=fe) == [[tok.tokens2ids(["我"])[0]], tok.tokens2ids(["hello"]), [1]]
+
+
+def _build(cfg):
+    from funasr_amd.seaco_paraformer import SeacoParaformer
+    ec = dict(cfg["encoder"])
+    input_size = ec.pop("input_size")
+    dc = dict(cfg["decoder"])
+    vocab = dc.pop("vocab_size")
+    dc.pop("encoder_output_size", None)
+    sc = dict(cfg["seaco_decoder"])
+    for k in ("vocab_size", "encoder_output_size", "att_layer_num"):
+        sc.pop(k, None)
+    return SeacoParaformer(encoder="SANMEncoder", encoder_conf=dict(ec, input_layer="pe"), decoder="ParaformerSANMDecoder",
+                           decoder_conf=dc, seaco_decoder="ParaformerSANMDecoder",
+                           seaco_decoder_conf=dict(sc, use_output_layer=False, wo_input_layer=True), predictor="CifPredictorV3",
+                           predictor_conf=dict(cfg["predictor"]), ctc_weight=0.0, input_size=input_size, vocab_size=vocab,
+                           inner_dim=512, bias_encoder_type="lstm", NO_BIAS=5)
+
+
+def test_state_dict_layout_matches_the_reference_checkpoint():
+    g, cfg, sd, vocab, hw_list = _setup()
+    model = _build(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+
+
+@pytest.mark.gpu
+def test_seaco_on_the_gpu_equals_reference_inference(cuda, tmp_path):
+    from funasr_amd.tokenizer import CharTokenizer
+    g, cfg, sd, vocab, hw_list = _setup()
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(cuda)
+    tok = CharTokenizer(token_list=vocab, unk_symbol="<unk>")
+    feats, lens = torch.from_numpy(g["feats"]).to(cuda), torch.from_numpy(g["lens"])
+    seg = {ch: ch for ch in vocab[3:-10]}
+    seg.update({"hello": "hel@@ lo", "world": "wor@@ ld", "the": "the"})
+    with open(tmp_path / "seg_dict", "w", encoding="utf-8") as f:
+        f.write("".join(f"{k} {v}\n" for k, v in seg.items()))
+    fe = _Frontend()
+    fe.cmvn_file = str(tmp_path / "am.mvn")
+    keys = [f"utt{b}" for b in range(3)]
+    for mode in ("fp32", "bf16x3"):
+        model.set_precision(mode)
+        for name, hw in (("plain", None), ("hot", str(g["hotwords"]))):
+            res, _ = model.inference(feats, data_lengths=lens, key=keys, tokenizer=tok, frontend=fe, data_type="fbank", hotword=hw)
+            for r, w in zip(res, json.loads(str(g[name]))):
+                assert r["text"] == w["text"] and r["timestamp"] == w["timestamp"], (mode, name, r, w)
