@@ -128,3 +128,34 @@ def make_punc_model_dir(path: str, vocab: list, enc_cfg: dict, sd: dict, punc_li
     with open(os.path.join(path, "tokens.json"), "w", encoding="utf-8") as f:
         json.dump(list(vocab), f, ensure_ascii=False)
     torch.save(dict(sd), os.path.join(path, "model.pt"))
+
+
+def make_seaco_model_dir(path: str, seed: int = 31, no_bias: int = 5) -> dict:
+    """SeACo-Paraformer model directory in the hub layout of `paraformer-zh` (config.yaml naming SeacoParaformer /
+    CifPredictorV3 / the kernel-21 bias decoder, model.pt, tokens.json, am.mvn, seg_dict)"""
+    from oracle import bicif_oracle as BO
+    from oracle import seaco_oracle as SO
+    base = make_model_dir(path, seed=seed)
+    cfg = base["cfg"]
+    cfg["predictor"] = dict(idim=512, threshold=1.0, l_order=1, r_order=1, tail_threshold=0.45, smooth_factor=1.0,
+                            noise_threshold=0.0, smooth_factor2=0.25, noise_threshold2=0.01, upsample_times=3,
+                            use_cif1_cnn=False, upsample_type="cnn_blstm")
+    cfg["seaco_decoder"] = dict(SO.SEACO_DECODER)
+    with open(os.path.join(path, "config.yaml"), encoding="utf-8") as f:
+        conf = yaml.safe_load(f)
+    conf["model"] = "SeacoParaformer"
+    conf["model_conf"].update(inner_dim=512, bias_encoder_type="lstm", bias_encoder_bid=False, NO_BIAS=no_bias)
+    conf["predictor"] = "CifPredictorV3"
+    conf["predictor_conf"] = {k: v for k, v in cfg["predictor"].items() if k not in ("smooth_factor", "noise_threshold")}
+    conf["seaco_decoder"] = "ParaformerSANMDecoder"
+    conf["seaco_decoder_conf"] = {"attention_heads": 4, "linear_units": 1024, "num_blocks": 4, "dropout_rate": 0.1,
+                                  "kernel_size": 21, "sanm_shfit": 0, "use_output_layer": False, "wo_input_layer": True}
+    with open(os.path.join(path, "config.yaml"), "w", encoding="utf-8") as f:
+        yaml.safe_dump(conf, f, allow_unicode=True)
+    sd = SO.seaco_state_dict(cfg, seed, no_bias)
+    torch.save(sd, os.path.join(path, "model.pt"))
+    with open(os.path.join(path, "seg_dict"), "w", encoding="utf-8") as f:
+        for ch in VOCAB[3:-6]:
+            f.write(f"{ch} {ch}\n")
+        f.write("world wor@@ ld\nhello hello\n")
+    return dict(cfg=cfg, sd=sd, no_bias=no_bias)

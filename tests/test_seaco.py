@@ -104,3 +104,43 @@ def test_seaco_on_the_gpu_equals_reference_inference(cuda, tmp_path):
             res, _ = model.inference(feats, data_lengths=lens, key=keys, tokenizer=tok, frontend=fe, data_type="fbank", hotword=hw)
             for r, w in zip(res, json.loads(str(g[name]))):
                 assert r["text"] == w["text"] and r["timestamp"] == w["timestamp"], (mode, name, r, w)
+
+
+def test_model_directory_builds_through_automodel(tmp_path):
+    from funasr_amd.auto_model import AutoModel
+    from tests._model_dir import make_seaco_model_dir
+    info = make_seaco_model_dir(str(tmp_path / "seaco"))
+    am = AutoModel(model=str(tmp_path / "seaco"), device="cpu")
+    assert type(am.model).__name__ == "SeacoParaformer" and type(am.model.predictor).__name__ == "CifPredictorV3"
+    assert am.model.NO_BIAS == info["no_bias"] and am.model.seaco_decoder.kernel_size == 21 and am.model.seaco_decoder.output_layer is None
+    assert am.kwargs["frontend"].cmvn_file.endswith("am.mvn")
+
+
+@pytest.mark.gpu
+def test_automodel_wav_to_text_with_hotwords_equals_the_oracle(cuda, tmp_path):
+    """wav -> AutoModel(model=<SeACo dir>).generate(hotword=...) -> text + timestamps, against the CPU oracle run on the same
+    waveforms (frontend + encoder + CifPredictorV3 + both decoders + timestamp head), batch of ragged clips"""
+    from funasr_amd import synth
+    from funasr_amd.auto_model import AutoModel
+    from oracle import seaco_oracle as SO
+    from tests._model_dir import VOCAB, make_seaco_model_dir
+    from tests.test_bicif import _texts_and_stamps
+    d = str(tmp_path / "seaco")
+    info = make_seaco_model_dir(d)
+    am = AutoModel(model=d, device="cuda:0")
+    waves = [synth.speech_like(n, seed=90 + i) for i, n in enumerate((40000, 31000, 22000))]
+    hot = "我们 world 地"
+    res = am.generate(input=[w.numpy() for w in waves], batch_size=3, hotword=hot)
+    plain = am.generate(input=[w.numpy() for w in waves], batch_size=3)
+    # the oracle's network on the features of the HIP frontend (the frontends differ by fp32 FFT round-off, pinned elsewhere)
+    wav = torch.nn.utils.rnn.pad_sequence(waves, batch_first=True).to(cuda)
+    feats, flens = am.kwargs["frontend"](wav, [w.numel() for w in waves])
+    feats, flens = feats.cpu(), flens.cpu()
+    hw_list = am.model.generate_hotwords_list(hot, tokenizer=am.kwargs["tokenizer"], frontend=am.kwargs["frontend"])
+    assert [len(h) for h in hw_list] == [2, 2, 1, 1]
+    for out, hw in ((res, hw_list), (plain, None)):
+        ref = SO.seaco_greedy(feats, flens, hw, info["sd"], info["cfg"], info["no_bias"])
+        want = _texts_and_stamps(ref["ids"], ref["us_alphas"], ref["us_peaks"], ref["olens"], VOCAB)
+        for r, (text, stamps) in zip(out, want):
+            assert r["text"] == text and r["timestamp"] == stamps
+    assert [r["text"] for r in res] != [r["text"] for r in plain]
