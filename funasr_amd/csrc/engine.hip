@@ -72,7 +72,7 @@ struct Tensor {
     bool set = false;
     // optional repack description
     int kind = 0;            // 0 plain copy, 1 pad rows [rows, cols] -> [rows, cols_pad], 2 conv [O, I, K] -> [O, K*I],
-                             // 3 upsampling conv, 4 tiled vector, 5 LSTM weight_hh (see add_upsample / add_tiled / add_lstm_hh)
+                             // 3 upsampling conv, 4 tiled vector (see add_upsample / add_tiled)
     int rows = 0, cols = 0, cols_pad = 0, taps = 0;
 };
 
@@ -111,12 +111,8 @@ struct TensorTable {
         PF_HIP_TRY(hipMalloc((void**)&x.d, sizeof(float) * (size_t)n * reps));
         t[name] = x; return 0;
     }
-    // LSTM weight_hh [4H][H] (gates i, f, g, o stacked) -> [unit][k][4 gates] (lstm.hip)
-    int add_lstm_hh(const std::string& name, int H) {
-        Tensor x; x.numel = (int64_t)4 * H * H; x.kind = 5; x.rows = H;
-        PF_HIP_TRY(hipMalloc((void**)&x.d, sizeof(float) * (size_t)x.numel));
-        t[name] = x; return 0;
-    }
+    // LSTM weight_hh [4H][H] (gates i, f, g, o stacked): kept in torch's layout, the step kernel picks its 16 rows (lstm.hip)
+    int add_lstm_hh(const std::string& name, int H) { return add(name, (int64_t)4 * H * H); }
     int set(const char* name, const float* data, int64_t numel) {
         auto it = t.find(name);
         if (it == t.end()) { set_error(std::string("unknown tensor name: ") + name); return -1; }
@@ -142,16 +138,9 @@ struct TensorTable {
                     for (int o = 0; o < O; ++o)
                         for (int j = 0; j < U; ++j)
                             dst[((size_t)j * O + o) * I + i] = src[((size_t)i * O + o) * U + j];
-            } else if (x.kind == 4) {
+            } else {
                 dst.resize((size_t)x.cols * x.rows);
                 for (int r = 0; r < x.rows; ++r) std::copy(src.begin(), src.end(), dst.begin() + (size_t)r * x.cols);
-            } else {
-                const int H = x.rows;
-                dst.resize((size_t)numel);
-                for (int g = 0; g < 4; ++g)
-                    for (int u = 0; u < H; ++u)
-                        for (int k = 0; k < H; ++k)
-                            dst[((size_t)u * H + k) * 4 + g] = src[((size_t)g * H + u) * H + k];
             }
             PF_HIP_TRY(hipMemcpy(x.d, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice));
         } else {
@@ -2153,21 +2142,12 @@ int pf_k_lstm(const float* x, const float* w_ih, const float* w_hh, const float*
     PF_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && out && B > 0 && T > 0 && D > 0 && H > 0 && (ndir == 1 || ndir == 2),
                "k_lstm: null/empty argument");
     if (check_device()) return -2;
-    const size_t hh = (size_t)4 * H * H;
-    std::vector<float> src(hh * ndir), dst(hh * ndir);
-    PF_HIP_TRY(hipMemcpy(src.data(), w_hh, sizeof(float) * src.size(), hipMemcpyDeviceToHost));
-    for (int d = 0; d < ndir; ++d)
-        for (int g = 0; g < 4; ++g)
-            for (int u = 0; u < H; ++u)
-                for (int k = 0; k < H; ++k)
-                    dst[d * hh + ((size_t)u * H + k) * 4 + g] = src[d * hh + ((size_t)g * H + u) * H + k];
-    DevBuf whh, x_tm, pre, h_a, h_b, cell;
-    if (whh.ensure(sizeof(float) * dst.size()) || x_tm.ensure(sizeof(float) * (size_t)B * T * D)) return -2;
-    PF_HIP_TRY(hipMemcpyAsync(whh.p, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice, s));
+    DevBuf x_tm, pre, h_a, h_b, cell;
+    if (x_tm.ensure(sizeof(float) * (size_t)B * T * D)) return -2;
     int rc;
     if ((rc = launch_rows_bt_to_tb(x, x_tm.as<float>(), B, T, D, s))) return rc;
     LstmW w{};
-    w.w_ih[0] = w_ih; w.w_ih[1] = w_ih + (size_t)4 * H * D; w.w_hh = whh.as<float>(); w.b_ih = b_ih; w.b_hh = b_hh;
+    w.w_ih[0] = w_ih; w.w_ih[1] = w_ih + (size_t)4 * H * D; w.w_hh = w_hh; w.b_ih = b_ih; w.b_hh = b_hh;
     if ((rc = lstm_forward(w, x_tm.as<float>(), T, B, D, H, ndir, out, 0, pre, h_a, h_b, cell, s))) return rc;
     PF_HIP_TRY(hipStreamSynchronize(s));
     return 0;

@@ -6,11 +6,11 @@ namespace pf {
 
 struct LstmStepArgs {
     const float* pre;        // device [ndir * 4H][ld_pre] gates-major input projections (W_ih x, no bias), column t * B + b
-    const float* whh;        // device [ndir][H][H][4]     recurrent weights re-laid (unit, k, gate)
+    const float* whh;        // device [ndir][4H][H]       recurrent weights in torch's layout (gates i, f, g, o stacked)
     const float* b_ih;       // device [ndir * 4H]
     const float* b_hh;       // device [ndir * 4H]
-    float* h_a;              // device [ndir][H][Bs] state ping
-    float* h_b;              // device [ndir][H][Bs] state pong
+    float* h_a;              // device ndir * H * Bs floats: state ping, in MFMA B-fragment order (lstm.hip)
+    float* h_b;              // state pong
     float* c;                // device [ndir][H][Bs] cell state
     float* out;              // layout 0: [B][T][ndir * H] row-major; layout 1: [T][ndir * H][Bs] (unit-major, for the head)
     size_t ld_pre;

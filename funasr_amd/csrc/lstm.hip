@@ -2,17 +2,23 @@
 // `blstm` = torch.nn.LSTM(idim, idim, 1, bidirectional) over the 3x upsampled encoder output; the same recurrence serves the
 // hotword LSTM of SeACo-Paraformer).
 //
-// Layouts are chosen so that every access of the per-step kernel is coalesced with lane = utterance:
+// The recurrent product gates[b, 4H] = h[b, :] . W_hh^T is GEMM-shaped and runs on the matrix cores
+// (`v_mfma_f32_16x16x4_f32`, exact fp32): one launch per time step, both directions in the same launch, grid = H/4 x ndir x
+// ceil(B/64) workgroups of 4 waves. A workgroup owns 4 hidden units = 16 gate rows (MFMA row = unit * 4 + gate, so that the
+// four accumulator registers of a lane are the i, f, g, o gates of ONE (unit, utterance) and the cell update is lane-local);
+// wave w owns utterances 16 w .. 16 w + 15 of the 64-utterance tile (MFMA columns). Layouts:
 //   * input projections `pre` are GATES-MAJOR: row n = dir * 4H + gate * H + unit (torch's i, f, g, o order), column
 //     t * B + b -- produced by the fp32 MFMA GEMM as W_ih . X_tm^T, X_tm being the time-major [T, B, D] input;
-//   * the recurrent state h, c is UNIT-MAJOR [dir][H][Bs] (Bs = B rounded up to 64), so the k-loop reads 256 contiguous
-//     bytes per k and the new state is written the same way;
-//   * W_hh is re-laid at load time to [dir][unit][k][4 gates]: one 16-byte wave-uniform load per k feeds the four gate
-//     accumulators of a lane.
-// One launch per time step (both directions in the same launch, grid = H/4 x ndir x ceil(B/64) workgroups of 4 waves; wave =
-// hidden unit, lane = utterance): no inter-workgroup synchronisation inside a kernel, the step order is the stream order.
-// The step is bound by the fp32 vector rate (B * 4H * H FMAs per direction), one L2 round trip and the launch latency, not
-// by HBM: W_hh (4 MB per direction) and the state come from the L2 / Infinity Cache every step.
+//   * W_hh stays in torch's [dir][4H][H] layout: the 16 rows of a workgroup are four 4-row blocks, staged once per step into
+//     LDS as [16 rows][H + 4] (the pad spreads the rows over the banks); a lane reads its A fragments as float4s;
+//   * the k index of MFMA step s in lane group q = lane / 16 is q * H/4 + s (any bijection works as long as A and B agree),
+//     which makes a lane's A operands contiguous in k;
+//   * the state h is stored in B-FRAGMENT ORDER, [dir][b / 16][s / 4][lane = q * 16 + b % 16][s % 4]: a wave loads its whole
+//     B operand (H x 16 utterances) with H/16 fully coalesced 16-byte loads per lane straight into registers, no LDS; the new
+//     state is scattered back as single floats (64 per wave). c is unit-major [dir][H][Bs].
+// Every load of a step is issued before any arithmetic (one L2 round trip per step). No inter-workgroup synchronisation
+// inside a kernel: the step order is the stream order. Work per step: B * 4H * H FMAs per direction (268 MFLOP at B = 64,
+// H = 512 = 1.7 us at the fp32 matrix rate).
 #include "common.h"
 #include "lstm.h"
 
@@ -20,81 +26,82 @@ namespace pf {
 
 namespace {
 
-constexpr int LSTM_MAX_H = 512;   // hidden units whose W_hh slice (4 units x H x 4 gates) fits the 32 KB LDS block
-constexpr int LSTM_KC = 64;       // k-rows of the state staged in LDS per pass (64 x 64 floats = 16 KB)
-constexpr int LSTM_HREG = LSTM_MAX_H * 16 / 256;   // float4 registers per thread holding the whole state tile
-constexpr int LSTM_WREG = LSTM_MAX_H * 4 / 256;    // float4 registers per thread holding the W_hh slice
+constexpr int LSTM_RS_PAD = 4;                // W slice in LDS: 16 rows x (H + 4) floats (33 KB at H = 512)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Everything a step reads is requested from L2 at once, before any arithmetic: the workgroup's W_hh slice (4 units, 32 KB at
-// H = 512) and its [H][64] tile of the previous state (128 KB) are loaded into registers with coalesced 16-byte loads, so
-// the step pays ONE memory latency instead of one per k-chunk (the first version streamed W through dependent scalar loads:
-// 22 us per step at H = 512). W goes to LDS once and is read back as a wave-uniform broadcast, the state
-// tile passes through LDS in 64-row chunks.
+// float index of h[k][b] in fragment order (see above)
+__device__ __forceinline__ size_t lstm_state_index(int dir, int H, int Bs, int k, int b) {
+    const int Q = H >> 2;
+    const int q = k / Q, s = k - q * Q;
+    const int lane = q * 16 + (b & 15);
+    return ((((size_t)dir * (Bs >> 4) + (b >> 4)) * (H >> 4) + (s >> 2)) * 64 + lane) * 4 + (s & 3);
+}
+
+// NM = H / 16: float4 registers per lane holding the wave's B operand = MFMA quads per step
+template <int NM>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs p) {
-    __shared__ float4 s_w[4 * LSTM_MAX_H];
-    __shared__ float s_h[LSTM_KC * 64];
+    constexpr int H = NM * 16, RS = H + LSTM_RS_PAD, Q4 = H / 4;   // Q4: float4s per W row = k values per lane group
+    constexpr int WREG = (16 * Q4 + 255) / 256;
+    __shared__ float s_w[16 * RS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int dir = blockIdx.y;
-    const int u = blockIdx.x * 4 + wave;
-    const int b0 = blockIdx.z * 64;
-    const int b = b0 + lane;
-    const int H = p.H;
+    const int u0 = blockIdx.x * 4;
     const int t = dir == 0 ? p.step : p.T - 1 - p.step;
+    const int btile = blockIdx.z * 4 + wave;                     // 16-utterance tile of this wave
+    const int ul = lane >> 4, j = lane & 15;
+    const int u = u0 + ul, b = btile * 16 + j;
     const bool valid = b < p.B;
-    const float* hp = p.h_prev + (size_t)dir * H * p.Bs + b0;
-    const float4* wsrc = reinterpret_cast<const float4*>(p.whh) + ((size_t)dir * H + (size_t)blockIdx.x * 4) * H;
-    float4 wreg[LSTM_WREG], hreg[LSTM_HREG];
+    // ---- all loads of the step
+    float4 wreg[WREG], hreg[NM];
 #pragma unroll
-    for (int j = 0; j < LSTM_WREG; ++j) {
-        const int q = tid + 256 * j;
-        wreg[j] = q < 4 * H ? wsrc[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < WREG; ++i) {
+        const int f = tid + 256 * i;                              // float4 f of the [16][H] slice, rows in (gate, unit) order
+        const int r = f / Q4, c4 = f - r * Q4;
+        wreg[i] = r < 16 ? *reinterpret_cast<const float4*>(p.whh + ((size_t)dir * 4 * H + (size_t)(r >> 2) * H + u0 + (r & 3)) * H + 4 * c4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const float4* hsrc = reinterpret_cast<const float4*>(p.h_prev) + (((size_t)dir * (p.Bs >> 4) + btile) * NM) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < LSTM_HREG; ++j) {
-        const int q = tid + 256 * j;                  // float4 q of the [H][64] tile: row q / 16, columns 4 (q % 16) ..
-        hreg[j] = q < 16 * H ? *reinterpret_cast<const float4*>(hp + (size_t)(q >> 4) * p.Bs + (q & 15) * 4)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float acc[4];
+    for (int m = 0; m < NM; ++m) hreg[m] = hsrc[(size_t)m * 64];
+    f32x4 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const size_t n = (size_t)dir * 4 * H + (size_t)g * H + u;
         const float x = valid ? p.pre[n * p.ld_pre + (size_t)t * p.B + b] : 0.f;
         acc[g] = x + (p.b_ih[n] + p.b_hh[n]);
     }
+    const size_t ci = ((size_t)dir * H + u) * p.Bs + b;
+    const float c_prev = p.c[ci];
+    // ---- W slice to LDS in MFMA row order (row = unit * 4 + gate)
 #pragma unroll
-    for (int j = 0; j < LSTM_WREG; ++j) s_w[tid + 256 * j] = wreg[j];
-    const float4* wl = s_w + wave * H;
-    // chunk c holds tile rows [64 c, 64 c + 64) = float4s [1024 c, 1024 c + 1024) = registers 4 c .. 4 c + 3 of every thread
-#pragma unroll
-    for (int c = 0; c < LSTM_MAX_H / LSTM_KC; ++c) {
-        if (c * LSTM_KC < H) {
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) reinterpret_cast<float4*>(s_h)[tid + 256 * j] = hreg[4 * c + j];
-            __syncthreads();
-            const int kn = min(LSTM_KC, H - c * LSTM_KC);
-#pragma unroll 8
-            for (int k = 0; k < kn; ++k) {
-                const float hv = s_h[k * 64 + lane];
-                const float4 w = wl[c * LSTM_KC + k];
-                acc[0] = fmaf(w.x, hv, acc[0]);
-                acc[1] = fmaf(w.y, hv, acc[1]);
-                acc[2] = fmaf(w.z, hv, acc[2]);
-                acc[3] = fmaf(w.w, hv, acc[3]);
-            }
-        }
+    for (int i = 0; i < WREG; ++i) {
+        const int f = tid + 256 * i;
+        const int r = f / Q4, c4 = f - r * Q4;
+        if (r < 16) *reinterpret_cast<float4*>(s_w + ((r & 3) * 4 + (r >> 2)) * RS + 4 * c4) = wreg[i];
     }
+    __syncthreads();
+    // ---- gates += W . h: lane (row = lane & 15, q = lane >> 4) feeds A[row][q * H/4 + s], B comes from hreg
+    const float* wrow = s_w + (lane & 15) * RS + (lane >> 4) * Q4;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const float4 a = *reinterpret_cast<const float4*>(wrow + 4 * m);
+        const float4 h4 = hreg[m];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, h4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, h4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, h4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, h4.w, acc, 0, 0, 0);
+    }
+    // ---- cell update: acc[0..3] = i, f, g, o of (unit u, utterance b)
     const float ig = sigmoidf_(acc[0]), fg = sigmoidf_(acc[1]), gg = tanhf(acc[2]), og = sigmoidf_(acc[3]);
-    const size_t si = ((size_t)dir * H + u) * p.Bs + b;
-    const float cn = fg * p.c[si] + ig * gg;
+    const float cn = fg * c_prev + ig * gg;
     const float hn = og * tanhf(cn);
-    p.c[si] = cn;
-    p.h_next[si] = hn;
+    p.c[ci] = cn;
+    p.h_next[lstm_state_index(dir, H, p.Bs, u, b)] = hn;
     const int C = p.ndir * H;
     if (p.out_layout == 1) {
         p.out[((size_t)t * C + (size_t)dir * H + u) * p.Bs + b] = hn;
@@ -177,9 +184,22 @@ __global__ __launch_bounds__(64) void us_scale_scan_kernel(float* __restrict__ a
 }  // namespace
 
 int launch_lstm_steps(const LstmStepArgs& a, hipStream_t stream) {
-    PF_REQUIRE(a.H > 0 && a.H % 4 == 0 && a.H <= LSTM_MAX_H && a.B > 0 && a.T > 0 && a.Bs % 64 == 0 && a.Bs >= a.B &&
-                   (a.ndir == 1 || a.ndir == 2),
-               "lstm: need H % 4 == 0, H <= 512, ndir 1 or 2, state stride a multiple of 64");
+    PF_REQUIRE(a.H > 0 && a.H % 16 == 0 && a.B > 0 && a.T > 0 && a.Bs % 64 == 0 && a.Bs >= a.B && (a.ndir == 1 || a.ndir == 2),
+               "lstm: need H % 16 == 0, ndir 1 or 2, state stride a multiple of 64");
+    void (*kernel)(LstmStepArgs) = nullptr;
+    switch (a.H / 16) {                     // the hidden size is a compile-time constant of the step kernel
+        case 1: kernel = lstm_step_kernel<1>; break;
+        case 2: kernel = lstm_step_kernel<2>; break;
+        case 3: kernel = lstm_step_kernel<3>; break;
+        case 4: kernel = lstm_step_kernel<4>; break;
+        case 6: kernel = lstm_step_kernel<6>; break;
+        case 8: kernel = lstm_step_kernel<8>; break;
+        case 16: kernel = lstm_step_kernel<16>; break;
+        case 20: kernel = lstm_step_kernel<20>; break;
+        case 32: kernel = lstm_step_kernel<32>; break;
+        default: break;
+    }
+    PF_REQUIRE(kernel != nullptr, "lstm: hidden size must be one of 16, 32, 48, 64, 96, 128, 256, 320, 512");
     PF_REQUIRE(a.pre && a.whh && a.b_ih && a.b_hh && a.h_a && a.h_b && a.c && a.out, "lstm: null argument");
     const size_t state = sizeof(float) * (size_t)a.ndir * a.H * a.Bs;
     PF_HIP_TRY(hipMemsetAsync(a.h_a, 0, state, stream));
@@ -190,7 +210,7 @@ int launch_lstm_steps(const LstmStepArgs& a, hipStream_t stream) {
         s.step = step;
         s.h_prev = (step & 1) ? a.h_b : a.h_a;
         s.h_next = (step & 1) ? a.h_a : a.h_b;
-        hipLaunchKernelGGL(lstm_step_kernel, grid, block, 0, stream, s);
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, s);
     }
     PF_HIP_TRY(hipGetLastError());
     return 0;

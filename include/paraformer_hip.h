@@ -342,7 +342,8 @@ int pf_k_attention_bf16(const void* Q, int32_t ldq, const void* K, int32_t ldk, 
                         int32_t ldo, const int32_t* klens_dev, int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
                         void* stream);
 /* torch.nn.LSTM (one layer, ndir = 1 | 2, zero initial state) on device tensors in torch's layouts: x [B, T, D],
- * w_ih [ndir][4H][D], w_hh [ndir][4H][H], b_ih / b_hh [ndir][4H] -> out [B, T, ndir * H]. Synchronises (lstm.hip). */
+ * w_ih [ndir][4H][D], w_hh [ndir][4H][H], b_ih / b_hh [ndir][4H] -> out [B, T, ndir * H]; H % 16 == 0, H <= 512, D % 32 == 0.
+ * Synchronises (lstm.hip). */
 int pf_k_lstm(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int32_t B, int32_t T,
               int32_t D, int32_t H, int32_t ndir, float* out, void* stream);
 /* CIF integrate-and-fire on caller-provided weights (cif_v1, cif_predictor.py:853-908): alphas [B, T], hidden
