@@ -1,8 +1,9 @@
 """Drop the HIP classes into the reference's own registry.
 
 `funasr.register.tables.register(table, key)` overwrites an existing key (funasr/register.py:172-177); calling
-`funasr_amd.install()` after `import funasr` therefore re-points "WavFrontend", "SANMEncoder", "CifPredictorV2",
-"ParaformerSANMDecoder", "Paraformer", "SenseVoiceEncoderSmall" and "SenseVoiceSmall" at the gfx950 implementations,
+`funasr_amd.install()` after `import funasr` therefore re-points "WavFrontend", "SANMEncoder", "CifPredictorV2" / "V3",
+"ParaformerSANMDecoder", "Paraformer", "BiCifParaformer", "SeacoParaformer", "ParaformerStreaming", "SenseVoiceSmall",
+"FsmnVADStreaming", "CTTransformer" (and their encoders / frontends) at the gfx950 implementations,
 and `funasr.AutoModel(model=<dir>, device="cuda")` builds them by name (funasr/auto/auto_model.py:591-646) with no
 other change. Without the `funasr` package pass any object with a compatible `register(table, key)` method.
 """
@@ -10,21 +11,18 @@ from __future__ import annotations
 
 
 def hip_classes():
-    """(table, key, class) triples of everything this package provides."""
-    from . import cif_predictor, paraformer, paraformer_decoder, sanm_encoder, sense_voice, tokenizer, wav_frontend
+    """(table, key, class) triples of everything this package provides: every class the package's own registry
+    (funasr_amd.register.tables) holds after its modules are imported -- frontends, encoders, predictors (V2, V3), decoder,
+    the model classes (Paraformer, BiCifParaformer, SeacoParaformer, ParaformerStreaming, SenseVoiceSmall,
+    FsmnVADStreaming, CTTransformer) and the tokenizers."""
+    from . import (bicif_paraformer, cif_predictor, ct_transformer, fsmn_vad, paraformer, paraformer_decoder,  # noqa: F401
+                   paraformer_streaming, sanm_encoder, seaco_paraformer, sense_voice, tokenizer, wav_frontend)
+    from .register import TABLE_NAMES, tables as own
 
-    out = [
-        ("frontend_classes", "WavFrontend", wav_frontend.WavFrontend),
-        ("frontend_classes", "wav_frontend", wav_frontend.WavFrontend),
-        ("encoder_classes", "SANMEncoder", sanm_encoder.SANMEncoder),
-        ("encoder_classes", "SenseVoiceEncoderSmall", sanm_encoder.SenseVoiceEncoderSmall),
-        ("predictor_classes", "CifPredictorV2", cif_predictor.CifPredictorV2),
-        ("decoder_classes", "ParaformerSANMDecoder", paraformer_decoder.ParaformerSANMDecoder),
-        ("model_classes", "Paraformer", paraformer.Paraformer),
-        ("model_classes", "SenseVoiceSmall", sense_voice.SenseVoiceSmall),
-    ]
-    if hasattr(tokenizer, "CharTokenizer"):
-        out.append(("tokenizer_classes", "CharTokenizer", tokenizer.CharTokenizer))
+    out = []
+    for table in TABLE_NAMES:
+        for key, cls in sorted(getattr(own, table, {}).items()):
+            out.append((table, key, cls))
     return out
 
 

@@ -84,9 +84,10 @@ def main():
     n_nb = int((o["dha_ids"] == NO_BIAS).sum())
     print("hotword ids", hw_list, "| NO_BIAS positions", n_nb, "of", o["dha_ids"].numel(), "| merged differs from decoder at",
           int((o["dec_ids"] != torch.where(o["dha_ids"] == NO_BIAS, o["dec_ids"], o["dha_ids"])).sum()))
+    ref_keys = {k: list(v.shape) for k, v in model.state_dict().items()}
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "seaco.npz")
     np.savez_compressed(path, cfg=json.dumps(cfg), seed=seed, no_bias=NO_BIAS, vocab=json.dumps(MB.VOCAB, ensure_ascii=False),
-                        hotwords=HOTWORDS, hw_list=json.dumps(hw_list), feats=feats.numpy(), lens=lens.numpy(),
+                        hotwords=HOTWORDS, hw_list=json.dumps(hw_list), ref_state_dict=json.dumps(ref_keys), feats=feats.numpy(), lens=lens.numpy(),
                         plain=json.dumps(out["plain"], ensure_ascii=False), hot=json.dumps(out["hot"], ensure_ascii=False))
     print("wrote", path)
 

@@ -28,6 +28,10 @@ def test_install_into_protocol_object():
     assert ("model_classes", "Paraformer") in done and ("encoder_classes", "SANMEncoder") in done
     assert t.calls[("predictor_classes", "CifPredictorV2")].__name__ == "CifPredictorV2"
     assert not any(tb == "tokenizer_classes" for tb, _ in done)          # reference tokenizers are reused as-is
+    for pair in (("model_classes", "SeacoParaformer"), ("model_classes", "BiCifParaformer"), ("predictor_classes", "CifPredictorV3"),
+                 ("model_classes", "ParaformerStreaming"), ("model_classes", "FsmnVADStreaming"), ("encoder_classes", "FSMN"),
+                 ("model_classes", "CTTransformer"), ("frontend_classes", "WavFrontendOnline"), ("model_classes", "SenseVoiceSmall")):
+        assert pair in done, pair
 
 
 @pytest.mark.skipif(not os.path.exists(REF_REGISTER), reason="reference checkout not present (GPU box)")

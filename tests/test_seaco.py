@@ -76,10 +76,15 @@ def _build(cfg):
 
 
 def test_state_dict_layout_matches_the_reference_checkpoint():
+    """every parameter of the reference SeacoParaformer (key and shape, dumped by oracle/make_golden_seaco.py) exists here
+    under the same name, and nothing else: a published model.pt loads with strict=True"""
     g, cfg, sd, vocab, hw_list = _setup()
     model = _build(cfg)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
+    ref = json.loads(str(g["ref_state_dict"]))
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == ref, (sorted(set(mine) ^ set(ref))[:10], [k for k in mine if k in ref and mine[k] != ref[k]][:10])
 
 
 @pytest.mark.gpu
