@@ -122,3 +122,23 @@ for trial in range(5000):
         bad += 1
         if bad < 6: print("SEGS", texts, want, got)
 print("join_vad_texts / vad_segment_sentences mismatches:", bad)
+
+# rich_transcription_postprocess / sentence_postprocess_sentencepiece (funasr/utils/postprocess_utils.py:281-480)
+from funasr.utils.postprocess_utils import rich_transcription_postprocess as ref_rich, sentence_postprocess_sentencepiece as ref_sp
+from funasr_amd.postprocess_utils import rich_transcription_postprocess, sentence_postprocess_sentencepiece
+from oracle.make_golden_postprocess import PIECES, rich_case
+bad = 0
+for trial in range(20000):
+    s = rich_case(rng)
+    try: want = ref_rich(s)
+    except Exception as e: want = ("EXC", type(e).__name__)
+    try: got = rich_transcription_postprocess(s)
+    except Exception as e: got = ("EXC", type(e).__name__)
+    if want != got:
+        bad += 1
+        if bad < 6: print("RICH", repr(s), repr(want), repr(got))
+    w = [rng.choice(PIECES) for _ in range(rng.randint(0, 12))]
+    if tuple(ref_sp(list(w))) != tuple(sentence_postprocess_sentencepiece(list(w))):
+        bad += 1
+        if bad < 6: print("SP", w)
+print("rich_transcription_postprocess / sentencepiece mismatches:", bad)
