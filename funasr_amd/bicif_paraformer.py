@@ -14,7 +14,7 @@ import torch
 
 from .paraformer import Paraformer
 from .register import tables
-from .timestamps import cif_timestamps
+from .timestamps import cif_token_spans
 from .tokenizer import sentence_postprocess
 
 
@@ -62,9 +62,8 @@ class BiCifParaformer(Paraformer):
 
     def _token_timestamps(self, res: dict, i: int, token, kwargs):
         n = res["olens_host"][i] * self.predictor.upsample_times    # model.py:375-380
-        _, stamps = cif_timestamps(res["us_alphas_host"][i][:n], res["us_peaks_host"][i][:n], list(token),
-                                   vad_offset=kwargs.get("begin_time", 0))
-        return stamps
+        return cif_token_spans(res["us_alphas_host"][i][:n], res["us_peaks_host"][i][:n], list(token),
+                               vad_offset=kwargs.get("begin_time", 0))
 
     def _postprocess(self, tokenizer, token, text, stamps):
         text, stamps, _ = sentence_postprocess(token, stamps)        # unconditional in the reference (:382-384)

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .audio import load_audio_list
 from .register import tables
-from .timestamps import cif_timestamps
+from .timestamps import cif_token_spans
 from .tokenizer import sentence_postprocess
 
 # importing registers the classes under the reference's names
@@ -193,9 +193,8 @@ class Paraformer(nn.Module):
     def _token_timestamps(self, res: dict, i: int, token, kwargs):
         # model.py:668-681. The reference hands (cif_peak, alphas) to the (us_alphas, us_peaks) parameters of
         # ts_prediction_lfr6_standard in THAT order; kept, so that the timestamps are the reference's.
-        _, stamps = cif_timestamps(res["peaks"][i].cpu(), res["alphas"][i].cpu(), list(token),
-                                   vad_offset=kwargs.get("begin_time", 0), upsample_rate=1)
-        return stamps
+        return cif_token_spans(res["peaks"][i].cpu(), res["alphas"][i].cpu(), list(token),
+                               vad_offset=kwargs.get("begin_time", 0), upsample_rate=1)
 
     def _postprocess(self, tokenizer, token, text, stamps):
         if not hasattr(tokenizer, "bpemodel"):

