@@ -193,7 +193,9 @@ class Paraformer(nn.Module):
     def _token_timestamps(self, res: dict, i: int, token, kwargs):
         # model.py:668-681. The reference hands (cif_peak, alphas) to the (us_alphas, us_peaks) parameters of
         # ts_prediction_lfr6_standard in THAT order; kept, so that the timestamps are the reference's.
-        return cif_token_spans(res["peaks"][i].cpu(), res["alphas"][i].cpu(), list(token),
+        if "peaks_host" not in res:                       # one D2H copy per batch, not two per utterance
+            res["peaks_host"], res["alphas_host"] = res["peaks"].cpu(), res["alphas"].cpu()
+        return cif_token_spans(res["peaks_host"][i], res["alphas_host"][i], list(token),
                                vad_offset=kwargs.get("begin_time", 0), upsample_rate=1)
 
     def _postprocess(self, tokenizer, token, text, stamps):
