@@ -135,6 +135,8 @@ def timestamp_sentence(punc_id_list, timestamp_postprocessed, text_postprocessed
     if punc_id_list is None or len(punc_id_list) == 0:
         return [{"text": text_postprocessed.split(), "start": timestamp_postprocessed[0][0],
                  "end": timestamp_postprocessed[-1][1], "timestamp": timestamp_postprocessed}]
+    if hasattr(punc_id_list, "tolist"):       # a tensor / array: iterate plain ints (tensor iteration makes one 0-d tensor per id)
+        punc_id_list = punc_id_list.tolist()
     sent, raw, stamps = "", "", []
     start, end = timestamp_postprocessed[0][0], timestamp_postprocessed[0][1]
     fresh = True
