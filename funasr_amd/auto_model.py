@@ -403,20 +403,34 @@ class AutoModel:
                     if k.startswith("timestamp"):
                         merged.setdefault(k, [])
                         for t in v:
-                            t[0] = int(t[0]) + int(segments[j][0])
-                            t[1] = int(t[1]) + int(segments[j][0])
+                            if isinstance(t, dict):                              # dict stamps in seconds (Fun-ASR-Nano style)
+                                t["start_time"] = (float(t["start_time"]) * 1000 + int(segments[j][0])) / 1000
+                                t["end_time"] = (float(t["end_time"]) * 1000 + int(segments[j][0])) / 1000
+                            else:
+                                t[0] = int(t[0]) + int(segments[j][0])
+                                t[1] = int(t[1]) + int(segments[j][0])
                         merged[k].extend(v)
                     elif "text" in k:
                         merged[k] = v if k not in merged else merged[k] + " " + v
                     elif k != "key":
                         merged[k] = v if k not in merged else merged[k] + v
+            if "timestamps" in merged and "timestamp" not in merged:                 # :1039-1044
+                merged["timestamp"] = [[int(t["start_time"] * 1000), int(t["end_time"] * 1000)] for t in merged["timestamps"]]
             if not len(merged.get("text", "").strip()):
                 continue
-            # punctuation (:1057-1075): the recording's text, joined without blanks between CJK chunks, goes through the
-            # punc model once; its text replaces the joined ASR text, its punc_array drives the sentence records
+            return_raw_text = kwargs.get("return_raw_text", False)
+            # ASR units with their own spelling (`words`, one per timestamp): punctuation must not re-spell them (:1048-1058)
+            words, word_stamps = merged.get("words"), merged.get("timestamp")
+            word_text = None
+            if (isinstance(words, list) and words and all(isinstance(w, str) and w.strip() for w in words)
+                    and isinstance(word_stamps, list) and len(words) == len(word_stamps)):
+                word_text = " ".join(words)
+            # punctuation (:1060-1086): the recording's text, joined without blanks between CJK chunks, goes through the
+            # punc model once; its text (or the original spelling with the marks inserted) replaces the joined ASR text
             punc_res, punc_array, punc_text = None, None, None
             punc_model = getattr(self, "punc_model", None)
             if punc_model is not None and "timestamps" not in merged:
+                from . import punc_align
                 from .vad_utils import join_vad_texts
                 pk = dict(copy.deepcopy({k: v for k, v in self.punc_kwargs.items() if k not in ("tokenizer", "frontend")}),
                           **{k: self.punc_kwargs[k] for k in ("tokenizer", "frontend") if k in self.punc_kwargs})
@@ -424,18 +438,39 @@ class AutoModel:
                 raw_text = copy.copy(merged["text"])
                 punc_text = join_vad_texts(item.get("text", "") for item in restored)
                 punc_res = self.inference(punc_text, model=punc_model, kwargs=pk, **cfg)
-                if kwargs.get("return_raw_text", False):
+                if return_raw_text:
                     merged["raw_text"] = raw_text
                 punc_array = punc_res[0].get("punc_array")
-                merged["text"] = punc_res[0]["text"]
+                surface = punc_align.punctuate_surface_text(punc_text, punc_array, punc_model) if word_text is not None else None
+                merged["text"] = surface or punc_res[0]["text"]
+            # which text / timestamps the sentence cutter sees (:1088-1121)
+            stamp_text = punc_text
             stamps = merged.get("timestamp", [])
             misaligned = False
-            if punc_res is not None and punc_array is not None and len(punc_array) != len(stamps):
-                punc_array, misaligned = None, True
+            surface_sentences = None
+            if punc_res is not None:
+                from . import punc_align
+                try:
+                    n_punc = len(punc_array)
+                except TypeError:
+                    n_punc, punc_array = -1, None
+                if word_text is not None and n_punc == len(words):
+                    stamp_text = word_text
+                elif word_text is not None and n_punc > 0:
+                    units = punc_align.merge_timestamp_units(punc_text, words, word_stamps, punc_array, punc_model)
+                    if units is not None:
+                        stamp_text, stamps = units
+                if punc_array is not None and n_punc != len(stamps):
+                    punc_array, misaligned = None, True
+                if word_text is not None and punc_array is not None:
+                    surface_sentences = punc_align.timestamp_sentences_from_surface(punc_text, stamps, punc_array, punc_model,
+                                                                                    return_raw_text=return_raw_text)
             if kwargs.get("sentence_timestamp", False):                                   # :1198-1234
                 from .timestamps import timestamp_sentence
                 from .vad_utils import vad_segment_sentences
-                if punc_model is None and not stamps:
+                if not len(merged["text"].strip()):
+                    merged["sentence_info"] = []
+                elif punc_model is None and punc_res is None and not stamps:
                     merged["sentence_info"] = vad_segment_sentences(restored, segments)
                 elif punc_res is None:
                     logging.warning("punc_model is required for sentence_timestamp, skipping sentence segmentation.")
@@ -443,9 +478,10 @@ class AutoModel:
                 elif misaligned:
                     logging.warning("punctuation timestamps could not be aligned, falling back to VAD segments.")
                     merged["sentence_info"] = vad_segment_sentences(restored, segments)
+                elif surface_sentences is not None:
+                    merged["sentence_info"] = surface_sentences
                 else:
-                    merged["sentence_info"] = timestamp_sentence(punc_array, stamps, punc_text,
-                                                                 return_raw_text=kwargs.get("return_raw_text", False),
+                    merged["sentence_info"] = timestamp_sentence(punc_array, stamps, stamp_text, return_raw_text=return_raw_text,
                                                                  english=kwargs.get("en_post_proc", False))
             merged["key"] = key
             out.append(merged)

@@ -149,3 +149,63 @@ for trial in range(20000):
         bad += 1
         if bad < 6: print("SP", w)
 print("rich_transcription_postprocess / sentencepiece mismatches:", bad)
+
+# the surface-alignment helpers of inference_with_vad (funasr/auto/auto_model.py:107-300) vs funasr_amd/punc_align.py
+_names = ("_get_punc_tokens", "_surface_token_spans", "_punc_symbol", "_punctuate_surface_text", "_merge_timestamp_units",
+          "_timestamp_sentences_from_surface")
+for node in ast.parse(_src).body:
+    if isinstance(node, ast.FunctionDef) and node.name in _names:
+        exec(compile(ast.Module([node], []), "auto_model.py", "exec"), _ns)
+from funasr_amd import punc_align as PA
+
+
+class _PM:
+    jieba_usr_dict = None
+    def __init__(self, marks): self.punc_list = marks
+
+
+bad = 0
+units = ["你", "好", "世", "界", "hello", "World", "don't", "a", "3d", "https", ":", "/", "nature", ".", "com", "@", "ok"]
+for trial in range(6000):
+    n = rng.randint(0, 8)
+    toks = [rng.choice(units) for _ in range(n)]
+    # surface text: tokens glued with or without blanks (ASCII runs need a blank to stay separate words)
+    text = ""
+    for t in toks:
+        text += (" " if (text and (rng.random() < 0.5 or (text[-1].isascii() and t[0].isascii()))) else "") + t
+    if rng.random() < 0.1: text += rng.choice([" ", "x", "。"])
+    pm = _PM(rng.choice([["<unk>", "_", "，", "。", "？", "、"], None, ["<unk>", "_", ","]]))
+    k = rng.choice([n, n, n, n + 1, max(n - 1, 0)])
+    pa = [rng.choice([1, 1, 2, 3, 4, 5]) for _ in range(k)]
+    pa_arg = rng.choice([pa, np.array(pa, dtype=np.int64), torch.tensor(pa)]) if rng.random() < 0.95 else 3
+    ts = [[100 * i, 100 * i + rng.randint(0, 99)] for i in range(n)]
+    # ASR units: sometimes the same tokens, sometimes split differently
+    words, wts = [], []
+    for t, (b, e) in zip(toks, ts):
+        if len(t) > 2 and rng.random() < 0.4:
+            c = rng.randint(1, len(t) - 1); m = (b + e) // 2
+            words += [t[:c], t[c:]]; wts += [[b, m], [m, e]]
+        else:
+            words.append(t); wts.append([b, e])
+    if rng.random() < 0.05 and wts: wts[-1] = [wts[-1][1] + 5, wts[-1][0]]
+    raw = rng.random() < 0.5
+    pairs = [
+        (lambda: _ns["_get_punc_tokens"](text, pa_arg, pm), lambda: PA.punc_tokens(text, pa_arg, pm)),
+        (lambda: _ns["_surface_token_spans"](text, toks), lambda: PA.surface_token_spans(text, toks)),
+        (lambda: _ns["_punctuate_surface_text"](text, pa_arg, pm), lambda: PA.punctuate_surface_text(text, pa_arg, pm)),
+        (lambda: _ns["_merge_timestamp_units"](text, words, wts, pa_arg, pm), lambda: PA.merge_timestamp_units(text, words, wts, pa_arg, pm)),
+        (lambda: _ns["_timestamp_sentences_from_surface"](text, ts, pa_arg, pm, return_raw_text=raw),
+         lambda: PA.timestamp_sentences_from_surface(text, ts, pa_arg, pm, return_raw_text=raw)),
+    ]
+    if toks and pa:
+        pairs.append((lambda: _ns["_punc_symbol"](pa[0], toks[0], pm), lambda: PA.punc_symbol(pa[0], toks[0], pm)))
+    for fi, (ref_f, my_f) in enumerate(pairs):
+        try: want = ref_f()
+        except Exception as e: want = ("EXC", type(e).__name__)
+        try: got = my_f()
+        except Exception as e: got = ("EXC", type(e).__name__)
+        norm = lambda v: [tuple(x) if isinstance(x, (list, tuple)) else x for x in v] if isinstance(v, list) else v
+        if norm(want) != norm(got) and str(want) != str(got):
+            bad += 1
+            if bad < 8: print("ALIGN", fi, repr(text), toks, pa_arg, want, got)
+print("surface-alignment helper mismatches:", bad)
