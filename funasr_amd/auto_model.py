@@ -278,9 +278,21 @@ class AutoModel:
 
     # ------------------------------------------------------------------------------------------------- generate
     def generate(self, input, input_len=None, progress_callback=None, **cfg):
-        if getattr(self, "vad_model", None) is None:                        # :689-712
-            return self.inference(input, input_len=input_len, progress_callback=progress_callback, **cfg)
-        return self.inference_with_vad(input, input_len=input_len, **cfg)
+        from .postprocess_hotwords import apply_postprocess_hotwords_to_results
+        if getattr(self, "vad_model", None) is None:                        # :729-742
+            results = self.inference(input, input_len=input_len, progress_callback=progress_callback, **cfg)
+            punc_model = getattr(self, "punc_model", None)
+            if punc_model is not None:                                       # no VAD: every result is punctuated on its own
+                for result in results:
+                    pk = dict(copy.deepcopy({k: v for k, v in self.punc_kwargs.items() if k not in ("tokenizer", "frontend")}),
+                              **{k: self.punc_kwargs[k] for k in ("tokenizer", "frontend") if k in self.punc_kwargs})
+                    pk.setdefault("device", self.kwargs.get("device", "cuda"))
+                    punc_res = self.inference(result["text"], model=punc_model, kwargs=pk, **cfg)
+                    if cfg.get("return_raw_text", self.kwargs.get("return_raw_text", False)):
+                        result["raw_text"] = copy.copy(result["text"])
+                    result["text"] = punc_res[0]["text"]
+            return apply_postprocess_hotwords_to_results(results, cfg)      # text-level hotword correction (:742,:748)
+        return apply_postprocess_hotwords_to_results(self.inference_with_vad(input, input_len=input_len, **cfg), cfg)
 
     def inference(self, input, input_len=None, model=None, kwargs=None, key=None, progress_callback=None, **cfg):
         if kwargs is None:                                                   # _reset_runtime_configs (:1318-1359)
