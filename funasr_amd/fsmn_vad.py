@@ -149,6 +149,7 @@ class FsmnVADStreaming(torch.nn.Module):
         cache["encoder"] = {}
         cache["prev_samples"] = torch.empty(0)
         cache["decision"] = NativeVadDecision(self.vad_opts, speech_noise_thres=kwargs.get("speech_noise_thres"))
+        cache["stats"] = cache["decision"]     # the reference's key: wrappers tune .speech_noise_thres / .max_end_sil_frame_cnt_thresh
         cache["frames_done"] = 0
         cache["wave"], cache["wave_start"] = None, 0   # waveform history behind the frame energies (streaming input)
         return cache

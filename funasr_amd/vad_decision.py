@@ -73,6 +73,14 @@ class _Segment:
         self.has_start = self.has_end = False
 
 
+def _alias_max_end_sil(cls):
+    """the reference's name for max_end_sil_ms: `cache["stats"].max_end_sil_frame_cnt_thresh` (model.py:929-936)"""
+    cls.max_end_sil_frame_cnt_thresh = property(lambda self: self.max_end_sil_ms,
+                                                lambda self, v: setattr(self, "max_end_sil_ms", v))
+    return cls
+
+
+@_alias_max_end_sil
 class VadDecision:
     """State of one audio stream. `push()` takes the network's silence scores and the frame energies of the next block
     of frames and returns the segments that became reportable."""
@@ -358,6 +366,9 @@ class NativeVadDecision:
                               lambda self, v: (setattr(self, "_max_end_sil_ms", float(v)), self._sync())[1])
     speech_noise_thres = property(lambda self: self._speech_noise_thres,
                                   lambda self, v: (setattr(self, "_speech_noise_thres", float(v)), self._sync())[1])
+    # the reference's name for the same quantity (`cache["stats"].max_end_sil_frame_cnt_thresh`, written by
+    # DynamicStreamingVAD, funasr/models/fsmn_vad_streaming/dynamic_vad.py:96-104)
+    max_end_sil_frame_cnt_thresh = max_end_sil_ms
 
     def push(self, sil_scores, decibels, is_final: bool = False, streaming_events: bool = False) -> List[List[int]]:
         import numpy as np
