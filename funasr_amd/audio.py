@@ -1,9 +1,14 @@
 """Host-side input handling: file / array / tensor / bytes -> mono float32 waveforms in [-1, 1] at the frontend rate.
 
 Mirrors the subset of `load_audio_text_image_video` the ASR path uses (funasr/utils/load_utils.py:48-179): local WAV
-paths (decoded with the stdlib `wave` module instead of torchaudio/soundfile/ffmpeg), numpy arrays, tensors, raw
-16-bit PCM bytes, and lists of those; a missing file raises FileNotFoundError like :95-112. A sample-rate mismatch is
-resampled on the host with a polyphase FIR (scipy) where the reference uses torchaudio.transforms.Resample (:176-178).
+paths (decoded with the stdlib `wave` module instead of torchaudio/soundfile/ffmpeg), numpy arrays, tensors, bytes, and
+lists of those; a missing file raises FileNotFoundError like :95-112. A sample-rate mismatch is resampled on the host with
+a polyphase FIR (scipy) where the reference uses torchaudio.transforms.Resample (:176-178).
+Bytes follow `load_bytes` (:306-341): a recognised container (`is_audio_container`, restating `_is_audio_container`
+:272-303 incl. the MPEG frame-chain test that keeps raw PCM starting with a sync-like sample from being mistaken for MP3) is
+DECODED -- RIFF / RIFX WAVE here; compressed formats need torchaudio / soundfile / ffmpeg, which this package does not
+depend on, and raise the reference's "complete supported audio file" error instead of being read as samples -- everything
+else is headerless little-endian int16 PCM.
 """
 from __future__ import annotations
 
@@ -33,6 +38,115 @@ def _decode_wav(src) -> tuple[torch.Tensor, int]:
     return torch.from_numpy(np.ascontiguousarray(x)), fs
 
 
+# ------------------------------------------------------------------------------------------- container sniffing
+_MPEG1_KBPS = {3: (32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 416, 448),     # layer I
+               2: (32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384),        # layer II
+               1: (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)}         # layer III
+_MPEG2_KBPS = {3: (32, 48, 56, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256),
+               2: (8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160),
+               1: (8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160)}
+_MPEG_HZ = {3: (44100, 48000, 32000), 2: (22050, 24000, 16000), 0: (11025, 12000, 8000)}
+
+
+def _mpeg_header(data: bytes, off: int):
+    """(version id, layer id, bitrate index, sample-rate index, padding bit) of a plausible MPEG audio frame header at `off`"""
+    if off < 0 or off + 4 > len(data):
+        return None
+    word = int.from_bytes(data[off: off + 4], "big")
+    if word >> 21 != 0x7FF:
+        return None
+    version, layer, bitrate, rate, pad = (word >> 19) & 3, (word >> 17) & 3, (word >> 12) & 15, (word >> 10) & 3, (word >> 9) & 1
+    if version == 1 or layer == 0 or bitrate == 15 or rate == 3:
+        return None
+    return version, layer, bitrate, rate, pad
+
+
+def _mpeg_frame_bytes(data: bytes, off: int) -> int:
+    """length of a fixed-bitrate frame, 0 for no header / free format"""
+    h = _mpeg_header(data, off)
+    if h is None or h[2] == 0:
+        return 0
+    version, layer, bitrate, rate, pad = h
+    bps = (_MPEG1_KBPS if version == 3 else _MPEG2_KBPS)[layer][bitrate - 1] * 1000
+    hz = _MPEG_HZ[version][rate]
+    if layer == 3:
+        return (12 * bps // hz + pad) * 4
+    return (144 if version == 3 or layer == 2 else 72) * bps // hz + pad
+
+
+def _mpeg_frame_chain(data: bytes) -> bool:
+    """two consecutive fixed-bitrate frames, or three equally spaced free-format headers of the same stream type"""
+    first = _mpeg_header(data, 0)
+    if first is None:
+        return False
+    if first[2] != 0:
+        n = _mpeg_frame_bytes(data, 0)
+        return n > 0 and _mpeg_frame_bytes(data, n) > 0
+    kind = (first[0], first[1], first[3])
+    slot = 4 if first[1] == 3 else 1
+    for second in range(24, min(len(data) - 3, 8192)):
+        h2 = _mpeg_header(data, second)
+        if h2 is None or (h2[0], h2[1], h2[3]) != kind or h2[2] != 0:
+            continue
+        third = second + (second - first[4] * slot) + h2[4] * slot
+        h3 = _mpeg_header(data, third)
+        if h3 is not None and (h3[0], h3[1], h3[3]) == kind and h3[2] == 0:
+            return True
+    return False
+
+
+def is_audio_container(data: bytes) -> bool:
+    if len(data) < 4:
+        return False
+    if len(data) >= 12 and data[:4] in (b"RIFF", b"RIFX", b"RF64", b"BW64") and data[8:12] == b"WAVE":
+        return True
+    if data[:3] == b"ID3" or (data[0] == 0xFF and data[1] & 0xE0 == 0xE0 and _mpeg_frame_chain(data)):
+        return True
+    if data[:4] in (b"OggS", b"fLaC", b"\x1a\x45\xdf\xa3"):
+        return True
+    return len(data) >= 8 and data[4:8] == b"ftyp"
+
+
+def _decode_rifx(data: bytes) -> tuple[torch.Tensor, int]:
+    """big-endian WAVE (RIFX): PCM chunks parsed by hand, the stdlib `wave` module only reads RIFF"""
+    import struct
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos: pos + 4], struct.unpack(">I", data[pos + 4: pos + 8])[0]
+        body = data[pos + 8: pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = struct.unpack(">HHIIHH", body[:16])
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None or fmt[0] != 1:
+        raise ValueError("RIFX: no PCM fmt / data chunk")
+    _, ch, fs, _, _, bits = fmt
+    if bits == 16:
+        x = np.frombuffer(pcm[: len(pcm) // 2 * 2], dtype=">i2").astype(np.float32) / 32768.0
+    elif bits == 32:
+        x = np.frombuffer(pcm[: len(pcm) // 4 * 4], dtype=">i4").astype(np.float32) / 2147483648.0
+    elif bits == 8:
+        x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported PCM sample width {bits} bits")
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(axis=1)
+    return torch.from_numpy(np.ascontiguousarray(x)), fs
+
+
+def _decode_container(data: bytes) -> tuple[torch.Tensor, int]:
+    try:
+        if data[:4] == b"RIFF":
+            return _decode_wav(io.BytesIO(data))
+        if data[:4] == b"RIFX":
+            return _decode_rifx(data)
+        raise ValueError("no decoder for this container in funasr_amd (stdlib WAVE only)")
+    except Exception as exc:  # noqa: BLE001
+        raise RuntimeError("Failed to decode container-formatted audio bytes. Verify that the input is a complete supported "
+                           "audio file and that torchaudio, soundfile, or ffmpeg is available.") from exc
+
+
 def load_audio(item, fs: int = 16000, audio_fs: int = 16000) -> torch.Tensor:
     if isinstance(item, str):
         if not os.path.exists(item):
@@ -40,10 +154,11 @@ def load_audio(item, fs: int = 16000, audio_fs: int = 16000) -> torch.Tensor:
                                     f"torch.Tensor, or bytes.")
         x, audio_fs = _decode_wav(item)
     elif isinstance(item, (bytes, bytearray)):
-        if item[:4] == b"RIFF":
-            x, audio_fs = _decode_wav(io.BytesIO(bytes(item)))
-        else:                                      # headerless 16-bit PCM (funasr/utils/load_utils.py:load_bytes)
-            x = torch.from_numpy(np.frombuffer(bytes(item), dtype="<i2").astype(np.float32) / 32768.0)
+        data = bytes(item)
+        if is_audio_container(data):
+            x, audio_fs = _decode_container(data)
+        else:                                      # headerless 16-bit PCM (funasr/utils/load_utils.py:329-341)
+            x = torch.from_numpy(np.frombuffer(data[: len(data) // 2 * 2], dtype="<i2").astype(np.float32) / 32768.0)
     elif isinstance(item, np.ndarray):
         x = torch.from_numpy(item)
     elif isinstance(item, torch.Tensor):

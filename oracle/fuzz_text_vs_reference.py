@@ -209,3 +209,32 @@ for trial in range(6000):
             bad += 1
             if bad < 8: print("ALIGN", fi, repr(text), toks, pa_arg, want, got)
 print("surface-alignment helper mismatches:", bad)
+
+# byte-container sniffing (funasr/utils/load_utils.py:182-303) vs funasr_amd.audio.is_audio_container
+_lu = open("/root/reference/funasr/utils/load_utils.py", encoding="utf-8").read()
+_ns2 = {}
+for node in ast.parse(_lu).body:
+    if isinstance(node, ast.FunctionDef) and node.name in ("_mp3_header_fields", "_mp3_frame_length", "_has_consecutive_mp3_frames", "_is_audio_container"):
+        exec(compile(ast.Module([node], []), "load_utils.py", "exec"), _ns2)
+from funasr_amd.audio import is_audio_container
+bad = 0
+magic = [b"RIFF", b"RIFX", b"RF64", b"BW64", b"ID3", b"OggS", b"fLaC", b"\x1a\x45\xdf\xa3", b"\xff\xfb", b"\xff\xf3", b"\xff\xe2", b"\xff\xfa"]
+for trial in range(60000):
+    n = rng.choice([0, 2, 3, 4, 8, 11, 12, 40, 300, 1200, 3000])
+    data = bytearray(nprng.integers(0, 256, size=n, dtype=np.uint8).tobytes())
+    r = rng.random()
+    if r < 0.5 and n >= 4:
+        m = rng.choice(magic); data[: len(m)] = m[: len(data)]
+        if rng.random() < 0.5 and n >= 12: data[8:12] = rng.choice([b"WAVE", b"WAVX", b"AVI "])
+    if r < 0.35 and n >= 300:                                 # MPEG-like header chains
+        hdr = bytes([0xFF, rng.choice([0xFB, 0xF3, 0xE3, 0xFD, 0xFA, 0xF2]), rng.choice([0x00, 0x10, 0x50, 0x90, 0xE0, 0x92, 0x02]), 0])
+        data[:4] = hdr
+        step = rng.choice([24, 104, 144, 208, 313, 417, 418, 52, 96])
+        for k in range(1, 4):
+            if k * step + 4 <= n and rng.random() < 0.85: data[k * step: k * step + 4] = hdr
+    if 0.5 <= r < 0.6 and n >= 8: data[4:8] = b"ftyp"
+    data = bytes(data)
+    if bool(_ns2["_is_audio_container"](data)) != bool(is_audio_container(data)):
+        bad += 1
+        if bad < 6: print("SNIFF", data[:16], len(data))
+print("is_audio_container mismatches:", bad)

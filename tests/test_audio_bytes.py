@@ -1,0 +1,75 @@
+"""Bytes input (`load_bytes`, funasr/utils/load_utils.py:272-341): the scenarios of the reference's
+tests/test_load_audio_bytes.py that do not need a compressed-audio decoder, replayed against funasr_amd.audio."""
+import io
+import struct
+import wave
+
+import numpy as np
+import pytest
+
+from funasr_amd.audio import is_audio_container, load_audio
+
+
+def _sine_pcm(fs, duration=0.1):
+    t = np.arange(round(fs * duration), dtype=np.float64) / fs
+    return np.round(np.sin(2 * np.pi * 440 * t) * 12000).astype(np.int16)
+
+
+def _wav_bytes(samples, fs):
+    out = io.BytesIO()
+    with wave.open(out, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(fs)
+        f.writeframes(samples.tobytes())
+    return out.getvalue()
+
+
+def _rifx_bytes(samples, fs):
+    pcm = samples.astype(">i2").tobytes()
+    return (b"RIFX" + struct.pack(">I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack(">IHHIIHH", 16, 1, 1, fs, fs * 2, 2, 16)
+            + b"data" + struct.pack(">I", len(pcm)) + pcm)
+
+
+def _mp3_like(frames=3, bitrate_index=9, free_format=False):
+    """structurally valid MPEG-1 layer III frame headers (44.1 kHz) at the right spacing, zero payload"""
+    if free_format:
+        header, length = bytes([0xFF, 0xFB, 0x00, 0x00]), 200
+    else:
+        header = bytes([0xFF, 0xFB, bitrate_index << 4, 0x00])
+        length = 144 * (32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320)[bitrate_index - 1] * 1000 // 44100
+    return b"".join(header + bytes(length - 4) for _ in range(frames))
+
+
+def test_wav_containers_are_decoded_not_read_as_samples():
+    s = _sine_pcm(16000)
+    x = load_audio(_wav_bytes(s, 16000)).numpy()
+    assert x.dtype == np.float32 and np.allclose(x, s.astype(np.float32) / 32768.0, atol=1e-6)
+    y = load_audio(_wav_bytes(_sine_pcm(8000), 8000)).numpy()                  # 8 kHz container -> 16 kHz
+    assert len(y) == 1600 and np.isfinite(y).all() and float(np.abs(y).max()) > 0.1
+    be = np.array([-32768, -1000, 0, 1000, 32767], dtype=np.int16)
+    assert np.array_equal(load_audio(_rifx_bytes(be, 16000)).numpy(), be.astype(np.float32) / 32768.0)
+    for marker in (b"RF64", b"BW64"):                                           # recognised as containers (64-bit WAVE)
+        assert is_audio_container(marker + b"\xff\xff\xff\xffWAVEplaceholder")
+
+
+def test_raw_pcm_is_preserved_even_when_it_looks_like_a_header():
+    for raw in (np.array([-32768, -12345, 0, 12345, 32767], dtype=np.int16).tobytes(),
+                b"\xff\xfb\x00\x00\x39\x30\xc7\xcf",                            # first sample looks like an MPEG sync word
+                b"RIFF\x00\x00\x00\x00NOPE\x00\x00\x00\x00"):                   # RIFF, but not WAVE
+        assert not is_audio_container(raw)
+        assert np.array_equal(load_audio(raw).numpy(), np.frombuffer(raw, dtype=np.int16).astype(np.float32) / 32768.0)
+    raw = bytearray(np.arange(160, dtype=np.int16).tobytes())                  # sync-like words at inconsistent distances
+    for off in (0, 100, 210):
+        raw[off: off + 4] = b"\xff\xfb\x00\x00"
+    raw = bytes(raw)
+    assert np.array_equal(load_audio(raw).numpy(), np.frombuffer(raw, dtype=np.int16).astype(np.float32) / 32768.0)
+
+
+def test_compressed_containers_never_fall_back_to_raw_pcm():
+    for blob in (_mp3_like(), _mp3_like(free_format=True), b"ID3\x03\x00" + bytes(40), b"OggS" + bytes(40), b"fLaC" + bytes(40),
+                 bytes(4) + b"ftypisom" + bytes(20), b"\x1a\x45\xdf\xa3" + bytes(20), b"RIFF\x10\x00\x00\x00WAVEbroken"):
+        assert is_audio_container(blob)
+        with pytest.raises(RuntimeError, match="complete supported audio file"):
+            load_audio(blob)
+    assert not is_audio_container(_mp3_like(frames=1)) and not is_audio_container(b"\xff\xfb")
