@@ -15,7 +15,7 @@ from __future__ import annotations
 import io
 import os
 import wave
-from typing import List, Sequence, Union
+from typing import List
 
 import numpy as np
 import torch

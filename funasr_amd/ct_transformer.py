@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import copy
 import re
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, List, Sequence
 
 import numpy as np
 import torch
