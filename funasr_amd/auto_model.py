@@ -17,8 +17,10 @@ Model directory format (funasr/download/download_model_from_hub.py:80-97): `conf
 segments; the segments are sorted by length, packed into batches under the reference's `batch_size_s` /
 `batch_size_threshold_s` policy, decoded by the HIP path, put back in order and merged (texts joined, per-token
 timestamps shifted by the segment start); with a `punc_model` (CT-Transformer directory or object) the joined text is
-punctuated once per recording and `sentence_timestamp` cuts it into sentence records. The speaker branch raises. `vad_model` may also be a local FSMN-VAD model directory: the network runs on the GPU (funasr_amd/fsmn_vad.py), its
-decision logic on the host (funasr_amd/vad_decision.py).
+punctuated once per recording (results that carry `words` keep their spelling, funasr_amd/punc_align.py) and
+`sentence_timestamp` cuts it into sentence records. The speaker branch raises. `vad_model` may also be a local FSMN-VAD
+model directory: the network runs on the GPU (funasr_amd/fsmn_vad.py), its decision logic on the host
+(funasr_amd/vad_decision.py). `generate` ends with the text-level hotword correction (funasr_amd/postprocess_hotwords.py).
 
 When the real package is importable, use `funasr.AutoModel` itself after `funasr_amd.install()`.
 """
@@ -360,8 +362,9 @@ class AutoModel:
         return plan
 
     def inference_with_vad(self, input, input_len=None, **cfg):
-        """VAD -> length-sorted dynamic batches -> ASR -> merge (funasr/auto/auto_model.py:852-1254 without the
-        punctuation and speaker branches). Returns one dict per recording: key, text, [timestamp], [sentence_info]."""
+        """VAD -> length-sorted dynamic batches -> ASR -> merge -> punctuation -> sentence records
+        (funasr/auto/auto_model.py:852-1254 without the speaker branch). Returns one dict per recording: key, text,
+        [timestamp], [raw_text], [sentence_info]."""
         if self.vad_model is None:
             raise RuntimeError("inference_with_vad needs AutoModel(vad_model=<VAD model object>)")
         from .audio import load_audio_list
