@@ -10,9 +10,15 @@
  *   pf_encoder    <-> SANMEncoder.forward                    funasr/models/sanm/encoder.py:392-461
  *                     SenseVoiceEncoderSmall.forward         funasr/models/sense_voice/model.py:623-655
  *   pf_predictor  <-> CifPredictorV2.forward                 funasr/models/paraformer/cif_predictor.py:253-314
+ *                     CifPredictorV3.forward / get_upsample_timestamp (pf_predictor_create_v3, pf_predictor_timestamp)
+ *                                                            funasr/models/bicif_paraformer/cif_predictor.py:215-352
  *   pf_decoder    <-> ParaformerSANMDecoder.forward          funasr/models/paraformer/decoder.py:397-449
- *                     (+ log_softmax/argmax of Paraformer.inference, funasr/models/paraformer/model.py:345,642)
+ *                     (+ log_softmax/argmax of Paraformer.inference, funasr/models/paraformer/model.py:345,642;
+ *                      kernel_size 21 / vocab_size 0 = SeACo's bias decoder, funasr/models/seaco_paraformer/model.py:98-108)
  *   pf_ctc        <-> CTC.log_softmax / argmax               funasr/models/ctc/ctc.py:192-216
+ *   pf_stream     <-> ParaformerStreaming chunk step         funasr/models/paraformer_streaming/model.py
+ *   pf_vad, pf_vad_decision <-> FsmnVADStreaming (network / state machine)   funasr/models/fsmn_vad_streaming/{encoder,model}.py
+ *   pf_k_lstm     <-> torch.nn.LSTM layer (hotword encoder of SeACo, seaco_paraformer/model.py:388-424)
  *
  * The handle style (opaque pointer, int return codes, library-owned scratch) follows the reference's own C
  * API for the same path, runtime/onnxruntime/include/funasrruntime.h:21-24,58-73. Tensor names accepted by
