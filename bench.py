@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary measurements (fp32-MFMA mode, bf16-operand mode)")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3"], help="mode of the MAIN timed region: "
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3", "f16x2"], help="mode of the MAIN timed region: "
                     "bf16x3 (default) = fp32 results, GEMM operands as three bf16 planes on the bf16 MFMA; fp32 = every GEMM on "
                     "the fp32 MFMA; bf16 = bf16 operands (bf16-class error; for profiling the throughput mode)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (dry run of the N>1 code "
@@ -193,7 +193,10 @@ def main():
         lib.pf_prof_read(k, C.byref(ms), C.byref(work), C.byref(n))
         prof[name] = dict(ms_per_step=ms.value / args.steps, work_per_step=work.value / args.steps,
                           launches_per_step=n.value / args.steps)
-    if args.precision == "bf16x3":
+    if args.precision == "f16x2":
+        # dominant kernel: gemm_f16x2_kernel: 3 fp16 MFMA flops per algorithmic flop, ceiling = dense fp16 peak / 3
+        gemm, kname, peak = prof["gemm_bf16x3"], "gemm_f16x2_kernel", PEAK_BF16_MFMA_TFLOPS / 3
+    elif args.precision == "bf16x3":
         # dominant kernel: gemm_split3_kernel. `achieved` = algorithmic (fp32-equivalent) 2MNK flops per second; the
         # kernel executes 6 bf16 MFMA flops per algorithmic flop, so its ceiling is the dense bf16 peak / 6
         gemm, kname, peak = prof["gemm_bf16x3"], "gemm_split3_kernel", PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS
@@ -207,6 +210,9 @@ def main():
                     flops_per_launch=gemm["work_per_step"] / max(gemm["launches_per_step"], 1),
                     avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
                     launches_per_step=gemm["launches_per_step"])
+    if args.precision == "f16x2":
+        roofline.update(peak_note="dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent product",
+                        executed_f16_tflops=round(ach * 3, 1), fp32_mfma_peak_for_comparison=PEAK_F32_MFMA_TFLOPS)
     if args.precision == "bf16x3":
         roofline.update(peak_note="dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent product",
                         executed_bf16_tflops=round(ach * SPLIT3_PRODUCTS, 1),
@@ -253,7 +259,7 @@ def main():
                 "token_error_rate_vs_main": round(ter, 4)}
 
     bf16_mode = fp32_mfma_mode = None
-    if world == 1 and not args.no_bf16 and args.precision == "bf16x3":
+    if world == 1 and not args.no_bf16 and args.precision in ("bf16x3", "f16x2"):
         try:
             fp32_mfma_mode = time_mode("fp32")
             fp32_mfma_mode["dtype"] = "f32, every GEMM on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s peak)"
@@ -277,6 +283,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate",
+                  "f16x2": "f32 (GEMM / attention operands split into 2 fp16 planes, 3 fp16 MFMA products, f32 accumulate; all else f32)",
                   "bf16x3": "f32 (GEMM operands split into 3 bf16 planes, 6 bf16 MFMA products, f32 accumulate; all else f32)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"Paraformer-large (50 enc + 16 dec blocks, vocab 8404, random-init), "

@@ -1,0 +1,216 @@
+// Flash-style self-attention with fp32-class results on the fp16 matrix cores (d_k = 128): both products run as THREE
+// v_mfma_f32_32x32x16_f16 per operand pair on two-plane fp16 split operands (x * 2^e = hi + lo, gemm_f16x2.hip) with
+// fp32 accumulators and fp32 softmax statistics. Its operands arrive READY: the QKV projection's epilogue
+// (gemm_f16x2.hip, QKV form) writes Q (pre-multiplied by d_k^-0.5 like the reference) and K as row-major planes and V
+// as TRANSPOSED planes V^T[d][row], so no per-tile conversion pass is left in this kernel -- K and V^T tiles go HBM -> LDS
+// by asm-issued global_load_lds_dwordx4 one tile ahead and are consumed by ds_read_b128 as MFMA A operands.
+//
+// Reference semantics: funasr/models/sanm/attention.py:270-306,322-327 (scores, key mask -inf, softmax, mask 0, .V).
+//
+// Row layout: sequence b occupies rows [b Tp, b Tp + Tp), Tp % 16 == 0 (the encoder pads T; rows >= len hold finite
+// don't-care values, masked here). V^T columns are rows with bits 2 and 3 of the index swapped, so that the 8 keys whose
+// scores one lane's S^T accumulator registers hold ({0..3, 8..11} + 4 (lane >> 5) of a 16-key step) are one 16-B chunk.
+//
+// One workgroup = 8 waves = 256 queries of one (sequence, head); a wave owns 32 queries x d_k, a lane one query.
+// Per 32-key tile and wave: S^T[key][q] = K Q^T (A = K planes from LDS, B = Q planes in registers): 24 MFMAs; online
+// softmax per lane; O^T[d][q] += V^T[d][key] P^T[key][q] (A = V^T planes from LDS, B = P split in registers): 24 MFMAs.
+// 48 MFMAs per tile against 96 in attention_split3.hip, and no split pass.
+#include "common.h"
+
+namespace pf {
+
+namespace {
+
+constexpr int DK = 128, KT = 32;
+constexpr int KP_B = KT * DK * 2;                        // one K plane tile: 32 keys x 256 B
+constexpr int VP_B = DK * KT * 2;                        // one V^T plane tile: 128 d x 64 B
+constexpr int STAGE_B = 2 * KP_B + 2 * VP_B;             // 32 KB
+constexpr int OLD = DK + 4;                              // epilogue slab row (floats)
+constexpr int SLAB_B = 8 * 32 * OLD * 4;                 // 135168
+constexpr int LDS_BYTES = SLAB_B > 2 * STAGE_B ? SLAB_B : 2 * STAGE_B;
+constexpr float P_SCALE = 1024.f;                        // probabilities are split as p * 2^10 (p <= 1)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, idx = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q = blockIdx.x * 256 + wave * 32 + idx;
+    const int qc = q < p.Tp ? q : p.Tp - 1;
+    const int klen = p.klens[b];
+    const size_t row0 = (size_t)b * p.Tp;
+
+    // ---- Q planes: step s covers d in [16 s, 16 s + 16); half-wave h holds the 8 d's of chunk 2 s + h
+    f16x8 qf[2][8];
+    {
+        const unsigned short* qp = p.Q + (row0 + qc) * p.ldq + head * DK + hh * 8;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                qf[pl][s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(qp + pl * p.q_plane + 16 * s));
+    }
+
+    floatx16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- DMA of one tile: 32 pieces of 1 KB; wave w issues K plane 0 / 1 rows 4w..4w+3 and V^T plane 0 / 1 rows
+    //      16w..16w+15. K row r (256 B): chunk c at c ^ (r & 15); V^T row d (64 B): chunk c at c ^ ((d >> 2) & 3)
+    const unsigned short* ksrc;
+    const unsigned short* vsrc;
+    {
+        const int kr = wave * 4 + (lane >> 4);
+        ksrc = p.K + (row0 + kr) * p.ldk + head * DK + (((lane & 15) ^ (kr & 15)) * 8);
+        const int dr = wave * 16 + (lane >> 2);
+        vsrc = p.VT + (size_t)(head * DK + dr) * p.ldvt + row0 + (((lane & 3) ^ ((dr >> 2) & 3)) * 8);
+    }
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
+    auto stage = [&](int kt) {
+        const unsigned base = lds_w + (unsigned)(kt & 1) * STAGE_B;
+        const size_t ko = (size_t)kt * KT * p.ldk;
+        glds16(ksrc + ko, base);
+        glds16(ksrc + p.k_plane + ko, base + KP_B);
+        glds16(vsrc + kt * KT, base + 2 * KP_B);
+        glds16(vsrc + p.vt_plane + kt * KT, base + 2 * KP_B + VP_B);
+    };
+
+    const float sscale = p.sscale;                       // 2^-(e_q + e_k)
+    const int ntiles = (klen + KT - 1) / KT;
+    stage(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * KT;
+        glds_wait_all();
+        __syncthreads();                    // tile kt landed; every wave is done with tile kt-1 (the other buffer)
+        if (kt + 1 < ntiles) stage(kt + 1);
+        const unsigned char* sb_ = smem + (kt & 1) * STAGE_B;
+
+        // ---- S^T tile (32 keys x 32 queries): small products into sa, hi*hi into sb (no dependent MFMA pairs)
+        floatx16 sa, sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
+        {
+            const unsigned char* kp = sb_ + idx * 256;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int co = ((2 * st + hh) ^ (idx & 15)) * 16;
+                const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kp + co));
+                const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kp + KP_B + co));
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[0][st], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qf[0][st], sb, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qf[1][st], sa, 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax for query (lane & 31); this lane holds keys k0 + (r&3) + 8(r>>2) + 4h
+        float s[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            s[r] = key < klen ? (sa[r] + sb[r]) * sscale : -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T. step st uses this lane's registers r in [8st, 8st+8): keys 16st + 4h + {0..3, 8..11}
+        const unsigned char* vp = sb_ + 2 * KP_B + idx * 64;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            uint4 ph, pl;
+            split2_pk(s[8 * st + 0] * P_SCALE, s[8 * st + 1] * P_SCALE, ph.x, pl.x);
+            split2_pk(s[8 * st + 2] * P_SCALE, s[8 * st + 3] * P_SCALE, ph.y, pl.y);
+            split2_pk(s[8 * st + 4] * P_SCALE, s[8 * st + 5] * P_SCALE, ph.z, pl.z);
+            split2_pk(s[8 * st + 6] * P_SCALE, s[8 * st + 7] * P_SCALE, ph.w, pl.w);
+            const f16x8 Ph = __builtin_bit_cast(f16x8, ph), Pl = __builtin_bit_cast(f16x8, pl);
+            const int co = ((2 * st + hh) ^ ((idx >> 2) & 3)) * 16;
+            f16x8 vf[4][2];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int pn = 0; pn < 2; ++pn)
+                    vf[d][pn] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(vp + pn * VP_B + d * 32 * 64 + co));
+            // product-major: consecutive MFMAs write the four different d accumulators
+#define PF_PV(PV_, PP_) _Pragma("unroll") for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[d][PV_], PP_, o[d], 0, 0, 0)
+            PF_PV(1, Ph);
+            PF_PV(0, Pl);
+            PF_PV(0, Ph);
+#undef PF_PV
+        }
+    }
+
+    // ---- epilogue: O^T (lane = query, registers = d) -> wave-private slab [32 q][128 d] -> row-wise 16-B plane pieces
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * OLD);
+    {
+        const float inv = p.oscale / l_run;              // oscale = 2^(e_ctx - e_v) / P_SCALE
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = make_float4(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(slab + idx * OLD + d * 32 + 8 * g + 4 * hh) = t;
+            }
+    }
+    // same wave wrote and reads its slab: no workgroup barrier needed, only the LDS counter (the compiler waits)
+    const int qw0 = blockIdx.x * 256 + wave * 32;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int rr = it * 4 + (lane >> 4), c8 = (lane & 15) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(slab + rr * OLD + c8);
+        const float4 c = *reinterpret_cast<const float4*>(slab + rr * OLD + c8 + 4);
+        if (qw0 + rr < p.Tp) {
+            uint4 h, l;
+            split2_pk(a.x, a.y, h.x, l.x);
+            split2_pk(a.z, a.w, h.y, l.y);
+            split2_pk(c.x, c.y, h.z, l.z);
+            split2_pk(c.z, c.w, h.w, l.w);
+            unsigned short* op = p.O + (row0 + qw0 + rr) * p.ldo + head * DK + c8;
+            *reinterpret_cast<uint4*>(op) = h;
+            *reinterpret_cast<uint4*>(op + p.o_plane) = l;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
+    PF_REQUIRE(a.B > 0 && a.H > 0 && a.Tp > 0 && a.Tp % 16 == 0, "attention_f16x2: rows per sequence must be a positive multiple of 16");
+    PF_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 8 == 0 && a.q_plane % 8 == 0 &&
+               a.k_plane % 8 == 0 && a.vt_plane % 8 == 0 && a.o_plane % 8 == 0, "attention_f16x2: strides % 8");
+    PF_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 && ((uintptr_t)a.O & 15) == 0,
+               "attention_f16x2: 16-B alignment");
+    static bool configured = false;
+    if (!configured) {
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        configured = true;
+    }
+    dim3 grid(ceil_div(a.Tp, 256), a.H, a.B);
+    hipLaunchKernelGGL(attention_f16x2_kernel, grid, dim3(512), LDS_BYTES, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pf

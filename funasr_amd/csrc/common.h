@@ -87,6 +87,31 @@ __device__ __forceinline__ void store_split3x4(unsigned short* p, size_t plane, 
     *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2(l0, l1);
 }
 
+// ---------------------------------------------------------------- two-plane fp16 split (gemm_f16x2.hip)
+// x (already multiplied by the tensor's power-of-two scale) = hi + lo to 2^-24 |x|: hi = f16(x) (11 significand bits,
+// round to nearest even), lo = f16(x - hi) (the difference is exact in fp32; lo keeps its leading 11 bits, or every bit
+// down to 2^-24 once it is subnormal). |x| must stay below 65504: every producer's scale comes from an a-priori bound.
+typedef _Float16 pf_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+    const pf_floatx2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pf_f16x2));
+}
+__device__ __forceinline__ void split2_pk(float a, float b, unsigned& h, unsigned& l) {
+    const pf_floatx2 v = {a, b};
+    const pf_f16x2 hv = __builtin_convertvector(v, pf_f16x2);
+    const pf_floatx2 back = __builtin_convertvector(hv, pf_floatx2);
+    h = __builtin_bit_cast(unsigned, hv);
+    l = cvt_pk_f16(a - back.x, b - back.y);
+}
+// four consecutive values (times `scale`, a power of two) -> the two planes at p and p + plane (8-B stores)
+__device__ __forceinline__ void store_split2x4(unsigned short* p, size_t plane, const float (&o)[4], float scale) {
+    unsigned h0, l0, h1, l1;
+    split2_pk(o[0] * scale, o[1] * scale, h0, l0);
+    split2_pk(o[2] * scale, o[3] * scale, h1, l1);
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + plane) = make_uint2(l0, l1);
+}
+
 // ---------------------------------------------------------------- LDS-DMA issued behind the compiler's back
 // hipcc cannot prove that a ds_read does not alias an LDS-DMA in flight (SIInsertWaitcnts only separates them with
 // alias-scope metadata HIP does not attach), so with __builtin_amdgcn_global_load_lds it puts `s_waitcnt vmcnt(0)` in
@@ -149,14 +174,51 @@ int launch_gemm_split3(const Gemm3Args& a, hipStream_t stream);
 // fp32 [M, N] -> three bf16 planes [M, ldy]; columns N..ldy-1 are written as zero
 int launch_split3(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, hipStream_t stream);
 
+// fp32-accurate GEMM with both operands as TWO fp16 planes (gemm_f16x2.hip): x * 2^e = hi + lo; three MFMA products
+// (hi*hi + hi*lo + lo*hi) into one fp32 accumulator, the epilogue multiplies by `oscale` = 2^-(e_A + e_W) first
+struct Gemm2Args {
+    const unsigned short* A; int lda; size_t a_plane;   // [2][M, K] fp16
+    const unsigned short* W; int ldw; size_t w_plane;   // [2][N, K] fp16
+    float oscale;                                       // exact power of two
+    const float* bias;
+    const float* R1; int ldr1;                          // v = v + R1, then v = R2 + v (as GemmArgs)
+    const float* R2; int ldr2;
+    float* C; int ldc;                                  // fp32 output ...
+    unsigned short* C2; int ldc2; size_t c_plane;       // ... or (C2 != nullptr) two fp16 planes of result * cscale
+    float cscale;
+    int M, N, K;                                        // K % 32 == 0, N % 4 == 0
+    int relu;
+    int tile;                                           // 0 = pick by shape, 1 = 256 x 128, 2 = 256 x 256 (measurement hook)
+    // QKV form (qkv_D > 0, N == 3 qkv_D, qkv_D % 256 == 0, M % 16 == 0): the fused q|k|v projection feeding
+    // attention_f16x2.hip. Columns [0, D) -> planes of (result * q_mul) at Qp (ld D); [D, 2D) -> planes of
+    // (result * k_mul) at Kp; [2D, 3D) -> fp32 at C (ld ldc; the FSMN memory block reads it) and the TRANSPOSED
+    // planes of (result * v_mul) at VT[d][col(row)], col = row with bits 2 and 3 swapped
+    int qkv_D;
+    unsigned short* Qp; unsigned short* Kp; size_t qk_plane;
+    unsigned short* VT; int ldvt; size_t vt_plane;
+    float q_mul, k_mul, v_mul;
+};
+int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream);
+// fp32 [M, N] * scale -> two fp16 planes [M, ldy]; columns N..ldy-1 are written as zero
+int launch_split2(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, float scale,
+                  hipStream_t stream);
+// max |x| over n floats -> *out_dev (one float, device); load-time helper for the per-tensor weight scale
+int launch_absmax(const float* x, size_t n, float* out_dev, hipStream_t stream);
+// max over rows n of (in_bound * sum_k |W[n, k]| + |bias[n]|) -> *out_dev: a-priori bound on a Linear's outputs
+int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* bias, float in_bound, float* out_dev,
+                       hipStream_t stream);
+
+// out_mode 3: y receives the two fp16 planes of result * oscale (gemm_f16x2.hip); seq_out > 0: output row
+// b * seq_out + t reads input row b * seq_in + t
 // out_mode 1 / in_bf16: y / x is a bf16 buffer (ldy / ldx in elements); out_mode 2: y receives the three bf16 planes
 // of the result (split3), `plane` elements apart; statistics are always fp32
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
                      int M, int D, int Dpad, float eps, hipStream_t stream, int out_mode = 0, int in_bf16 = 0,
-                     size_t plane = 0);
+                     size_t plane = 0, float oscale = 1.f, int seq_out = 0, int seq_in = 0);
 
+// Tp > T: y is the padded layout [B, Tp, D] (rows t >= T zero)
 int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
-                        hipStream_t stream);
+                        hipStream_t stream, int Tp = 0);
 
 struct FsmnArgs {
     const float* in;  int ldin;   // [B*T, C] view (row stride ldin)
@@ -190,6 +252,18 @@ int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
 int launch_attention_bf16(const AttnArgs& a, hipStream_t stream);
 // fp32 in / fp32 (or plane) out like launch_attention_f32, both products on the bf16 MFMA from three-plane split operands
 int launch_attention_split3(const AttnArgs& a, hipStream_t stream);
+// self-attention on two-plane fp16 operands written by the QKV form of gemm_f16x2.hip (attention_f16x2.hip)
+struct Attn2Args {
+    const unsigned short* Q; int ldq; size_t q_plane;     // [2][B Tp, H 128] fp16 planes of q * d_k^-0.5 * 2^e_q
+    const unsigned short* K; int ldk; size_t k_plane;     // [2][B Tp (+32 rows slack), H 128] planes of k * 2^e_k
+    const unsigned short* VT; int ldvt; size_t vt_plane;  // [2][H 128, ldvt >= B Tp + 32] transposed planes of v * 2^e_v
+    unsigned short* O; int ldo; size_t o_plane;           // [2][B Tp, H 128] planes of the result * 2^e_ctx
+    const int* klens;                                     // device int32 [B] valid keys per sequence (1 .. Tp)
+    int B, H, Tp;                                         // Tp % 16 == 0
+    float sscale;                                         // 2^-(e_q + e_k)
+    float oscale;                                         // 2^(e_ctx - e_v - 10)
+};
+int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream);
 
 // small heads (d_k <= 64) on short sequences: plain fp32 FMAs, one wave per query (attention_small.hip)
 bool attention_small_applicable(const AttnArgs& a, int dk);

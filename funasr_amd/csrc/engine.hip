@@ -187,6 +187,51 @@ struct TensorTable {
         b16[key] = p;
         return p;
     }
+    // the two fp16 planes [2][rows, cols] of weight * 2^e (gemm_f16x2.hip), e from max |w| so that the largest hi lies in
+    // [2^14, 2^15); cached like the bf16 copies, the exponent beside it
+    std::map<std::string, int> exp2;
+    const unsigned short* get_split2(const std::string& name, int rows, int cols, int* e_out, hipStream_t s) {
+        const std::string key = name + "#split2";
+        auto it = b16.find(key);
+        if (it != b16.end()) { *e_out = exp2[key]; return it->second; }
+        const Tensor& x = t.at(name);
+        const size_t n = x.kind == 1 ? (size_t)x.rows * x.cols_pad : (size_t)x.numel;
+        float amax = 0.f;
+        if (n != (size_t)rows * cols || cols % 8 != 0 || dev_absmax(x.d, n, &amax, s)) {
+            set_error("split2 planes of " + name + " failed");
+            return nullptr;
+        }
+        const int e = amax > 0.f ? 14 - (int)floorf(log2f(amax)) : 0;
+        unsigned short* p = nullptr;
+        if (e < -100 || e > 100 || hipMalloc((void**)&p, sizeof(unsigned short) * 2 * n) != hipSuccess) {
+            set_error("split2 planes of " + name + " failed");
+            return nullptr;
+        }
+        if (launch_split2(x.d, cols, p, cols, n, rows, cols, ldexpf(1.f, e), s)) { (void)hipFree(p); return nullptr; }
+        b16[key] = p; exp2[key] = e; *e_out = e;
+        return p;
+    }
+    // load-time reductions (one float back to the host)
+    static int dev_absmax(const float* x, size_t n, float* out, hipStream_t s) {
+        float* d = nullptr;
+        PF_HIP_TRY(hipMalloc((void**)&d, sizeof(float)));
+        int rc = launch_absmax(x, n, d, s);
+        if (!rc && hipMemcpyAsync(out, d, sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) rc = -2;
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = -2;
+        (void)hipFree(d);
+        return rc;
+    }
+    // max over rows n of (in_bound * sum_k |W[n, k]| + |bias[n]|): an a-priori bound on |W x + b| for |x_k| <= in_bound
+    static int dev_linear_bound(const float* W, int rows, int cols, int ld, const float* bias, float in_bound, float* out,
+                                hipStream_t s) {
+        float* d = nullptr;
+        PF_HIP_TRY(hipMalloc((void**)&d, sizeof(float)));
+        int rc = launch_rowl1_bound(W, rows, cols, ld, bias, in_bound, d, s);
+        if (!rc && hipMemcpyAsync(out, d, sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) rc = -2;
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = -2;
+        (void)hipFree(d);
+        return rc;
+    }
     const unsigned short* get_bf16(const std::string& name, hipStream_t s) {
         auto it = b16.find(name);
         if (it != b16.end()) return it->second;
@@ -340,6 +385,10 @@ struct EncLayerW {
     int in_dim, in_pad;
     const unsigned short *qkv_w16 = nullptr, *out_w16 = nullptr, *w1_16 = nullptr, *w2_16 = nullptr;   // bf16 mode
     const unsigned short *qkv_w3 = nullptr, *out_w3 = nullptr, *w1_3 = nullptr, *w2_3 = nullptr;       // bf16x3 mode
+    // f16x2 mode: weight planes with their exponents, and the exponents of the activation planes (from a-priori bounds)
+    const unsigned short *qkv_w2 = nullptr, *out_w2 = nullptr, *w1_2 = nullptr, *w2_2 = nullptr;
+    int ew_qkv = 0, ew_out = 0, ew_1 = 0, ew_2 = 0;
+    int e_x1 = 0, e_q = 0, e_k = 0, e_v = 0, e_x2 = 0, e_h = 0;
     std::string prefix;
 };
 
@@ -354,7 +403,19 @@ struct Encoder {
     // 2: fp32 results from bf16x3 split operands on the bf16 MFMA (gemm_split3.hip), everything else as in mode 0
     int precision = 0;
     DevBuf xn16, qkv16, ctx16, ffn16;   // mode 1: bf16 activations; mode 2: xn16 / ctx16 / ffn16 hold three planes each
+    // mode 3 (f16x2): xn16 / ctx16 / ffn16 hold two fp16 planes each; q2 / k2 / vt2 are the attention operands the QKV
+    // projection writes (k2 with 32 rows of slack per plane, vt2 rows of Mp + 64 columns: tiles may run past the last row)
+    DevBuf q2, k2, vt2;
+    int Tp = 0;                         // rows per sequence of the current forward (T, or T rounded up to 16 in mode 3)
 };
+
+// exponent e with bound * 2^e <= 2^15 (a factor 2 under fp16's 65504 for the roundings on the way)
+static int exp_for_bound(float bound) {
+    if (!(bound > 0.f)) return 15;
+    int e = (int)floorf(log2f(32768.f / bound));
+    return e > 15 ? 15 : e;
+}
+static float pow2f(int e) { return ldexpf(1.f, e); }
 
 static void enc_layer_names(std::vector<std::pair<std::string, int>>& out, const pf_encoder_config& c) {
     // (prefix, input_dim) of every SAN-M block in execution order
@@ -429,7 +490,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
     float* ffn = e->ffn.as<float>();
     const int* lens = cc ? cc->lens : e->lens.as<int>();
     int rc;
-    if (e->precision != 0 && D / c.n_heads != 128) { set_error("encoder: the bf16 / bf16x3 modes need d_model / n_heads == 128"); return -1; }
+    if (e->precision != 0 && D / c.n_heads != 128) { set_error("encoder: the bf16 / bf16x3 / f16x2 modes need d_model / n_heads == 128"); return -1; }
     if (e->precision == 1 && !cc) {
         // ---- bf16-operand mode: LN writes bf16, GEMMs and attention take bf16 operands with fp32 accumulation, the
         //      residual stream x, the FSMN memory and every epilogue stay fp32
@@ -519,6 +580,70 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         }
         if ((rc = gemm3(xn3, D, w.w1_3, w.b1, nullptr, 0, ffn3, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
         return gemm3(ffn3, F, w.w2_3, w.b2, x, D, nullptr, D, F, 0, nullptr, 0, x, D);
+    }
+    if (e->precision == 3 && !cc) {
+        // ---- fp32-accurate mode on the fp16 matrix cores, three products per result (gemm_f16x2.hip, attention_f16x2.hip):
+        //      every GEMM / attention operand is two fp16 planes of the tensor times a power of two; T is padded to Tp
+        //      (B here = sequences, T = Tp rows each); FSMN, residuals, LayerNorm statistics, softmax stay fp32
+        unsigned short* xn2 = e->xn16.as<unsigned short>();
+        unsigned short* ctx2 = e->ctx16.as<unsigned short>();
+        unsigned short* ffn2 = e->ffn16.as<unsigned short>();
+        unsigned short* q2 = e->q2.as<unsigned short>();
+        unsigned short* k2 = e->k2.as<unsigned short>();
+        unsigned short* vt2 = e->vt2.as<unsigned short>();
+        const int ldvt = M + 64;
+        float* vbuf = qkv;                                  // fp32 v projection [M, D] for the FSMN memory block
+        auto gemm2 = [&](const unsigned short* A, int lda, int ea, const unsigned short* W, int ew, const float* bias, float* C,
+                         int ldc, unsigned short* C2, int ec, int N, int K, int relu, const float* R1, int ldr1,
+                         const float* R2, int ldr2) {
+            Gemm2Args g{};
+            g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)N * K;
+            g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
+            g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = N; g.c_plane = (size_t)M * N; g.cscale = pow2f(ec);
+            g.M = M; g.N = N; g.K = K; g.relu = relu;
+            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
+            return launch_gemm_f16x2(g, s);
+        };
+        {
+            ProfScope ps(PROF_LN, 8.0 * M * (double)w.in_dim, s);
+            if ((rc = launch_layernorm(x_in, ld_in, w.n1g, w.n1b, reinterpret_cast<float*>(xn2), w.in_pad, M, w.in_dim,
+                                       w.in_pad, c.ln_eps, s, 3, 0, (size_t)M * w.in_pad, pow2f(w.e_x1)))) return rc;
+        }
+        const float dk_scale = powf((float)(D / c.n_heads), -0.5f);
+        {
+            Gemm2Args g{};
+            g.A = xn2; g.lda = w.in_pad; g.a_plane = (size_t)M * w.in_pad; g.W = w.qkv_w2; g.ldw = w.in_pad;
+            g.w_plane = (size_t)3 * D * w.in_pad; g.oscale = pow2f(-(w.e_x1 + w.ew_qkv)); g.bias = w.qkv_b;
+            g.C = vbuf; g.ldc = D; g.M = M; g.N = 3 * D; g.K = w.in_pad;
+            g.qkv_D = D; g.Qp = q2; g.Kp = k2; g.qk_plane = (size_t)(M + 32) * D;
+            g.VT = vt2; g.ldvt = ldvt; g.vt_plane = (size_t)D * ldvt;
+            g.q_mul = dk_scale * pow2f(w.e_q); g.k_mul = pow2f(w.e_k); g.v_mul = pow2f(w.e_v);
+            ProfScope ps(PROF_GEMM3, 2.0 * M * 3.0 * D * w.in_pad, s);
+            if ((rc = launch_gemm_f16x2(g, s))) return rc;
+        }
+        FsmnArgs fa{};
+        fa.in = vbuf; fa.ldin = D; fa.w = w.fsmn_w; fa.R = nullptr; fa.ldr = 0; fa.out = mem; fa.ldo = D;
+        fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size;
+        fa.left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
+        if ((rc = fsmn(fa, s))) return rc;
+        {
+            Attn2Args aa{};
+            aa.Q = q2; aa.ldq = D; aa.q_plane = (size_t)(M + 32) * D; aa.K = k2; aa.ldk = D; aa.k_plane = (size_t)(M + 32) * D;
+            aa.VT = vt2; aa.ldvt = ldvt; aa.vt_plane = (size_t)D * ldvt;
+            aa.O = ctx2; aa.ldo = D; aa.o_plane = (size_t)M * D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tp = T;
+            aa.sscale = pow2f(-(w.e_q + w.e_k)); aa.oscale = pow2f(-10);      // ctx planes carry v's exponent
+            ProfScope ps(PROF_ATTN, 4.0 * B * (double)T * T * D, s);
+            if ((rc = launch_attention_f16x2(aa, s))) return rc;
+        }
+        const float* resid2 = (w.in_dim == D) ? x_in : nullptr;
+        if ((rc = gemm2(ctx2, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid2, ld_in))) return rc;
+        {
+            ProfScope ps(PROF_LN, 8.0 * M * (double)D, s);
+            if ((rc = launch_layernorm(x, D, w.n2g, w.n2b, reinterpret_cast<float*>(xn2), D, M, D, D, c.ln_eps, s, 3, 0,
+                                       (size_t)M * D, pow2f(w.e_x2)))) return rc;
+        }
+        if ((rc = gemm2(xn2, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
+        return gemm2(ffn2, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D);
     }
     // norm1 -> fused QKV projection
     if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
@@ -1151,7 +1276,7 @@ int pf_encoder_set_tensor(pf_encoder* eh, const char* name, const float* data, i
  * residual stream / LayerNorm statistics / softmax / FSMN): the throughput mode of BASELINE configs[1] */
 int pf_encoder_set_precision(pf_encoder* eh, int32_t mode) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);
-    PF_REQUIRE(e && mode >= 0 && mode <= 2, "encoder_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 operands) or 2 (fp32 via bf16x3)");
+    PF_REQUIRE(e && mode >= 0 && mode <= 3, "encoder_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 operands), 2 (fp32 via bf16x3) or 3 (fp32 via f16x2)");
     e->precision = mode;
     return 0;
 }
@@ -1169,9 +1294,49 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
     int rc;
     if (!e->resolved && (rc = encoder_resolve(e))) return rc;
     const pf_encoder_config& c = e->cfg;
-    const size_t M = (size_t)B * T;
+    // f16x2 mode: every sequence occupies Tp = T rounded up to 16 rows (attention_f16x2.hip's tile alignment); the
+    // extra rows are zero on entry, masked as keys, never returned
+    const bool x2 = e->precision == 3 && c.d_model / c.n_heads == 128 && c.d_model % 256 == 0;
+    const int Tp = x2 ? round_up(T, 16) : T;
+    e->Tp = Tp;
+    const size_t M = (size_t)B * Tp;
     const int D = c.d_model, F = c.ffn_dim, Din = c.input_dim, Dpad = round_up(Din, 64);
     const int Fbuf = F > Din ? F : Din;
+    if (e->precision == 3 && !x2) { set_error("encoder: the f16x2 mode needs d_model / n_heads == 128 and d_model % 256 == 0"); return -1; }
+    if (x2) {
+        const size_t cap_q = e->q2.cap, cap_k = e->k2.cap, cap_v = e->vt2.cap;
+        if (e->xn16.ensure(sizeof(unsigned short) * 2 * M * (Dpad > D ? Dpad : D)) ||
+            e->ctx16.ensure(sizeof(unsigned short) * 2 * M * D) || e->ffn16.ensure(sizeof(unsigned short) * 2 * M * F) ||
+            e->q2.ensure(sizeof(unsigned short) * 2 * (M + 32) * D) || e->k2.ensure(sizeof(unsigned short) * 2 * (M + 32) * D) ||
+            e->vt2.ensure(sizeof(unsigned short) * 2 * D * (M + 64)))
+            return -2;
+        // slack rows / columns past the last sequence are read by the last key tile (and masked): keep them finite
+        if (e->q2.cap != cap_q) PF_HIP_TRY(hipMemsetAsync(e->q2.p, 0, e->q2.cap, s));
+        if (e->k2.cap != cap_k) PF_HIP_TRY(hipMemsetAsync(e->k2.p, 0, e->k2.cap, s));
+        if (e->vt2.cap != cap_v) PF_HIP_TRY(hipMemsetAsync(e->vt2.p, 0, e->vt2.cap, s));
+        const float dk_scale = powf((float)(D / c.n_heads), -0.5f);
+        for (auto& w : e->layers) {
+            if (w.qkv_w2) continue;
+            const std::string qkv_name = w.prefix + "self_attn.linear_q_k_v.weight";
+            w.qkv_w2 = e->tt.get_split2(qkv_name, 3 * D, w.in_pad, &w.ew_qkv, s);
+            w.out_w2 = e->tt.get_split2(w.prefix + "self_attn.linear_out.weight", D, D, &w.ew_out, s);
+            w.w1_2 = e->tt.get_split2(w.prefix + "feed_forward.w_1.weight", F, D, &w.ew_1, s);
+            w.w2_2 = e->tt.get_split2(w.prefix + "feed_forward.w_2.weight", D, F, &w.ew_2, s);
+            if (!w.qkv_w2 || !w.out_w2 || !w.w1_2 || !w.w2_2) return -2;
+            // a-priori bounds -> plane exponents. LayerNorm: |y| <= sqrt(D) max|gamma| + max|beta|; a Linear over inputs
+            // bounded by b: |W x + c| <= b max_n sum_k |W[n, k]| + |c[n]|; attention output <= max |v|; relu only shrinks
+            float g1, b1, g2, b2, bq, bk, bv, bh;
+            if (TensorTable::dev_absmax(w.n1g, w.in_dim, &g1, s) || TensorTable::dev_absmax(w.n1b, w.in_dim, &b1, s) ||
+                TensorTable::dev_absmax(w.n2g, D, &g2, s) || TensorTable::dev_absmax(w.n2b, D, &b2, s)) return -2;
+            const float bx1 = sqrtf((float)w.in_dim) * g1 + b1, bx2 = sqrtf((float)D) * g2 + b2;
+            if (TensorTable::dev_linear_bound(w.qkv_w, D, w.in_pad, w.in_pad, w.qkv_b, bx1, &bq, s) ||
+                TensorTable::dev_linear_bound(w.qkv_w + (size_t)D * w.in_pad, D, w.in_pad, w.in_pad, w.qkv_b + D, bx1, &bk, s) ||
+                TensorTable::dev_linear_bound(w.qkv_w + (size_t)2 * D * w.in_pad, D, w.in_pad, w.in_pad, w.qkv_b + 2 * D, bx1, &bv, s) ||
+                TensorTable::dev_linear_bound(w.w1, F, D, D, w.b1, bx2, &bh, s)) return -2;
+            w.e_x1 = exp_for_bound(bx1); w.e_x2 = exp_for_bound(bx2);
+            w.e_q = exp_for_bound(bq * dk_scale); w.e_k = exp_for_bound(bk); w.e_v = exp_for_bound(bv); w.e_h = exp_for_bound(bh);
+        }
+    }
     if (e->precision == 1) {
         if (e->xn16.ensure(sizeof(unsigned short) * M * (Dpad > D ? Dpad : D)) || e->qkv16.ensure(sizeof(unsigned short) * M * 3 * D) ||
             e->ctx16.ensure(sizeof(unsigned short) * M * D) || e->ffn16.ensure(sizeof(unsigned short) * M * F))
@@ -1211,17 +1376,20 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
     // it in norm1 (and as residual when input_dim == d_model) strictly before its own FFN overwrites that buffer.
     float* x0 = e->ffn.as<float>();
     const float scale = (float)sqrt((double)D);
-    if ((rc = launch_scale_add_pe(xs, pe, x0, B, T, Din, scale, s))) return rc;
+    if ((rc = launch_scale_add_pe(xs, pe, x0, B, T, Din, scale, s, Tp))) return rc;
     float* x = e->x.as<float>();
     const int total = (int)e->layers.size();
     const int nrun = run_blocks < 0 ? total : (run_blocks < total ? run_blocks : total);
-    if (nrun == 0) {
-        PF_HIP_TRY(hipMemcpyAsync(out, x0, sizeof(float) * M * Din, hipMemcpyDeviceToDevice, s));
+    // [B, Tp, w] workspace rows -> the caller's [B, T, w]
+    auto unpad_copy = [&](const float* src, int w) -> int {
+        PF_HIP_TRY(hipMemcpy2DAsync(out, sizeof(float) * (size_t)T * w, src, sizeof(float) * (size_t)Tp * w,
+                                    sizeof(float) * (size_t)T * w, B, hipMemcpyDeviceToDevice, s));
         return 0;
-    }
+    };
+    if (nrun == 0) return unpad_copy(x0, Din);
     for (int l = 0; l < nrun; ++l) {
-        if (l == 0) rc = encoder_block(e, e->layers[0], x0, Din, x, B, T, s);
-        else rc = encoder_block(e, e->layers[l], x, D, x, B, T, s);
+        if (l == 0) rc = encoder_block(e, e->layers[0], x0, Din, x, B, Tp, s);
+        else rc = encoder_block(e, e->layers[l], x, D, x, B, Tp, s);
         if (rc) return rc;
         if (c.tp_blocks > 0 && l + 1 == c.n_blocks && (run_blocks < 0 || nrun > c.n_blocks)) {
             // SenseVoice: after_norm sits between `encoders` and `tp_encoders` (sense_voice/model.py:645-652)
@@ -1229,13 +1397,12 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
                                 c.ln_eps, s))) return rc;
         }
     }
-    if (run_blocks >= 0) {
-        PF_HIP_TRY(hipMemcpyAsync(out, x, sizeof(float) * M * D, hipMemcpyDeviceToDevice, s));
-        return 0;
-    }
+    if (run_blocks >= 0) return unpad_copy(x, D);
     const char* fin_w = c.tp_blocks > 0 ? "tp_norm.weight" : "after_norm.weight";
     const char* fin_b = c.tp_blocks > 0 ? "tp_norm.bias" : "after_norm.bias";
-    return layernorm(x, D, e->tt.get(fin_w), e->tt.get(fin_b), out, D, (int)M, D, D, c.ln_eps, s);
+    if (Tp == T) return layernorm(x, D, e->tt.get(fin_w), e->tt.get(fin_b), out, D, (int)M, D, D, c.ln_eps, s);
+    ProfScope ps(PROF_LN, 8.0 * B * (double)T * D, s);
+    return launch_layernorm(x, D, e->tt.get(fin_w), e->tt.get(fin_b), out, D, B * T, D, D, c.ln_eps, s, 0, 0, 0, 1.f, T, Tp);
 }
 
 // ------------------------------------------------------------------------------------------------- predictor
@@ -1529,7 +1696,7 @@ int pf_decoder_set_tensor(pf_decoder* dh, const char* name, const float* data, i
 /* same modes as pf_encoder_set_precision; the bf16 mode serves the fused arg-max route (logits_dev == NULL) */
 int pf_decoder_set_precision(pf_decoder* dh, int32_t mode) {
     Decoder* d = reinterpret_cast<Decoder*>(dh);
-    PF_REQUIRE(d && mode >= 0 && mode <= 2, "decoder_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 operands) or 2 (fp32 via bf16x3)");
+    PF_REQUIRE(d && mode >= 0 && mode <= 3, "decoder_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 operands), 2 (fp32 via bf16x3) or 3 (fp32 via f16x2)");
     d->precision = mode;
     return 0;
 }
@@ -1571,7 +1738,7 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     if (d->precision == 1 && !logits) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
     // bf16x3 mode: the two GEMMs that are large at every batch size (w_1: N = ffn_dim; linear_k_v: M = B * T) take
     // three-plane operands on the bf16 matrix cores; the D x D projections and w_2 keep the fp32 MFMA tiles
-    const bool x3 = d->precision == 2;
+    const bool x3 = d->precision == 2 || d->precision == 3;
     const unsigned short* mem3 = nullptr;
     if (x3) {
         if (d->t16.ensure(sizeof(unsigned short) * 3 * (size_t)Mq * D) || d->mem16.ensure(sizeof(unsigned short) * 3 * (size_t)Mk * D))
@@ -2065,6 +2232,42 @@ int pf_k_gemm_split3(const void* A3, int32_t lda, int64_t a_plane, const void* W
     PF_HIP_TRY(hipEventCreate(&b));
     PF_HIP_TRY(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) if ((rc = launch_gemm_split3(g, s))) return rc;
+    PF_HIP_TRY(hipEventRecord(b, s));
+    PF_HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    PF_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_out = ms / iters;
+    return 0;
+}
+/* fp32 [M, N] * scale (a power of two) -> two fp16 planes [2][M, ldy] (gemm_f16x2.hip) */
+int pf_k_split2(const float* x, int32_t ldx, void* y2, int32_t ldy, int64_t plane, int32_t M, int32_t N, float scale,
+                void* stream) {
+    return launch_split2(x, ldx, reinterpret_cast<unsigned short*>(y2), ldy, (size_t)plane, M, N, scale,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+/* fp32-accurate GEMM from two-plane fp16 operands; tile: 0 by shape, 1 = 256 x 128, 2 = 256 x 256;
+ * iters > 0 with ms_out: additionally times `iters` back-to-back launches (after 3 warm-up launches) */
+int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane,
+                    float oscale, const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2,
+                    float* C, int32_t ldc, void* C2, int32_t ldc2, int64_t c_plane, float cscale, int32_t M, int32_t N,
+                    int32_t K, int32_t relu, int32_t tile, int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Gemm2Args g{};
+    g.A = reinterpret_cast<const unsigned short*>(A2); g.lda = lda; g.a_plane = (size_t)a_plane;
+    g.W = reinterpret_cast<const unsigned short*>(W2); g.ldw = ldw; g.w_plane = (size_t)w_plane; g.oscale = oscale;
+    g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
+    g.C2 = reinterpret_cast<unsigned short*>(C2); g.ldc2 = ldc2; g.c_plane = (size_t)c_plane; g.cscale = cscale;
+    g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = tile;
+    int rc;
+    if (iters <= 0 || !ms_out) return launch_gemm_f16x2(g, s);
+    for (int i = 0; i < 3; ++i) if ((rc = launch_gemm_f16x2(g, s))) return rc;
+    hipEvent_t a, b;
+    PF_HIP_TRY(hipEventCreate(&a));
+    PF_HIP_TRY(hipEventCreate(&b));
+    PF_HIP_TRY(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if ((rc = launch_gemm_f16x2(g, s))) return rc;
     PF_HIP_TRY(hipEventRecord(b, s));
     PF_HIP_TRY(hipEventSynchronize(b));
     float ms = 0.f;

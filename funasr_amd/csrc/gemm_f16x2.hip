@@ -1,0 +1,357 @@
+// fp32-accurate GEMM on the fp16 matrix cores with THREE products per result instead of the six of gemm_split3.hip:
+// C = epilogue(A[M,K] * W[N,K]^T) with both operands held as TWO fp16 planes of the pre-scaled tensor
+//     x * 2^e = hi + lo,   hi = f16(x * 2^e),  lo = f16(x * 2^e - hi)        (11 + 11 significand bits + lo's sign)
+// and v_mfma_f32_32x32x16_f16 products  hi*hi + hi*lo + lo*hi  into ONE fp32 accumulator (each f16 x f16 product is
+// exact in fp32). What is dropped or rounded away is <= 2^-24 |a||w| per term (lo*lo, and lo's own rounding): the size
+// of fp32's product rounding, like the terms gemm_split3.hip drops. fp16 has 5 exponent bits, so the planes carry a
+// per-tensor power-of-two scale 2^e chosen from an a-priori bound (weights: max |w| at load; activations: the LayerNorm
+// / attention / ReLU bounds engine.hip derives from the parameters), which keeps every hi below 65504 and puts the
+// typical lo far above fp16's subnormal step 2^-24; the epilogue undoes both scales with one exact multiplication.
+// Matrix-pipe ceiling 2.5 PFLOP/s / 3 = 833 TFLOP/s of fp32-equivalent work. Same call sites as gemm_f32.hip /
+// gemm_split3.hip (funasr/models/sanm/attention.py:256,306, funasr/models/transformer/positionwise_feed_forward.py:32).
+//
+// Design (gfx950): as gemm_split3.hip -- 8 waves in a 4 x 2 grid, 32-deep K stages of 64-B LDS rows moved HBM -> LDS by
+// asm-issued global_load_lds_dwordx4 pieces (double buffered, one piece per group of MFMAs), chunk swizzle
+// c ^ ((r >> 2) & 3), XCD-aware block order, LDS-slab float4 epilogue -- in two block shapes:
+//   256 x 128 (wave = 2 x 2 MFMA tiles):  8 ds_read_b128 + 12 MFMA per 16-deep step, 48-KB stages
+//   256 x 256 (wave = 2 x 4 MFMA tiles): 12 ds_read_b128 + 24 MFMA per 16-deep step, 64-KB stages, 2/3 of the L2 -> LDS
+//                                         bytes per flop: the shape for N >= 1024
+#include "common.h"
+
+namespace pf {
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// wave grid 4 (M) x 2 (N); a wave owns WM x WN tiles of 32 x 32
+template <int WM, int WN> struct Geo2 {
+    static constexpr int BM = 4 * WM * 32, BN = 2 * WN * 32;
+    static constexpr int KS = 32, ROWB = 64, CPR = 4, RPP = 16;
+    static constexpr int A_PLANE_B = BM * ROWB, B_PLANE_B = BN * ROWB;
+    static constexpr int STAGE_B = 2 * (A_PLANE_B + B_PLANE_B);
+    static constexpr int NPIECE = STAGE_B / 1024;               // 48 / 64
+    static constexpr int A_PIECES = 2 * BM / RPP;
+    static constexpr int PPW = NPIECE / 8;                      // 6 / 8
+    static constexpr int ELD = WN * 32 + 4;                     // epilogue slab row (floats)
+    static constexpr int SLAB_B = 8 * 32 * ELD * 4;
+    static constexpr int LDS_B = 2 * STAGE_B > SLAB_B ? 2 * STAGE_B : SLAB_B;
+};
+
+template <int WM, int WN, int MODE, int OUT>   // OUT: 0 fp32 C, 1 two fp16 planes, 2 the QKV form (Gemm2Args)
+__global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM, int nN) {
+    typedef Geo2<WM, WN> G;
+    constexpr int BM = G::BM, BN = G::BN, KS = G::KS, ROWB = G::ROWB, CPR = G::CPR, RPP = G::RPP, PPW = G::PPW;
+    constexpr int STAGE_B = G::STAGE_B, A_PLANE_B = G::A_PLANE_B, B_PLANE_B = G::B_PLANE_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int L = blockIdx.x;
+    const int xcd = L & 7, j8 = L >> 3;
+    const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
+    if (mblk >= nM) return;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int hh = lane >> 5, idx = lane & 31;
+
+    // ---- DMA sources: a stage is NPIECE pieces of 1 KB (16 rows of one plane), the A planes first, then the W planes,
+    //      linear in LDS; wave w issues pieces w, w + 8, ...; lane l lands at row l / 4, physical chunk l % 4 and
+    //      fetches the logical chunk the read-side swizzle expects there
+    const unsigned short* src[PPW];
+    {
+        const int prow = lane / CPR;
+        const int chunk = (lane % CPR) ^ ((prow >> 2) & (CPR - 1));
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave + 8 * i;
+            if (q < G::A_PIECES) {
+                int row = m0 + (q % (BM / RPP)) * RPP + prow;
+                row = row < p.M ? row : p.M - 1;
+                src[i] = p.A + (size_t)(q / (BM / RPP)) * p.a_plane + (size_t)row * p.lda + chunk * 8;
+            } else {
+                const int qq = q - G::A_PIECES;
+                int col = n0 + (qq % (BN / RPP)) * RPP + prow;
+                col = col < p.N ? col : p.N - 1;
+                src[i] = p.W + (size_t)(qq / (BN / RPP)) * p.w_plane + (size_t)col * p.ldw + chunk * 8;
+            }
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
+    auto piece = [&](int i, int buf, int kt) {
+        glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * 8192);
+    };
+
+    floatx16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    const int f = (idx >> 2) & (CPR - 1);
+    const int aoff = (wr * (WM * 32) + idx) * ROWB;
+    const int boff = 2 * A_PLANE_B + (wc * (WN * 32) + idx) * ROWB;
+    int coff[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) coff[st] = ((2 * st + hh) ^ f) * 16;
+
+    const int nk = p.K / KS;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) piece(i, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        glds_wait_all();
+        __syncthreads();
+        const bool nxt = kt + 1 < nk;
+        const int nb = (kt + 1) & 1;
+        const unsigned char* sb = smem + (kt & 1) * STAGE_B;
+#define PF_PIECE(I) do { if ((I) < PPW && nxt) piece((I) < PPW ? (I) : 0, nb, kt + 1); } while (0)
+#define PF_PROD(PA, PB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                  \
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA], b[jj][PB], acc[i][jj], 0, 0, 0)
+#define PF_LOAD(S)                                                                                                    \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                                \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                                \
+            a[i][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * A_PLANE_B + aoff + i * 32 * ROWB + coff[S]));   \
+        _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                                                             \
+            b[jj][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[S])); \
+    }
+        f16x8 a[WM][2], b[WN][2];
+        // the two small products first, hi*hi last (fixed order: results do not depend on the block shape's schedule)
+        PF_LOAD(0)
+        PF_PROD(1, 0); PF_PIECE(0); PF_PIECE(1);
+        PF_PROD(0, 1); PF_PIECE(2); PF_PIECE(3);
+        PF_PROD(0, 0); PF_PIECE(4);
+        PF_LOAD(1)
+        PF_PROD(1, 0); PF_PIECE(5); PF_PIECE(6);
+        PF_PROD(0, 1); PF_PIECE(7);
+        PF_PROD(0, 0);
+#undef PF_PROD
+#undef PF_LOAD
+#undef PF_PIECE
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)):
+    //      through a wave-private LDS slab so that every global access is a 16-B piece of a contiguous row segment
+    constexpr bool HAS_R1 = (MODE & 1) != 0, HAS_R2 = (MODE & 2) != 0;
+    constexpr int ELD = G::ELD;
+    constexpr int LPR = WN * 8;              // lanes per slab row (float4 each)
+    constexpr int RPS = 64 / LPR;            // rows per pass
+    constexpr int NPASS = 32 / RPS;
+    __syncthreads();
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ELD);
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int col = n0 + wc * (WN * 32) + c4 * 4;
+    const bool colok = col + 3 < p.N;
+    const float oscale = p.oscale;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && colok) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * hh) * ELD + jj * 32 + idx] = acc[i][jj][r];
+        const int row0 = m0 + wr * (WM * 32) + i * 32 + rsub;
+        if (!colok) continue;
+        // QKV form: this block's 256 columns lie inside one of q | k | v (qkv_D % 256 == 0)
+        const int seg = OUT == 2 ? n0 / p.qkv_D : 0;
+        const int scol = OUT == 2 ? col - seg * p.qkv_D : col;
+#pragma unroll
+        for (int h2 = 0; h2 < NPASS / 8; ++h2) {
+            float4 v[8], r1[8], r2[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                v[it] = *reinterpret_cast<const float4*>(slab + ((h2 * 8 + it) * RPS + rsub) * ELD + c4 * 4);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = row0 + (h2 * 8 + it) * RPS;
+                const int rr = row < p.M ? row : p.M - 1;
+                if constexpr (HAS_R1) r1[it] = *reinterpret_cast<const float4*>(p.R1 + (size_t)rr * p.ldr1 + col);
+                if constexpr (HAS_R2) r2[it] = *reinterpret_cast<const float4*>(p.R2 + (size_t)rr * p.ldr2 + col);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = row0 + (h2 * 8 + it) * RPS;
+                float o[4] = {v[it].x * oscale + bias4.x, v[it].y * oscale + bias4.y, v[it].z * oscale + bias4.z,
+                              v[it].w * oscale + bias4.w};
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                }
+                if constexpr (HAS_R1) { o[0] = o[0] + r1[it].x; o[1] = o[1] + r1[it].y; o[2] = o[2] + r1[it].z; o[3] = o[3] + r1[it].w; }
+                if constexpr (HAS_R2) { o[0] = r2[it].x + o[0]; o[1] = r2[it].y + o[1]; o[2] = r2[it].z + o[2]; o[3] = r2[it].w + o[3]; }
+                if (row >= p.M) continue;
+                if constexpr (OUT == 2) {
+                    if (seg == 0) store_split2x4(p.Qp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.q_mul);
+                    else if (seg == 1) store_split2x4(p.Kp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.k_mul);
+                    else *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + scol) = make_float4(o[0], o[1], o[2], o[3]);
+                } else if constexpr (OUT == 1) {
+                    store_split2x4(p.C2 + (size_t)row * p.ldc2 + col, p.c_plane, o, p.cscale);
+                } else {
+                    *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        if constexpr (OUT == 2) {
+            // V^T planes: the slab read column-wise. A 16-B piece = one d (column), 8 rows {0..3, 8..11} + 4 half of the
+            // 16-row group G -- the rows whose scores one attention lane holds per 16-key step (attention_f16x2.hip).
+            // Raw accumulators are still in the slab: bias and scales are applied again here.
+            if (seg == 2) {
+                const int vc0 = n0 - 2 * p.qkv_D + wc * (WN * 32);
+#pragma unroll
+                for (int ps = 0; ps < WN * 32 * 4 / 64; ++ps) {
+                    const int piece = ps * 64 + lane;
+                    const int nl = piece >> 2, G = (piece >> 1) & 1, half = piece & 1;
+                    const int rb = 16 * G + 4 * half;
+                    const float bv = p.bias ? p.bias[n0 + wc * (WN * 32) + nl] : 0.f;
+                    float t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        t[j] = (slab[(rb + (j & 3) + 8 * (j >> 2)) * ELD + nl] * oscale + bv) * p.v_mul;
+                    const int mb = m0 + wr * (WM * 32) + i * 32 + 16 * G;
+                    if (mb < p.M) {
+                        uint4 h, l;
+                        split2_pk(t[0], t[1], h.x, l.x);
+                        split2_pk(t[2], t[3], h.y, l.y);
+                        split2_pk(t[4], t[5], h.z, l.z);
+                        split2_pk(t[6], t[7], h.w, l.w);
+                        unsigned short* vp = p.VT + (size_t)(vc0 + nl) * p.ldvt + mb + 8 * half;
+                        *reinterpret_cast<uint4*>(vp) = h;
+                        *reinterpret_cast<uint4*>(vp + p.vt_plane) = l;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fp32 [M, N] (row stride ldx) * scale -> two fp16 planes [M, ldy] (`plane` elements apart); columns N..ldy are zero
+__global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ y,
+                                                     int ldy, size_t plane, int M, int N, float scale) {
+    const int c4n = ldy >> 2;
+    const size_t total = (size_t)M * c4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / c4n), c = (int)(i % c4n) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < N) {
+            const float4 t = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < N) v[e] = x[(size_t)row * ldx + c + e];
+        }
+        store_split2x4(y + (size_t)row * ldy + c, plane, v, scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));   // non-negative floats order like their bits
+}
+
+// one wave per row n: bound_n = in_bound * sum_k |W[n, k]| + |bias[n]|; *out = max_n bound_n
+__global__ __launch_bounds__(256) void rowl1_bound_kernel(const float* __restrict__ W, int rows, int cols, int ld,
+                                                          const float* __restrict__ bias, float in_bound, unsigned* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float a = 0.f;
+    for (int k = lane; k < cols; k += 64) a += fabsf(W[(size_t)row * ld + k]);
+    a = wave_sum(a);
+    // rounded up a little: the fp32 sum above is not an upper bound to the last bit
+    const float bnd = (in_bound * a) * 1.0001f + (bias ? fabsf(bias[row]) : 0.f);
+    if (lane == 0) atomicMax(out, __builtin_bit_cast(unsigned, bnd));
+}
+
+template <int WM, int WN, int MODE, int OUT>
+int launch_tile(const Gemm2Args& a, hipStream_t stream) {
+    typedef Geo2<WM, WN> G;
+    static bool configured = false;
+    if (!configured) {
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
+        configured = true;
+    }
+    const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
+    const int nMpad = (nM + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT>), dim3((unsigned)nMpad * nN), dim3(512), G::LDS_B, stream, a, nM, nN);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <int MODE, int OUT>
+int launch_one(const Gemm2Args& a, hipStream_t stream) {
+    // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
+    // and does not anyway: both shapes issue the same products in the same k order)
+    const bool wide = a.tile == 2 || (a.tile == 0 && a.N >= 1024 && a.N % 256 == 0);
+    return wide ? launch_tile<2, 4, MODE, OUT>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
+}
+
+}  // namespace
+
+int launch_split2(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, float scale,
+                  hipStream_t stream) {
+    PF_REQUIRE(M > 0 && N > 0 && ldy >= N && ldy % 4 == 0, "split2: ldy must cover N and be a multiple of 4");
+    PF_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && plane % 4 == 0, "split2: alignment");
+    const size_t total = (size_t)M * (ldy >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, y, ldy, plane, M, N, scale);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_absmax(const float* x, size_t n, float* out_dev, hipStream_t stream) {
+    PF_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), stream));
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, n, reinterpret_cast<unsigned*>(out_dev));
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* bias, float in_bound, float* out_dev,
+                       hipStream_t stream) {
+    PF_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(float), stream));
+    hipLaunchKernelGGL(rowl1_bound_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, W, rows, cols, ld, bias, in_bound,
+                       reinterpret_cast<unsigned*>(out_dev));
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
+    PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f16x2: empty problem");
+    PF_REQUIRE(a.K % 32 == 0, "gemm_f16x2: K must be a multiple of 32 (pad the planes with zeros)");
+    PF_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_plane % 8 == 0 && a.w_plane % 8 == 0, "gemm_f16x2: operand strides % 8");
+    PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_f16x2: operands must be 16-B aligned");
+    PF_REQUIRE(a.N % 4 == 0, "gemm_f16x2: N % 4");
+    if (a.C2 && a.qkv_D <= 0) PF_REQUIRE(a.ldc2 % 4 == 0 && a.c_plane % 4 == 0 && ((uintptr_t)a.C2 & 7) == 0, "gemm_f16x2: plane output alignment");
+    else PF_REQUIRE(a.C && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_f16x2: output alignment");
+    if (a.bias) PF_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm_f16x2: bias alignment");
+    if (a.R1) PF_REQUIRE(a.ldr1 % 4 == 0 && ((uintptr_t)a.R1 & 15) == 0, "gemm_f16x2: R1 alignment");
+    if (a.R2) PF_REQUIRE(a.ldr2 % 4 == 0 && ((uintptr_t)a.R2 & 15) == 0, "gemm_f16x2: R2 alignment");
+    const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
+    if (a.qkv_D > 0) {
+        PF_REQUIRE(mode == 0 && !a.relu && a.N == 3 * a.qkv_D && a.qkv_D % 256 == 0 && a.M % 16 == 0,
+                   "gemm_f16x2: the QKV form needs N == 3 D, D % 256 == 0, M % 16 == 0, no residuals");
+        PF_REQUIRE(a.Qp && a.Kp && a.VT && a.C && a.ldvt % 8 == 0 && a.vt_plane % 8 == 0 && a.qk_plane % 8 == 0 &&
+                   ((uintptr_t)a.Qp & 15) == 0 && ((uintptr_t)a.Kp & 15) == 0 && ((uintptr_t)a.VT & 15) == 0,
+                   "gemm_f16x2: QKV outputs");
+        return launch_tile<2, 4, 0, 2>(a, stream);
+    }
+    if (a.C2) {
+        PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");
+        return launch_one<0, 1>(a, stream);
+    }
+    switch (mode) {
+        case 0: return launch_one<0, 0>(a, stream);
+        case 1: return launch_one<1, 0>(a, stream);
+        case 2: return launch_one<2, 0>(a, stream);
+        default: return launch_one<3, 0>(a, stream);
+    }
+}
+
+}  // namespace pf

@@ -27,16 +27,18 @@ __device__ __forceinline__ float4 load4(const float* base, size_t off, bool bf16
 }
 
 // One wave per row. NV = float4 chunks per lane (D <= 256 * NV).
-// OUT: 0 fp32, 1 bf16, 2 three bf16 planes (split3) `plane` elements apart
+// OUT: 0 fp32, 1 bf16, 2 three bf16 planes (split3) `plane` elements apart, 3 two fp16 planes of result * oscale
+// seq_out > 0: output row r = b * seq_out + t reads input row b * seq_in + t (drops a padded layout's extra rows)
 template <int NV, int OUT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         int ldy, int M, int D, int Dpad, float eps, int in_bf16,
-                                                        size_t plane) {
+                                                        size_t plane, float oscale, int seq_out, int seq_in) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
+    const int xrow = seq_out > 0 ? (row / seq_out) * seq_in + row % seq_out : row;
     const int nchunk = D >> 2;
     float4 v[NV];
     float s = 0.f;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int j = 0; j < NV; ++j) {
         const int c = lane + 64 * j;
         if (c < nchunk) {
-            v[j] = load4(x, (size_t)row * ldx + 4 * c, in_bf16 != 0);
+            v[j] = load4(x, (size_t)xrow * ldx + 4 * c, in_bf16 != 0);
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         } else {
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -78,7 +80,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             o.w = (v[j].w - mean) * rstd * g.w + b.w;
         }
         if (4 * c < Dpad) {
-            if constexpr (OUT == 2) {
+            if constexpr (OUT == 3) {
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                store_split2x4(yb + 4 * c, plane, ov, oscale);
+            } else if constexpr (OUT == 2) {
                 const float ov[4] = {o.x, o.y, o.z, o.w};
                 store_split3x4(yb + 4 * c, plane, ov);
             } else if constexpr (OUT == 1) {
@@ -108,6 +113,29 @@ __global__ __launch_bounds__(256) void scale_add_pe_kernel(const float* __restri
         o.y = __fadd_rn(__fmul_rn(a.y, scale), p.y);
         o.z = __fadd_rn(__fmul_rn(a.z, scale), p.z);
         o.w = __fadd_rn(__fmul_rn(a.w, scale), p.w);
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// the same into a padded layout: y is [B, Tp, D], rows t >= T are zero
+__global__ __launch_bounds__(256) void scale_add_pe_pad_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                               float* __restrict__ y, int T, int Tp, int D4, float scale,
+                                                               size_t total4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t per_seq = (size_t)Tp * D4;
+    for (; i < total4; i += stride) {
+        const size_t bq = i / per_seq, r = i % per_seq;
+        const int t = (int)(r / D4);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) {
+            const float4 a = reinterpret_cast<const float4*>(x)[bq * (size_t)T * D4 + r];
+            const float4 p = reinterpret_cast<const float4*>(pe)[r];
+            o.x = __fadd_rn(__fmul_rn(a.x, scale), p.x);
+            o.y = __fadd_rn(__fmul_rn(a.y, scale), p.y);
+            o.z = __fadd_rn(__fmul_rn(a.z, scale), p.z);
+            o.w = __fadd_rn(__fmul_rn(a.w, scale), p.w);
+        }
         reinterpret_cast<float4*>(y)[i] = o;
     }
 }
@@ -191,7 +219,8 @@ int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t st
 }
 
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int M,
-                     int D, int Dpad, float eps, hipStream_t stream, int out_mode, int in_bf16, size_t plane) {
+                     int D, int Dpad, float eps, hipStream_t stream, int out_mode, int in_bf16, size_t plane,
+                     float oscale, int seq_out, int seq_in) {
     PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm: D must be a multiple of 4 and <= 2048");
     PF_REQUIRE(Dpad >= D && Dpad % 4 == 0 && Dpad <= 2048 && ldy >= Dpad, "layernorm: bad Dpad/ldy");
     PF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: strides must be multiples of 4");
@@ -200,9 +229,10 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     const int nv = ceil_div(Dpad / 4, 64);
 #define PF_LN(NV_)                                                                                                 \
     do {                                                                                                          \
-        if (out_mode == 2) hipLaunchKernelGGL((layernorm_kernel<NV_, 2>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane); \
-        else if (out_mode == 1) hipLaunchKernelGGL((layernorm_kernel<NV_, 1>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane); \
-        else hipLaunchKernelGGL((layernorm_kernel<NV_, 0>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane);         \
+        if (out_mode == 3) hipLaunchKernelGGL((layernorm_kernel<NV_, 3>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in); \
+        else if (out_mode == 2) hipLaunchKernelGGL((layernorm_kernel<NV_, 2>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in); \
+        else if (out_mode == 1) hipLaunchKernelGGL((layernorm_kernel<NV_, 1>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in); \
+        else hipLaunchKernelGGL((layernorm_kernel<NV_, 0>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in);         \
     } while (0)
     if (nv <= 2) PF_LN(2);
     else if (nv <= 3) PF_LN(3);
@@ -213,8 +243,15 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
 }
 
 int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
-                        hipStream_t stream) {
+                        hipStream_t stream, int Tp) {
     PF_REQUIRE(B > 0 && T > 0 && D % 4 == 0, "scale_add_pe: D must be a multiple of 4");
+    if (Tp > T) {
+        const size_t tot = (size_t)B * Tp * (D / 4);
+        const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+        hipLaunchKernelGGL(scale_add_pe_pad_kernel, dim3(nb), dim3(256), 0, stream, x, pe, y, T, Tp, D / 4, scale, tot);
+        PF_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const size_t total4 = (size_t)B * T * (D / 4);
     const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(scale_add_pe_kernel, dim3(blocks), dim3(256), 0, stream, x, pe, y, T, D / 4, scale, total4);

@@ -246,6 +246,42 @@ def gemm_split3(a3: torch.Tensor, w3: torch.Tensor, bias=None, relu=False, add1=
     return (out, float(ms.value)) if time_iters > 0 else out
 
 
+def split2(x: torch.Tensor, scale_exp: int = 0, kpad: int = 32) -> torch.Tensor:
+    """fp32 [M, N] -> fp16 planes [2, M, Npad] with x * 2**scale_exp = hi + lo to 2^-24 relative (columns N..Npad-1 zero)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    ld = (N + kpad - 1) // kpad * kpad
+    y = torch.empty(2, M, ld, device=x.device, dtype=torch.float16)
+    _lib.check(lib.pf_k_split2(_ptr(x), x.stride(0), _ptr(y), ld, M * ld, M, N, float(2.0 ** scale_exp), _stream()), "pf_k_split2")
+    return y
+
+
+def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=None, add2=None, scale_exp: int = 0,
+               out_planes=False, out_scale_exp: int = 0, tile: int = 0, time_iters: int = 0):
+    """a2 [2, M, K], w2 [2, N, K] fp16 planes (ops.split2; scale_exp = the SUM of their scale exponents) -> fp32 [M, N]
+    (or the planes [2, M, N] of the result * 2**out_scale_exp); fp32-class accuracy from three fp16 MFMA products per
+    operand pair. With time_iters > 0 returns (out, ms per launch)."""
+    lib = _lib.load()
+    assert a2.dtype == torch.float16 and w2.dtype == torch.float16 and a2.is_contiguous() and w2.is_contiguous()
+    _, M, K = a2.shape
+    N = w2.shape[1]
+    assert w2.shape[2] == K
+    ms = C.c_float(0)
+    if out_planes:
+        out = torch.empty(2, M, N, device=a2.device, dtype=torch.float16)
+        c, ldc, c2, ldc2, cpl = None, 0, out, N, M * N
+    else:
+        out = torch.empty(M, N, device=a2.device, dtype=torch.float32)
+        c, ldc, c2, ldc2, cpl = out, N, None, 0, 0
+    _lib.check(lib.pf_k_gemm_f16x2(_ptr(a2), K, M * K, _ptr(w2), K, N * K, float(2.0 ** -scale_exp), _ptr(bias),
+                                   _ptr(add1), add1.stride(0) if add1 is not None else 0,
+                                   _ptr(add2), add2.stride(0) if add2 is not None else 0,
+                                   _ptr(c), ldc, _ptr(c2), ldc2, cpl, float(2.0 ** out_scale_exp), M, N, K, int(relu),
+                                   int(tile), int(time_iters), C.byref(ms), _stream()), "pf_k_gemm_f16x2")
+    return (out, float(ms.value)) if time_iters > 0 else out
+
+
 def attention_bf16(q, k, v, klens, n_heads: int, scale: float):
     """bf16 q [B, Tq, H*128], k/v [B, Tk, H*128] (row-strided views allowed) -> bf16 [B, Tq, H*128]."""
     lib = _lib.load()

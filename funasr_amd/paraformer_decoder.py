@@ -77,8 +77,8 @@ class ParaformerSANMDecoder(HipModule):
     def set_precision(self, mode: str = "fp32"):
         """"fp32" (default, parity), "bf16" (bf16 operands for the GEMMs + cross-attention on the greedy route) or
         "bf16x3" (fp32 results from bf16x3 split operands for the large GEMMs, see SANMEncoder.set_precision)."""
-        if mode not in ("fp32", "bf16", "bf16x3"):
-            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
+        if mode not in ("fp32", "bf16", "bf16x3", "f16x2"):
+            raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3' or 'f16x2'")
         self._precision = mode
         return self
 
@@ -88,7 +88,7 @@ class ParaformerSANMDecoder(HipModule):
 
     def _run(self, hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits: bool, want_ids: bool, want_hidden: bool = False):
         lib, h = self._ensure_handle()
-        _lib.check(lib.pf_decoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2}[getattr(self, "_precision", "fp32")]),
+        _lib.check(lib.pf_decoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[getattr(self, "_precision", "fp32")]),
                    "pf_decoder_set_precision")
         dev = self._handle_device
         mem = hs_pad.to(device=dev, dtype=torch.float32).contiguous()

@@ -76,11 +76,11 @@ class _SANMEncoderBase(HipModule):
         attention with fp32 accumulation / residual stream / LayerNorm / softmax -- the throughput mode. "bf16x3": fp32
         results from operands split into three bf16 planes (x = hi + mid + lo exactly), six bf16 MFMA products per GEMM
         operand pair -- fp32-class error at the bf16 matrix rate; everything but the GEMMs is the fp32 path."""
-        if mode not in ("fp32", "bf16", "bf16x3"):
-            raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
+        if mode not in ("fp32", "bf16", "bf16x3", "f16x2"):
+            raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3' or 'f16x2'")
         self._precision = mode
         if self._handle is not None:
-            _lib.check(_lib.load().pf_encoder_set_precision(self._handle, {"fp32": 0, "bf16": 1, "bf16x3": 2}[mode]),
+            _lib.check(_lib.load().pf_encoder_set_precision(self._handle, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[mode]),
                        "pf_encoder_set_precision")
         return self
 
@@ -95,7 +95,7 @@ class _SANMEncoderBase(HipModule):
 
     def _run(self, xs_pad: torch.Tensor, ilens, run_blocks: int = -1):
         lib, h = self._ensure_handle()
-        _lib.check(lib.pf_encoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2}[getattr(self, "_precision", "fp32")]),
+        _lib.check(lib.pf_encoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[getattr(self, "_precision", "fp32")]),
                    "pf_encoder_set_precision")
         dev = self._handle_device
         xs = xs_pad.to(device=dev, dtype=torch.float32).contiguous()

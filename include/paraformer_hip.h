@@ -321,6 +321,13 @@ int pf_k_gemm_split3(const void* A3, int32_t lda, int64_t a_plane, const void* W
                      const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C,
                      int32_t ldc, void* C3, int32_t ldc3, int64_t c_plane, int32_t M, int32_t N, int32_t K,
                      int32_t relu, int32_t iters, float* ms_out, void* stream);
+/* two-plane fp16 split operands (x * scale = hi + lo) and the fp32-accurate three-product GEMM on them (gemm_f16x2.hip) */
+int pf_k_split2(const float* x, int32_t ldx, void* y2, int32_t ldy, int64_t plane, int32_t M, int32_t N, float scale,
+                void* stream);
+int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane,
+                    float oscale, const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2,
+                    float* C, int32_t ldc, void* C2, int32_t ldc2, int64_t c_plane, float cscale, int32_t M, int32_t N,
+                    int32_t K, int32_t relu, int32_t tile, int32_t iters, float* ms_out, void* stream);
 /* fp32 -> bf16 (round to nearest even), n % 4 == 0 */
 int pf_k_cast_bf16(const float* x, void* y, int64_t n, void* stream);
 int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t M,

@@ -31,7 +31,7 @@ def fires_of(peaks):
     return (torch.floor(torch.as_tensor(peaks)) >= 1)
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
+@pytest.fixture(params=["fp32", "bf16x3", "f16x2"])
 def f32_mode(request):
     """the two fp32-accurate GEMM routes: v_mfma_f32_32x32x2_f32 (gemm_f32.hip) and three-bf16-plane operands with six
     bf16 MFMA products (gemm_split3.hip). Both must meet every fp32 parity bar."""
