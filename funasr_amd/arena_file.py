@@ -24,8 +24,17 @@ import torch
 MAGIC = b"PFARENA1"
 
 
-def save_arena(model_or_state: Union[torch.nn.Module, Dict[str, torch.Tensor]], path: str, dtype: str = "float32") -> int:
-    """-> bytes written. Layout: MAGIC | u64 header length | header JSON | padding to 64 | data."""
+def source_stamp(path: str):
+    """(size, mtime_ns) of the checkpoint an arena was made from: load_model_dir ignores an arena whose stamp no longer
+    matches the model.pt beside it (a replaced / fine-tuned checkpoint must not be shadowed by a stale arena)."""
+    st = os.stat(path)
+    return [int(st.st_size), int(st.st_mtime_ns)]
+
+
+def save_arena(model_or_state: Union[torch.nn.Module, Dict[str, torch.Tensor]], path: str, dtype: str = "float32",
+               source: str = None) -> int:
+    """-> bytes written. Layout: MAGIC | u64 header length | header JSON | padding to 64 | data. `source`: the checkpoint
+    file this arena mirrors (its size / mtime go into the header, see source_stamp)."""
     if dtype not in ("float32", "bfloat16"):
         raise ValueError("arena dtype must be 'float32' or 'bfloat16'")
     sd = model_or_state.state_dict() if isinstance(model_or_state, torch.nn.Module) else model_or_state
@@ -35,7 +44,10 @@ def save_arena(model_or_state: Union[torch.nn.Module, Dict[str, torch.Tensor]], 
             raise TypeError(f"{name}: the arena holds floating-point parameters only")
         index.append({"name": name, "shape": list(t.shape), "offset": off})
         off += t.numel()
-    header = json.dumps({"dtype": dtype, "numel": off, "index": index}).encode("utf-8")
+    head = {"dtype": dtype, "numel": off, "index": index}
+    if source is not None:
+        head["source"] = {"name": os.path.basename(source), "stamp": source_stamp(source)}
+    header = json.dumps(head).encode("utf-8")
     pad = (-(len(MAGIC) + 8 + len(header))) % 64
     tdt = torch.float32 if dtype == "float32" else torch.bfloat16
     tmp = path + ".tmp"
@@ -51,6 +63,16 @@ def save_arena(model_or_state: Union[torch.nn.Module, Dict[str, torch.Tensor]], 
     return os.path.getsize(path)
 
 
+def read_arena_header(path: str) -> dict:
+    with open(path, "rb") as f:
+        if f.read(len(MAGIC)) != MAGIC:
+            raise ValueError(f"{path}: not a weight arena file")
+        (hlen,) = struct.unpack("<Q", f.read(8))
+        if hlen > os.path.getsize(path):
+            raise ValueError(f"{path}: arena header length beyond the file")
+        return json.loads(f.read(hlen).decode("utf-8"))
+
+
 def read_arena(path: str):
     """-> (header dict, flat torch tensor viewing the memory-mapped data; float32 or bfloat16)"""
     with open(path, "rb") as f:
@@ -60,6 +82,17 @@ def read_arena(path: str):
         header = json.loads(f.read(hlen).decode("utf-8"))
     data_off = len(MAGIC) + 8 + hlen
     data_off += (-data_off) % 64
+    # the header is untrusted input: every tensor must lie inside the declared element count, and that inside the file
+    itemsize = 4 if header.get("dtype") == "float32" else 2
+    numel = int(header["numel"])
+    if header.get("dtype") not in ("float32", "bfloat16") or numel < 0 or data_off + numel * itemsize > os.path.getsize(path):
+        raise ValueError(f"{path}: arena header declares {numel} elements of {header.get('dtype')}, beyond the file's length")
+    for e in header["index"]:
+        n = 1
+        for d in e["shape"]:
+            n *= int(d)
+        if int(e["offset"]) < 0 or int(e["offset"]) + n > numel:
+            raise ValueError(f"{path}: tensor {e['name']} ({n} elements at {e['offset']}) lies outside the arena")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", UserWarning)             # read-only mapping: the tensor is only ever read
         if header["dtype"] == "float32":

@@ -167,12 +167,19 @@ def load_audio(item, fs: int = 16000, audio_fs: int = 16000) -> torch.Tensor:
         x, audio_fs = _decode_wav(item)
     else:
         raise TypeError(f"unsupported audio input type {type(item)}")
+    if x.dtype in (torch.int16,):                  # integer PCM -> [-1, 1) BEFORE anything casts it to float
+        x = x.to(torch.float32) / 32768.0
     if x.dim() > 1:
-        x = x.reshape(-1, x.shape[-1]).mean(0) if x.shape[0] <= 8 else x.reshape(-1)
+        # [channels, n] or [n, channels]: the channel axis is the small one; anything else is ambiguous
+        x = x.reshape(-1, x.shape[-1]) if x.dim() > 2 else x
+        if x.shape[0] <= 8:
+            x = x.to(torch.float32).mean(0)
+        elif x.shape[1] <= 8:
+            x = x.to(torch.float32).mean(1)
+        else:
+            raise ValueError(f"audio array of shape {tuple(x.shape)}: neither axis looks like a channel axis (<= 8)")
     if audio_fs != fs:
         x = resample(x.to(torch.float32), audio_fs, fs)
-    if x.dtype in (torch.int16,):
-        x = x.to(torch.float32) / 32768.0
     return x.to(torch.float32)
 
 

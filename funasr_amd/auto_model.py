@@ -130,7 +130,15 @@ def load_model_dir(model_dir: str) -> dict:
 
     # a `model.arena` beside (or instead of) model.pt is preferred: one mapped blob instead of ~950 pickled tensors
     init_param = resolve("init_param", "model.arena") if "init_param" not in metas else None
-    init_param = init_param or resolve("init_param", "model.pt")
+    pt = resolve("init_param", "model.pt")
+    if init_param and pt:
+        # the arena must be the twin of the checkpoint beside it: stale (model.pt replaced since) or unstamped -> ignore it
+        from .arena_file import read_arena_header, source_stamp
+        src = read_arena_header(init_param).get("source")
+        if not src or src.get("stamp") != source_stamp(pt):
+            logging.warning("%s does not match %s (size / mtime): loading the checkpoint instead", init_param, pt)
+            init_param = None
+    init_param = init_param or pt
     if init_param:
         kwargs["init_param"] = init_param
     tokens = resolve("tokenizer_conf.token_list", "tokens.json") if "tokenizer_conf" not in metas else None
@@ -158,7 +166,10 @@ def load_pretrained_model(path: str, model: torch.nn.Module, ignore_init_mismatc
         from .arena_file import load_arena
         load_arena(model, path, strict=True)
         return
-    src = torch.load(path, map_location="cpu", weights_only=False)
+    # tensors only, like the reference's default torch.load on torch >= 2.6 (a model.pt may come from a third party); the
+    # full unpickler is an explicit opt-in for legacy checkpoints that wrap non-tensor objects
+    unsafe = bool(kwargs.get("trust_pickle", False)) or os.environ.get("FUNASR_AMD_TRUST_PICKLE") == "1"
+    src = torch.load(path, map_location="cpu", weights_only=not unsafe)
     for k in ("state_dict", "model_state_dict", "model"):
         if isinstance(src, dict) and k in src and isinstance(src[k], dict):
             src = src[k]

@@ -180,6 +180,7 @@ struct Gemm2Args {
     const unsigned short* A; int lda; size_t a_plane;   // [2][M, K] fp16
     const unsigned short* W; int ldw; size_t w_plane;   // [2][N, K] fp16
     float oscale;                                       // exact power of two
+    const float* oscale_dev;                            // optional device float multiplied into oscale (a scale chosen on the device)
     const float* bias;
     const float* R1; int ldr1;                          // v = v + R1, then v = R2 + v (as GemmArgs)
     const float* R2; int ldr2;
@@ -201,7 +202,10 @@ struct Gemm2Args {
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream);
 // fp32 [M, N] * scale -> two fp16 planes [M, ldy]; columns N..ldy-1 are written as zero
 int launch_split2(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, float scale,
-                  hipStream_t stream);
+                  hipStream_t stream, const float* scale_dev = nullptr);
+// sc[0] = 2^e, sc[1] = 2^-e with e = floor(log2(32768 / *amax_dev)): the plane scale of a tensor whose max |x| is only
+// known on the device (and its inverse for the consuming GEMM's oscale_dev)
+int launch_pow2_scale(const float* amax_dev, float* sc, hipStream_t stream);
 // max |x| over n floats -> *out_dev (one float, device); load-time helper for the per-tensor weight scale
 int launch_absmax(const float* x, size_t n, float* out_dev, hipStream_t stream);
 // max over rows n of (in_bound * sum_k |W[n, k]| + |bias[n]|) -> *out_dev: a-priori bound on a Linear's outputs

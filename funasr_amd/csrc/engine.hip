@@ -166,9 +166,11 @@ struct TensorTable {
     // bf16 copy of a (repacked) tensor for the bf16-operand mode, made on first use and dropped when the fp32
     // master changes
     std::map<std::string, unsigned short*> b16;
+    std::map<std::string, int> exp2;    // exponents of the #split2 entries
     void drop_bf16() {
         for (auto& kv : b16) if (kv.second) (void)hipFree(kv.second);
         b16.clear();
+        exp2.clear();
     }
     // the three bf16 planes [3][rows, cols] of a [rows, cols] weight (gemm_split3.hip); shares the b16 cache under a
     // suffixed key, so it is dropped with it
@@ -189,7 +191,6 @@ struct TensorTable {
     }
     // the two fp16 planes [2][rows, cols] of weight * 2^e (gemm_f16x2.hip), e from max |w| so that the largest hi lies in
     // [2^14, 2^15); cached like the bf16 copies, the exponent beside it
-    std::map<std::string, int> exp2;
     const unsigned short* get_split2(const std::string& name, int rows, int cols, int* e_out, hipStream_t s) {
         const std::string key = name + "#split2";
         auto it = b16.find(key);
@@ -701,6 +702,10 @@ struct Predictor {
 struct DecLayerW {
     const float *n1g, *n1b, *w1, *b1, *fng, *fnb, *w2, *n2g, *n2b, *fsmn_w, *n3g, *n3b, *q_w, *q_b, *kv_w, *kv_b,
         *o_w, *o_b;
+    // f16x2 mode: weight planes + exponents, and the exponents of the LayerNorm-output planes (from gamma / beta)
+    const unsigned short *w1_2 = nullptr, *w2_2 = nullptr, *q_2 = nullptr, *kv_2 = nullptr;
+    int ew_1 = 0, ew_2 = 0, ew_q = 0, ew_kv = 0, e_n1 = 0, e_fn = 0, e_n3 = 0;
+    bool x2_ready = false;
 };
 struct Decoder {
     pf_decoder_config cfg;
@@ -711,6 +716,7 @@ struct Decoder {
     DevBuf x, t1, t2, ffn, ffn2, q, kv, ctx, mem_lens, tok_lens, pval, pidx, hid;
     int precision = 0;       // 0 fp32, 1 bf16 operands (GEMMs + cross-attention), fp32 residual / LN statistics / FSMN
     DevBuf t16, ffn16, ffn2_16, q16, kv16, ctx16, mem16, hid16;
+    DevBuf dsc;              // f16x2 mode: [amax(memory), 2^e, 2^-e] chosen on the device per forward
 };
 
 static int decoder_resolve(Decoder* d) {
@@ -787,6 +793,62 @@ static int gemm3_simple(const unsigned short* A3, int lda, int M, const unsigned
     g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = relu;
     ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
     return launch_gemm_split3(g, s);
+}
+
+static int gemm2_simple(const unsigned short* A2, int lda, int M, int ea, const unsigned short* W2, int ew, const float* bias,
+                        float* C, int ldc, int N, int K, int relu, const float* R2, int ldr2, hipStream_t s,
+                        const float* oscale_dev = nullptr) {
+    if (!W2) return -2;
+    Gemm2Args g{};
+    g.A = A2; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W2; g.ldw = K; g.w_plane = (size_t)N * K;
+    g.oscale = pow2f(-(ea + ew)); g.oscale_dev = oscale_dev; g.bias = bias; g.R2 = R2; g.ldr2 = ldr2;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = relu;
+    ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
+    return launch_gemm_f16x2(g, s);
+}
+
+// f16x2 mode: exponents and weight planes of one decoder layer (once)
+static int dec_layer_x2(Decoder* d, DecLayerW& w, const std::string& p, bool attn, hipStream_t s) {
+    if (w.x2_ready) return 0;
+    const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
+    float g, b;
+    if (TensorTable::dev_absmax(w.n1g, D, &g, s) || TensorTable::dev_absmax(w.n1b, D, &b, s)) return -2;
+    w.e_n1 = exp_for_bound(sqrtf((float)D) * g + b);
+    if (TensorTable::dev_absmax(w.fng, F, &g, s) || TensorTable::dev_absmax(w.fnb, F, &b, s)) return -2;
+    w.e_fn = exp_for_bound(sqrtf((float)F) * g + b);
+    w.w1_2 = d->tt.get_split2(p + "feed_forward.w_1.weight", F, D, &w.ew_1, s);
+    w.w2_2 = d->tt.get_split2(p + "feed_forward.w_2.weight", D, F, &w.ew_2, s);
+    if (!w.w1_2 || !w.w2_2) return -2;
+    if (attn) {
+        if (TensorTable::dev_absmax(w.n3g, D, &g, s) || TensorTable::dev_absmax(w.n3b, D, &b, s)) return -2;
+        w.e_n3 = exp_for_bound(sqrtf((float)D) * g + b);
+        w.q_2 = d->tt.get_split2(p + "src_attn.linear_q.weight", D, D, &w.ew_q, s);
+        w.kv_2 = d->tt.get_split2(p + "src_attn.linear_k_v.weight", 2 * D, D, &w.ew_kv, s);
+        if (!w.q_2 || !w.kv_2) return -2;
+    }
+    w.x2_ready = true;
+    return 0;
+}
+
+// f16x2 form of dec_ffn: both LayerNorms write two-plane fp16 operands, w_1 and w_2 run on the fp16 matrix cores
+static int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s) {
+    const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
+    float* ffn = d->ffn.as<float>();
+    unsigned short* t2p = d->t16.as<unsigned short>();
+    unsigned short* f2p = d->ffn16.as<unsigned short>();
+    int rc;
+    {
+        ProfScope ps(PROF_LN, 8.0 * M * (double)D, s);
+        if ((rc = launch_layernorm(x, D, w.n1g, w.n1b, reinterpret_cast<float*>(t2p), D, M, D, D, d->cfg.ln_eps, s, 3, 0,
+                                   (size_t)M * D, pow2f(w.e_n1)))) return rc;
+    }
+    if ((rc = gemm2_simple(t2p, D, M, w.e_n1, w.w1_2, w.ew_1, w.b1, ffn, F, F, D, 1, nullptr, 0, s))) return rc;
+    {
+        ProfScope ps(PROF_LN, 8.0 * M * (double)F, s);
+        if ((rc = launch_layernorm(ffn, F, w.fng, w.fnb, reinterpret_cast<float*>(f2p), F, M, F, F, d->cfg.ln_eps, s, 3, 0,
+                                   (size_t)M * F, pow2f(w.e_fn)))) return rc;
+    }
+    return gemm2_simple(f2p, F, M, w.e_fn, w.w2_2, w.ew_2, nullptr, out, D, D, F, 0, nullptr, 0, s);
 }
 
 // w1_3 != nullptr (bf16x3 mode): norm1 writes the three planes and w_1 runs on the bf16 matrix cores
@@ -1738,8 +1800,27 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     if (d->precision == 1 && !logits) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
     // bf16x3 mode: the two GEMMs that are large at every batch size (w_1: N = ffn_dim; linear_k_v: M = B * T) take
     // three-plane operands on the bf16 matrix cores; the D x D projections and w_2 keep the fp32 MFMA tiles
-    const bool x3 = d->precision == 2 || d->precision == 3;
+    const bool x3 = d->precision == 2;
+    const bool x2 = d->precision == 3;
     const unsigned short* mem3 = nullptr;
+    const unsigned short* mem2 = nullptr;
+    float* dsc = nullptr;
+    if (x2) {
+        // f16x2 mode: w_1, w_2, linear_q, linear_k_v on the fp16 matrix cores (gemm_f16x2.hip). The memory planes' scale
+        // is chosen on the device from max |memory| (no host round trip); linear_out keeps the fp32 MFMA tile (its operand,
+        // the attention output, has no a-priori bound here)
+        if (d->t16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D) || d->ffn16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * F) ||
+            d->mem16.ensure(sizeof(unsigned short) * 2 * (size_t)Mk * D) || d->dsc.ensure(sizeof(float) * 4))
+            return -2;
+        dsc = d->dsc.as<float>();
+        if ((rc = launch_absmax(memory, (size_t)Mk * D, dsc, s))) return rc;
+        if ((rc = launch_pow2_scale(dsc, dsc + 1, s))) return rc;
+        if ((rc = launch_split2(memory, D, d->mem16.as<unsigned short>(), D, (size_t)Mk * D, Mk, D, 1.f, s, dsc + 1))) return rc;
+        mem2 = d->mem16.as<unsigned short>();
+        for (int l = 0; l < c.n_blocks; ++l)
+            if ((rc = dec_layer_x2(d, d->layers[l], "decoders." + std::to_string(l) + ".", true, s))) return rc;
+        if ((rc = dec_layer_x2(d, d->last, "decoders3.0.", false, s))) return rc;
+    }
     if (x3) {
         if (d->t16.ensure(sizeof(unsigned short) * 3 * (size_t)Mq * D) || d->mem16.ensure(sizeof(unsigned short) * 3 * (size_t)Mk * D))
             return -2;
@@ -1753,16 +1834,31 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
         // DecoderLayerSANM.forward (paraformer/decoder.py:78-121)
         const unsigned short* w1_3 = w3(lp + "feed_forward.w_1.weight", F, D);
         if (x3 && !w1_3) return -2;
-        if ((rc = dec_ffn(d, w, x, t2, Mq, s, w1_3))) return rc;                              // tgt = FFN(norm1(tgt))
+        if (x2) rc = dec_ffn_x2(d, w, x, t2, Mq, s);
+        else rc = dec_ffn(d, w, x, t2, Mq, s, w1_3);                                          // tgt = FFN(norm1(tgt))
+        if (rc) return rc;
         if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;   // norm2
         FsmnArgs fa{};                                                                        // x = residual + fsmn
         fa.in = t1; fa.ldin = D; fa.w = w.fsmn_w; fa.R = x; fa.ldr = D; fa.out = x; fa.ldo = D;
         fa.lens = d->tok_lens.as<int>(); fa.B = B; fa.T = N; fa.C = D; fa.K = c.kernel_size; fa.left_pad = left_pad;
         if ((rc = fsmn(fa, s))) return rc;
-        if ((rc = layernorm(x, D, w.n3g, w.n3b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;    // norm3
-        if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s)))
-            return rc;
-        if (x3) {
+        if (x2) {                                                                             // norm3 -> linear_q
+            unsigned short* t2p = d->t16.as<unsigned short>();
+            {
+                ProfScope ps(PROF_LN, 8.0 * Mq * (double)D, s);
+                if ((rc = launch_layernorm(x, D, w.n3g, w.n3b, reinterpret_cast<float*>(t2p), D, Mq, D, D, c.ln_eps, s, 3, 0,
+                                           (size_t)Mq * D, pow2f(w.e_n3)))) return rc;
+            }
+            if ((rc = gemm2_simple(t2p, D, Mq, w.e_n3, w.q_2, w.ew_q, w.q_b, d->q.as<float>(), D, D, D, 0, nullptr, 0, s))) return rc;
+        } else {
+            if ((rc = layernorm(x, D, w.n3g, w.n3b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;    // norm3
+            if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s)))
+                return rc;
+        }
+        if (x2) {
+            if ((rc = gemm2_simple(mem2, D, Mk, 0, w.kv_2, w.ew_kv, w.kv_b, d->kv.as<float>(), 2 * D, 2 * D, D, 0, nullptr, 0, s,
+                                   dsc + 2))) return rc;
+        } else if (x3) {
             if ((rc = gemm3_simple(mem3, D, Mk, w3(lp + "src_attn.linear_k_v.weight", 2 * D, D), w.kv_b, d->kv.as<float>(),
                                    2 * D, 2 * D, D, 0, s))) return rc;
         } else if ((rc = gemm_simple(memory, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
@@ -1782,7 +1878,9 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     {
         const unsigned short* w1_3 = w3("decoders3.0.feed_forward.w_1.weight", F, D);
         if (x3 && !w1_3) return -2;
-        if ((rc = dec_ffn(d, d->last, x, t2, Mq, s, w1_3))) return rc;
+        if (x2) rc = dec_ffn_x2(d, d->last, x, t2, Mq, s);
+        else rc = dec_ffn(d, d->last, x, t2, Mq, s, w1_3);
+        if (rc) return rc;
     }
     float* hid = hidden_out ? hidden_out : d->hid.as<float>();
     if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), hid, D, Mq, D, D,
@@ -1970,6 +2068,15 @@ pf_stream* pf_stream_create(pf_encoder* eh, pf_predictor* ph, pf_decoder* dh, co
         dec_left != K - 1) {
         set_error("stream: unsupported config (d_model 512, look_back >= 0 (finite), max_tokens <= 24, causal decoder "
                   "FSMN i.e. sanm_shfit == (kernel_size-1)/2 as in paraformer_streaming/template.yaml:62)");
+        return nullptr;
+    }
+    // CIF fires at most once per frame carrying weight (alpha < 1): a step's window has chunk_left + chunk_right + n frames,
+    // the first chunk_left of them are zeroed (cif_predictor.py:343-346), plus the carried remainder and the final tail
+    // weight (:347-357). The token capacity must cover that, or tokens would be dropped silently (stream.hip clamps
+    // n_fired); the hipGraph cache key packs n_frames into 10 bits
+    if (c.max_tokens < c.chunk_right + c.max_frames + 2 || c.max_frames >= 1024) {
+        set_error("stream: max_tokens (" + std::to_string(c.max_tokens) + ", limit 24) must cover chunk_right + max_frames + 2 = " +
+                  std::to_string(c.chunk_right + c.max_frames + 2) + " possible fires per step; max_frames must stay below 1024");
         return nullptr;
     }
     int rc;

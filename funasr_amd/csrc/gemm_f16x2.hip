@@ -24,23 +24,25 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// wave grid 4 (M) x 2 (N); a wave owns WM x WN tiles of 32 x 32
-template <int WM, int WN> struct Geo2 {
-    static constexpr int BM = 4 * WM * 32, BN = 2 * WN * 32;
+// wave grid WGM (M) x 2 (N); a wave owns WM x WN tiles of 32 x 32
+template <int WM, int WN, int WGM = 4> struct Geo2 {
+    static constexpr int NW = WGM * 2;                          // waves per workgroup
+    static constexpr int BM = WGM * WM * 32, BN = 2 * WN * 32;
     static constexpr int KS = 32, ROWB = 64, CPR = 4, RPP = 16;
     static constexpr int A_PLANE_B = BM * ROWB, B_PLANE_B = BN * ROWB;
     static constexpr int STAGE_B = 2 * (A_PLANE_B + B_PLANE_B);
     static constexpr int NPIECE = STAGE_B / 1024;               // 48 / 64
     static constexpr int A_PIECES = 2 * BM / RPP;
-    static constexpr int PPW = NPIECE / 8;                      // 6 / 8
+    static constexpr int PPW = NPIECE / NW;                     // 6 / 8
     static constexpr int ELD = WN * 32 + 4;                     // epilogue slab row (floats)
-    static constexpr int SLAB_B = 8 * 32 * ELD * 4;
+    static constexpr int SLAB_B = NW * 32 * ELD * 4;
     static constexpr int LDS_B = 2 * STAGE_B > SLAB_B ? 2 * STAGE_B : SLAB_B;
 };
 
-template <int WM, int WN, int MODE, int OUT>   // OUT: 0 fp32 C, 1 two fp16 planes, 2 the QKV form (Gemm2Args)
-__global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM, int nN) {
-    typedef Geo2<WM, WN> G;
+// ABL (measurement only, tools/bench_gemm2.py): 1 = no global stores in the epilogue, 2 = no epilogue, 3 = no operand DMA
+template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4>   // OUT: 0 fp32 C, 1 two fp16 planes, 2 the QKV form (Gemm2Args)
+__global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM, int nN) {
+    typedef Geo2<WM, WN, WGM> G;
     constexpr int BM = G::BM, BN = G::BN, KS = G::KS, ROWB = G::ROWB, CPR = G::CPR, RPP = G::RPP, PPW = G::PPW;
     constexpr int STAGE_B = G::STAGE_B, A_PLANE_B = G::A_PLANE_B, B_PLANE_B = G::B_PLANE_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM,
         const int chunk = (lane % CPR) ^ ((prow >> 2) & (CPR - 1));
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const int q = wave + 8 * i;
+            const int q = wave + G::NW * i;
             if (q < G::A_PIECES) {
                 int row = m0 + (q % (BM / RPP)) * RPP + prow;
                 row = row < p.M ? row : p.M - 1;
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM,
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
     auto piece = [&](int i, int buf, int kt) {
-        glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * 8192);
+        if constexpr (ABL == 3) return;
+        glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * (G::NW * 1024));
     };
 
     floatx16 acc[WM][WN];
@@ -119,16 +122,40 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM,
         _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                                                             \
             b[jj][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[S])); \
     }
-        f16x8 a[WM][2], b[WN][2];
-        // the two small products first, hi*hi last (fixed order: results do not depend on the block shape's schedule)
-        PF_LOAD(0)
-        PF_PROD(1, 0); PF_PIECE(0); PF_PIECE(1);
-        PF_PROD(0, 1); PF_PIECE(2); PF_PIECE(3);
-        PF_PROD(0, 0); PF_PIECE(4);
-        PF_LOAD(1)
-        PF_PROD(1, 0); PF_PIECE(5); PF_PIECE(6);
-        PF_PROD(0, 1); PF_PIECE(7);
-        PF_PROD(0, 0);
+        if constexpr (SCHED == 0) {
+            f16x8 a[WM][2], b[WN][2];
+            // the two small products first, hi*hi last (fixed order: results do not depend on the block shape's schedule)
+            PF_LOAD(0)
+            PF_PROD(1, 0); PF_PIECE(0); PF_PIECE(1);
+            PF_PROD(0, 1); PF_PIECE(2); PF_PIECE(3);
+            PF_PROD(0, 0); PF_PIECE(4);
+            PF_LOAD(1)
+            PF_PROD(1, 0); PF_PIECE(5); PF_PIECE(6);
+            PF_PROD(0, 1); PF_PIECE(7);
+            PF_PROD(0, 0);
+        } else {
+            // both k-steps' fragments are requested before the first MFMA: one LDS-latency bubble per stage instead of two
+            f16x8 a[WM][2], b[WN][2], a1[WM][2], b1[WN][2];
+            PF_LOAD(0)
+            {
+#define a a1
+#define b b1
+                PF_LOAD(1)
+#undef a
+#undef b
+            }
+            if constexpr (SCHED == 2) { PF_PIECE(0); PF_PIECE(1); PF_PIECE(2); PF_PIECE(3); }
+            PF_PROD(1, 0); if constexpr (SCHED == 1) { PF_PIECE(0); PF_PIECE(1); } else { PF_PIECE(4); PF_PIECE(5); }
+            PF_PROD(0, 1); if constexpr (SCHED == 1) { PF_PIECE(2); PF_PIECE(3); } else { PF_PIECE(6); PF_PIECE(7); }
+            PF_PROD(0, 0); if constexpr (SCHED == 1) { PF_PIECE(4); }
+#define a a1
+#define b b1
+            PF_PROD(1, 0); if constexpr (SCHED == 1) { PF_PIECE(5); PF_PIECE(6); }
+            PF_PROD(0, 1); if constexpr (SCHED == 1) { PF_PIECE(7); }
+            PF_PROD(0, 0);
+#undef a
+#undef b
+        }
 #undef PF_PROD
 #undef PF_LOAD
 #undef PF_PIECE
@@ -136,6 +163,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM,
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)):
     //      through a wave-private LDS slab so that every global access is a 16-B piece of a contiguous row segment
+    if constexpr (ABL == 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][jj][r];
+        if (t == 123.456f) p.C[0] = t;
+        return;
+    }
     constexpr bool HAS_R1 = (MODE & 1) != 0, HAS_R2 = (MODE & 2) != 0;
     constexpr int ELD = G::ELD;
     constexpr int LPR = WN * 8;              // lanes per slab row (float4 each)
@@ -146,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM,
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int col = n0 + wc * (WN * 32) + c4 * 4;
     const bool colok = col + 3 < p.N;
-    const float oscale = p.oscale;
+    const float oscale = p.oscale_dev ? p.oscale * *p.oscale_dev : p.oscale;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && colok) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
@@ -186,6 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM,
                 if constexpr (HAS_R1) { o[0] = o[0] + r1[it].x; o[1] = o[1] + r1[it].y; o[2] = o[2] + r1[it].z; o[3] = o[3] + r1[it].w; }
                 if constexpr (HAS_R2) { o[0] = r2[it].x + o[0]; o[1] = r2[it].y + o[1]; o[2] = r2[it].z + o[2]; o[3] = r2[it].w + o[3]; }
                 if (row >= p.M) continue;
+                if constexpr (ABL == 1) { if (o[0] == 123.456f) p.C[0] = o[1] + o[2] + o[3]; continue; }
                 if constexpr (OUT == 2) {
                     if (seg == 0) store_split2x4(p.Qp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.q_mul);
                     else if (seg == 1) store_split2x4(p.Kp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.k_mul);
@@ -232,7 +271,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM,
 
 // fp32 [M, N] (row stride ldx) * scale -> two fp16 planes [M, ldy] (`plane` elements apart); columns N..ldy are zero
 __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ y,
-                                                     int ldy, size_t plane, int M, int N, float scale) {
+                                                     int ldy, size_t plane, int M, int N, float scale,
+                                                     const float* __restrict__ scale_dev) {
+    if (scale_dev) scale *= *scale_dev;
     const int c4n = ldy >> 2;
     const size_t total = (size_t)M * c4n;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -269,18 +310,18 @@ __global__ __launch_bounds__(256) void rowl1_bound_kernel(const float* __restric
     if (lane == 0) atomicMax(out, __builtin_bit_cast(unsigned, bnd));
 }
 
-template <int WM, int WN, int MODE, int OUT>
+template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4>
 int launch_tile(const Gemm2Args& a, hipStream_t stream) {
-    typedef Geo2<WM, WN> G;
+    typedef Geo2<WM, WN, WGM> G;
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT>),
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
         configured = true;
     }
     const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
     const int nMpad = (nM + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT>), dim3((unsigned)nMpad * nN), dim3(512), G::LDS_B, stream, a, nM, nN);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM>), dim3((unsigned)nMpad * nN), dim3(WGM * 128), G::LDS_B, stream, a, nM, nN);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -288,19 +329,48 @@ template <int MODE, int OUT>
 int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
     // and does not anyway: both shapes issue the same products in the same k order)
-    const bool wide = a.tile == 2 || (a.tile == 0 && a.N >= 1024 && a.N % 256 == 0);
-    return wide ? launch_tile<2, 4, MODE, OUT>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
+    if constexpr (MODE == 0 && OUT == 0) {
+        if (a.tile == 3) return launch_tile<2, 2, 0, 0, 0, 0, 2>(a, stream);      // 128 x 128, 4 waves, two workgroups per CU
+        if (a.tile >= 64) return (a.tile >> 6) == 1 ? launch_tile<2, 4, 0, 0, 0, 1>(a, stream) : launch_tile<2, 4, 0, 0, 0, 2>(a, stream);
+        if (a.tile >= 16) {                 // ablation builds of the wide tile
+            switch (a.tile >> 4) {
+                case 1: return launch_tile<2, 4, 0, 0, 1>(a, stream);
+                case 2: return launch_tile<2, 4, 0, 0, 2>(a, stream);
+                default: return launch_tile<2, 4, 0, 0, 3>(a, stream);
+            }
+        }
+    }
+    // 256 x 256 blocks when they still fill the chip (>= 192 blocks), else 256 x 128 (twice the blocks). The choice moves
+    // no result: both shapes issue the same products in the same k order per output element (bitwise equal, tested)
+    const long wide_blocks = (long)ceil_div(a.M, 256) * (a.N / 256);
+    const bool wide = a.tile == 2 || (a.tile == 0 && a.N % 256 == 0 && (a.N >= 1024 || wide_blocks >= 192));
+    // SCHED 2 on the 256 x 256 shape (both k-steps' fragments requested up front, DMA pieces early): 0-10 % faster there
+    return wide ? launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
 }
 
 }  // namespace
 
+__global__ void pow2_scale_kernel(const float* __restrict__ amax, float* __restrict__ sc) {
+    const float a = *amax;
+    int e = a > 0.f ? (int)floorf(log2f(32768.f / a)) : 0;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    sc[0] = ldexpf(1.f, e);
+    sc[1] = ldexpf(1.f, -e);
+}
+
+int launch_pow2_scale(const float* amax_dev, float* sc, hipStream_t stream) {
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, stream, amax_dev, sc);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_split2(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, float scale,
-                  hipStream_t stream) {
+                  hipStream_t stream, const float* scale_dev) {
     PF_REQUIRE(M > 0 && N > 0 && ldy >= N && ldy % 4 == 0, "split2: ldy must cover N and be a multiple of 4");
     PF_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && plane % 4 == 0, "split2: alignment");
     const size_t total = (size_t)M * (ldy >> 2);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, y, ldy, plane, M, N, scale);
+    hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, y, ldy, plane, M, N, scale, scale_dev);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -340,7 +410,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         PF_REQUIRE(a.Qp && a.Kp && a.VT && a.C && a.ldvt % 8 == 0 && a.vt_plane % 8 == 0 && a.qk_plane % 8 == 0 &&
                    ((uintptr_t)a.Qp & 15) == 0 && ((uintptr_t)a.Kp & 15) == 0 && ((uintptr_t)a.VT & 15) == 0,
                    "gemm_f16x2: QKV outputs");
-        return launch_tile<2, 4, 0, 2>(a, stream);
+        return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);
     }
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");

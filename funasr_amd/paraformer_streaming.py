@@ -124,18 +124,21 @@ class StreamBatch:
     """S independent streams advanced in lock-step over one (encoder, predictor, decoder) triple; all caches in HBM."""
 
     def __init__(self, model: "ParaformerStreaming", n_streams: int = 1, chunk_size: Sequence[int] = (0, 10, 5),
-                 encoder_chunk_look_back: int = 4, decoder_chunk_look_back: int = 1, max_frames: int = 16,
-                 max_tokens: int = 20, use_graph: bool = True, pe_rows: int = 8192):
+                 encoder_chunk_look_back: int = 4, decoder_chunk_look_back: int = 1, max_frames: int = None,
+                 max_tokens: int = None, use_graph: bool = True, pe_rows: int = 8192):
         self.model = model
         self.S, self.chunk_size = n_streams, list(chunk_size)
-        self.max_frames, self.max_tokens = max(max_frames, chunk_size[1]), max_tokens
+        # a step brings at most chunk_cur new frames plus the final flush of the look-ahead; CIF fires at most once per
+        # weighted frame (the window minus its chunk_left zeroed frames) plus the carried remainder and the tail weight
+        self.max_frames = max(max_frames or 0, chunk_size[1] + chunk_size[2] + 1)
+        self.max_tokens = max_tokens if max_tokens is not None else chunk_size[2] + self.max_frames + 2
         lib, he = model.encoder._ensure_handle()
         _, hp = model.predictor._ensure_handle()
         _, hd = model.decoder._ensure_handle()
         self.dev = model.encoder._handle_device
         self.lib = lib
         cfg = _lib.pf_stream_config(n_streams, chunk_size[0], chunk_size[1], chunk_size[2], encoder_chunk_look_back,
-                                    decoder_chunk_look_back, self.max_frames, max_tokens, int(use_graph))
+                                    decoder_chunk_look_back, self.max_frames, self.max_tokens, int(use_graph))
         with torch.cuda.device(self.dev):
             self._h = _lib.check_handle(lib.pf_stream_create(he, hp, hd, C.byref(cfg)), "pf_stream_create")
             pe = sinusoidal_position_table(pe_rows, model.encoder._input_size).contiguous()
@@ -257,8 +260,11 @@ class ParaformerStreaming(Paraformer):
         stride = int(chunk_size[1] * 960)                                   # 600 ms (:688-689)
         t1 = time.perf_counter()
         is_final = bool(kwargs.get("is_final", False))
-        if isinstance(data_in, str):
-            is_final = True                                                 # a file is a whole utterance (:699-700)
+        first = data_in[0] if isinstance(data_in, (list, tuple)) and len(data_in) else data_in
+        if isinstance(first, str) or hasattr(first, "read"):
+            # a file (also inside the list AutoModel.inference always passes: load_audio_text_image_video forwards `cache`
+            # through its list recursion, :692-701) is a whole utterance: run the look-ahead / tail chunk now
+            is_final = True
         audio_list = load_audio_list(data_in, fs=frontend.fs, audio_fs=kwargs.get("fs", 16000))
         t2 = time.perf_counter()
         meta_data["load_data"] = f"{t2 - t1:0.3f}"

@@ -30,3 +30,24 @@ def _built_extension():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     yield
+
+
+def _usable_cores() -> int:
+    """min(affinity mask, cgroup quota): torch's default thread count follows the machine, and an OpenMP pool larger than
+    the container's CPU quota runs the oracle ~100x slower."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads():
+    import torch
+    torch.set_num_threads(_usable_cores())

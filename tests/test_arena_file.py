@@ -48,9 +48,44 @@ def test_model_directory_prefers_the_arena_file(tmp_path):
     d = str(tmp_path / "m")
     info = make_model_dir(d)
     ref, _ = AutoModel.build_model(model=d, device="cpu")
-    save_arena(ref, os.path.join(d, "model.arena"))
+    pt = os.path.join(d, "model.pt")
+    save_arena(ref, os.path.join(d, "model.arena"))              # unstamped: the checkpoint beside it wins
+    assert load_model_dir(d)["init_param"].endswith("model.pt")
+    save_arena(ref, os.path.join(d, "model.arena"), source=pt)   # stamped twin of model.pt: preferred
     assert load_model_dir(d)["init_param"].endswith("model.arena")
-    os.remove(os.path.join(d, "model.pt"))                       # the arena alone is enough
+    sd = torch.load(pt, map_location="cpu", weights_only=True)   # the checkpoint is replaced (fine-tune / new download) ...
+    torch.save({k: v + 1 for k, v in sd.items()} if all(torch.is_tensor(v) for v in sd.values()) else sd, pt)
+    os.utime(pt, ns=(1, 1))
+    assert load_model_dir(d)["init_param"].endswith("model.pt")  # ... and a stale arena no longer shadows it
+    os.remove(pt)                                                # the arena alone is enough
     got, _ = AutoModel.build_model(model=d, device="cpu")
     for (k, a), (_, b) in zip(ref.state_dict().items(), got.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_arena_header_is_bounds_checked(tmp_path):
+    """offsets / element counts in the header are untrusted: a tensor outside the declared blob, or a blob beyond the file,
+    is rejected before anything is mapped"""
+    import json, struct
+    from funasr_amd.arena_file import MAGIC
+    sd = {"w": torch.arange(12, dtype=torch.float32).reshape(3, 4)}
+    path = str(tmp_path / "a.arena")
+    save_arena(sd, path)
+    raw = open(path, "rb").read()
+    (hlen,) = struct.unpack("<Q", raw[8:16])
+    head = json.loads(raw[16:16 + hlen])
+
+    def rewrite(h, name):
+        hb = json.dumps(h).encode()
+        pad = (-(len(MAGIC) + 8 + len(hb))) % 64
+        p = str(tmp_path / name)
+        with open(p, "wb") as f:
+            f.write(MAGIC + struct.pack("<Q", len(hb)) + hb + b"\0" * pad + raw[-48:])
+        return p
+
+    bad = dict(head, index=[dict(head["index"][0], offset=5)])
+    with pytest.raises(ValueError):
+        read_arena(rewrite(bad, "off.arena"))
+    with pytest.raises(ValueError):
+        read_arena(rewrite(dict(head, numel=10 ** 9), "numel.arena"))
+    read_arena(rewrite(head, "ok.arena"))

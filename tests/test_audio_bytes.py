@@ -73,3 +73,24 @@ def test_compressed_containers_never_fall_back_to_raw_pcm():
         with pytest.raises(RuntimeError, match="complete supported audio file"):
             load_audio(blob)
     assert not is_audio_container(_mp3_like(frames=1)) and not is_audio_container(b"\xff\xfb")
+
+
+def test_int16_arrays_are_scaled_before_resampling_and_channels_are_averaged():
+    """integer PCM must come out in [-1, 1] whether or not it is resampled on the way; a 2-D array is [channels, n] or
+    [n, channels] (the small axis is the channel axis), anything else is refused"""
+    import numpy as np
+    import torch
+    from funasr_amd.audio import load_audio
+    t = np.arange(8000) / 8000.0
+    pcm = (np.sin(2 * np.pi * 220 * t) * 10000).astype(np.int16)
+    same = load_audio(pcm, fs=8000, audio_fs=8000)
+    up = load_audio(pcm, fs=16000, audio_fs=8000)
+    assert abs(float(same.abs().max()) - 10000 / 32768.0) < 1e-3
+    assert up.numel() == 16000 and abs(float(up.abs().max()) - 10000 / 32768.0) < 2e-2
+    st = np.stack([pcm, pcm // 2], 0)                                    # [channels, n]
+    a = load_audio(st, fs=8000, audio_fs=8000)
+    b = load_audio(np.ascontiguousarray(st.T), fs=8000, audio_fs=8000)   # [n, channels]
+    assert a.shape == (8000,) and torch.allclose(a, b) and abs(float(a.abs().max()) - 7500 / 32768.0) < 1e-3
+    import pytest
+    with pytest.raises(ValueError):
+        load_audio(np.zeros((100, 100), np.float32))

@@ -151,3 +151,23 @@ def test_sensevoice_encoder_and_ctc_match_reference():
     assert (out - t(g["out"])).abs().max().item() < 1e-5
     logp = torch.log_softmax(torch.nn.functional.linear(out, sd["ctc.ctc_lo.weight"], sd["ctc.ctc_lo.bias"]), -1)
     assert np.array_equal(logp.argmax(-1).numpy(), g["frame_ids"])
+
+
+def test_oracle_sensevoice_glue_reproduces_reference_inference():
+    """the oracle's SenseVoice path (query frames, encoder, CTC arg-max, unique_consecutive, blank removal) against the
+    fixture recorded from the reference class's own `inference` (oracle/make_golden_sensevoice.py)"""
+    import json
+    from funasr_amd import synth
+    from oracle import paraformer_oracle as O
+    g = np.load(os.path.join(GOLD, "sensevoice_inference.npz"), allow_pickle=False)
+    cfg = json.loads(str(g["config"]))
+    sd = synth.sensevoice_state_dict(cfg, seed=int(g["seed"]))
+    sd["ctc.ctc_lo.bias"][0] += float(g["ctc_blank_bias_add"])
+    feats, lens = torch.from_numpy(g["feats"]), torch.from_numpy(g["lens"])
+    lid_dict = {"auto": 0, "zh": 3, "en": 4, "yue": 7, "ja": 11, "ko": 12, "nospeech": 13}
+    for ci, kw in enumerate(json.loads(str(g["cases"]))):
+        tn = kw.get("text_norm") or ("withitn" if kw.get("use_itn", False) else "woitn")
+        with torch.no_grad():
+            r = O.sensevoice_greedy(feats, lens, sd, cfg, language_id=lid_dict.get(kw.get("language", "auto"), 0),
+                                    textnorm_id={"withitn": 14, "woitn": 15}[tn])
+        assert [" ".join(str(i) for i in ids) for ids in r["ids"]] == json.loads(str(g[f"texts_{ci}"])), ci

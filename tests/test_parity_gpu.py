@@ -33,8 +33,9 @@ def fires_of(peaks):
 
 @pytest.fixture(params=["fp32", "bf16x3", "f16x2"])
 def f32_mode(request):
-    """the two fp32-accurate GEMM routes: v_mfma_f32_32x32x2_f32 (gemm_f32.hip) and three-bf16-plane operands with six
-    bf16 MFMA products (gemm_split3.hip). Both must meet every fp32 parity bar."""
+    """the three fp32-accurate GEMM routes: v_mfma_f32_32x32x2_f32 (gemm_f32.hip), three-bf16-plane operands with six bf16
+    MFMA products (gemm_split3.hip), two-fp16-plane operands with three fp16 MFMA products (gemm_f16x2.hip, which also
+    moves the encoder's self-attention to attention_f16x2.hip). All must meet every fp32 parity bar."""
     return request.param
 
 
@@ -243,6 +244,31 @@ def test_sensevoice_encoder_and_ctc_vs_reference_golden(cuda, f32_mode):
     assert np.array_equal(ctc.argmax(out).cpu().numpy(), g["frame_ids"])
 
 
+def test_sensevoice_inference_equals_reference_inference(cuda, f32_mode):
+    """`SenseVoiceSmall.inference` end to end (query frames by language / text-norm, encoder, fused CTC arg-max,
+    unique_consecutive, blank removal, tokenizer.decode, keys) against the fixture recorded from the REFERENCE class's own
+    `inference` (funasr/models/sense_voice/model.py:918-1030; oracle/make_golden_sensevoice.py), all six query cases."""
+    from funasr_amd.sense_voice import SenseVoiceSmall
+    g = gold("sensevoice_inference")
+    cfg = json.loads(str(g["config"]))
+    sd = synth.sensevoice_state_dict(cfg, seed=int(g["seed"]))
+    sd["ctc.ctc_lo.bias"][0] += float(g["ctc_blank_bias_add"])
+    model = SenseVoiceSmall.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(cuda).set_precision(f32_mode)
+
+    class IdTokenizer:
+        def decode(self, ids):
+            return " ".join(str(int(i)) for i in ids)
+
+    feats, lens = t(g["feats"]).to(cuda), t(g["lens"])
+    for ci, kw in enumerate(json.loads(str(g["cases"]))):
+        res, meta = model.inference(feats, data_lengths=lens, key=[f"utt{i}" for i in range(feats.shape[0])],
+                                    tokenizer=IdTokenizer(), frontend=None, device=cuda, data_type="fbank", **kw)
+        assert [r["text"] for r in res] == json.loads(str(g[f"texts_{ci}"])), (ci, kw)
+        assert [r["key"] for r in res] == json.loads(str(g[f"keys_{ci}"]))
+
+
 # ------------------------------------------------------------------- full-size, size-independent properties
 def test_full_size_batch_independence_and_fused_argmax(cuda, f32_mode):
     """BASELINE config 2 shapes (B=64 x 30 s -> T=500) on a shallow model: (1) every clip's encoder output and token
@@ -275,6 +301,59 @@ def test_full_size_batch_independence_and_fused_argmax(cuda, f32_mode):
     ids = logits.argmax(-1).cpu()
     for b in range(B):
         assert ids[b, : res["token_num"][b]].tolist() == res["raw_ids"][b]
+
+
+def test_full_configuration_ragged_batch_vs_oracle(cuda, f32_mode):
+    """The headline configuration itself -- Paraformer-large, 50 + 16 blocks, vocabulary 8404, T = 500 frames, B = 8 ragged
+    30 s ... 9 s clips from waveforms -- against the CPU oracle clip by clip: encoder <= 1e-3 (north_star), CIF fire
+    indices and token counts bit-exact, token ids equal except where the ORACLE's own top-2 logits are closer than 1e-4
+    (random-init weights put arg-maxes over 8404 classes on near-ties that any fp32 summation order may flip; the
+    fp32-MFMA mode flips such tokens too, tools/mode_parity.py / profiles/r02_mode_parity.json)."""
+    from funasr_amd.paraformer import Paraformer
+    from funasr_amd.wav_frontend import WavFrontend
+    from oracle import paraformer_oracle as O
+    cfg = synth.PARAFORMER_LARGE
+    sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(cuda).set_precision(f32_mode)
+    shift, scale = synth.synthetic_cmvn(560)
+    cmvn = torch.stack([shift, scale])
+    fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0, device=cuda)
+    secs = [30.0, 30.0, 27.3, 24.1, 19.9, 15.0, 12.2, 9.0]
+    clips = [synth.speech_like(int(sec * 16000), seed=40 + i) for i, sec in enumerate(secs)]
+    lens = [c.numel() for c in clips]
+    wav = torch.zeros(len(clips), max(lens))
+    for i, c in enumerate(clips):
+        wav[i, : lens[i]] = c
+    feats, flens = fe(wav.to(cuda), lens)
+    assert int(flens.max()) == 500
+    res = model.recognize_features(feats, flens, return_intermediate=True)
+    enc, peaks = res["enc"].cpu(), res["peaks"].cpu()
+    worst, margin, flips = 0.0, 1.0, 0
+    with torch.no_grad():
+        # the oracle decodes the SAME padded batch (the reference's batch semantics: the CIF convolution of a shorter clip's
+        # last frames sees the encoder's output on its padding, cif_predictor.py:275-277, so a clip's tail token depends on
+        # the batch it is padded in -- decoding it alone is a different, equally valid, reference result)
+        f, fl = O.wav_frontend(clips, cmvn)
+        r = O.paraformer_greedy(f, fl, sd, cfg)
+        top2 = torch.topk(r["logits"], 2, dim=-1).values
+        for i in range(len(clips)):
+            T = int(r["olens"][i])
+            assert T == int(flens[i])
+            worst = max(worst, float((r["enc"][i, :T] - enc[i, :T]).abs().max()))
+            fire_c = torch.floor(r["peaks"][i]) >= 1
+            assert torch.equal(fire_c, torch.floor(peaks[i, : fire_c.numel()]) >= 1), f"clip {i}: CIF fire indices differ"
+            assert int(r["token_num"][i]) == res["token_num"][i]
+            ps = torch.cumsum(r["alphas"][i].double(), 0)[: T + 1]
+            fr = ps - torch.floor(ps)
+            margin = min(margin, float(torch.minimum(fr, 1 - fr)[ps > 0.5].min()))
+            for pos, (x, y) in enumerate(zip(r["raw_ids"][i], res["raw_ids"][i])):
+                if x != y:
+                    flips += 1
+                    assert float(top2[i, pos, 0] - top2[i, pos, 1]) < 1e-4, f"clip {i} token {pos}: {x} != {y} and not a near-tie"
+    assert worst < 1e-3, worst
+    print(f"[{f32_mode}] encoder max|d| {worst:.2e}, min prefix-sum margin {margin:.2e}, near-tie token flips {flips}")
 
 
 def test_bf16_operand_mode_stays_close_to_fp32_mode(cuda):

@@ -136,6 +136,25 @@ def test_streaming_inference_api_two_calls_equals_reference_tokens(cuda):
     assert r3[0]["token_int"] == sum(ref, [])
 
 
+def test_streaming_inference_on_a_wav_path_inside_a_list_is_a_whole_utterance(cuda, tmp_path):
+    """AutoModel.inference always hands `data_in` over as a list (auto_model.py:796-812): a file PATH in that list is a
+    complete recording, so the look-ahead flush and the tail chunk must run without is_final being passed
+    (paraformer_streaming/model.py:692-701) -- the trailing tokens of the reference session are all there."""
+    import wave
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    fe = frontend(cuda)
+    path = str(tmp_path / "utt.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes(g["pcm"].astype("<i2").tobytes())
+    kw = dict(chunk_size=[0, 10, 5], encoder_chunk_look_back=4, decoder_chunk_look_back=1)
+    ref = sum((g[f"tokens_{i}"].tolist() for i in range(int(g["n_chunks"]))), [])
+    for data_in in ([path], path):
+        r, _ = model.inference(data_in, key=["utt"], tokenizer=None, frontend=fe, cache={}, **kw)
+        assert r[0]["token_int"] == ref
+
+
 @pytest.mark.parametrize("chunk,enc_lb,dec_lb", [([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1)])
 def test_stream_other_chunk_geometries_vs_streaming_oracle(cuda, chunk, enc_lb, dec_lb):
     """chunk_size / look-back settings other than the golden session's, against the (reference-pinned) streaming oracle
