@@ -19,6 +19,79 @@ _STUBS = ["torchaudio", "torchaudio.compliance", "torchaudio.compliance.kaldi", 
           "rapidfuzz.distance", "omegaconf", "soundfile", "jieba", "editdistance", "hydra", "modelscope"]
 
 
+def _install_omegaconf() -> None:
+    """A small WORKING stand-in for the parts of omegaconf the reference's AutoModel construction path uses
+    (funasr/download/download_model_from_hub.py:72-103, funasr/auto/auto_model.py:18,565-571): OmegaConf.load / merge /
+    to_container / create and the DictConfig / ListConfig types, on plain dicts read by yaml.safe_load."""
+    if "omegaconf" in sys.modules and getattr(sys.modules["omegaconf"], "_pf_functional", False):
+        return
+    try:
+        import omegaconf  # noqa: F401  (the real package, if the image ever gains it)
+        if not isinstance(sys.modules["omegaconf"], _Stub):
+            return
+    except Exception:
+        pass
+    import yaml
+
+    class DictConfig(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    class ListConfig(list):
+        pass
+
+    def wrap(x):
+        if isinstance(x, dict):
+            return DictConfig({k: wrap(v) for k, v in x.items()})
+        if isinstance(x, (list, tuple)) and not isinstance(x, str):
+            return ListConfig([wrap(v) for v in x])
+        return x
+
+    def unwrap(x):
+        if isinstance(x, dict):
+            return {k: unwrap(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [unwrap(v) for v in x]
+        return x
+
+    def merge2(a, b):
+        out = DictConfig(a)
+        for k, v in b.items():
+            out[k] = merge2(out[k], v) if isinstance(out.get(k), dict) and isinstance(v, dict) else wrap(v)
+        return out
+
+    class OmegaConf:
+        @staticmethod
+        def load(path):
+            with open(path, "r", encoding="utf-8") as f:
+                return wrap(yaml.safe_load(f) or {})
+
+        @staticmethod
+        def create(obj=None):
+            return wrap(obj if obj is not None else {})
+
+        @staticmethod
+        def merge(*cfgs):
+            out = DictConfig()
+            for c in cfgs:
+                out = merge2(out, wrap(c))
+            return out
+
+        @staticmethod
+        def to_container(cfg, resolve=True):
+            return unwrap(cfg)
+
+    m = types.ModuleType("omegaconf")
+    m.OmegaConf, m.DictConfig, m.ListConfig, m._pf_functional = OmegaConf, DictConfig, ListConfig, True
+    sys.modules["omegaconf"] = m
+
+
 class _Stub(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__"):
@@ -40,6 +113,7 @@ def install() -> None:
         pkg = types.ModuleType("funasr")
         pkg.__path__ = [os.path.join(REF_ROOT, "funasr")]
         sys.modules["funasr"] = pkg
+    _install_omegaconf()
     for name in _STUBS:
         try:
             if name not in sys.modules:
@@ -68,3 +142,14 @@ def modules():
                 cif_wo_hidden_v1=cif_wo_hidden_v1, ParaformerSANMDecoder=ParaformerSANMDecoder,
                 SenseVoiceEncoderSmall=SenseVoiceEncoderSmall, CTC=CTC, wav_frontend=wav_frontend,
                 SinusoidalPositionEncoder=SinusoidalPositionEncoder)
+
+
+def reference_automodel():
+    """The reference's own `funasr.auto.auto_model.AutoModel` class (funasr/auto/auto_model.py), imported with the stand-ins
+    above, plus its registry and the host-side classes its construction path resolves by name (tokenizers). The model /
+    frontend / encoder / predictor / decoder keys are left EMPTY here: `funasr_amd.install()` fills them."""
+    install()
+    import funasr.tokenizer.char_tokenizer  # noqa: F401  registers CharTokenizer
+    from funasr.auto.auto_model import AutoModel
+    from funasr.register import tables
+    return AutoModel, tables

@@ -1,0 +1,83 @@
+"""The reference's OWN `funasr.AutoModel` (funasr/auto/auto_model.py, imported from /root/reference with the small stand-ins of
+oracle/ref_import.py for omegaconf & co.) driven over `funasr_amd.install()`: INTEGRATION.md section 1 promises that
+`install()` + `funasr.AutoModel(model=<dir>)` builds the HIP classes by name and that `generate()` reaches their `inference`
+with the arguments the reference passes. Build container only (the GPU box has no /root/reference): construction and the
+call contract are checked here on CPU; the numerical result of the same `inference` is what tests/test_auto_model.py checks
+on the GPU through this package's AutoModel shim."""
+import inspect
+import os
+
+import pytest
+import torch
+
+from oracle import ref_import
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason="reference checkout not present (GPU box)")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    AutoModel, tables = ref_import.reference_automodel()
+    from funasr_amd.install import install
+    done = install(tables)
+    assert ("model_classes", "Paraformer") in done
+    return AutoModel, tables
+
+
+def test_reference_automodel_builds_the_hip_classes_from_a_model_dir(ref, tmp_path):
+    """build_model (auto_model.py:522-675): download_model on a local dir (download_model_from_hub.py:72-103), tokenizer /
+    frontend / model resolved from the reference registry, reference load_pretrained_model(strict) into our modules"""
+    AutoModel, tables = ref
+    from funasr_amd.auto_model import AutoModel as Shim
+    from funasr_amd.paraformer import Paraformer
+    from funasr_amd.wav_frontend import WavFrontend
+    from tests._model_dir import make_model_dir
+    d = str(tmp_path / "m")
+    info = make_model_dir(d)
+    am = AutoModel(model=d, device="cpu", disable_update=True, disable_pbar=True, frontend_conf={"dither": 0.0})
+    assert type(am.model) is Paraformer and type(am.kwargs["frontend"]) is WavFrontend
+    assert type(am.kwargs["tokenizer"]).__module__.startswith("funasr.tokenizer")      # the reference's own tokenizer
+    assert am.kwargs["frontend_conf"]["cmvn_file"].endswith("am.mvn") and am.kwargs["vocab_size"] == len(am.kwargs["token_list"])
+    # the reference loader filled every parameter: identical to what this package's AutoModel shim builds from the same dir
+    shim, _ = Shim.build_model(model=d, device="cpu")
+    got, want = am.model.state_dict(), shim.state_dict()
+    assert list(got) == list(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert torch.equal(got["encoder.encoders.0.norm1.weight"], info["sd"]["encoder.encoders.0.norm1.weight"])
+
+
+def test_reference_generate_reaches_our_inference_with_a_compatible_call(ref, tmp_path, monkeypatch):
+    """generate() -> inference() (auto_model.py:696-850): `model.inference(data_in=[...], key=[...], **kwargs)` with the
+    tokenizer / frontend / device entries of kwargs -- the call must bind to Paraformer.inference's signature, and what it
+    returns ((results, meta_data) with meta_data["batch_data_time"]) must flow back out of generate()."""
+    AutoModel, tables = ref
+    from funasr_amd.paraformer import Paraformer
+    from tests._model_dir import make_model_dir, write_wav
+    from funasr_amd import synth
+    d = str(tmp_path / "m")
+    make_model_dir(d)
+    wavs = []
+    for i in range(3):
+        p = str(tmp_path / f"u{i}.wav")
+        write_wav(p, synth.speech_like(16000 + 4000 * i, seed=i))
+        wavs.append(p)
+    am = AutoModel(model=d, device="cpu", disable_update=True, disable_pbar=True, batch_size=2, frontend_conf={"dither": 0.0})
+    seen = []
+    real_sig = inspect.signature(Paraformer.inference)
+
+    def recorder(self, *args, **kwargs):
+        bound = real_sig.bind(self, *args, **kwargs)            # TypeError if the reference's call does not fit
+        a = bound.arguments
+        seen.append(a)
+        kw = a.get("kwargs", {})
+        assert a["tokenizer"] is am.kwargs["tokenizer"] and a["frontend"] is am.kwargs["frontend"]
+        assert kw.get("device") == "cpu" and isinstance(a["data_in"], list) and len(a["key"]) == len(a["data_in"])
+        res = [{"key": k, "text": f"text of {os.path.basename(p)}"} for k, p in zip(a["key"], a["data_in"])]
+        return res, {"batch_data_time": 1.0 * len(res), "load_data": "0.0", "extract_feat": "0.0"}
+
+    monkeypatch.setattr(Paraformer, "inference", recorder)
+    out = am.generate(input=wavs)
+    assert [len(c["data_in"]) for c in seen] == [2, 1]          # batch_size 2 over three files (auto_model.py:800-806)
+    assert [r["text"] for r in out] == [f"text of u{i}.wav" for i in range(3)]
+    assert [r["key"] for r in out] == ["u0", "u1", "u2"]
