@@ -150,10 +150,10 @@ def main():
         return model.enqueue_features(feats, flens)
 
     def collect(pending):
-        res = model.collect(pending)
-        if world > 1:      # gather hypotheses on rank 0 (fixed-stride int32 ids + counts), the path's only exchange
-            dp.gather_hypotheses(res["raw_ids"], N_PAD, dst=0, device=device)
-        return res
+        if world > 1 and pending["ids"] is not None:
+            # gather hypotheses on rank 0 (fixed-stride int32 ids + counts packed on the device), the path's only exchange
+            dp.gather_packed(dp.pack_hypotheses_device(pending["ids"], pending["tok"], N_PAD), dst=0)
+        return model.collect(pending)
 
     def step():
         return collect(enqueue())
@@ -195,22 +195,22 @@ def main():
     trace(f"timed region done: {dt:.3f} s for {args.steps} steps")
     if world > 1:
         dt = max_over_ranks(dt)
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
     audio_s = world * B * args.seconds * args.steps
     value = audio_s / dt
 
     # ---- per-kernel numbers: the same steps again with a hipEvent pair around every launch of the dominant kernels, on the
-    #      launch stream (the events cost ~5 ms per step, which is why this pass is not the timed one)
+    #      launch stream (the events cost ~5 ms per step, which is why this pass is not the timed one). Every rank runs it
+    #      (the steps contain the hypothesis gather); only rank 0's numbers are reported
     torch.cuda.synchronize()
     lib.pf_prof_reset()
     lib.pf_prof_enable(1)
     run_steps(args.steps)
-    torch.cuda.synchronize()
+    sync()
     lib.pf_prof_enable(0)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
     prof = read_prof(lib, args.steps)
     if args.precision in PRODUCTS:
         # dominant kernel: the split-operand GEMM. `achieved` = algorithmic (fp32-equivalent) 2MNK flops per second; the

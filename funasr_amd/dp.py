@@ -72,6 +72,31 @@ def pack_hypotheses(ids: Sequence[Sequence[int]], n_pad: int, device=None) -> to
     return out if device is None else out.to(device)
 
 
+def pack_hypotheses_device(ids: torch.Tensor, counts: Sequence[int], n_pad: int) -> torch.Tensor:
+    """The same [B, 1 + n_pad] int32 layout built ON THE DEVICE from the decoder's arg-max tensor `ids` [B, N] (int32, what
+    ParaformerSANMDecoder.greedy returns) and the per-clip token counts: three tensor ops, no per-clip host loop, and the
+    gather can start without the ids ever visiting the host."""
+    B, N = ids.shape
+    n = min(N, n_pad)
+    cnt = torch.as_tensor(list(counts), dtype=torch.int32, device=ids.device).clamp_(max=n_pad)
+    out = torch.full((B, 1 + n_pad), -1, dtype=torch.int32, device=ids.device)
+    out[:, 0] = cnt
+    keep = torch.arange(n, device=ids.device)[None, :] < cnt[:, None]
+    out[:, 1:1 + n] = torch.where(keep, ids[:, :n].to(torch.int32), out[:, 1:1 + n])
+    return out
+
+
+def gather_packed(mine: torch.Tensor, dst: int = 0):
+    """gather of equally shaped packed hypothesis tensors; on `dst` the list of per-rank id lists, elsewhere None"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = _collective_device(mine.contiguous())
+    bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [unpack_hypotheses(b) for b in bufs]
+
+
 def unpack_hypotheses(t: torch.Tensor) -> List[List[int]]:
     t = t.cpu()
     return [t[b, 1:1 + int(t[b, 0])].tolist() for b in range(t.shape[0])]

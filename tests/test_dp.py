@@ -33,6 +33,17 @@ def test_pack_unpack_hypotheses_roundtrip():
     assert back == [[5, 6, 7], [], [1] * 32, [8403]]          # truncated to n_pad like bench.py
 
 
+def test_device_side_pack_equals_host_pack():
+    """pack_hypotheses_device (tensor ops on the decoder's [B, N] arg-max tensor) == pack_hypotheses (per-clip host loop)"""
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 8404, (5, 40), generator=g, dtype=torch.int32)
+    counts = [40, 0, 17, 33, 1]
+    host = dp.pack_hypotheses([ids[b, :c].tolist() for b, c in enumerate(counts)], n_pad=32)
+    assert torch.equal(dp.pack_hypotheses_device(ids, counts, n_pad=32), host)
+    wide = dp.pack_hypotheses_device(ids, counts, n_pad=64)                 # n_pad beyond N: still -1 padded
+    assert wide.shape == (5, 65) and dp.unpack_hypotheses(wide) == [ids[b, :c].tolist() for b, c in enumerate(counts)]
+
+
 def _fake_decode_factory(lengths):
     def decode(indices):
         return [[(i * 7 + k) % 8404 for k in range(lengths[i] % 13)] for i in indices]

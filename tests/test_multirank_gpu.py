@@ -1,0 +1,63 @@
+"""First contact of the N > 1 code paths on ONE GPU: two ranks (torch.distributed.run, gloo, both on cuda:0) through the very
+commands the driver uses on an 8-GPU node -- `bench.py --gpus 2` and the corpus sweep -- so that RCCL day is boring:
+rendezvous, the packed-arena weight broadcast, sharding, the device-packed hypothesis gather, max-over-ranks timing and the
+rank-0 JSON line are all exercised; the sweep's hypotheses must come back in CORPUS order and equal the 1-rank result."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(cmd, timeout):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+def _torchrun(n, script_args):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(_port())] + script_args
+
+
+@pytest.mark.timeout(900)
+def test_sweep_two_ranks_equals_one_rank_in_corpus_order(cuda, tmp_path):
+    """every clip decoded alone (--batch-seconds 1: a clip's tail token depends on what it is padded with, which is
+    reference behaviour, so equality across shardings is defined per clip), 1 rank vs 2 ranks"""
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    common = ["--clips", "48", "--batch-seconds", "1", "--no-overlap"]
+    _run([sys.executable, "tools/sweep.py"] + common + ["--dump", one], 400)
+    out = _run(_torchrun(2, ["tools/sweep.py"] + common + ["--dist-backend", "gloo", "--dump", two]), 500)
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["clips"] == 48 and line["value"] > 0
+    a, b = json.load(open(one)), json.load(open(two))
+    assert len(a) == len(b) == 48 and all(len(x) > 0 for x in a)
+    assert a == b
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_prints_one_whole_job_line(cuda):
+    out = _run(_torchrun(2, ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo"]), 600)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["weight_arena_bytes_broadcast"] > 8e8
+    assert d["config"]["hypothesis_gather_bytes_per_rank_per_step"] == 64 * 513 * 4
+    # whole-job aggregate: both ranks' clips over the max-over-ranks time
+    assert abs(d["value"] - 2 * 64 * 30.0 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01
+    assert "roofline" in d and d["roofline"]["frac"] > 0

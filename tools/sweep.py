@@ -32,7 +32,8 @@ def main():
     ap.add_argument("--clips", type=int, default=2000)
     ap.add_argument("--batch-seconds", type=float, default=1920.0, help="padded audio seconds per batch (64 x 30 s)")
     ap.add_argument("--model", default="paraformer", choices=["paraformer", "sensevoice"])
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16", "bf16x3"])
+    ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16", "bf16x3", "f16x2"])
+    ap.add_argument("--dump", default=None, help="rank 0 writes the hypotheses in CORPUS order to this JSON file")
     ap.add_argument("--no-overlap", action="store_true", help="assemble, decode and collect one batch at a time")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
@@ -155,6 +156,16 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.dist_backend == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    if rank == 0 and args.dump:
+        if world > 1:                                          # rank r decoded the clips dp.shard_indices(lens, world, r), in that order
+            corpus = [None] * args.clips
+            for r in range(world):
+                for k, i in enumerate(dp.shard_indices(lens, world, r)):
+                    corpus[i] = gathered[r][k]
+        else:
+            corpus = [hyps[i] for i in range(args.clips)]
+        with open(args.dump, "w") as f:
+            json.dump(corpus, f)
     if rank == 0:
         total_s = sum(durs)
         padded = sum(len(b) * max(lens[i] for i in b) for b in batches) / 16000.0
