@@ -398,7 +398,7 @@ def run_sensevoice(device, args):
 
     out = {}
     for mode in (args.precision if args.precision != "bf16" else "f16x2", "fp32"):
-        model.encoder.set_precision(mode)
+        model.set_precision(mode)
         for _ in range(2):
             r = step()
         torch.cuda.synchronize()

@@ -130,6 +130,7 @@ SIGNATURES = {
     "pf_ctc_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "pf_ctc_missing": (C.c_int, [_vp]),
     "pf_ctc_greedy": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "pf_ctc_set_precision": (C.c_int, [_vp, _i32]),
     "pf_stream_create": (_vp, [_vp, _vp, _vp, C.POINTER(pf_stream_config)]),
     "pf_stream_destroy": (None, [_vp]),
     "pf_stream_set_pe": (C.c_int, [_vp, _vp, _i32]),

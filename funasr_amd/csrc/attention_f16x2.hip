@@ -38,15 +38,17 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, idx = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y;
+    const int Tq = p.Tq > 0 ? p.Tq : p.Tp;               // cross-attention: Q / O rows per sequence differ from K's
     const int q = blockIdx.x * 256 + wave * 32 + idx;
-    const int qc = q < p.Tp ? q : p.Tp - 1;
+    const int qc = q < Tq ? q : Tq - 1;
     const int klen = p.klens[b];
     const size_t row0 = (size_t)b * p.Tp;
+    const size_t qrow0 = (size_t)b * Tq;
 
     // ---- Q planes: step s covers d in [16 s, 16 s + 16); half-wave h holds the 8 d's of chunk 2 s + h
     f16x8 qf[2][8];
     {
-        const unsigned short* qp = p.Q + (row0 + qc) * p.ldq + head * DK + hh * 8;
+        const unsigned short* qp = p.Q + (qrow0 + qc) * p.ldq + head * DK + hh * 8;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
         glds16(vsrc + p.vt_plane + kt * KT, base + 2 * KP_B + VP_B);
     };
 
-    const float sscale = p.sscale;                       // 2^-(e_q + e_k)
+    const float sscale = p.sscale_dev ? p.sscale * *p.sscale_dev : p.sscale;   // 2^-(e_q + e_k)
     const int ntiles = (klen + KT - 1) / KT;
     stage(0);
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -180,13 +182,13 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
         const int rr = it * 4 + (lane >> 4), c8 = (lane & 15) * 8;
         const float4 a = *reinterpret_cast<const float4*>(slab + rr * OLD + c8);
         const float4 c = *reinterpret_cast<const float4*>(slab + rr * OLD + c8 + 4);
-        if (qw0 + rr < p.Tp) {
+        if (qw0 + rr < Tq) {
             uint4 h, l;
             split2_pk(a.x, a.y, h.x, l.x);
             split2_pk(a.z, a.w, h.y, l.y);
             split2_pk(c.x, c.y, h.z, l.z);
             split2_pk(c.z, c.w, h.w, l.w);
-            unsigned short* op = p.O + (row0 + qw0 + rr) * p.ldo + head * DK + c8;
+            unsigned short* op = p.O + (qrow0 + qw0 + rr) * p.ldo + head * DK + c8;
             *reinterpret_cast<uint4*>(op) = h;
             *reinterpret_cast<uint4*>(op + p.o_plane) = l;
         }
@@ -207,7 +209,7 @@ int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured = true;
     }
-    dim3 grid(ceil_div(a.Tp, 256), a.H, a.B);
+    dim3 grid(ceil_div(a.Tq > 0 ? a.Tq : a.Tp, 256), a.H, a.B);
     hipLaunchKernelGGL(attention_f16x2_kernel, grid, dim3(512), LDS_BYTES, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;

@@ -198,11 +198,26 @@ struct Gemm2Args {
     unsigned short* Qp; unsigned short* Kp; size_t qk_plane;
     unsigned short* VT; int ldvt; size_t vt_plane;
     float q_mul, k_mul, v_mul;
+    // KV form (kv_form != 0, N == 2 qkv_D): the decoder's fused k|v projection of the memory: columns [0, D) -> K planes,
+    // [D, 2D) -> V^T planes only (C may be null). kv_mul_dev (optional): device floats {k, v} multiplied into k_mul / v_mul
+    // (scales chosen on the device from max |memory|)
+    int kv_form;
+    const float* kv_mul_dev;
+    // fused row arg-max (vocabulary projections): when amax_val != nullptr nothing is written to C / C2 but one partial
+    // (max, lowest index of the max) per (row, wave column range): entry 2 * column_block + wave_column of row `row`
+    float* amax_val; int* amax_idx; int amax_ld;
 };
+// number of arg-max partials per row launch_gemm_f16x2 writes for an N-column problem
+int gemm_f16x2_argmax_parts(int M, int N);
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream);
 // fp32 [M, N] * scale -> two fp16 planes [M, ldy]; columns N..ldy-1 are written as zero
+// seq_out > 0: output row b * seq_out + t holds input row b * seq_in + t for t < seq_in and zeros for the padding rows
+// (M counts OUTPUT rows)
 int launch_split2(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, float scale,
-                  hipStream_t stream, const float* scale_dev = nullptr);
+                  hipStream_t stream, const float* scale_dev = nullptr, int seq_out = 0, int seq_in = 0);
+// per decoder layer l: out[4 l .. 4 l + 3] = {k_mul, v_mul, 1 / k_mul, 1 / v_mul}, the power-of-two plane scales of
+// k = Wk m + bk and v from the bounds (*amax_dev) * l1[2 l + {0, 1}] + bmax[2 l + {0, 1}]
+int launch_kv_scales(const float* amax_dev, const float* l1_bmax_dev, int n_layers, float* out, hipStream_t stream);
 // sc[0] = 2^e, sc[1] = 2^-e with e = floor(log2(32768 / *amax_dev)): the plane scale of a tensor whose max |x| is only
 // known on the device (and its inverse for the consuming GEMM's oscale_dev)
 int launch_pow2_scale(const float* amax_dev, float* sc, hipStream_t stream);
@@ -263,8 +278,10 @@ struct Attn2Args {
     const unsigned short* VT; int ldvt; size_t vt_plane;  // [2][H 128, ldvt >= B Tp + 32] transposed planes of v * 2^e_v
     unsigned short* O; int ldo; size_t o_plane;           // [2][B Tp, H 128] planes of the result * 2^e_ctx
     const int* klens;                                     // device int32 [B] valid keys per sequence (1 .. Tp)
-    int B, H, Tp;                                         // Tp % 16 == 0
+    int B, H, Tp;                                         // Tp % 16 == 0: rows per sequence of K / V^T
+    int Tq;                                               // rows per sequence of Q / O (0 = Tp: self-attention)
     float sscale;                                         // 2^-(e_q + e_k)
+    const float* sscale_dev;                              // optional device float multiplied into sscale
     float oscale;                                         // 2^(e_ctx - e_v - 10)
 };
 int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream);

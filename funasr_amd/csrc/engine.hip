@@ -703,8 +703,9 @@ struct DecLayerW {
     const float *n1g, *n1b, *w1, *b1, *fng, *fnb, *w2, *n2g, *n2b, *fsmn_w, *n3g, *n3b, *q_w, *q_b, *kv_w, *kv_b,
         *o_w, *o_b;
     // f16x2 mode: weight planes + exponents, and the exponents of the LayerNorm-output planes (from gamma / beta)
-    const unsigned short *w1_2 = nullptr, *w2_2 = nullptr, *q_2 = nullptr, *kv_2 = nullptr;
-    int ew_1 = 0, ew_2 = 0, ew_q = 0, ew_kv = 0, e_n1 = 0, e_fn = 0, e_n3 = 0;
+    const unsigned short *w1_2 = nullptr, *w2_2 = nullptr, *q_2 = nullptr, *kv_2 = nullptr, *o_2 = nullptr;
+    int ew_1 = 0, ew_2 = 0, ew_q = 0, ew_kv = 0, ew_o = 0, e_n1 = 0, e_fn = 0, e_n3 = 0, e_q = 0;
+    float kv_l1b[4] = {0.f, 0.f, 0.f, 0.f};      // max row L1 norm and max |bias| of the k half, then of the v half, of linear_k_v
     bool x2_ready = false;
 };
 struct Decoder {
@@ -717,6 +718,10 @@ struct Decoder {
     int precision = 0;       // 0 fp32, 1 bf16 operands (GEMMs + cross-attention), fp32 residual / LN statistics / FSMN
     DevBuf t16, ffn16, ffn2_16, q16, kv16, ctx16, mem16, hid16;
     DevBuf dsc;              // f16x2 mode: [amax(memory), 2^e, 2^-e] chosen on the device per forward
+    DevBuf dscl, dlb;        // per layer {k_mul, v_mul, 1/k_mul, 1/v_mul} (device-chosen) and the constants they come from
+    DevBuf k2, vt2;          // cross-attention operands written by the KV form of linear_k_v (attention_f16x2.hip)
+    bool lb_uploaded = false;
+    int e_an = INT32_MIN;    // exponent of the after_norm output planes (f16x2 vocabulary projection)
 };
 
 static int decoder_resolve(Decoder* d) {
@@ -748,6 +753,8 @@ static int decoder_resolve(Decoder* d) {
         w.w2 = d->tt.get(p + "feed_forward.w_2.weight");
         d->last = w;
     }
+    d->lb_uploaded = false;
+    d->e_an = INT32_MIN;
     d->resolved = true;
     return 0;
 }
@@ -781,6 +788,8 @@ struct Ctc {
     int d_model, vocab;
     TensorTable tt;
     DevBuf pval, pidx;
+    int precision = 0;       // 0 fp32 MFMA, 3 f16x2 arg-max route
+    DevBuf h2, dsc;          // f16x2: planes of the hidden states, [amax, 2^e, 2^-e]
 };
 
 
@@ -824,7 +833,15 @@ static int dec_layer_x2(Decoder* d, DecLayerW& w, const std::string& p, bool att
         w.e_n3 = exp_for_bound(sqrtf((float)D) * g + b);
         w.q_2 = d->tt.get_split2(p + "src_attn.linear_q.weight", D, D, &w.ew_q, s);
         w.kv_2 = d->tt.get_split2(p + "src_attn.linear_k_v.weight", 2 * D, D, &w.ew_kv, s);
-        if (!w.q_2 || !w.kv_2) return -2;
+        w.o_2 = d->tt.get_split2(p + "src_attn.linear_out.weight", D, D, &w.ew_o, s);
+        if (!w.q_2 || !w.kv_2 || !w.o_2) return -2;
+        float bq;
+        if (TensorTable::dev_linear_bound(w.q_w, D, D, D, w.q_b, sqrtf((float)D) * g + b, &bq, s)) return -2;
+        w.e_q = exp_for_bound(bq * powf((float)(D / d->cfg.n_heads), -0.5f));
+        if (TensorTable::dev_linear_bound(w.kv_w, D, D, D, nullptr, 1.f, &w.kv_l1b[0], s) ||
+            TensorTable::dev_absmax(w.kv_b, D, &w.kv_l1b[1], s) ||
+            TensorTable::dev_linear_bound(w.kv_w + (size_t)D * D, D, D, D, nullptr, 1.f, &w.kv_l1b[2], s) ||
+            TensorTable::dev_absmax(w.kv_b + D, D, &w.kv_l1b[3], s)) return -2;
     }
     w.x2_ready = true;
     return 0;
@@ -1802,6 +1819,7 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     // three-plane operands on the bf16 matrix cores; the D x D projections and w_2 keep the fp32 MFMA tiles
     const bool x3 = d->precision == 2;
     const bool x2 = d->precision == 3;
+    const int Tp = round_up(T, 16), Mkp = B * Tp;           // f16x2: padded key rows per sequence
     const unsigned short* mem3 = nullptr;
     const unsigned short* mem2 = nullptr;
     float* dsc = nullptr;
@@ -1809,17 +1827,33 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
         // f16x2 mode: w_1, w_2, linear_q, linear_k_v on the fp16 matrix cores (gemm_f16x2.hip). The memory planes' scale
         // is chosen on the device from max |memory| (no host round trip); linear_out keeps the fp32 MFMA tile (its operand,
         // the attention output, has no a-priori bound here)
+        const size_t cap_k = d->k2.cap, cap_v = d->vt2.cap;
         if (d->t16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D) || d->ffn16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * F) ||
-            d->mem16.ensure(sizeof(unsigned short) * 2 * (size_t)Mk * D) || d->dsc.ensure(sizeof(float) * 4))
+            d->q16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D) || d->ctx16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D) ||
+            d->mem16.ensure(sizeof(unsigned short) * 2 * (size_t)Mkp * D) || d->dsc.ensure(sizeof(float) * 4) ||
+            d->k2.ensure(sizeof(unsigned short) * 2 * ((size_t)Mkp + 32) * D) || d->vt2.ensure(sizeof(unsigned short) * 2 * D * ((size_t)Mkp + 64)) ||
+            d->dscl.ensure(sizeof(float) * 4 * c.n_blocks) || d->dlb.ensure(sizeof(float) * 4 * c.n_blocks))
             return -2;
-        dsc = d->dsc.as<float>();
-        if ((rc = launch_absmax(memory, (size_t)Mk * D, dsc, s))) return rc;
-        if ((rc = launch_pow2_scale(dsc, dsc + 1, s))) return rc;
-        if ((rc = launch_split2(memory, D, d->mem16.as<unsigned short>(), D, (size_t)Mk * D, Mk, D, 1.f, s, dsc + 1))) return rc;
-        mem2 = d->mem16.as<unsigned short>();
+        // rows / columns past the last sequence are read by the last key tile (and masked): keep them finite
+        if (d->k2.cap != cap_k) PF_HIP_TRY(hipMemsetAsync(d->k2.p, 0, d->k2.cap, s));
+        if (d->vt2.cap != cap_v) PF_HIP_TRY(hipMemsetAsync(d->vt2.p, 0, d->vt2.cap, s));
         for (int l = 0; l < c.n_blocks; ++l)
             if ((rc = dec_layer_x2(d, d->layers[l], "decoders." + std::to_string(l) + ".", true, s))) return rc;
         if ((rc = dec_layer_x2(d, d->last, "decoders3.0.", false, s))) return rc;
+        if (!d->lb_uploaded) {
+            std::vector<float> lb((size_t)4 * c.n_blocks);
+            for (int l = 0; l < c.n_blocks; ++l) for (int j = 0; j < 4; ++j) lb[4 * l + j] = d->layers[l].kv_l1b[j];
+            PF_HIP_TRY(hipMemcpyAsync(d->dlb.p, lb.data(), sizeof(float) * lb.size(), hipMemcpyHostToDevice, s));
+            PF_HIP_TRY(hipStreamSynchronize(s));             // `lb` is a stack object
+            d->lb_uploaded = true;
+        }
+        dsc = d->dsc.as<float>();
+        if ((rc = launch_absmax(memory, (size_t)Mk * D, dsc, s))) return rc;
+        if ((rc = launch_pow2_scale(dsc, dsc + 1, s))) return rc;
+        if ((rc = launch_kv_scales(dsc, d->dlb.as<float>(), c.n_blocks, d->dscl.as<float>(), s))) return rc;
+        // memory planes in the padded row layout of attention_f16x2.hip (Tp rows per sequence, padding rows zero)
+        if ((rc = launch_split2(memory, D, d->mem16.as<unsigned short>(), D, (size_t)Mkp * D, Mkp, D, 1.f, s, dsc + 1, Tp, T))) return rc;
+        mem2 = d->mem16.as<unsigned short>();
     }
     if (x3) {
         if (d->t16.ensure(sizeof(unsigned short) * 3 * (size_t)Mq * D) || d->mem16.ensure(sizeof(unsigned short) * 3 * (size_t)Mk * D))
@@ -1849,15 +1883,45 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
                 if ((rc = launch_layernorm(x, D, w.n3g, w.n3b, reinterpret_cast<float*>(t2p), D, Mq, D, D, c.ln_eps, s, 3, 0,
                                            (size_t)Mq * D, pow2f(w.e_n3)))) return rc;
             }
-            if ((rc = gemm2_simple(t2p, D, Mq, w.e_n3, w.q_2, w.ew_q, w.q_b, d->q.as<float>(), D, D, D, 0, nullptr, 0, s))) return rc;
+            Gemm2Args g{};                                                                    // q planes, pre-multiplied by d_k^-0.5
+            g.A = t2p; g.lda = D; g.a_plane = (size_t)Mq * D; g.W = w.q_2; g.ldw = D; g.w_plane = (size_t)D * D;
+            g.oscale = pow2f(-(w.e_n3 + w.ew_q)); g.bias = w.q_b; g.C2 = d->q16.as<unsigned short>(); g.ldc2 = D;
+            g.c_plane = (size_t)Mq * D; g.cscale = powf((float)(D / c.n_heads), -0.5f) * pow2f(w.e_q);
+            g.M = Mq; g.N = D; g.K = D;
+            ProfScope ps(PROF_GEMM3, 2.0 * Mq * (double)D * D, s);
+            if ((rc = launch_gemm_f16x2(g, s))) return rc;
         } else {
             if ((rc = layernorm(x, D, w.n3g, w.n3b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;    // norm3
             if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s)))
                 return rc;
         }
         if (x2) {
-            if ((rc = gemm2_simple(mem2, D, Mk, 0, w.kv_2, w.ew_kv, w.kv_b, d->kv.as<float>(), 2 * D, 2 * D, D, 0, nullptr, 0, s,
-                                   dsc + 2))) return rc;
+            // linear_k_v in its KV form: K planes and V^T planes straight into the attention kernel's operand layout
+            const float* lsc = d->dscl.as<float>() + 4 * l;
+            unsigned short* k2 = d->k2.as<unsigned short>();
+            unsigned short* vt2 = d->vt2.as<unsigned short>();
+            {
+                Gemm2Args g{};
+                g.A = mem2; g.lda = D; g.a_plane = (size_t)Mkp * D; g.W = w.kv_2; g.ldw = D; g.w_plane = (size_t)2 * D * D;
+                g.oscale = pow2f(-w.ew_kv); g.oscale_dev = dsc + 2; g.bias = w.kv_b; g.M = Mkp; g.N = 2 * D; g.K = D;
+                g.qkv_D = D; g.kv_form = 1; g.Kp = k2; g.qk_plane = ((size_t)Mkp + 32) * D; g.VT = vt2; g.ldvt = Mkp + 64;
+                g.vt_plane = (size_t)D * (Mkp + 64); g.k_mul = 1.f; g.v_mul = 1.f; g.kv_mul_dev = lsc;
+                ProfScope ps(PROF_GEMM3, 2.0 * Mkp * 2.0 * D * D, s);
+                if ((rc = launch_gemm_f16x2(g, s))) return rc;
+            }
+            {
+                Attn2Args aa{};
+                aa.Q = d->q16.as<unsigned short>(); aa.ldq = D; aa.q_plane = (size_t)Mq * D;
+                aa.K = k2; aa.ldk = D; aa.k_plane = ((size_t)Mkp + 32) * D; aa.VT = vt2; aa.ldvt = Mkp + 64;
+                aa.vt_plane = (size_t)D * (Mkp + 64); aa.O = d->ctx16.as<unsigned short>(); aa.ldo = D; aa.o_plane = (size_t)Mq * D;
+                aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tp = Tp; aa.Tq = N;
+                aa.sscale = pow2f(-w.e_q); aa.sscale_dev = lsc + 2; aa.oscale = pow2f(-10);        // ctx planes carry v's scale
+                ProfScope ps(PROF_ATTN, 4.0 * B * (double)N * T * D, s);
+                if ((rc = launch_attention_f16x2(aa, s))) return rc;
+            }
+            if ((rc = gemm2_simple(d->ctx16.as<unsigned short>(), D, Mq, 0, w.o_2, w.ew_o, w.o_b, x, D, D, D, 0, x, D, s, lsc + 3)))
+                return rc;                                                                        // x = residual + att
+            continue;
         } else if (x3) {
             if ((rc = gemm3_simple(mem3, D, Mk, w3(lp + "src_attn.linear_k_v.weight", 2 * D, D), w.kv_b, d->kv.as<float>(),
                                    2 * D, 2 * D, D, 0, s))) return rc;
@@ -1883,6 +1947,35 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
         if (rc) return rc;
     }
     float* hid = hidden_out ? hidden_out : d->hid.as<float>();
+    if (x2 && V > 0 && ids && !logits && !hidden_out) {
+        // greedy route in the f16x2 mode: after_norm writes two-plane operands, the vocabulary projection runs on the fp16
+        // matrix cores with the row arg-max fused into its epilogue (no [Mq, V] logits, no fp32 copy of the hidden states)
+        int ew_v = 0;
+        const unsigned short* wv2 = d->tt.get_split2("output_layer.weight", V, D, &ew_v, s);
+        if (!wv2) return -2;
+        if (d->e_an == INT32_MIN) {
+            float g, b;
+            if (TensorTable::dev_absmax(d->tt.get("after_norm.weight"), D, &g, s) || TensorTable::dev_absmax(d->tt.get("after_norm.bias"), D, &b, s)) return -2;
+            d->e_an = exp_for_bound(sqrtf((float)D) * g + b);
+        }
+        unsigned short* h2 = d->t16.as<unsigned short>();
+        {
+            ProfScope ps(PROF_LN, 8.0 * Mq * (double)D, s);
+            if ((rc = launch_layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), reinterpret_cast<float*>(h2), D,
+                                       Mq, D, D, c.ln_eps, s, 3, 0, (size_t)Mq * D, pow2f(d->e_an)))) return rc;
+        }
+        const int nparts = gemm_f16x2_argmax_parts(Mq, V);
+        if (d->pval.ensure(sizeof(float) * (size_t)Mq * nparts) || d->pidx.ensure(sizeof(int) * (size_t)Mq * nparts)) return -2;
+        Gemm2Args g{};
+        g.A = h2; g.lda = D; g.a_plane = (size_t)Mq * D; g.W = wv2; g.ldw = D; g.w_plane = (size_t)V * D;
+        g.oscale = pow2f(-(d->e_an + ew_v)); g.bias = d->tt.get("output_layer.bias"); g.M = Mq; g.N = V; g.K = D;
+        g.amax_val = d->pval.as<float>(); g.amax_idx = d->pidx.as<int>(); g.amax_ld = nparts;
+        {
+            ProfScope ps(PROF_GEMM3, 2.0 * Mq * (double)V * D, s);
+            if ((rc = launch_gemm_f16x2(g, s))) return rc;
+        }
+        return launch_argmax_reduce(d->pval.as<float>(), d->pidx.as<int>(), nparts, nparts, ids, nullptr, Mq, s);
+    }
     if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), hid, D, Mq, D, D,
                         c.ln_eps, s))) return rc;
     if (V == 0) return 0;
@@ -1909,12 +2002,42 @@ int pf_ctc_missing(const pf_ctc* ch) {
     const Ctc* c = reinterpret_cast<const Ctc*>(ch);
     return c ? c->tt.missing() : -1;
 }
+/* 0 = fp32 MFMA (default); 3 = the arg-max route (logits_dev == NULL) on the fp16 matrix cores from two-plane operands
+ * (gemm_f16x2.hip): the hidden states' plane scale is chosen on the device from max |hidden|, fp32-class logits */
+int pf_ctc_set_precision(pf_ctc* ch, int32_t mode) {
+    Ctc* c = reinterpret_cast<Ctc*>(ch);
+    PF_REQUIRE(c && (mode == 0 || mode == 3), "ctc_set_precision: mode must be 0 (fp32 MFMA) or 3 (fp32 via f16x2)");
+    c->precision = mode;
+    return 0;
+}
 int pf_ctc_greedy(pf_ctc* ch, const float* hidden, int32_t M, int32_t* ids, float* logits, void* stream) {
     Ctc* c = reinterpret_cast<Ctc*>(ch);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     PF_REQUIRE(c && hidden && M > 0, "ctc_greedy: null/empty");
     std::string first;
     if (c->tt.missing(&first)) { set_error("ctc: tensor not set: " + first); return -3; }
+    if (c->precision == 3 && ids && !logits && !g_stream_mode && c->d_model % 32 == 0) {
+        const int D = c->d_model, V = c->vocab;
+        int ew = 0, rc;
+        const unsigned short* w2 = c->tt.get_split2("ctc_lo.weight", V, D, &ew, s);
+        if (!w2) return -2;
+        const int nparts = gemm_f16x2_argmax_parts(M, V);
+        if (c->h2.ensure(sizeof(unsigned short) * 2 * (size_t)M * D) || c->dsc.ensure(sizeof(float) * 4) ||
+            c->pval.ensure(sizeof(float) * (size_t)M * nparts) || c->pidx.ensure(sizeof(int) * (size_t)M * nparts)) return -2;
+        float* dsc = c->dsc.as<float>();
+        if ((rc = launch_absmax(hidden, (size_t)M * D, dsc, s))) return rc;
+        if ((rc = launch_pow2_scale(dsc, dsc + 1, s))) return rc;
+        if ((rc = launch_split2(hidden, D, c->h2.as<unsigned short>(), D, (size_t)M * D, M, D, 1.f, s, dsc + 1))) return rc;
+        Gemm2Args g{};
+        g.A = c->h2.as<unsigned short>(); g.lda = D; g.a_plane = (size_t)M * D; g.W = w2; g.ldw = D; g.w_plane = (size_t)V * D;
+        g.oscale = pow2f(-ew); g.oscale_dev = dsc + 2; g.bias = c->tt.get("ctc_lo.bias"); g.M = M; g.N = V; g.K = D;
+        g.amax_val = c->pval.as<float>(); g.amax_idx = c->pidx.as<int>(); g.amax_ld = nparts;
+        {
+            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)V * D, s);
+            if ((rc = launch_gemm_f16x2(g, s))) return rc;
+        }
+        return launch_argmax_reduce(c->pval.as<float>(), c->pidx.as<int>(), nparts, nparts, ids, nullptr, M, s);
+    }
     return vocab_project(hidden, M, c->d_model, c->tt.get("ctc_lo.weight"), c->tt.get("ctc_lo.bias"), c->vocab, logits,
                          ids, c->pval, c->pidx, s);
 }

@@ -174,6 +174,46 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
         if (t == 123.456f) p.C[0] = t;
         return;
     }
+    if constexpr (OUT == 3) {
+        // fused row arg-max over this wave's WN * 32 columns, straight from the accumulators (C/D layout: col = lane & 31,
+        // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); ties go to the lowest column like torch.argmax
+        const float osc = p.oscale_dev ? p.oscale * *p.oscale_dev : p.oscale;
+        float bv[WN];
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj) {
+            const int col = n0 + wc * (WN * 32) + jj * 32 + idx;
+            bv[jj] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * (WM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float best = -INFINITY;
+                int besti = 0x7fffffff;
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj) {
+                    const int col = n0 + wc * (WN * 32) + jj * 32 + idx;
+                    if (col < p.N) {
+                        const float v = acc[i][jj][r] * osc + bv[jj];
+                        if (v > best) { best = v; besti = col; }
+                    }
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {   // stays inside the 32-lane half (same row)
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(besti, o, 64);
+                    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+                }
+                if (idx == 0 && row < p.M) {
+                    const size_t o = (size_t)row * p.amax_ld + 2 * nblk + wc;
+                    p.amax_val[o] = best;
+                    p.amax_idx[o] = besti;
+                }
+            }
+        }
+        return;
+    }
     constexpr bool HAS_R1 = (MODE & 1) != 0, HAS_R2 = (MODE & 2) != 0;
     constexpr int ELD = G::ELD;
     constexpr int LPR = WN * 8;              // lanes per slab row (float4 each)
@@ -197,8 +237,12 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
         const int row0 = m0 + wr * (WM * 32) + i * 32 + rsub;
         if (!colok) continue;
         // QKV form: this block's 256 columns lie inside one of q | k | v (qkv_D % 256 == 0)
-        const int seg = OUT == 2 ? n0 / p.qkv_D : 0;
-        const int scol = OUT == 2 ? col - seg * p.qkv_D : col;
+        const int seg = OUT == 2 ? n0 / p.qkv_D + (p.kv_form ? 1 : 0) : 0;      // 0 q, 1 k, 2 v
+        const int scol = OUT == 2 ? col - (n0 / p.qkv_D) * p.qkv_D : col;
+        float k_mul = p.k_mul, v_mul = p.v_mul;
+        if constexpr (OUT == 2) {
+            if (p.kv_mul_dev) { k_mul *= p.kv_mul_dev[0]; v_mul *= p.kv_mul_dev[1]; }
+        }
 #pragma unroll
         for (int h2 = 0; h2 < NPASS / 8; ++h2) {
             float4 v[8], r1[8], r2[8];
@@ -227,8 +271,8 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
                 if constexpr (ABL == 1) { if (o[0] == 123.456f) p.C[0] = o[1] + o[2] + o[3]; continue; }
                 if constexpr (OUT == 2) {
                     if (seg == 0) store_split2x4(p.Qp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.q_mul);
-                    else if (seg == 1) store_split2x4(p.Kp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.k_mul);
-                    else *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + scol) = make_float4(o[0], o[1], o[2], o[3]);
+                    else if (seg == 1) store_split2x4(p.Kp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, k_mul);
+                    else if (p.C) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + scol) = make_float4(o[0], o[1], o[2], o[3]);
                 } else if constexpr (OUT == 1) {
                     store_split2x4(p.C2 + (size_t)row * p.ldc2 + col, p.c_plane, o, p.cscale);
                 } else {
@@ -241,7 +285,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
             // 16-row group G -- the rows whose scores one attention lane holds per 16-key step (attention_f16x2.hip).
             // Raw accumulators are still in the slab: bias and scales are applied again here.
             if (seg == 2) {
-                const int vc0 = n0 - 2 * p.qkv_D + wc * (WN * 32);
+                const int vc0 = n0 - (p.kv_form ? 1 : 2) * p.qkv_D + wc * (WN * 32);
 #pragma unroll
                 for (int ps = 0; ps < WN * 32 * 4 / 64; ++ps) {
                     const int piece = ps * 64 + lane;
@@ -251,7 +295,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
                     float t[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        t[j] = (slab[(rb + (j & 3) + 8 * (j >> 2)) * ELD + nl] * oscale + bv) * p.v_mul;
+                        t[j] = (slab[(rb + (j & 3) + 8 * (j >> 2)) * ELD + nl] * oscale + bv) * v_mul;
                     const int mb = m0 + wr * (WM * 32) + i * 32 + 16 * G;
                     if (mb < p.M) {
                         uint4 h, l;
@@ -272,19 +316,27 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
 // fp32 [M, N] (row stride ldx) * scale -> two fp16 planes [M, ldy] (`plane` elements apart); columns N..ldy are zero
 __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ y,
                                                      int ldy, size_t plane, int M, int N, float scale,
-                                                     const float* __restrict__ scale_dev) {
+                                                     const float* __restrict__ scale_dev, int seq_out, int seq_in) {
     if (scale_dev) scale *= *scale_dev;
     const int c4n = ldy >> 2;
     const size_t total = (size_t)M * c4n;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int row = (int)(i / c4n), c = (int)(i % c4n) * 4;
+        int xrow = row;
+        bool pad = false;
+        if (seq_out > 0) {
+            const int b = row / seq_out, t = row % seq_out;
+            pad = t >= seq_in;
+            xrow = b * seq_in + t;
+        }
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (c + 3 < N) {
-            const float4 t = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
+        if (pad) {
+        } else if (c + 3 < N) {
+            const float4 t = *reinterpret_cast<const float4*>(x + (size_t)xrow * ldx + c);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (c + e < N) v[e] = x[(size_t)row * ldx + c + e];
+            for (int e = 0; e < 4; ++e) if (c + e < N) v[e] = x[(size_t)xrow * ldx + c + e];
         }
         store_split2x4(y + (size_t)row * ldy + c, plane, v, scale);
     }
@@ -364,13 +416,29 @@ int launch_pow2_scale(const float* amax_dev, float* sc, hipStream_t stream) {
     return 0;
 }
 
+__global__ void kv_scales_kernel(const float* __restrict__ amax, const float* __restrict__ lb, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;          // one (layer, k | v) pair per thread
+    if (i >= 2 * n) return;
+    const float bound = *amax * lb[2 * i] + lb[2 * i + 1];
+    int e = bound > 0.f ? (int)floorf(log2f(32768.f / bound)) : 0;
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);
+    out[4 * (i >> 1) + (i & 1)] = ldexpf(1.f, e);
+    out[4 * (i >> 1) + 2 + (i & 1)] = ldexpf(1.f, -e);
+}
+
+int launch_kv_scales(const float* amax_dev, const float* l1_bmax_dev, int n_layers, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(kv_scales_kernel, dim3(ceil_div(2 * n_layers, 64)), dim3(64), 0, stream, amax_dev, l1_bmax_dev, n_layers, out);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_split2(const float* x, int ldx, unsigned short* y, int ldy, size_t plane, int M, int N, float scale,
-                  hipStream_t stream, const float* scale_dev) {
+                  hipStream_t stream, const float* scale_dev, int seq_out, int seq_in) {
     PF_REQUIRE(M > 0 && N > 0 && ldy >= N && ldy % 4 == 0, "split2: ldy must cover N and be a multiple of 4");
     PF_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 && plane % 4 == 0, "split2: alignment");
     const size_t total = (size_t)M * (ldy >> 2);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, y, ldy, plane, M, N, scale, scale_dev);
+    hipLaunchKernelGGL(split2_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, y, ldy, plane, M, N, scale, scale_dev, seq_out, seq_in);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -392,22 +460,31 @@ int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* 
     return 0;
 }
 
+int gemm_f16x2_argmax_parts(int M, int N) { (void)M; return 2 * ceil_div(N, 256); }
+
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
     PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f16x2: empty problem");
+    if (a.amax_val) {
+        PF_REQUIRE(a.amax_idx && a.amax_ld >= gemm_f16x2_argmax_parts(a.M, a.N) && !a.R1 && !a.R2 && !a.relu && a.qkv_D <= 0,
+                   "gemm_f16x2: the arg-max form takes bias only and needs amax_ld >= 2 ceil(N / 256)");
+        PF_REQUIRE(a.K % 32 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0,
+                   "gemm_f16x2: operand alignment");
+        return launch_tile<2, 4, 0, 3, 0, 2>(a, stream);
+    }
     PF_REQUIRE(a.K % 32 == 0, "gemm_f16x2: K must be a multiple of 32 (pad the planes with zeros)");
     PF_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_plane % 8 == 0 && a.w_plane % 8 == 0, "gemm_f16x2: operand strides % 8");
     PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm_f16x2: operands must be 16-B aligned");
     PF_REQUIRE(a.N % 4 == 0, "gemm_f16x2: N % 4");
     if (a.C2 && a.qkv_D <= 0) PF_REQUIRE(a.ldc2 % 4 == 0 && a.c_plane % 4 == 0 && ((uintptr_t)a.C2 & 7) == 0, "gemm_f16x2: plane output alignment");
-    else PF_REQUIRE(a.C && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_f16x2: output alignment");
+    else if (a.qkv_D <= 0 || a.C) PF_REQUIRE(a.C && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_f16x2: output alignment");
     if (a.bias) PF_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm_f16x2: bias alignment");
     if (a.R1) PF_REQUIRE(a.ldr1 % 4 == 0 && ((uintptr_t)a.R1 & 15) == 0, "gemm_f16x2: R1 alignment");
     if (a.R2) PF_REQUIRE(a.ldr2 % 4 == 0 && ((uintptr_t)a.R2 & 15) == 0, "gemm_f16x2: R2 alignment");
     const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
     if (a.qkv_D > 0) {
-        PF_REQUIRE(mode == 0 && !a.relu && a.N == 3 * a.qkv_D && a.qkv_D % 256 == 0 && a.M % 16 == 0,
-                   "gemm_f16x2: the QKV form needs N == 3 D, D % 256 == 0, M % 16 == 0, no residuals");
-        PF_REQUIRE(a.Qp && a.Kp && a.VT && a.C && a.ldvt % 8 == 0 && a.vt_plane % 8 == 0 && a.qk_plane % 8 == 0 &&
+        PF_REQUIRE(mode == 0 && !a.relu && a.N == (a.kv_form ? 2 : 3) * a.qkv_D && a.qkv_D % 256 == 0 && a.M % 16 == 0,
+                   "gemm_f16x2: the QKV / KV form needs N == 3 D (2 D), D % 256 == 0, M % 16 == 0, no residuals");
+        PF_REQUIRE((a.kv_form || (a.Qp && a.C)) && a.Kp && a.VT && a.ldvt % 8 == 0 && a.vt_plane % 8 == 0 && a.qk_plane % 8 == 0 &&
                    ((uintptr_t)a.Qp & 15) == 0 && ((uintptr_t)a.Kp & 15) == 0 && ((uintptr_t)a.VT & 15) == 0,
                    "gemm_f16x2: QKV outputs");
         return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);

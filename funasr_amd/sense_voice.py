@@ -47,8 +47,10 @@ class SenseVoiceSmall(nn.Module):
             self.set_precision(kwargs["precision"])
 
     def set_precision(self, mode: str = "fp32"):
-        """Arithmetic mode of the encoder (see SANMEncoder.set_precision); the CTC projection + arg-max stay fp32."""
+        """Arithmetic mode of the encoder (see SANMEncoder.set_precision); in "f16x2" the CTC projection with its fused
+        arg-max runs from two-plane operands too, otherwise it stays on the fp32 MFMA."""
         self.encoder.set_precision(mode)
+        self.ctc.set_precision(mode)
         return self
 
     @classmethod

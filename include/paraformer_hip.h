@@ -253,6 +253,9 @@ int pf_ctc_set_tensor(pf_ctc* c, const char* name, const float* data, int64_t nu
 int pf_ctc_missing(const pf_ctc* c);
 /* hidden_dev: [M, d_model]; ids_dev: int32 [M] frame-wise argmax; logits_dev (nullable): [M, vocab]. No sync. */
 int pf_ctc_greedy(pf_ctc* c, const float* hidden_dev, int32_t M, int32_t* ids_dev, float* logits_dev, void* stream);
+/* 0 = fp32 MFMA (default), 3 = the arg-max route (logits_dev == NULL) from two-plane fp16 operands on the fp16 MFMA
+ * (fp32-class logits; the modes of pf_encoder_set_precision) */
+int pf_ctc_set_precision(pf_ctc* c, int32_t mode);
 
 /* ----------------------------------------------------------------------------------------------- streaming
  * Chunked online decoding (ParaformerStreaming, funasr/models/paraformer_streaming/model.py:552-763): one handle =
