@@ -235,6 +235,8 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
                      int M, int D, int Dpad, float eps, hipStream_t stream, int out_mode = 0, int in_bf16 = 0,
                      size_t plane = 0, float oscale = 1.f, int seq_out = 0, int seq_in = 0);
 
+// y[row] = x[row] - logsumexp(x[row]) over N columns (may run in place)
+int launch_log_softmax(const float* x, int ldx, float* y, int ldy, int M, int N, hipStream_t stream);
 // Tp > T: y is the padded layout [B, Tp, D] (rows t >= T zero)
 int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
                         hipStream_t stream, int Tp = 0);

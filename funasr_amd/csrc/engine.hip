@@ -2523,6 +2523,10 @@ int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ld
     if ((rc = gemm(g, s))) return rc;
     return launch_argmax_reduce(sval, sidx, nparts, nparts, ids, nullptr, M, s);
 }
+/* y[row] = x[row] - logsumexp(x[row]) over N columns, fp32 (may run in place) */
+int pf_k_log_softmax(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t M, int32_t N, void* stream) {
+    return launch_log_softmax(x, ldx, y, ldy, M, N, reinterpret_cast<hipStream_t>(stream));
+}
 int pf_k_layernorm(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
                    int32_t M, int32_t D, int32_t Dpad, float eps, void* stream) {
     return layernorm(x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, reinterpret_cast<hipStream_t>(stream));

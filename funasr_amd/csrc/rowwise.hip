@@ -117,6 +117,25 @@ __global__ __launch_bounds__(256) void scale_add_pe_kernel(const float* __restri
     }
 }
 
+// row-wise log-softmax over a vocabulary (decoder / CTC scores for the beam search, paraformer/model.py:345,
+// transformer/scorers/ctc.py:46): one wave per row, three sweeps (max, sum of exp, write), fp32, libm expf / logf
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                          int M, int N) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) mx = fmaxf(mx, xr[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) sum += expf(xr[j] - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + logf(sum);
+    float* yr = y + (size_t)row * ldy;
+    for (int j = lane; j < N; j += 64) yr[j] = xr[j] - lse;
+}
+
 // the same into a padded layout: y is [B, Tp, D], rows t >= T are zero
 __global__ __launch_bounds__(256) void scale_add_pe_pad_kernel(const float* __restrict__ x, const float* __restrict__ pe,
                                                                float* __restrict__ y, int T, int Tp, int D4, float scale,
@@ -238,6 +257,13 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     else if (nv <= 3) PF_LN(3);
     else PF_LN(8);
 #undef PF_LN
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_log_softmax(const float* x, int ldx, float* y, int ldy, int M, int N, hipStream_t stream) {
+    PF_REQUIRE(M > 0 && N > 0 && ldx >= N && ldy >= N, "log_softmax: bad shape");
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, stream, x, ldx, y, ldy, M, N);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -47,8 +47,9 @@ class CTC(HipModule):
         return ids.view(*lead), (logits.view(*lead, self.odim) if want_logits else None)
 
     def log_softmax(self, hs_pad):
+        from . import ops
         _, logits = self._run(hs_pad, True)
-        return torch.log_softmax(logits, dim=-1)
+        return ops.log_softmax(logits.contiguous(), inplace=True)          # row kernel, in place over the GEMM's output
 
     def argmax(self, hs_pad):
         ids, _ = self._run(hs_pad, False)

@@ -57,6 +57,18 @@ def gemm_argmax(a: torch.Tensor, w: torch.Tensor, bias=None):
     return ids
 
 
+def log_softmax(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
+    """row-wise log-softmax over the last dimension of a contiguous fp32 tensor (one wave per row)"""
+    lib = _lib.load()
+    _f32c(x, "x")
+    assert x.is_contiguous()
+    N = x.shape[-1]
+    M = x.numel() // N
+    y = x if inplace else torch.empty_like(x)
+    _lib.check(lib.pf_k_log_softmax(_ptr(x), N, _ptr(y), N, M, N, _stream()), "pf_k_log_softmax")
+    return y
+
+
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, pad_to: int | None = None):
     lib = _lib.load()
     _f32c(x, "x")

@@ -42,9 +42,8 @@ class Paraformer(nn.Module):
                  sampling_ratio: float = 0.2, share_embedding: bool = False, use_1st_decoder_loss: bool = False,
                  **kwargs):
         super().__init__()
-        if normalize is not None or ctc_weight > 0.0:
-            raise NotImplementedError("Paraformer(HIP): utterance-MVN `normalize` and a CTC branch are not on the "
-                                      "greedy inference path of the published Paraformer-large recipe")
+        if normalize is not None:
+            raise NotImplementedError("Paraformer(HIP): utterance-MVN `normalize` is not part of the published recipes")
         enc_conf = dict(encoder_conf or {})
         enc_conf.pop("input_size", None)
         self.encoder = tables.encoder_classes.get(encoder)(input_size=input_size, **enc_conf)
@@ -58,8 +57,12 @@ class Paraformer(nn.Module):
         self.sos = sos if sos is not None else vocab_size - 1
         self.eos = eos if eos is not None else vocab_size - 1
         self.ctc, self.specaug, self.normalize = None, None, None
+        if ctc_weight > 0.0:                                 # model.py:109-111: the CTC head exists only then
+            from .ctc import CTC
+            self.ctc = CTC(odim=vocab_size, encoder_output_size=d, **(ctc_conf or {}))
         self.ctc_weight = ctc_weight
         self.beam_search = None
+        self.nbest = 1
         if kwargs.get("precision"):                      # model_conf: {precision: fp32 | bf16x3 | bf16}
             self.set_precision(kwargs["precision"])
 
@@ -124,11 +127,49 @@ class Paraformer(nn.Module):
         """[B, T, 560] features -> per-utterance token ids (sos/eos/blank removed), all on the current HIP stream."""
         return self.collect(self.enqueue_features(speech, speech_lengths, return_intermediate))
 
+    # ------------------------------------------------------------------------------------------------ beam search
+    def init_beam_search(self, **kwargs):
+        """model.py:482-532: scorers ctc (weight decoding_ctc_weight) and length_bonus (weight penalty); `lm` / `ngram` have
+        no scorer object in the reference either. pre-beam on the full score unless the model's own ctc_weight is 1."""
+        from .beam_search import BeamSearchPara
+        token_list = kwargs.get("token_list")
+        self.beam_search = BeamSearchPara(beam_size=kwargs.get("beam_size", 2), vocab_size=len(token_list), sos=self.sos,
+                                          eos=self.eos, ctc_weight=kwargs.get("decoding_ctc_weight", 0.0) if self.ctc is not None else 0.0,
+                                          length_bonus_weight=kwargs.get("penalty", 0.0), blank=self.blank_id,
+                                          pre_beam=self.ctc_weight != 1.0)
+
+    def recognize_features_beam(self, speech: torch.Tensor, speech_lengths, maxlenratio: float = 0.0,
+                                minlenratio: float = 0.0, return_intermediate: bool = False):
+        """The beam-search route of `inference` (model.py:596-637): encoder, predictor, decoder LOGITS, then on the device the
+        row-wise log-softmax of the decoder scores and of the CTC head; the per-hypothesis bookkeeping runs on the host
+        (funasr_amd/beam_search.py) per utterance like the reference's. -> dict(nbest=[[Hypothesis]], token_num, ...)"""
+        from . import ops
+        enc, olens = self.encode(speech, speech_lengths)
+        embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
+        tok = [int(round(v)) for v in token_num.tolist()]
+        B = enc.shape[0]
+        out = dict(token_num=tok, nbest=[[] for _ in range(B)])
+        if return_intermediate:
+            out.update(enc=enc, olens=olens, embeds=embeds, alphas=alphas, peaks=peaks)
+        if max(tok) < 1:
+            return out
+        logits, _ = self.decoder(enc, olens, embeds, torch.tensor(tok))
+        am = ops.log_softmax(logits.contiguous(), inplace=True).cpu()          # one D2H copy of the batch's scores
+        ctc_logp = self.ctc.log_softmax(enc).cpu().numpy() if (self.ctc is not None and self.beam_search.w_ctc != 0) else None
+        for i in range(B):
+            if tok[i] < 1:
+                continue
+            lp = ctc_logp[i, : int(olens[i])] if ctc_logp is not None else None
+            out["nbest"][i] = self.beam_search(am[i, : tok[i]], lp, maxlenratio=maxlenratio, minlenratio=minlenratio)[: self.nbest]
+        return out
+
     # ---------------------------------------------------------------------------------------------- AutoModel API
     def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
-        if kwargs.get("decoding_ctc_weight", 0.0) > 1e-5 or (kwargs.get("lm_weight", 0.0) > 1e-5 and kwargs.get("lm_file")):
-            raise NotImplementedError("beam search with CTC/LM rescoring (paraformer/model.py:482-532) is outside the "
-                                      "greedy hot path")
+        is_use_ctc = kwargs.get("decoding_ctc_weight", 0.0) > 0.00001 and self.ctc is not None        # model.py:554-562
+        is_use_lm = kwargs.get("lm_weight", 0.0) > 0.00001 and kwargs.get("lm_file", None) is not None
+        if self.beam_search is None and (is_use_lm or is_use_ctc):
+            self.init_beam_search(**kwargs)
+            self.nbest = kwargs.get("nbest", 1)
         meta_data = {}
         device = kwargs.get("device", None)
         if isinstance(data_in, torch.Tensor) and kwargs.get("data_type", "sound") == "fbank":
@@ -151,6 +192,8 @@ class Paraformer(nn.Module):
             meta_data["extract_feat"] = f"{t3 - t2:0.3f}"
             meta_data["batch_data_time"] = (int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000)
         want_stamps = self._always_timestamps or kwargs.get("pred_timestamp", False)
+        if self.beam_search is not None and not self._always_timestamps:
+            return self._inference_beam(speech, speech_lengths, key, tokenizer, want_stamps, meta_data, **kwargs)
         res = self.recognize_features(speech, speech_lengths, return_intermediate=want_stamps)
         B = len(res["ids"])
         if key is None:
@@ -188,6 +231,39 @@ class Paraformer(nn.Module):
                     ibest_writer["text"][key[i]] = text
             else:
                 results.append({"key": key[i], "token_int": token_int})
+        return results, meta_data
+
+    def _inference_beam(self, speech, speech_lengths, key, tokenizer, want_stamps, meta_data, **kwargs):
+        """result assembly of model.py:629-697 for the n-best of the beam search (one result per hypothesis)"""
+        res = self.recognize_features_beam(speech, speech_lengths, kwargs.get("maxlenratio", 0.0), kwargs.get("minlenratio", 0.0),
+                                           return_intermediate=want_stamps)
+        B = len(res["nbest"])
+        if key is None:
+            key = [f"utt_{i}" for i in range(B)]
+        if isinstance(key[0], (list, tuple)):
+            key = key[0]
+        if len(key) < B:
+            key = list(key) * B
+        if max(res["token_num"]) < 1:
+            return [], meta_data
+        drop = (self.eos, self.sos, self.blank_id)
+        results = []
+        for i in range(B):
+            for hyp in res["nbest"][i]:
+                token_int = [t for t in hyp.yseq[1:-1] if t not in drop]
+                if tokenizer is None:
+                    results.append({"key": key[i], "token_int": token_int, "score": hyp.score})
+                    continue
+                token = tokenizer.ids2tokens(token_int)
+                text = tokenizer.tokens2text(token)
+                if want_stamps:
+                    stamps = self._token_timestamps(res, i, token, kwargs)
+                    text, stamps = self._postprocess(tokenizer, token, text, stamps)
+                    results.append({"key": key[i], "text": text, "timestamp": stamps})
+                else:
+                    if not hasattr(tokenizer, "bpemodel"):
+                        text, _ = sentence_postprocess(token)
+                    results.append({"key": key[i], "text": text})
         return results, meta_data
 
     def _token_timestamps(self, res: dict, i: int, token, kwargs):

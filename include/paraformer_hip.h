@@ -335,6 +335,8 @@ int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2
 int pf_k_cast_bf16(const float* x, void* y, int64_t n, void* stream);
 int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t M,
                          int32_t N, int32_t K, int32_t* ids, float* scratch_val, int32_t* scratch_idx, void* stream);
+/* row-wise log-softmax over N columns (the scores the beam search of paraformer/search.py consumes); in place allowed */
+int pf_k_log_softmax(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t M, int32_t N, void* stream);
 int pf_k_layernorm(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
                    int32_t M, int32_t D, int32_t Dpad, float eps, void* stream);
 int pf_k_fsmn(const float* in, int32_t ldin, const float* w, const float* R, int32_t ldr, float* out, int32_t ldo,

@@ -269,6 +269,60 @@ def test_sensevoice_inference_equals_reference_inference(cuda, f32_mode):
         assert [r["key"] for r in res] == json.loads(str(g[f"keys_{ci}"]))
 
 
+def test_beam_search_with_ctc_rescoring_vs_oracle(cuda):
+    """`inference(decoding_ctc_weight=0.5, beam_size=3)` on a Paraformer WITH a CTC head (model.py:554-562,629-637): the device
+    supplies decoder and CTC log-probs (HIP GEMMs + the row log-softmax kernel), the host runs the beam search that
+    tests/test_beam_search.py pins against the reference's BeamSearchPara. Expected n-best: the same search over the CPU
+    oracle's scores."""
+    import torch.nn.functional as F
+    from funasr_amd.beam_search import BeamSearchPara
+    from funasr_amd.paraformer import Paraformer
+    from oracle import paraformer_oracle as O
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2, dec_blocks=2, vocab=97)
+    sd = synth.paraformer_state_dict(cfg, seed=31, cif_bias=0.4)
+    g = torch.Generator().manual_seed(8)
+    sd["ctc.ctc_lo.weight"] = torch.randn(97, 512, generator=g) * 0.08
+    sd["ctc.ctc_lo.bias"] = torch.randn(97, generator=g) * 0.1
+    sd["ctc.ctc_lo.bias"][0] += 1.0
+    ec = dict(cfg["encoder"]); input_size = ec.pop("input_size")
+    dc = dict(cfg["decoder"]); vocab = dc.pop("vocab_size"); dc.pop("encoder_output_size", None)
+    model = Paraformer(encoder="SANMEncoder", encoder_conf=dict(ec, input_layer="pe"), decoder="ParaformerSANMDecoder",
+                       decoder_conf=dc, predictor="CifPredictorV2", predictor_conf=dict(cfg["predictor"]), ctc_weight=0.3,
+                       input_size=input_size, vocab_size=vocab)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if "embed" not in k], (missing, unexpected)
+    model = model.to(cuda)
+    B, T = 3, 60
+    feats = torch.randn(B, T, 560, generator=g) * 0.7
+    lens = torch.tensor([60, 41, 25], dtype=torch.int32)
+    for b in range(B):
+        feats[b, lens[b]:] = 0
+    kw = dict(decoding_ctc_weight=0.5, beam_size=3, penalty=0.1, nbest=2, token_list=[str(i) for i in range(97)],
+              data_type="fbank", device=cuda)
+    res, _ = model.inference(feats.to(cuda), data_lengths=lens, key=["a", "b", "c"], tokenizer=None, frontend=None, **kw)
+    with torch.no_grad():
+        r = O.paraformer_greedy(feats, lens, sd, cfg)
+        am = torch.log_softmax(r["logits"], -1)
+        logp = torch.log_softmax(F.linear(r["enc"], sd["ctc.ctc_lo.weight"], sd["ctc.ctc_lo.bias"]), -1).numpy()
+    bs = BeamSearchPara(beam_size=3, vocab_size=97, sos=1, eos=2, ctc_weight=0.5, length_bonus_weight=0.1)
+    want = []
+    for i in range(B):
+        n = int(r["token_num"][i])
+        for h in bs(am[i, :n], logp[i, : int(r["olens"][i])])[:2]:
+            want.append((["a", "b", "c"][i], [t for t in h.yseq[1:-1] if t not in (0, 1, 2)], h.score))
+    assert [(x["key"], x["token_int"]) for x in res] == [(k, ids) for k, ids, _ in want]
+    assert max(abs(x["score"] - w[2]) for x, w in zip(res, want)) < 5e-3
+    # without decoding_ctc_weight the same model object (beam search now initialised) still takes the beam route; a fresh
+    # model without it is greedy
+    plain = Paraformer(encoder="SANMEncoder", encoder_conf=dict(ec, input_layer="pe"), decoder="ParaformerSANMDecoder",
+                       decoder_conf=dc, predictor="CifPredictorV2", predictor_conf=dict(cfg["predictor"]), ctc_weight=0.3,
+                       input_size=input_size, vocab_size=vocab)
+    plain.load_state_dict(sd, strict=False)
+    g_res, _ = plain.to(cuda).inference(feats.to(cuda), data_lengths=lens, key=["a", "b", "c"], tokenizer=None, frontend=None,
+                                        data_type="fbank", device=cuda)
+    assert [x["token_int"] for x in g_res] == r["ids"]
+
+
 # ------------------------------------------------------------------- full-size, size-independent properties
 def test_full_size_batch_independence_and_fused_argmax(cuda, f32_mode):
     """BASELINE config 2 shapes (B=64 x 30 s -> T=500) on a shallow model: (1) every clip's encoder output and token
