@@ -114,6 +114,7 @@ SIGNATURES = {
     "pf_decoder_missing": (C.c_int, [_vp]),
     "pf_decoder_set_precision": (C.c_int, [_vp, _i32]),
     "pf_decoder_forward": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pf_decoder_asf_scores": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pf_vad_create": (_vp, [C.POINTER(pf_vad_config)]),
     "pf_vad_destroy": (None, [_vp]),
     "pf_vad_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),

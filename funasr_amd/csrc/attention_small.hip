@@ -94,6 +94,58 @@ bool attention_small_applicable(const AttnArgs& a, int dk) {
     return dk <= SMALL_MAX_DK && dk % 4 == 0 && a.Tk <= 64 * SMALL_MAX_KEYS_PER_LANE && a.K2 == nullptr && a.O3 == nullptr;
 }
 
+// ---- attention-score filter of SeACo (seaco_paraformer/model.py:323-349 over decoder.py:485-513 `forward_asf6` and
+//      attention.py:760-784 with ret_attn): the softmax attention matrix of ONE sequence, summed over heads and queries.
+// one wave per (query, head): scores over all keys (lane-per-key), softmax, masked keys 0 -> P[(h * N + q) * T + k]
+__global__ __launch_bounds__(64) void asf_probs_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+                                                       float* __restrict__ P, int N, int T, int klen, int dk, float scale) {
+    __shared__ float qs[128];
+    const int q = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    for (int d = lane; d < dk; d += 64) qs[d] = Q[(size_t)q * ldq + h * dk + d] * scale;
+    __syncthreads();
+    float* pr = P + ((size_t)h * N + q) * T;
+    float mx = -INFINITY;
+    for (int k = lane; k < T; k += 64) {
+        float sc = -INFINITY;
+        if (k < klen) {
+            const float* kp = K + (size_t)k * ldk + h * dk;
+            sc = 0.f;
+            for (int d = 0; d < dk; d += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(kp + d);
+                sc = fmaf(qs[d], kv.x, sc); sc = fmaf(qs[d + 1], kv.y, sc); sc = fmaf(qs[d + 2], kv.z, sc); sc = fmaf(qs[d + 3], kv.w, sc);
+            }
+        }
+        pr[k] = sc;
+        mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < T; k += 64) sum += (k < klen) ? expf(pr[k] - mx) : 0.f;
+    sum = wave_sum(sum);
+    for (int k = lane; k < T; k += 64) pr[k] = (k < klen) ? expf(pr[k] - mx) / sum : 0.f;
+}
+// out[k] = sum_q (sum_h P[h][q][k]): attn[0].sum(0).sum(0)
+__global__ __launch_bounds__(256) void asf_colsum_kernel(const float* __restrict__ P, int H, int N, int T, float* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= T) return;
+    float acc = 0.f;
+    for (int q = 0; q < N; ++q) {
+        float t = 0.f;
+        for (int h = 0; h < H; ++h) t += P[((size_t)h * N + q) * T + k];
+        acc += t;
+    }
+    out[k] = acc;
+}
+
+int launch_asf_scores(const float* Q, int ldq, const float* K, int ldk, float* P_scratch, float* out, int H, int dk, int N, int T,
+                      int klen, float scale, hipStream_t stream) {
+    PF_REQUIRE(H > 0 && N > 0 && T > 0 && klen >= 1 && klen <= T && dk % 4 == 0 && dk <= 128 && ldk % 4 == 0, "asf_scores: bad shape");
+    hipLaunchKernelGGL(asf_probs_kernel, dim3(N, H), dim3(64), 0, stream, Q, ldq, K, ldk, P_scratch, N, T, klen, dk, scale);
+    hipLaunchKernelGGL(asf_colsum_kernel, dim3(ceil_div(T, 256)), dim3(256), 0, stream, P_scratch, H, N, T, out);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_attention_small(const AttnArgs& a, int dk, hipStream_t stream) {
     PF_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
     PF_REQUIRE(attention_small_applicable(a, dk), "attention_small: d_k <= 64 (multiple of 4), Tk <= 1024, one key/value source");

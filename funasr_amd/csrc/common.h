@@ -289,6 +289,10 @@ struct Attn2Args {
 int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream);
 
 // small heads (d_k <= 64) on short sequences: plain fp32 FMAs, one wave per query (attention_small.hip)
+// SeACo's attention-score filter: out[k] = sum over heads and queries of softmax_k(q . k / sqrt(d_k)) for ONE sequence
+// (Q [N, H dk], K [T, >= H dk] row strides ldq / ldk; keys >= klen get probability 0); P_scratch holds H * N * T floats
+int launch_asf_scores(const float* Q, int ldq, const float* K, int ldk, float* P_scratch, float* out, int H, int dk, int N, int T,
+                      int klen, float scale, hipStream_t stream);
 bool attention_small_applicable(const AttnArgs& a, int dk);
 int launch_attention_small(const AttnArgs& a, int dk, hipStream_t stream);
 // out[i] = table[ids[i]] (embedding lookup; ids clamped to [0, rows))

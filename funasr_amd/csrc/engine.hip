@@ -722,6 +722,7 @@ struct Decoder {
     DevBuf k2, vt2;          // cross-attention operands written by the KV form of linear_k_v (attention_f16x2.hip)
     bool lb_uploaded = false;
     int e_an = INT32_MIN;    // exponent of the after_norm output planes (f16x2 vocabulary projection)
+    DevBuf asf_p;            // SeACo score filter: attention probabilities of sequence 0 [H, N, T]
 };
 
 static int decoder_resolve(Decoder* d) {
@@ -1784,11 +1785,33 @@ int pf_decoder_missing(const pf_decoder* dh) {
     return d ? d->tt.missing() : -1;
 }
 
+// asf_layer >= 0: run blocks 0 .. asf_layer - 1, then block asf_layer up to its cross-attention SCORES and return the
+// attention-score filter of sequence 0 in asf_scores [T] (decoder.py:485-513 forward_asf6 / :696-714 get_attn_mat)
+static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* mem_lens, const float* embeds,
+                                const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids,
+                                float* hidden_out, hipStream_t s, int asf_layer, float* asf_scores);
+
 int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_lens, const float* embeds,
                        const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids,
                        float* hidden_out, void* stream) {
+    return decoder_forward_impl(reinterpret_cast<Decoder*>(dh), memory, mem_lens, embeds, tok_lens, B, T, N, logits, ids,
+                                hidden_out, reinterpret_cast<hipStream_t>(stream), -1, nullptr);
+}
+/* SeACo attention-score filter (seaco_paraformer/model.py:323-335): the bias decoder's blocks 0 .. n_blocks_before - 1 in
+ * full, then block n_blocks_before up to its cross-attention probabilities over the T memory rows (= hotword embeddings);
+ * scores_dev [T] receives their sum over heads and token positions for sequence 0 (attn[0].sum(0).sum(0)). fp32 kernels. */
+int pf_decoder_asf_scores(pf_decoder* dh, const float* memory, const int32_t* mem_lens, const float* embeds,
+                          const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, int32_t n_blocks_before,
+                          float* scores_dev, void* stream) {
     Decoder* d = reinterpret_cast<Decoder*>(dh);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(d && scores_dev && n_blocks_before >= 0 && n_blocks_before < d->cfg.n_blocks, "decoder_asf_scores: bad block index");
+    return decoder_forward_impl(d, memory, mem_lens, embeds, tok_lens, B, T, N, nullptr, nullptr, nullptr,
+                                reinterpret_cast<hipStream_t>(stream), n_blocks_before, scores_dev);
+}
+
+static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* mem_lens, const float* embeds,
+                                const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids,
+                                float* hidden_out, hipStream_t s, int asf_layer, float* asf_scores) {
     PF_REQUIRE(d && memory && mem_lens && embeds && tok_lens && B > 0 && T > 0 && N > 0, "decoder_forward: null/empty");
     for (int b = 0; b < B; ++b) {
         PF_REQUIRE(mem_lens[b] >= 1 && mem_lens[b] <= T, "decoder_forward: memory lens out of range");
@@ -1812,13 +1835,13 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
     float* t2 = d->t2.as<float>();
     PF_HIP_TRY(hipMemcpyAsync(x, embeds, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     const int left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
-    if (V == 0) PF_REQUIRE(!logits && !ids && hidden_out && d->precision != 1,
+    if (V == 0 && asf_layer < 0) PF_REQUIRE(!logits && !ids && hidden_out && d->precision != 1,
                            "decoder_forward: a decoder without output layer returns hidden states only (fp32 / bf16x3)");
-    if (d->precision == 1 && !logits) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
+    if (d->precision == 1 && !logits && asf_layer < 0) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
     // bf16x3 mode: the two GEMMs that are large at every batch size (w_1: N = ffn_dim; linear_k_v: M = B * T) take
     // three-plane operands on the bf16 matrix cores; the D x D projections and w_2 keep the fp32 MFMA tiles
-    const bool x3 = d->precision == 2;
-    const bool x2 = d->precision == 3;
+    const bool x3 = d->precision == 2 && asf_layer < 0;
+    const bool x2 = d->precision == 3 && asf_layer < 0;      // the score filter runs on the fp32 kernels
     const int Tp = round_up(T, 16), Mkp = B * Tp;           // f16x2: padded key rows per sequence
     const unsigned short* mem3 = nullptr;
     const unsigned short* mem2 = nullptr;
@@ -1927,6 +1950,11 @@ int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_l
                                    2 * D, 2 * D, D, 0, s))) return rc;
         } else if ((rc = gemm_simple(memory, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
                                      nullptr, 0, s))) return rc;
+        if (l == asf_layer) {
+            if (d->asf_p.ensure(sizeof(float) * (size_t)c.n_heads * N * T)) return -2;
+            return launch_asf_scores(d->q.as<float>(), D, d->kv.as<float>(), 2 * D, d->asf_p.as<float>(), asf_scores, c.n_heads,
+                                     D / c.n_heads, N, T, mem_lens[0], powf((float)(D / c.n_heads), -0.5f), s);
+        }
         AttnArgs aa{};
         aa.Q = d->q.as<float>(); aa.ldq = D; aa.K = d->kv.as<float>(); aa.ldk = 2 * D;
         aa.V = d->kv.as<float>() + D; aa.ldv = 2 * D; aa.O = d->ctx.as<float>(); aa.ldo = D;

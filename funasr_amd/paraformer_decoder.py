@@ -109,6 +109,23 @@ class ParaformerSANMDecoder(HipModule):
         olens = torch.tensor(tlens, dtype=torch.int64, device=dev)
         return logits, ids, hid, olens
 
+    def forward_asf6(self, hs_pad, hlens, ys_in_pad, ys_in_lens, n_blocks_before: int = 5) -> torch.Tensor:
+        """decoder.py:485-513 reduced to what SeACo's filter uses (seaco_paraformer/model.py:326-329): the attention
+        probabilities of block `n_blocks_before` for sequence 0, summed over heads and token positions -> [T] (device)."""
+        lib, h = self._ensure_handle()
+        dev = self._handle_device
+        mem = hs_pad.to(device=dev, dtype=torch.float32).contiguous()
+        emb = ys_in_pad.to(device=dev, dtype=torch.float32).contiguous()
+        B, T, _ = mem.shape
+        N = emb.shape[1]
+        mlen_c, _ = host_i32(hlens, B)
+        tlen_c, _ = host_i32(ys_in_lens, B)
+        scores = torch.empty(T, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pf_decoder_asf_scores(h, mem.data_ptr(), mlen_c, emb.data_ptr(), tlen_c, B, T, N, n_blocks_before,
+                                                 scores.data_ptr(), stream_ptr()), "pf_decoder_asf_scores")
+        return scores
+
     def forward(self, hs_pad, hlens, ys_in_pad, ys_in_lens, chunk_mask=None, return_hidden: bool = False,
                 return_both: bool = False):
         if chunk_mask is not None:

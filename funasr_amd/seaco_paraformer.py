@@ -85,6 +85,7 @@ class SeacoParaformer(BiCifParaformer):
         self.NO_BIAS = kwargs.get("NO_BIAS", 8377)
         self.predictor_name = kwargs.get("predictor")
         self.hotword_list = None
+        self.nfilter = _NFILTER                              # `nfilter` of _seaco_decode_with_ASF (:277), 50 at its only call site
         self._hw_cache = {}
 
     # --------------------------------------------------------------------------------------------------- hotwords
@@ -151,9 +152,6 @@ class SeacoParaformer(BiCifParaformer):
         hw_list = self.hotword_list
         if hw_list is None:
             return super().enqueue_features(speech, speech_lengths, return_intermediate)
-        if len(hw_list) > _NFILTER:
-            raise NotImplementedError(f"more than {_NFILTER} hotwords need the attention-score filter "
-                                      "(seaco_paraformer/model.py:323-349), which is not built")
         enc, olens = self.encode(speech, speech_lengths)
         embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
         tok = [int(round(v)) for v in token_num.tolist()]
@@ -164,6 +162,16 @@ class SeacoParaformer(BiCifParaformer):
             sel = self._hotword_representation(hw_list)
             ctx = sel[None].expand(B, -1, -1).contiguous()
             clen = [sel.shape[0]] * B
+            nfilter, n_hot = self.nfilter, sel.shape[0]
+            if 0 < nfilter < n_hot:
+                # attention-score filter (:323-349): keep the nfilter hotwords the bias decoder's 6th block attends to most
+                # (sequence 0's attention, summed over heads and token positions) plus the trailing no-bias entry
+                scores = self.seaco_decoder.forward_asf6(ctx, clen, dec_hidden, tok)
+                keep = torch.topk(scores.cpu(), min(nfilter, n_hot - 1))[1].tolist()
+                keep.append(n_hot - 1)
+                sel = sel[torch.tensor(keep, device=sel.device)].contiguous()
+                ctx = sel[None].expand(B, -1, -1).contiguous()
+                clen = [sel.shape[0]] * B
             cif_att, _ = self.seaco_decoder(ctx, clen, embeds, tok)
             dec_att, _ = self.seaco_decoder(ctx, clen, dec_hidden, tok)
             merged = (cif_att + dec_att).view(-1, cif_att.shape[-1])          # _merge (:193-200)

@@ -202,6 +202,13 @@ int pf_decoder_set_precision(pf_decoder* d, int32_t mode);
 int pf_decoder_forward(pf_decoder* d, const float* memory_dev, const int32_t* mem_lens_host,
                        const float* embeds_dev, const int32_t* tok_lens_host, int32_t B, int32_t T, int32_t N,
                        float* logits_dev, int32_t* ids_dev, float* hidden_dev, void* stream);
+/* SeACo attention-score filter (funasr/models/seaco_paraformer/model.py:323-335 over paraformer/decoder.py:485-513
+ * `forward_asf6`): blocks 0 .. n_blocks_before - 1 of the (bias) decoder in full, then block n_blocks_before up to its
+ * cross-attention probabilities over the T memory rows (the hotword embeddings); scores_dev [T] receives their sum over
+ * heads and token positions for sequence 0 (attn_mat[0].sum(0).sum(0)). */
+int pf_decoder_asf_scores(pf_decoder* d, const float* memory_dev, const int32_t* mem_lens_host, const float* embeds_dev,
+                          const int32_t* tok_lens_host, int32_t B, int32_t T, int32_t N, int32_t n_blocks_before,
+                          float* scores_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- ctc */
 /* ---- FSMN-VAD network (funasr/models/fsmn_vad_streaming/encoder.py:288-378 FSMN.forward), reduced to what the decision

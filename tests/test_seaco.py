@@ -111,6 +111,47 @@ def test_seaco_on_the_gpu_equals_reference_inference(cuda, tmp_path):
                 assert r["text"] == w["text"] and r["timestamp"] == w["timestamp"], (mode, name, r, w)
 
 
+@pytest.mark.gpu
+def test_attention_score_filter_for_more_than_50_hotwords_equals_reference(cuda, tmp_path):
+    """58 hotwords + the no-bias entry: `_seaco_decode_with_ASF` first ranks them by the bias decoder's block-5 attention
+    (sequence 0, summed over heads and token positions; seaco_paraformer/model.py:323-335, decoder.py:485-513) and keeps the
+    top 50. Fixture from the REFERENCE class (oracle/make_golden_seaco_asf.py): the filter's scores and the final texts /
+    timestamps."""
+    from funasr_amd.tokenizer import CharTokenizer
+    from oracle import seaco_oracle as SO
+    g = np.load(os.path.join(os.path.dirname(GOLD), "seaco_asf.npz"), allow_pickle=False)
+    cfg = json.loads(str(g["cfg"]))
+    vocab = json.loads(str(g["vocab"]))
+    sd = SO.seaco_state_dict(cfg, int(g["seed"]), int(g["no_bias"]))
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(cuda)
+    tok = CharTokenizer(token_list=vocab, unk_symbol="<unk>")
+    feats, lens = torch.from_numpy(g["feats"]).to(cuda), torch.from_numpy(g["lens"])
+    with open(tmp_path / "seg_dict", "w", encoding="utf-8") as f:
+        f.write("".join(f"{ch} {ch}\n" for ch in vocab[3:-10]))
+    fe = _Frontend()
+    fe.cmvn_file = str(tmp_path / "am.mvn")
+    keys = [f"utt{b}" for b in range(3)]
+    # (1) the filter's scores themselves
+    hw_list = model.generate_hotwords_list(str(g["hotwords"]), tokenizer=tok, frontend=fe)
+    assert hw_list == json.loads(str(g["hw_list"])) and len(hw_list) == 59
+    enc, olens = model.encode(feats, lens)
+    embeds, token_num, _, _ = model.calc_predictor(enc, olens)
+    tk = [int(round(v)) for v in token_num.tolist()]
+    _, _, dec_hidden, _ = model.decoder._run(enc, olens, embeds, tk, want_logits=False, want_ids=False, want_hidden=True)
+    sel = model._hotword_representation(hw_list)
+    ctx = sel[None].expand(3, -1, -1).contiguous()
+    scores = model.seaco_decoder.forward_asf6(ctx, [59] * 3, dec_hidden, tk).cpu()
+    ref = torch.from_numpy(g["asf_scores"])
+    assert (scores - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    assert torch.topk(scores, 50)[1].tolist() == torch.topk(ref, 50)[1].tolist()
+    # (2) end to end through inference()
+    res, _ = model.inference(feats, data_lengths=lens, key=keys, tokenizer=tok, frontend=fe, data_type="fbank", hotword=str(g["hotwords"]))
+    for r, w in zip(res, json.loads(str(g["hot"]))):
+        assert r["text"] == w["text"] and r["timestamp"] == w["timestamp"], (r, w)
+
+
 def test_model_directory_builds_through_automodel(tmp_path):
     from funasr_amd.auto_model import AutoModel
     from tests._model_dir import make_seaco_model_dir
