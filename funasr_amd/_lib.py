@@ -114,6 +114,8 @@ SIGNATURES = {
     "pf_decoder_missing": (C.c_int, [_vp]),
     "pf_decoder_set_precision": (C.c_int, [_vp, _i32]),
     "pf_decoder_forward": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pf_decoder_create_contextual": (_vp, [C.POINTER(pf_decoder_config)]),
+    "pf_decoder_forward_contextual": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _vp, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_decoder_asf_scores": (C.c_int, [_vp, _vp, _pi32, _vp, _pi32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pf_vad_create": (_vp, [C.POINTER(pf_vad_config)]),
     "pf_vad_destroy": (None, [_vp]),

@@ -38,6 +38,7 @@ from typing import Any, Dict, List, Tuple
 import torch
 
 from . import bicif_paraformer as _bicif_paraformer  # noqa: F401  (registers BiCifParaformer / CifPredictorV3)
+from . import contextual_paraformer as _contextual_paraformer  # noqa: F401  (registers ContextualParaformer + its decoder)
 from . import ct_transformer as _ct_transformer  # noqa: F401  (registers CTTransformer)
 from . import fsmn_vad as _fsmn_vad  # noqa: F401  (registers FSMN / FsmnVADStreaming)
 from . import paraformer as _paraformer  # noqa: F401  (registers the model classes)

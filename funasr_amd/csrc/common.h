@@ -235,6 +235,7 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
                      int M, int D, int Dpad, float eps, hipStream_t stream, int out_mode = 0, int in_bf16 = 0,
                      size_t plane = 0, float oscale = 1.f, int seq_out = 0, int seq_in = 0);
 
+int launch_scale_cols(float* x, int ld, int M, int N, float sc, hipStream_t stream);
 // y[row] = x[row] - logsumexp(x[row]) over N columns (may run in place)
 int launch_log_softmax(const float* x, int ldx, float* y, int ldy, int M, int N, hipStream_t stream);
 // Tp > T: y is the padded layout [B, Tp, D] (rows t >= T zero)

@@ -708,8 +708,15 @@ struct DecLayerW {
     float kv_l1b[4] = {0.f, 0.f, 0.f, 0.f};      // max row L1 norm and max |bias| of the k half, then of the v half, of linear_k_v
     bool x2_ready = false;
 };
+// ContextualParaformerDecoder keeps its last attention block under "last_decoder." (contextual_paraformer/decoder.py:241)
+static std::string dec_layer_prefix(bool contextual, int n_blocks, int i) {
+    return (contextual && i == n_blocks - 1) ? std::string("last_decoder.") : "decoders." + std::to_string(i) + ".";
+}
+
 struct Decoder {
     pf_decoder_config cfg;
+    bool contextual = false;
+    DevBuf xself, xcat, ctx_lens;     // contextual: x after the FSMN residual, [x_src_attn | cx] rows, hotword counts
     TensorTable tt;
     std::vector<DecLayerW> layers;
     DecLayerW last;          // decoders3.0 (FFN only)
@@ -731,7 +738,7 @@ static int decoder_resolve(Decoder* d) {
     if (miss) { set_error("decoder: " + std::to_string(miss) + " tensors not set, e.g. " + first); return -3; }
     d->layers.clear();
     for (int i = 0; i < d->cfg.n_blocks; ++i) {
-        const std::string p = "decoders." + std::to_string(i) + ".";
+        const std::string p = dec_layer_prefix(d->contextual, d->cfg.n_blocks, i);
         DecLayerW w;
         w.n1g = d->tt.get(p + "norm1.weight"); w.n1b = d->tt.get(p + "norm1.bias");
         w.w1 = d->tt.get(p + "feed_forward.w_1.weight"); w.b1 = d->tt.get(p + "feed_forward.w_1.bias");
@@ -1716,7 +1723,13 @@ int pf_predictor_timestamp(pf_predictor* ph, const float* hidden, const int32_t*
 }
 
 // --------------------------------------------------------------------------------------------------- decoder
-pf_decoder* pf_decoder_create(const pf_decoder_config* cfg) {
+static pf_decoder* decoder_create_impl(const pf_decoder_config* cfg, bool contextual);
+pf_decoder* pf_decoder_create(const pf_decoder_config* cfg) { return decoder_create_impl(cfg, false); }
+/* ContextualParaformerDecoder (funasr/models/contextual_paraformer/decoder.py:133-352): n_blocks - 1 standard blocks
+ * ("decoders.{i}."), the last block under "last_decoder.", plus the hotword branch "bias_decoder.norm3.*",
+ * "bias_decoder.src_attn.linear_{q,k_v,out}.*" and the 1x1 fusion "bias_output.weight" [D, 2D, 1] */
+pf_decoder* pf_decoder_create_contextual(const pf_decoder_config* cfg) { return decoder_create_impl(cfg, true); }
+static pf_decoder* decoder_create_impl(const pf_decoder_config* cfg, bool contextual) {
     if (!cfg) { set_error("decoder: null config"); return nullptr; }
     if (check_device()) return nullptr;
     const pf_decoder_config& c = *cfg;
@@ -1729,6 +1742,7 @@ pf_decoder* pf_decoder_create(const pf_decoder_config* cfg) {
     }
     std::unique_ptr<Decoder> d(new Decoder());
     d->cfg = c;
+    d->contextual = contextual;
     const int D = c.d_model, F = c.ffn_dim;
     int rc = 0;
     auto add_ffn = [&](const std::string& p) {
@@ -1741,7 +1755,7 @@ pf_decoder* pf_decoder_create(const pf_decoder_config* cfg) {
         rc |= d->tt.add(p + "feed_forward.w_2.weight", (int64_t)D * F);
     };
     for (int i = 0; i < c.n_blocks; ++i) {
-        const std::string p = "decoders." + std::to_string(i) + ".";
+        const std::string p = dec_layer_prefix(contextual, c.n_blocks, i);
         add_ffn(p);
         rc |= d->tt.add(p + "norm2.weight", D);
         rc |= d->tt.add(p + "norm2.bias", D);
@@ -1754,6 +1768,17 @@ pf_decoder* pf_decoder_create(const pf_decoder_config* cfg) {
         rc |= d->tt.add(p + "src_attn.linear_k_v.bias", 2 * D);
         rc |= d->tt.add(p + "src_attn.linear_out.weight", (int64_t)D * D);
         rc |= d->tt.add(p + "src_attn.linear_out.bias", D);
+    }
+    if (contextual) {
+        rc |= d->tt.add("bias_decoder.norm3.weight", D);
+        rc |= d->tt.add("bias_decoder.norm3.bias", D);
+        rc |= d->tt.add("bias_decoder.src_attn.linear_q.weight", (int64_t)D * D);
+        rc |= d->tt.add("bias_decoder.src_attn.linear_q.bias", D);
+        rc |= d->tt.add("bias_decoder.src_attn.linear_k_v.weight", (int64_t)2 * D * D);
+        rc |= d->tt.add("bias_decoder.src_attn.linear_k_v.bias", 2 * D);
+        rc |= d->tt.add("bias_decoder.src_attn.linear_out.weight", (int64_t)D * D);
+        rc |= d->tt.add("bias_decoder.src_attn.linear_out.bias", D);
+        rc |= d->tt.add("bias_output.weight", (int64_t)D * 2 * D);
     }
     add_ffn("decoders3.0.");
     rc |= d->tt.add("after_norm.weight", D);
@@ -1787,9 +1812,10 @@ int pf_decoder_missing(const pf_decoder* dh) {
 
 // asf_layer >= 0: run blocks 0 .. asf_layer - 1, then block asf_layer up to its cross-attention SCORES and return the
 // attention-score filter of sequence 0 in asf_scores [T] (decoder.py:485-513 forward_asf6 / :696-714 get_attn_mat)
+struct DecCtxArgs { const float* info; int n_hot; float clas_scale; };    // hotword embeddings [B, n_hot, D] (contextual decoder)
 static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* mem_lens, const float* embeds,
                                 const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids,
-                                float* hidden_out, hipStream_t s, int asf_layer, float* asf_scores);
+                                float* hidden_out, hipStream_t s, int asf_layer, float* asf_scores, const DecCtxArgs* cx = nullptr);
 
 int pf_decoder_forward(pf_decoder* dh, const float* memory, const int32_t* mem_lens, const float* embeds,
                        const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids,
@@ -1809,9 +1835,22 @@ int pf_decoder_asf_scores(pf_decoder* dh, const float* memory, const int32_t* me
                                 reinterpret_cast<hipStream_t>(stream), n_blocks_before, scores_dev);
 }
 
+/* ContextualParaformerDecoder.forward (contextual_paraformer/decoder.py:293-352): the last attention block's FSMN-side state
+ * x_self_attn also queries the hotword embeddings `contextual_dev` [B, n_hot, D] through bias_decoder; its output (times
+ * clas_scale) and the block's own cross-attention output are fused by the 1x1 bias_output: x = x_self_attn + W [x_src | cx]. */
+int pf_decoder_forward_contextual(pf_decoder* dh, const float* memory, const int32_t* mem_lens, const float* embeds,
+                                  const int32_t* tok_lens, const float* contextual_dev, int32_t n_hot, float clas_scale,
+                                  int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids, float* hidden_out, void* stream) {
+    Decoder* d = reinterpret_cast<Decoder*>(dh);
+    PF_REQUIRE(d && d->contextual && contextual_dev && n_hot >= 1, "decoder_forward_contextual: needs a contextual decoder and >= 1 hotword row");
+    DecCtxArgs cx{contextual_dev, n_hot, clas_scale};
+    return decoder_forward_impl(d, memory, mem_lens, embeds, tok_lens, B, T, N, logits, ids, hidden_out,
+                                reinterpret_cast<hipStream_t>(stream), -1, nullptr, &cx);
+}
+
 static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* mem_lens, const float* embeds,
                                 const int32_t* tok_lens, int32_t B, int32_t T, int32_t N, float* logits, int32_t* ids,
-                                float* hidden_out, hipStream_t s, int asf_layer, float* asf_scores) {
+                                float* hidden_out, hipStream_t s, int asf_layer, float* asf_scores, const DecCtxArgs* cx) {
     PF_REQUIRE(d && memory && mem_lens && embeds && tok_lens && B > 0 && T > 0 && N > 0, "decoder_forward: null/empty");
     for (int b = 0; b < B; ++b) {
         PF_REQUIRE(mem_lens[b] >= 1 && mem_lens[b] <= T, "decoder_forward: memory lens out of range");
@@ -1837,11 +1876,12 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
     const int left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
     if (V == 0 && asf_layer < 0) PF_REQUIRE(!logits && !ids && hidden_out && d->precision != 1,
                            "decoder_forward: a decoder without output layer returns hidden states only (fp32 / bf16x3)");
-    if (d->precision == 1 && !logits && asf_layer < 0) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
+    if (d->precision == 1 && !logits && asf_layer < 0 && !cx) return decoder_forward_bf16(d, memory, B, T, N, ids, hidden_out, s);
     // bf16x3 mode: the two GEMMs that are large at every batch size (w_1: N = ffn_dim; linear_k_v: M = B * T) take
     // three-plane operands on the bf16 matrix cores; the D x D projections and w_2 keep the fp32 MFMA tiles
-    const bool x3 = d->precision == 2 && asf_layer < 0;
-    const bool x2 = d->precision == 3 && asf_layer < 0;      // the score filter runs on the fp32 kernels
+    PF_REQUIRE(d->contextual == (cx != nullptr) || asf_layer >= 0, "decoder_forward: a contextual decoder runs through pf_decoder_forward_contextual");
+    const bool x3 = d->precision == 2 && asf_layer < 0 && !cx;
+    const bool x2 = d->precision == 3 && asf_layer < 0 && !cx;      // the score filter / hotword branch run on the fp32 kernels
     const int Tp = round_up(T, 16), Mkp = B * Tp;           // f16x2: padded key rows per sequence
     const unsigned short* mem3 = nullptr;
     const unsigned short* mem2 = nullptr;
@@ -1861,7 +1901,7 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
         if (d->k2.cap != cap_k) PF_HIP_TRY(hipMemsetAsync(d->k2.p, 0, d->k2.cap, s));
         if (d->vt2.cap != cap_v) PF_HIP_TRY(hipMemsetAsync(d->vt2.p, 0, d->vt2.cap, s));
         for (int l = 0; l < c.n_blocks; ++l)
-            if ((rc = dec_layer_x2(d, d->layers[l], "decoders." + std::to_string(l) + ".", true, s))) return rc;
+            if ((rc = dec_layer_x2(d, d->layers[l], dec_layer_prefix(d->contextual, c.n_blocks, l), true, s))) return rc;
         if ((rc = dec_layer_x2(d, d->last, "decoders3.0.", false, s))) return rc;
         if (!d->lb_uploaded) {
             std::vector<float> lb((size_t)4 * c.n_blocks);
@@ -1887,7 +1927,7 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
     auto w3 = [&](const std::string& name, int rows, int cols) { return x3 ? d->tt.get_split3(name, rows, cols, s) : nullptr; };
     for (int l = 0; l < c.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
-        const std::string lp = "decoders." + std::to_string(l) + ".";
+        const std::string lp = dec_layer_prefix(d->contextual, c.n_blocks, l);
         // DecoderLayerSANM.forward (paraformer/decoder.py:78-121)
         const unsigned short* w1_3 = w3(lp + "feed_forward.w_1.weight", F, D);
         if (x3 && !w1_3) return -2;
@@ -1950,6 +1990,12 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
                                    2 * D, 2 * D, D, 0, s))) return rc;
         } else if ((rc = gemm_simple(memory, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
                                      nullptr, 0, s))) return rc;
+        const bool ctx_block = cx && l == c.n_blocks - 1;
+        if (ctx_block) {
+            // x (after the FSMN residual) is x_self_attn: keep it, it is the hotword branch's query and the final residual
+            if (d->xself.ensure(sizeof(float) * (size_t)Mq * D) || d->xcat.ensure(sizeof(float) * (size_t)Mq * 2 * D)) return -2;
+            PF_HIP_TRY(hipMemcpyAsync(d->xself.p, x, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
+        }
         if (l == asf_layer) {
             if (d->asf_p.ensure(sizeof(float) * (size_t)c.n_heads * N * T)) return -2;
             return launch_asf_scores(d->q.as<float>(), D, d->kv.as<float>(), 2 * D, d->asf_p.as<float>(), asf_scores, c.n_heads,
@@ -1963,6 +2009,38 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
         // cross-attention keeps the fp32 MFMA kernel in every fp32-accurate mode: with Tq = tokens (~120) one 128-query
         // block per (utterance, head) is the better shape (102 us vs 111 us for the 256-query split kernel)
         if ((rc = attention(aa, 4.0 * B * (double)N * T * D, s))) return rc;
+        if (ctx_block) {
+            float* xcat = d->xcat.as<float>();                   // [Mq, 2D]: x_src_attn | cx * clas_scale
+            const float* xs = d->xself.as<float>();
+            if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, xcat, 2 * D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s)))
+                return rc;                                                                    // x_src_attn (no residual)
+            // bias_decoder: norm3 -> cross-attention over the hotword embeddings (decoder.py:114-130)
+            const int Mh = B * cx->n_hot;
+            if (d->kv.ensure(sizeof(float) * (size_t)(Mh > Mk ? Mh : Mk) * 2 * D)) return -2;
+            std::vector<int32_t> hl((size_t)B, cx->n_hot);
+            if ((rc = upload_lens(d->ctx_lens, hl.data(), B, s))) return rc;
+            PF_HIP_TRY(hipStreamSynchronize(s));                  // `hl` is a stack object
+            if ((rc = layernorm(xs, D, d->tt.get("bias_decoder.norm3.weight"), d->tt.get("bias_decoder.norm3.bias"), t1, D, Mq, D, D,
+                                c.ln_eps, s))) return rc;
+            if ((rc = gemm_simple(t1, D, d->tt.get("bias_decoder.src_attn.linear_q.weight"), D,
+                                  d->tt.get("bias_decoder.src_attn.linear_q.bias"), d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
+            if ((rc = gemm_simple(cx->info, D, d->tt.get("bias_decoder.src_attn.linear_k_v.weight"), D,
+                                  d->tt.get("bias_decoder.src_attn.linear_k_v.bias"), d->kv.as<float>(), 2 * D, Mh, 2 * D, D, 0, nullptr, 0,
+                                  nullptr, 0, s))) return rc;
+            AttnArgs ab{};
+            ab.Q = d->q.as<float>(); ab.ldq = D; ab.K = d->kv.as<float>(); ab.ldk = 2 * D; ab.V = d->kv.as<float>() + D; ab.ldv = 2 * D;
+            ab.O = d->ctx.as<float>(); ab.ldo = D; ab.klens = d->ctx_lens.as<int>(); ab.B = B; ab.H = c.n_heads; ab.Tq = N; ab.Tk = cx->n_hot;
+            ab.scale = aa.scale;
+            if ((rc = attention(ab, 4.0 * B * (double)N * cx->n_hot * D, s))) return rc;
+            if ((rc = gemm_simple(d->ctx.as<float>(), D, d->tt.get("bias_decoder.src_attn.linear_out.weight"), D,
+                                  d->tt.get("bias_decoder.src_attn.linear_out.bias"), xcat + D, 2 * D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s)))
+                return rc;                                                                    // cx
+            if (cx->clas_scale != 1.0f && (rc = launch_scale_cols(xcat + D, 2 * D, Mq, D, cx->clas_scale, s))) return rc;
+            // bias_output (Conv1d(2D -> D, k = 1, no bias)) and the residual: x = x_self_attn + W [x_src_attn | cx * scale]
+            if ((rc = gemm_simple(xcat, 2 * D, d->tt.get("bias_output.weight"), 2 * D, nullptr, x, D, Mq, D, 2 * D, 0, nullptr, 0, xs, D, s)))
+                return rc;
+            continue;
+        }
         if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, x, D, Mq, D, D, 0, nullptr, 0, x, D, s)))
             return rc;                                                                        // x = residual + att
     }

@@ -261,6 +261,25 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     return 0;
 }
 
+__global__ __launch_bounds__(256) void scale_cols_kernel(float* __restrict__ x, int ld, int M, int N4, float sc) {
+    const size_t total = (size_t)M * N4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float4* p = reinterpret_cast<float4*>(x + (i / N4) * (size_t)ld) + i % N4;
+        float4 v = *p;
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        *p = v;
+    }
+}
+// x[r, 0..N) *= sc for M rows of stride ld (N, ld multiples of 4, x 16-B aligned)
+int launch_scale_cols(float* x, int ld, int M, int N, float sc, hipStream_t stream) {
+    PF_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0, "scale_cols: alignment");
+    const size_t total = (size_t)M * (N / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(blocks), dim3(256), 0, stream, x, ld, M, N / 4, sc);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_log_softmax(const float* x, int ldx, float* y, int ldy, int M, int N, hipStream_t stream) {
     PF_REQUIRE(M > 0 && N > 0 && ldx >= N && ldy >= N, "log_softmax: bad shape");
     hipLaunchKernelGGL(log_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, stream, x, ldx, y, ldy, M, N);

@@ -209,6 +209,15 @@ int pf_decoder_forward(pf_decoder* d, const float* memory_dev, const int32_t* me
 int pf_decoder_asf_scores(pf_decoder* d, const float* memory_dev, const int32_t* mem_lens_host, const float* embeds_dev,
                           const int32_t* tok_lens_host, int32_t B, int32_t T, int32_t N, int32_t n_blocks_before,
                           float* scores_dev, void* stream);
+/* ContextualParaformerDecoder (funasr/models/contextual_paraformer/decoder.py:133-352): created like pf_decoder_create with
+ * n_blocks = att_layer_num; tensor names "decoders.{0..n_blocks-2}.*", "last_decoder.*", "bias_decoder.norm3.*",
+ * "bias_decoder.src_attn.linear_{q,k_v,out}.*", "bias_output.weight", "decoders3.0.*", "after_norm.*", "output_layer.*".
+ * forward_contextual additionally takes the hotword embeddings contextual_dev [B, n_hot, d_model] and clas_scale. */
+pf_decoder* pf_decoder_create_contextual(const pf_decoder_config* cfg);
+int pf_decoder_forward_contextual(pf_decoder* d, const float* memory_dev, const int32_t* mem_lens_host, const float* embeds_dev,
+                                  const int32_t* tok_lens_host, const float* contextual_dev, int32_t n_hot, float clas_scale,
+                                  int32_t B, int32_t T, int32_t N, float* logits_dev, int32_t* ids_dev, float* hidden_dev,
+                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- ctc */
 /* ---- FSMN-VAD network (funasr/models/fsmn_vad_streaming/encoder.py:288-378 FSMN.forward), reduced to what the decision

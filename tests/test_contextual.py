@@ -1,0 +1,76 @@
+"""ContextualParaformer (CLAS hotword biasing; funasr_amd/contextual_paraformer.py) against the fixture recorded from the
+REFERENCE classes' own `inference` (tests/golden/contextual.npz, oracle/make_golden_contextual.py): without hotwords, with
+hotwords, with clas_scale 0.6; plus the state_dict layout of the reference model."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "contextual.npz")
+
+
+class _Frontend:
+    fs, frame_shift, lfr_n = 16000, 10, 6
+    cmvn_file = None
+
+
+def _setup():
+    from oracle.make_golden_contextual import contextual_state_dict
+    g = np.load(GOLD, allow_pickle=False)
+    cfg = json.loads(str(g["cfg"]))
+    return g, cfg, contextual_state_dict(cfg, int(g["seed"])), json.loads(str(g["vocab"]))
+
+
+def _build(cfg):
+    from funasr_amd.contextual_paraformer import ContextualParaformer
+    ec = dict(cfg["encoder"])
+    input_size = ec.pop("input_size")
+    dc = dict(cfg["decoder"])
+    vocab = dc.pop("vocab_size")
+    dc.pop("encoder_output_size", None)
+    return ContextualParaformer(encoder="SANMEncoder", encoder_conf=dict(ec, input_layer="pe"), decoder="ContextualParaformerDecoder",
+                                decoder_conf=dc, predictor="CifPredictorV2", predictor_conf=dict(cfg["predictor"]), ctc_weight=0.0,
+                                input_size=input_size, vocab_size=vocab, inner_dim=512, bias_encoder_type="lstm")
+
+
+def test_state_dict_layout_matches_the_reference_model():
+    g, cfg, sd, vocab = _setup()
+    model = _build(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    ref = json.loads(str(g["ref_state_dict"]))
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert mine == ref, (sorted(set(mine) ^ set(ref))[:10], [k for k in mine if k in ref and mine[k] != ref[k]][:10])
+
+
+def test_registered_under_the_reference_keys():
+    from funasr_amd import install as inst
+    pairs = {(t, k) for t, k, _ in inst.hip_classes()}
+    assert ("model_classes", "ContextualParaformer") in pairs and ("decoder_classes", "ContextualParaformerDecoder") in pairs
+
+
+@pytest.mark.gpu
+def test_contextual_paraformer_on_the_gpu_equals_reference_inference(cuda, tmp_path):
+    from funasr_amd.tokenizer import CharTokenizer
+    g, cfg, sd, vocab = _setup()
+    model = _build(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(cuda)
+    tok = CharTokenizer(token_list=vocab, unk_symbol="<unk>")
+    feats, lens = torch.from_numpy(g["feats"]).to(cuda), torch.from_numpy(g["lens"])
+    seg = {ch: ch for ch in vocab[3:-10]}
+    seg.update({"hello": "hel@@ lo", "world": "wor@@ ld", "the": "the"})
+    with open(tmp_path / "seg_dict", "w", encoding="utf-8") as f:
+        f.write("".join(f"{k} {v}\n" for k, v in seg.items()))
+    fe = _Frontend()
+    fe.cmvn_file = str(tmp_path / "am.mvn")
+    keys = [f"utt{b}" for b in range(3)]
+    assert model.generate_hotwords_list(str(g["hotwords"]), tokenizer=tok, frontend=fe) == json.loads(str(g["hw_list"]))
+    for name, kw in (("plain", dict()), ("hot", dict(hotword=str(g["hotwords"]))),
+                     ("hot_scaled", dict(hotword=str(g["hotwords"]), clas_scale=0.6))):
+        res, _ = model.inference(feats, data_lengths=lens, key=keys, tokenizer=tok, frontend=fe, data_type="fbank", **kw)
+        want = json.loads(str(g[name]))
+        assert [r["text"] for r in res] == [w["text"] for w in want], (name, res, want)
+        assert [r["key"] for r in res] == [w["key"] for w in want]
