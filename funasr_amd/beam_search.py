@@ -47,7 +47,9 @@ class CTCPrefixScore:
 
     def __call__(self, y: List[int], cs: np.ndarray, r_prev: np.ndarray):
         out_len = len(y) - 1                                  # ignore sos
-        r = np.ndarray((self.T, 2, len(cs)), dtype=np.float32)
+        # (the reference leaves the rows before out_len - 1 uninitialised; they are never read -- filled here so that no
+        # garbage NaN ever reaches logaddexp)
+        r = np.full((self.T, 2, len(cs)), LOGZERO, dtype=np.float32)
         xs = self.x[:, cs]
         if out_len == 0:
             r[0, 0] = xs[0]

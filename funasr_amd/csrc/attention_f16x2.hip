@@ -27,23 +27,29 @@ constexpr int VP_B = DK * KT * 2;                        // one V^T plane tile: 
 constexpr int STAGE_B = 2 * KP_B + 2 * VP_B;             // 32 KB
 constexpr int OLD = DK + 4;                              // epilogue slab row (floats)
 constexpr int SLAB_B = 8 * 32 * OLD * 4;                 // 135168
-constexpr int LDS_BYTES = SLAB_B > 2 * STAGE_B ? SLAB_B : 2 * STAGE_B;
+constexpr int LDS_BYTES = SLAB_B > 3 * STAGE_B ? SLAB_B : 3 * STAGE_B;
 constexpr float P_SCALE = 1024.f;                        // probabilities are split as p * 2^10 (p <= 1)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// PIPE = 1: software-pipelined schedule -- the S^T products of tile t+1 are issued BEFORE the softmax of tile t, in one
+// scheduling region, so the matrix pipe works under the softmax's VALU (three LDS stages instead of two)
+template <int PIPE>
 __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NSTAGE = PIPE ? 3 : 2;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, idx = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int Tq = p.Tq > 0 ? p.Tq : p.Tp;               // cross-attention: Q / O rows per sequence differ from K's
+    // cross-attention: Q / O rows per sequence differ from K's; packed queries: sequence b owns rows [qoffs[b], qoffs[b+1])
+    const int Tq = p.qoffs ? p.qoffs[b + 1] - p.qoffs[b] : (p.Tq > 0 ? p.Tq : p.Tp);
+    if (blockIdx.x * 256 >= Tq) return;                  // (uniform per workgroup) nothing to do for this query block
     const int q = blockIdx.x * 256 + wave * 32 + idx;
     const int qc = q < Tq ? q : Tq - 1;
     const int klen = p.klens[b];
     const size_t row0 = (size_t)b * p.Tp;
-    const size_t qrow0 = (size_t)b * Tq;
+    const size_t qrow0 = p.qoffs ? (size_t)p.qoffs[b] : (size_t)b * Tq;
 
     // ---- Q planes: step s covers d in [16 s, 16 s + 16); half-wave h holds the 8 d's of chunk 2 s + h
     f16x8 qf[2][8];
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     }
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
     auto stage = [&](int kt) {
-        const unsigned base = lds_w + (unsigned)(kt & 1) * STAGE_B;
+        const unsigned base = lds_w + (unsigned)(kt % NSTAGE) * STAGE_B;
         const size_t ko = (size_t)kt * KT * p.ldk;
         glds16(ksrc + ko, base);
         glds16(ksrc + p.k_plane + ko, base + KP_B);
@@ -85,82 +91,105 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
 
     const float sscale = p.sscale_dev ? p.sscale * *p.sscale_dev : p.sscale;   // 2^-(e_q + e_k)
     const int ntiles = (klen + KT - 1) / KT;
-    stage(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int k0 = kt * KT;
+
+    // S^T tile (32 keys x 32 queries): small products into sa, hi*hi into sb (no dependent MFMA pairs)
+#define PF_QK(KT_, SA, SB)                                                                                            \
+    {                                                                                                                 \
+        const unsigned char* kp = smem + ((KT_) % NSTAGE) * STAGE_B + idx * 256;                                      \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { SA[r] = 0.f; SB[r] = 0.f; }                                  \
+        _Pragma("unroll") for (int st = 0; st < 8; ++st) {                                                            \
+            const int co = ((2 * st + hh) ^ (idx & 15)) * 16;                                                         \
+            const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kp + co));                     \
+            const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kp + KP_B + co));              \
+            SA = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[0][st], SA, 0, 0, 0);                                  \
+            SB = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qf[0][st], SB, 0, 0, 0);                                  \
+            SA = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qf[1][st], SA, 0, 0, 0);                                  \
+        }                                                                                                             \
+    }
+    // online softmax for query (lane & 31); this lane holds keys k0 + (r&3) + 8(r>>2) + 4h of the tile; s <- p
+#define PF_SOFTMAX(K0_, SA, SB)                                                                                       \
+    {                                                                                                                 \
+        float mx = -INFINITY;                                                                                         \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
+            const int key = (K0_) + (r & 3) + 8 * (r >> 2) + 4 * hh;                                                  \
+            s[r] = key < klen ? (SA[r] + SB[r]) * sscale : -INFINITY;                                                 \
+            mx = fmaxf(mx, s[r]);                                                                                     \
+        }                                                                                                             \
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                       \
+        const float m_new = fmaxf(m_run, mx);                                                                         \
+        const float alpha = __expf(m_run - m_new);                                                                    \
+        float psum = 0.f;                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
+            s[r] = __expf(s[r] - m_new);                                                                              \
+            psum += s[r];                                                                                             \
+        }                                                                                                             \
+        psum += __shfl_xor(psum, 32, 64);                                                                             \
+        l_run = l_run * alpha + psum;                                                                                 \
+        m_run = m_new;                                                                                                \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int r = 0; r < 16; ++r) o[d][r] *= alpha; \
+    }
+    // O^T += V^T P^T. step st uses this lane's registers r in [8st, 8st+8): keys 16st + 4h + {0..3, 8..11}
+#define PF_PV(KT_)                                                                                                    \
+    {                                                                                                                 \
+        const unsigned char* vp = smem + ((KT_) % NSTAGE) * STAGE_B + 2 * KP_B + idx * 64;                            \
+        _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                            \
+            uint4 ph, pl;                                                                                             \
+            split2_pk(s[8 * st + 0] * P_SCALE, s[8 * st + 1] * P_SCALE, ph.x, pl.x);                                  \
+            split2_pk(s[8 * st + 2] * P_SCALE, s[8 * st + 3] * P_SCALE, ph.y, pl.y);                                  \
+            split2_pk(s[8 * st + 4] * P_SCALE, s[8 * st + 5] * P_SCALE, ph.z, pl.z);                                  \
+            split2_pk(s[8 * st + 6] * P_SCALE, s[8 * st + 7] * P_SCALE, ph.w, pl.w);                                  \
+            const f16x8 Ph = __builtin_bit_cast(f16x8, ph), Pl = __builtin_bit_cast(f16x8, pl);                       \
+            const int co = ((2 * st + hh) ^ ((idx >> 2) & 3)) * 16;                                                   \
+            f16x8 vf[4][2];                                                                                           \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int pn = 0; pn < 2; ++pn)            \
+                vf[d][pn] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(vp + pn * VP_B + d * 32 * 64 + co)); \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[d][1], Ph, o[d], 0, 0, 0); \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[d][0], Pl, o[d], 0, 0, 0); \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[d][0], Ph, o[d], 0, 0, 0); \
+        }                                                                                                             \
+    }
+
+    float s[16];
+    if constexpr (PIPE == 0) {
+        stage(0);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            glds_wait_all();
+            __syncthreads();                    // tile kt landed; every wave is done with tile kt-1 (the other buffer)
+            if (kt + 1 < ntiles) stage(kt + 1);
+            floatx16 sa, sb;
+            PF_QK(kt, sa, sb)
+            PF_SOFTMAX(kt * KT, sa, sb)
+            PF_PV(kt)
+        }
+    } else {
+        floatx16 ca, cb, na, nb;
+        stage(0);
+        if (ntiles > 1) stage(1);
         glds_wait_all();
-        __syncthreads();                    // tile kt landed; every wave is done with tile kt-1 (the other buffer)
-        if (kt + 1 < ntiles) stage(kt + 1);
-        const unsigned char* sb_ = smem + (kt & 1) * STAGE_B;
-
-        // ---- S^T tile (32 keys x 32 queries): small products into sa, hi*hi into sb (no dependent MFMA pairs)
-        floatx16 sa, sb;
+        __syncthreads();
+        PF_QK(0, ca, cb)
+        for (int kt = 0; kt < ntiles; ++kt) {
+            // tile kt + 1 (issued one iteration ago) must have landed for S_next; its buffer and tile kt's are live, the third
+            // buffer (tile kt - 1, fully consumed before this barrier) takes tile kt + 2
+            if (kt > 0) { glds_wait_all(); __syncthreads(); }
+            if (kt + 2 < ntiles) stage(kt + 2);
+            // branch-free (one scheduling region): the last iteration recomputes its own tile's scores and drops them
+            const int kn = kt + 1 < ntiles ? kt + 1 : kt;
+            PF_QK(kn, na, nb)
+            PF_SOFTMAX(kt * KT, ca, cb)
+            // interleave: one MFMA, then a few of the softmax's VALU ops, so the matrix pipe runs under them
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
-        {
-            const unsigned char* kp = sb_ + idx * 256;
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                const int co = ((2 * st + hh) ^ (idx & 15)) * 16;
-                const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kp + co));
-                const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(kp + KP_B + co));
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qf[0][st], sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qf[0][st], sb, 0, 0, 0);
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qf[1][st], sa, 0, 0, 0);
+            for (int g = 0; g < 24; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
             }
-        }
-
-        // ---- online softmax for query (lane & 31); this lane holds keys k0 + (r&3) + 8(r>>2) + 4h
-        float s[16];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            s[r] = key < klen ? (sa[r] + sb[r]) * sscale : -INFINITY;
-            mx = fmaxf(mx, s[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_new);
-            psum += s[r];
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-
-        // ---- O^T += V^T P^T. step st uses this lane's registers r in [8st, 8st+8): keys 16st + 4h + {0..3, 8..11}
-        const unsigned char* vp = sb_ + 2 * KP_B + idx * 64;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            uint4 ph, pl;
-            split2_pk(s[8 * st + 0] * P_SCALE, s[8 * st + 1] * P_SCALE, ph.x, pl.x);
-            split2_pk(s[8 * st + 2] * P_SCALE, s[8 * st + 3] * P_SCALE, ph.y, pl.y);
-            split2_pk(s[8 * st + 4] * P_SCALE, s[8 * st + 5] * P_SCALE, ph.z, pl.z);
-            split2_pk(s[8 * st + 6] * P_SCALE, s[8 * st + 7] * P_SCALE, ph.w, pl.w);
-            const f16x8 Ph = __builtin_bit_cast(f16x8, ph), Pl = __builtin_bit_cast(f16x8, pl);
-            const int co = ((2 * st + hh) ^ ((idx >> 2) & 3)) * 16;
-            f16x8 vf[4][2];
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int pn = 0; pn < 2; ++pn)
-                    vf[d][pn] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(vp + pn * VP_B + d * 32 * 64 + co));
-            // product-major: consecutive MFMAs write the four different d accumulators
-#define PF_PV(PV_, PP_) _Pragma("unroll") for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[d][PV_], PP_, o[d], 0, 0, 0)
-            PF_PV(1, Ph);
-            PF_PV(0, Pl);
-            PF_PV(0, Ph);
-#undef PF_PV
+            PF_PV(kt)
+            ca = na; cb = nb;
         }
     }
+#undef PF_QK
+#undef PF_SOFTMAX
+#undef PF_PV
 
     // ---- epilogue: O^T (lane = query, registers = d) -> wave-private slab [32 q][128 d] -> row-wise 16-B plane pieces
     __syncthreads();
@@ -205,12 +234,15 @@ int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
                "attention_f16x2: 16-B alignment");
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel),
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured = true;
     }
     dim3 grid(ceil_div(a.Tq > 0 ? a.Tq : a.Tp, 256), a.H, a.B);
-    hipLaunchKernelGGL(attention_f16x2_kernel, grid, dim3(512), LDS_BYTES, stream, a);
+    if (a.variant == 1) hipLaunchKernelGGL(attention_f16x2_kernel<1>, grid, dim3(512), LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(attention_f16x2_kernel<0>, grid, dim3(512), LDS_BYTES, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

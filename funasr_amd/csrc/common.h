@@ -250,6 +250,8 @@ struct FsmnArgs {
     const int* lens;              // device int32 [B]: valid rows per sequence
     int B, T, C, K, left_pad;
     int in_bf16;                  // `in` holds bf16 (ldin in elements)
+    const int* offs;              // optional packed layout: sequence b occupies rows [offs[b], offs[b] + lens[b]) of in / R / out
+                                  // (T then only sizes the grid: >= max lens)
 };
 int launch_fsmn(const FsmnArgs& a, hipStream_t stream);
 
@@ -286,6 +288,9 @@ struct Attn2Args {
     float sscale;                                         // 2^-(e_q + e_k)
     const float* sscale_dev;                              // optional device float multiplied into sscale
     float oscale;                                         // 2^(e_ctx - e_v - 10)
+    int variant;                                          // kernel schedule (measurement hook), 0 = default
+    const int* qoffs;                                     // optional packed queries: sequence b owns rows [qoffs[b], qoffs[b+1]) of
+                                                          // Q / O (device int32 [B + 1]); Tq then only sizes the grid
 };
 int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream);
 
@@ -297,6 +302,8 @@ int launch_asf_scores(const float* Q, int ldq, const float* K, int ldk, float* P
 bool attention_small_applicable(const AttnArgs& a, int dk);
 int launch_attention_small(const AttnArgs& a, int dk, hipStream_t stream);
 // out[i] = table[ids[i]] (embedding lookup; ids clamped to [0, rows))
+// out[map[i], 0..n_per) = in[i, 0..n_per): int32 rows scattered through a row map (token ids back to the padded [B, N] layout)
+int launch_scatter_i32(const int* in, const int* map, int* out, int n, hipStream_t stream);
 int launch_gather_rows(const float* table, int ld, int rows, const int* ids, float* out, int n, int D, hipStream_t stream);
 
 // FSMN-VAD row kernels (vad.hip)

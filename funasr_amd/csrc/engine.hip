@@ -730,6 +730,9 @@ struct Decoder {
     bool lb_uploaded = false;
     int e_an = INT32_MIN;    // exponent of the after_norm output planes (f16x2 vocabulary projection)
     DevBuf asf_p;            // SeACo score filter: attention probabilities of sequence 0 [H, N, T]
+    // token packing (f16x2 greedy route): row offsets per sequence, packed row -> padded row map, packed ids
+    DevBuf offs_dev, map_dev, ids_packed;
+    std::vector<int32_t> h_offs, h_map;
 };
 
 static int decoder_resolve(Decoder* d) {
@@ -1860,7 +1863,8 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
     if (!d->resolved && (rc = decoder_resolve(d))) return rc;
     const pf_decoder_config& c = d->cfg;
     const int D = c.d_model, F = c.ffn_dim, V = c.vocab_size;
-    const int Mq = B * N, Mk = B * T;
+    int Mq = B * N;                                          // rows processed per token-side op (shrinks when packed, below)
+    const int Mq_pad = B * N, Mk = B * T;
     if (d->x.ensure(sizeof(float) * (size_t)Mq * D) || d->t1.ensure(sizeof(float) * (size_t)Mq * D) ||
         d->t2.ensure(sizeof(float) * (size_t)Mq * D) || d->ffn.ensure(sizeof(float) * (size_t)Mq * F) ||
         d->ffn2.ensure(sizeof(float) * (size_t)Mq * F) || d->q.ensure(sizeof(float) * (size_t)Mq * D) ||
@@ -1872,7 +1876,9 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
     float* x = d->x.as<float>();
     float* t1 = d->t1.as<float>();
     float* t2 = d->t2.as<float>();
-    PF_HIP_TRY(hipMemcpyAsync(x, embeds, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
+    // the f16x2 greedy route may pack the token rows instead (below); every other route starts from the padded embeddings
+    const bool may_pack = d->precision == 3 && asf_layer < 0 && !cx && ids && !logits && !hidden_out && V > 0;
+    if (!may_pack) PF_HIP_TRY(hipMemcpyAsync(x, embeds, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     const int left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
     if (V == 0 && asf_layer < 0) PF_REQUIRE(!logits && !ids && hidden_out && d->precision != 1,
                            "decoder_forward: a decoder without output layer returns hidden states only (fp32 / bf16x3)");
@@ -1918,6 +1924,29 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
         if ((rc = launch_split2(memory, D, d->mem16.as<unsigned short>(), D, (size_t)Mkp * D, Mkp, D, 1.f, s, dsc + 1, Tp, T))) return rc;
         mem2 = d->mem16.as<unsigned short>();
     }
+    // Token packing (f16x2 greedy route): a batch is padded to its longest hypothesis (N = max token count), but every
+    // token-side op is row-wise except the FSMN (per sequence, along tokens) and the attention (per query). So only the
+    // VALID token rows are processed, packed back to back: sequence b owns rows [offs[b], offs[b] + tok_lens[b]). The FSMN
+    // and the attention kernel take the offsets; ids are scattered back to the caller's [B, N] layout at the end.
+    bool pack = false;
+    const int* offs_dev = nullptr;
+    if (may_pack) {
+        int total = 0;
+        d->h_offs.assign((size_t)B + 1, 0);
+        for (int b = 0; b < B; ++b) { d->h_offs[b] = total; total += tok_lens[b]; }
+        d->h_offs[B] = total;
+        if (total > 0 && total < Mq_pad) {
+            d->h_map.resize((size_t)total);
+            for (int b = 0; b < B; ++b) for (int t = 0; t < tok_lens[b]; ++t) d->h_map[(size_t)d->h_offs[b] + t] = b * N + t;
+            if (d->offs_dev.ensure(sizeof(int32_t) * ((size_t)B + 1)) || d->map_dev.ensure(sizeof(int32_t) * (size_t)Mq_pad) ||
+                d->ids_packed.ensure(sizeof(int32_t) * (size_t)Mq_pad)) return -2;
+            PF_HIP_TRY(hipMemcpyAsync(d->offs_dev.p, d->h_offs.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, s));
+            PF_HIP_TRY(hipMemcpyAsync(d->map_dev.p, d->h_map.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, s));
+            if ((rc = launch_gather_rows(embeds, D, Mq_pad, d->map_dev.as<int>(), x, total, D, s))) return rc;
+            pack = true; offs_dev = d->offs_dev.as<int>(); Mq = total;
+        }
+    }
+    if (may_pack && !pack) PF_HIP_TRY(hipMemcpyAsync(x, embeds, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     if (x3) {
         if (d->t16.ensure(sizeof(unsigned short) * 3 * (size_t)Mq * D) || d->mem16.ensure(sizeof(unsigned short) * 3 * (size_t)Mk * D))
             return -2;
@@ -1938,6 +1967,7 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
         FsmnArgs fa{};                                                                        // x = residual + fsmn
         fa.in = t1; fa.ldin = D; fa.w = w.fsmn_w; fa.R = x; fa.ldr = D; fa.out = x; fa.ldo = D;
         fa.lens = d->tok_lens.as<int>(); fa.B = B; fa.T = N; fa.C = D; fa.K = c.kernel_size; fa.left_pad = left_pad;
+        fa.offs = offs_dev;
         if ((rc = fsmn(fa, s))) return rc;
         if (x2) {                                                                             // norm3 -> linear_q
             unsigned short* t2p = d->t16.as<unsigned short>();
@@ -1977,7 +2007,7 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
                 aa.Q = d->q16.as<unsigned short>(); aa.ldq = D; aa.q_plane = (size_t)Mq * D;
                 aa.K = k2; aa.ldk = D; aa.k_plane = ((size_t)Mkp + 32) * D; aa.VT = vt2; aa.ldvt = Mkp + 64;
                 aa.vt_plane = (size_t)D * (Mkp + 64); aa.O = d->ctx16.as<unsigned short>(); aa.ldo = D; aa.o_plane = (size_t)Mq * D;
-                aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tp = Tp; aa.Tq = N;
+                aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tp = Tp; aa.Tq = N; aa.qoffs = offs_dev;
                 aa.sscale = pow2f(-w.e_q); aa.sscale_dev = lsc + 2; aa.oscale = pow2f(-10);        // ctx planes carry v's scale
                 ProfScope ps(PROF_ATTN, 4.0 * B * (double)N * T * D, s);
                 if ((rc = launch_attention_f16x2(aa, s))) return rc;
@@ -2080,7 +2110,10 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
             ProfScope ps(PROF_GEMM3, 2.0 * Mq * (double)V * D, s);
             if ((rc = launch_gemm_f16x2(g, s))) return rc;
         }
-        return launch_argmax_reduce(d->pval.as<float>(), d->pidx.as<int>(), nparts, nparts, ids, nullptr, Mq, s);
+        if (!pack) return launch_argmax_reduce(d->pval.as<float>(), d->pidx.as<int>(), nparts, nparts, ids, nullptr, Mq, s);
+        if ((rc = launch_argmax_reduce(d->pval.as<float>(), d->pidx.as<int>(), nparts, nparts, d->ids_packed.as<int>(), nullptr, Mq, s))) return rc;
+        PF_HIP_TRY(hipMemsetAsync(ids, 0, sizeof(int32_t) * (size_t)Mq_pad, s));       // padding positions: id 0, like an untouched row
+        return launch_scatter_i32(d->ids_packed.as<int>(), d->map_dev.as<int>(), ids, Mq, s);
     }
     if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), hid, D, Mq, D, D,
                         c.ln_eps, s))) return rc;
@@ -2604,6 +2637,39 @@ int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2
     PF_HIP_TRY(hipEventCreate(&b));
     PF_HIP_TRY(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) if ((rc = launch_gemm_f16x2(g, s))) return rc;
+    PF_HIP_TRY(hipEventRecord(b, s));
+    PF_HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    PF_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_out = ms / iters;
+    return 0;
+}
+/* self / cross attention on two-plane fp16 operands (attention_f16x2.hip): Q2 [2][B Tq, H 128] (q * d_k^-0.5 * 2^e_q),
+ * K2 [2][>= B Tp + 32, H 128], VT2 [2][H 128, ldvt >= B Tp + 32] (columns = rows with index bits 2 and 3 swapped), O2 out
+ * planes [2][B Tq, H 128]. variant: 0 = default schedule, 1 = alternative schedule (measurement hook).
+ * iters > 0 with ms_out: additionally times `iters` launches */
+int pf_k_attention_f16x2(const void* Q2, int64_t q_plane, const void* K2, int64_t k_plane, const void* VT2, int32_t ldvt,
+                         int64_t vt_plane, void* O2, int64_t o_plane, const int32_t* klens_dev, int32_t B, int32_t H,
+                         int32_t Tp, int32_t Tq, float sscale, float oscale, int32_t variant, int32_t iters, float* ms_out,
+                         void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Attn2Args aa{};
+    const int D = H * 128;
+    aa.Q = reinterpret_cast<const unsigned short*>(Q2); aa.ldq = D; aa.q_plane = (size_t)q_plane;
+    aa.K = reinterpret_cast<const unsigned short*>(K2); aa.ldk = D; aa.k_plane = (size_t)k_plane;
+    aa.VT = reinterpret_cast<const unsigned short*>(VT2); aa.ldvt = ldvt; aa.vt_plane = (size_t)vt_plane;
+    aa.O = reinterpret_cast<unsigned short*>(O2); aa.ldo = D; aa.o_plane = (size_t)o_plane;
+    aa.klens = klens_dev; aa.B = B; aa.H = H; aa.Tp = Tp; aa.Tq = Tq; aa.sscale = sscale; aa.oscale = oscale; aa.variant = variant;
+    int rc;
+    if (iters <= 0 || !ms_out) return launch_attention_f16x2(aa, s);
+    for (int i = 0; i < 3; ++i) if ((rc = launch_attention_f16x2(aa, s))) return rc;
+    hipEvent_t a, b;
+    PF_HIP_TRY(hipEventCreate(&a));
+    PF_HIP_TRY(hipEventCreate(&b));
+    PF_HIP_TRY(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if ((rc = launch_attention_f16x2(aa, s))) return rc;
     PF_HIP_TRY(hipEventRecord(b, s));
     PF_HIP_TRY(hipEventSynchronize(b));
     float ms = 0.f;

@@ -169,6 +169,8 @@ __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
     const int c4 = threadIdx.x;
     if (c4 * 4 >= p.C) return;
     const int len = p.lens[b];
+    const size_t base = p.offs ? (size_t)p.offs[b] : (size_t)b * p.T;
+    if (p.offs && t0 >= len) return;                     // packed layout: rows past the sequence do not exist
     float4 w[KS];
     {
         const float* wp = p.w + (size_t)c4 * 4 * KS;
@@ -185,14 +187,14 @@ __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
     for (int i = 0; i < KS + FSMN_TT - 1; ++i) {
         const int tt = t0 - LP + i;
         if (tt >= 0 && tt < p.T && tt < len)
-            win[i] = load4(p.in, ((size_t)b * p.T + tt) * p.ldin + c4 * 4, p.in_bf16 != 0);
+            win[i] = load4(p.in, (base + tt) * p.ldin + c4 * 4, p.in_bf16 != 0);
         else
             win[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < FSMN_TT; ++i) {
         const int t = t0 + i;
-        if (t < p.T) {
+        if (t < p.T && !(p.offs && t >= len)) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < len) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
                 const float4 c = win[i + LP];   // the (masked) input row itself
                 o.x = acc.x + c.x; o.y = acc.y + c.y; o.z = acc.z + c.z; o.w = acc.w + c.w;
             }
-            const size_t row = (size_t)b * p.T + t;
+            const size_t row = base + t;
             if (p.R) {
                 const float4 r = *reinterpret_cast<const float4*>(p.R + row * p.ldr + c4 * 4);
                 o.x = r.x + o.x; o.y = r.y + o.y; o.z = r.z + o.z; o.w = r.w + o.w;
@@ -276,6 +278,17 @@ int launch_scale_cols(float* x, int ld, int M, int N, float sc, hipStream_t stre
     const size_t total = (size_t)M * (N / 4);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(scale_cols_kernel, dim3(blocks), dim3(256), 0, stream, x, ld, M, N / 4, sc);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void scatter_i32_kernel(const int* __restrict__ in, const int* __restrict__ map, int* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[map[i]] = in[i];
+}
+int launch_scatter_i32(const int* in, const int* map, int* out, int n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(scatter_i32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, in, map, out, n);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

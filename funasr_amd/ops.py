@@ -294,6 +294,34 @@ def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=N
     return (out, float(ms.value)) if time_iters > 0 else out
 
 
+def attention_f16x2(q, k, v, klens, n_heads: int, scale: float, eq: int = 6, ek: int = 6, ev: int = 6, variant: int = 0,
+                    time_iters: int = 0):
+    """fp32 q [B, Tq, D], k / v [B, Tp, D] (Tp % 16 == 0) -> fp32 [B, Tq, D] through attention_f16x2.hip: builds the kernel's
+    operand layouts here (planes via ops.split2, V transposed with index bits 2 and 3 of the row swapped) -- the layouts the
+    QKV form of gemm_f16x2 writes in the engine. Test / measurement helper."""
+    lib = _lib.load()
+    B, Tq, D = q.shape
+    Tp = k.shape[1]
+    assert Tp % 16 == 0 and D == n_heads * 128
+    dev = q.device
+    q2 = split2((q * scale).reshape(B * Tq, D).contiguous(), eq)
+    k2 = torch.zeros(2, B * Tp + 32, D, device=dev, dtype=torch.float16)
+    k2[:, : B * Tp] = split2(k.reshape(B * Tp, D).contiguous(), ek)
+    v2 = split2(v.reshape(B * Tp, D).contiguous(), ev)
+    m = torch.arange(B * Tp, device=dev)
+    col = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1)
+    ldvt = B * Tp + 64
+    vt = torch.zeros(2, D, ldvt, device=dev, dtype=torch.float16)
+    vt[:, :, col] = v2.transpose(1, 2)
+    o2 = torch.empty(2, B * Tq, D, device=dev, dtype=torch.float16)
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_attention_f16x2(_ptr(q2), B * Tq * D, _ptr(k2), (B * Tp + 32) * D, _ptr(vt), ldvt, D * ldvt, _ptr(o2), B * Tq * D,
+                                        _ptr(klens), B, n_heads, Tp, Tq, float(2.0 ** -(eq + ek)), float(2.0 ** -10), int(variant),
+                                        int(time_iters), C.byref(ms), _stream()), "pf_k_attention_f16x2")
+    out = ((o2[0].float() + o2[1].float()) * 2.0 ** -ev).view(B, Tq, D)
+    return (out, float(ms.value)) if time_iters > 0 else out
+
+
 def attention_bf16(q, k, v, klens, n_heads: int, scale: float):
     """bf16 q [B, Tq, H*128], k/v [B, Tk, H*128] (row-strided views allowed) -> bf16 [B, Tq, H*128]."""
     lib = _lib.load()

@@ -347,6 +347,11 @@ int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2
                     float oscale, const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2,
                     float* C, int32_t ldc, void* C2, int32_t ldc2, int64_t c_plane, float cscale, int32_t M, int32_t N,
                     int32_t K, int32_t relu, int32_t tile, int32_t iters, float* ms_out, void* stream);
+/* attention on two-plane fp16 operands (attention_f16x2.hip; the layouts the QKV / KV forms of gemm_f16x2.hip write) */
+int pf_k_attention_f16x2(const void* Q2, int64_t q_plane, const void* K2, int64_t k_plane, const void* VT2, int32_t ldvt,
+                         int64_t vt_plane, void* O2, int64_t o_plane, const int32_t* klens_dev, int32_t B, int32_t H,
+                         int32_t Tp, int32_t Tq, float sscale, float oscale, int32_t variant, int32_t iters, float* ms_out,
+                         void* stream);
 /* fp32 -> bf16 (round to nearest even), n % 4 == 0 */
 int pf_k_cast_bf16(const float* x, void* y, int64_t n, void* stream);
 int pf_k_gemm_argmax_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, int32_t M,
