@@ -633,6 +633,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             aa.VT = vt2; aa.ldvt = ldvt; aa.vt_plane = (size_t)D * ldvt;
             aa.O = ctx2; aa.ldo = D; aa.o_plane = (size_t)M * D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tp = T;
             aa.sscale = pow2f(-(w.e_q + w.e_k)); aa.oscale = pow2f(-10);      // ctx planes carry v's exponent
+            aa.variant = 1;                                                     // pipelined schedule: ~4 % faster on the self-attention shape
             ProfScope ps(PROF_ATTN, 4.0 * B * (double)T * T * D, s);
             if ((rc = launch_attention_f16x2(aa, s))) return rc;
         }
