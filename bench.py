@@ -256,6 +256,7 @@ def main():
                                f"{B} x {args.seconds:g} s distinct 16 kHz clips per GPU, wav in HBM -> token ids on host",
                    "clips_per_gpu": B, "clip_seconds": args.seconds, "parallelism": f"utterance-dp{world}",
                    "tokens_per_clip": round(sum(res["token_num"]) / len(res["token_num"]), 1),
+                   "tokens_max": max(res["token_num"]), "tokens_min": min(res["token_num"]),
                    "rccl_ranks": world, "weight_arena_bytes_broadcast": arena_bytes,
                    "hypothesis_gather_bytes_per_rank_per_step": (B * (N_PAD + 1) * 4) if world > 1 else 0},
         "roofline": roofline, "kernels": kernels,
