@@ -15,7 +15,13 @@
  *   pf_decoder    <-> ParaformerSANMDecoder.forward          funasr/models/paraformer/decoder.py:397-449
  *                     (+ log_softmax/argmax of Paraformer.inference, funasr/models/paraformer/model.py:345,642;
  *                      kernel_size 21 / vocab_size 0 = SeACo's bias decoder, funasr/models/seaco_paraformer/model.py:98-108)
+ *                     pf_decoder_asf_scores <-> ParaformerSANMDecoder.forward_asf6 as SeACo's hotword filter uses it
+ *                                                            funasr/models/paraformer/decoder.py:485-513, seaco_paraformer/model.py:323-335
+ *                     pf_decoder_create_contextual / pf_decoder_forward_contextual <-> ContextualParaformerDecoder.forward
+ *                                                            funasr/models/contextual_paraformer/decoder.py:133-352
  *   pf_ctc        <-> CTC.log_softmax / argmax               funasr/models/ctc/ctc.py:192-216
+ *   pf_k_log_softmax <-> the log_softmax feeding BeamSearchPara / CTCPrefixScorer
+ *                                                            funasr/models/paraformer/model.py:345,629-637, transformer/scorers/ctc.py:46
  *   pf_stream     <-> ParaformerStreaming chunk step         funasr/models/paraformer_streaming/model.py
  *   pf_vad, pf_vad_decision <-> FsmnVADStreaming (network / state machine)   funasr/models/fsmn_vad_streaming/{encoder,model}.py
  *   pf_k_lstm     <-> torch.nn.LSTM layer (hotword encoder of SeACo, seaco_paraformer/model.py:388-424)
