@@ -142,7 +142,7 @@ def test_bicif_paraformer_text_and_timestamps_equal_reference_inference(cuda):
     model = model.to(cuda)
     tok = CharTokenizer(token_list=vocab, unk_symbol="<unk>")
     feats, lens = _t(g, "e2e_feats").to(cuda), _t(g, "e2e_lens")
-    for mode in ("fp32", "bf16x3"):
+    for mode in ("fp32", "bf16x3", "f16x2"):
         model.set_precision(mode)
         res, _ = model.inference(feats, data_lengths=lens, key=[w["key"] for w in want], tokenizer=tok, data_type="fbank")
         for r, w in zip(res, want):

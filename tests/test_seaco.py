@@ -103,7 +103,7 @@ def test_seaco_on_the_gpu_equals_reference_inference(cuda, tmp_path):
     fe = _Frontend()
     fe.cmvn_file = str(tmp_path / "am.mvn")
     keys = [f"utt{b}" for b in range(3)]
-    for mode in ("fp32", "bf16x3"):
+    for mode in ("fp32", "bf16x3", "f16x2"):
         model.set_precision(mode)
         for name, hw in (("plain", None), ("hot", str(g["hotwords"]))):
             res, _ = model.inference(feats, data_lengths=lens, key=keys, tokenizer=tok, frontend=fe, data_type="fbank", hotword=hw)
