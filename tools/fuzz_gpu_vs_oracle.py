@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Shape fuzz on the GPU: random batch sizes / frame counts / ragged lengths through the HIP pipeline in both
+"""Shape fuzz on the GPU: random batch sizes / frame counts / ragged lengths through the HIP pipeline in all three
 fp32-accurate modes against the CPU oracle (token ids, CIF fire positions, encoder error). Not part of the test run."""
 import os
 import sys
@@ -14,7 +14,7 @@ from oracle import paraformer_oracle as O         # noqa: E402
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-worst, bad = {"fp32": 0.0, "bf16x3": 0.0}, 0
+worst, bad = {"fp32": 0.0, "bf16x3": 0.0, "f16x2": 0.0}, 0
 for ci in range(n_cases):
     cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=int(torch.randint(1, 4, (1,), generator=g)),
                      dec_blocks=int(torch.randint(1, 3, (1,), generator=g)), vocab=int(torch.randint(30, 300, (1,), generator=g)))
@@ -33,7 +33,7 @@ for ci in range(n_cases):
         ref = O.paraformer_greedy(x, lens, sd, cfg)
     except IndexError:
         continue
-    for mode in ("fp32", "bf16x3"):
+    for mode in ("fp32", "bf16x3", "f16x2"):
         model.set_precision(mode)
         res = model.recognize_features(x.to(dev), lens, return_intermediate=True)
         err = (res["enc"].cpu() - ref["enc"]).abs().max().item()
@@ -44,3 +44,7 @@ for ci in range(n_cases):
             bad += 1
             print(f"case {ci} mode {mode} B={B} T={T} lens={lens.tolist()} err={err:.2e} same={same}")
 print(f"{n_cases} cases: max encoder |d| {worst}, failures {bad}")
+import json
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump({"cases": n_cases, "seed": int(sys.argv[1]) if len(sys.argv) > 1 else 0, "max_encoder_abs_diff": worst, "failures": bad},
+          open("gpurun_out/fuzz_gpu_vs_oracle.json", "w"))
