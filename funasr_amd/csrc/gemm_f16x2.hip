@@ -611,9 +611,11 @@ template <int MODE, int OUT>
 int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
     // and does not anyway: both shapes issue the same products in the same k order)
+    if constexpr (OUT == 0) {              // measurement hooks (tools/abl_gemm2.py)
+        if (a.tile == 3) return launch_tile<2, 2, MODE, 0, 0, 0, 2>(a, stream);   // 128 x 128, 4 waves, two workgroups per CU
+        if (a.tile >= 256) return (a.tile >> 8) == 1 ? launch_tile<2, 4, MODE, 0, 0, 1>(a, stream) : launch_tile<2, 4, MODE, 0, 0, 2>(a, stream);
+    }
     if constexpr (MODE == 0 && OUT == 0) {
-        if (a.tile == 3) return launch_tile<2, 2, 0, 0, 0, 0, 2>(a, stream);      // 128 x 128, 4 waves, two workgroups per CU
-        if (a.tile >= 256) return (a.tile >> 8) == 1 ? launch_tile<2, 4, 0, 0, 0, 1>(a, stream) : launch_tile<2, 4, 0, 0, 0, 2>(a, stream);
         if (a.tile >= 16) {                 // ablation builds of the wide tile: bits 4.. = ABL
             switch (a.tile >> 4) {
                 case 1: return launch_tile<2, 4, 0, 0, 1>(a, stream);
@@ -623,10 +625,21 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
             }
         }
     }
-    // 256 x 256 blocks when they still fill the chip (>= 192 blocks), else 256 x 128 (twice the blocks). The choice moves
-    // no result: both shapes issue the same products in the same k order per output element (bitwise equal, tested)
-    const long wide_blocks = (long)ceil_div(a.M, 256) * (a.N / 256);
-    const bool wide = a.tile == 2 || (a.tile == 0 && a.N % 256 == 0 && (a.N >= 1024 || wide_blocks >= 192));
+    // 256 x 256 blocks or 256 x 128 ones (twice as many, each 0.57 of the time: tools/abl_gemm2.py), whichever needs less
+    // time in whole rounds over the CUs: 290 wide blocks on 256 CUs are two rounds, 580 narrow ones three half-rounds.
+    // The choice moves no result: both shapes issue the same products in the same k order per output element (bitwise
+    // equal, tested), so a clip's result still does not depend on what else is in the batch.
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            n = pr.multiProcessorCount;
+        return n;
+    }();
+    const long m_tiles = ceil_div(a.M, 256);
+    const long wide_blocks = m_tiles * (a.N / 256), narrow_blocks = m_tiles * ceil_div(a.N, 128);
+    const double cost_wide = (double)((wide_blocks + n_cu - 1) / n_cu), cost_narrow = 0.57 * (double)((narrow_blocks + n_cu - 1) / n_cu);
+    const bool wide = a.tile == 2 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
     // SCHED 2 on the 256 x 256 shape (both k-steps' fragments requested up front, DMA pieces early): 0-10 % faster there
     return wide ? launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
 }

@@ -6,6 +6,21 @@ import torch
 from funasr_amd import ops
 dev = torch.device("cuda:0")
 M = 32768
+if len(sys.argv) > 1 and sys.argv[1] == "resid":
+    # the out-projection / w_2 forms with residual operands (modes 3 and 2): which tile shape hides the epilogue's residual reads best
+    for name, N, K, nres in (("out+2res", 512, 512, 2), ("out+1res", 512, 512, 1), ("out", 512, 512, 0), ("ffn2+1res", 512, 2048, 1)):
+        a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
+        r1 = torch.randn(M, N, device=dev); r2 = torch.randn(M, N, device=dev)
+        a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+        kw = dict(add1=r1 if nres == 2 else None, add2=r2 if nres >= 1 else None)
+        row = {}
+        ref = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=2, **kw)
+        for label, tile in (("wide", 2), ("narrow", 1), ("small2wg", 3), ("wide_sched0", 2 + 256)):
+            out = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, **kw)
+            ms = min(ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20, **kw)[1] for _ in range(3))
+            row[label] = (round(ms * 1e3, 1), bool(torch.equal(out, ref)))
+        print(name, row, flush=True)
+    sys.exit(0)
 for name, N, K in (("qkv", 1536, 512), ("ffn1", 2048, 512), ("ffn2", 512, 2048), ("out", 512, 512)):
     a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
     a2, w2 = ops.split2(a, 8), ops.split2(w, 12)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Corpus sweep (BASELINE configs[3], scaled): decode N clips with AISHELL-1-like durations (mean 5.0 s, 1.9-14.7 s;
-the 7176 test durations sum to 36 108.9 s, runtime/triton_gpu/client/aishell_test.txt) through the full path, batched by a
-seconds budget after a length sort (the reference's `batch_size_s` policy, funasr/auto/auto_model.py:893-955) and, under
+the 7176 test durations sum to 36 108.9 s, runtime/triton_gpu/client/aishell_test.txt) through the full path, batched after a
+length sort by a budget of padded encoder ROWS (default; sized to whole rounds of GEMM blocks on the 256 CUs) or of padded
+seconds (`--batch-seconds`, the reference's `batch_size_s` policy, funasr/auto/auto_model.py:893-955) and, under
 torchrun, sharded over the ranks with funasr_amd.dp (weights broadcast as one arena, hypotheses gathered on rank 0).
 
   python tools/sweep.py --clips 2000                       # 1 GPU
@@ -30,7 +31,11 @@ def durations(n, seed=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=2000)
-    ap.add_argument("--batch-seconds", type=float, default=1920.0, help="padded audio seconds per batch (64 x 30 s)")
+    ap.add_argument("--batch-seconds", type=float, default=0.0, help="padded audio seconds per batch (the reference's batch_size_s "
+                    "policy); 0 = use --batch-rows")
+    ap.add_argument("--batch-rows", type=int, default=32768, help="padded encoder rows per batch: B * ceil16(frames of the longest "
+                    "clip) <= this. 32768 rows = 128 row tiles of 256 = exactly one round of 256 x 256 blocks for the N = 512 "
+                    "GEMMs on 256 CUs (64 x 30 s clips is the same amount of work)")
     ap.add_argument("--model", default="paraformer", choices=["paraformer", "sensevoice"])
     ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16", "bf16x3", "f16x2"])
     ap.add_argument("--dump", default=None, help="rank 0 writes the hypotheses in CORPUS order to this JSON file")
@@ -74,11 +79,16 @@ def main():
     # a small pool of base clips, cut / rolled per utterance (cheap to generate, distinct content)
     pool = [synth.speech_like(int(14.7 * 16000) + 1, seed=1000 + i) for i in range(16)]
     clips = {i: pool[i % 16].roll(31 * i)[: lens[i]] for i in mine}
-    # batches by padded-seconds budget
+    # batches by padded-rows (or padded-seconds) budget
     batches, cur = [], []
+    def over_budget(n_clips, longest):
+        if args.batch_seconds > 0:
+            return n_clips * longest / 16000.0 > args.batch_seconds
+        return n_clips * ((fe.num_frames(longest) + 15) // 16 * 16) > args.batch_rows
+
     for i in mine:
         longest = lens[cur[0]] if cur else lens[i]
-        if cur and (len(cur) + 1) * longest / 16000.0 > args.batch_seconds:
+        if cur and over_budget(len(cur) + 1, longest):
             batches.append(cur)
             cur = []
         cur.append(i)
@@ -122,7 +132,10 @@ def main():
         timing["collect"] += time.perf_counter() - t
         return ids
 
-    finish(launch(batches[0]))                               # warm-up (allocations, weight push)
+    # warm-up: the longest-clip batch and the one with the most clips, so that every grow-only buffer (device workspaces,
+    # pinned id buffers) has its final size before the clock starts
+    finish(launch(batches[0]))
+    finish(launch(max(batches, key=len)))
     torch.cuda.synchronize()
     for k in timing:
         timing[k] = 0.0
@@ -172,7 +185,8 @@ def main():
         mine_s = sum(lens[i] for i in mine) / 16000.0
         print(json.dumps({"metric": f"corpus sweep audio-seconds/s ({args.model}, {args.precision})", "value": round(total_s / dt, 1),
                           "n_gpus": world, "clips": args.clips, "audio_hours": round(total_s / 3600, 2), "wall_s": round(dt, 3),
-                          "batches_rank0": len(batches), "padding_efficiency_rank0": round(mine_s / padded, 3),
+                          "batches_rank0": len(batches), "batch_budget": (f"{args.batch_seconds} s" if args.batch_seconds > 0 else f"{args.batch_rows} rows"),
+                          "padding_efficiency_rank0": round(mine_s / padded, 3),
                           "tokens_rank0": sum(len(v) for v in hyps.values()),
                           "host_seconds_rank0": {k: round(v, 3) for k, v in timing.items()}}), flush=True)
     if world > 1:
