@@ -171,7 +171,7 @@ class ContextualParaformer(Paraformer):
 
     # ------------------------------------------------------------------------------------------- device pipeline
     def enqueue_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
-        enc, olens = self.encode(speech, speech_lengths)
+        enc, olens = self.encode(speech, speech_lengths, all_rows=return_intermediate)
         embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
         tok = [int(round(v)) for v in token_num.tolist()]
         ids = None

@@ -8,7 +8,9 @@
 // Reference semantics: funasr/models/sanm/attention.py:270-306,322-327 (scores, key mask -inf, softmax, mask 0, .V).
 //
 // Row layout: sequence b occupies rows [b Tp, b Tp + Tp), Tp % 16 == 0 (the encoder pads T; rows >= len hold finite
-// don't-care values, masked here). V^T columns are rows with bits 2 and 3 of the index swapped, so that the 8 keys whose
+// don't-care values, masked here) -- or, packed, the rows koffs / qoffs name (the encoder keeps them 16-aligned so that a
+// sequence's key tiles, hence its bits, do not depend on where it lies). V^T columns are rows with bits 2 and 3 of the
+// index swapped, so that the 8 keys whose
 // scores one lane's S^T accumulator registers hold ({0..3, 8..11} + 4 (lane >> 5) of a 16-key step) are one 16-B chunk.
 //
 // One workgroup = 8 waves = 256 queries of one (sequence, head); a wave owns 32 queries x d_k, a lane one query.
@@ -48,7 +50,12 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     const int q = blockIdx.x * 256 + wave * 32 + idx;
     const int qc = q < Tq ? q : Tq - 1;
     const int klen = p.klens[b];
-    const size_t row0 = (size_t)b * p.Tp;
+    // keys: rows [b Tp, b Tp + klen), or with koffs any rows [koffs[b], koffs[b] + klen): tiles then start at the 16-row
+    // group below the first key (the V^T column order is per 16-row group of the GLOBAL row index) and the kskip rows in
+    // front -- the tail of the neighbouring sequence, finite values -- are masked like the rows behind the last key
+    const int kstart = p.koffs ? p.koffs[b] : b * p.Tp;
+    const size_t row0 = (size_t)(kstart & ~15);
+    const int kskip = kstart & 15, kend = kskip + klen;
     const size_t qrow0 = p.qoffs ? (size_t)p.qoffs[b] : (size_t)b * Tq;
 
     // ---- Q planes: step s covers d in [16 s, 16 s + 16); half-wave h holds the 8 d's of chunk 2 s + h
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     };
 
     const float sscale = p.sscale_dev ? p.sscale * *p.sscale_dev : p.sscale;   // 2^-(e_q + e_k)
-    const int ntiles = (klen + KT - 1) / KT;
+    const int ntiles = (kend + KT - 1) / KT;
 
     // S^T tile (32 keys x 32 queries): small products into sa, hi*hi into sb (no dependent MFMA pairs)
 #define PF_QK(KT_, SA, SB)                                                                                            \
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
         float mx = -INFINITY;                                                                                         \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
             const int key = (K0_) + (r & 3) + 8 * (r >> 2) + 4 * hh;                                                  \
-            s[r] = key < klen ? (SA[r] + SB[r]) * sscale : -INFINITY;                                                 \
+            s[r] = (unsigned)(key - kskip) < (unsigned)klen ? (SA[r] + SB[r]) * sscale : -INFINITY;                   \
             mx = fmaxf(mx, s[r]);                                                                                     \
         }                                                                                                             \
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                       \
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
 }  // namespace
 
 int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
-    PF_REQUIRE(a.B > 0 && a.H > 0 && a.Tp > 0 && a.Tp % 16 == 0, "attention_f16x2: rows per sequence must be a positive multiple of 16");
+    PF_REQUIRE(a.B > 0 && a.H > 0 && (a.koffs || (a.Tp > 0 && a.Tp % 16 == 0)), "attention_f16x2: rows per sequence must be a positive multiple of 16");
     PF_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 8 == 0 && a.q_plane % 8 == 0 &&
                a.k_plane % 8 == 0 && a.vt_plane % 8 == 0 && a.o_plane % 8 == 0, "attention_f16x2: strides % 8");
     PF_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 && ((uintptr_t)a.O & 15) == 0,

@@ -233,7 +233,9 @@ int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* 
 // of the result (split3), `plane` elements apart; statistics are always fp32
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
                      int M, int D, int Dpad, float eps, hipStream_t stream, int out_mode = 0, int in_bf16 = 0,
-                     size_t plane = 0, float oscale = 1.f, int seq_out = 0, int seq_in = 0);
+                     size_t plane = 0, float oscale = 1.f, int seq_out = 0, int seq_in = 0, const int* out_map = nullptr);
+// out_map (device int32 [M]): row r is written to output row out_map[r] (negative: dropped) -- the packed row layout back
+// to the caller's [B, T] rows
 
 int launch_scale_cols(float* x, int ld, int M, int N, float sc, hipStream_t stream);
 // y[row] = x[row] - logsumexp(x[row]) over N columns (may run in place)
@@ -241,6 +243,9 @@ int launch_log_softmax(const float* x, int ldx, float* y, int ldy, int M, int N,
 // Tp > T: y is the padded layout [B, Tp, D] (rows t >= T zero)
 int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T, int D, float scale,
                         hipStream_t stream, int Tp = 0);
+// packed row layout: y[r] = x[map[r]] * scale + pe[map[r] % T] for the M rows of `map` (device int32; negative: zero row)
+int launch_scale_add_pe_rows(const float* x, const float* pe, float* y, const int* map, int M, int T, int D, float scale,
+                             hipStream_t stream);
 
 struct FsmnArgs {
     const float* in;  int ldin;   // [B*T, C] view (row stride ldin)
@@ -250,7 +255,7 @@ struct FsmnArgs {
     const int* lens;              // device int32 [B]: valid rows per sequence
     int B, T, C, K, left_pad;
     int in_bf16;                  // `in` holds bf16 (ldin in elements)
-    const int* offs;              // optional packed layout: sequence b occupies rows [offs[b], offs[b] + lens[b]) of in / R / out
+    const int* offs;              // optional packed layout (device int32 [B + 1]): sequence b occupies rows [offs[b], offs[b + 1]) of in / R / out, the first lens[b] of them valid
                                   // (T then only sizes the grid: >= max lens)
 };
 int launch_fsmn(const FsmnArgs& a, hipStream_t stream);
@@ -291,6 +296,9 @@ struct Attn2Args {
     int variant;                                          // kernel schedule (measurement hook), 0 = default
     const int* qoffs;                                     // optional packed queries: sequence b owns rows [qoffs[b], qoffs[b+1]) of
                                                           // Q / O (device int32 [B + 1]); Tq then only sizes the grid
+    const int* koffs;                                     // optional packed keys: sequence b's keys are rows [koffs[b], koffs[b] +
+                                                          // klens[b]) of K / V^T, ANY start row (tiles start at the 16-row group
+                                                          // below it, the keys of the neighbour in front are masked); Tp unused
 };
 int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream);
 

@@ -408,6 +408,13 @@ struct Encoder {
     // projection writes (k2 with 32 rows of slack per plane, vt2 rows of Mp + 64 columns: tiles may run past the last row)
     DevBuf q2, k2, vt2;
     int Tp = 0;                         // rows per sequence of the current forward (T, or T rounded up to 16 in mode 3)
+    // mode 3, packed row layout (pf_encoder_set_row_packing): sequence b occupies the slot [offs[b], offs[b + 1]) =
+    // min(len_b + pack_extra, T) rows rounded up to 16, one slot right after the other; the rows behind are not computed
+    int pack_extra = -1;                // < 0: off (every row of [B, T] is computed, as the reference does)
+    DevBuf offs_dev, map_dev;
+    std::vector<int32_t> h_offs, h_map;
+    const int* cur_offs = nullptr;      // device offsets of the forward in flight (nullptr: padded layout)
+    int cur_M = 0;                      // its row count (a multiple of 16)
 };
 
 // exponent e with bound * 2^e <= 2^15 (a factor 2 under fp16's 65504 for the roundings on the way)
@@ -483,7 +490,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
                          hipStream_t s, const EncChunkCtx* cc = nullptr) {
     // EncoderLayerSANM.forward (sanm/encoder.py:72-148), normalize_before, no concat_after
     const pf_encoder_config& c = e->cfg;
-    const int M = B * T, D = c.d_model, F = c.ffn_dim;
+    const int M = (e->cur_offs && !cc) ? e->cur_M : B * T, D = c.d_model, F = c.ffn_dim;
     float* xn = e->xn.as<float>();
     float* qkv = e->qkv.as<float>();
     float* mem = e->mem.as<float>();
@@ -624,11 +631,12 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         }
         FsmnArgs fa{};
         fa.in = vbuf; fa.ldin = D; fa.w = w.fsmn_w; fa.R = nullptr; fa.ldr = 0; fa.out = mem; fa.ldo = D;
-        fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size;
+        fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size; fa.offs = e->cur_offs;
         fa.left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
         if ((rc = fsmn(fa, s))) return rc;
         {
             Attn2Args aa{};
+            aa.qoffs = aa.koffs = e->cur_offs; aa.Tq = e->cur_offs ? T : 0;
             aa.Q = q2; aa.ldq = D; aa.q_plane = (size_t)(M + 32) * D; aa.K = k2; aa.ldk = D; aa.k_plane = (size_t)(M + 32) * D;
             aa.VT = vt2; aa.ldvt = ldvt; aa.vt_plane = (size_t)D * ldvt;
             aa.O = ctx2; aa.ldo = D; aa.o_plane = (size_t)M * D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tp = T;
@@ -1371,6 +1379,14 @@ int pf_encoder_set_precision(pf_encoder* eh, int32_t mode) {
     e->precision = mode;
     return 0;
 }
+/* f16x2 mode only: extra_rows >= 0 lays the sequences out back to back and computes min(len_b + extra_rows, T) rows of
+ * sequence b -- the rest of out_dev reads as zero; extra_rows < 0 (default) computes every row of [B, T] in the padded layout */
+int pf_encoder_set_row_packing(pf_encoder* eh, int32_t extra_rows) {
+    Encoder* e = reinterpret_cast<Encoder*>(eh);
+    PF_REQUIRE(e, "encoder_set_row_packing: null handle");
+    e->pack_extra = extra_rows < 0 ? -1 : (extra_rows > (1 << 30) ? (1 << 30) : extra_rows);
+    return 0;
+}
 int pf_encoder_missing(const pf_encoder* eh) {
     const Encoder* e = reinterpret_cast<const Encoder*>(eh);
     return e ? e->tt.missing() : -1;
@@ -1390,7 +1406,26 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
     const bool x2 = e->precision == 3 && c.d_model / c.n_heads == 128 && c.d_model % 256 == 0;
     const int Tp = x2 ? round_up(T, 16) : T;
     e->Tp = Tp;
-    const size_t M = (size_t)B * Tp;
+    // packed rows (opt-in, f16x2 mode, full-depth forward): sequence b keeps min(len_b + pack_extra, T) rows in a slot
+    // rounded up to 16 rows (attention_f16x2.hip's tile alignment: with every sequence starting on a 16-row boundary its key
+    // tiles are the ones of the padded layout, so the kept rows are BITWISE what the padded layout computes and a clip's result
+    // stays independent of its batch neighbours); slots lie back to back, nothing is computed for the padding behind them.
+    // Taken only when it saves rows.
+    e->cur_offs = nullptr;
+    int packed_rows = 0, max_rows = 0;
+    if (x2 && e->pack_extra >= 0 && run_blocks < 0) {
+        e->h_offs.assign((size_t)B + 1, 0);
+        for (int b = 0; b < B; ++b) {
+            const int rows = lens_host[b] + e->pack_extra < T ? lens_host[b] + e->pack_extra : T;
+            const int slot = round_up(rows, 16);
+            e->h_offs[b] = packed_rows;
+            packed_rows += slot;
+            if (slot > max_rows) max_rows = slot;
+        }
+        e->h_offs[B] = packed_rows;
+    }
+    const bool pack = packed_rows > 0 && (size_t)packed_rows < (size_t)B * Tp;
+    const size_t M = pack ? (size_t)packed_rows : (size_t)B * Tp;
     const int D = c.d_model, F = c.ffn_dim, Din = c.input_dim, Dpad = round_up(Din, 64);
     const int Fbuf = F > Din ? F : Din;
     if (e->precision == 3 && !x2) { set_error("encoder: the f16x2 mode needs d_model / n_heads == 128 and d_model % 256 == 0"); return -1; }
@@ -1467,8 +1502,37 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
     // it in norm1 (and as residual when input_dim == d_model) strictly before its own FFN overwrites that buffer.
     float* x0 = e->ffn.as<float>();
     const float scale = (float)sqrt((double)D);
-    if ((rc = launch_scale_add_pe(xs, pe, x0, B, T, Din, scale, s, Tp))) return rc;
     float* x = e->x.as<float>();
+    if (pack) {
+        // row r of the packed layout <- row h_map[r] of the caller's [B, T]; the up-to-15 rows that fill a slot are further
+        // padding rows of that sequence (zero input, masked as keys, FSMN memory 0, never returned)
+        e->h_map.assign(M, -1);
+        for (int b = 0; b < B; ++b) {
+            const int rows = lens_host[b] + e->pack_extra < T ? lens_host[b] + e->pack_extra : T;
+            for (int t = 0; t < rows; ++t) e->h_map[(size_t)e->h_offs[b] + t] = b * T + t;
+        }
+        if (e->offs_dev.ensure(sizeof(int32_t) * ((size_t)B + 1)) || e->map_dev.ensure(sizeof(int32_t) * M)) return -2;
+        PF_HIP_TRY(hipMemcpyAsync(e->offs_dev.p, e->h_offs.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, s));
+        PF_HIP_TRY(hipMemcpyAsync(e->map_dev.p, e->h_map.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
+        if ((rc = launch_scale_add_pe_rows(xs, pe, x0, e->map_dev.as<int>(), (int)M, T, Din, scale, s))) return rc;
+        e->cur_offs = e->offs_dev.as<int>();
+        e->cur_M = (int)M;
+        const int total = (int)e->layers.size();
+        for (int l = 0; l < total && !rc; ++l) {
+            rc = l == 0 ? encoder_block(e, e->layers[0], x0, Din, x, B, max_rows, s) : encoder_block(e, e->layers[l], x, D, x, B, max_rows, s);
+            if (!rc && c.tp_blocks > 0 && l + 1 == c.n_blocks)
+                rc = layernorm(x, D, e->tt.get("after_norm.weight"), e->tt.get("after_norm.bias"), x, D, (int)M, D, D, c.ln_eps, s);
+        }
+        e->cur_offs = nullptr;
+        if (rc) return rc;
+        // final LayerNorm scatters the rows back to [B, T]; the rows that were not computed read as zero
+        PF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * T * D, s));
+        ProfScope ps(PROF_LN, 8.0 * (double)packed_rows * D, s);
+        return launch_layernorm(x, D, e->tt.get(c.tp_blocks > 0 ? "tp_norm.weight" : "after_norm.weight"),
+                                e->tt.get(c.tp_blocks > 0 ? "tp_norm.bias" : "after_norm.bias"), out, D, (int)M, D, D, c.ln_eps, s,
+                                0, 0, 0, 1.f, 0, 0, e->map_dev.as<int>());
+    }
+    if ((rc = launch_scale_add_pe(xs, pe, x0, B, T, Din, scale, s, Tp))) return rc;
     const int total = (int)e->layers.size();
     const int nrun = run_blocks < 0 ? total : (run_blocks < total ? run_blocks : total);
     // [B, Tp, w] workspace rows -> the caller's [B, T, w]

@@ -34,11 +34,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         int ldy, int M, int D, int Dpad, float eps, int in_bf16,
-                                                        size_t plane, float oscale, int seq_out, int seq_in) {
+                                                        size_t plane, float oscale, int seq_out, int seq_in,
+                                                        const int* __restrict__ out_map) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int xrow = seq_out > 0 ? (row / seq_out) * seq_in + row % seq_out : row;
+    const int xr0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xr0 >= M) return;
+    const int row = out_map ? out_map[xr0] : xr0;        // output row (packed layout -> the caller's rows)
+    if (row < 0) return;
+    const int xrow = out_map ? xr0 : (seq_out > 0 ? (row / seq_out) * seq_in + row % seq_out : row);
     const int nchunk = D >> 2;
     float4 v[NV];
     float s = 0.f;
@@ -159,6 +162,28 @@ __global__ __launch_bounds__(256) void scale_add_pe_pad_kernel(const float* __re
     }
 }
 
+// packed row layout (one sequence after the other, no padding rows): row r takes the caller's row map[r] of [B, T, D]
+__global__ __launch_bounds__(256) void scale_add_pe_rows_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                                float* __restrict__ y, const int* __restrict__ map, int T,
+                                                                int D4, float scale, size_t total4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < total4; i += stride) {
+        const int r = (int)(i / D4), c = (int)(i % D4);
+        const int src = map[r];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src >= 0) {
+            const float4 a = reinterpret_cast<const float4*>(x)[(size_t)src * D4 + c];
+            const float4 p = reinterpret_cast<const float4*>(pe)[(size_t)(src % T) * D4 + c];
+            o.x = __fadd_rn(__fmul_rn(a.x, scale), p.x);
+            o.y = __fadd_rn(__fmul_rn(a.y, scale), p.y);
+            o.z = __fadd_rn(__fmul_rn(a.z, scale), p.z);
+            o.w = __fadd_rn(__fmul_rn(a.w, scale), p.w);
+        }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
 // FSMN memory block. Thread = 4 channels; block = (C/4 threads) x FSMN_TT consecutive frames of one sequence,
 // a register sliding window of KS + TT - 1 masked input rows (each input row is fetched once per block).
 constexpr int FSMN_TT = 8;
@@ -170,7 +195,10 @@ __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
     if (c4 * 4 >= p.C) return;
     const int len = p.lens[b];
     const size_t base = p.offs ? (size_t)p.offs[b] : (size_t)b * p.T;
-    if (p.offs && t0 >= len) return;                     // packed layout: rows past the sequence do not exist
+    // packed layout: sequence b owns rows [offs[b], offs[b + 1]) -- its len valid rows and possibly padding rows behind
+    // them (the encoder keeps the first one: the predictor reads it); rows past that do not exist
+    const int rows = p.offs ? p.offs[b + 1] - p.offs[b] : p.T;
+    if (t0 >= rows) return;
     float4 w[KS];
     {
         const float* wp = p.w + (size_t)c4 * 4 * KS;
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(256) void fsmn_kernel(FsmnArgs p) {
 #pragma unroll
     for (int i = 0; i < FSMN_TT; ++i) {
         const int t = t0 + i;
-        if (t < p.T && !(p.offs && t >= len)) {
+        if (t < rows) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < len) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -241,7 +269,7 @@ int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t st
 
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int M,
                      int D, int Dpad, float eps, hipStream_t stream, int out_mode, int in_bf16, size_t plane,
-                     float oscale, int seq_out, int seq_in) {
+                     float oscale, int seq_out, int seq_in, const int* out_map) {
     PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "layernorm: D must be a multiple of 4 and <= 2048");
     PF_REQUIRE(Dpad >= D && Dpad % 4 == 0 && Dpad <= 2048 && ldy >= Dpad, "layernorm: bad Dpad/ldy");
     PF_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "layernorm: strides must be multiples of 4");
@@ -250,10 +278,10 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     const int nv = ceil_div(Dpad / 4, 64);
 #define PF_LN(NV_)                                                                                                 \
     do {                                                                                                          \
-        if (out_mode == 3) hipLaunchKernelGGL((layernorm_kernel<NV_, 3>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in); \
-        else if (out_mode == 2) hipLaunchKernelGGL((layernorm_kernel<NV_, 2>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in); \
-        else if (out_mode == 1) hipLaunchKernelGGL((layernorm_kernel<NV_, 1>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in); \
-        else hipLaunchKernelGGL((layernorm_kernel<NV_, 0>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in);         \
+        if (out_mode == 3) hipLaunchKernelGGL((layernorm_kernel<NV_, 3>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in, out_map); \
+        else if (out_mode == 2) hipLaunchKernelGGL((layernorm_kernel<NV_, 2>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in, out_map); \
+        else if (out_mode == 1) hipLaunchKernelGGL((layernorm_kernel<NV_, 1>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in, out_map); \
+        else hipLaunchKernelGGL((layernorm_kernel<NV_, 0>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, M, D, Dpad, eps, in_bf16, plane, oscale, seq_out, seq_in, out_map);         \
     } while (0)
     if (nv <= 2) PF_LN(2);
     else if (nv <= 3) PF_LN(3);
@@ -313,6 +341,16 @@ int launch_scale_add_pe(const float* x, const float* pe, float* y, int B, int T,
     const size_t total4 = (size_t)B * T * (D / 4);
     const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(scale_add_pe_kernel, dim3(blocks), dim3(256), 0, stream, x, pe, y, T, D / 4, scale, total4);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_scale_add_pe_rows(const float* x, const float* pe, float* y, const int* map, int M, int T, int D, float scale,
+                             hipStream_t stream) {
+    PF_REQUIRE(M > 0 && T > 0 && D % 4 == 0 && map, "scale_add_pe_rows: bad arguments");
+    const size_t tot = (size_t)M * (D / 4);
+    const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+    hipLaunchKernelGGL(scale_add_pe_rows_kernel, dim3(nb), dim3(256), 0, stream, x, pe, y, map, T, D / 4, scale, tot);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -89,8 +89,16 @@ class Paraformer(nn.Module):
         return self
 
     # ------------------------------------------------------------------------------------------- device pipeline
-    def encode(self, speech: torch.Tensor, speech_lengths, **kwargs):
-        out, olens, _ = self.encoder(speech, speech_lengths)      # model.py:286-313
+    def encode(self, speech: torch.Tensor, speech_lengths, all_rows: bool = False, **kwargs):
+        """model.py:286-313. The reference's encoder computes every row of the padded batch; what reads its output here --
+        CifPredictorV2 (the conv reaches r_order rows past the last valid frame and the tail weight sits on row len,
+        cif_predictor.py:196-205,275-277), the decoder's cross-attention and the CTC head (rows < len) -- needs rows
+        <= len + r_order - 1 only, so in the f16x2 mode only those are computed (the rest of `out` is zero). `all_rows`, the
+        V3 predictor (its timestamp head runs over the whole padded tensor) and other encoders keep every row."""
+        if hasattr(self.encoder, "set_row_packing"):
+            v2_only = type(self.predictor).__name__ == "CifPredictorV2"
+            self.encoder.set_row_packing(max(1, int(self.predictor.r_order)) if (v2_only and not all_rows) else self.encoder.ALL_ROWS)
+        out, olens, _ = self.encoder(speech, speech_lengths)
         return out, olens
 
     def calc_predictor(self, encoder_out, encoder_out_lens):
@@ -101,7 +109,7 @@ class Paraformer(nn.Module):
         synchronisation inside is the CIF token count (it sizes the decoder, like the .item() at cif_predictor.py:311).
         `collect()` brings the ids to the host; a serving loop enqueues batch i+1 before collecting batch i, so the
         GPU never waits for the host-side post-processing."""
-        enc, olens = self.encode(speech, speech_lengths)
+        enc, olens = self.encode(speech, speech_lengths, all_rows=return_intermediate)
         embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
         tok = [int(round(v)) for v in token_num.tolist()]           # pre_token_length.round().long(), model.py:614
         ids = None
@@ -144,7 +152,7 @@ class Paraformer(nn.Module):
         row-wise log-softmax of the decoder scores and of the CTC head; the per-hypothesis bookkeeping runs on the host
         (funasr_amd/beam_search.py) per utterance like the reference's. -> dict(nbest=[[Hypothesis]], token_num, ...)"""
         from . import ops
-        enc, olens = self.encode(speech, speech_lengths)
+        enc, olens = self.encode(speech, speech_lengths, all_rows=return_intermediate)
         embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
         tok = [int(round(v)) for v in token_num.tolist()]
         B = enc.shape[0]

@@ -12,6 +12,8 @@ reference) and mirrored into library-owned HBM before the first forward.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -84,6 +86,16 @@ class _SANMEncoderBase(HipModule):
                        "pf_encoder_set_precision")
         return self
 
+    ALL_ROWS = 1 << 30
+
+    def set_row_packing(self, extra_rows: Optional[int] = ALL_ROWS):
+        """f16x2 mode: how many rows of each sequence the encoder computes. `extra_rows` = k: the len_b valid rows plus k of the
+        padding rows behind them (capped at T), sequences laid out back to back -- what a consumer that reads only a prefix
+        needs (CTC: 0, CIF predictor: 1); the other rows of the output are zero. ALL_ROWS (default): every row of [B, T],
+        still without alignment padding between sequences. None: the padded layout (every row, 16-row aligned sequences)."""
+        self._row_packing = extra_rows
+        return self
+
     def _make_config(self):
         return _lib.pf_encoder_config(self._input_size, self._output_size, self.attention_heads, self.linear_units,
                                       self.num_blocks, self.tp_blocks, self.kernel_size, self.sanm_shfit, self.ln_eps)
@@ -97,6 +109,10 @@ class _SANMEncoderBase(HipModule):
         lib, h = self._ensure_handle()
         _lib.check(lib.pf_encoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[getattr(self, "_precision", "fp32")]),
                    "pf_encoder_set_precision")
+        pack = getattr(self, "_row_packing", self.ALL_ROWS)
+        if os.environ.get("PF_ENC_NO_PACK"):                 # A/B switch for measurements
+            pack = None
+        _lib.check(lib.pf_encoder_set_row_packing(h, -1 if pack is None else int(pack)), "pf_encoder_set_row_packing")
         dev = self._handle_device
         xs = xs_pad.to(device=dev, dtype=torch.float32).contiguous()
         B, T, Din = xs.shape

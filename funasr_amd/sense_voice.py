@@ -72,6 +72,9 @@ class SenseVoiceSmall(nn.Module):
     def recognize_features(self, speech: torch.Tensor, speech_lengths, language: str = "auto",
                            textnorm: str = "woitn", return_intermediate: bool = False):
         x, lens = self.prepend_queries(speech, speech_lengths, language, textnorm)
+        if hasattr(self.encoder, "set_row_packing"):
+            # the CTC head reads rows < len only (model.py:1014): in the f16x2 mode the padding rows are not computed at all
+            self.encoder.set_row_packing(self.encoder.ALL_ROWS if return_intermediate else 0)
         enc, olens = self.encoder(x, lens)
         frame_ids = self.ctc.argmax(enc).cpu()                       # one D2H copy for the batch
         ids: List[List[int]] = []

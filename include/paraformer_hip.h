@@ -120,6 +120,14 @@ int pf_encoder_missing(const pf_encoder* e);
  * Meets the same parity bars as mode 0 (tests/test_parity_gpu.py, fixture f32_mode); intended for large batches
  * (256-row tiles). */
 int pf_encoder_set_precision(pf_encoder* e, int32_t mode);
+/* Row packing (mode 3 only; other modes ignore it). The reference runs the encoder over every row of the padded batch
+ * [B, T] (sanm/encoder.py:428-470: masks, not skipping); its consumers read only a prefix of each sequence: the CTC head
+ * rows < len (sense_voice/model.py:1014), the CIF predictor rows <= len (the conv at the last valid frame and the tail
+ * frame, cif_predictor.py:196-205,275-277), the decoder's cross-attention rows < len. extra_rows >= 0: sequence b gets
+ * min(len_b + extra_rows, T) rows, laid out back to back (no alignment padding), identical in value to the same rows of
+ * the padded computation up to the summation order of the attention's key tiles; the remaining rows of out_dev are
+ * zero. extra_rows >= T keeps every row. extra_rows < 0 (default): padded layout, every row computed. */
+int pf_encoder_set_row_packing(pf_encoder* e, int32_t extra_rows);
 /* xs_dev: [B, T, input_dim] (un-scaled features, exactly what SANMEncoder.forward receives), lens_host: [B],
  * pe_dev: [T, input_dim] sinusoidal table (embedding.py:396-420; NULL = library computes it with libm),
  * out_dev: [B, T, d_model]. run_blocks < 0 runs everything incl. the final norm(s); run_blocks = k >= 0 stops

@@ -127,6 +127,65 @@ def test_encoder_full_depth_vs_oracle(cuda, f32_mode):
     assert err < 1e-3, err
 
 
+def test_encoder_row_packing_is_bitwise_the_padded_layout(cuda):
+    """f16x2 mode, pf_encoder_set_row_packing: computing only a prefix of every sequence (len + k rows) in 16-row slots laid
+    back to back gives BITWISE the rows the padded layout computes (every slot starts on the attention's tile boundary, so a
+    sequence's key tiles do not move), zeros behind them; SANMEncoder and the SenseVoice encoder (its mid after_norm)."""
+    from funasr_amd.sanm_encoder import SenseVoiceEncoderSmall
+    g = torch.Generator().manual_seed(5)
+    lens = torch.tensor([97, 40, 83, 1, 16, 33, 96, 15], dtype=torch.int32)
+    B, T = lens.numel(), int(lens.max())
+    xs = torch.randn(B, T, 560, generator=g) * 0.7
+    for b in range(B):
+        xs[b, lens[b]:] = 0
+    pcfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=3)["encoder"]
+    scfg = synth.tiny(synth.SENSEVOICE_SMALL, enc_blocks=2, tp_blocks=2)
+    ssd = synth.sensevoice_state_dict(scfg, seed=4)
+    encs = [_encoder(pcfg, synth.encoder_state_dict(pcfg, seed=9), cuda),
+            _encoder(scfg["encoder"], {k[len("encoder."):]: v for k, v in ssd.items() if k.startswith("encoder.")}, cuda,
+                     cls=SenseVoiceEncoderSmall)]
+    for enc in encs:
+        enc.set_precision("f16x2")
+        full = enc.set_row_packing(None)(xs.to(cuda), lens)[0].cpu()
+        assert torch.equal(enc.set_row_packing(enc.ALL_ROWS)(xs.to(cuda), lens)[0].cpu(), full)
+        for k in (0, 1, 3):
+            out = enc.set_row_packing(k)(xs.to(cuda), lens)[0].cpu()
+            for b in range(B):
+                n = min(int(lens[b]) + k, T)
+                assert torch.equal(out[b, :n], full[b, :n]), (k, b)
+                assert not out[b, n:].any(), (k, b)
+        # one sequence alone (nothing to save: padded layout) == the same sequence inside the packed batch
+        enc.set_row_packing(1)
+        alone = enc(xs[1:2].to(cuda), lens[1:2])[0].cpu()
+        assert torch.equal(alone[0, : int(lens[1]) + 1], full[1, : int(lens[1]) + 1])
+
+
+def test_paraformer_prefix_rows_give_the_all_rows_result(cuda):
+    """`recognize_features` computes len + 1 encoder rows per clip in the f16x2 mode (what CifPredictorV2 and the decoder
+    read); token ids, counts and CIF peaks equal the all-rows run (`return_intermediate=True`) and the CPU oracle's."""
+    from funasr_amd.paraformer import Paraformer
+    from oracle import paraformer_oracle as O
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=3, dec_blocks=2, vocab=8404)
+    sd = synth.paraformer_state_dict(cfg, seed=21, cif_bias=0.5)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(cuda).set_precision("f16x2")
+    g = torch.Generator().manual_seed(8)
+    lens = torch.tensor([120, 77, 119, 30, 64, 5], dtype=torch.int32)
+    feats = torch.randn(lens.numel(), 120, 560, generator=g) * 0.7
+    for b in range(lens.numel()):
+        feats[b, lens[b]:] = 0
+    packed = model.recognize_features(feats.to(cuda), lens)
+    full = model.recognize_features(feats.to(cuda), lens, return_intermediate=True)
+    assert packed["token_num"] == full["token_num"] and packed["raw_ids"] == full["raw_ids"]
+    ref = O.paraformer_greedy(feats, lens, sd, cfg)
+    assert packed["token_num"] == ref["token_num"].tolist()
+    top2 = torch.topk(ref["logits"], 2, dim=-1).values
+    for i, (a, b) in enumerate(zip(ref["raw_ids"], packed["raw_ids"])):
+        for pos, (x, y) in enumerate(zip(a, b)):       # random-init output layer: only near-ties of the oracle itself may differ
+            assert x == y or float(top2[i, pos, 0] - top2[i, pos, 1]) < 1e-4, (i, pos, x, y)
+
+
 # --------------------------------------------------------------------------------------------------- predictor
 def test_cif_bit_exact_given_reference_alphas(cuda):
     from funasr_amd import ops

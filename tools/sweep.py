@@ -33,9 +33,10 @@ def main():
     ap.add_argument("--clips", type=int, default=2000)
     ap.add_argument("--batch-seconds", type=float, default=0.0, help="padded audio seconds per batch (the reference's batch_size_s "
                     "policy); 0 = use --batch-rows")
-    ap.add_argument("--batch-rows", type=int, default=32768, help="padded encoder rows per batch: B * ceil16(frames of the longest "
-                    "clip) <= this. 32768 rows = 128 row tiles of 256 = exactly one round of 256 x 256 blocks for the N = 512 "
-                    "GEMMs on 256 CUs (64 x 30 s clips is the same amount of work)")
+    ap.add_argument("--batch-rows", type=int, default=32768, help="encoder rows per batch (the rows the encoder really computes: "
+                    "16-row slots of frames + 1 in the f16x2 mode, B * ceil16(longest) otherwise). 32768 rows = 128 row tiles "
+                    "of 256 = exactly one round of 256 x 256 blocks for the N = 512 GEMMs on 256 CUs (64 x 30 s clips is the "
+                    "same amount of work)")
     ap.add_argument("--model", default="paraformer", choices=["paraformer", "sensevoice"])
     ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16", "bf16x3", "f16x2"])
     ap.add_argument("--dump", default=None, help="rank 0 writes the hypotheses in CORPUS order to this JSON file")
@@ -81,17 +82,26 @@ def main():
     clips = {i: pool[i % 16].roll(31 * i)[: lens[i]] for i in mine}
     # batches by padded-rows (or padded-seconds) budget
     batches, cur = [], []
-    def over_budget(n_clips, longest):
-        if args.batch_seconds > 0:
-            return n_clips * longest / 16000.0 > args.batch_seconds
-        return n_clips * ((fe.num_frames(longest) + 15) // 16 * 16) > args.batch_rows
+    # rows the encoder computes for one clip: its frames (+ SenseVoice's 4 query frames) plus the one padding row the CIF
+    # predictor reads, in a 16-row slot (pf_encoder_set_row_packing); the f16x2 encoder lays the slots back to back
+    q = 4 if args.model == "sensevoice" else 0
+    extra = 0 if args.model == "sensevoice" else 1
+    packed = args.precision == "f16x2" and not os.environ.get("PF_ENC_NO_PACK")
 
+    def slot(n_samples, longest):
+        t, tmax = fe.num_frames(n_samples) + q, fe.num_frames(longest) + q
+        return (min(t + extra, tmax) + 15) // 16 * 16 if packed else (tmax + 15) // 16 * 16
+
+    cur_rows = 0
     for i in mine:
         longest = lens[cur[0]] if cur else lens[i]
-        if cur and over_budget(len(cur) + 1, longest):
+        over = ((len(cur) + 1) * longest / 16000.0 > args.batch_seconds) if args.batch_seconds > 0 else \
+            (cur_rows + slot(lens[i], longest) > args.batch_rows)
+        if cur and over:
             batches.append(cur)
-            cur = []
+            cur, cur_rows, longest = [], 0, lens[i]
         cur.append(i)
+        cur_rows += slot(lens[i], longest)
     if cur:
         batches.append(cur)
 
