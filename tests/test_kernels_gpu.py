@@ -46,6 +46,27 @@ def test_gemm_f32_matches_fp64(cuda, gemm_path, M, N, K):
     assert _rel(out2, ref2) < 2e-6
 
 
+def test_small_m_gemm_rows_do_not_depend_on_m(cuda):
+    """gemm_skinny.hip: every variant (1 / 2 / 4 row tiles, 16 waves x 1 slice or 4 waves x 4 slices) sums the 16 K slices in
+    one fixed order, so a row's result is bitwise the same whatever M is -- a stream's bits do not depend on how many streams
+    run beside it."""
+    from funasr_amd import _lib, ops
+    lib = _lib.load()
+    lib.pf_set_skinny_max_m(1 << 30)
+    try:
+        g = torch.Generator().manual_seed(11)
+        for N, K in ((1536, 576), (512, 2048), (130, 96)):
+            a = torch.randn(300, K, generator=g)
+            w = torch.randn(N, K, generator=g)
+            bias = torch.randn(N, generator=g)
+            full = ops.gemm(a.to(cuda), w.to(cuda), bias.to(cuda)).cpu()
+            for M in (1, 15, 16, 20, 33, 64, 65, 200):
+                part = ops.gemm(a[:M].contiguous().to(cuda), w.to(cuda), bias.to(cuda)).cpu()
+                assert torch.equal(part, full[:M]), (N, K, M)
+    finally:
+        lib.pf_set_skinny_max_m(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (500, 1536, 576), (333, 2048, 512), (1000, 512, 2048), (70, 130, 192)])
 def test_gemm_bf16_operands_fp32_accumulate(cuda, M, N, K):
     """bf16-operand mode: against fp64 on the SAME bf16-rounded operands only the fp32 accumulation differs."""
