@@ -292,6 +292,129 @@ __global__ __launch_bounds__(256, 2) void attention_f32_dma_kernel(AttnArgs p) {
     }
 }
 
+// ---- few-query variant: the streaming step attends 15 window rows (or <= 24 token rows) of one stream over a few dozen
+// keys, one launch in a chain of dependent few-microsecond launches. The 128-query kernels above spend ~4 us of dependent
+// v_mfma_f32_32x32x2_f32 per 32-key tile on one SIMD whatever the number of queries; here one workgroup = 16 queries of one
+// (stream, head), its four waves split the KEYS (16 per wave and 64-key round), every operand goes global -> registers in
+// one round of loads (no LDS staging, no barrier before the end), v_mfma_f32_16x16x4_f32:
+//   S^T[key][q] = K Q^T : A = K (row = key, k = d), B = Q^T -- a lane's 16-B loads along d feed four MFMAs (the MFMA k
+//                 index is only a pairing); the lane then holds S^T[4 kq + r][q = lane & 15];
+//   O^T[d][q]  += V^T P : k slot kq of step s pairs key 4 kq + s on both operands, so B is the lane's own register s.
+// Each wave keeps online-softmax statistics over its keys; the four partial results meet in LDS and are combined in a
+// fixed order (flash-decoding merge). Exact fp32 products and accumulation, libm expf.
+__global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
+    __shared__ float red_o[4][16][DK + 1];
+    __shared__ float red_m[4][16], red_l[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 16;
+    const int n1 = p.K2 ? p.n1_dev[b * p.n1_stride] : p.klens[b];
+    const int klen = p.K2 ? n1 + p.n2 : n1;
+
+    float4 qf[8];
+    {
+        int qrow = q0 + i16;
+        qrow = qrow < p.Tq ? qrow : p.Tq - 1;
+        const float* qp = p.Q + ((size_t)b * p.Tq + qrow) * p.ldq + head * DK + kq * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + 16 * j);
+            qf[j] = make_float4(t.x * p.scale, t.y * p.scale, t.z * p.scale, t.w * p.scale);   // q * d_k^-0.5 like the reference
+        }
+    }
+    // row pointers of key `key` (clamped to the last valid one: those scores are masked) in the one or two sources
+    auto krow = [&](int key) -> const float* {
+        key = key < klen ? key : klen - 1;
+        return key < n1 ? p.K + ((size_t)b * p.Tk + key) * p.ldk : p.K2 + ((size_t)b * p.T2 + (key - n1)) * p.ldk2;
+    };
+    auto vrow = [&](int key) -> const float* {
+        key = key < klen ? key : klen - 1;
+        return key < n1 ? p.V + ((size_t)b * p.Tk + key) * p.ldv : p.V2 + ((size_t)b * p.T2 + (key - n1)) * p.ldv2;
+    };
+
+    floatx4 o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < klen; k0 += 64) {
+        const int kw0 = k0 + 16 * wave;
+        if (kw0 >= klen) break;                           // (wave-uniform) no key of this round for this wave
+        float4 kf[8];
+        {
+            const float* kp = krow(kw0 + i16) + head * DK + kq * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[j] = *reinterpret_cast<const float4*>(kp + 16 * j);
+        }
+        float vf[4][8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* vp = vrow(kw0 + 4 * kq + s) + head * DK + i16;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) vf[s][dt] = vp[16 * dt];
+        }
+        floatx4 sc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].x, qf[j].x, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].y, qf[j].y, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].z, qf[j].z, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j].w, qf[j].w, sc, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (kw0 + 4 * kq + r >= klen) sc[r] = -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));           // finite: key kw0 is valid
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first round
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = expf(sc[r] - m_new);
+            psum += sc[r];
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s][dt], sc[s], o[dt], 0, 0, 0);
+    }
+
+    // lane holds O^T[d = 16 dt + 4 kq + r][q = i16] of its wave's keys
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red_o[wave][i16][16 * dt + 4 * kq + r] = o[dt][r];
+    if (kq == 0) { red_m[wave][i16] = m_run; red_l[wave][i16] = l_run; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = tid + 256 * e;
+        const int qq = t >> 7, d = t & 127;
+        if (q0 + qq >= p.Tq) continue;
+        float m = fmaxf(fmaxf(red_m[0][qq], red_m[1][qq]), fmaxf(red_m[2][qq], red_m[3][qq]));
+        float l = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {                     // fixed order; a wave without keys has m = -inf, weight 0
+            const float wgt = expf(red_m[w][qq] - m);
+            l += red_l[w][qq] * wgt;
+            acc += red_o[w][qq][d] * wgt;
+        }
+        p.O[((size_t)b * p.Tq + q0 + qq) * p.ldo + head * DK + d] = acc / l;
+    }
+}
+
 }  // namespace
 
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
@@ -299,6 +422,11 @@ int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0, "attention: strides % 4");
     PF_REQUIRE(a.O || a.O3, "attention: null output");
     if (a.O3) PF_REQUIRE(a.o_plane % 4 == 0 && ((uintptr_t)a.O3 & 7) == 0, "attention: plane output alignment");
+    if (a.few_q && a.Tq <= 32 && !a.O3) {
+        hipLaunchKernelGGL(attention_f32_fewq_kernel, dim3(ceil_div(a.Tq, 16), a.H, a.B), dim3(256), 0, stream, a);
+        PF_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     dim3 grid(ceil_div(a.Tq, 128), a.H, a.B);
     // the K/V ring form of the streaming step (two sources, a few dozen keys) keeps the register-staged loader; the
     // offline form (one source) takes the LDS-DMA double-buffered kernel. Both do the same arithmetic in the same order.

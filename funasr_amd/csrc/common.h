@@ -275,6 +275,9 @@ struct AttnArgs {
     const int* n1_dev; int n1_stride;   // device int32, element b * n1_stride (stride 0 = one value for all)
     // fp32 kernels only: write the three bf16 planes of the result (split3; same ldo, `o_plane` elements apart) instead of O
     unsigned short* O3; size_t o_plane;
+    // launch_attention_f32 only: the caller is the streaming step (Tq <= 32 rows per stream, a few dozen keys): take the
+    // few-query kernel. Set by the CALLER, never derived from the batch (a result must not depend on its neighbours)
+    int few_q;
 };
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
 // bf16 Q/K/V in, bf16 O out (strides in elements), fp32 softmax statistics and accumulators

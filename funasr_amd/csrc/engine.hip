@@ -304,7 +304,14 @@ static int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3 = f
     ProfScope ps(PROF_ATTN, flops, s);
     if (dk != 128) return launch_attention_small(a, dk, s);      // CT-Transformer sized heads
     static const bool no_x3 = getenv("PF_ATTN_F32") != nullptr;     // A/B switch for measurements
-    return (x3 && !no_x3) ? launch_attention_split3(a, s) : launch_attention_f32(a, s);
+    if (x3 && !no_x3) return launch_attention_split3(a, s);
+    static const bool no_fewq = getenv("PF_ATTN_NO_FEWQ") != nullptr;   // A/B switch for measurements
+    if ((g_stream_mode || g_skinny_max_m > 0) && !no_fewq) {             // by caller (streaming step; g_skinny_max_m: test hook)
+        AttnArgs f = a;
+        f.few_q = 1;
+        return launch_attention_f32(f, s);
+    }
+    return launch_attention_f32(a, s);
 }
 
 // ================================================================================================ frontend

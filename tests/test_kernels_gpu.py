@@ -227,6 +227,36 @@ def test_attention_f32(cuda, B, Tq, Tk, lens):
     assert e3 < 2e-5 and e3 < 3 * e32 + 1e-6, (e3, e32)
 
 
+@pytest.mark.parametrize("B,Tq,Tk,lens", [(1, 15, 55, [55]), (3, 15, 64, [64, 1, 17]), (2, 20, 130, [130, 65]), (2, 1, 16, [16, 5]),
+                                          (4, 32, 33, [33, 32, 16, 2])])
+def test_attention_f32_few_query_kernel(cuda, B, Tq, Tk, lens):
+    """attention_f32_fewq_kernel (the streaming step's window / token attention: keys split over the waves, flash-decoding
+    merge) against fp64 softmax attention, and against the 128-query kernel."""
+    from funasr_amd import _lib, ops
+    H, dk = 4, 128
+    g = torch.Generator().manual_seed(Tq * 131 + Tk)
+    q = torch.randn(B, Tq, H * dk, generator=g)
+    kv = torch.randn(B, Tk, 2 * H * dk, generator=g)
+    klens = torch.tensor(lens, dtype=torch.int32)
+    scale = dk ** -0.5
+    qh = q.double().view(B, Tq, H, dk).transpose(1, 2) * scale
+    kh = kv[:, :, :H * dk].double().reshape(B, Tk, H, dk).transpose(1, 2)
+    vh = kv[:, :, H * dk:].double().reshape(B, Tk, H, dk).transpose(1, 2)
+    m = (torch.arange(Tk)[None, :] >= klens[:, None])[:, None, None, :]
+    p = torch.softmax((qh @ kh.transpose(-1, -2)).masked_fill(m, float("-inf")), -1).masked_fill(m, 0.0)
+    ref = (p @ vh).transpose(1, 2).reshape(B, Tq, H * dk)
+    kvd = kv.to(cuda)
+    tile = ops.attention(q.to(cuda), kvd[:, :, :H * dk], kvd[:, :, H * dk:], klens.to(cuda), H, scale).cpu()
+    lib = _lib.load()
+    lib.pf_set_skinny_max_m(1 << 30)                        # the test hook that selects the streaming step's kernels
+    try:
+        few = ops.attention(q.to(cuda), kvd[:, :, :H * dk], kvd[:, :, H * dk:], klens.to(cuda), H, scale).cpu()
+    finally:
+        lib.pf_set_skinny_max_m(0)
+    assert (few.double() - ref).abs().max().item() < 2e-5
+    assert (few - tile).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("B,Tq,Tk,lens", [(2, 100, 100, [100, 37]), (1, 500, 500, [500]), (3, 40, 300, [300, 1, 129])])
 def test_attention_bf16(cuda, B, Tq, Tk, lens):
     """bf16-operand attention against fp64 softmax attention on the same bf16-rounded Q/K/V: the differences are the
