@@ -278,7 +278,13 @@ struct AttnArgs {
     // launch_attention_f32 only: the caller is the streaming step (Tq <= 32 rows per stream, a few dozen keys): take the
     // few-query kernel. Set by the CALLER, never derived from the batch (a result must not depend on its neighbours)
     int few_q;
+    // few-query kernel with ONE workgroup per (stream, head) (Tq <= 16) and a second source only: after its keys are read,
+    // the workgroup appends rows [app_r0, app_r0 + app_rows) of (K2, V2) -- its head's columns -- to the ring (K, V; Tk =
+    // capacity) at write pointer app_wp[b * app_wp_stride], like ring_append_kernel (stream.hip); app_gate[b] < 1 skips
+    int app_rows, app_r0; const int* app_wp; int app_wp_stride; const int* app_gate;
 };
+// true when launch_attention_f32 will take the few-query kernel AND perform the append itself
+inline bool attention_fuses_append(const AttnArgs& a) { return a.few_q && a.Tq <= 16 && !a.O3 && a.K2 && a.app_rows > 0; }
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
 // bf16 Q/K/V in, bf16 O out (strides in elements), fp32 softmax statistics and accumulators
 int launch_attention_bf16(const AttnArgs& a, hipStream_t stream);

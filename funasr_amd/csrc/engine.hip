@@ -300,18 +300,22 @@ static int fsmn(const FsmnArgs& a, hipStream_t s) {
     ProfScope ps(PROF_FSMN, (a.R ? 12.0 : 8.0) * a.B * (double)a.T * a.C, s);
     return launch_fsmn(a, s);
 }
-static int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3 = false, int dk = 128) {
+// `appended` (optional): the caller filled the app_* fields; on return it says whether the kernel did the ring append
+// itself (few-query kernel, one workgroup per (stream, head)) -- otherwise the caller launches ring_append_kernel
+static int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3 = false, int dk = 128, bool* appended = nullptr) {
     ProfScope ps(PROF_ATTN, flops, s);
-    if (dk != 128) return launch_attention_small(a, dk, s);      // CT-Transformer sized heads
+    if (appended) *appended = false;
+    AttnArgs f = a;
+    f.few_q = 0;
+    if (dk != 128) { f.app_rows = 0; return launch_attention_small(f, dk, s); }      // CT-Transformer sized heads
     static const bool no_x3 = getenv("PF_ATTN_F32") != nullptr;     // A/B switch for measurements
-    if (x3 && !no_x3) return launch_attention_split3(a, s);
+    if (x3 && !no_x3) { f.app_rows = 0; return launch_attention_split3(f, s); }
     static const bool no_fewq = getenv("PF_ATTN_NO_FEWQ") != nullptr;   // A/B switch for measurements
-    if ((g_stream_mode || g_skinny_max_m > 0) && !no_fewq) {             // by caller (streaming step; g_skinny_max_m: test hook)
-        AttnArgs f = a;
-        f.few_q = 1;
-        return launch_attention_f32(f, s);
-    }
-    return launch_attention_f32(a, s);
+    static const bool no_fuse = getenv("PF_ATTN_NO_APPEND") != nullptr;
+    f.few_q = ((g_stream_mode || g_skinny_max_m > 0) && !no_fewq) ? 1 : 0;   // by caller (streaming step; g_skinny_max_m: test hook)
+    if (!appended || no_fuse || !attention_fuses_append(f)) f.app_rows = 0;
+    else *appended = true;
+    return launch_attention_f32(f, s);
 }
 
 // ================================================================================================ frontend
@@ -683,8 +687,12 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         aa.K2 = qkv + D; aa.ldk2 = 3 * D; aa.V2 = qkv + 2 * D; aa.ldv2 = 3 * D; aa.T2 = T; aa.n2 = T;
         aa.n1_dev = &cc->st->enc_valid; aa.n1_stride = 0;
     }
-    if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s, false, D / c.n_heads))) return rc;
+    bool appended = false;
     if (cc && cc->cap > 0 && cc->append_rows > 0) {
+        aa.app_rows = cc->append_rows; aa.app_r0 = 0; aa.app_wp = &cc->st->enc_wp; aa.app_wp_stride = 0; aa.app_gate = nullptr;
+    }
+    if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s, false, D / c.n_heads, &appended))) return rc;
+    if (cc && cc->cap > 0 && cc->append_rows > 0 && !appended) {
         RingAppendArgs ra{};
         ra.src = qkv + D; ra.ldsrc = 3 * D; ra.src_T = T; ra.r0 = 0; ra.rows = cc->append_rows; ra.cols = 2 * D;
         ra.ring = cc->ring; ra.cap = cc->cap; ra.S = B; ra.st = cc->st;
@@ -1153,8 +1161,12 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             at.K = d->kv.as<float>(); at.ldk = 2 * D; at.V = d->kv.as<float>() + D; at.ldv = 2 * D; at.Tk = W;
             at.klens = st->lensW.as<int>();
         }
-        if ((rc = attention(at, 4.0 * S * (double)Nmax * W * D, s))) return rc;
+        bool appended = false;
         if (st->dec_cap > 0) {
+            at.app_rows = W; at.app_r0 = 0; at.app_wp = st->dec_wp.as<int>(); at.app_wp_stride = 1; at.app_gate = st->n_fired.as<int>();
+        }
+        if ((rc = attention(at, 4.0 * S * (double)Nmax * W * D, s, false, 128, &appended))) return rc;
+        if (st->dec_cap > 0 && !appended) {
             RingAppendArgs ra{};
             ra.src = d->kv.as<float>(); ra.ldsrc = 2 * D; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
             ra.ring = st->dec_ring.as<float>() + l * dring_layer; ra.cap = st->dec_cap; ra.S = S; ra.st = nullptr;
