@@ -1,6 +1,6 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes for HBM traffic of the
-# bench workload. Outputs under gpurun_out/prof_$TAG; tools/summarize_prof.py condenses them into profiles/.
+# Run on the GPU box (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes for HBM traffic and the
+# matrix-pipe busy cycles of the bench workload. Outputs under gpurun_out/prof_$TAG; tools/summarize_prof.py condenses them into profiles/.
 # usage: tools/profile.sh TAG [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
@@ -15,6 +15,8 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O
 echo "pmc_fetch rc=$?" >> "$OUT/pmc_fetch.log"
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/pmc_write.log" 2>&1
 echo "pmc_write rc=$?" >> "$OUT/pmc_write.log"
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -o bench -- $BENCH > "$OUT/pmc_mfma.log" 2>&1
+echo "pmc_mfma rc=$?" >> "$OUT/pmc_mfma.log"
 cd - > /dev/null
 python tools/summarize_prof.py "$OUT" "$TAG" > "$OUT/summary.md" 2>&1
 # keep the merged-back payload small: per-dispatch traces can be tens of MB

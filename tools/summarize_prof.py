@@ -78,6 +78,19 @@ def main():
         print(f"| {k} | {n} | {fr:.3f} | {wr:.3f} |")
         if k in fetch and k in write:
             traffic[k] = dict(launches=n, read_bytes_per_launch=fr * 1e6, write_bytes_per_launch=wr * 1e6)
+    # matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (32 per v_mfma_*_32x32x16);
+    # against duration x 1024 SIMDs x the 2.4 GHz peak clock it is the fraction of the dense-MFMA peak the kernel used
+    mfma = pmc_table(root, "pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    if mfma:
+        avg_ns = {short(r.get("Name", "?")): float(r.get("AverageNs", 0)) for r in rows}
+        print("\n## matrix pipe (separate --pmc pass: SQ_VALU_MFMA_BUSY_CYCLES, summed over the SIMDs)\n")
+        print("| kernel | launches | MFMA busy cycles / launch | avg us (stats pass) | busy / (1024 SIMDs x 2.4 GHz x duration) |")
+        print("|---|---|---|---|---|")
+        for k in sorted(mfma, key=lambda k: -mfma[k][0])[:12]:
+            per = mfma[k][0] / max(mfma[k][1], 1)
+            ns = avg_ns.get(k, 0.0)
+            frac = per / (1024 * 2.4 * ns) if ns > 0 else float("nan")
+            print(f"| {k} | {mfma[k][1]} | {per:.3e} | {ns / 1e3:.1f} | {frac:.3f} |")
     import json
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_traffic.json")
     try:
