@@ -410,7 +410,16 @@ class AutoModel:
             if kwargs["device"] == "cpu":
                 bs = 0
             decoded: List[dict] = []
-            for beg, end in self.plan_vad_batches(durs, bs, threshold_ms):
+            plan = self.plan_vad_batches(durs, bs, threshold_ms)
+            if kwargs.get("batch_size_rows") and kwargs["device"] != "cpu":
+                # MI355X-native alternative to batch_size_s: a budget of encoder ROWS per batch (funasr_amd/dp.py; 32 768 =
+                # one round of GEMM blocks over the chip). frames = LFR frames of the segment, 60 ms each
+                from . import dp
+                fe = kwargs.get("frontend")
+                frames = [fe.num_frames(int(d * 16)) if hasattr(fe, "num_frames") else max(1, int(d) // 60) for d in durs]
+                plan = dp.plan_batches_by_rows(frames, int(kwargs["batch_size_rows"]), extra_rows=1,
+                                               packed=getattr(getattr(self.model, "encoder", None), "_precision", "fp32") == "f16x2")
+            for beg, end in plan:
                 idx = order[beg:end]
                 # slice_padding_audio_samples (funasr/utils/vad_utils.py:28-51): 16 samples per millisecond
                 clips = [speech[int(segments[j][0] * 16): min(int(segments[j][1] * 16), len(speech))] for j in idx]

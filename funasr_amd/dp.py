@@ -23,6 +23,41 @@ def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:
     return order[rank::world]
 
 
+def encoder_rows(frames: int, longest: int, extra_rows: int = 1, packed: bool = True, align: int = 16) -> int:
+    """Rows the f16x2 encoder computes for a clip of `frames` frames in a batch whose longest clip has `longest`: with row
+    packing (`pf_encoder_set_row_packing`) its own frames plus `extra_rows` padding rows in an `align`-row slot, without it
+    the longest clip's frames rounded up -- every clip of a padded batch costs the same."""
+    up = lambda n: (n + align - 1) // align * align
+    return up(min(frames + extra_rows, longest)) if packed else up(longest)
+
+
+def plan_batches_by_rows(frames: Sequence[int], budget_rows: int, extra_rows: int = 1, packed: bool = True,
+                         align: int = 16) -> List[tuple]:
+    """Cut a LENGTH-SORTED list of clips (frame counts, ascending or descending) into consecutive batches [begin, end) whose
+    encoder rows stay within `budget_rows` (a batch always takes at least one clip). The unit of work on this GPU is the row,
+    not the padded second: 32 768 rows are one full round of 256 x 256 GEMM blocks over 256 CUs, and a batch that
+    spills a few blocks into another round pays for the whole round."""
+    plan, beg, rows, longest = [], 0, 0, 0
+    for i, f in enumerate(frames):
+        f = int(f)
+        new_longest = max(longest, f)
+        if packed:
+            new_rows = rows + encoder_rows(f, new_longest, extra_rows, True, align)
+            if new_longest != longest:           # a longer clip lifts the cap min(frames + extra, longest) of the earlier ones
+                new_rows = sum(encoder_rows(int(g), new_longest, extra_rows, True, align) for g in frames[beg:i + 1])
+        else:
+            new_rows = (i + 1 - beg) * encoder_rows(f, new_longest, extra_rows, False, align)
+        if i > beg and new_rows > budget_rows:
+            plan.append((beg, i))
+            beg, longest = i, f
+            rows = encoder_rows(f, f, extra_rows, packed, align)
+            continue
+        rows, longest = new_rows, new_longest
+    if len(frames) > beg:
+        plan.append((beg, len(frames)))
+    return plan
+
+
 def pack_arena(params: Sequence[torch.Tensor]) -> torch.Tensor:
     """Flatten parameters into one contiguous fp32 arena (same device as the first parameter)."""
     return torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])

@@ -100,3 +100,29 @@ def test_world_size_2_gloo_broadcast_shard_gather():
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, "ok"), (1, "ok")], res
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_row_budget_batch_planner():
+    """dp.plan_batches_by_rows: consecutive batches over a length-sorted list, every batch within the row budget (or a single
+    clip), packed slots (frames + extra in 16-row slots, capped by the batch's longest clip) or the padded product."""
+    import random
+    from funasr_amd import dp
+    rng = random.Random(3)
+    frames = sorted((rng.randint(20, 250) for _ in range(400)), reverse=True)
+    for order in (frames, frames[::-1]):
+        for packed in (True, False):
+            for budget in (64, 1000, 32768):
+                plan = dp.plan_batches_by_rows(order, budget, extra_rows=1, packed=packed)
+                assert plan[0][0] == 0 and plan[-1][1] == len(order)
+                assert all(a[1] == b[0] and a[0] < a[1] for a, b in zip(plan, plan[1:]))
+                for b, e in plan:
+                    longest = max(order[b:e])
+                    rows = sum(dp.encoder_rows(f, longest, 1, packed) for f in order[b:e])
+                    assert rows <= budget or e - b == 1
+                    if e < len(order):             # greedy: the next clip would not have fitted
+                        longest2 = max(longest, order[e])
+                        rows2 = sum(dp.encoder_rows(f, longest2, 1, packed) for f in order[b:e + 1])
+                        assert rows2 > budget
+    assert dp.encoder_rows(83, 245, 1, True) == 96 and dp.encoder_rows(83, 245, 1, False) == 256
+    assert dp.encoder_rows(245, 245, 1, True) == 256            # the longest clip has no padding row behind it
+    assert dp.plan_batches_by_rows([], 100) == []

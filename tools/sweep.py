@@ -80,30 +80,24 @@ def main():
     # a small pool of base clips, cut / rolled per utterance (cheap to generate, distinct content)
     pool = [synth.speech_like(int(14.7 * 16000) + 1, seed=1000 + i) for i in range(16)]
     clips = {i: pool[i % 16].roll(31 * i)[: lens[i]] for i in mine}
-    # batches by padded-rows (or padded-seconds) budget
-    batches, cur = [], []
-    # rows the encoder computes for one clip: its frames (+ SenseVoice's 4 query frames) plus the one padding row the CIF
-    # predictor reads, in a 16-row slot (pf_encoder_set_row_packing); the f16x2 encoder lays the slots back to back
+    # batches by encoder-rows (or padded-seconds) budget. Rows the encoder computes for one clip: its frames (+ SenseVoice's 4
+    # query frames) plus the one padding row the CIF predictor reads, in a 16-row slot (pf_encoder_set_row_packing)
     q = 4 if args.model == "sensevoice" else 0
     extra = 0 if args.model == "sensevoice" else 1
     packed = args.precision == "f16x2" and not os.environ.get("PF_ENC_NO_PACK")
-
-    def slot(n_samples, longest):
-        t, tmax = fe.num_frames(n_samples) + q, fe.num_frames(longest) + q
-        return (min(t + extra, tmax) + 15) // 16 * 16 if packed else (tmax + 15) // 16 * 16
-
-    cur_rows = 0
-    for i in mine:
-        longest = lens[cur[0]] if cur else lens[i]
-        over = ((len(cur) + 1) * longest / 16000.0 > args.batch_seconds) if args.batch_seconds > 0 else \
-            (cur_rows + slot(lens[i], longest) > args.batch_rows)
-        if cur and over:
+    if args.batch_seconds > 0:
+        batches, cur = [], []
+        for i in mine:
+            longest = lens[cur[0]] if cur else lens[i]
+            if cur and (len(cur) + 1) * longest / 16000.0 > args.batch_seconds:
+                batches.append(cur)
+                cur = []
+            cur.append(i)
+        if cur:
             batches.append(cur)
-            cur, cur_rows, longest = [], 0, lens[i]
-        cur.append(i)
-        cur_rows += slot(lens[i], longest)
-    if cur:
-        batches.append(cur)
+    else:
+        plan = dp.plan_batches_by_rows([fe.num_frames(lens[i]) + q for i in mine], args.batch_rows, extra_rows=extra, packed=packed)
+        batches = [list(mine[b:e]) for b, e in plan]
 
     # The loaded corpus lives in one pinned host arena (what a data-loader worker hands over); a batch is built ON THE
     # DEVICE: a zeroed [B, n_max] tensor (pad_sequence semantics, load_utils.py:413) receives one asynchronous H2D copy
