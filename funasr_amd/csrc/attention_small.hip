@@ -19,6 +19,14 @@ __global__ __launch_bounds__(256) void attention_small_kernel(AttnArgs p, int dk
     const int head = blockIdx.y, b = blockIdx.z;
     if (q >= p.Tq) return;
     const int klen = p.klens[b];
+    // which keys this query may see (key padding; SANMVadEncoder: causal, or the VAD corner)
+    int kend = klen, corner = 0x7fffffff;
+    if (p.mask_mode == 1) kend = klen < q + 1 ? klen : q + 1;
+    else if (p.mask_mode == 2) {
+        const int vp = p.vad_pos[b];
+        if (vp > 0 && vp < p.Tk && q < vp - 1) corner = vp;
+    }
+    auto visible = [&](int key) { return key < kend && key < corner; };
     const float* qp = p.Q + ((size_t)b * p.Tq + q) * p.ldq + head * dk;
     const float* kb = p.K + (size_t)b * p.Tk * p.ldk + head * dk;
     const float* vb = p.V + (size_t)b * p.Tk * p.ldv + head * dk;
@@ -36,7 +44,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(AttnArgs p, int dk
     for (int j = 0; j < SMALL_MAX_KEYS_PER_LANE; ++j) {
         const int key = lane + 64 * j;
         float acc = -INFINITY;
-        if (key < klen) {
+        if (visible(key)) {
             const float* kp = kb + (size_t)key * p.ldk;
             acc = 0.f;
 #pragma unroll
@@ -55,7 +63,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(AttnArgs p, int dk
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < SMALL_MAX_KEYS_PER_LANE; ++j) {
-        s[j] = (lane + 64 * j < klen) ? expf(s[j] - mx) : 0.f;
+        s[j] = visible(lane + 64 * j) ? expf(s[j] - mx) : 0.f;
         sum += s[j];
     }
     sum = wave_sum(sum);
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(256) void attention_small_kernel(AttnArgs p, int dk
 #pragma unroll
         for (int j = 0; j < SMALL_MAX_KEYS_PER_LANE; ++j) {
             const int key = lane + 64 * j;
-            if (key < klen) {
+            if (visible(key)) {
                 const float4 t = *reinterpret_cast<const float4*>(vb + (size_t)key * p.ldv + d0);
                 acc.x = fmaf(s[j], t.x, acc.x); acc.y = fmaf(s[j], t.y, acc.y);
                 acc.z = fmaf(s[j], t.z, acc.z); acc.w = fmaf(s[j], t.w, acc.w);

@@ -282,6 +282,10 @@ struct AttnArgs {
     // the workgroup appends rows [app_r0, app_r0 + app_rows) of (K2, V2) -- its head's columns -- to the ring (K, V; Tk =
     // capacity) at write pointer app_wp[b * app_wp_stride], like ring_append_kernel (stream.hip); app_gate[b] < 1 skips
     int app_rows, app_r0; const int* app_wp; int app_wp_stride; const int* app_gate;
+    // launch_attention_small only (SANMVadEncoder, ct_transformer_streaming/encoder.py:372-418): 0 = key padding only,
+    // 1 = also causal (key <= query), 2 = also the VAD corner (transformer/utils/mask.py:38-52): queries before
+    // vad_pos[b] - 1 do not see keys from vad_pos[b] on (when 0 < vad_pos[b] < Tk)
+    int mask_mode; const int* vad_pos;
 };
 // true when launch_attention_f32 will take the few-query kernel AND perform the append itself
 inline bool attention_fuses_append(const AttnArgs& a) { return a.few_q && a.Tq <= 16 && !a.O3 && a.K2 && a.app_rows > 0; }

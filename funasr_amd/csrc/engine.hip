@@ -426,6 +426,11 @@ struct Encoder {
     std::vector<int32_t> h_offs, h_map;
     const int* cur_offs = nullptr;      // device offsets of the forward in flight (nullptr: padded layout)
     int cur_M = 0;                      // its row count (a multiple of 16)
+    // SANMVadEncoder (pf_encoder_set_vad_mask): every block's attention is causal, the last block's uses the VAD corner
+    bool vad_mask = false;
+    std::vector<int32_t> h_vad;
+    DevBuf vad_dev;
+    int cur_mask_mode = 0;              // mask mode of the block being enqueued (AttnArgs.mask_mode)
 };
 
 // exponent e with bound * 2^e <= 2^15 (a factor 2 under fp16's 65504 for the roundings on the way)
@@ -681,6 +686,10 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
     aa.Q = qkv; aa.ldq = 3 * D; aa.K = qkv + D; aa.ldk = 3 * D; aa.V = qkv + 2 * D; aa.ldv = 3 * D;
     aa.O = ctx; aa.ldo = D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
     aa.scale = powf((float)(D / c.n_heads), -0.5f);
+    if (e->cur_mask_mode && !cc) {
+        if (D / c.n_heads > 64) { set_error("encoder: the causal / VAD masks are built for heads of d_k <= 64 (attention_small.hip)"); return -1; }
+        aa.mask_mode = e->cur_mask_mode; aa.vad_pos = e->vad_dev.as<int>();
+    }
     if (cc && cc->cap > 0) {
         // keys = [ring rows 0 .. enc_valid) | this window's K/V], no padding mask (forward_chunk passes mask=None)
         aa.K = cc->ring; aa.ldk = 2 * D; aa.V = cc->ring + D; aa.ldv = 2 * D; aa.Tk = cc->cap;
@@ -1406,6 +1415,16 @@ int pf_encoder_set_row_packing(pf_encoder* eh, int32_t extra_rows) {
     e->pack_extra = extra_rows < 0 ? -1 : (extra_rows > (1 << 30) ? (1 << 30) : extra_rows);
     return 0;
 }
+/* SANMVadEncoder.forward (ct_transformer_streaming/encoder.py:355-430): vad_pos_host != NULL makes every block's attention
+ * causal and the last block's use the VAD corner mask of vad_pos_host[b] (B values, consumed by the next forwards with that
+ * batch size); NULL switches the masks off. fp32 mode, heads of d_k <= 64. */
+int pf_encoder_set_vad_mask(pf_encoder* eh, const int32_t* vad_pos_host, int32_t B) {
+    Encoder* e = reinterpret_cast<Encoder*>(eh);
+    PF_REQUIRE(e && (vad_pos_host == nullptr || B > 0), "encoder_set_vad_mask: bad argument");
+    e->vad_mask = vad_pos_host != nullptr;
+    e->h_vad.assign(vad_pos_host ? vad_pos_host : nullptr, vad_pos_host ? vad_pos_host + B : nullptr);
+    return 0;
+}
 int pf_encoder_missing(const pf_encoder* eh) {
     const Encoder* e = reinterpret_cast<const Encoder*>(eh);
     return e ? e->tt.missing() : -1;
@@ -1513,6 +1532,11 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         e->ctx.ensure(sizeof(float) * M * D) || e->ffn.ensure(sizeof(float) * M * Fbuf))
         return -2;
     if ((rc = upload_lens(e->lens, lens_host, B, s))) return rc;
+    e->cur_mask_mode = 0;
+    if (e->vad_mask) {
+        PF_REQUIRE(e->precision == 0 && (int)e->h_vad.size() == B, "encoder: the VAD-masked encoder runs in the fp32 mode with one vad position per sequence");
+        if ((rc = upload_lens(e->vad_dev, e->h_vad.data(), B, s))) return rc;
+    }
     if (!pe) {
         if ((rc = encoder_default_pe(e, T, s))) return rc;
         pe = e->pe.as<float>();
@@ -1562,8 +1586,11 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
     };
     if (nrun == 0) return unpad_copy(x0, Din);
     for (int l = 0; l < nrun; ++l) {
+        // SANMVadEncoder: `encoders0` and all but the last of `encoders` are causal, the last one takes the VAD corner
+        e->cur_mask_mode = e->vad_mask ? ((l >= 1 && l + 1 == total) ? 2 : 1) : 0;
         if (l == 0) rc = encoder_block(e, e->layers[0], x0, Din, x, B, Tp, s);
         else rc = encoder_block(e, e->layers[l], x, D, x, B, Tp, s);
+        e->cur_mask_mode = 0;
         if (rc) return rc;
         if (c.tp_blocks > 0 && l + 1 == c.n_blocks && (run_blocks < 0 || nrun > c.n_blocks)) {
             // SenseVoice: after_norm sits between `encoders` and `tp_encoders` (sense_voice/model.py:645-652)

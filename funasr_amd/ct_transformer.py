@@ -214,3 +214,116 @@ class CTTransformer(torch.nn.Module):
 
     def forward(self, *a, **k):  # pragma: no cover
         raise NotImplementedError("training forward() is out of scope; use inference() / punc_forward()")
+
+
+# ------------------------------------------------------------------------------------------- streaming (realtime) model
+def assemble_streaming(text: str, cache: dict, encode: Callable[[List[str]], Sequence[int]],
+                       predict: Callable[[np.ndarray, int], np.ndarray], punc_list: List[str], sentence_end_id: int,
+                       split_size: int = 20, carry_limit: int = 200):
+    """One call of CTTransformerStreaming.inference (ct_transformer_streaming/model.py:78-219) with the network as a
+    callable `predict(ids[int32, L], vad_pos) -> punc ids[L]`: the words carried over from the previous calls (`cache
+    ["pre_text"]`, everything after the last sentence end) are put in front of the new text, the whole is decoded in
+    mini-sentences like the offline model, and only what belongs to the new text is returned -- without a trailing mark,
+    which the next call may still revise. -> (text, punc ids of the LAST mini-sentence as the reference returns them)."""
+    if len(cache) == 0:
+        cache["pre_text"] = []
+    pre = cache["pre_text"]
+    text = "".join(pre) + " " + text
+    tokens = split_words(text)
+    token_ids = np.asarray(encode(tokens))
+    minis = split_to_mini_sentence(tokens, split_size)
+    minis_id = split_to_mini_sentence(token_ids, split_size)
+    assert len(minis) == len(minis_id)
+    carry: List[str] = []
+    carry_id = np.array([], dtype="int32")
+    marks_all: List[str] = []
+    words_all: List[str] = []
+    puncs = np.array([], dtype=np.int64)
+    last = len(minis) - 1
+    for mi in range(len(minis)):
+        sent = carry + list(minis[mi])
+        ids = np.concatenate((carry_id, minis_id[mi]), axis=0)
+        puncs = np.array(predict(ids, len(pre)), dtype=np.int64).reshape(-1)
+        assert puncs.shape[0] == len(sent)
+        if mi < last:
+            end, comma = -1, -1
+            for i in range(len(puncs) - 2, 1, -1):
+                if punc_list[puncs[i]] in _SENT_END:
+                    end = i
+                    break
+                if comma < 0 and punc_list[puncs[i]] == "，":
+                    comma = i
+            if end < 0 and len(sent) > carry_limit and comma >= 0:
+                end = comma                                      # too long without a sentence end: cut at a comma
+                puncs[end] = sentence_end_id
+            carry, carry_id = sent[end + 1:], ids[end + 1:]
+            sent, puncs = sent[: end + 1], puncs[: end + 1]
+        marks_all += [punc_list[int(x)] for x in puncs]
+        words_all += sent
+    assert len(marks_all) == len(words_all)
+    pieces, marks_out, skipped = [], [], 0
+    for i in range(len(words_all)):
+        if i > 0 and len(words_all[i][0].encode()) == 1 and len(words_all[i - 1][-1].encode()) == 1:
+            words_all[i] = " " + words_all[i]
+        if skipped < len(pre):                                   # the carried words were returned by an earlier call
+            skipped += 1
+        else:
+            pieces.append(words_all[i])
+        if skipped >= len(pre):
+            marks_out.append(marks_all[i])
+            if marks_all[i] != "_":
+                pieces.append(marks_all[i])
+    out = "".join(pieces)
+    end = -1
+    for i in range(len(marks_all) - 2, 1, -1):
+        if marks_all[i] in _SENT_END:
+            end = i
+            break
+    cache["pre_text"] = words_all[end + 1:]
+    if out and out[-1] in punc_list:                             # (the reference indexes out[-1] unguarded: IndexError on "")
+        out = out[:-1]
+        marks_out[-1] = "_"
+    return out, puncs
+
+
+@tables.register("model_classes", "CTTransformerStreaming")
+class CTTransformerStreaming(CTTransformer):
+    """`CTTransformerStreaming` (funasr/models/ct_transformer_streaming/model.py:33-219): the realtime punctuation model of
+    the streaming pipelines. Same parameters as CTTransformer over a `SANMVadEncoder` (causal self-attention, VAD corner in
+    the last block: sanm_encoder.py); `inference(..., cache=<dict kept by the caller>)` carries the unfinished sentence
+    from call to call."""
+
+    def with_vad(self) -> bool:
+        return True
+
+    def punc_forward(self, text: torch.Tensor, text_lengths: torch.Tensor, vad_indexes: torch.Tensor = None, **kwargs):
+        """text int [B, L], vad_indexes int [B] -> (logits [B, L, n_punc], None)   (model.py:59-72)"""
+        from . import ops
+        dev = self.embed.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("CTTransformerStreaming runs only on an AMD GPU through libparaformer_hip.so (no CPU fallback)")
+        ids = text.to(device=dev, dtype=torch.int32).contiguous()
+        x = ops.gather_rows(self.embed.weight.detach().to(torch.float32), ids.view(-1)).view(ids.shape[0], ids.shape[1], -1)
+        h, _, _ = self.encoder(x, text_lengths, vad_indexes=vad_indexes)
+        y = ops.gemm(h.reshape(-1, h.shape[-1]).contiguous(), self.decoder.weight.detach().float().contiguous(),
+                     self.decoder.bias.detach().float().contiguous())
+        return y.view(h.shape[0], h.shape[1], -1), None
+
+    def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, cache: dict = None,
+                  **kwargs):
+        if cache is None:
+            cache = {}
+        assert len(data_in) == 1
+
+        def predict(ids: np.ndarray, vad_pos: int) -> np.ndarray:
+            t = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64))[None]
+            y, _ = self.punc_forward(t, torch.tensor([t.shape[1]], dtype=torch.int32), torch.tensor([vad_pos], dtype=torch.int32))
+            return y.view(-1, y.shape[-1]).argmax(dim=1).cpu().numpy()
+
+        out, marks = assemble_streaming(data_in[0], cache, tokenizer.encode, predict, self.punc_list, self.sentence_end_id,
+                                        split_size=kwargs.get("split_size", 20))
+        punc_array = torch.from_numpy(np.asarray(marks, dtype=np.int64))
+        if punc_array.numel() == 1:
+            punc_array = punc_array.view(1, 1)                   # the reference does not squeeze a single prediction (:140-141)
+        return [{"key": key[0], "text": out, "punc_array": punc_array}], {}
+

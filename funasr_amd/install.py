@@ -4,7 +4,7 @@
 `funasr_amd.install()` after `import funasr` therefore re-points "WavFrontend", "SANMEncoder", "CifPredictorV2" / "V3",
 "ParaformerSANMDecoder", "Paraformer", "BiCifParaformer", "SeacoParaformer", "ContextualParaformer" (+ its decoder),
 "ParaformerStreaming", "SenseVoiceSmall",
-"FsmnVADStreaming", "CTTransformer" (and their encoders / frontends) at the gfx950 implementations,
+"FsmnVADStreaming", "CTTransformer", "CTTransformerStreaming" (and their encoders / frontends) at the gfx950 implementations,
 and `funasr.AutoModel(model=<dir>, device="cuda")` builds them by name (funasr/auto/auto_model.py:591-646) with no
 other change. Without the `funasr` package pass any object with a compatible `register(table, key)` method.
 """
@@ -15,7 +15,7 @@ def hip_classes():
     """(table, key, class) triples of everything this package provides: every class the package's own registry
     (funasr_amd.register.tables) holds after its modules are imported -- frontends, encoders, predictors (V2, V3), decoder,
     the model classes (Paraformer, BiCifParaformer, SeacoParaformer, ParaformerStreaming, SenseVoiceSmall,
-    FsmnVADStreaming, CTTransformer) and the tokenizers."""
+    FsmnVADStreaming, CTTransformer, CTTransformerStreaming) and the tokenizers."""
     from . import (bicif_paraformer, cif_predictor, contextual_paraformer, ct_transformer, fsmn_vad, paraformer, paraformer_decoder,  # noqa: F401
                    paraformer_streaming, sanm_encoder, seaco_paraformer, sense_voice, tokenizer, wav_frontend)
     from .register import TABLE_NAMES, tables as own

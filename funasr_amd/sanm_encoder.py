@@ -152,6 +152,29 @@ class SANMEncoder(_SANMEncoderBase):
         return out, olens, None
 
 
+@tables.register("encoder_classes", "SANMVadEncoder")
+class SANMVadEncoder(SANMEncoder):
+    """`SANMVadEncoder` (funasr/models/ct_transformer_streaming/encoder.py:175-430, the encoder of CTTransformerStreaming):
+    the SAN-M encoder with the same parameters and state_dict keys, whose self-attention is causal in every block and masked
+    by the VAD corner (transformer/utils/mask.py:38-52) in the last one. `forward(xs_pad, ilens, vad_indexes)`. fp32 mode."""
+
+    def forward(self, xs_pad: torch.Tensor, ilens, vad_indexes=None, prev_states=None, ctc=None):
+        if getattr(self, "_precision", "fp32") != "fp32":
+            raise NotImplementedError("SANMVadEncoder(HIP): the masked attention is built for the fp32 mode")
+        B = xs_pad.shape[0]
+        vad = [0] * B if vad_indexes is None else [int(v) for v in torch.as_tensor(vad_indexes).reshape(-1).tolist()]
+        if len(vad) != B:
+            raise ValueError(f"vad_indexes holds {len(vad)} values for a batch of {B}")
+        lib, h = self._ensure_handle()
+        arr = (_lib.C.c_int32 * B)(*vad)
+        _lib.check(lib.pf_encoder_set_vad_mask(h, arr, B), "pf_encoder_set_vad_mask")
+        try:
+            out, olens = self._run(xs_pad, ilens)
+        finally:
+            _lib.check(lib.pf_encoder_set_vad_mask(h, None, 0), "pf_encoder_set_vad_mask")
+        return out, olens, None
+
+
 @tables.register("encoder_classes", "SenseVoiceEncoderSmall")
 class SenseVoiceEncoderSmall(_SANMEncoderBase):
     def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4, linear_units: int = 2048,

@@ -128,6 +128,11 @@ int pf_encoder_set_precision(pf_encoder* e, int32_t mode);
  * the padded computation up to the summation order of the attention's key tiles; the remaining rows of out_dev are
  * zero. extra_rows >= T keeps every row. extra_rows < 0 (default): padded layout, every row computed. */
 int pf_encoder_set_row_packing(pf_encoder* e, int32_t extra_rows);
+/* SANMVadEncoder (funasr/models/ct_transformer_streaming/encoder.py:175-430, the encoder of CTTransformerStreaming): the
+ * SAN-M encoder whose self-attention is causal in every block and, in the last one, masked by the VAD corner of
+ * transformer/utils/mask.py:38-52 (queries before vad_pos - 1 do not see keys from vad_pos on). vad_pos_host: one value
+ * per sequence of the following forwards (copied), NULL switches the masks off again. fp32 mode, heads of d_k <= 64. */
+int pf_encoder_set_vad_mask(pf_encoder* e, const int32_t* vad_pos_host, int32_t B);
 /* xs_dev: [B, T, input_dim] (un-scaled features, exactly what SANMEncoder.forward receives), lens_host: [B],
  * pe_dev: [T, input_dim] sinusoidal table (embedding.py:396-420; NULL = library computes it with libm),
  * out_dev: [B, T, d_model]. run_blocks < 0 runs everything incl. the final norm(s); run_blocks = k >= 0 stops

@@ -30,7 +30,8 @@ def test_install_into_protocol_object():
     assert not any(tb == "tokenizer_classes" for tb, _ in done)          # reference tokenizers are reused as-is
     for pair in (("model_classes", "SeacoParaformer"), ("model_classes", "BiCifParaformer"), ("predictor_classes", "CifPredictorV3"),
                  ("model_classes", "ParaformerStreaming"), ("model_classes", "FsmnVADStreaming"), ("encoder_classes", "FSMN"),
-                 ("model_classes", "CTTransformer"), ("frontend_classes", "WavFrontendOnline"), ("model_classes", "SenseVoiceSmall")):
+                 ("model_classes", "CTTransformer"), ("frontend_classes", "WavFrontendOnline"), ("model_classes", "SenseVoiceSmall"),
+                 ("model_classes", "CTTransformerStreaming"), ("encoder_classes", "SANMVadEncoder"), ("model_classes", "ContextualParaformer")):
         assert pair in done, pair
 
 
