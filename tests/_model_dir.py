@@ -108,17 +108,18 @@ def make_vad_model_dir(path: str, encoder_sd: dict) -> None:
     write_mvn(os.path.join(path, "am.mvn"), torch.full((400,), -8.0), torch.full((400,), 0.25))
 
 
-def make_punc_model_dir(path: str, vocab: list, enc_cfg: dict, sd: dict, punc_list: list) -> None:
-    """CT-Transformer model directory in the hub layout (config.yaml naming CTTransformer / SANMEncoder / CharTokenizer,
-    model.pt, tokens.json)"""
+def make_punc_model_dir(path: str, vocab: list, enc_cfg: dict, sd: dict, punc_list: list, model: str = "CTTransformer",
+                        encoder: str = "SANMEncoder") -> None:
+    """CT-Transformer model directory in the hub layout (config.yaml naming CTTransformer / SANMEncoder / CharTokenizer --
+    or the realtime pair CTTransformerStreaming / SANMVadEncoder --, model.pt, tokens.json)"""
     import json
     os.makedirs(path, exist_ok=True)
     conf = {
-        "model": "CTTransformer",
+        "model": model,
         "model_conf": {"ignore_id": 0, "embed_unit": enc_cfg["input_size"], "att_unit": enc_cfg["output_size"],
                        "dropout_rate": 0.1, "punc_list": list(punc_list), "punc_weight": [1.0] * len(punc_list),
                        "sentence_end_id": 3},
-        "encoder": "SANMEncoder",
+        "encoder": encoder,
         "encoder_conf": dict(enc_cfg, input_layer="pe"),
         "tokenizer": "CharTokenizer",
         "tokenizer_conf": {"unk_symbol": "<unk>"},

@@ -89,3 +89,36 @@ def test_network_and_sessions_on_the_gpu_equal_reference(cuda):
     y, _ = plain.punc_forward(ids, lens)
     ref = punc_oracle.punc_forward(ids, lens, sd, enc)
     assert (y[0, : c["lens"][0]].cpu() - ref[0, : c["lens"][0]]).abs().max().item() < 5e-5
+
+
+def _dir(tmp_path):
+    from oracle import punc_oracle
+    from tests._model_dir import make_punc_model_dir
+    g, vocab, enc = _gold()
+    sd = punc_oracle.synthetic_state_dict(len(vocab), enc, seed=int(g["seed"]))
+    d = str(tmp_path / "punc_rt")
+    make_punc_model_dir(d, vocab, enc, sd, punc_oracle.PUNC_LIST, model="CTTransformerStreaming", encoder="SANMVadEncoder")
+    return d, g
+
+
+def test_realtime_punc_model_directory_builds(tmp_path):
+    from funasr_amd.auto_model import AutoModel
+    d, _ = _dir(tmp_path)
+    am = AutoModel(model=d, device="cpu")
+    assert type(am.model).__name__ == "CTTransformerStreaming" and type(am.model.encoder).__name__ == "SANMVadEncoder"
+    assert am.model.with_vad()
+
+
+@pytest.mark.gpu
+def test_automodel_realtime_punctuation_session_equals_reference(cuda, tmp_path):
+    """AutoModel(model=<realtime punc dir>).generate(input=piece, cache=session) call after call == the reference class's
+    own session on the same weights"""
+    from funasr_amd.auto_model import AutoModel
+    d, g = _dir(tmp_path)
+    am = AutoModel(model=d, device="cuda:0")
+    for calls in json.loads(str(g["e2e"])):
+        cache = {}
+        for c in calls:
+            r = am.generate(input=c["text"], cache=cache)
+            assert len(r) == 1 and r[0]["text"] == c["out"] and r[0]["punc_array"].reshape(-1).tolist() == c["punc_array"]
+            assert cache["pre_text"] == c["pre_text"]
