@@ -51,6 +51,26 @@ class CTC(HipModule):
         _, logits = self._run(hs_pad, True)
         return ops.log_softmax(logits.contiguous(), inplace=True)          # row kernel, in place over the GEMM's output
 
-    def argmax(self, hs_pad):
+    def argmax(self, hs_pad, ban_ids=None):
+        """frame-wise arg-max over the vocabulary, fused into the projection GEMM. `ban_ids`: classes that must not win (the
+        reference writes -inf into their log-probabilities, sense_voice/model.py:1004-1005) -- here a sibling head with the
+        same weights and a -inf bias for them, so the fused route stays a single launch."""
+        if ban_ids:
+            return self._banned_head(tuple(sorted(int(i) for i in ban_ids)))._run(hs_pad, False)[0]
         ids, _ = self._run(hs_pad, False)
         return ids
+
+    def _banned_head(self, ban: tuple) -> "CTC":
+        cache = self.__dict__.setdefault("_ban_heads", {})
+        key = (ban, self.ctc_lo.weight.data_ptr(), self.ctc_lo.weight._version, self.ctc_lo.bias._version)
+        if cache.get("key") != key:                              # weights moved or changed: rebuild
+            head = CTC(self.odim, self.eprojs)
+            with torch.no_grad():
+                bias = self.ctc_lo.bias.detach().clone()
+                bias[list(ban)] = float("-inf")
+            head.load_state_dict({"ctc_lo.weight": self.ctc_lo.weight.detach(), "ctc_lo.bias": bias})
+            head = head.to(self.ctc_lo.weight.device)
+            cache.clear()
+            cache.update(key=key, head=head)
+        cache["head"].set_precision(getattr(self, "_precision", "fp32"))
+        return cache["head"]

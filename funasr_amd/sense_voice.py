@@ -4,8 +4,8 @@ Host-side mirror of `SenseVoiceSmall` (funasr/models/sense_voice/model.py:658-10
 for the CTC-greedy inference path: same constructor keywords, state_dict layout (encoder.*, embed.weight,
 ctc.ctc_lo.*), the four query frames [language, event, emotion, textnorm] placed in front of the speech features
 (:971-995) and `inference(...) -> (results, meta_data)`. The [B, T, 25055] log-softmax is never materialised: the
-arg-max is fused into the CTC projection GEMM; `ban_emo_unk` and `output_timestamp` (forced alignment) fall outside
-the hot path and raise.
+arg-max is fused into the CTC projection GEMM (`ban_emo_unk`: a -inf bias for <|EMO_UNKNOWN|> on a sibling head, same
+single launch); `output_timestamp` (CTC forced alignment, out of scope per SURVEY 2) raises.
 """
 from __future__ import annotations
 
@@ -41,6 +41,7 @@ class SenseVoiceSmall(nn.Module):
         self.eos = eos if eos is not None else vocab_size - 1
         self.lid_dict = {"auto": 0, "zh": 3, "en": 4, "yue": 7, "ja": 11, "ko": 12, "nospeech": 13}
         self.textnorm_dict = {"withitn": 14, "woitn": 15}
+        self.emo_dict = {"unk": 25009, "happy": 25001, "sad": 25002, "angry": 25003, "neutral": 25004}   # model.py:738-744
         self.embed = nn.Embedding(7 + len(self.lid_dict) + len(self.textnorm_dict), input_size)
         self.embed.weight.requires_grad_(False)
         if kwargs.get("precision"):                      # model_conf: {precision: fp32 | bf16x3 | bf16}
@@ -70,13 +71,13 @@ class SenseVoiceSmall(nn.Module):
         return torch.cat((q.to(speech.dtype), speech), dim=1).contiguous(), lens
 
     def recognize_features(self, speech: torch.Tensor, speech_lengths, language: str = "auto",
-                           textnorm: str = "woitn", return_intermediate: bool = False):
+                           textnorm: str = "woitn", return_intermediate: bool = False, ban_ids=None):
         x, lens = self.prepend_queries(speech, speech_lengths, language, textnorm)
         if hasattr(self.encoder, "set_row_packing"):
             # the CTC head reads rows < len only (model.py:1014): in the f16x2 mode the padding rows are not computed at all
             self.encoder.set_row_packing(self.encoder.ALL_ROWS if return_intermediate else 0)
         enc, olens = self.encoder(x, lens)
-        frame_ids = self.ctc.argmax(enc).cpu()                       # one D2H copy for the batch
+        frame_ids = self.ctc.argmax(enc, ban_ids=ban_ids).cpu()     # one D2H copy for the batch
         ids: List[List[int]] = []
         for b in range(enc.shape[0]):
             y = torch.unique_consecutive(frame_ids[b, : int(olens[b])], dim=-1)     # model.py:1013-1016
@@ -88,8 +89,8 @@ class SenseVoiceSmall(nn.Module):
 
     def inference(self, data_in, data_lengths=None, key: list = ["wav_file_tmp_name"], tokenizer=None, frontend=None,
                   **kwargs):
-        if kwargs.get("output_timestamp", False) or kwargs.get("ban_emo_unk", False):
-            raise NotImplementedError("CTC forced-alignment timestamps / ban_emo_unk are outside the hot path")
+        if kwargs.get("output_timestamp", False):
+            raise NotImplementedError("CTC forced-alignment timestamps are outside the hot path (SURVEY 2)")
         meta_data = {}
         device = kwargs.get("device", None)
         if isinstance(data_in, torch.Tensor) and kwargs.get("data_type", "sound") == "fbank":
@@ -113,7 +114,8 @@ class SenseVoiceSmall(nn.Module):
             meta_data["batch_data_time"] = int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000
         use_itn = kwargs.get("use_itn", False)
         textnorm = kwargs.get("text_norm", None) or ("withitn" if use_itn else "woitn")
-        res = self.recognize_features(speech, speech_lengths, kwargs.get("language", "auto"), textnorm)
+        ban = [self.emo_dict["unk"]] if kwargs.get("ban_emo_unk", False) else None          # model.py:1004-1005
+        res = self.recognize_features(speech, speech_lengths, kwargs.get("language", "auto"), textnorm, ban_ids=ban)
         B = len(res["ids"])
         if isinstance(key[0], (list, tuple)):
             key = key[0]

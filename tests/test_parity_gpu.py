@@ -328,6 +328,30 @@ def test_sensevoice_inference_equals_reference_inference(cuda, f32_mode):
         assert [r["key"] for r in res] == json.loads(str(g[f"keys_{ci}"]))
 
 
+def test_sensevoice_ban_emo_unk_equals_reference_inference(cuda, f32_mode):
+    """`inference(..., ban_emo_unk=True)`: <|EMO_UNKNOWN|> (id 25009 of the real 25055 vocabulary) never wins a frame -- the
+    ids the REFERENCE class returns with and without the ban (oracle/make_golden_sensevoice_ban.py)."""
+    from funasr_amd.sense_voice import SenseVoiceSmall
+    g = gold("sensevoice_ban")
+    cfg = json.loads(str(g["config"]))
+    sd = synth.sensevoice_state_dict(cfg, seed=int(g["seed"]))
+    for k, v in json.loads(str(g["bias_add"])).items():
+        sd["ctc.ctc_lo.bias"][int(k)] += float(v)
+    model = SenseVoiceSmall.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(cuda).set_precision(f32_mode)
+
+    class IdTokenizer:
+        def decode(self, ids):
+            return " ".join(str(int(i)) for i in ids)
+
+    feats, lens = t(g["feats"]).to(cuda), t(g["lens"])
+    for name, kw in (("plain", {}), ("ban", dict(ban_emo_unk=True)), ("plain", {})):
+        res, _ = model.inference(feats, data_lengths=lens, key=[f"utt{i}" for i in range(feats.shape[0])],
+                                 tokenizer=IdTokenizer(), frontend=None, device=cuda, data_type="fbank", language="auto", **kw)
+        assert [r["text"] for r in res] == json.loads(str(g[f"texts_{name}"])), name
+
+
 def test_beam_search_with_ctc_rescoring_vs_oracle(cuda):
     """`inference(decoding_ctc_weight=0.5, beam_size=3)` on a Paraformer WITH a CTC head (model.py:554-562,629-637): the device
     supplies decoder and CTC log-probs (HIP GEMMs + the row log-softmax kernel), the host runs the beam search that
