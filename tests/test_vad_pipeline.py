@@ -130,6 +130,23 @@ def test_inference_with_vad_sorts_batches_restores_and_merges():
     assert out[0]["sentence_info"] == []
 
 
+def test_inference_with_vad_row_budget_batches_give_the_same_result():
+    """`batch_size_rows` (an encoder-row budget per batch, funasr_amd.dp.plan_batches_by_rows) only regroups the sorted
+    segments: same text / timestamps as the reference's `batch_size_s` policy, batches within the budget"""
+    n = 100 * 16000
+    wav = torch.arange(n, dtype=torch.float32)
+    segs = [[1000, 4000], [5000, 5600], [7000, 20000], [21000, 21900], [30000, 33000], [40000, 41000], [50000, 58000]]
+    ref = _auto(_FakeVAD([segs]), _FakeASR(), batch_size_s=10, batch_size_threshold_s=8).generate([wav])
+    asr = _FakeASR()
+    out = _auto(_FakeVAD([segs]), asr, batch_size_s=10, batch_size_threshold_s=8, batch_size_rows=256).generate([wav])
+    assert out[0]["text"] == ref[0]["text"] and out[0]["timestamp"] == ref[0]["timestamp"]
+    frames = lambda samples: max(1, (samples // 16) // 60)        # the fake frontend-less estimate of auto_model: 60 ms per row
+    for call in asr.calls:                                        # padded layout (the fake model has no f16x2 encoder)
+        rows = len(call) * ((max(frames(c) for c in call) + 15) // 16 * 16)
+        assert rows <= 256 or len(call) == 1, call
+    assert sum(len(c) for c in asr.calls) == len(segs) and len(asr.calls) > 1
+
+
 class _FakePunc:
     """marks a comma after every 3rd word and a period after every 7th; one punc id per word, like CTTransformer"""
     def parameters(self):
