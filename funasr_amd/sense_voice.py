@@ -5,7 +5,7 @@ for the CTC-greedy inference path: same constructor keywords, state_dict layout 
 ctc.ctc_lo.*), the four query frames [language, event, emotion, textnorm] placed in front of the speech features
 (:971-995) and `inference(...) -> (results, meta_data)`. The [B, T, 25055] log-softmax is never materialised: the
 arg-max is fused into the CTC projection GEMM (`ban_emo_unk`: a -inf bias for <|EMO_UNKNOWN|> on a sibling head, same
-single launch); `output_timestamp` (CTC forced alignment, out of scope per SURVEY 2) raises.
+single launch); `output_timestamp` adds the reference's CTC forced alignment of the decoded pieces on the host (:1036-1078).
 """
 from __future__ import annotations
 
@@ -20,6 +20,37 @@ from .ctc import CTC
 from .register import tables
 from . import sanm_encoder as _sanm_encoder  # noqa: F401
 from . import wav_frontend as _wav_frontend  # noqa: F401
+
+
+def ctc_forced_align(log_probs, targets, blank: int = 0):
+    """`ctc_forced_align` (funasr/models/sense_voice/utils/ctc_alignment.py:2-77, batch of one) on the host: the Viterbi path of
+    the target labels (with optional blanks between and around them) through the emissions. log_probs float [T, C], targets
+    int [L] -> int64 [T]: the label (or `blank`) aligned to every frame. O(T L) scalar work on a few dozen frames -- the
+    reference runs it as ~T small tensor ops; numpy float32 here, the same comparisons in the same order."""
+    import numpy as np
+    lp = np.asarray(log_probs, dtype=np.float32)
+    tg = np.asarray(targets, dtype=np.int64)
+    T, L = lp.shape[0], tg.shape[0]
+    ext = np.full(2 * L + 1, blank, dtype=np.int64)              # blank, y1, blank, y2, ..., blank
+    ext[1::2] = tg
+    diff = np.concatenate(([False, False], ext[2:] != ext[:-2]))
+    neg_inf = np.float32(-np.inf)
+    PAD = 2
+    best = np.full(PAD + ext.shape[0], neg_inf, dtype=np.float32)
+    best[PAD + 0] = lp[0, blank]
+    best[PAD + 1] = lp[0, ext[1]]
+    back = np.zeros((T, PAD + ext.shape[0]), dtype=np.int64)
+    for t in range(1, T):
+        prev = np.stack((best[2:], best[1:-1], np.where(diff, best[:-2], neg_inf)))
+        idx = prev.argmax(axis=0)                                # first maximum, like torch.max over dim 0
+        best[PAD:] = lp[t, ext] + prev[idx, np.arange(prev.shape[1])]
+        back[t, PAD:] = idx
+    last = np.array([best[PAD + 2 * L - 1], best[PAD + 2 * L]])
+    path = np.zeros(T, dtype=np.int64)
+    path[T - 1] = PAD + 2 * L - 1 + int(last.argmax())
+    for t in range(T - 1, 0, -1):
+        path[t - 1] += path[t] - back[t, path[t]]
+    return ext[np.clip(path - PAD, 0, None)]
 
 
 @tables.register("model_classes", "SenseVoiceSmall")
@@ -87,10 +118,70 @@ class SenseVoiceSmall(nn.Module):
             out.update(enc=enc, olens=olens)
         return out
 
+    @staticmethod
+    def post(timestamp):
+        """model.py:1080-1112: [piece, start_s, end_s] per aligned piece -> ([[start_ms, end_ms]], [word]): "▁" alone is
+        dropped, a piece starting with "▁" opens a word, consecutive ASCII-alphabetic pieces are glued to the word before"""
+        stamps, words, prev = [], [], None
+        for i, (word, start, end) in enumerate(timestamp):
+            start, end = int(start * 1000), int(end * 1000)
+            if word == "▁":
+                continue
+            if i == 0:
+                stamps.append([start, end])
+                words.append(word)
+            elif word.startswith("▁"):
+                word = word[1:]
+                stamps.append([start, end])
+                words.append(word)
+            elif prev is not None and prev.isalpha() and prev.isascii() and word.isalpha() and word.isascii():
+                word = prev + word
+                stamps[-1][1] = end
+                words[-1] = word
+            else:
+                stamps.append([start, end])
+                words.append(word)
+            prev = word
+        return stamps, words
+
+    def ctc_timestamps(self, text: str, logp_speech, tokenizer):
+        """The `output_timestamp` branch of the reference for one utterance (model.py:1036-1078): the decoded text is cut
+        into pieces again (the four rich-tag pieces in front dropped), the pieces' ids are force-aligned to the CTC
+        log-probabilities of the speech frames (frames whose arg-max is blank get blank log-probability 0 first), every run
+        of a non-blank label becomes [piece, start, end] in seconds at 60 ms per frame, shifted by half a frame.
+        logp_speech: float [T - 4, V] (host). -> (timestamp, words) or None when the text has no pieces."""
+        from itertools import groupby
+        import numpy as np
+        tokens = tokenizer.text2tokens(text)[4:]
+        token_ids = []
+        for ids in tokenizer.tokens2ids(tokens):
+            if ids:
+                token_ids.extend(ids)
+            else:
+                token_ids.append(124)                            # the reference's stand-in for a piece without ids
+        if len(token_ids) == 0:
+            return None
+        lp = np.array(logp_speech, dtype=np.float32, copy=True)
+        pred = lp.argmax(-1)
+        lp[pred == self.blank_id, self.blank_id] = 0
+        tg = np.asarray(token_ids, dtype=np.int64)
+        tg[tg == self.ignore_id] = self.blank_id
+        align = ctc_forced_align(lp, tg, blank=self.blank_id)
+        ts_max = lp.shape[0]
+        timestamp, start, k = [], 0, 0
+        for label, run in groupby(align.tolist()):
+            end = start + len(list(run))
+            if label != 0:
+                timestamp.append([tokens[k], max((start * 60 - 30) / 1000, 0), min((end * 60 - 30) / 1000, (ts_max * 60 - 30) / 1000)])
+                k += 1
+            start = end
+        return self.post(timestamp)
+
     def inference(self, data_in, data_lengths=None, key: list = ["wav_file_tmp_name"], tokenizer=None, frontend=None,
                   **kwargs):
-        if kwargs.get("output_timestamp", False):
-            raise NotImplementedError("CTC forced-alignment timestamps are outside the hot path (SURVEY 2)")
+        output_timestamp = kwargs.get("output_timestamp", False)
+        if output_timestamp and tokenizer is None:
+            raise ValueError("output_timestamp needs the tokenizer (text2tokens / tokens2ids)")
         meta_data = {}
         device = kwargs.get("device", None)
         if isinstance(data_in, torch.Tensor) and kwargs.get("data_type", "sound") == "fbank":
@@ -115,16 +206,26 @@ class SenseVoiceSmall(nn.Module):
         use_itn = kwargs.get("use_itn", False)
         textnorm = kwargs.get("text_norm", None) or ("withitn" if use_itn else "woitn")
         ban = [self.emo_dict["unk"]] if kwargs.get("ban_emo_unk", False) else None          # model.py:1004-1005
-        res = self.recognize_features(speech, speech_lengths, kwargs.get("language", "auto"), textnorm, ban_ids=ban)
+        res = self.recognize_features(speech, speech_lengths, kwargs.get("language", "auto"), textnorm, ban_ids=ban,
+                                      return_intermediate=output_timestamp)
         B = len(res["ids"])
+        logp = None
+        if output_timestamp:                                     # one D2H copy of the batch's log-probabilities (:1045)
+            logp = self.ctc.log_softmax(res["enc"]).cpu()
         if isinstance(key[0], (list, tuple)):
             key = key[0]
         if len(key) < B:
             key = list(key) * B
         results = []
         for i in range(B):
-            if tokenizer is not None:
-                results.append({"key": key[i], "text": tokenizer.decode(res["ids"][i])})
-            else:
+            if tokenizer is None:
                 results.append({"key": key[i], "token_int": res["ids"][i]})
+                continue
+            item = {"key": key[i], "text": tokenizer.decode(res["ids"][i])}
+            if output_timestamp:
+                n = int(res["olens"][i])
+                ts = self.ctc_timestamps(item["text"], logp[i, 4:n].numpy(), tokenizer)
+                if ts is not None:
+                    item["timestamp"], item["words"] = ts
+            results.append(item)
         return results, meta_data

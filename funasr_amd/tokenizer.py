@@ -200,7 +200,8 @@ class SentencepiecesTokenizer:
     def tokens2text(self, tokens: Iterable[str]) -> str:
         return self.sp.DecodePieces(list(tokens))
 
-    def encode(self, line: str, **kwargs) -> List[int]:
+    def encode(self, line, **kwargs):
+        """a string -> ids; a LIST of strings -> one id list per string (what `tokens2ids` relies on)"""
         return self.sp.EncodeAsIds(line)
 
     def decode(self, ids, **kwargs) -> str:
@@ -209,8 +210,10 @@ class SentencepiecesTokenizer:
     def get_vocab_size(self) -> int:
         return self.sp.GetPieceSize()
 
-    def ids2tokens(self, ids) -> List[str]:
-        return [self.sp.IdToPiece(int(i)) for i in ids]
+    # the reference aliases these two to decode / encode (sentencepiece_tokenizer.py:84-100): ids2tokens returns TEXT and
+    # tokens2ids re-encodes every piece string, i.e. returns a list of id lists -- SenseVoice's timestamp branch depends on it
+    def ids2tokens(self, *args, **kwargs):
+        return self.decode(*args, **kwargs)
 
-    def tokens2ids(self, tokens) -> List[int]:
-        return [self.sp.PieceToId(t) for t in tokens]
+    def tokens2ids(self, *args, **kwargs):
+        return self.encode(*args, **kwargs)
