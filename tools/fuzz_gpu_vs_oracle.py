@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Shape fuzz on the GPU: random batch sizes / frame counts / ragged lengths through the HIP pipeline in all three
-fp32-accurate modes against the CPU oracle (token ids, CIF fire positions, encoder error). Not part of the test run."""
+fp32-accurate modes against the CPU oracle (token ids, CIF fire positions, encoder error), plus the row-packed production call
+in the f16x2 mode against the all-rows call. Not part of the test run."""
 import os
 import sys
 
@@ -14,7 +15,7 @@ from oracle import paraformer_oracle as O         # noqa: E402
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-worst, bad = {"fp32": 0.0, "bf16x3": 0.0, "f16x2": 0.0}, 0
+worst, bad, n_packed, near_ties = {"fp32": 0.0, "bf16x3": 0.0, "f16x2": 0.0}, 0, 0, []
 for ci in range(n_cases):
     cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=int(torch.randint(1, 4, (1,), generator=g)),
                      dec_blocks=int(torch.randint(1, 3, (1,), generator=g)), vocab=int(torch.randint(30, 300, (1,), generator=g)))
@@ -38,13 +39,28 @@ for ci in range(n_cases):
         res = model.recognize_features(x.to(dev), lens, return_intermediate=True)
         err = (res["enc"].cpu() - ref["enc"]).abs().max().item()
         worst[mode] = max(worst[mode], err)
-        same = res["raw_ids"] == ref["raw_ids"] and res["token_num"] == ref["token_num"].tolist() and \
+        same = res["token_num"] == ref["token_num"].tolist() and \
             torch.equal(torch.floor(res["peaks"].cpu()) >= 1, torch.floor(ref["peaks"]) >= 1)
+        if same and res["raw_ids"] != ref["raw_ids"]:
+            # random-init output layers: an id may differ only where the ORACLE's own top-2 logits are a near-tie (< 1e-4)
+            top2 = torch.topk(ref["logits"], 2, dim=-1).values
+            for b, (u, v) in enumerate(zip(res["raw_ids"], ref["raw_ids"])):
+                for pos, (a_, b_) in enumerate(zip(u, v)):
+                    if a_ != b_:
+                        gap = float(top2[b, pos, 0] - top2[b, pos, 1])
+                        near_ties.append(dict(case=ci, mode=mode, clip=b, pos=pos, cpu_top2_logit_gap=gap))
+                        same = same and gap < 1e-4
+        if mode == "f16x2":
+            # the production call: only len + 1 encoder rows per clip are computed (row packing) -- same integers
+            packed = model.recognize_features(x.to(dev), lens)
+            same = same and packed["raw_ids"] == res["raw_ids"] and packed["token_num"] == res["token_num"]
+            n_packed += 1
         if not same or err > 1e-3:
             bad += 1
             print(f"case {ci} mode {mode} B={B} T={T} lens={lens.tolist()} err={err:.2e} same={same}")
 print(f"{n_cases} cases: max encoder |d| {worst}, failures {bad}")
 import json
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump({"cases": n_cases, "seed": int(sys.argv[1]) if len(sys.argv) > 1 else 0, "max_encoder_abs_diff": worst, "failures": bad},
+json.dump({"cases": n_cases, "seed": int(sys.argv[1]) if len(sys.argv) > 1 else 0, "max_encoder_abs_diff": worst, "failures": bad,
+           "row_packed_runs_compared": n_packed, "near_tie_token_flips": near_ties},
           open("gpurun_out/fuzz_gpu_vs_oracle.json", "w"))
