@@ -37,7 +37,8 @@ def stream_cfg():
     return cfg
 
 
-def main():
+def build():
+    """the reference's ParaformerStreaming + WavFrontendOnline on the seeded weights -> (model, frontend, cfg, enc_conf)"""
     ref_import.install()
     import torchaudio.compliance.kaldi as kaldi           # the stub module
 
@@ -81,17 +82,24 @@ def main():
     am_mvn = os.path.join(GOLD, "am.mvn")
     frontend = wf.WavFrontendOnline(cmvn_file=am_mvn, fs=16000, window="hamming", n_mels=80, frame_length=25,
                                     frame_shift=10, lfr_m=7, lfr_n=6, dither=0.0)
+    return model, frontend, cfg, enc_conf
 
-    class Tok:                                             # ids2tokens -> the ids themselves (as strings)
-        def ids2tokens(self, ids):
-            return [str(int(i)) for i in ids]
 
+class Tok:                                                 # ids2tokens -> the ids themselves (as strings)
+    def ids2tokens(self, ids):
+        return [str(int(i)) for i in ids]
+
+
+def clip():
     # 5 full chunks + 700 leftover samples in call 1; call 2 (final) brings 3 more chunks and a 500-sample tail
     n1, n2 = 5 * 9600 + 700, 3 * 9600 - 200
     wav = synth.speech_like(n1 + n2, seed=77)
     pcm = (wav * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
-    wav = pcm.to(torch.float32) / 32768.0
+    return pcm, pcm.to(torch.float32) / 32768.0, n1
 
+
+def run(model, frontend, enc_conf, wav, n1, chunk, enc_lb, dec_lb):
+    """two calls of the reference's inference (mid-stream + final) -> one record per chunk it decoded"""
     records = []
     orig_generate = model.generate_chunk
 
@@ -119,14 +127,23 @@ def main():
 
     model.generate_chunk = spy
     cache = {}
-    kw = dict(chunk_size=CHUNK, encoder_chunk_look_back=4, decoder_chunk_look_back=1, device="cpu",
+    kw = dict(chunk_size=chunk, encoder_chunk_look_back=enc_lb, decoder_chunk_look_back=dec_lb, device="cpu",
               encoder_conf=enc_conf, frontend_conf=dict(n_mels=80, lfr_m=7))
-    with torch.no_grad():
-        r1, _ = model.inference([wav[:n1]], key=["utt"], tokenizer=Tok(), frontend=frontend, cache=cache, is_final=False, **kw)
-        r2, _ = model.inference([wav[n1:]], key=["utt"], tokenizer=Tok(), frontend=frontend, cache=cache, is_final=True, **kw)
-    print("call 1 text:", r1[0]["text"], "| call 2 text:", r2[0]["text"])
+    try:
+        with torch.no_grad():
+            r1, _ = model.inference([wav[:n1]], key=["utt"], tokenizer=Tok(), frontend=frontend, cache=cache, is_final=False, **kw)
+            r2, _ = model.inference([wav[n1:]], key=["utt"], tokenizer=Tok(), frontend=frontend, cache=cache, is_final=True, **kw)
+    finally:
+        model.generate_chunk = orig_generate
+    print("chunk", chunk, "look back", enc_lb, dec_lb, "| call 1 text:", r1[0]["text"], "| call 2 text:", r2[0]["text"])
     print("chunks:", len(records), "tokens/chunk:", [len(r["tokens"]) for r in records], "tail:", [r["tail"] for r in records])
+    return records
 
+
+def main():
+    model, frontend, cfg, enc_conf = build()
+    pcm, wav, n1 = clip()
+    records = run(model, frontend, enc_conf, wav, n1, CHUNK, 4, 1)
     arrs = dict(pcm=pcm.numpy(), n1=np.int64(n1), seed=np.int64(SEED), cif_bias=np.float32(0.6),
                 config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), n_chunks=np.int64(len(records)))
     for i, r in enumerate(records):
@@ -141,5 +158,24 @@ def main():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB)")
 
 
+def main_geometries():
+    """other chunk sizes / look-back settings of the SAME clip and weights -> tests/golden/streaming_geometries.npz (per
+    session: the online features, token ids and flags of every chunk)"""
+    model, frontend, cfg, enc_conf = build()
+    _, wav, n1 = clip()
+    arrs, sessions = {}, []
+    for si, (chunk, enc_lb, dec_lb) in enumerate((([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1))):
+        frontend.cache_reset() if hasattr(frontend, "cache_reset") else None
+        records = run(model, frontend, enc_conf, wav, n1, chunk, enc_lb, dec_lb)
+        sessions.append(dict(chunk=chunk, enc_lb=enc_lb, dec_lb=dec_lb, n_chunks=len(records)))
+        for i, r in enumerate(records):
+            arrs[f"s{si}_feats_{i}"] = r["feats"].astype(np.float32)
+            arrs[f"s{si}_tokens_{i}"] = np.asarray(r["tokens"], dtype=np.int64)
+            arrs[f"s{si}_flags_{i}"] = np.asarray([r["is_final"], r["tail"], r["start_idx"]], dtype=np.int64)
+    path = os.path.join(GOLD, "streaming_geometries.npz")
+    np.savez_compressed(path, sessions=json.dumps(sessions), **arrs)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
 if __name__ == "__main__":
-    main()
+    main_geometries() if "--geometries" in sys.argv else main()

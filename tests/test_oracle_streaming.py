@@ -81,3 +81,29 @@ def test_streaming_frontend_features_match_reference():
         ref = torch.from_numpy(g[f"feats_{k}"])[0]
         assert f.shape == ref.shape and torch.equal(f, ref), k
         k += 1
+
+
+def test_streaming_oracle_matches_reference_in_other_chunk_geometries():
+    """chunk sizes / look-back settings other than the main fixture's, from the reference's own ParaformerStreaming.inference
+    on the same clip and weights (oracle/make_golden_streaming.py --geometries): the oracle, driven chunk by chunk with the
+    recorded online features, returns the reference's token ids and position counter on every chunk incl. the tail chunk"""
+    import json
+    import numpy as np
+    import os
+    g, cfg, sd, wav, cmvn = load()
+    gg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "streaming_geometries.npz"), allow_pickle=False)
+    sessions = json.loads(str(gg["sessions"]))
+    assert [s["chunk"] for s in sessions] == [[5, 10, 5], [0, 8, 4], [0, 10, 5]]
+    for si, s in enumerate(sessions):
+        st = S.model_init(cfg, tuple(s["chunk"]), s["enc_lb"], s["dec_lb"])
+        for i in range(s["n_chunks"]):
+            fin, tail, start_idx = (int(v) for v in gg[f"s{si}_flags_{i}"])
+            if tail:
+                st["tail_chunk"] = True
+                feats = st["feats"]
+            else:
+                feats = torch.from_numpy(gg[f"s{si}_feats_{i}"])
+            with torch.no_grad():
+                ids = S.generate_chunk(feats, st, sd, cfg, bool(fin))
+            assert ids == gg[f"s{si}_tokens_{i}"].tolist(), (s, i)
+            assert st["start_idx"] == start_idx, (s, i)

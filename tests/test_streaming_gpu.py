@@ -155,6 +155,29 @@ def test_streaming_inference_on_a_wav_path_inside_a_list_is_a_whole_utterance(cu
         assert r[0]["token_int"] == ref
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_stream_other_chunk_geometries_match_reference_sessions(cuda, use_graph):
+    """the reference's own ParaformerStreaming.inference at other chunk sizes / look-back settings (same clip and weights,
+    tests/golden/streaming_geometries.npz): token ids and the position counter on every chunk incl. the tail chunk"""
+    import json
+    import numpy as np
+    import os
+    from funasr_amd.paraformer_streaming import StreamBatch
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    gg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "streaming_geometries.npz"), allow_pickle=False)
+    for si, s in enumerate(json.loads(str(gg["sessions"]))):
+        sb = StreamBatch(model, 1, s["chunk"], s["enc_lb"], s["dec_lb"], use_graph=use_graph)
+        for i in range(s["n_chunks"]):
+            fin, tail, start_idx = (int(v) for v in gg[f"s{si}_flags_{i}"])
+            feats = None if tail else torch.from_numpy(gg[f"s{si}_feats_{i}"]).to(cuda)
+            ids = sb.step(feats, is_final=bool(fin), tail_chunk=bool(tail))
+            got = [t for t in ids[0] if t not in (0, 1, 2)]
+            assert got == gg[f"s{si}_tokens_{i}"].tolist(), (s, i, got)
+            assert sb.peek()["start_idx"] == start_idx
+        sb.close()
+
+
 @pytest.mark.parametrize("chunk,enc_lb,dec_lb", [([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1)])
 def test_stream_other_chunk_geometries_vs_streaming_oracle(cuda, chunk, enc_lb, dec_lb):
     """chunk_size / look-back settings other than the golden session's, against the (reference-pinned) streaming oracle
