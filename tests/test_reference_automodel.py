@@ -81,3 +81,46 @@ def test_reference_generate_reaches_our_inference_with_a_compatible_call(ref, tm
     assert [len(c["data_in"]) for c in seen] == [2, 1]          # batch_size 2 over three files (auto_model.py:800-806)
     assert [r["text"] for r in out] == [f"text of u{i}.wav" for i in range(3)]
     assert [r["key"] for r in out] == ["u0", "u1", "u2"]
+
+
+def test_reference_automodel_builds_the_punctuation_models_and_passes_the_session_cache(ref, tmp_path, monkeypatch):
+    """the offline and the realtime punctuation model directories through the REFERENCE's AutoModel over install(): classes by
+    registry name (CTTransformer / SANMEncoder, CTTransformerStreaming / SANMVadEncoder), the reference's own CharTokenizer,
+    parameters loaded by its load_pretrained_model; generate(input=text, cache=session) hands the caller's dict to
+    CTTransformerStreaming.inference (auto_model.py:780-781 drops a STALE cache only)"""
+    import json
+    import numpy as np
+    AutoModel, tables = ref
+    from funasr_amd.ct_transformer import CTTransformer, CTTransformerStreaming
+    from funasr_amd.sanm_encoder import SANMEncoder, SANMVadEncoder
+    from oracle import punc_oracle
+    from tests._model_dir import make_punc_model_dir
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for fixture, model_name, enc_name, mcls, ecls in (("punc.npz", "CTTransformer", "SANMEncoder", CTTransformer, SANMEncoder),
+                                                      ("punc_streaming.npz", "CTTransformerStreaming", "SANMVadEncoder", CTTransformerStreaming, SANMVadEncoder)):
+        g = np.load(os.path.join(gold, fixture), allow_pickle=False)
+        vocab, enc = json.loads(str(g["vocab"])), json.loads(str(g["enc_cfg"]))
+        sd = punc_oracle.synthetic_state_dict(len(vocab), enc, seed=int(g["seed"]))
+        d = str(tmp_path / model_name)
+        make_punc_model_dir(d, vocab, enc, sd, punc_oracle.PUNC_LIST, model=model_name, encoder=enc_name)
+        am = AutoModel(model=d, device="cpu", disable_update=True, disable_pbar=True)
+        assert type(am.model) is mcls and type(am.model.encoder) is ecls
+        assert type(am.kwargs["tokenizer"]).__module__.startswith("funasr.tokenizer")
+        got = am.model.state_dict()
+        for k, v in sd.items():
+            assert torch.equal(got[k], v), k
+    seen = []
+    sig = inspect.signature(CTTransformerStreaming.inference)
+
+    def recorder(self, *args, **kwargs):
+        a = sig.bind(self, *args, **kwargs).arguments
+        seen.append(a)
+        a["cache"].setdefault("pre_text", []).append(a["data_in"][0])
+        return [{"key": a["key"][0], "text": a["data_in"][0] + "。", "punc_array": torch.tensor([3])}], {}
+
+    monkeypatch.setattr(CTTransformerStreaming, "inference", recorder)
+    session = {}
+    out1 = am.generate(input="今天天气", cache=session)
+    out2 = am.generate(input="真不错", cache=session)
+    assert seen[0]["cache"] is session and seen[1]["cache"] is session and session["pre_text"] == ["今天天气", "真不错"]
+    assert seen[0]["tokenizer"] is am.kwargs["tokenizer"] and out1[0]["text"] == "今天天气。" and out2[0]["text"] == "真不错。"
