@@ -49,6 +49,14 @@ CONFIGS = {
     "FsmnVADStreaming": dict(encoder="FSMN", encoder_conf=VAD_ENC),
     "CTTransformer": dict(encoder="SANMEncoder", encoder_conf=PUNC_ENC, vocab_size=50, punc_list=["<unk>", "_", "，", "。", "？", "、"],
                           embed_unit=256, att_unit=256, ignore_id=0, sentence_end_id=3),
+    "CTTransformerStreaming": dict(encoder="SANMVadEncoder", encoder_conf=dict(PUNC_ENC, num_blocks=3, sanm_shfit=5), vocab_size=50,
+                                   punc_list=["<unk>", "_", "，", "。", "？", "、"], embed_unit=256, att_unit=256, ignore_id=0,
+                                   sentence_end_id=3),
+    "ContextualParaformer": dict(encoder="SANMEncoder", encoder_conf=ENC, decoder="ContextualParaformerDecoder", decoder_conf=DEC,
+                                 predictor="CifPredictorV2", predictor_conf=V2, input_size=560, vocab_size=97, ctc_weight=0.0,
+                                 inner_dim=512, bias_encoder_type="lstm"),
+    "Paraformer+CTC": dict(encoder="SANMEncoder", encoder_conf=ENC, decoder="ParaformerSANMDecoder", decoder_conf=DEC,
+                           predictor="CifPredictorV2", predictor_conf=V2, input_size=560, vocab_size=97, ctc_weight=0.3),
 }
 
 
@@ -63,6 +71,10 @@ def main():
     import funasr.models.sense_voice.model  # noqa: F401
     from funasr.models.bicif_paraformer.model import BiCifParaformer
     from funasr.models.ct_transformer.model import CTTransformer
+    from funasr.models.ct_transformer_streaming.model import CTTransformerStreaming
+    from funasr.models.contextual_paraformer.model import ContextualParaformer
+    import funasr.models.contextual_paraformer.decoder  # noqa: F401
+    import funasr.models.ct_transformer_streaming.encoder  # noqa: F401
     from funasr.models.fsmn_vad_streaming.model import FsmnVADStreaming
     from funasr.models.paraformer.model import Paraformer
     from funasr.models.paraformer_streaming.model import ParaformerStreaming
@@ -70,9 +82,13 @@ def main():
     from funasr.models.sense_voice.model import SenseVoiceSmall
     classes = dict(Paraformer=Paraformer, BiCifParaformer=BiCifParaformer, SeacoParaformer=SeacoParaformer,
                    ParaformerStreaming=ParaformerStreaming, SenseVoiceSmall=SenseVoiceSmall, FsmnVADStreaming=FsmnVADStreaming,
-                   CTTransformer=CTTransformer)
+                   CTTransformer=CTTransformer, CTTransformerStreaming=CTTransformerStreaming,
+                   ContextualParaformer=ContextualParaformer)
+    classes["Paraformer+CTC"] = Paraformer                  # the beam-search configuration: a CTC head next to the decoder
     out = {}
     for name, conf in CONFIGS.items():
+        if conf is None or name not in classes:
+            continue
         try:
             model = classes[name](**conf)
         except Exception as e:  # noqa: BLE001
