@@ -12,6 +12,7 @@
 // fma chain depends on K only -- never on how many rows or streams are in the batch (hipGraph replay == eager, a
 // stream's result is bitwise independent of its neighbours).
 #include "common.h"
+#include <type_traits>
 
 namespace pf {
 
@@ -61,30 +62,44 @@ __global__ __launch_bounds__(SK_KW * 64) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 4
-    for (int k = kb; k < ke; k += 16) {
-        float4 a[RM], b[CN];
+    // U consecutive 16-wide k steps: all their loads first, then their MFMAs in ascending k (the summation order of the plain
+    // loop). Written out because the compiler does not unroll a runtime-trip-count loop around MFMAs (convergent), and an
+    // un-unrolled loop pays one memory latency per step -- eight in a row for a K = 2048 slice.
+    auto steps_of = [&](auto U_, int k0) {
+        constexpr int U = decltype(U_)::value;
+        float4 a[U][RM], b[U][CN];
 #pragma unroll
-        for (int i = 0; i < RM; ++i) a[i] = *reinterpret_cast<const float4*>(ap[i] + k);
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int j = 0; j < CN; ++j) b[j] = *reinterpret_cast<const float4*>(wp[j] + k);
+            for (int i = 0; i < RM; ++i) a[u][i] = *reinterpret_cast<const float4*>(ap[i] + k0 + 16 * u);
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+            for (int j = 0; j < CN; ++j) b[u][j] = *reinterpret_cast<const float4*>(wp[j] + k0 + 16 * u);
+        }
 #pragma unroll
-            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].x, b[u][j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].y, b[u][j].y, acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-    }
+                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].z, b[u][j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].w, b[u][j].w, acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nit = ke > kb ? (ke - kb) >> 4 : 0;
+    int it = 0;
+    for (; it + 4 <= nit; it += 4) steps_of(std::integral_constant<int, 4>{}, kb + 16 * it);
+    if (it + 2 <= nit) { steps_of(std::integral_constant<int, 2>{}, kb + 16 * it); it += 2; }
+    if (it < nit) steps_of(std::integral_constant<int, 1>{}, kb + 16 * it);
 
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* mine = red + (size_t)wave * (RM * 16 * LD);
