@@ -75,3 +75,28 @@ def test_inference_with_output_timestamp_equals_reference(cuda):
             assert ("timestamp" in r) == e["has_ts"]
             if e["has_ts"]:
                 assert r["words"] == e["words"] and [[float(a), float(b)] for a, b in r["timestamp"]] == e["timestamp"], mode
+
+
+def test_forced_alignment_equals_the_reference_function_on_random_emissions():
+    """funasr/models/sense_voice/utils/ctc_alignment.py `ctc_forced_align` itself (build container only) on 300 random
+    emission / target pairs: the host restatement returns the same frame labels"""
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("reference checkout not present (GPU box)")
+    ref_import.install()
+    from funasr.models.sense_voice.utils.ctc_alignment import ctc_forced_align as ref
+    from funasr_amd.sense_voice import ctc_forced_align as mine
+    g = torch.Generator().manual_seed(0)
+    checked = 0
+    for _ in range(300):
+        T = int(torch.randint(1, 40, (1,), generator=g))
+        C = int(torch.randint(3, 12, (1,), generator=g))
+        L = int(torch.randint(1, max(2, min(T, 8) + 1), (1,), generator=g))
+        lp = torch.log_softmax(torch.randn(1, T, C, generator=g) * 2, -1)
+        tg = torch.randint(1, C, (1, L), generator=g)
+        if L + int((tg[0, 1:] == tg[0, :-1]).sum()) > T:        # no valid path: the reference's output is unspecified
+            continue
+        r = ref(lp.clone(), tg.clone(), torch.tensor([T]), torch.tensor([L]))[0].numpy()
+        assert np.array_equal(r, mine(lp[0].numpy(), tg[0].numpy())), (T, C, L)
+        checked += 1
+    assert checked > 150
