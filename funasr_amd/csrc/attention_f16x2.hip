@@ -35,10 +35,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // PIPE = 1: software-pipelined schedule -- the S^T products of tile t+1 are issued BEFORE the softmax of tile t, in one
 // scheduling region, so the matrix pipe works under the softmax's VALU (three LDS stages instead of two)
-template <int PIPE>
-__global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
+// WAVES = 8: 256 queries per workgroup, one workgroup per CU. WAVES = 4 (with PIPE = 0; measurement variant 2, not yet the
+// default): 128 queries, two 64-KB stages and a 68-KB epilogue slab, so TWO workgroups share a CU and run out of phase -- one
+// is in its MFMA segments while the other is in its softmax -- at the price of fetching every K / V^T tile for 128 instead of
+// 256 queries (from L2).
+// LAZY (measurement variant 3): the running maximum of the online softmax is only moved when a tile's maximum exceeds it by
+// more than LAZY_TAU -- the probabilities are then at most e^TAU instead of 1 (p * 2^10 stays far inside fp16), and the 64
+// accumulator multiplications per tile are skipped whenever no query of the wave moved its maximum.
+constexpr float LAZY_TAU = 3.0f;
+template <int PIPE, int WAVES = 8, bool LAZY = false>
+__global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NSTAGE = PIPE ? 3 : 2;
+    constexpr int QB = WAVES * 32;                           // queries per workgroup
+    constexpr int NV = 8 / WAVES;                            // DMA pieces are dealt to 8 virtual waves: NV per real wave
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,8 +56,8 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     const int b = blockIdx.z, head = blockIdx.y;
     // cross-attention: Q / O rows per sequence differ from K's; packed queries: sequence b owns rows [qoffs[b], qoffs[b+1])
     const int Tq = p.qoffs ? p.qoffs[b + 1] - p.qoffs[b] : (p.Tq > 0 ? p.Tq : p.Tp);
-    if (blockIdx.x * 256 >= Tq) return;                  // (uniform per workgroup) nothing to do for this query block
-    const int q = blockIdx.x * 256 + wave * 32 + idx;
+    if (blockIdx.x * QB >= Tq) return;                   // (uniform per workgroup) nothing to do for this query block
+    const int q = blockIdx.x * QB + wave * 32 + idx;
     const int qc = q < Tq ? q : Tq - 1;
     const int klen = p.klens[b];
     // keys: rows [b Tp, b Tp + klen), or with koffs any rows [koffs[b], koffs[b] + klen): tiles then start at the 16-row
@@ -78,22 +88,28 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
 
     // ---- DMA of one tile: 32 pieces of 1 KB; wave w issues K plane 0 / 1 rows 4w..4w+3 and V^T plane 0 / 1 rows
     //      16w..16w+15. K row r (256 B): chunk c at c ^ (r & 15); V^T row d (64 B): chunk c at c ^ ((d >> 2) & 3)
-    const unsigned short* ksrc;
-    const unsigned short* vsrc;
-    {
-        const int kr = wave * 4 + (lane >> 4);
-        ksrc = p.K + (row0 + kr) * p.ldk + head * DK + (((lane & 15) ^ (kr & 15)) * 8);
-        const int dr = wave * 16 + (lane >> 2);
-        vsrc = p.VT + (size_t)(head * DK + dr) * p.ldvt + row0 + (((lane & 3) ^ ((dr >> 2) & 3)) * 8);
+    const unsigned short* ksrc[NV];
+    const unsigned short* vsrc[NV];
+    unsigned lds_w[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int vw = wave * NV + v;                        // virtual wave 0..7
+        const int kr = vw * 4 + (lane >> 4);
+        ksrc[v] = p.K + (row0 + kr) * p.ldk + head * DK + (((lane & 15) ^ (kr & 15)) * 8);
+        const int dr = vw * 16 + (lane >> 2);
+        vsrc[v] = p.VT + (size_t)(head * DK + dr) * p.ldvt + row0 + (((lane & 3) ^ ((dr >> 2) & 3)) * 8);
+        lds_w[v] = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)vw * 1024);
     }
-    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
     auto stage = [&](int kt) {
-        const unsigned base = lds_w + (unsigned)(kt % NSTAGE) * STAGE_B;
         const size_t ko = (size_t)kt * KT * p.ldk;
-        glds16(ksrc + ko, base);
-        glds16(ksrc + p.k_plane + ko, base + KP_B);
-        glds16(vsrc + kt * KT, base + 2 * KP_B);
-        glds16(vsrc + p.vt_plane + kt * KT, base + 2 * KP_B + VP_B);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const unsigned base = lds_w[v] + (unsigned)(kt % NSTAGE) * STAGE_B;
+            glds16(ksrc[v] + ko, base);
+            glds16(ksrc[v] + p.k_plane + ko, base + KP_B);
+            glds16(vsrc[v] + kt * KT, base + 2 * KP_B);
+            glds16(vsrc[v] + p.vt_plane + kt * KT, base + 2 * KP_B + VP_B);
+        }
     };
 
     const float sscale = p.sscale_dev ? p.sscale * *p.sscale_dev : p.sscale;   // 2^-(e_q + e_k)
@@ -123,8 +139,13 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
             mx = fmaxf(mx, s[r]);                                                                                     \
         }                                                                                                             \
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                       \
-        const float m_new = fmaxf(m_run, mx);                                                                         \
-        const float alpha = __expf(m_run - m_new);                                                                    \
+        float m_new = fmaxf(m_run, mx);                                                                               \
+        bool moved = true;                                                                                            \
+        if constexpr (LAZY) {                       /* keep a stale maximum while the true one is < e^TAU above it */  \
+            moved = m_new > m_run + LAZY_TAU;                                                                         \
+            m_new = moved ? m_new : m_run;                                                                            \
+        }                                                                                                             \
+        const float alpha = moved ? __expf(m_run - m_new) : 1.f;                                                      \
         float psum = 0.f;                                                                                             \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
             s[r] = __expf(s[r] - m_new);                                                                              \
@@ -133,7 +154,9 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
         psum += __shfl_xor(psum, 32, 64);                                                                             \
         l_run = l_run * alpha + psum;                                                                                 \
         m_run = m_new;                                                                                                \
-        _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int r = 0; r < 16; ++r) o[d][r] *= alpha; \
+        if (!LAZY || __any(moved)) {                                                                                  \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int r = 0; r < 16; ++r) o[d][r] *= alpha; \
+        }                                                                                                             \
     }
     // O^T += V^T P^T. step st uses this lane's registers r in [8st, 8st+8): keys 16st + 4h + {0..3, 8..11}
 #define PF_PV(KT_)                                                                                                    \
@@ -212,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
             }
     }
     // same wave wrote and reads its slab: no workgroup barrier needed, only the LDS counter (the compiler waits)
-    const int qw0 = blockIdx.x * 256 + wave * 32;
+    const int qw0 = blockIdx.x * QB + wave * 32;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int rr = it * 4 + (lane >> 4), c8 = (lane & 15) * 8;
@@ -239,17 +262,32 @@ int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
                a.k_plane % 8 == 0 && a.vt_plane % 8 == 0 && a.o_plane % 8 == 0, "attention_f16x2: strides % 8");
     PF_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 && ((uintptr_t)a.O & 15) == 0,
                "attention_f16x2: 16-B alignment");
+    constexpr int LDS4 = (4 * 32 * OLD * 4 > 2 * STAGE_B) ? 4 * 32 * OLD * 4 : 2 * STAGE_B;     // four-wave variant: 67.6 KB
     static bool configured = false;
     if (!configured) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0, 8, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<1, 8, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured = true;
     }
-    dim3 grid(ceil_div(a.Tq > 0 ? a.Tq : a.Tp, 256), a.H, a.B);
-    if (a.variant == 1) hipLaunchKernelGGL(attention_f16x2_kernel<1>, grid, dim3(512), LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(attention_f16x2_kernel<0>, grid, dim3(512), LDS_BYTES, stream, a);
+    const int rows = a.Tq > 0 ? a.Tq : a.Tp;
+    if (a.variant == 4)
+        hipLaunchKernelGGL((attention_f16x2_kernel<1, 8, true>), dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
+    else if (a.variant == 3)
+        hipLaunchKernelGGL((attention_f16x2_kernel<0, 8, true>), dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
+    else if (a.variant == 2)
+        hipLaunchKernelGGL((attention_f16x2_kernel<0, 4>), dim3(ceil_div(rows, 128), a.H, a.B), dim3(256), LDS4, stream, a);
+    else if (a.variant == 1)
+        hipLaunchKernelGGL(attention_f16x2_kernel<1>, dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
+    else
+        hipLaunchKernelGGL(attention_f16x2_kernel<0>, dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
