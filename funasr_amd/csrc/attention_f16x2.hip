@@ -113,6 +113,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Arg
     };
 
     const float sscale = p.sscale_dev ? p.sscale * *p.sscale_dev : p.sscale;   // 2^-(e_q + e_k)
+    // LAZY variants work in the base-2 domain: log2(e) is folded into the score scale and exp is a bare v_exp_f32
+    const float sscale2 = LAZY ? sscale * 1.4426950408889634f : sscale;
+#define PF_EXP(x_) (LAZY ? __builtin_amdgcn_exp2f(x_) : __expf(x_))
+    constexpr float PSC = LAZY ? 1.f : P_SCALE;              // (a multiplication by the literal 1 is folded away)
     const int ntiles = (kend + KT - 1) / KT;
 
     // S^T tile (32 keys x 32 queries): small products into sa, hi*hi into sb (no dependent MFMA pairs)
@@ -133,22 +137,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Arg
 #define PF_SOFTMAX(K0_, SA, SB)                                                                                       \
     {                                                                                                                 \
         float mx = -INFINITY;                                                                                         \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
-            const int key = (K0_) + (r & 3) + 8 * (r >> 2) + 4 * hh;                                                  \
-            s[r] = (unsigned)(key - kskip) < (unsigned)klen ? (SA[r] + SB[r]) * sscale : -INFINITY;                   \
-            mx = fmaxf(mx, s[r]);                                                                                     \
+        if (LAZY && (K0_) >= kskip && (K0_) + KT <= kend) {      /* (wave-uniform) every key of the tile is valid */   \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                          \
+                s[r] = (SA[r] + SB[r]) * sscale2;                                                                     \
+                mx = fmaxf(mx, s[r]);                                                                                 \
+            }                                                                                                         \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                          \
+                const int key = (K0_) + (r & 3) + 8 * (r >> 2) + 4 * hh;                                              \
+                s[r] = (unsigned)(key - kskip) < (unsigned)klen ? (SA[r] + SB[r]) * sscale2 : -INFINITY;              \
+                mx = fmaxf(mx, s[r]);                                                                                 \
+            }                                                                                                         \
         }                                                                                                             \
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                       \
         float m_new = fmaxf(m_run, mx);                                                                               \
         bool moved = true;                                                                                            \
         if constexpr (LAZY) {                       /* keep a stale maximum while the true one is < e^TAU above it */  \
-            moved = m_new > m_run + LAZY_TAU;                                                                         \
+            moved = m_new > m_run + LAZY_TAU * 1.4426950408889634f;                                                                         \
             m_new = moved ? m_new : m_run;                                                                            \
         }                                                                                                             \
-        const float alpha = moved ? __expf(m_run - m_new) : 1.f;                                                      \
+        const float alpha = moved ? PF_EXP(m_run - m_new) : 1.f;                                                      \
         float psum = 0.f;                                                                                             \
+        const float m_off = LAZY ? m_new - 10.f : m_new;        /* LAZY: p comes out as p * 2^10, the split's scale */  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
-            s[r] = __expf(s[r] - m_new);                                                                              \
+            s[r] = PF_EXP(s[r] - m_off);                                                                              \
             psum += s[r];                                                                                             \
         }                                                                                                             \
         psum += __shfl_xor(psum, 32, 64);                                                                             \
@@ -164,10 +176,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Arg
         const unsigned char* vp = smem + ((KT_) % NSTAGE) * STAGE_B + 2 * KP_B + idx * 64;                            \
         _Pragma("unroll") for (int st = 0; st < 2; ++st) {                                                            \
             uint4 ph, pl;                                                                                             \
-            split2_pk(s[8 * st + 0] * P_SCALE, s[8 * st + 1] * P_SCALE, ph.x, pl.x);                                  \
-            split2_pk(s[8 * st + 2] * P_SCALE, s[8 * st + 3] * P_SCALE, ph.y, pl.y);                                  \
-            split2_pk(s[8 * st + 4] * P_SCALE, s[8 * st + 5] * P_SCALE, ph.z, pl.z);                                  \
-            split2_pk(s[8 * st + 6] * P_SCALE, s[8 * st + 7] * P_SCALE, ph.w, pl.w);                                  \
+            split2_pk(s[8 * st + 0] * PSC, s[8 * st + 1] * PSC, ph.x, pl.x);                                  \
+            split2_pk(s[8 * st + 2] * PSC, s[8 * st + 3] * PSC, ph.y, pl.y);                                  \
+            split2_pk(s[8 * st + 4] * PSC, s[8 * st + 5] * PSC, ph.z, pl.z);                                  \
+            split2_pk(s[8 * st + 6] * PSC, s[8 * st + 7] * PSC, ph.w, pl.w);                                  \
             const f16x8 Ph = __builtin_bit_cast(f16x8, ph), Pl = __builtin_bit_cast(f16x8, pl);                       \
             const int co = ((2 * st + hh) ^ ((idx >> 2) & 3)) * 16;                                                   \
             f16x8 vf[4][2];                                                                                           \
@@ -218,6 +230,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Arg
         }
     }
 #undef PF_QK
+#undef PF_EXP
 #undef PF_SOFTMAX
 #undef PF_PV
 
@@ -225,7 +238,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Arg
     __syncthreads();
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * OLD);
     {
-        const float inv = p.oscale / l_run;              // oscale = 2^(e_ctx - e_v) / P_SCALE
+        // oscale = 2^(e_ctx - e_v) / P_SCALE; in the LAZY variants l_run was summed in the p * 2^10 units as well
+        const float inv = (LAZY ? p.oscale * P_SCALE : p.oscale) / l_run;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
