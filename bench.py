@@ -73,6 +73,8 @@ def parse():
                     "path with every rank on cuda:0 of a single-GPU box)")
     ap.add_argument("--cpu-clips", type=int, default=64, help="max clips of the same workload timed on the host oracle")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per thread setting")
+    ap.add_argument("--enc-option", action="append", default=[], metavar="KEY=VALUE", help="A/B runs: encoder schedule options of the "
+                    "f16x2 mode (pf_encoder_set_option), e.g. fuse_row=0, attn_variant=1; results are bitwise / fp32-class equal")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap on host threads for the CPU baseline (0 = all usable)")
     return ap.parse_args()
 
@@ -181,6 +183,9 @@ def main():
         return float(tt.item())
 
     model.set_precision(args.precision)
+    for kv in args.enc_option:
+        key, _, val = kv.partition("=")
+        model.encoder.set_option(key, int(val))
     for i in range(args.warmup):
         res = step()
         torch.cuda.synchronize()

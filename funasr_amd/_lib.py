@@ -100,6 +100,7 @@ SIGNATURES = {
     "pf_encoder_missing": (C.c_int, [_vp]),
     "pf_encoder_set_precision": (C.c_int, [_vp, _i32]),
     "pf_encoder_set_row_packing": (C.c_int, [_vp, _i32]),
+    "pf_encoder_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "pf_encoder_set_vad_mask": (C.c_int, [_vp, _vp, _i32]),
     "pf_encoder_forward": (C.c_int, [_vp, _vp, _pi32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "pf_predictor_create": (_vp, [C.POINTER(pf_predictor_config)]),
@@ -157,6 +158,12 @@ SIGNATURES = {
                                   _f32, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
     "pf_k_attention_f16x2": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _f32,
                                        _i32, _i32, C.POINTER(C.c_float), _vp]),
+    "pf_k_gemm_f16x2_row": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _f32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32,
+                                      _vp, _i64, _f32, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
+    "pf_k_layernorm_planes": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _f32, _i32, C.POINTER(C.c_float), _vp]),
+    "pf_k_gemm_f16x2_qkv": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _f32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
+                                      _i32, _i64, _f32, _f32, _f32, _i32, C.POINTER(C.c_float), _vp]),
+    "pf_k_gemm_f16x2_argmax": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _f32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_gemm_argmax_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_log_softmax": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "pf_k_layernorm": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),

@@ -33,31 +33,44 @@ constexpr int LDS_BYTES = SLAB_B > 3 * STAGE_B ? SLAB_B : 3 * STAGE_B;
 constexpr float P_SCALE = 1024.f;                        // probabilities are split as p * 2^10 (p <= 1)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// PIPE = 1: software-pipelined schedule -- the S^T products of tile t+1 are issued BEFORE the softmax of tile t, in one
-// scheduling region, so the matrix pipe works under the softmax's VALU (three LDS stages instead of two)
-// WAVES = 8: 256 queries per workgroup, one workgroup per CU. WAVES = 4 (with PIPE = 0; measurement variant 2, not yet the
-// default): 128 queries, two 64-KB stages and a 68-KB epilogue slab, so TWO workgroups share a CU and run out of phase -- one
-// is in its MFMA segments while the other is in its softmax -- at the price of fetching every K / V^T tile for 128 instead of
-// 256 queries (from L2).
-// LAZY (measurement variant 3): the running maximum of the online softmax is only moved when a tile's maximum exceeds it by
-// more than LAZY_TAU -- the probabilities are then at most e^TAU instead of 1 (p * 2^10 stays far inside fp16), and the 64
-// accumulator multiplications per tile are skipped whenever no query of the wave moved its maximum.
+// Schedules (Attn2Args.variant; all three are tested against float64 attention, tests/test_kernels_f16x2_gpu.py):
+// 3 (the engine's choice), LAZY: the running maximum of the online softmax is only moved when a tile's maximum exceeds it by
+//   more than LAZY_TAU -- the probabilities are then at most e^TAU instead of 1 (p * 2^10 stays far inside fp16) and the 64
+//   accumulator multiplications per tile are skipped whenever no query of the wave moved its maximum; exponentials in base 2
+//   (log2 e folded into the score scale), no key-mask compares on tiles whose keys are all valid. 110 us against 122 / 124 for
+//   variants 1 / 0 at B = 64, T = 512 (profiles/r02l_bench_attn2.json).
+// 1, PIPE: software-pipelined -- the S^T products of tile t+1 are issued BEFORE the softmax of tile t, in one scheduling
+//   region, so the matrix pipe works under the softmax's VALU (three LDS stages instead of two); bitwise equal to variant 0.
+// 0: the plain schedule.
+// (Measured in round 2 and removed: a four-wave workgroup with two workgroups per CU, 127 us; LAZY + PIPE, 114 us.)
 constexpr float LAZY_TAU = 3.0f;
-template <int PIPE, int WAVES = 8, bool LAZY = false>
-__global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Args p) {
+template <int PIPE, bool LAZY = false>
+__global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NSTAGE = PIPE ? 3 : 2;
-    constexpr int QB = WAVES * 32;                           // queries per workgroup
-    constexpr int NV = 8 / WAVES;                            // DMA pieces are dealt to 8 virtual waves: NV per real wave
+    constexpr int QB = 256;                                  // queries per workgroup: 8 waves x 32
+    constexpr int NV = 1;                                    // DMA pieces per wave and plane tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5, idx = lane & 31;
-    const int b = blockIdx.z, head = blockIdx.y;
+    // workgroup -> (sequence, head, query block). XCD-aware order (xcd_nqb > 0, 1-D grid): the hardware deals workgroup L to
+    // XCD L % 8, so the xcd_nqb query blocks of one (sequence, head) get consecutive slots of ONE XCD and fetch that pair's
+    // K / V^T tiles through the same L2 (the plain 3-D order puts neighbouring query blocks on different XCDs: every tile
+    // came from HBM once per query block, 1.7x the compulsory bytes at T = 512)
+    int b, head, qblk;
+    if (p.xcd_nqb > 0) {
+        const int L = blockIdx.x, j = L >> 3;
+        const int pair = (j / p.xcd_nqb) * 8 + (L & 7);
+        if (pair >= p.B * p.H) return;
+        qblk = j % p.xcd_nqb; head = pair % p.H; b = pair / p.H;
+    } else {
+        b = blockIdx.z; head = blockIdx.y; qblk = blockIdx.x;
+    }
     // cross-attention: Q / O rows per sequence differ from K's; packed queries: sequence b owns rows [qoffs[b], qoffs[b+1])
     const int Tq = p.qoffs ? p.qoffs[b + 1] - p.qoffs[b] : (p.Tq > 0 ? p.Tq : p.Tp);
-    if (blockIdx.x * QB >= Tq) return;                   // (uniform per workgroup) nothing to do for this query block
-    const int q = blockIdx.x * QB + wave * 32 + idx;
+    if (qblk * QB >= Tq) return;                         // (uniform per workgroup) nothing to do for this query block
+    const int q = qblk * QB + wave * 32 + idx;
     const int qc = q < Tq ? q : Tq - 1;
     const int klen = p.klens[b];
     // keys: rows [b Tp, b Tp + klen), or with koffs any rows [koffs[b], koffs[b] + klen): tiles then start at the 16-row
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attention_f16x2_kernel(Attn2Arg
             }
     }
     // same wave wrote and reads its slab: no workgroup barrier needed, only the LDS counter (the compiler waits)
-    const int qw0 = blockIdx.x * QB + wave * 32;
+    const int qw0 = qblk * QB + wave * 32;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int rr = it * 4 + (lane >> 4), c8 = (lane & 15) * 8;
@@ -276,32 +289,30 @@ int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
                a.k_plane % 8 == 0 && a.vt_plane % 8 == 0 && a.o_plane % 8 == 0, "attention_f16x2: strides % 8");
     PF_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 && ((uintptr_t)a.O & 15) == 0,
                "attention_f16x2: 16-B alignment");
-    constexpr int LDS4 = (4 * 32 * OLD * 4 > 2 * STAGE_B) ? 4 * 32 * OLD * 4 : 2 * STAGE_B;     // four-wave variant: 67.6 KB
     static bool configured = false;
     if (!configured) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0, 4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0, 8, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<1, 8, true>),
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured = true;
     }
     const int rows = a.Tq > 0 ? a.Tq : a.Tp;
-    if (a.variant == 4)
-        hipLaunchKernelGGL((attention_f16x2_kernel<1, 8, true>), dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
-    else if (a.variant == 3)
-        hipLaunchKernelGGL((attention_f16x2_kernel<0, 8, true>), dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
-    else if (a.variant == 2)
-        hipLaunchKernelGGL((attention_f16x2_kernel<0, 4>), dim3(ceil_div(rows, 128), a.H, a.B), dim3(256), LDS4, stream, a);
+    Attn2Args k = a;
+    PF_REQUIRE(a.variant == 0 || a.variant == 1 || a.variant == 3, "attention_f16x2: variant must be 0, 1 or 3");
+    const int nqb = ceil_div(rows, 256);
+    dim3 grid(nqb, a.H, a.B);
+    // more than one query block per (sequence, head): XCD-aware 1-D order (xcd_nqb < 0 keeps the plain order: measurement hook)
+    k.xcd_nqb = (a.xcd_nqb >= 0 && nqb > 1) ? nqb : 0;
+    if (k.xcd_nqb > 0) grid = dim3((unsigned)(ceil_div(a.B * a.H, 8) * 8 * nqb), 1, 1);
+    if (a.variant == 3)
+        hipLaunchKernelGGL((attention_f16x2_kernel<0, true>), grid, dim3(512), LDS_BYTES, stream, k);
     else if (a.variant == 1)
-        hipLaunchKernelGGL(attention_f16x2_kernel<1>, dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(attention_f16x2_kernel<1>, grid, dim3(512), LDS_BYTES, stream, k);
     else
-        hipLaunchKernelGGL(attention_f16x2_kernel<0>, dim3(ceil_div(rows, 256), a.H, a.B), dim3(512), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(attention_f16x2_kernel<0>, grid, dim3(512), LDS_BYTES, stream, k);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

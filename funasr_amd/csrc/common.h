@@ -112,6 +112,26 @@ __device__ __forceinline__ void store_split2x4(unsigned short* p, size_t plane, 
     *reinterpret_cast<uint2*>(p + plane) = make_uint2(l0, l1);
 }
 
+// ---------------------------------------------------------------- LayerNorm arithmetic shared by layernorm_kernel (rowwise.hip)
+// and the fused residual + LayerNorm epilogue (gemm_f16x2_row.hip): both evaluate exactly these expression trees in the same
+// order (per 4-column chunk, then chunk l + chunk l + 64, then the 64-lane xor butterfly 32, 16, .. 1), so the fused epilogue
+// returns the bits of the stand-alone kernel.
+__device__ __forceinline__ float ln_sum4(const float4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float ln_sqdev4(const float4 v, const float mean) {
+    const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+    return (a * a + b * b) + (cc * cc + d * d);
+}
+__device__ __forceinline__ float ln_mean(const float s, const int D) { return s / (float)D; }
+__device__ __forceinline__ float ln_rstd(const float q, const int D, const float eps) { return 1.0f / sqrtf(q / (float)D + eps); }
+__device__ __forceinline__ float4 ln_apply4(const float4 v, const float mean, const float rstd, const float4 g, const float4 b) {
+    float4 o;
+    o.x = (v.x - mean) * rstd * g.x + b.x;
+    o.y = (v.y - mean) * rstd * g.y + b.y;
+    o.z = (v.z - mean) * rstd * g.z + b.z;
+    o.w = (v.w - mean) * rstd * g.w + b.w;
+    return o;
+}
+
 // ---------------------------------------------------------------- LDS-DMA issued behind the compiler's back
 // hipcc cannot prove that a ds_read does not alias an LDS-DMA in flight (SIInsertWaitcnts only separates them with
 // alias-scope metadata HIP does not attach), so with __builtin_amdgcn_global_load_lds it puts `s_waitcnt vmcnt(0)` in
@@ -122,6 +142,15 @@ __device__ __forceinline__ void store_split2x4(unsigned short* p, size_t plane, 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+// the same with the non-temporal hint: for operand panels exactly one workgroup reads (they should not displace the weight
+// panels every workgroup of the XCD re-reads from its L2)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
@@ -190,6 +219,8 @@ struct Gemm2Args {
     int M, N, K;                                        // K % 32 == 0, N % 4 == 0
     int relu;
     int tile;                                           // 0 = pick by shape, 1 = 256 x 128, 2 = 256 x 256 (measurement hook)
+    int deph;                                           // > 0: de-phased rounds of the 256 x 256 shape (gemm_f16x2.hip DEPH): that many
+                                                        // workgroups (a multiple of 8, typically half the CUs) start with a half tile
     // QKV form (qkv_D > 0, N == 3 qkv_D, qkv_D % 256 == 0, M % 16 == 0): the fused q|k|v projection feeding
     // attention_f16x2.hip. Columns [0, D) -> planes of (result * q_mul) at Qp (ld D); [D, 2D) -> planes of
     // (result * k_mul) at Kp; [2D, 3D) -> fp32 at C (ld ldc; the FSMN memory block reads it) and the TRANSPOSED
@@ -210,6 +241,27 @@ struct Gemm2Args {
 // number of arg-max partials per row launch_gemm_f16x2 writes for an N-column problem
 int gemm_f16x2_argmax_parts(int M, int N);
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream);
+// Full-row form for N == 512 (gemm_f16x2_row.hip): one workgroup per 128 complete rows, epilogue
+//   v = relu?(A W^T * oscale + bias);  v = v + R1;  v = R2 + v;  C = v (fp32, optional);
+//   ln_g != nullptr: y = LayerNorm(v; ln_g, ln_b, ln_eps) -> two fp16 planes of y * yscale at Y2, or fp32 at Yf
+// bitwise equal to launch_gemm_f16x2 followed by launch_layernorm (same products, same summation orders)
+struct GemmRowArgs {
+    const unsigned short* A; int lda; size_t a_plane;   // [2][M, K] fp16
+    const unsigned short* W; int ldw; size_t w_plane;   // [2][512, K] fp16
+    float oscale; const float* oscale_dev;
+    const float* bias;
+    const float* R1; int ldr1;
+    const float* R2; int ldr2;
+    float* C; int ldc;                                  // may alias R1 / R2 (every element is read, then written, by one lane)
+    const float* ln_g; const float* ln_b; float ln_eps;
+    unsigned short* Y2; int ldy2; size_t y_plane; float yscale;
+    float* Yf; int ldyf;
+    int M, N, K;                                        // N == 512, K % 32 == 0
+    int relu;
+    int a_nt;                                           // non-temporal hint on the A panel's loads (measurement hook)
+};
+bool gemm_f16x2_row_applicable(int N, int K);
+int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream);
 // fp32 [M, N] * scale -> two fp16 planes [M, ldy]; columns N..ldy-1 are written as zero
 // seq_out > 0: output row b * seq_out + t holds input row b * seq_in + t for t < seq_in and zeros for the padding rows
 // (M counts OUTPUT rows)
@@ -309,6 +361,7 @@ struct Attn2Args {
     int variant;                                          // kernel schedule (measurement hook), 0 = default
     const int* qoffs;                                     // optional packed queries: sequence b owns rows [qoffs[b], qoffs[b+1]) of
                                                           // Q / O (device int32 [B + 1]); Tq then only sizes the grid
+    int xcd_nqb;                                          // set by the launcher (XCD-aware workgroup order); callers: 0, or -1 = plain order
     const int* koffs;                                     // optional packed keys: sequence b's keys are rows [koffs[b], koffs[b] +
                                                           // klens[b]) of K / V^T, ANY start row (tiles start at the 16-row group
                                                           // below it, the keys of the neighbour in front are masked); Tp unused

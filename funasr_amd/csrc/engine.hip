@@ -308,12 +308,9 @@ static int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3 = f
     AttnArgs f = a;
     f.few_q = 0;
     if (dk != 128) { f.app_rows = 0; return launch_attention_small(f, dk, s); }      // CT-Transformer sized heads
-    static const bool no_x3 = getenv("PF_ATTN_F32") != nullptr;     // A/B switch for measurements
-    if (x3 && !no_x3) { f.app_rows = 0; return launch_attention_split3(f, s); }
-    static const bool no_fewq = getenv("PF_ATTN_NO_FEWQ") != nullptr;   // A/B switch for measurements
-    static const bool no_fuse = getenv("PF_ATTN_NO_APPEND") != nullptr;
-    f.few_q = ((g_stream_mode || g_skinny_max_m > 0) && !no_fewq) ? 1 : 0;   // by caller (streaming step; g_skinny_max_m: test hook)
-    if (!appended || no_fuse || !attention_fuses_append(f)) f.app_rows = 0;
+    if (x3) { f.app_rows = 0; return launch_attention_split3(f, s); }
+    f.few_q = (g_stream_mode || g_skinny_max_m > 0) ? 1 : 0;   // by caller (streaming step; g_skinny_max_m: test hook)
+    if (!appended || !attention_fuses_append(f)) f.app_rows = 0;
     else *appended = true;
     return launch_attention_f32(f, s);
 }
@@ -431,6 +428,11 @@ struct Encoder {
     std::vector<int32_t> h_vad;
     DevBuf vad_dev;
     int cur_mask_mode = 0;              // mask mode of the block being enqueued (AttnArgs.mask_mode)
+    // mode 3: the N = 512 projections (linear_out, w_2) run in their full-row form (gemm_f16x2_row.hip) whose epilogue does
+    // the residual adds AND the LayerNorm that follows (norm2; the NEXT block's norm1), bitwise equal to the separate kernels.
+    // fuse_row = 0 restores the separate launches (A/B measurements, tests)
+    int fuse_row = 1;
+    int attn_variant = 3;               // attention_f16x2.hip schedule (3: lazy rescale)
 };
 
 // exponent e with bound * 2^e <= 2^15 (a factor 2 under fp16's 65504 for the roundings on the way)
@@ -502,8 +504,10 @@ struct EncChunkCtx {
     const int* lens;     // device [B]: every window row is valid in a chunk
 };
 
+// mode 3 only: `xn_ready` = the planes of norm1(x_in) already lie in xn16 (written by the previous block's w_2 epilogue);
+// `next` = the block whose norm1 this block's w_2 epilogue should apply (nullptr: none follows directly)
 static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float* x, int B, int T,
-                         hipStream_t s, const EncChunkCtx* cc = nullptr) {
+                         hipStream_t s, const EncChunkCtx* cc = nullptr, bool xn_ready = false, const EncLayerW* next = nullptr) {
     // EncoderLayerSANM.forward (sanm/encoder.py:72-148), normalize_before, no concat_after
     const pf_encoder_config& c = e->cfg;
     const int M = (e->cur_offs && !cc) ? e->cur_M : B * T, D = c.d_model, F = c.ffn_dim;
@@ -628,7 +632,19 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
             return launch_gemm_f16x2(g, s);
         };
-        {
+        const bool fuse = e->fuse_row && gemm_f16x2_row_applicable(D, D) && gemm_f16x2_row_applicable(D, F);
+        auto gemm_row = [&](const unsigned short* A, int lda, int ea, const unsigned short* W, int ew, const float* bias, int K,
+                            const float* R1, const float* R2, int ldr2, const float* lg, const float* lb, int ey) {
+            GemmRowArgs g{};
+            g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)D * K;
+            g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = D; g.R2 = R2; g.ldr2 = ldr2; g.C = x; g.ldc = D;
+            g.ln_g = lg; g.ln_b = lb; g.ln_eps = c.ln_eps;
+            if (lg) { g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(ey); }
+            g.M = M; g.N = D; g.K = K;
+            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)D * K, s);
+            return launch_gemm_f16x2_row(g, s);
+        };
+        if (!(fuse && xn_ready)) {
             ProfScope ps(PROF_LN, 8.0 * M * (double)w.in_dim, s);
             if ((rc = launch_layernorm(x_in, ld_in, w.n1g, w.n1b, reinterpret_cast<float*>(xn2), w.in_pad, M, w.in_dim,
                                        w.in_pad, c.ln_eps, s, 3, 0, (size_t)M * w.in_pad, pow2f(w.e_x1)))) return rc;
@@ -657,18 +673,27 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             aa.VT = vt2; aa.ldvt = ldvt; aa.vt_plane = (size_t)D * ldvt;
             aa.O = ctx2; aa.ldo = D; aa.o_plane = (size_t)M * D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tp = T;
             aa.sscale = pow2f(-(w.e_q + w.e_k)); aa.oscale = pow2f(-10);      // ctx planes carry v's exponent
-            aa.variant = 1;                                                     // pipelined schedule: ~4 % faster on the self-attention shape
+            aa.variant = e->attn_variant;
             ProfScope ps(PROF_ATTN, 4.0 * B * (double)T * T * D, s);
             if ((rc = launch_attention_f16x2(aa, s))) return rc;
         }
         const float* resid2 = (w.in_dim == D) ? x_in : nullptr;
-        if ((rc = gemm2(ctx2, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid2, ld_in))) return rc;
-        {
+        if (fuse) {
+            // linear_out + fsmn memory + residual -> x, and norm2(x) -> the planes w_1 reads, in one launch
+            if ((rc = gemm_row(ctx2, D, w.e_v, w.out_w2, w.ew_out, w.out_b, D, mem, resid2, ld_in, w.n2g, w.n2b, w.e_x2))) return rc;
+        } else {
+            if ((rc = gemm2(ctx2, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid2, ld_in))) return rc;
             ProfScope ps(PROF_LN, 8.0 * M * (double)D, s);
             if ((rc = launch_layernorm(x, D, w.n2g, w.n2b, reinterpret_cast<float*>(xn2), D, M, D, D, c.ln_eps, s, 3, 0,
                                        (size_t)M * D, pow2f(w.e_x2)))) return rc;
         }
         if ((rc = gemm2(xn2, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
+        if (fuse) {
+            // w_2 + residual -> x, and (when a block follows directly) its norm1(x) -> the planes its QKV projection reads
+            const bool ln = next && next->in_dim == D;
+            return gemm_row(ffn2, F, w.e_h, w.w2_2, w.ew_2, w.b2, F, nullptr, x, D, ln ? next->n1g : nullptr, ln ? next->n1b : nullptr,
+                            ln ? next->e_x1 : 0);
+        }
         return gemm2(ffn2, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D);
     }
     // norm1 -> fused QKV projection
@@ -1205,6 +1230,25 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
 using namespace pf;
 
 // ================================================================================================== C ABI
+// time `iters` launches of fn on s (after 3 warm-up launches); the pf_k_* measurement hooks
+template <class F> static int time_launches(F&& fn, int iters, float* ms_out, hipStream_t s) {
+    int rc;
+    for (int i = 0; i < 3; ++i) if ((rc = fn())) return rc;
+    hipEvent_t a, b;
+    PF_HIP_TRY(hipEventCreate(&a));
+    PF_HIP_TRY(hipEventCreate(&b));
+    PF_HIP_TRY(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if ((rc = fn())) return rc;
+    PF_HIP_TRY(hipEventRecord(b, s));
+    PF_HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    PF_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_out = ms / iters;
+    return 0;
+}
+
 extern "C" {
 
 const char* pf_last_error(void) { return get_error(); }
@@ -1409,6 +1453,18 @@ int pf_encoder_set_precision(pf_encoder* eh, int32_t mode) {
 }
 /* f16x2 mode only: extra_rows >= 0 lays the sequences out back to back and computes min(len_b + extra_rows, T) rows of
  * sequence b -- the rest of out_dev reads as zero; extra_rows < 0 (default) computes every row of [B, T] in the padded layout */
+/* tuning / A-B options of the f16x2 mode: "fuse_row" (1 = linear_out / w_2 in their full-row form with the residual adds and
+ * the following LayerNorm in the epilogue, the default; 0 = separate launches; results are bitwise equal), "attn_variant"
+ * (attention_f16x2.hip schedule: 3 lazy rescale, the default; 1 pipelined; 0 plain) */
+int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
+    Encoder* e = reinterpret_cast<Encoder*>(eh);
+    PF_REQUIRE(e && key, "encoder_set_option: null");
+    const std::string k = key;
+    if (k == "fuse_row") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fuse_row is 0 or 1"); e->fuse_row = value; return 0; }
+    if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
+    set_error("encoder_set_option: unknown key " + k);
+    return -1;
+}
 int pf_encoder_set_row_packing(pf_encoder* eh, int32_t extra_rows) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);
     PF_REQUIRE(e, "encoder_set_row_packing: null handle");
@@ -1561,9 +1617,15 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         e->cur_offs = e->offs_dev.as<int>();
         e->cur_M = (int)M;
         const int total = (int)e->layers.size();
+        bool xn_ready = false;
         for (int l = 0; l < total && !rc; ++l) {
-            rc = l == 0 ? encoder_block(e, e->layers[0], x0, Din, x, B, max_rows, s) : encoder_block(e, e->layers[l], x, D, x, B, max_rows, s);
-            if (!rc && c.tp_blocks > 0 && l + 1 == c.n_blocks)
+            // the next block's norm1 rides in this block's w_2 epilogue unless another op sits between them (SenseVoice's after_norm)
+            const bool boundary = c.tp_blocks > 0 && l + 1 == c.n_blocks;
+            const EncLayerW* next = (l + 1 < total && !boundary) ? &e->layers[l + 1] : nullptr;
+            rc = l == 0 ? encoder_block(e, e->layers[0], x0, Din, x, B, max_rows, s, nullptr, false, next)
+                        : encoder_block(e, e->layers[l], x, D, x, B, max_rows, s, nullptr, xn_ready, next);
+            xn_ready = next != nullptr && next->in_dim == D;
+            if (!rc && boundary)
                 rc = layernorm(x, D, e->tt.get("after_norm.weight"), e->tt.get("after_norm.bias"), x, D, (int)M, D, D, c.ln_eps, s);
         }
         e->cur_offs = nullptr;
@@ -1585,11 +1647,15 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         return 0;
     };
     if (nrun == 0) return unpad_copy(x0, Din);
+    bool xn_ready = false;
     for (int l = 0; l < nrun; ++l) {
         // SANMVadEncoder: `encoders0` and all but the last of `encoders` are causal, the last one takes the VAD corner
         e->cur_mask_mode = e->vad_mask ? ((l >= 1 && l + 1 == total) ? 2 : 1) : 0;
-        if (l == 0) rc = encoder_block(e, e->layers[0], x0, Din, x, B, Tp, s);
-        else rc = encoder_block(e, e->layers[l], x, D, x, B, Tp, s);
+        const bool boundary = c.tp_blocks > 0 && l + 1 == c.n_blocks;
+        const EncLayerW* next = (l + 1 < nrun && !boundary) ? &e->layers[l + 1] : nullptr;
+        if (l == 0) rc = encoder_block(e, e->layers[0], x0, Din, x, B, Tp, s, nullptr, false, next);
+        else rc = encoder_block(e, e->layers[l], x, D, x, B, Tp, s, nullptr, xn_ready, next);
+        xn_ready = next != nullptr && next->in_dim == D;
         e->cur_mask_mode = 0;
         if (rc) return rc;
         if (c.tp_blocks > 0 && l + 1 == c.n_blocks && (run_blocks < 0 || nrun > c.n_blocks)) {
@@ -2120,6 +2186,7 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
                 aa.vt_plane = (size_t)D * (Mkp + 64); aa.O = d->ctx16.as<unsigned short>(); aa.ldo = D; aa.o_plane = (size_t)Mq * D;
                 aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tp = Tp; aa.Tq = N; aa.qoffs = offs_dev;
                 aa.sscale = pow2f(-w.e_q); aa.sscale_dev = lsc + 2; aa.oscale = pow2f(-10);        // ctx planes carry v's scale
+                aa.variant = 3;                                                                   // lazy rescale (attention_f16x2.hip)
                 ProfScope ps(PROF_ATTN, 4.0 * B * (double)N * T * D, s);
                 if ((rc = launch_attention_f16x2(aa, s))) return rc;
             }
@@ -2246,6 +2313,7 @@ void pf_ctc_destroy(pf_ctc* c) { delete reinterpret_cast<Ctc*>(c); }
 int pf_ctc_set_tensor(pf_ctc* ch, const char* name, const float* data, int64_t numel) {
     Ctc* c = reinterpret_cast<Ctc*>(ch);
     PF_REQUIRE(c && name && data, "ctc_set_tensor: null");
+    c->tt.drop_bf16();          // the f16x2 arg-max route caches weight planes: they follow the fp32 master
     return c->tt.set(name, data, numel);
 }
 int pf_ctc_missing(const pf_ctc* ch) {
@@ -2740,6 +2808,7 @@ int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2
     g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
     g.C2 = reinterpret_cast<unsigned short*>(C2); g.ldc2 = ldc2; g.c_plane = (size_t)c_plane; g.cscale = cscale;
     g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = tile;
+    if ((tile & 0xff) == 8) { g.tile = 0; g.deph = (tile >> 8) * 8; }       // tile = 8 + 256 n: de-phased rounds, 8 n half-tile workgroups
     int rc;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2(g, s);
     for (int i = 0; i < 3; ++i) if ((rc = launch_gemm_f16x2(g, s))) return rc;
@@ -2772,7 +2841,8 @@ int pf_k_attention_f16x2(const void* Q2, int64_t q_plane, const void* K2, int64_
     aa.K = reinterpret_cast<const unsigned short*>(K2); aa.ldk = D; aa.k_plane = (size_t)k_plane;
     aa.VT = reinterpret_cast<const unsigned short*>(VT2); aa.ldvt = ldvt; aa.vt_plane = (size_t)vt_plane;
     aa.O = reinterpret_cast<unsigned short*>(O2); aa.ldo = D; aa.o_plane = (size_t)o_plane;
-    aa.klens = klens_dev; aa.B = B; aa.H = H; aa.Tp = Tp; aa.Tq = Tq; aa.sscale = sscale; aa.oscale = oscale; aa.variant = variant;
+    aa.klens = klens_dev; aa.B = B; aa.H = H; aa.Tp = Tp; aa.Tq = Tq; aa.sscale = sscale; aa.oscale = oscale;
+    aa.variant = variant & 15; aa.xcd_nqb = (variant & 16) ? -1 : 0;          // + 16: plain (not XCD-aware) workgroup order
     int rc;
     if (iters <= 0 || !ms_out) return launch_attention_f16x2(aa, s);
     for (int i = 0; i < 3; ++i) if ((rc = launch_attention_f16x2(aa, s))) return rc;
@@ -2789,6 +2859,62 @@ int pf_k_attention_f16x2(const void* Q2, int64_t q_plane, const void* K2, int64_
     (void)hipEventDestroy(b);
     *ms_out = ms / iters;
     return 0;
+}
+/* full-row form (gemm_f16x2_row.hip), N = 512: v = relu?(A W^T oscale + bias) + R1, R2 + v -> C (fp32, optional); with ln_g:
+ * LayerNorm(v) -> planes of y * yscale at Y2 (ld 512, planes y_plane apart) or fp32 at Yf (ld 512) */
+int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                        const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc,
+                        const float* ln_g, const float* ln_b, float ln_eps, void* Y2, int64_t y_plane, float yscale, float* Yf,
+                        int32_t M, int32_t K, int32_t relu, int32_t a_nt, int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GemmRowArgs g{};
+    g.A = reinterpret_cast<const unsigned short*>(A2); g.lda = lda; g.a_plane = (size_t)a_plane;
+    g.W = reinterpret_cast<const unsigned short*>(W2); g.ldw = ldw; g.w_plane = (size_t)w_plane; g.oscale = oscale;
+    g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
+    g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
+    g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K; g.relu = relu; g.a_nt = a_nt;
+    if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
+    return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
+}
+/* LayerNorm with the two-plane fp16 output the f16x2 GEMMs consume (planes of y * scale, `plane` elements apart, ld ldy) */
+int pf_k_layernorm_planes(const float* x, int32_t ldx, const float* gamma, const float* beta, void* y2, int32_t ldy, int64_t plane,
+                          float scale, int32_t M, int32_t D, float eps, int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    auto fn = [&] { return launch_layernorm(x, ldx, gamma, beta, reinterpret_cast<float*>(y2), ldy, M, D, ldy, eps, s, 3, 0, (size_t)plane, scale); };
+    if (iters <= 0 || !ms_out) return fn();
+    return time_launches(fn, iters, ms_out, s);
+}
+/* the QKV form (kv_form = 0: N = 3 D -> Q planes, K planes, fp32 V, V^T planes) and the KV form (kv_form = 1: N = 2 D -> K
+ * planes, V^T planes) of gemm_f16x2.hip; Qp / Kp planes are qk_plane apart (ld D), VT [2][D, ldvt] vt_plane apart */
+int pf_k_gemm_f16x2_qkv(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                        const float* bias, int32_t M, int32_t D, int32_t K, int32_t kv_form, void* Qp, void* Kp, int64_t qk_plane,
+                        float* Vf, void* VT, int32_t ldvt, int64_t vt_plane, float q_mul, float k_mul, float v_mul,
+                        int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Gemm2Args g{};
+    g.A = reinterpret_cast<const unsigned short*>(A2); g.lda = lda; g.a_plane = (size_t)a_plane;
+    g.W = reinterpret_cast<const unsigned short*>(W2); g.ldw = ldw; g.w_plane = (size_t)w_plane; g.oscale = oscale; g.bias = bias;
+    g.C = Vf; g.ldc = D; g.M = M; g.N = (kv_form ? 2 : 3) * D; g.K = K; g.qkv_D = D; g.kv_form = kv_form;
+    g.Qp = reinterpret_cast<unsigned short*>(Qp); g.Kp = reinterpret_cast<unsigned short*>(Kp); g.qk_plane = (size_t)qk_plane;
+    g.VT = reinterpret_cast<unsigned short*>(VT); g.ldvt = ldvt; g.vt_plane = (size_t)vt_plane;
+    g.q_mul = q_mul; g.k_mul = k_mul; g.v_mul = v_mul;
+    if (iters <= 0 || !ms_out) return launch_gemm_f16x2(g, s);
+    return time_launches([&] { return launch_gemm_f16x2(g, s); }, iters, ms_out, s);
+}
+/* the fused arg-max form (vocabulary / CTC projections): ids[row] = argmax_n (A W^T oscale + bias)[row, n], lowest index on ties;
+ * sval / sidx: scratch [M, 2 ceil(N / 256)] */
+int pf_k_gemm_f16x2_argmax(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                           const float* bias, int32_t M, int32_t N, int32_t K, int32_t* ids, float* sval, int32_t* sidx,
+                           void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(ids && sval && sidx, "gemm_f16x2_argmax: scratch required");
+    Gemm2Args g{};
+    g.A = reinterpret_cast<const unsigned short*>(A2); g.lda = lda; g.a_plane = (size_t)a_plane;
+    g.W = reinterpret_cast<const unsigned short*>(W2); g.ldw = ldw; g.w_plane = (size_t)w_plane; g.oscale = oscale; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.amax_val = sval; g.amax_idx = sidx; g.amax_ld = gemm_f16x2_argmax_parts(M, N);
+    int rc;
+    if ((rc = launch_gemm_f16x2(g, s))) return rc;
+    return launch_argmax_reduce(sval, sidx, g.amax_ld, g.amax_ld, ids, nullptr, M, s);
 }
 /* fp32 -> bf16 (round to nearest even), n elements */
 int pf_k_cast_bf16(const float* x, void* y, int64_t n, void* stream) {

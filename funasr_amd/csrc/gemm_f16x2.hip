@@ -40,35 +40,51 @@ template <int WM, int WN, int WGM = 4> struct Geo2 {
 };
 
 // ABL (measurement only, tools/bench_gemm2.py): 1 = no global stores in the epilogue, 2 = no epilogue, 3 = no operand DMA
-template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4>   // OUT: 0 fp32 C, 1 two fp16 planes, 2 the QKV form (Gemm2Args)
+// DEPH (de-phased rounds, Gemm2Args.deph > 0): every CU holds one workgroup, so the workgroups of a round start together, run
+// the same k-loop and reach their epilogues together -- the output of a whole round (tens of MB) hits HBM as one burst while
+// the matrix pipes idle, round after round. With DEPH the first `deph` workgroups of the grid compute only the UPPER half
+// (rows 0..127: the waves of the two upper wave rows, one per SIMD -- half the time) of their tile and `deph` extra
+// workgroups at the END of the grid compute the lower halves: the CUs that drew a half tile run half a tile period out of
+// phase with the others from then on, so one half of the chip stores while the other half multiplies. Same products, same k
+// order per output element: bitwise equal to the plain order (tested).
+template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, bool DEPH = false>   // OUT: 0 fp32 C, 1 two fp16 planes, 2 the QKV form (Gemm2Args)
 __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM, int nN) {
     typedef Geo2<WM, WN, WGM> G;
     constexpr int BM = G::BM, BN = G::BN, KS = G::KS, ROWB = G::ROWB, CPR = G::CPR, RPP = G::RPP, PPW = G::PPW;
     constexpr int STAGE_B = G::STAGE_B, A_PLANE_B = G::A_PLANE_B, B_PLANE_B = G::B_PLANE_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int L = blockIdx.x;
+    int L = blockIdx.x;
+    int half = 0;                                   // DEPH: 0 = whole tile, 1 = its rows 0..BM/2-1, 2 = its rows BM/2..BM-1
+    if constexpr (DEPH) {
+        const int T = (nM + 7) / 8 * 8 * nN;
+        if (L < p.deph) half = 1;
+        else if (L >= T) { half = 2; L -= T; }
+    }
     const int xcd = L & 7, j8 = L >> 3;
     const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
     if (mblk >= nM) return;
-    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int m0 = mblk * BM + (half == 2 ? BM / 2 : 0), n0 = nblk * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int hh = lane >> 5, idx = lane & 31;
+    const bool act = !DEPH || half == 0 || wr < WGM / 2;   // (wave-uniform) a half tile is the work of the upper wave rows
 
     // ---- DMA sources: a stage is NPIECE pieces of 1 KB (16 rows of one plane), the A planes first, then the W planes,
     //      linear in LDS; wave w issues pieces w, w + 8, ...; lane l lands at row l / 4, physical chunk l % 4 and
     //      fetches the logical chunk the read-side swizzle expects there
     const unsigned short* src[PPW];
+    bool skip[PPW];                                 // DEPH: A pieces of the rows a half tile does not compute
     {
         const int prow = lane / CPR;
         const int chunk = (lane % CPR) ^ ((prow >> 2) & (CPR - 1));
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int q = wave + G::NW * i;
+            skip[i] = DEPH && half != 0 && q < G::A_PIECES && (q % (BM / RPP)) >= BM / RPP / 2;
             if (q < G::A_PIECES) {
                 int row = m0 + (q % (BM / RPP)) * RPP + prow;
                 row = row < p.M ? row : p.M - 1;
@@ -84,6 +100,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
     auto piece = [&](int i, int buf, int kt) {
         if constexpr (ABL == 3) return;
+        if constexpr (DEPH) { if (skip[i]) return; }
         glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * (G::NW * 1024));
     };
 
@@ -133,6 +150,9 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
             PF_PROD(1, 0); PF_PIECE(5); PF_PIECE(6);
             PF_PROD(0, 1); PF_PIECE(7);
             PF_PROD(0, 0);
+        } else if (!act) {
+            // idle wave rows of a half tile: the DMA pieces only
+            PF_PIECE(0); PF_PIECE(1); PF_PIECE(2); PF_PIECE(3); PF_PIECE(4); PF_PIECE(5); PF_PIECE(6); PF_PIECE(7);
         } else {
             // both k-steps' fragments are requested before the first MFMA: one LDS-latency bubble per stage instead of two
             f16x8 a[WM][2], b[WN][2], a1[WM][2], b1[WN][2];
@@ -220,6 +240,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     constexpr int RPS = 64 / LPR;            // rows per pass
     constexpr int NPASS = 32 / RPS;
     __syncthreads();
+    if constexpr (DEPH) { if (!act) return; }
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ELD);
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int col = n0 + wc * (WN * 32) + c4 * 4;
@@ -316,233 +337,6 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent form of the 256 x 256 shape for FULL tiles (M % 256 == 0, N % 256 == 0, K / 32 even): one workgroup per CU
-// walks tiles L = blockIdx.x, + gridDim.x, ... The measured cost of the epilogue is not issuing the stores (an L2-resident
-// target makes them free, tools/abl_gemm2.py `l2store`) but waiting for them to drain before the CU can take its next
-// block -- every CU finishes a round together, so each round ends in an HBM write burst with the matrix pipe idle. Here the
-// wave goes on to the next tile while its stores drain:
-//   * the next tile's stage 0 is prefetched during the last k-stage, its stage 1 right after it, i.e. BEFORE any store of
-//     this tile is issued: the VMEM queue retires in order, so `s_waitcnt vmcnt(#stores)` at the next tile's first stage waits
-//     for exactly those DMAs and for no store (the stores are unconditional on full tiles: their count is a constant);
-//   * the first vmcnt(0) that has stores in front of it comes two k-stages later;
-//   * the epilogue transposes one 32 x 32 accumulator tile at a time through a wave-private 4-KB slab in the 32 KB of LDS the
-//     two 64-KB stages leave free (nothing aliases the stage buffers, no workgroup barrier inside the epilogue).
-// Same products in the same k order as gemm_f16x2_kernel: bitwise-equal results (tested).
-constexpr int P_STAGE_B = 2 * (256 + 256) * 64;          // 64 KB
-constexpr int P_SLAB_OFF = 2 * P_STAGE_B;                // 128 KB
-constexpr int P_LDS_B = P_SLAB_OFF + 8 * 4096;           // 160 KB
-
-template <int NST> __device__ __forceinline__ void wait_dma_before_stores() {
-    // at most NST younger ops (this wave's stores) may still be outstanding: everything older -- the DMAs -- has landed
-    if constexpr (NST >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-}
-
-template <int MODE, int OUT>   // MODE: 0 or 2 (R2 residual); OUT: 0 fp32, 1 planes, 2 QKV / KV form
-__global__ __launch_bounds__(512, 2) void gemm_f16x2_persist_kernel(Gemm2Args p, int nM, int nN, int ntiles) {
-    constexpr int WM = 2, WN = 4, BM = 256, BN = 256, KS = 32, ROWB = 64, RPP = 16, PPW = 8;
-    constexpr int A_PLANE_B = BM * ROWB, B_PLANE_B = BN * ROWB, STAGE_B = P_STAGE_B;
-    constexpr int NSTORE = OUT == 0 ? 32 : 64;           // store instructions per wave per tile (see the epilogue)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int hh = lane >> 5, idx = lane & 31;
-    const int prow = lane >> 2;
-    const int chunk = (lane & 3) ^ ((prow >> 2) & 3);
-
-    // tile L -> (mblk, nblk) as in gemm_f16x2_kernel; gridDim.x is a multiple of 8, so a workgroup stays on one XCD's rows
-    auto tile_of = [&](int L, int& mblk, int& nblk) {
-        const int xcd = L & 7, j8 = L >> 3;
-        mblk = (j8 / nN) * 8 + xcd; nblk = j8 % nN;
-        return mblk < nM;
-    };
-    auto next_valid = [&](int L) {
-        int mb, nb;
-        for (L += gridDim.x; L < ntiles; L += gridDim.x) if (tile_of(L, mb, nb)) return L;
-        return -1;
-    };
-    const unsigned short* src[PPW];
-    auto set_src = [&](int mblk, int nblk) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int q = wave + 8 * i;                  // pieces 0..31: A planes, 32..63: W planes
-            if (q < 32) src[i] = p.A + (size_t)(q >> 4) * p.a_plane + (size_t)(mblk * BM + (q & 15) * RPP + prow) * p.lda + chunk * 8;
-            else src[i] = p.W + (size_t)((q - 32) >> 4) * p.w_plane + (size_t)(nblk * BN + ((q - 32) & 15) * RPP + prow) * p.ldw + chunk * 8;
-        }
-    };
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
-    auto piece = [&](int i, int buf, int kt) { glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * 8192); };
-
-    const int f = (idx >> 2) & 3;
-    const int aoff = (wr * 64 + idx) * ROWB;
-    const int boff = 2 * A_PLANE_B + (wc * 128 + idx) * ROWB;
-    int coff[2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st) coff[st] = ((2 * st + hh) ^ f) * 16;
-    const int nk = p.K / KS;
-    float* slab = reinterpret_cast<float*>(smem + P_SLAB_OFF) + wave * 1024;
-    const float oscale = p.oscale_dev ? p.oscale * *p.oscale_dev : p.oscale;
-
-    int L = blockIdx.x, mblk = 0, nblk = 0;
-    if (L >= ntiles) return;
-    if (!tile_of(L, mblk, nblk)) { L = next_valid(L); if (L < 0) return; tile_of(L, mblk, nblk); }
-    set_src(mblk, nblk);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) piece(i, 0, 0);
-    bool pre1 = false;                                   // stage 1 of the current tile already issued (by the previous epilogue)
-
-    while (true) {
-        const int m0 = mblk * BM, n0 = nblk * BN;
-        const int Lnext = next_valid(L);
-        int mnext = 0, nnext = 0;
-        if (Lnext >= 0) tile_of(Lnext, mnext, nnext);
-        floatx16 acc[WM][WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int jj = 0; jj < WN; ++jj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
-
-        for (int kt = 0; kt < nk; ++kt) {
-            // stages 0 and 1 of a prefetched tile are older than every store in flight: a counted wait covers both, stage 1
-            // then needs no wait at all; from stage 2 on the queue is drained as in the plain kernel
-            if (pre1) { if (kt == 0) wait_dma_before_stores<NSTORE>(); else if (kt >= 2) glds_wait_all(); }
-            else glds_wait_all();
-            __syncthreads();
-            const bool last = kt + 1 == nk;
-            const bool issue = last ? (Lnext >= 0) : !(kt == 0 && pre1);
-            const int nb = (kt + 1) & 1;                                // nk is even: the next tile's stage 0 lands in buffer 0
-            if (last && issue) set_src(mnext, nnext);                   // this tile's pieces are all issued: reuse the registers
-            const int kn = last ? 0 : kt + 1;
-            const unsigned char* sb = smem + (kt & 1) * STAGE_B;
-#define PP_PIECE(I) do { if (issue) piece(I, nb, kn); } while (0)
-#define PP_PROD(PA, PB)                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                  \
-        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA], b[jj][PB], acc[i][jj], 0, 0, 0)
-#define PP_LOAD(S)                                                                                                    \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                                \
-        _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                                \
-            a[i][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * A_PLANE_B + aoff + i * 32 * ROWB + coff[S]));   \
-        _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                                                             \
-            b[jj][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[S])); \
-    }
-            f16x8 a[WM][2], b[WN][2];
-            PP_LOAD(0)
-            PP_PROD(1, 0); PP_PIECE(0); PP_PIECE(1);
-            PP_PROD(0, 1); PP_PIECE(2); PP_PIECE(3);
-            PP_PROD(0, 0); PP_PIECE(4);
-            PP_LOAD(1)
-            PP_PROD(1, 0); PP_PIECE(5); PP_PIECE(6);
-            PP_PROD(0, 1); PP_PIECE(7);
-            PP_PROD(0, 0);
-#undef PP_PROD
-#undef PP_LOAD
-        }
-#undef PP_PIECE
-        // ---- epilogue. Every VMEM LOAD it needs (the bias) is issued first: a load placed between stores could only be
-        //      waited for together with every older store. Then -- every wave is done with both stage buffers after the
-        //      barrier -- buffer 1 takes the next tile's stage 1, issued like stage 0 above before any store of this tile.
-        const int c4 = lane & 7, rsub = lane >> 3;
-        const int seg = OUT == 2 ? n0 / p.qkv_D + (p.kv_form ? 1 : 0) : 0;
-        float4 bias4[WN];
-        float bvv[WN][2];
-#pragma unroll
-        for (int jj = 0; jj < WN; ++jj) {
-            bias4[jj] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + wc * 128 + jj * 32 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps)
-                bvv[jj][ps] = (OUT == 2 && seg == 2 && p.bias) ? p.bias[n0 + wc * 128 + jj * 32 + ps * 16 + (lane >> 2)] : 0.f;
-        }
-        // the compiler does not see the asm-issued DMAs: make it consume the loads (its own vmcnt wait) before they are issued
-        asm volatile("" :: "v"(bias4[0].x), "v"(bias4[1].x), "v"(bias4[2].x), "v"(bias4[3].x), "v"(bvv[0][0]), "v"(bvv[3][1]));
-        pre1 = false;
-        if (Lnext >= 0) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) piece(i, 1, 1);
-            pre1 = true;
-        }
-
-        // one 32 x 32 tile at a time through the wave-private slab [32][32] (row stride 128 B: the 16 column writes of a lane
-        // and the float4 row reads are conflict-free); lane -> row rsub + 8 pass, columns 4 c4 .. 4 c4 + 3
-        float k_mul = p.k_mul, v_mul = p.v_mul;
-        if constexpr (OUT == 2) {
-            if (p.kv_mul_dev) { k_mul *= p.kv_mul_dev[0]; v_mul *= p.kv_mul_dev[1]; }
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-#pragma unroll
-            for (int jj = 0; jj < WN; ++jj) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + idx] = acc[i][jj][r];
-                const int col = n0 + wc * 128 + jj * 32 + c4 * 4;
-                const int scol = OUT == 2 ? col - (n0 / p.qkv_D) * p.qkv_D : col;
-                const float4 b4 = bias4[jj];
-                float4 v[4], r2[4];
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) v[ps] = *reinterpret_cast<const float4*>(slab + (rsub + 8 * ps) * 32 + c4 * 4);
-                const int row0 = m0 + wr * 64 + i * 32 + rsub;
-                if constexpr (MODE == 2) {
-#pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) r2[ps] = *reinterpret_cast<const float4*>(p.R2 + (size_t)(row0 + 8 * ps) * p.ldr2 + col);
-                }
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    const int row = row0 + 8 * ps;
-                    float o[4] = {v[ps].x * oscale + b4.x, v[ps].y * oscale + b4.y, v[ps].z * oscale + b4.z, v[ps].w * oscale + b4.w};
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-                    }
-                    if constexpr (MODE == 2) { o[0] = r2[ps].x + o[0]; o[1] = r2[ps].y + o[1]; o[2] = r2[ps].z + o[2]; o[3] = r2[ps].w + o[3]; }
-                    if constexpr (OUT == 2) {
-                        // 2 stores per pass on every path (q / k: two planes; v: fp32 + below two V^T stores per pass)
-                        if (seg == 0) store_split2x4(p.Qp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.q_mul);
-                        else if (seg == 1) store_split2x4(p.Kp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, k_mul);
-                        else if (p.C) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + scol) = make_float4(o[0], o[1], o[2], o[3]);
-                    } else if constexpr (OUT == 1) {
-                        store_split2x4(p.C2 + (size_t)row * p.ldc2 + col, p.c_plane, o, p.cscale);
-                    } else {
-                        *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                }
-                if constexpr (OUT == 2) {
-                    if (seg == 2) {
-                        // V^T planes from the same slab, read column-wise: a 16-B piece = column nl, rows {0..3, 8..11} + 4 half
-                        // of the 16-row group G (attention_f16x2.hip); 128 pieces per tile, two per lane
-                        const int vc0 = n0 - (p.kv_form ? 1 : 2) * p.qkv_D + wc * 128 + jj * 32;
-#pragma unroll
-                        for (int ps = 0; ps < 2; ++ps) {
-                            const int pc = ps * 64 + lane;
-                            const int nl = pc >> 2, G = (pc >> 1) & 1, half = pc & 1;
-                            const int rb = 16 * G + 4 * half;
-                            const float bv = bvv[jj][ps];
-                            float t[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) t[j] = (slab[(rb + (j & 3) + 8 * (j >> 2)) * 32 + nl] * oscale + bv) * v_mul;
-                            uint4 h, l;
-                            split2_pk(t[0], t[1], h.x, l.x);
-                            split2_pk(t[2], t[3], h.y, l.y);
-                            split2_pk(t[4], t[5], h.z, l.z);
-                            split2_pk(t[6], t[7], h.w, l.w);
-                            unsigned short* vp = p.VT + (size_t)(vc0 + nl) * p.ldvt + m0 + wr * 64 + i * 32 + 16 * G + 8 * half;
-                            *reinterpret_cast<uint4*>(vp) = h;
-                            *reinterpret_cast<uint4*>(vp + p.vt_plane) = l;
-                        }
-                    }
-                }
-            }
-        }
-        if (Lnext < 0) break;
-        L = Lnext; mblk = mnext; nblk = nnext;
-    }
-}
-
 // fp32 [M, N] (row stride ldx) * scale -> two fp16 planes [M, ldy] (`plane` elements apart); columns N..ldy are zero
 __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ y,
                                                      int ldy, size_t plane, int M, int N, float scale,
@@ -592,21 +386,27 @@ __global__ __launch_bounds__(256) void rowl1_bound_kernel(const float* __restric
     if (lane == 0) atomicMax(out, __builtin_bit_cast(unsigned, bnd));
 }
 
-template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4>
+template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, bool DEPH = false>
 int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     typedef Geo2<WM, WN, WGM> G;
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM>),
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, DEPH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
         configured = true;
     }
     const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
     const int nMpad = (nM + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM>), dim3((unsigned)nMpad * nN), dim3(WGM * 128), G::LDS_B, stream, a, nM, nN);
+    Gemm2Args k = a;
+    if (DEPH) k.deph = a.deph / 8 * 8 < nMpad * nN ? a.deph / 8 * 8 : nMpad * nN;      // whole XCD groups, at most every tile
+    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, DEPH>), dim3((unsigned)(nMpad * nN + (DEPH ? k.deph : 0))),
+                       dim3(WGM * 128), G::LDS_B, stream, k, nM, nN);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
+// de-phased form of the wide shape (Gemm2Args.deph > 0, N % 256 == 0)
+template <int MODE, int OUT>
+int launch_deph(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 2, 4, true>(a, stream); }
 template <int MODE, int OUT>
 int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
@@ -704,33 +504,6 @@ int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* 
     return 0;
 }
 
-// the persistent form serves full-tile problems that give every CU more than one tile. Measured: alone it
-// hides about half of the end-of-block store drain (qkv 166 -> 152 us at M = 32768), the same gain the SCHED 2
-// fragment order reaches without it (149 us); in the engine the two are level (42.19 vs 42.16 ms of GEMM per step), so
-// the one-tile-per-block kernel stays the default and this form is opt-in (PF_GEMM_PERSIST=1) for further work.
-static bool persist_ok(const Gemm2Args& a) {
-    static const bool on = getenv("PF_GEMM_PERSIST") != nullptr;
-    if (!on || a.tile == 2 || a.tile == 1) return false;
-    if (a.M % 256 || a.N % 256 || (a.K / 32) % 2 || a.R1 || a.R2 || a.amax_val) return false;   // loads between stores would serialise them
-    if (a.qkv_D > 0 && a.kv_form && !a.C) { /* V^T only: still 64 stores (fp32 path absent) -> not a constant: skip */ return false; }
-    return (long)(a.M / 256) * (a.N / 256) > 256;
-}
-template <int MODE, int OUT>
-static int launch_persist(const Gemm2Args& a, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_persist_kernel<MODE, OUT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_B));
-        configured = true;
-    }
-    const int nM = a.M / 256, nN = a.N / 256;
-    const int ntiles = (nM + 7) / 8 * 8 * nN;
-    const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL((gemm_f16x2_persist_kernel<MODE, OUT>), dim3((unsigned)grid), dim3(512), P_LDS_B, stream, a, nM, nN, ntiles);
-    PF_HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 int gemm_f16x2_argmax_parts(int M, int N) { (void)M; return 2 * ceil_div(N, 256); }
 
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
@@ -758,19 +531,16 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         PF_REQUIRE((a.kv_form || (a.Qp && a.C)) && a.Kp && a.VT && a.ldvt % 8 == 0 && a.vt_plane % 8 == 0 && a.qk_plane % 8 == 0 &&
                    ((uintptr_t)a.Qp & 15) == 0 && ((uintptr_t)a.Kp & 15) == 0 && ((uintptr_t)a.VT & 15) == 0,
                    "gemm_f16x2: QKV outputs");
-        if (persist_ok(a)) return launch_persist<0, 2>(a, stream);
+        if (a.deph > 0) return launch_deph<0, 2>(a, stream);
         return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);
     }
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");
-        if (persist_ok(a)) return launch_persist<0, 1>(a, stream);
+        if (a.deph > 0 && a.N % 256 == 0) return launch_deph<0, 1>(a, stream);
         return launch_one<0, 1>(a, stream);
     }
-    const bool shape_ok = a.M % 256 == 0 && a.N % 256 == 0 && (a.K / 32) % 2 == 0 && !a.R1;
-    if ((a.tile == 4 && shape_ok) || (a.tile == 0 && persist_ok(a))) {
-        if (mode == 0) return launch_persist<0, 0>(a, stream);
-        if (mode == 2) return launch_persist<2, 0>(a, stream);
-    }
+    if (a.deph > 0 && a.N % 256 == 0 && (mode == 0 || mode == 2))
+        return mode == 0 ? launch_deph<0, 0>(a, stream) : launch_deph<2, 0>(a, stream);
     switch (mode) {
         case 0: return launch_one<0, 0>(a, stream);
         case 1: return launch_one<1, 0>(a, stream);

@@ -50,24 +50,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + 64 * j;
         if (c < nchunk) {
             v[j] = load4(x, (size_t)xrow * ldx + 4 * c, in_bf16 != 0);
-            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            s += ln_sum4(v[j]);
         } else {
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     s = wave_sum(s);
-    const float mean = s / (float)D;
+    const float mean = ln_mean(s, D);
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane + 64 * j;
-        if (c < nchunk) {
-            const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
-            q += (a * a + b * b) + (cc * cc + d * d);
-        }
+        if (c < nchunk) q += ln_sqdev4(v[j], mean);
     }
     q = wave_sum(q);
-    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    const float rstd = ln_rstd(q, D, eps);
     float* yr = y + (size_t)row * ldy;
     unsigned short* yb = reinterpret_cast<unsigned short*>(y) + (size_t)row * ldy;     // bf16 view (ldy in elements)
 #pragma unroll
@@ -77,10 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (c < nchunk) {
             const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
             const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c);
-            o.x = (v[j].x - mean) * rstd * g.x + b.x;
-            o.y = (v[j].y - mean) * rstd * g.y + b.y;
-            o.z = (v[j].z - mean) * rstd * g.z + b.z;
-            o.w = (v[j].w - mean) * rstd * g.w + b.w;
+            o = ln_apply4(v[j], mean, rstd, g, b);
         }
         if (4 * c < Dpad) {
             if constexpr (OUT == 3) {

@@ -294,6 +294,95 @@ def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=N
     return (out, float(ms.value)) if time_iters > 0 else out
 
 
+def gemm_f16x2_row(a2: torch.Tensor, w2: torch.Tensor, bias=None, add1=None, add2=None, scale_exp: int = 0, relu=False,
+                   ln=None, out_scale_exp: int = 0, ln_planes: bool = True, want_c: bool = True, a_nt: bool = False,
+                   time_iters: int = 0):
+    """Full-row form (gemm_f16x2_row.hip, N = 512): c = relu?(a w^T + bias) + add1, add2 + c; with ln = (gamma, beta, eps)
+    also y = LayerNorm(c) as fp16 planes [2, M, 512] of y * 2**out_scale_exp (ln_planes) or fp32 [M, 512].
+    Returns (c or None, y or None[, ms])."""
+    lib = _lib.load()
+    assert a2.dtype == torch.float16 and w2.dtype == torch.float16 and a2.is_contiguous() and w2.is_contiguous()
+    _, M, K = a2.shape
+    assert w2.shape[1] == 512 and w2.shape[2] == K
+    dev = a2.device
+    c = torch.empty(M, 512, device=dev, dtype=torch.float32) if (want_c or ln is None) else None
+    y2 = yf = None
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln
+        if ln_planes:
+            y2 = torch.empty(2, M, 512, device=dev, dtype=torch.float16)
+        else:
+            yf = torch.empty(M, 512, device=dev, dtype=torch.float32)
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_gemm_f16x2_row(_ptr(a2), K, M * K, _ptr(w2), K, 512 * K, float(2.0 ** -scale_exp), _ptr(bias),
+                                       _ptr(add1), add1.stride(0) if add1 is not None else 0,
+                                       _ptr(add2), add2.stride(0) if add2 is not None else 0,
+                                       _ptr(c), 512, _ptr(g), _ptr(b), float(eps), _ptr(y2), M * 512, float(2.0 ** out_scale_exp),
+                                       _ptr(yf), M, K, int(relu), int(a_nt), int(time_iters), C.byref(ms), _stream()),
+               "pf_k_gemm_f16x2_row")
+    y = y2 if y2 is not None else yf
+    return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
+
+
+def layernorm_planes(x: torch.Tensor, gamma, beta, eps: float, scale_exp: int = 0, time_iters: int = 0):
+    """LayerNorm over the last dim of fp32 [M, D] -> fp16 planes [2, M, D] of y * 2**scale_exp (layernorm_kernel, plane output)."""
+    lib = _lib.load()
+    M, D = x.shape
+    assert x.stride(1) == 1
+    y = torch.empty(2, M, D, device=x.device, dtype=torch.float16)
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_layernorm_planes(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(y), D, M * D, float(2.0 ** scale_exp),
+                                         M, D, float(eps), int(time_iters), C.byref(ms), _stream()), "pf_k_layernorm_planes")
+    return (y, float(ms.value)) if time_iters > 0 else y
+
+
+def vt_columns(m: torch.Tensor) -> torch.Tensor:
+    """column of V^T that holds row m: bits 2 and 3 of the row index swapped (attention_f16x2.hip)"""
+    return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1)
+
+
+def gemm_f16x2_qkv(a2: torch.Tensor, w2: torch.Tensor, bias, D: int, scale_exp: int, q_mul: float, k_mul: float, v_mul: float,
+                   kv_form: bool = False, time_iters: int = 0):
+    """QKV form (w2 [2, 3 D, K]) / KV form (w2 [2, 2 D, K]) of gemm_f16x2: returns dict(q2, k2 planes [2, M + 32, D] (q2 None in
+    the KV form), v fp32 [M, D] (None in the KV form), vt planes [2, D, M + 64])."""
+    lib = _lib.load()
+    _, M, K = a2.shape
+    dev = a2.device
+    nseg = 2 if kv_form else 3
+    assert w2.shape[1] == nseg * D and M % 16 == 0
+    q2 = None if kv_form else torch.zeros(2, M + 32, D, device=dev, dtype=torch.float16)
+    k2 = torch.zeros(2, M + 32, D, device=dev, dtype=torch.float16)
+    v = None if kv_form else torch.empty(M, D, device=dev, dtype=torch.float32)
+    ldvt = M + 64
+    vt = torch.zeros(2, D, ldvt, device=dev, dtype=torch.float16)
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_gemm_f16x2_qkv(_ptr(a2), K, M * K, _ptr(w2), K, nseg * D * K, float(2.0 ** -scale_exp), _ptr(bias), M, D, K,
+                                       int(kv_form), _ptr(q2), _ptr(k2), (M + 32) * D, _ptr(v), _ptr(vt), ldvt, D * ldvt,
+                                       float(q_mul), float(k_mul), float(v_mul), int(time_iters), C.byref(ms), _stream()),
+               "pf_k_gemm_f16x2_qkv")
+    out = dict(q2=q2, k2=k2, v=v, vt=vt)
+    if time_iters > 0:
+        out["ms"] = float(ms.value)
+    return out
+
+
+def gemm_f16x2_argmax(a2: torch.Tensor, w2: torch.Tensor, bias, scale_exp: int = 0) -> torch.Tensor:
+    """ids[row] = argmax_n (a w^T * 2**-scale_exp + bias)[row, n] through the fused arg-max epilogue of gemm_f16x2."""
+    lib = _lib.load()
+    _, M, K = a2.shape
+    N = w2.shape[1]
+    nparts = 2 * ((N + 255) // 256)
+    dev = a2.device
+    ids = torch.empty(M, device=dev, dtype=torch.int32)
+    sval = torch.empty(M, nparts, device=dev, dtype=torch.float32)
+    sidx = torch.empty(M, nparts, device=dev, dtype=torch.int32)
+    _lib.check(lib.pf_k_gemm_f16x2_argmax(_ptr(a2), K, M * K, _ptr(w2), K, N * K, float(2.0 ** -scale_exp), _ptr(bias), M, N, K,
+                                          _ptr(ids), _ptr(sval), _ptr(sidx), _stream()), "pf_k_gemm_f16x2_argmax")
+    return ids
+
+
 def attention_f16x2(q, k, v, klens, n_heads: int, scale: float, eq: int = 6, ek: int = 6, ev: int = 6, variant: int = 0,
                     time_iters: int = 0):
     """fp32 q [B, Tq, D], k / v [B, Tp, D] (Tp % 16 == 0) -> fp32 [B, Tq, D] through attention_f16x2.hip: builds the kernel's
@@ -308,8 +397,7 @@ def attention_f16x2(q, k, v, klens, n_heads: int, scale: float, eq: int = 6, ek:
     k2 = torch.zeros(2, B * Tp + 32, D, device=dev, dtype=torch.float16)
     k2[:, : B * Tp] = split2(k.reshape(B * Tp, D).contiguous(), ek)
     v2 = split2(v.reshape(B * Tp, D).contiguous(), ev)
-    m = torch.arange(B * Tp, device=dev)
-    col = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1)
+    col = vt_columns(torch.arange(B * Tp, device=dev))
     ldvt = B * Tp + 64
     vt = torch.zeros(2, D, ldvt, device=dev, dtype=torch.float16)
     vt[:, :, col] = v2.transpose(1, 2)

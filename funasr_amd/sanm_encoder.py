@@ -96,6 +96,15 @@ class _SANMEncoderBase(HipModule):
         self._row_packing = extra_rows
         return self
 
+    def set_option(self, key: str, value: int):
+        """Schedule options of the f16x2 mode (`pf_encoder_set_option`): "fuse_row" (1 default: linear_out / w_2 with the
+        residual adds and the following LayerNorm in the GEMM epilogue; 0: separate launches, bitwise equal), "attn_variant"
+        (3 default: lazy rescale; 1 pipelined; 0 plain)."""
+        if not hasattr(self, "_options"):
+            self._options = {}
+        self._options[str(key)] = int(value)
+        return self
+
     def _make_config(self):
         return _lib.pf_encoder_config(self._input_size, self._output_size, self.attention_heads, self.linear_units,
                                       self.num_blocks, self.tp_blocks, self.kernel_size, self.sanm_shfit, self.ln_eps)
@@ -110,9 +119,9 @@ class _SANMEncoderBase(HipModule):
         _lib.check(lib.pf_encoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[getattr(self, "_precision", "fp32")]),
                    "pf_encoder_set_precision")
         pack = getattr(self, "_row_packing", self.ALL_ROWS)
-        if os.environ.get("PF_ENC_NO_PACK"):                 # A/B switch for measurements
-            pack = None
         _lib.check(lib.pf_encoder_set_row_packing(h, -1 if pack is None else int(pack)), "pf_encoder_set_row_packing")
+        for key, value in getattr(self, "_options", {}).items():
+            _lib.check(lib.pf_encoder_set_option(h, key.encode(), int(value)), "pf_encoder_set_option")
         dev = self._handle_device
         xs = xs_pad.to(device=dev, dtype=torch.float32).contiguous()
         B, T, Din = xs.shape

@@ -128,6 +128,10 @@ int pf_encoder_set_precision(pf_encoder* e, int32_t mode);
  * the padded computation up to the summation order of the attention's key tiles; the remaining rows of out_dev are
  * zero. extra_rows >= T keeps every row. extra_rows < 0 (default): padded layout, every row computed. */
 int pf_encoder_set_row_packing(pf_encoder* e, int32_t extra_rows);
+/* Options of mode 3 that do not change a result bit or only the kernel schedule: key "fuse_row" (1, default: linear_out / w_2
+ * in their full-row form, residual adds + the following LayerNorm in the GEMM epilogue; 0: separate launches -- bitwise equal),
+ * key "attn_variant" (attention_f16x2.hip: 3 lazy rescale, default; 1 pipelined; 0 plain). Unknown keys return -1. */
+int pf_encoder_set_option(pf_encoder* e, const char* key, int32_t value);
 /* SANMVadEncoder (funasr/models/ct_transformer_streaming/encoder.py:175-430, the encoder of CTTransformerStreaming): the
  * SAN-M encoder whose self-attention is causal in every block and, in the last one, masked by the VAD corner of
  * transformer/utils/mask.py:38-52 (queries before vad_pos - 1 do not see keys from vad_pos on). vad_pos_host: one value
@@ -359,6 +363,25 @@ int pf_k_gemm_split3(const void* A3, int32_t lda, int64_t a_plane, const void* W
                      const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C,
                      int32_t ldc, void* C3, int32_t ldc3, int64_t c_plane, int32_t M, int32_t N, int32_t K,
                      int32_t relu, int32_t iters, float* ms_out, void* stream);
+/* the kernels of the headline mode, one at a time (tests/test_kernels_f16x2_gpu.py):
+ * full-row form of the N = 512 projections with the residual adds and the following LayerNorm in the epilogue
+ * (gemm_f16x2_row.hip; replaces linear_out / w_2 + LayerNorm of funasr/models/sanm/encoder.py:120-146) */
+int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                        const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc,
+                        const float* ln_g, const float* ln_b, float ln_eps, void* Y2, int64_t y_plane, float yscale, float* Yf,
+                        int32_t M, int32_t K, int32_t relu, int32_t a_nt, int32_t iters, float* ms_out, void* stream);
+/* LayerNorm writing the two fp16 planes of y * scale (what the f16x2 GEMMs read) */
+int pf_k_layernorm_planes(const float* x, int32_t ldx, const float* gamma, const float* beta, void* y2, int32_t ldy, int64_t plane,
+                          float scale, int32_t M, int32_t D, float eps, int32_t iters, float* ms_out, void* stream);
+/* QKV form (kv_form 0, N = 3 D: Q planes, K planes, fp32 V, V^T planes) / KV form (kv_form 1, N = 2 D: K planes, V^T planes) */
+int pf_k_gemm_f16x2_qkv(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                        const float* bias, int32_t M, int32_t D, int32_t K, int32_t kv_form, void* Qp, void* Kp, int64_t qk_plane,
+                        float* Vf, void* VT, int32_t ldvt, int64_t vt_plane, float q_mul, float k_mul, float v_mul,
+                        int32_t iters, float* ms_out, void* stream);
+/* fused arg-max form (vocabulary / CTC projection): ids[row] = argmax_n, lowest index on ties; scratch [M, 2 ceil(N / 256)] */
+int pf_k_gemm_f16x2_argmax(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                           const float* bias, int32_t M, int32_t N, int32_t K, int32_t* ids, float* scratch_val,
+                           int32_t* scratch_idx, void* stream);
 /* two-plane fp16 split operands (x * scale = hi + lo) and the fp32-accurate three-product GEMM on them (gemm_f16x2.hip) */
 int pf_k_split2(const float* x, int32_t ldx, void* y2, int32_t ldy, int64_t plane, int32_t M, int32_t N, float scale,
                 void* stream);

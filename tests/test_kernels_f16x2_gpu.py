@@ -1,0 +1,365 @@
+"""Kernel-level parity of the kernels that carry the headline mode (`f16x2`), one kernel per test, through the C ABI:
+gemm_f16x2_kernel in every epilogue form and block shape, its full-row form with the fused LayerNorm (gemm_f16x2_row.hip),
+attention_f16x2_kernel in every schedule that is kept, split2 and the plane-range machinery.
+
+References are float64 evaluations of the reference's arithmetic -- nn.Linear (+ relu, + residuals)
+funasr/models/sanm/attention.py:241-306, funasr/models/transformer/positionwise_feed_forward.py:14-34, LayerNorm
+funasr/models/transformer/layer_norm.py:13-38, scaled dot-product attention funasr/models/sanm/attention.py:270-306 -- on the
+values the planes actually hold (hi + lo, exact in float64), so the bars test the kernels' arithmetic and not the split.
+
+Error model of one f16x2 product sum: the dropped lo*lo term and lo's own rounding are <= 2^-22 |a||w| per term, the
+fp32 accumulation adds ~sqrt(K) 2^-24 of sum |a||w|; the bar used below is  |err| <= 4e-7 * sum_k |a_k||w_k| (+ the epilogue's
+fp32 roundings), about 2^-21.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes_value(p2: torch.Tensor) -> torch.Tensor:
+    """float64 value of a two-plane tensor [2, ...] (still times its power-of-two scale)"""
+    return p2[0].double() + p2[1].double()
+
+
+def _gemm_ref(a2, w2, scale_exp, bias=None, relu=False, add1=None, add2=None):
+    a, w = _planes_value(a2), _planes_value(w2)
+    out = (a @ w.T) * 2.0 ** -scale_exp
+    mag = (a.abs() @ w.abs().T) * 2.0 ** -scale_exp          # sum |a||w|: the scale of the rounding errors
+    if bias is not None:
+        out = out + bias.double()
+    if relu:
+        out = torch.relu(out)
+    if add1 is not None:
+        out = out + add1.double()
+    if add2 is not None:
+        out = out + add2.double()
+    return out, mag
+
+
+def _check(out, ref, mag, extra=0.0, what=""):
+    err = (out.double() - ref).abs()
+    bound = 4e-7 * mag + 2.5e-7 * ref.abs() + extra
+    worst = (err / bound).max().item()
+    assert worst <= 1.0, f"{what}: error {err.max().item():.3e} is {worst:.2f}x the bound"
+
+
+def _operands(M, N, K, cuda, ea=8, ew=12, seed=0):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(seed + M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g).to(cuda)
+    # asymmetric weights catch a transposed C write
+    w = (torch.randn(N, K, generator=g) * K ** -0.5 * torch.linspace(0.5, 1.5, N)[:, None]).to(cuda)
+    return ops.split2(a, ea), ops.split2(w, ew), ea + ew, g
+
+
+SHAPES = [(1536, 512), (2048, 512), (512, 2048), (512, 512), (1028, 576)]       # (N, K); 1028: ragged N, narrow tile only
+
+
+@pytest.mark.parametrize("M", [70, 500, 4000, 32768])
+@pytest.mark.parametrize("N,K", SHAPES)
+def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
+    """fp32 output with bias / relu / one or two addends, both block shapes (bitwise equal), the de-phased order (bitwise equal)"""
+    from funasr_amd import ops
+    if M == 32768 and N == 1028:
+        pytest.skip("one ragged shape at the big M is enough")
+    a2, w2, se, g = _operands(M, N, K, cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    r1 = torch.randn(M, N, generator=g).to(cuda)
+    r2 = torch.randn(M, N, generator=g).to(cuda)
+    forms = [dict(), dict(relu=True), dict(add2=r2), dict(relu=True, add1=r1, add2=r2), dict(add1=r1)]
+    for kw in forms:
+        ref, mag = _gemm_ref(a2, w2, se, bias, kw.get("relu", False), kw.get("add1"), kw.get("add2"))
+        narrow = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=1, **kw)
+        _check(narrow, ref, mag, what=f"256x128 {sorted(kw)}")
+        if N % 256 == 0:
+            wide = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=2, **kw)
+            assert torch.equal(wide, narrow), f"256x256 and 256x128 tiles differ {sorted(kw)}"
+            auto = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=0, **kw)
+            assert torch.equal(auto, narrow)
+            if "add1" not in kw:                                 # (the de-phased order exists for the forms the engine uses)
+                deph = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=8 + 256 * 16, **kw)
+                assert torch.equal(deph, narrow), f"de-phased order differs {sorted(kw)}"
+
+
+@pytest.mark.parametrize("M", [70, 4000, 32768])
+def test_gemm_f16x2_plane_output(cuda, M):
+    """w_1's form: relu, result written as two fp16 planes of result * 2^e (the next GEMM's operand)"""
+    from funasr_amd import ops
+    N, K = 2048, 512
+    a2, w2, se, g = _operands(M, N, K, cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    ref, mag = _gemm_ref(a2, w2, se, bias, relu=True)
+    eo = 9
+    p_n = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=1)
+    p_w = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=2)
+    p_d = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=8 + 256 * 16)
+    assert torch.equal(p_n, p_w) and torch.equal(p_d, p_w)
+    assert torch.isfinite(p_w.float()).all()
+    val = _planes_value(p_w) * 2.0 ** -eo
+    # the split adds <= 2^-22 of the element (+ the subnormal floor 2^-25 in the scaled domain)
+    _check(val, ref, mag, extra=2.0 ** -22 * ref.abs() + 2.0 ** -25 * 2.0 ** -eo, what="plane output")
+    # and the fp32 form of the same product equals hi + lo of the planes to the split's precision
+    f32 = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, tile=2).double()
+    assert ((val - f32).abs() <= 2.0 ** -22 * f32.abs() + 2.0 ** -25 * 2.0 ** -eo).all()
+
+
+@pytest.mark.parametrize("M,K", [(80, 512), (512, 576), (4096, 512), (32768, 512)])
+@pytest.mark.parametrize("kv_form", [False, True])
+def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
+    """the fused q|k|v projection writing the attention kernel's operands: Q / K planes, fp32 V, transposed V planes whose
+    columns are rows with index bits 2 and 3 swapped; the KV form (decoder memory): K planes + V^T planes"""
+    from funasr_amd import ops
+    D = 512
+    nseg = 2 if kv_form else 3
+    a2, w2, se, g = _operands(M, nseg * D, K, cuda)
+    bias = torch.randn(nseg * D, generator=g).to(cuda)
+    q_mul, k_mul, v_mul = 128 ** -0.5 * 2.0 ** 7, 2.0 ** 6, 2.0 ** 5
+    out = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form)
+    ref, mag = _gemm_ref(a2, w2, se, bias)
+    segs = dict(k=0, v=1) if kv_form else dict(q=0, k=1, v=2)
+
+    def seg(x, name):
+        return x[:, segs[name] * D:(segs[name] + 1) * D]
+
+    def check_planes(p2, name, mul):
+        assert torch.isfinite(p2.float()).all()
+        val = _planes_value(p2) / mul
+        r, m = seg(ref, name), seg(mag, name)
+        _check(val, r, m, extra=2.0 ** -22 * r.abs() + 2.0 ** -25 / mul, what=f"{name} planes")
+
+    if not kv_form:
+        check_planes(out["q2"][:, :M], "q", q_mul)
+        _check(out["v"], seg(ref, "v"), seg(mag, "v"), what="fp32 v")
+        assert not out["q2"][:, M:].any(), "rows past M of the Q planes were written"
+    check_planes(out["k2"][:, :M], "k", k_mul)
+    assert not out["k2"][:, M:].any()
+    cols = ops.vt_columns(torch.arange(M, device=cuda))
+    vt = out["vt"][:, :, cols].transpose(1, 2)                  # back to [2, M, D]
+    check_planes(vt, "v", v_mul)
+    touched = torch.zeros(M + 64, dtype=torch.bool, device=cuda)
+    touched[cols] = True
+    assert not out["vt"][:, :, ~touched].any(), "V^T columns outside the row set were written"
+
+
+@pytest.mark.parametrize("M,N", [(70, 8404), (2000, 8404), (500, 25055), (11000, 8404)])
+def test_gemm_f16x2_fused_argmax(cuda, M, N):
+    """vocabulary / CTC projection with the arg-max in the epilogue: equals the arg-max of the float64 logits wherever their
+    top-2 gap exceeds the kernel's error bound; ties go to the lowest index"""
+    from funasr_amd import ops
+    K = 512
+    a2, w2, se, g = _operands(M, N, K, cuda, seed=5)
+    bias = torch.randn(N, generator=g).to(cuda)
+    ids = ops.gemm_f16x2_argmax(a2, w2, bias, scale_exp=se).long()
+    ref, mag = _gemm_ref(a2, w2, se, bias)
+    top2 = ref.topk(2, dim=1)
+    rid = top2.indices[:, 0]
+    gap = top2.values[:, 0] - top2.values[:, 1]
+    tol = 2 * (4e-7 * mag.max(dim=1).values + 2.5e-7 * top2.values[:, 0].abs())
+    clear = gap > tol
+    assert clear.float().mean() > 0.99
+    assert torch.equal(ids[clear], rid[clear])
+    # where the gap is inside the bound, the kernel's pick must still be within the bound of the maximum
+    picked = ref.gather(1, ids[:, None])[:, 0]
+    assert ((top2.values[:, 0] - picked) <= tol).all()
+    # exact ties -> lowest index (torch.argmax semantics): duplicate weight rows
+    w2t = w2.clone()
+    w2t[:, 7] = w2t[:, 3]
+    bt = bias.clone(); bt[7] = bt[3] = 50.0
+    ids_t = ops.gemm_f16x2_argmax(a2, w2t, bt, scale_exp=se)
+    assert (ids_t == 3).all()
+
+
+@pytest.mark.parametrize("M", [70, 500, 4000, 32768])
+@pytest.mark.parametrize("K,r1,r2", [(512, True, True), (512, True, False), (2048, False, True), (512, False, False)])
+def test_row_form_is_bitwise_gemm_then_layernorm(cuda, M, K, r1, r2):
+    """gemm_f16x2_row.hip (128 x 512 full-row tile; residual adds + LayerNorm + plane split in the epilogue) returns the bits of
+    gemm_f16x2_kernel followed by layernorm_kernel: linear_out / w_2 and the LayerNorm behind them
+    (funasr/models/sanm/encoder.py:120-146, transformer/layer_norm.py:13-38)"""
+    from funasr_amd import ops
+    a2, w2, se, g = _operands(M, 512, K, cuda, seed=9)
+    bias = torch.randn(512, generator=g).to(cuda)
+    add1 = (torch.randn(M, 512, generator=g) * 3).to(cuda) if r1 else None
+    add2 = (torch.randn(M, 512, generator=g) * 10 + 2).to(cuda) if r2 else None
+    gamma = (torch.rand(512, generator=g) * 2 + 0.1).to(cuda)
+    beta = torch.randn(512, generator=g).to(cuda)
+    eps, ey = 1e-12, 7
+    c_ref = ops.gemm_f16x2(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, tile=2)
+    y_ref = ops.layernorm_planes(c_ref, gamma, beta, eps, scale_exp=ey)
+    yf_ref = ops.layernorm(c_ref, gamma, beta, eps)
+    for nt in (False, True):
+        c, y = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, ln=(gamma, beta, eps), out_scale_exp=ey, a_nt=nt)
+        assert torch.equal(c, c_ref), "fp32 result of the row form differs from gemm_f16x2"
+        assert torch.equal(y, y_ref), "LayerNorm planes of the row form differ from layernorm_kernel"
+    c, yf = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False)
+    assert torch.equal(c, c_ref) and torch.equal(yf, yf_ref)
+    c_only, none = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se)
+    assert none is None and torch.equal(c_only, c_ref)
+    nc, y_only = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, ln=(gamma, beta, eps), out_scale_exp=ey, want_c=False)
+    assert nc is None and torch.equal(y_only, y_ref)
+    # in place: C aliases the second addend (the encoder's residual stream)
+    if r2:
+        x = add2.clone()
+        lib_c, y_ip = _row_in_place(ops, a2, w2, bias, add1, x, se, gamma, beta, eps, ey)
+        assert torch.equal(lib_c, c_ref) and torch.equal(y_ip, y_ref)
+    # and against float64 LayerNorm of the float64 product (the reference's arithmetic, not our kernels')
+    ref, mag = _gemm_ref(a2, w2, se, bias, add1=add1, add2=add2)
+    ln64 = torch.nn.functional.layer_norm(ref, (512,), gamma.double(), beta.double(), eps)
+    got = _planes_value(y) * 2.0 ** -ey
+    assert (got - ln64).abs().max().item() < 2e-5 * max(1.0, ln64.abs().max().item())
+
+
+def _row_in_place(ops, a2, w2, bias, add1, x, se, gamma, beta, eps, ey):
+    import ctypes as C
+    from funasr_amd import _lib
+    lib = _lib.load()
+    _, M, K = a2.shape
+    y2 = torch.empty(2, M, 512, device=a2.device, dtype=torch.float16)
+    ms = C.c_float(0)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(lib.pf_k_gemm_f16x2_row(p(a2), K, M * K, p(w2), K, 512 * K, float(2.0 ** -se), p(bias), p(add1), 512 if add1 is not None else 0,
+                                       p(x), 512, p(x), 512, p(gamma), p(beta), float(eps), p(y2), M * 512, float(2.0 ** ey), None,
+                                       M, K, 0, 0, 0, C.byref(ms), torch.cuda.current_stream().cuda_stream), "pf_k_gemm_f16x2_row")
+    return x, y2
+
+
+def _attn_ref(q, k, v, klens, H, scale):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    dk = D // H
+    qh = q.double().view(B, Tq, H, dk).transpose(1, 2) * scale
+    kh = k.double().view(B, Tk, H, dk).transpose(1, 2)
+    vh = v.double().view(B, Tk, H, dk).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    mask = torch.arange(Tk, device=q.device)[None, :] >= klens.to(q.device)[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1).masked_fill(mask[:, None, None, :], 0.0)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, D)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H", [(3, 48, 48, 4), (2, 512, 512, 4), (3, 704, 704, 4), (4, 120, 512, 4), (2, 300, 208, 2)])
+def test_attention_f16x2_variants_vs_float64(cuda, B, Tq, Tk, H):
+    """every schedule kept in attention_f16x2.hip (0 plain, 1 pipelined, 3 lazy rescale), XCD-aware and plain workgroup order,
+    self- and cross-attention shapes, ragged key lengths: <= 2e-6 of the value range against float64 attention; 0 == 1 bitwise;
+    the workgroup order moves no bit"""
+    from funasr_amd import ops
+    D = 128 * H
+    g = torch.Generator().manual_seed(B * 1000 + Tq + Tk)
+    q = torch.randn(B, Tq, D, generator=g).to(cuda)
+    k = torch.randn(B, Tk, D, generator=g).to(cuda)
+    v = torch.randn(B, Tk, D, generator=g).to(cuda)
+    # a few large scores: running-maximum moves late in the key range (the lazy variant's stale-maximum path)
+    k[:, Tk // 2:, :] *= 1.5
+    q[0, :, :128] *= 3.0
+    klens = torch.tensor([Tk] + [max(1, Tk - 17 * (i + 1) - (5 if i % 2 else 0)) for i in range(B - 1)], dtype=torch.int32, device=cuda)
+    scale = 128 ** -0.5
+    ref = _attn_ref(q, k, v, klens, H, scale)
+    # operand ranges: |q scale| * 2^eq < 2^15 etc.
+    eq, ek, ev = 9, 10, 11
+    outs = {}
+    for variant in (0, 1, 3):
+        for plain in (0, 16):
+            o = ops.attention_f16x2(q, k, v, klens, H, scale, eq=eq, ek=ek, ev=ev, variant=variant + plain)
+            assert torch.isfinite(o).all()
+            err = (o.double() - ref).abs().max().item()
+            assert err < 2e-6 * max(1.0, ref.abs().max().item()), f"variant {variant} order {plain}: {err:.3e}"
+            outs[(variant, plain)] = o
+        assert torch.equal(outs[(variant, 0)], outs[(variant, 16)]), f"variant {variant}: the workgroup order changed the result"
+    assert torch.equal(outs[(0, 0)], outs[(1, 0)]), "pipelined schedule is not bitwise the plain one"
+
+
+def test_split2_planes_and_subnormal_floor(cuda):
+    """x 2^e = hi + lo to 2^-24 relative, or to the fp16 subnormal step 2^-25 once lo underflows; no plane overflows at the bound"""
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(257, 520, generator=g)
+    x[0, 0], x[0, 1], x[1, 0] = 1.9999, -1.9999, 2.0 ** -30
+    x = x.clamp(-1.9999, 1.9999).to(cuda)
+    e = 14                                                       # bound 2: 2 * 2^14 = 2^15
+    p = ops.split2(x, e, kpad=32)
+    assert p.shape == (2, 257, 544) and torch.isfinite(p.float()).all()
+    assert not p[:, :, 520:].any()
+    val = _planes_value(p)[:, :520] * 2.0 ** -e
+    err = (val - x.double()).abs()
+    assert (err <= 2.0 ** -24 * x.double().abs() + 2.0 ** -25 * 2.0 ** -e).all()
+
+
+@pytest.mark.parametrize("K,N", [(512, 2048), (2048, 512)])
+def test_f16x2_range_adversarial_scales(cuda, K, N):
+    """The a-priori plane exponents (engine.hip: LayerNorm output <= sqrt(D) max|gamma| + max|beta|; Linear <= b max_n sum_k |W| +
+    |c|) on trained-scale parameters: gamma = 30, weights x 100. No plane overflows when every input sits AT the bound, and
+    inputs at 2^-20 of the bound keep the error inside the split's floor: |err| <= 2^-22 sum |a||w| + the subnormal step of each
+    operand's scaled domain."""
+    from funasr_amd import ops
+    M = 300
+    g = torch.Generator().manual_seed(K)
+    gamma, beta_max = 30.0, 4.0
+    bound_a = math.sqrt(K) * gamma + beta_max                   # LayerNorm bound over K columns
+    ea = math.floor(math.log2(32768.0 / bound_a))
+    w = (torch.randn(N, K, generator=g) * K ** -0.5 * 100.0).to(cuda)
+    ew = 14 - math.floor(math.log2(w.abs().max().item()))
+    bias = (torch.randn(N, generator=g) * 100).to(cuda)
+    w2 = ops.split2(w, ew)
+    assert torch.isfinite(w2.float()).all() and w2[0].float().abs().max().item() < 32768.0
+    bound_out = bound_a * w.abs().sum(dim=1).max().item() + bias.abs().max().item()
+    eo = math.floor(math.log2(32768.0 / bound_out))
+    for frac, name in ((1.0, "at the bound"), (2.0 ** -20, "2^-20 of the bound"), (0.37, "mixed")):
+        a = torch.full((M, K), bound_a * frac)
+        a *= torch.where(torch.rand(M, K, generator=g) < 0.5, -1.0, 1.0)
+        if name == "mixed":
+            a *= torch.rand(M, K, generator=g) * 2.0 ** -torch.randint(0, 24, (M, K), generator=g).float()
+        a = a.to(cuda)
+        a2 = ops.split2(a, ea)
+        assert torch.isfinite(a2.float()).all(), f"A planes overflow {name}"
+        out = ops.gemm_f16x2(a2, w2, bias, scale_exp=ea + ew, tile=1)
+        planes = ops.gemm_f16x2(a2, w2, bias, scale_exp=ea + ew, out_planes=True, out_scale_exp=eo, tile=1)
+        assert torch.isfinite(out).all() and torch.isfinite(planes.float()).all(), f"overflow {name}"
+        ref = a.double() @ w.double().T + bias.double()
+        mag = a.double().abs() @ w.double().abs().T
+        floor = 2.0 ** -25 * (2.0 ** -ea * w.double().abs().sum(dim=1)[None, :] + 2.0 ** -ew * a.double().abs().sum(dim=1)[:, None])
+        err = (out.double() - ref).abs()
+        bound = 2.0 ** -22 * mag + 1.5 * floor + 2.5e-7 * ref.abs() + 1e-7 * bias.abs().max().item()
+        worst = (err / bound).max().item()
+        assert worst <= 1.0, f"{name}: error is {worst:.2f}x the bound (max {err.max().item():.3e})"
+        val = _planes_value(planes) * 2.0 ** -eo
+        assert ((val - out.double()).abs() <= 2.0 ** -22 * out.double().abs() + 2.0 ** -25 * 2.0 ** -eo).all()
+
+
+def test_layernorm_planes_gamma30_no_overflow(cuda):
+    """LayerNorm writing planes at the exponent the engine derives from gamma = 30 / beta = 4: finite, <= 2^15, split-accurate"""
+    from funasr_amd import ops
+    D, M = 512, 999
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(M, D, generator=g) * 50 + 7).to(cuda)
+    x[0] = 0.0; x[0, 5] = 1e4                                    # one-hot row: a normalised value near sqrt(D)
+    gamma = torch.full((D,), 30.0); gamma[::3] = -30.0
+    beta = torch.full((D,), 4.0)
+    e = math.floor(math.log2(32768.0 / (math.sqrt(D) * 30.0 + 4.0)))
+    p = ops.layernorm_planes(x, gamma.to(cuda), beta.to(cuda), 1e-12, scale_exp=e)
+    assert torch.isfinite(p.float()).all() and p[0].float().abs().max().item() <= 32768.0
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double().to(cuda), beta.double().to(cuda), 1e-12)
+    val = _planes_value(p) * 2.0 ** -e
+    assert (val - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+
+
+def test_ctc_planes_follow_a_weight_reload(cuda):
+    """pf_ctc_set_tensor drops the cached weight planes of the f16x2 arg-max route: after a second load_state_dict the ids are
+    those of the NEW weights (compared with the fp32 route)"""
+    from funasr_amd.ctc import CTC
+    g = torch.Generator().manual_seed(0)
+    ctc = CTC(odim=700, encoder_output_size=512).to(cuda)
+    h = torch.randn(2, 40, 512, generator=g).to(cuda)
+    lens = torch.tensor([40, 33])
+    ids = {}
+    for rnd in range(2):
+        sd = {"ctc_lo.weight": torch.randn(700, 512, generator=g) * 0.05, "ctc_lo.bias": torch.randn(700, generator=g)}
+        ctc.load_state_dict(sd)
+        ctc.to(cuda)
+        for mode in ("f16x2", "fp32"):
+            ctc.set_precision(mode)
+            ids[(rnd, mode)] = ctc.argmax(h).cpu()
+        agree = (ids[(rnd, "f16x2")] == ids[(rnd, "fp32")]).float().mean().item()
+        assert agree > 0.98, f"load {rnd}: f16x2 ids disagree with fp32 ids ({agree:.3f})"
+    assert not torch.equal(ids[(0, "fp32")], ids[(1, "fp32")])

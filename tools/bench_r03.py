@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Round-3 micro-benchmarks (one gpurun call, within-call A/B): attention_f16x2 schedules x workgroup order, gemm_f16x2 plain
+vs de-phased rounds, the full-row form (fused LayerNorm) vs GEMM + layernorm_kernel. Prints one JSON object per line."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from funasr_amd import ops
+
+dev = torch.device("cuda:0")
+which = set(sys.argv[1:]) or {"attn", "gemm", "row"}
+M = 32768
+
+
+def best(fn, n=3):
+    return min(fn() for _ in range(n))
+
+
+if "attn" in which:
+    B, T, H = 64, 512, 4
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, T, 512, generator=g).to(dev); k = torch.randn(B, T, 512, generator=g).to(dev); v = torch.randn(B, T, 512, generator=g).to(dev)
+    klens = torch.full((B,), 500, dtype=torch.int32, device=dev)
+    row = {}
+    for variant in (0, 1, 3):
+        for plain in (0, 16):
+            ms = best(lambda: ops.attention_f16x2(q, k, v, klens, H, 128 ** -0.5, variant=variant + plain, time_iters=20)[1])
+            row[f"v{variant}{'_plain' if plain else '_xcd'}"] = round(ms * 1e3, 1)
+    print(json.dumps({"attention_f16x2_us_B64_T512": row}), flush=True)
+    # cross-attention shape of the decoder: 172 tokens x 512 keys
+    qx = torch.randn(B, 176, 512, generator=g).to(dev)
+    row = {f"v{variant}": round(best(lambda: ops.attention_f16x2(qx, k, v, klens, H, 128 ** -0.5, variant=variant, time_iters=20)[1]) * 1e3, 1) for variant in (0, 1, 3)}
+    print(json.dumps({"cross_attention_us_B64_Tq176": row}), flush=True)
+
+if "gemm" in which:
+    for name, N, K, kw in (("qkv_fp32out", 1536, 512, {}), ("w1_planes", 2048, 512, dict(relu=True, out_planes=True, out_scale_exp=9)),
+                           ("w2_resid", 512, 2048, dict(resid=True)), ("out_fp32", 512, 512, {})):
+        a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
+        a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+        kw = dict(kw)
+        if kw.pop("resid", False):
+            kw["add2"] = torch.randn(M, N, device=dev)
+        row = {}
+        ref = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=2, **kw)
+        for label, tile in (("wide", 2), ("deph64", 8 + 256 * 8), ("deph128", 8 + 256 * 16), ("deph192", 8 + 256 * 24), ("wide_again", 2)):
+            out = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, **kw)
+            ms = best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20, **kw)[1])
+            row[label] = (round(ms * 1e3, 1), bool(torch.equal(out, ref)))
+        print(json.dumps({name: row}), flush=True)
+    # the QKV form (the engine's projection: Q / K planes, fp32 V, V^T planes)
+    a = torch.randn(M, 512, device=dev); w = torch.randn(1536, 512, device=dev) * 512 ** -0.5; b = torch.randn(1536, device=dev)
+    a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+    ms = best(lambda: ops.gemm_f16x2_qkv(a2, w2, b, 512, 20, 2.0 ** 4, 2.0 ** 6, 2.0 ** 6, time_iters=20)["ms"])
+    print(json.dumps({"qkv_form_us": round(ms * 1e3, 1)}), flush=True)
+
+if "row" in which:
+    gamma = torch.rand(512, device=dev) + 0.5; beta = torch.randn(512, device=dev)
+    for name, K, r1 in (("out_proj+ln2", 512, True), ("w2+ln1", 2048, False)):
+        a = torch.randn(M, K, device=dev); w = torch.randn(512, K, device=dev) * K ** -0.5; b = torch.randn(512, device=dev)
+        a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+        add1 = torch.randn(M, 512, device=dev) if r1 else None
+        add2 = torch.randn(M, 512, device=dev)
+        row = {}
+        for tile, label in ((2, "wide"), (1, "narrow")):
+            row[f"gemm_{label}"] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, add1=add1, add2=add2, scale_exp=20, tile=tile, time_iters=20)[1]) * 1e3, 1)
+        c = ops.gemm_f16x2(a2, w2, b, add1=add1, add2=add2, scale_exp=20, tile=2)
+        row["layernorm_planes"] = round(best(lambda: ops.layernorm_planes(c, gamma, beta, 1e-12, scale_exp=7, time_iters=20)[1]) * 1e3, 1)
+        for nt in (False, True):
+            row[f"row_fused{'_nt' if nt else ''}"] = round(best(lambda: ops.gemm_f16x2_row(a2, w2, b, add1=add1, add2=add2, scale_exp=20, ln=(gamma, beta, 1e-12),
+                                                                                          out_scale_exp=7, a_nt=nt, time_iters=20)[2]) * 1e3, 1)
+        row["row_no_ln"] = round(best(lambda: ops.gemm_f16x2_row(a2, w2, b, add1=add1, add2=add2, scale_exp=20, time_iters=20)[2]) * 1e3, 1)
+        print(json.dumps({name: row}), flush=True)

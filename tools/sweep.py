@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--model", default="paraformer", choices=["paraformer", "sensevoice"])
     ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16", "bf16x3", "f16x2"])
     ap.add_argument("--dump", default=None, help="rank 0 writes the hypotheses in CORPUS order to this JSON file")
+    ap.add_argument("--no-pack", action="store_true", help="A/B: plan batches for the padded layout (no encoder row packing)")
     ap.add_argument("--no-overlap", action="store_true", help="assemble, decode and collect one batch at a time")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
@@ -84,7 +85,7 @@ def main():
     # query frames) plus the one padding row the CIF predictor reads, in a 16-row slot (pf_encoder_set_row_packing)
     q = 4 if args.model == "sensevoice" else 0
     extra = 0 if args.model == "sensevoice" else 1
-    packed = args.precision == "f16x2" and not os.environ.get("PF_ENC_NO_PACK")
+    packed = args.precision == "f16x2" and not args.no_pack
     if args.batch_seconds > 0:
         batches, cur = [], []
         for i in mine:
