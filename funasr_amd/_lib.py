@@ -162,7 +162,7 @@ SIGNATURES = {
                                       _vp, _i64, _f32, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
     "pf_k_layernorm_planes": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _f32, _i32, _i32, _f32, _i32, C.POINTER(C.c_float), _vp]),
     "pf_k_gemm_f16x2_qkv": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _f32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp,
-                                      _i32, _i64, _f32, _f32, _f32, _i32, C.POINTER(C.c_float), _vp]),
+                                      _i32, _i64, _f32, _f32, _f32, _i32, _i32, C.POINTER(C.c_float), _vp]),
     "pf_k_gemm_f16x2_argmax": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _f32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_gemm_argmax_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_log_softmax": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),

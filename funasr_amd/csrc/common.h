@@ -88,9 +88,10 @@ __device__ __forceinline__ void store_split3x4(unsigned short* p, size_t plane, 
 }
 
 // ---------------------------------------------------------------- two-plane fp16 split (gemm_f16x2.hip)
-// x (already multiplied by the tensor's power-of-two scale) = hi + lo to 2^-24 |x|: hi = f16(x) (11 significand bits,
-// round to nearest even), lo = f16(x - hi) (the difference is exact in fp32; lo keeps its leading 11 bits, or every bit
-// down to 2^-24 once it is subnormal). |x| must stay below 65504: every producer's scale comes from an a-priori bound.
+// x (already multiplied by the tensor's power-of-two scale) = hi + lo to 2^-23 |x| in the worst case (x at the bottom of hi's
+// binade and lo at the top of its own; 2^-25 |x| on average): hi = f16(x) (11 significand bits, round to nearest even),
+// lo = f16(x - hi) (the difference is exact in fp32; lo keeps its leading 11 bits, or every bit down to 2^-24 once it is
+// subnormal). |x| must stay below 65504: every producer's scale comes from an a-priori bound.
 typedef _Float16 pf_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
     const pf_floatx2 v = {a, b};
@@ -219,8 +220,6 @@ struct Gemm2Args {
     int M, N, K;                                        // K % 32 == 0, N % 4 == 0
     int relu;
     int tile;                                           // 0 = pick by shape, 1 = 256 x 128, 2 = 256 x 256 (measurement hook)
-    int deph;                                           // > 0: de-phased rounds of the 256 x 256 shape (gemm_f16x2.hip DEPH): that many
-                                                        // workgroups (a multiple of 8, typically half the CUs) start with a half tile
     // QKV form (qkv_D > 0, N == 3 qkv_D, qkv_D % 256 == 0, M % 16 == 0): the fused q|k|v projection feeding
     // attention_f16x2.hip. Columns [0, D) -> planes of (result * q_mul) at Qp (ld D); [D, 2D) -> planes of
     // (result * k_mul) at Kp; [2D, 3D) -> fp32 at C (ld ldc; the FSMN memory block reads it) and the TRANSPOSED

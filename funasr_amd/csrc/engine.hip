@@ -433,6 +433,8 @@ struct Encoder {
     // fuse_row = 0 restores the separate launches (A/B measurements, tests)
     int fuse_row = 1;
     int attn_variant = 3;               // attention_f16x2.hip schedule (3: lazy rescale)
+    int row_nt = 1;                     // non-temporal A loads in the full-row GEMMs: 0 none, 1 linear_out (K = 512), 2 linear_out and w_2
+    int gemm_tile = 0;                  // Gemm2Args.tile of the block's GEMMs (0: by shape; 5: 128 x 256, two workgroups per CU)
 };
 
 // exponent e with bound * 2^e <= 2^15 (a factor 2 under fp16's 65504 for the roundings on the way)
@@ -628,7 +630,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)N * K;
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
             g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = N; g.c_plane = (size_t)M * N; g.cscale = pow2f(ec);
-            g.M = M; g.N = N; g.K = K; g.relu = relu;
+            g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = e->gemm_tile;
             ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
             return launch_gemm_f16x2(g, s);
         };
@@ -640,7 +642,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = D; g.R2 = R2; g.ldr2 = ldr2; g.C = x; g.ldc = D;
             g.ln_g = lg; g.ln_b = lb; g.ln_eps = c.ln_eps;
             if (lg) { g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(ey); }
-            g.M = M; g.N = D; g.K = K;
+            g.M = M; g.N = D; g.K = K; g.a_nt = e->row_nt >= (K == D ? 1 : 2);
             ProfScope ps(PROF_GEMM3, 2.0 * M * (double)D * K, s);
             return launch_gemm_f16x2_row(g, s);
         };
@@ -657,7 +659,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             g.C = vbuf; g.ldc = D; g.M = M; g.N = 3 * D; g.K = w.in_pad;
             g.qkv_D = D; g.Qp = q2; g.Kp = k2; g.qk_plane = (size_t)(M + 32) * D;
             g.VT = vt2; g.ldvt = ldvt; g.vt_plane = (size_t)D * ldvt;
-            g.q_mul = dk_scale * pow2f(w.e_q); g.k_mul = pow2f(w.e_k); g.v_mul = pow2f(w.e_v);
+            g.q_mul = dk_scale * pow2f(w.e_q); g.k_mul = pow2f(w.e_k); g.v_mul = pow2f(w.e_v); g.tile = e->gemm_tile;
             ProfScope ps(PROF_GEMM3, 2.0 * M * 3.0 * D * w.in_pad, s);
             if ((rc = launch_gemm_f16x2(g, s))) return rc;
         }
@@ -1461,6 +1463,8 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     PF_REQUIRE(e && key, "encoder_set_option: null");
     const std::string k = key;
     if (k == "fuse_row") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fuse_row is 0 or 1"); e->fuse_row = value; return 0; }
+    if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
+    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5, "encoder_set_option: gemm_tile is 0, 1, 2 or 5"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
     set_error("encoder_set_option: unknown key " + k);
     return -1;
@@ -2808,7 +2812,6 @@ int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2
     g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
     g.C2 = reinterpret_cast<unsigned short*>(C2); g.ldc2 = ldc2; g.c_plane = (size_t)c_plane; g.cscale = cscale;
     g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = tile;
-    if ((tile & 0xff) == 8) { g.tile = 0; g.deph = (tile >> 8) * 8; }       // tile = 8 + 256 n: de-phased rounds, 8 n half-tile workgroups
     int rc;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2(g, s);
     for (int i = 0; i < 3; ++i) if ((rc = launch_gemm_f16x2(g, s))) return rc;
@@ -2888,7 +2891,7 @@ int pf_k_layernorm_planes(const float* x, int32_t ldx, const float* gamma, const
  * planes, V^T planes) of gemm_f16x2.hip; Qp / Kp planes are qk_plane apart (ld D), VT [2][D, ldvt] vt_plane apart */
 int pf_k_gemm_f16x2_qkv(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
                         const float* bias, int32_t M, int32_t D, int32_t K, int32_t kv_form, void* Qp, void* Kp, int64_t qk_plane,
-                        float* Vf, void* VT, int32_t ldvt, int64_t vt_plane, float q_mul, float k_mul, float v_mul,
+                        float* Vf, void* VT, int32_t ldvt, int64_t vt_plane, float q_mul, float k_mul, float v_mul, int32_t tile,
                         int32_t iters, float* ms_out, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     Gemm2Args g{};
@@ -2897,7 +2900,7 @@ int pf_k_gemm_f16x2_qkv(const void* A2, int32_t lda, int64_t a_plane, const void
     g.C = Vf; g.ldc = D; g.M = M; g.N = (kv_form ? 2 : 3) * D; g.K = K; g.qkv_D = D; g.kv_form = kv_form;
     g.Qp = reinterpret_cast<unsigned short*>(Qp); g.Kp = reinterpret_cast<unsigned short*>(Kp); g.qk_plane = (size_t)qk_plane;
     g.VT = reinterpret_cast<unsigned short*>(VT); g.ldvt = ldvt; g.vt_plane = (size_t)vt_plane;
-    g.q_mul = q_mul; g.k_mul = k_mul; g.v_mul = v_mul;
+    g.q_mul = q_mul; g.k_mul = k_mul; g.v_mul = v_mul; g.tile = tile;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2(g, s);
     return time_launches([&] { return launch_gemm_f16x2(g, s); }, iters, ms_out, s);
 }

@@ -24,67 +24,62 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// wave grid WGM (M) x 2 (N); a wave owns WM x WN tiles of 32 x 32
-template <int WM, int WN, int WGM = 4> struct Geo2 {
+// wave grid WGM (M) x 2 (N); a wave owns WM x WN tiles of 32 x 32. KS_: depth of a K stage -- 32 (64-B LDS rows, two
+// stages) or 16 (32-B rows, a ring of three stages: the shape for TWO workgroups per CU, see gemm_f16x2_kernel)
+template <int WM, int WN, int WGM = 4, int KS_ = 32> struct Geo2 {
     static constexpr int NW = WGM * 2;                          // waves per workgroup
     static constexpr int BM = WGM * WM * 32, BN = 2 * WN * 32;
-    static constexpr int KS = 32, ROWB = 64, CPR = 4, RPP = 16;
+    static constexpr int KS = KS_, ROWB = 2 * KS, CPR = ROWB / 16, RPP = 1024 / ROWB;
+    static constexpr int SWZ = CPR == 4 ? 2 : 3;                // rows per 256 B of LDS = 1 << SWZ: the swizzle changes that often
+    static constexpr int NSTG = KS == 16 ? 3 : 2;
     static constexpr int A_PLANE_B = BM * ROWB, B_PLANE_B = BN * ROWB;
     static constexpr int STAGE_B = 2 * (A_PLANE_B + B_PLANE_B);
-    static constexpr int NPIECE = STAGE_B / 1024;               // 48 / 64
+    static constexpr int NPIECE = STAGE_B / 1024;               // 48 / 64 (24 in the 16-deep 128 x 256 shape)
     static constexpr int A_PIECES = 2 * BM / RPP;
     static constexpr int PPW = NPIECE / NW;                     // 6 / 8
     static constexpr int ELD = WN * 32 + 4;                     // epilogue slab row (floats)
     static constexpr int SLAB_B = NW * 32 * ELD * 4;
-    static constexpr int LDS_B = 2 * STAGE_B > SLAB_B ? 2 * STAGE_B : SLAB_B;
+    static constexpr int LDS_B = NSTG * STAGE_B > SLAB_B ? NSTG * STAGE_B : SLAB_B;
 };
+template <int N> __device__ __forceinline__ void glds_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 // ABL (measurement only, tools/bench_gemm2.py): 1 = no global stores in the epilogue, 2 = no epilogue, 3 = no operand DMA
-// DEPH (de-phased rounds, Gemm2Args.deph > 0): every CU holds one workgroup, so the workgroups of a round start together, run
-// the same k-loop and reach their epilogues together -- the output of a whole round (tens of MB) hits HBM as one burst while
-// the matrix pipes idle, round after round. With DEPH the first `deph` workgroups of the grid compute only the UPPER half
-// (rows 0..127: the waves of the two upper wave rows, one per SIMD -- half the time) of their tile and `deph` extra
-// workgroups at the END of the grid compute the lower halves: the CUs that drew a half tile run half a tile period out of
-// phase with the others from then on, so one half of the chip stores while the other half multiplies. Same products, same k
-// order per output element: bitwise equal to the plain order (tested).
-template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, bool DEPH = false>   // OUT: 0 fp32 C, 1 two fp16 planes, 2 the QKV form (Gemm2Args)
+// KS_ = 16 with WGM = 2 (four waves, 128 x 256 block, 72 KB of LDS): TWO workgroups per CU. With one 512-thread workgroup per
+// CU every CU's waves meet at the same barriers, load their first stages together and drain their epilogues together -- the
+// matrix pipes idle through each prologue and epilogue (a quarter of a K = 512 GEMM). Two independent four-wave workgroups
+// per CU (one wave of each per SIMD, the same 256 VGPRs per wave) run out of phase: one's barrier waits, first-stage loads
+// and epilogue stores lie under the other's MFMAs. Price: 1.5x the L2 -> LDS bytes per flop of the 256 x 256 block, and one
+// barrier per 16-deep step (24 MFMAs per wave) instead of per 32-deep stage; the stage ring is three deep so that a stage's
+// DMA has two whole steps to land. Same products, same k order per output element as the other shapes: bitwise equal (tested).
+template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, int KS_ = 32>   // OUT: 0 fp32 C, 1 two fp16 planes, 2 the QKV form (Gemm2Args)
 __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, int nM, int nN) {
-    typedef Geo2<WM, WN, WGM> G;
+    typedef Geo2<WM, WN, WGM, KS_> G;
     constexpr int BM = G::BM, BN = G::BN, KS = G::KS, ROWB = G::ROWB, CPR = G::CPR, RPP = G::RPP, PPW = G::PPW;
     constexpr int STAGE_B = G::STAGE_B, A_PLANE_B = G::A_PLANE_B, B_PLANE_B = G::B_PLANE_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    int L = blockIdx.x;
-    int half = 0;                                   // DEPH: 0 = whole tile, 1 = its rows 0..BM/2-1, 2 = its rows BM/2..BM-1
-    if constexpr (DEPH) {
-        const int T = (nM + 7) / 8 * 8 * nN;
-        if (L < p.deph) half = 1;
-        else if (L >= T) { half = 2; L -= T; }
-    }
+    const int L = blockIdx.x;
     const int xcd = L & 7, j8 = L >> 3;
     const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
     if (mblk >= nM) return;
-    const int m0 = mblk * BM + (half == 2 ? BM / 2 : 0), n0 = nblk * BN;
+    const int m0 = mblk * BM, n0 = nblk * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int hh = lane >> 5, idx = lane & 31;
-    const bool act = !DEPH || half == 0 || wr < WGM / 2;   // (wave-uniform) a half tile is the work of the upper wave rows
 
     // ---- DMA sources: a stage is NPIECE pieces of 1 KB (16 rows of one plane), the A planes first, then the W planes,
     //      linear in LDS; wave w issues pieces w, w + 8, ...; lane l lands at row l / 4, physical chunk l % 4 and
     //      fetches the logical chunk the read-side swizzle expects there
     const unsigned short* src[PPW];
-    bool skip[PPW];                                 // DEPH: A pieces of the rows a half tile does not compute
     {
         const int prow = lane / CPR;
-        const int chunk = (lane % CPR) ^ ((prow >> 2) & (CPR - 1));
+        const int chunk = (lane % CPR) ^ ((prow >> G::SWZ) & (CPR - 1));
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int q = wave + G::NW * i;
-            skip[i] = DEPH && half != 0 && q < G::A_PIECES && (q % (BM / RPP)) >= BM / RPP / 2;
             if (q < G::A_PIECES) {
                 int row = m0 + (q % (BM / RPP)) * RPP + prow;
                 row = row < p.M ? row : p.M - 1;
@@ -100,7 +95,6 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
     auto piece = [&](int i, int buf, int kt) {
         if constexpr (ABL == 3) return;
-        if constexpr (DEPH) { if (skip[i]) return; }
         glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * (G::NW * 1024));
     };
 
@@ -112,7 +106,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    const int f = (idx >> 2) & (CPR - 1);
+    const int f = (idx >> G::SWZ) & (CPR - 1);
     const int aoff = (wr * (WM * 32) + idx) * ROWB;
     const int boff = 2 * A_PLANE_B + (wc * (WN * 32) + idx) * ROWB;
     int coff[2];
@@ -120,6 +114,43 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     for (int st = 0; st < 2; ++st) coff[st] = ((2 * st + hh) ^ f) * 16;
 
     const int nk = p.K / KS;
+    if constexpr (KS_ == 16) {
+        // ring of three 16-deep stages: stage kt + 2 is issued while stage kt is multiplied; a wave's pieces retire in order, so
+        // "at most PPW outstanding" means its pieces of stage kt have landed; the barrier then covers the other waves' pieces
+        // and frees the buffer of stage kt - 1 (= the one stage kt + 2 goes into)
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) piece(i, 0, 0);
+        if (nk > 1) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) piece(i, 1, 1);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) glds_wait_but<PPW>(); else glds_wait_all();
+            __syncthreads();
+            const unsigned char* sb = smem + (kt % 3) * STAGE_B;
+            f16x8 a[WM][2], b[WN][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    a[i][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * A_PLANE_B + aoff + i * 32 * ROWB + coff[0]));
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj)
+                    b[jj][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[0]));
+            }
+            if (kt + 2 < nk) {
+#pragma unroll
+                for (int i = 0; i < PPW; ++i) piece(i, (kt + 2) % 3, kt + 2);
+            }
+#define PF_PROD16(PA, PB)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                  \
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA], b[jj][PB], acc[i][jj], 0, 0, 0)
+            PF_PROD16(1, 0);
+            PF_PROD16(0, 1);
+            PF_PROD16(0, 0);
+#undef PF_PROD16
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) piece(i, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -150,9 +181,6 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
             PF_PROD(1, 0); PF_PIECE(5); PF_PIECE(6);
             PF_PROD(0, 1); PF_PIECE(7);
             PF_PROD(0, 0);
-        } else if (!act) {
-            // idle wave rows of a half tile: the DMA pieces only
-            PF_PIECE(0); PF_PIECE(1); PF_PIECE(2); PF_PIECE(3); PF_PIECE(4); PF_PIECE(5); PF_PIECE(6); PF_PIECE(7);
         } else {
             // both k-steps' fragments are requested before the first MFMA: one LDS-latency bubble per stage instead of two
             f16x8 a[WM][2], b[WN][2], a1[WM][2], b1[WN][2];
@@ -179,6 +207,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
 #undef PF_PROD
 #undef PF_LOAD
 #undef PF_PIECE
+    }
     }
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)):
@@ -240,7 +269,6 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     constexpr int RPS = 64 / LPR;            // rows per pass
     constexpr int NPASS = 32 / RPS;
     __syncthreads();
-    if constexpr (DEPH) { if (!act) return; }
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ELD);
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int col = n0 + wc * (WN * 32) + c4 * 4;
@@ -386,27 +414,24 @@ __global__ __launch_bounds__(256) void rowl1_bound_kernel(const float* __restric
     if (lane == 0) atomicMax(out, __builtin_bit_cast(unsigned, bnd));
 }
 
-template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, bool DEPH = false>
+template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, int KS_ = 32>
 int launch_tile(const Gemm2Args& a, hipStream_t stream) {
-    typedef Geo2<WM, WN, WGM> G;
+    typedef Geo2<WM, WN, WGM, KS_> G;
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, DEPH>),
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, KS_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
         configured = true;
     }
     const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
     const int nMpad = (nM + 7) / 8 * 8;
-    Gemm2Args k = a;
-    if (DEPH) k.deph = a.deph / 8 * 8 < nMpad * nN ? a.deph / 8 * 8 : nMpad * nN;      // whole XCD groups, at most every tile
-    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, DEPH>), dim3((unsigned)(nMpad * nN + (DEPH ? k.deph : 0))),
-                       dim3(WGM * 128), G::LDS_B, stream, k, nM, nN);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, KS_>), dim3((unsigned)nMpad * nN), dim3(WGM * 128), G::LDS_B, stream, a, nM, nN);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
-// de-phased form of the wide shape (Gemm2Args.deph > 0, N % 256 == 0)
+// the 128 x 256 four-wave shape, two workgroups per CU (tile 5; N % 256 == 0)
 template <int MODE, int OUT>
-int launch_deph(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 2, 4, true>(a, stream); }
+int launch_pair(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 0, 2, 16>(a, stream); }
 template <int MODE, int OUT>
 int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
@@ -531,16 +556,22 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         PF_REQUIRE((a.kv_form || (a.Qp && a.C)) && a.Kp && a.VT && a.ldvt % 8 == 0 && a.vt_plane % 8 == 0 && a.qk_plane % 8 == 0 &&
                    ((uintptr_t)a.Qp & 15) == 0 && ((uintptr_t)a.Kp & 15) == 0 && ((uintptr_t)a.VT & 15) == 0,
                    "gemm_f16x2: QKV outputs");
-        if (a.deph > 0) return launch_deph<0, 2>(a, stream);
+        if (a.tile == 5) return launch_pair<0, 2>(a, stream);
         return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);
     }
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");
-        if (a.deph > 0 && a.N % 256 == 0) return launch_deph<0, 1>(a, stream);
+        if (a.tile == 5 && a.N % 256 == 0) return launch_pair<0, 1>(a, stream);
         return launch_one<0, 1>(a, stream);
     }
-    if (a.deph > 0 && a.N % 256 == 0 && (mode == 0 || mode == 2))
-        return mode == 0 ? launch_deph<0, 0>(a, stream) : launch_deph<2, 0>(a, stream);
+    if (a.tile == 5 && a.N % 256 == 0) {
+        switch (mode) {
+            case 0: return launch_pair<0, 0>(a, stream);
+            case 1: return launch_pair<1, 0>(a, stream);
+            case 2: return launch_pair<2, 0>(a, stream);
+            default: return launch_pair<3, 0>(a, stream);
+        }
+    }
     switch (mode) {
         case 0: return launch_one<0, 0>(a, stream);
         case 1: return launch_one<1, 0>(a, stream);

@@ -344,7 +344,7 @@ def vt_columns(m: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_f16x2_qkv(a2: torch.Tensor, w2: torch.Tensor, bias, D: int, scale_exp: int, q_mul: float, k_mul: float, v_mul: float,
-                   kv_form: bool = False, time_iters: int = 0):
+                   kv_form: bool = False, tile: int = 0, time_iters: int = 0):
     """QKV form (w2 [2, 3 D, K]) / KV form (w2 [2, 2 D, K]) of gemm_f16x2: returns dict(q2, k2 planes [2, M + 32, D] (q2 None in
     the KV form), v fp32 [M, D] (None in the KV form), vt planes [2, D, M + 64])."""
     lib = _lib.load()
@@ -360,7 +360,7 @@ def gemm_f16x2_qkv(a2: torch.Tensor, w2: torch.Tensor, bias, D: int, scale_exp: 
     ms = C.c_float(0)
     _lib.check(lib.pf_k_gemm_f16x2_qkv(_ptr(a2), K, M * K, _ptr(w2), K, nseg * D * K, float(2.0 ** -scale_exp), _ptr(bias), M, D, K,
                                        int(kv_form), _ptr(q2), _ptr(k2), (M + 32) * D, _ptr(v), _ptr(vt), ldvt, D * ldvt,
-                                       float(q_mul), float(k_mul), float(v_mul), int(time_iters), C.byref(ms), _stream()),
+                                       float(q_mul), float(k_mul), float(v_mul), int(tile), int(time_iters), C.byref(ms), _stream()),
                "pf_k_gemm_f16x2_qkv")
     out = dict(q2=q2, k2=k2, v=v, vt=vt)
     if time_iters > 0:

@@ -130,7 +130,9 @@ int pf_encoder_set_precision(pf_encoder* e, int32_t mode);
 int pf_encoder_set_row_packing(pf_encoder* e, int32_t extra_rows);
 /* Options of mode 3 that do not change a result bit or only the kernel schedule: key "fuse_row" (1, default: linear_out / w_2
  * in their full-row form, residual adds + the following LayerNorm in the GEMM epilogue; 0: separate launches -- bitwise equal),
- * key "attn_variant" (attention_f16x2.hip: 3 lazy rescale, default; 1 pipelined; 0 plain). Unknown keys return -1. */
+ * key "attn_variant" (attention_f16x2.hip: 3 lazy rescale, default; 1 pipelined; 0 plain), key "gemm_tile" (block shape of
+ * the block's gemm_f16x2 launches: 0 by shape, default; 1 / 2 the 256 x 128 / 256 x 256 shapes; 5 the 128 x 256 shape with two
+ * workgroups per CU -- all bitwise equal). Unknown keys return -1. */
 int pf_encoder_set_option(pf_encoder* e, const char* key, int32_t value);
 /* SANMVadEncoder (funasr/models/ct_transformer_streaming/encoder.py:175-430, the encoder of CTTransformerStreaming): the
  * SAN-M encoder whose self-attention is causal in every block and, in the last one, masked by the VAD corner of
@@ -376,7 +378,7 @@ int pf_k_layernorm_planes(const float* x, int32_t ldx, const float* gamma, const
 /* QKV form (kv_form 0, N = 3 D: Q planes, K planes, fp32 V, V^T planes) / KV form (kv_form 1, N = 2 D: K planes, V^T planes) */
 int pf_k_gemm_f16x2_qkv(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
                         const float* bias, int32_t M, int32_t D, int32_t K, int32_t kv_form, void* Qp, void* Kp, int64_t qk_plane,
-                        float* Vf, void* VT, int32_t ldvt, int64_t vt_plane, float q_mul, float k_mul, float v_mul,
+                        float* Vf, void* VT, int32_t ldvt, int64_t vt_plane, float q_mul, float k_mul, float v_mul, int32_t tile,
                         int32_t iters, float* ms_out, void* stream);
 /* fused arg-max form (vocabulary / CTC projection): ids[row] = argmax_n, lowest index on ties; scratch [M, 2 ceil(N / 256)] */
 int pf_k_gemm_f16x2_argmax(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,

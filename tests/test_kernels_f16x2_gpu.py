@@ -7,9 +7,10 @@ funasr/models/sanm/attention.py:241-306, funasr/models/transformer/positionwise_
 funasr/models/transformer/layer_norm.py:13-38, scaled dot-product attention funasr/models/sanm/attention.py:270-306 -- on the
 values the planes actually hold (hi + lo, exact in float64), so the bars test the kernels' arithmetic and not the split.
 
-Error model of one f16x2 product sum: the dropped lo*lo term and lo's own rounding are <= 2^-22 |a||w| per term, the
-fp32 accumulation adds ~sqrt(K) 2^-24 of sum |a||w|; the bar used below is  |err| <= 4e-7 * sum_k |a_k||w_k| (+ the epilogue's
-fp32 roundings), about 2^-21.
+Error model of one f16x2 product sum: an operand is hi + lo to 2^-23 of its magnitude in the worst case (hi's
+11 bits + lo's 11 bits + lo's sign: 2^-24 typically), the dropped lo*lo term is <= 2^-22 |a||w|, the fp32 accumulation adds
+~sqrt(K) 2^-24 of sum |a||w|; worst case 2^-21 sum |a||w|. The bar on random operands is |err| <= 4e-7 sum_k |a_k||w_k|
+(+ the epilogue's fp32 roundings), the bar on adversarial operands the worst case.
 """
 import math
 
@@ -61,7 +62,7 @@ SHAPES = [(1536, 512), (2048, 512), (512, 2048), (512, 512), (1028, 576)]       
 @pytest.mark.parametrize("M", [70, 500, 4000, 32768])
 @pytest.mark.parametrize("N,K", SHAPES)
 def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
-    """fp32 output with bias / relu / one or two addends, both block shapes (bitwise equal), the de-phased order (bitwise equal)"""
+    """fp32 output with bias / relu / one or two addends, both block shapes (bitwise equal)"""
     from funasr_amd import ops
     if M == 32768 and N == 1028:
         pytest.skip("one ragged shape at the big M is enough")
@@ -79,9 +80,8 @@ def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
             assert torch.equal(wide, narrow), f"256x256 and 256x128 tiles differ {sorted(kw)}"
             auto = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=0, **kw)
             assert torch.equal(auto, narrow)
-            if "add1" not in kw:                                 # (the de-phased order exists for the forms the engine uses)
-                deph = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=8 + 256 * 16, **kw)
-                assert torch.equal(deph, narrow), f"de-phased order differs {sorted(kw)}"
+            pair = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=5, **kw)
+            assert torch.equal(pair, narrow), f"128x256 two-workgroups-per-CU shape differs {sorted(kw)}"
 
 
 @pytest.mark.parametrize("M", [70, 4000, 32768])
@@ -95,8 +95,8 @@ def test_gemm_f16x2_plane_output(cuda, M):
     eo = 9
     p_n = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=1)
     p_w = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=2)
-    p_d = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=8 + 256 * 16)
-    assert torch.equal(p_n, p_w) and torch.equal(p_d, p_w)
+    p_p = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=5)
+    assert torch.equal(p_n, p_w) and torch.equal(p_p, p_w)
     assert torch.isfinite(p_w.float()).all()
     val = _planes_value(p_w) * 2.0 ** -eo
     # the split adds <= 2^-22 of the element (+ the subnormal floor 2^-25 in the scaled domain)
@@ -118,6 +118,9 @@ def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
     bias = torch.randn(nseg * D, generator=g).to(cuda)
     q_mul, k_mul, v_mul = 128 ** -0.5 * 2.0 ** 7, 2.0 ** 6, 2.0 ** 5
     out = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form)
+    pair = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=5)
+    for key in ("q2", "k2", "v", "vt"):
+        assert (out[key] is None and pair[key] is None) or torch.equal(out[key], pair[key]), f"128x256 shape: {key} differs"
     ref, mag = _gemm_ref(a2, w2, se, bias)
     segs = dict(k=0, v=1) if kv_form else dict(q=0, k=1, v=2)
 
@@ -271,7 +274,8 @@ def test_attention_f16x2_variants_vs_float64(cuda, B, Tq, Tk, H):
 
 
 def test_split2_planes_and_subnormal_floor(cuda):
-    """x 2^e = hi + lo to 2^-24 relative, or to the fp16 subnormal step 2^-25 once lo underflows; no plane overflows at the bound"""
+    """x 2^e = hi + lo to 2^-23 relative in the worst case (x at the bottom of hi's binade, lo at the top of its own), or to
+    the fp16 subnormal step once lo underflows; no plane overflows at the bound"""
     from funasr_amd import ops
     g = torch.Generator().manual_seed(3)
     x = torch.randn(257, 520, generator=g)
@@ -283,15 +287,16 @@ def test_split2_planes_and_subnormal_floor(cuda):
     assert not p[:, :, 520:].any()
     val = _planes_value(p)[:, :520] * 2.0 ** -e
     err = (val - x.double()).abs()
-    assert (err <= 2.0 ** -24 * x.double().abs() + 2.0 ** -25 * 2.0 ** -e).all()
+    assert (err <= 2.0 ** -23 * x.double().abs() + 2.0 ** -25 * 2.0 ** -e).all()
+    assert (err / x.double().abs().clamp_min(1e-3)).mean().item() < 2.0 ** -25       # typical: far below the worst case
 
 
 @pytest.mark.parametrize("K,N", [(512, 2048), (2048, 512)])
 def test_f16x2_range_adversarial_scales(cuda, K, N):
     """The a-priori plane exponents (engine.hip: LayerNorm output <= sqrt(D) max|gamma| + max|beta|; Linear <= b max_n sum_k |W| +
     |c|) on trained-scale parameters: gamma = 30, weights x 100. No plane overflows when every input sits AT the bound, and
-    inputs at 2^-20 of the bound keep the error inside the split's floor: |err| <= 2^-22 sum |a||w| + the subnormal step of each
-    operand's scaled domain."""
+    inputs at 2^-20 of the bound keep the error inside the split's floor: |err| <= 2^-21 sum |a||w| (both operands' 2^-23 plus
+    the dropped lo*lo term) + the subnormal step of each operand's scaled domain."""
     from funasr_amd import ops
     M = 300
     g = torch.Generator().manual_seed(K)
@@ -320,7 +325,7 @@ def test_f16x2_range_adversarial_scales(cuda, K, N):
         mag = a.double().abs() @ w.double().abs().T
         floor = 2.0 ** -25 * (2.0 ** -ea * w.double().abs().sum(dim=1)[None, :] + 2.0 ** -ew * a.double().abs().sum(dim=1)[:, None])
         err = (out.double() - ref).abs()
-        bound = 2.0 ** -22 * mag + 1.5 * floor + 2.5e-7 * ref.abs() + 1e-7 * bias.abs().max().item()
+        bound = 2.0 ** -21 * mag + 1.5 * floor + 2.5e-7 * ref.abs() + 1e-7 * bias.abs().max().item()
         worst = (err / bound).max().item()
         assert worst <= 1.0, f"{name}: error is {worst:.2f}x the bound (max {err.max().item():.3e})"
         val = _planes_value(planes) * 2.0 ** -eo

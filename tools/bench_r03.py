@@ -33,7 +33,7 @@ if "attn" in which:
 
 if "gemm" in which:
     for name, N, K, kw in (("qkv_fp32out", 1536, 512, {}), ("w1_planes", 2048, 512, dict(relu=True, out_planes=True, out_scale_exp=9)),
-                           ("w2_resid", 512, 2048, dict(resid=True)), ("out_fp32", 512, 512, {})):
+                           ("w2_resid", 512, 2048, dict(resid=True)), ("out_resid", 512, 512, dict(resid=True)), ("out_fp32", 512, 512, {})):
         a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
         a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
         kw = dict(kw)
@@ -41,7 +41,7 @@ if "gemm" in which:
             kw["add2"] = torch.randn(M, N, device=dev)
         row = {}
         ref = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=2, **kw)
-        for label, tile in (("wide", 2), ("deph64", 8 + 256 * 8), ("deph128", 8 + 256 * 16), ("deph192", 8 + 256 * 24), ("wide_again", 2)):
+        for label, tile in (("wide", 2), ("narrow", 1), ("pair", 5), ("wide_again", 2), ("pair_again", 5)):
             out = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, **kw)
             ms = best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20, **kw)[1])
             row[label] = (round(ms * 1e3, 1), bool(torch.equal(out, ref)))
@@ -49,8 +49,9 @@ if "gemm" in which:
     # the QKV form (the engine's projection: Q / K planes, fp32 V, V^T planes)
     a = torch.randn(M, 512, device=dev); w = torch.randn(1536, 512, device=dev) * 512 ** -0.5; b = torch.randn(1536, device=dev)
     a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
-    ms = best(lambda: ops.gemm_f16x2_qkv(a2, w2, b, 512, 20, 2.0 ** 4, 2.0 ** 6, 2.0 ** 6, time_iters=20)["ms"])
-    print(json.dumps({"qkv_form_us": round(ms * 1e3, 1)}), flush=True)
+    row = {label: round(best(lambda: ops.gemm_f16x2_qkv(a2, w2, b, 512, 20, 2.0 ** 4, 2.0 ** 6, 2.0 ** 6, tile=tile, time_iters=20)["ms"]) * 1e3, 1)
+           for label, tile in (("wide", 0), ("pair", 5), ("wide_again", 0), ("pair_again", 5))}
+    print(json.dumps({"qkv_form_us": row}), flush=True)
 
 if "row" in which:
     gamma = torch.rand(512, device=dev) + 0.5; beta = torch.randn(512, device=dev)
