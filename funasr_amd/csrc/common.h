@@ -113,6 +113,21 @@ __device__ __forceinline__ void store_split2x4(unsigned short* p, size_t plane, 
     *reinterpret_cast<uint2*>(p + plane) = make_uint2(l0, l1);
 }
 
+// the same, but lanes 2k / 2k + 1 -- which hold columns c .. c + 3 / c + 4 .. c + 7 of ONE row, both active -- trade halves
+// (one DPP quad permute per dword) so that each issues ONE 16-B store (even lane: the hi plane's 8 columns, odd lane: the lo
+// plane's) instead of two 8-B stores: half the store instructions, each at the full store width. `p` = this lane's four
+// columns in the hi plane (16-B aligned for the even lane).
+__device__ __forceinline__ unsigned dpp_swap1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ void store_split2x4_pair(unsigned short* p, size_t plane, const float (&o)[4], float scale, int lane) {
+    unsigned h0, l0, h1, l1;
+    split2_pk(o[0] * scale, o[1] * scale, h0, l0);
+    split2_pk(o[2] * scale, o[3] * scale, h1, l1);
+    const bool odd = (lane & 1) != 0;
+    const unsigned r0 = dpp_swap1(odd ? h0 : l0), r1 = dpp_swap1(odd ? h1 : l1);
+    if (!odd) *reinterpret_cast<uint4*>(p) = make_uint4(h0, h1, r0, r1);
+    else *reinterpret_cast<uint4*>(p - 4 + plane) = make_uint4(r0, r1, l0, l1);
+}
+
 // ---------------------------------------------------------------- LayerNorm arithmetic shared by layernorm_kernel (rowwise.hip)
 // and the fused residual + LayerNorm epilogue (gemm_f16x2_row.hip): both evaluate exactly these expression trees in the same
 // order (per 4-column chunk, then chunk l + chunk l + 64, then the 64-lane xor butterfly 32, 16, .. 1), so the fused epilogue
@@ -220,6 +235,7 @@ struct Gemm2Args {
     int M, N, K;                                        // K % 32 == 0, N % 4 == 0
     int relu;
     int tile;                                           // 0 = pick by shape, 1 = 256 x 128, 2 = 256 x 256 (measurement hook)
+    long a_kstep, w_kstep;                              // > 0: K-blocked operand layout [K / 32][rows][32] (lda / ldw = 32, *_kstep = rows * 32)
     // QKV form (qkv_D > 0, N == 3 qkv_D, qkv_D % 256 == 0, M % 16 == 0): the fused q|k|v projection feeding
     // attention_f16x2.hip. Columns [0, D) -> planes of (result * q_mul) at Qp (ld D); [D, 2D) -> planes of
     // (result * k_mul) at Kp; [2D, 3D) -> fp32 at C (ld ldc; the FSMN memory block reads it) and the TRANSPOSED

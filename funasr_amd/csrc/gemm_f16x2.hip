@@ -93,9 +93,13 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
         }
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem) + (unsigned)wave * 1024);
+    // elements between the K stages of an operand row: KS in the row-major plane layout [rows, K]; rows * KS in the K-blocked
+    // layout [K / KS][rows][KS] (a_kstep / w_kstep > 0), where a piece's 16 rows are ONE contiguous KB = eight whole 128-B lines
+    // (row-major, a piece touches 64 B of sixteen lines and the other halves are fetched again by the next stage)
+    const size_t a_step = p.a_kstep > 0 ? (size_t)p.a_kstep : (size_t)KS, w_step = p.w_kstep > 0 ? (size_t)p.w_kstep : (size_t)KS;
     auto piece = [&](int i, int buf, int kt) {
         if constexpr (ABL == 3) return;
-        glds16(src[i] + kt * KS, lds0 + (unsigned)buf * STAGE_B + (unsigned)i * (G::NW * 1024));
+        glds16(src[i] + kt * (i < G::A_PIECES / G::NW ? a_step : w_step), lds0 + (unsigned)buf * STAGE_B + (unsigned)i * (G::NW * 1024));
     };
 
     floatx16 acc[WM][WN];
@@ -273,6 +277,8 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int col = n0 + wc * (WN * 32) + c4 * 4;
     const bool colok = col + 3 < p.N;
+    // plane output: 16-B stores by lane pairs when a pair's 8 columns are always valid together and 16-B aligned
+    const bool wide_st = OUT == 1 && p.N % 8 == 0 && p.ldc2 % 8 == 0 && p.c_plane % 8 == 0 && ((uintptr_t)p.C2 & 15) == 0;
     const float oscale = p.oscale_dev ? p.oscale * *p.oscale_dev : p.oscale;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && colok) bias4 = *reinterpret_cast<const float4*>(p.bias + col);
@@ -318,12 +324,13 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
                 if constexpr (HAS_R2) { o[0] = r2[it].x + o[0]; o[1] = r2[it].y + o[1]; o[2] = r2[it].z + o[2]; o[3] = r2[it].w + o[3]; }
                 if (row >= p.M) continue;
                 if constexpr (ABL == 1) { if (o[0] == 123.456f) p.C[0] = o[1] + o[2] + o[3]; continue; }
-                if constexpr (OUT == 2) {
-                    if (seg == 0) store_split2x4(p.Qp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.q_mul);
-                    else if (seg == 1) store_split2x4(p.Kp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, k_mul);
+                if constexpr (OUT == 2) {           // (qkv_D % 256 == 0: a lane pair's 8 columns lie in one segment)
+                    if (seg == 0) store_split2x4_pair(p.Qp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, p.q_mul, lane);
+                    else if (seg == 1) store_split2x4_pair(p.Kp + (size_t)row * p.qkv_D + scol, p.qk_plane, o, k_mul, lane);
                     else if (p.C) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + scol) = make_float4(o[0], o[1], o[2], o[3]);
                 } else if constexpr (OUT == 1) {
-                    store_split2x4(p.C2 + (size_t)row * p.ldc2 + col, p.c_plane, o, p.cscale);
+                    if (wide_st) store_split2x4_pair(p.C2 + (size_t)row * p.ldc2 + col, p.c_plane, o, p.cscale, lane);
+                    else store_split2x4(p.C2 + (size_t)row * p.ldc2 + col, p.c_plane, o, p.cscale);
                 } else if constexpr (ABL == 4) {
                     // same store instructions, but into a 64-KB window that stays in L2: issue cost without the HBM drain
                     *reinterpret_cast<float4*>(p.C + (size_t)(row & 63) * 256 + (col & 255)) = make_float4(o[0], o[1], o[2], o[3]);
@@ -372,6 +379,8 @@ __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x
     if (scale_dev) scale *= *scale_dev;
     const int c4n = ldy >> 2;
     const size_t total = (size_t)M * c4n;
+    // threads 2k / 2k + 1 hold neighbouring 4-column groups of one row and run the same trip count when ldy % 8 == 0
+    const bool wide_st = ldy % 8 == 0 && plane % 8 == 0 && ((uintptr_t)y & 15) == 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int row = (int)(i / c4n), c = (int)(i % c4n) * 4;
         int xrow = row;
@@ -390,7 +399,8 @@ __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (c + e < N) v[e] = x[(size_t)xrow * ldx + c + e];
         }
-        store_split2x4(y + (size_t)row * ldy + c, plane, v, scale);
+        if (wide_st) store_split2x4_pair(y + (size_t)row * ldy + c, plane, v, scale, threadIdx.x);
+        else store_split2x4(y + (size_t)row * ldy + c, plane, v, scale);
     }
 }
 

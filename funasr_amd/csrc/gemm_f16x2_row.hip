@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
             const float4 y = ln_apply4(ov[i][it], ST[rl], ST[RW_BM + rl], g4, b4);
             if (p.Y2) {
                 const float yv[4] = {y.x, y.y, y.z, y.w};
-                store_split2x4(p.Y2 + (size_t)row * p.ldy2 + col, p.y_plane, yv, p.yscale);
+                store_split2x4_pair(p.Y2 + (size_t)row * p.ldy2 + col, p.y_plane, yv, p.yscale, lane);
             } else {
                 *reinterpret_cast<float4*>(p.Yf + (size_t)row * p.ldyf + col) = y;
             }
@@ -273,7 +273,7 @@ int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream) {
     if (ln) {
         PF_REQUIRE(a.ln_b && ((uintptr_t)a.ln_g & 15) == 0 && ((uintptr_t)a.ln_b & 15) == 0, "gemm_f16x2_row: LayerNorm parameters");
         PF_REQUIRE((a.Y2 != nullptr) != (a.Yf != nullptr), "gemm_f16x2_row: the LayerNorm form writes planes (Y2) or fp32 (Yf)");
-        if (a.Y2) PF_REQUIRE(a.ldy2 % 4 == 0 && a.y_plane % 4 == 0 && ((uintptr_t)a.Y2 & 7) == 0, "gemm_f16x2_row: plane output alignment");
+        if (a.Y2) PF_REQUIRE(a.ldy2 % 8 == 0 && a.y_plane % 8 == 0 && ((uintptr_t)a.Y2 & 15) == 0, "gemm_f16x2_row: plane output alignment");
         else PF_REQUIRE(a.ldyf % 4 == 0 && ((uintptr_t)a.Yf & 15) == 0, "gemm_f16x2_row: fp32 LayerNorm output alignment");
     } else {
         PF_REQUIRE(a.C, "gemm_f16x2_row: nothing to write");

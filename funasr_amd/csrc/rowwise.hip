@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = ln_rstd(q, D, eps);
     float* yr = y + (size_t)row * ldy;
     unsigned short* yb = reinterpret_cast<unsigned short*>(y) + (size_t)row * ldy;     // bf16 view (ldy in elements)
+    // plane output: lanes 2k / 2k + 1 hold neighbouring chunks of the row and pass the Dpad test together when Dpad % 8 == 0
+    const bool wide_st = OUT == 3 && Dpad % 8 == 0 && ldy % 8 == 0 && plane % 8 == 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane + 64 * j;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (4 * c < Dpad) {
             if constexpr (OUT == 3) {
                 const float ov[4] = {o.x, o.y, o.z, o.w};
-                store_split2x4(yb + 4 * c, plane, ov, oscale);
+                if (wide_st) store_split2x4_pair(yb + 4 * c, plane, ov, oscale, lane);
+                else store_split2x4(yb + 4 * c, plane, ov, oscale);
             } else if constexpr (OUT == 2) {
                 const float ov[4] = {o.x, o.y, o.z, o.w};
                 store_split3x4(yb + 4 * c, plane, ov);

@@ -269,16 +269,28 @@ def split2(x: torch.Tensor, scale_exp: int = 0, kpad: int = 32) -> torch.Tensor:
     return y
 
 
+def kblocked(p2: torch.Tensor) -> torch.Tensor:
+    """planes [2, rows, K] -> the K-blocked layout [2, K / 32, rows, 32] (a 16-row DMA piece is one contiguous KB)"""
+    _, R, K = p2.shape
+    return p2.view(2, R, K // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
 def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=None, add2=None, scale_exp: int = 0,
-               out_planes=False, out_scale_exp: int = 0, tile: int = 0, time_iters: int = 0):
+               out_planes=False, out_scale_exp: int = 0, tile: int = 0, time_iters: int = 0, kblock: bool = False):
     """a2 [2, M, K], w2 [2, N, K] fp16 planes (ops.split2; scale_exp = the SUM of their scale exponents) -> fp32 [M, N]
     (or the planes [2, M, N] of the result * 2**out_scale_exp); fp32-class accuracy from three fp16 MFMA products per
     operand pair. With time_iters > 0 returns (out, ms per launch)."""
     lib = _lib.load()
     assert a2.dtype == torch.float16 and w2.dtype == torch.float16 and a2.is_contiguous() and w2.is_contiguous()
-    _, M, K = a2.shape
-    N = w2.shape[1]
-    assert w2.shape[2] == K
+    if kblock:                                   # operands made by kblocked(): [2, K / 32, rows, 32]
+        _, kb, M, _ = a2.shape
+        K, N, ld = kb * 32, w2.shape[2], 32
+        assert w2.shape[1] == kb
+        tile |= 0x1000
+    else:
+        _, M, K = a2.shape
+        N, ld = w2.shape[1], K
+        assert w2.shape[2] == K
     ms = C.c_float(0)
     if out_planes:
         out = torch.empty(2, M, N, device=a2.device, dtype=torch.float16)
@@ -286,7 +298,7 @@ def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=N
     else:
         out = torch.empty(M, N, device=a2.device, dtype=torch.float32)
         c, ldc, c2, ldc2, cpl = out, N, None, 0, 0
-    _lib.check(lib.pf_k_gemm_f16x2(_ptr(a2), K, M * K, _ptr(w2), K, N * K, float(2.0 ** -scale_exp), _ptr(bias),
+    _lib.check(lib.pf_k_gemm_f16x2(_ptr(a2), ld, M * K, _ptr(w2), ld, N * K, float(2.0 ** -scale_exp), _ptr(bias),
                                    _ptr(add1), add1.stride(0) if add1 is not None else 0,
                                    _ptr(add2), add2.stride(0) if add2 is not None else 0,
                                    _ptr(c), ldc, _ptr(c2), ldc2, cpl, float(2.0 ** out_scale_exp), M, N, K, int(relu),

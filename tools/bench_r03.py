@@ -41,16 +41,19 @@ if "gemm" in which:
             kw["add2"] = torch.randn(M, N, device=dev)
         row = {}
         ref = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=2, **kw)
-        for label, tile in (("wide", 2), ("narrow", 1), ("pair", 5), ("wide_again", 2), ("pair_again", 5)):
-            out = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, **kw)
-            ms = best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20, **kw)[1])
+        a2k, w2k = ops.kblocked(a2), ops.kblocked(w2)
+        for label, tile, kb in (("wide", 2, False), ("wide_kblock", 2, True), ("narrow", 1, False), ("narrow_kblock", 1, True),
+                                ("wide_again", 2, False), ("wide_kblock_again", 2, True)):
+            aa, ww = (a2k, w2k) if kb else (a2, w2)
+            out = ops.gemm_f16x2(aa, ww, b, scale_exp=20, tile=tile, kblock=kb, **kw)
+            ms = best(lambda: ops.gemm_f16x2(aa, ww, b, scale_exp=20, tile=tile, time_iters=20, kblock=kb, **kw)[1])
             row[label] = (round(ms * 1e3, 1), bool(torch.equal(out, ref)))
         print(json.dumps({name: row}), flush=True)
     # the QKV form (the engine's projection: Q / K planes, fp32 V, V^T planes)
     a = torch.randn(M, 512, device=dev); w = torch.randn(1536, 512, device=dev) * 512 ** -0.5; b = torch.randn(1536, device=dev)
     a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
     row = {label: round(best(lambda: ops.gemm_f16x2_qkv(a2, w2, b, 512, 20, 2.0 ** 4, 2.0 ** 6, 2.0 ** 6, tile=tile, time_iters=20)["ms"]) * 1e3, 1)
-           for label, tile in (("wide", 0), ("pair", 5), ("wide_again", 0), ("pair_again", 5))}
+           for label, tile in (("wide", 0), ("wide_again", 0))}
     print(json.dumps({"qkv_form_us": row}), flush=True)
 
 if "row" in which:
