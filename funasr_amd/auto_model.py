@@ -284,8 +284,16 @@ class AutoModel:
             load_pretrained_model(init_param, model, ignore_init_mismatch=kwargs.get("ignore_init_mismatch", True))
         elif init_param is not None:
             logging.warning("init_param %s does not exist: model keeps its initial weights", init_param)
-        if kwargs.get("fp16", False) or kwargs.get("bf16", False):
-            raise NotImplementedError("fp16/bf16 storage of the parameters is not built: the HIP path computes in fp32")
+        # the reference casts the whole module (auto_model.py:664-668); here the kwargs choose the OPERAND mode of the GEMMs and
+        # the attention -- parameters, residual stream, LayerNorm statistics, softmax and the CIF predictor stay fp32:
+        # bf16=True -> bf16 operands, fp32 accumulate (bf16-class error, like the reference's cast);
+        # fp16=True -> the fp16 matrix cores with two-plane operands ("f16x2": fp32-class results, also the default)
+        if kwargs.get("bf16", False) or kwargs.get("fp16", False):
+            mode = "bf16" if kwargs.get("bf16", False) else "f16x2"
+            if hasattr(model, "set_precision"):
+                model.set_precision(mode)
+            else:
+                logging.warning("%s has no arithmetic modes: fp16 / bf16 ignored", type(model).__name__)
         model.to(device)
         model.eval()
         return model, kwargs
@@ -418,7 +426,7 @@ class AutoModel:
                 fe = kwargs.get("frontend")
                 frames = [fe.num_frames(int(d * 16)) if hasattr(fe, "num_frames") else max(1, int(d) // 60) for d in durs]
                 plan = dp.plan_batches_by_rows(frames, int(kwargs["batch_size_rows"]), extra_rows=1,
-                                               packed=getattr(getattr(self.model, "encoder", None), "_precision", "fp32") == "f16x2")
+                                               packed=getattr(getattr(self.model, "encoder", None), "_mode", lambda: "fp32")() == "f16x2")
             for beg, end in plan:
                 idx = order[beg:end]
                 # slice_padding_audio_samples (funasr/utils/vad_utils.py:28-51): 16 samples per millisecond

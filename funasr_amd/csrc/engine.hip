@@ -1406,6 +1406,9 @@ pf_encoder* pf_encoder_create(const pf_encoder_config* cfg) {
     }
     std::unique_ptr<Encoder> e(new Encoder());
     e->cfg = c;
+    // default arithmetic: the f16x2 mode (fp32-class results on the fp16 matrix cores, the measured mode) wherever its
+    // kernels exist, the fp32 MFMA otherwise; pf_encoder_set_precision overrides
+    e->precision = (c.n_heads > 0 && c.d_model / c.n_heads == 128 && c.d_model % 256 == 0 && c.ffn_dim % 256 == 0) ? 3 : 0;
     std::vector<std::pair<std::string, int>> names;
     enc_layer_names(names, c);
     const int D = c.d_model, F = c.ffn_dim;
@@ -1445,7 +1448,7 @@ int pf_encoder_set_tensor(pf_encoder* eh, const char* name, const float* data, i
     e->tt.drop_bf16();
     return e->tt.set(name, data, numel);
 }
-/* 0 = fp32 MFMA (parity mode, default), 1 = bf16 operands for the GEMMs and the attention (fp32 accumulate, fp32
+/* 0 = fp32 MFMA, 1 = bf16 operands for the GEMMs and the attention (fp32 accumulate, fp32
  * residual stream / LayerNorm statistics / softmax / FSMN): the throughput mode of BASELINE configs[1] */
 int pf_encoder_set_precision(pf_encoder* eh, int32_t mode) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);
@@ -1926,6 +1929,7 @@ static pf_decoder* decoder_create_impl(const pf_decoder_config* cfg, bool contex
     }
     std::unique_ptr<Decoder> d(new Decoder());
     d->cfg = c;
+    d->precision = (c.n_heads > 0 && c.d_model / c.n_heads == 128 && c.d_model % 256 == 0 && c.ffn_dim % 256 == 0) ? 3 : 0;
     d->contextual = contextual;
     const int D = c.d_model, F = c.ffn_dim;
     int rc = 0;
@@ -2310,6 +2314,7 @@ pf_ctc* pf_ctc_create(int32_t d_model, int32_t vocab) {
     if (d_model <= 0 || d_model % 32 || vocab <= 0) { set_error("ctc: d_model % 32 == 0 required"); return nullptr; }
     std::unique_ptr<Ctc> c(new Ctc());
     c->d_model = d_model; c->vocab = vocab;
+    c->precision = 3;                        // the fused arg-max route on the fp16 matrix cores (pf_ctc_set_precision(c, 0): fp32 MFMA)
     if (c->tt.add("ctc_lo.weight", (int64_t)vocab * d_model) || c->tt.add("ctc_lo.bias", vocab)) return nullptr;
     return reinterpret_cast<pf_ctc*>(c.release());
 }

@@ -20,9 +20,12 @@ class CTC(HipModule):
         self.odim, self.eprojs = odim, encoder_output_size
         self.ctc_lo = linear(odim, encoder_output_size)
 
-    def set_precision(self, mode: str = "fp32"):
-        """"fp32" (default) or "f16x2": the arg-max route on the fp16 matrix cores from two-plane operands (fp32-class
-        logits, three products; gemm_f16x2.hip). Other mode names keep the fp32 kernel."""
+    def _mode(self) -> str:
+        return getattr(self, "_precision", None) or ("f16x2" if self.eprojs % 32 == 0 else "fp32")
+
+    def set_precision(self, mode=None):
+        """"f16x2" (default): the arg-max route on the fp16 matrix cores from two-plane operands (fp32-class logits, three
+        products; gemm_f16x2.hip). "fp32": the fp32 MFMA kernel; other mode names keep it too. None restores the default."""
         self._precision = mode
         return self
 
@@ -34,7 +37,7 @@ class CTC(HipModule):
 
     def _run(self, hs_pad, want_logits):
         lib, h = self._ensure_handle()
-        _lib.check(lib.pf_ctc_set_precision(h, 3 if getattr(self, "_precision", "fp32") == "f16x2" else 0), "pf_ctc_set_precision")
+        _lib.check(lib.pf_ctc_set_precision(h, 3 if self._mode() == "f16x2" else 0), "pf_ctc_set_precision")
         dev = self._handle_device
         x = hs_pad.to(device=dev, dtype=torch.float32).contiguous()
         lead = x.shape[:-1]
@@ -72,5 +75,5 @@ class CTC(HipModule):
             head = head.to(self.ctc_lo.weight.device)
             cache.clear()
             cache.update(key=key, head=head)
-        cache["head"].set_precision(getattr(self, "_precision", "fp32"))
+        cache["head"].set_precision(getattr(self, "_precision", None))
         return cache["head"]

@@ -63,7 +63,7 @@ class Paraformer(nn.Module):
         self.ctc_weight = ctc_weight
         self.beam_search = None
         self.nbest = 1
-        if kwargs.get("precision"):                      # model_conf: {precision: fp32 | bf16x3 | bf16}
+        if kwargs.get("precision"):                      # model_conf: {precision: f16x2 | fp32 | bf16x3 | bf16}
             self.set_precision(kwargs["precision"])
 
     # ------------------------------------------------------------------------------------------------ builders
@@ -79,13 +79,16 @@ class Paraformer(nn.Module):
                    decoder_conf=dc, predictor="CifPredictorV2", predictor_conf=dict(cfg["predictor"]), ctc_weight=0.0,
                    input_size=input_size, vocab_size=vocab)
 
-    def set_precision(self, mode: str = "fp32"):
-        """"fp32": exact-fp32 MFMA everywhere (default). "bf16x3": the same fp32 results with the large GEMMs on the bf16
-        matrix cores from three-plane split operands (meets the fp32 parity bars; for large batches). "bf16": bf16 operands
-        for the encoder's and the decoder's GEMMs and attention (fp32 accumulate / residual / LN / softmax / FSMN), bf16-class
-        error. The CIF predictor is fp32 in every mode."""
+    def set_precision(self, mode=None):
+        """"f16x2" (the default): fp32-class results, every GEMM / attention operand as two fp16 planes on the fp16 matrix
+        cores (three products, fp32 accumulate) -- the measured mode, meets every fp32 parity bar. "fp32": exact-fp32 MFMA
+        everywhere (the opt-out, 2.4x slower). "bf16x3": fp32-class results from three bf16 planes (six products). "bf16": bf16
+        operands (fp32 accumulate / residual / LN / softmax / FSMN), bf16-class error. The CIF predictor is fp32 in every
+        mode. None restores the default."""
         self.encoder.set_precision(mode)
         self.decoder.set_precision(mode)
+        if getattr(self, "ctc", None) is not None and hasattr(self.ctc, "set_precision"):
+            self.ctc.set_precision(mode)
         return self
 
     # ------------------------------------------------------------------------------------------- device pipeline

@@ -74,10 +74,18 @@ class ParaformerSANMDecoder(HipModule):
         # SeACo's bias decoder is built with use_output_layer false: forward() returns the hidden states (decoder.py:332-335)
         self.output_layer = linear(vocab_size, D) if use_output_layer else None
 
-    def set_precision(self, mode: str = "fp32"):
-        """"fp32" (default, parity), "bf16" (bf16 operands for the GEMMs + cross-attention on the greedy route) or
-        "bf16x3" (fp32 results from bf16x3 split operands for the large GEMMs, see SANMEncoder.set_precision)."""
-        if mode not in ("fp32", "bf16", "bf16x3", "f16x2"):
+    def _default_precision(self) -> str:
+        ok = self.d_model % 256 == 0 and self.d_model // self.attention_heads == 128 and self.linear_units % 256 == 0
+        return "f16x2" if ok else "fp32"
+
+    def _mode(self) -> str:
+        return getattr(self, "_precision", None) or self._default_precision()
+
+    def set_precision(self, mode=None):
+        """"f16x2" (default where supported: fp32-class results from two-plane fp16 operands on the fp16 matrix cores), "fp32"
+        (exact fp32 MFMA, the opt-out), "bf16x3", "bf16" (bf16 operands on the greedy route); see SANMEncoder.set_precision.
+        None restores the default."""
+        if mode is not None and mode not in ("fp32", "bf16", "bf16x3", "f16x2"):
             raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3' or 'f16x2'")
         self._precision = mode
         return self
@@ -88,7 +96,7 @@ class ParaformerSANMDecoder(HipModule):
 
     def _run(self, hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits: bool, want_ids: bool, want_hidden: bool = False):
         lib, h = self._ensure_handle()
-        _lib.check(lib.pf_decoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[getattr(self, "_precision", "fp32")]),
+        _lib.check(lib.pf_decoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[self._mode()]),
                    "pf_decoder_set_precision")
         dev = self._handle_device
         mem = hs_pad.to(device=dev, dtype=torch.float32).contiguous()

@@ -73,11 +73,25 @@ class _SANMEncoderBase(HipModule):
     def output_size(self) -> int:
         return self._output_size
 
-    def set_precision(self, mode: str = "fp32"):
-        """"fp32": exact fp32 MFMA (default, the parity configuration). "bf16": bf16 operands for the GEMMs and the
-        attention with fp32 accumulation / residual stream / LayerNorm / softmax -- the throughput mode. "bf16x3": fp32
-        results from operands split into three bf16 planes (x = hi + mid + lo exactly), six bf16 MFMA products per GEMM
-        operand pair -- fp32-class error at the bf16 matrix rate; everything but the GEMMs is the fp32 path."""
+    def _default_precision(self) -> str:
+        """The measured mode wherever its kernels exist (heads of d_k = 128, d_model % 256 == 0: Paraformer, SenseVoice and
+        their variants), fp32 otherwise (the CT-Transformer's small heads)."""
+        ok = self._output_size % 256 == 0 and self._output_size // self.attention_heads == 128 and self.linear_units % 256 == 0
+        return "f16x2" if ok else "fp32"
+
+    def _mode(self) -> str:
+        return getattr(self, "_precision", None) or self._default_precision()
+
+    def set_precision(self, mode: Optional[str] = None):
+        """"f16x2" (the default where supported, see _default_precision): fp32-class results with every GEMM / attention
+        operand split into two fp16 planes (x 2^e = hi + lo), three fp16 MFMA products per operand pair, fp32 accumulate --
+        meets every fp32 parity bar (tests/test_parity_gpu.py). "fp32": every product on the exact fp32 MFMA (the opt-out;
+        2.4x slower). "bf16x3": fp32-class results from three bf16 planes, six products. "bf16": bf16 operands with fp32
+        accumulation / residual stream / LayerNorm / softmax -- bf16-class error (what the reference's `bf16=True` asks for).
+        None restores the default."""
+        if mode is None:
+            self._precision = None
+            return self
         if mode not in ("fp32", "bf16", "bf16x3", "f16x2"):
             raise ValueError("precision must be 'fp32', 'bf16', 'bf16x3' or 'f16x2'")
         self._precision = mode
@@ -116,7 +130,7 @@ class _SANMEncoderBase(HipModule):
 
     def _run(self, xs_pad: torch.Tensor, ilens, run_blocks: int = -1):
         lib, h = self._ensure_handle()
-        _lib.check(lib.pf_encoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[getattr(self, "_precision", "fp32")]),
+        _lib.check(lib.pf_encoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[self._mode()]),
                    "pf_encoder_set_precision")
         pack = getattr(self, "_row_packing", self.ALL_ROWS)
         _lib.check(lib.pf_encoder_set_row_packing(h, -1 if pack is None else int(pack)), "pf_encoder_set_row_packing")
@@ -167,8 +181,11 @@ class SANMVadEncoder(SANMEncoder):
     the SAN-M encoder with the same parameters and state_dict keys, whose self-attention is causal in every block and masked
     by the VAD corner (transformer/utils/mask.py:38-52) in the last one. `forward(xs_pad, ilens, vad_indexes)`. fp32 mode."""
 
+    def _default_precision(self) -> str:
+        return "fp32"
+
     def forward(self, xs_pad: torch.Tensor, ilens, vad_indexes=None, prev_states=None, ctc=None):
-        if getattr(self, "_precision", "fp32") != "fp32":
+        if self._mode() != "fp32":
             raise NotImplementedError("SANMVadEncoder(HIP): the masked attention is built for the fp32 mode")
         B = xs_pad.shape[0]
         vad = [0] * B if vad_indexes is None else [int(v) for v in torch.as_tensor(vad_indexes).reshape(-1).tolist()]

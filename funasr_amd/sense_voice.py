@@ -75,10 +75,10 @@ class SenseVoiceSmall(nn.Module):
         self.emo_dict = {"unk": 25009, "happy": 25001, "sad": 25002, "angry": 25003, "neutral": 25004}   # model.py:738-744
         self.embed = nn.Embedding(7 + len(self.lid_dict) + len(self.textnorm_dict), input_size)
         self.embed.weight.requires_grad_(False)
-        if kwargs.get("precision"):                      # model_conf: {precision: fp32 | bf16x3 | bf16}
+        if kwargs.get("precision"):                      # model_conf: {precision: f16x2 | fp32 | bf16x3 | bf16}
             self.set_precision(kwargs["precision"])
 
-    def set_precision(self, mode: str = "fp32"):
+    def set_precision(self, mode=None):
         """Arithmetic mode of the encoder (see SANMEncoder.set_precision); in "f16x2" the CTC projection with its fused
         arg-max runs from two-plane operands too, otherwise it stays on the fp32 MFMA."""
         self.encoder.set_precision(mode)

@@ -112,13 +112,15 @@ void pf_encoder_destroy(pf_encoder* e);
 int pf_encoder_set_tensor(pf_encoder* e, const char* name, const float* data, int64_t numel);
 /* number of tensors still missing (0 = ready) */
 int pf_encoder_missing(const pf_encoder* e);
-/* 0 = fp32 MFMA everywhere (default; the parity configuration: activations <= 1e-3, CIF indices equal to the CPU
- * reference). 1 = bf16 OPERANDS for the GEMMs and the attention with fp32 accumulation; residual stream, LayerNorm
- * statistics, softmax and FSMN stay fp32 (the reference's own bf16=True casts the whole module, auto_model.py:665-668).
- * 2 = fp32 results from the bf16 matrix cores: every GEMM operand is held as three bf16 planes (x = hi + mid + lo
- * exactly) and multiplied with six bf16 MFMA products, fp32 accumulate (gemm_split3.hip); everything else is mode 0.
- * Meets the same parity bars as mode 0 (tests/test_parity_gpu.py, fixture f32_mode); intended for large batches
- * (256-row tiles). */
+/* Arithmetic mode. 3 = "f16x2", THE DEFAULT wherever its kernels exist (d_model / n_heads == 128, d_model % 256 == 0,
+ * ffn_dim % 256 == 0; mode 0 otherwise): fp32-class results on the fp16 matrix cores -- every GEMM / attention operand is two
+ * fp16 planes of the tensor times a power of two (x 2^e = hi + lo), three MFMA products per operand pair, fp32 accumulate,
+ * fp32 residual stream / LayerNorm statistics / softmax / FSMN (gemm_f16x2.hip, gemm_f16x2_row.hip, attention_f16x2.hip).
+ * Meets every parity bar of mode 0 (activations <= 1e-3, CIF indices equal to the CPU reference; tests/test_parity_gpu.py,
+ * fixture f32_mode) and is the measured mode of bench.py. 0 = every product on the exact fp32 MFMA (the opt-out, 2.4x
+ * slower). 1 = bf16 OPERANDS for the GEMMs and the attention with fp32 accumulation (bf16-class error; the reference's own
+ * bf16=True casts the whole module, auto_model.py:665-668). 2 = fp32-class results from three bf16 planes per operand, six
+ * bf16 MFMA products (gemm_split3.hip). */
 int pf_encoder_set_precision(pf_encoder* e, int32_t mode);
 /* Row packing (mode 3 only; other modes ignore it). The reference runs the encoder over every row of the padded batch
  * [B, T] (sanm/encoder.py:428-470: masks, not skipping); its consumers read only a prefix of each sequence: the CTC head

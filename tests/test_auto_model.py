@@ -61,6 +61,21 @@ def test_build_from_model_dir_on_cpu_and_loud_failure(model_dir):
         am.generate(input=list(model_dir["waves"])[0])
 
 
+def test_default_precision_and_the_reference_fp16_bf16_kwargs(model_dir):
+    """the measured mode is the default; the reference's `bf16=True` / `fp16=True` construction kwargs
+    (funasr/auto/auto_model.py:664-668) select the operand mode instead of raising"""
+    am = AutoModel(model=model_dir["dir"], device="cpu")
+    assert am.model.encoder._mode() == "f16x2" and am.model.decoder._mode() == "f16x2"
+    assert AutoModel(model=model_dir["dir"], device="cpu", bf16=True).model.encoder._mode() == "bf16"
+    assert AutoModel(model=model_dir["dir"], device="cpu", fp16=True).model.decoder._mode() == "f16x2"
+    am.model.set_precision("fp32")
+    assert am.model.encoder._mode() == "fp32" and am.model.decoder._mode() == "fp32"
+    am.model.set_precision(None)
+    assert am.model.encoder._mode() == "f16x2"
+    from funasr_amd.sanm_encoder import SANMEncoder
+    assert SANMEncoder(input_size=256, output_size=256, attention_heads=8, linear_units=1024, num_blocks=1, input_layer="pe")._mode() == "fp32"
+
+
 def test_unknown_model_and_unbuilt_pipelines_raise(model_dir):
     with pytest.raises(FileNotFoundError):
         AutoModel(model="iic/not-a-local-dir", device="cpu")
