@@ -188,3 +188,68 @@ def speech_like(n_samples: int, seed: int, fs: int = 16000) -> torch.Tensor:
     x = x + 0.01 * torch.randn(n_samples, generator=g, dtype=torch.float64)
     x = x / x.abs().max() * 0.3
     return x.float()
+
+
+def confident_output_layer(weight: torch.Tensor, bias: torch.Tensor, hidden: torch.Tensor, margin: float = 4.0,
+                           merge_cos: float = 0.98, chunk: int = 2048):
+    """A "trained-like" output layer from a random one. A random Linear over 8404 classes puts the top two logits of a
+    position ~0.24 sigma apart on average with a FLAT density of gaps near zero: about one position in 10^4 is a near-tie
+    that any fp32 summation order flips, so id-level parity on random weights cannot tell a benign near-tie from a small
+    systematic error. A trained model is confident on in-distribution speech. This is the closed-form stand-in for that
+    training, on the hidden states `hidden` [n, D] the layer actually sees (the decoder's after_norm output at the token
+    positions of a calibration batch; the encoder output at valid frames for a CTC head), in ONE step (no iteration):
+      * position k is labelled with the class the random layer prefers for its CENTRED hidden state hc_k = h_k - mean (as
+        diverse a label sequence as before); positions whose centred states nearly coincide (cosine > merge_cos) take the
+        label of the first of them;
+      * W_c += M hc_k / |hc_k|^2 and b_c -= M hc_k . mean / |hc_k|^2 for every position k labelled c: adds exactly M to
+        position k's own logit of class c and M cos(hc_k, hc_j) |hc_j| / |hc_k| at any other position j. With
+        M = margin / (1 - merge_cos) a position's own class leads every class labelled at a non-merged position by >= ~margin.
+    Pure torch, runs on the tensors' device. Returns (weight, bias, stats); stats: min / median top-2 gap, the share of
+    positions with a top-2 gap above 1e-3, distinct classes, merged positions."""
+    W, b = weight.detach().clone().float(), bias.detach().clone().float()
+    H = hidden.detach().float()
+    n = H.shape[0]
+    mean = H.mean(0)
+    Hc = H - mean
+    nrm2 = (Hc * Hc).sum(1, keepdim=True).clamp_min(1e-12)
+    Hn = Hc / nrm2.sqrt()
+    blocks = [slice(r0, min(n, r0 + chunk)) for r0 in range(0, n, chunk)]
+    cls = torch.cat([(Hc[r] @ W.T).argmax(1) for r in blocks])
+    rep = torch.cat([((Hn[r] @ Hn.T) > merge_cos).float().argmax(1) for r in blocks])     # first near-duplicate (<= own index)
+    for _ in range(64):
+        nxt = rep[rep]
+        if bool(torch.equal(nxt, rep)):
+            break
+        rep = nxt
+    cls = cls[rep]
+    M = margin / (1.0 - merge_cos)
+    d = Hc / nrm2
+    W.index_add_(0, cls, M * d)
+    b.index_add_(0, cls, -M * (d @ mean))
+    gaps = []
+    for r in blocks:
+        v = (H[r] @ W.T + b).topk(2, dim=1).values
+        gaps.append(v[:, 0] - v[:, 1])
+    gaps = torch.cat(gaps)
+    ar = torch.arange(n, device=H.device)
+    stats = dict(min_gap=float(gaps.min()), median_gap=float(gaps.median()), frac_gap_above_1e3=float((gaps > 1e-3).float().mean()),
+                 distinct_classes=int(cls.unique().numel()), merged_positions=int((rep != ar).sum()), positions=int(n), boost=M)
+    return W, b, stats
+
+
+def make_paraformer_confident(model, feats: torch.Tensor, flens, margin: float = 4.0):
+    """Calibrate the output layer of a (synthetic) Paraformer mirror on one batch of features with confident_output_layer:
+    runs the model's own device path up to the decoder's hidden states at the token positions, rewrites
+    `decoder.output_layer.{weight,bias}` in place and returns ({state_dict key: cpu tensor} for the CPU oracle, stats)."""
+    enc, olens = model.encode(feats, flens)
+    embeds, token_num, _, _ = model.calc_predictor(enc, olens)
+    tok = [int(round(v)) for v in token_num.tolist()]
+    hid, _ = model.decoder(enc, olens, embeds, torch.tensor(tok), return_hidden=True)
+    H = torch.cat([hid[b, : tok[b]] for b in range(len(tok)) if tok[b] > 0])
+    lay = model.decoder.output_layer
+    W, b, stats = confident_output_layer(lay.weight.to(H.device), lay.bias.to(H.device), H, margin=margin)
+    with torch.no_grad():
+        lay.weight.copy_(W.to(lay.weight.device))
+        lay.bias.copy_(b.to(lay.bias.device))
+    model.decoder.mark_dirty()
+    return {"decoder.output_layer.weight": W.cpu(), "decoder.output_layer.bias": b.cpu()}, stats

@@ -358,7 +358,7 @@ def paraformer_decoder(memory: Tensor, mem_lens: Tensor, embeds: Tensor, tok_len
 def paraformer_greedy(feats: Tensor, lens: Tensor, sd: SD, cfg: dict, sos: int = 1, eos: int = 2, blank: int = 0):
     """Device half of Paraformer.inference, funasr/models/paraformer/model.py:596-666: encode -> predictor ->
     round().long() -> decoder -> log_softmax -> argmax per valid token -> drop sos/eos/blank.
-    Returns dict(enc, alphas, peaks, token_num, embeds, logits, ids (list of lists), raw_ids)."""
+    Returns dict(enc, alphas, peaks, token_num, embeds, hidden, logits, ids (list of lists), raw_ids)."""
     enc, olens = sanm_encoder(feats, lens, sd, cfg["encoder"], "encoder.")
     embeds, token_num, alphas, peaks = cif_predictor(enc, olens, sd, cfg["predictor"], "predictor.")
     tok = token_num.round().long()
@@ -366,7 +366,8 @@ def paraformer_greedy(feats: Tensor, lens: Tensor, sd: SD, cfg: dict, sos: int =
     if int(tok.max()) < 1:
         res.update(logits=None, ids=[[] for _ in range(feats.shape[0])], raw_ids=[[] for _ in range(feats.shape[0])])
         return res
-    logits = paraformer_decoder(enc, olens, embeds, tok, sd, cfg["decoder"], "decoder.")
+    logits, hidden = paraformer_decoder(enc, olens, embeds, tok, sd, cfg["decoder"], "decoder.", return_hidden=True)
+    res.update(hidden=hidden)          # the output layer's input (tests re-score it with a calibrated output layer)
     logp = torch.log_softmax(logits, dim=-1)
     raw, ids = [], []
     for b in range(feats.shape[0]):

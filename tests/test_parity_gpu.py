@@ -491,6 +491,24 @@ def test_full_configuration_ragged_batch_vs_oracle(cuda, f32_mode):
                     assert float(top2[i, pos, 0] - top2[i, pos, 1]) < 1e-4, f"clip {i} token {pos}: {x} != {y} and not a near-tie"
     assert worst < 1e-3, worst
     print(f"[{f32_mode}] encoder max|d| {worst:.2e}, min prefix-sum margin {margin:.2e}, near-tie token flips {flips}")
+    # ---- the same comparison with a CONFIDENT output layer (synth.confident_output_layer: the closed-form stand-in for
+    #      training, calibrated on this batch's own hidden states): top-2 gaps far above any summation-order noise, so the ids
+    #      must be identical on every position -- no near-tie waiver
+    over, stats = synth.make_paraformer_confident(model, feats, flens)
+    assert stats["frac_gap_above_1e3"] >= 0.999 and stats["distinct_classes"] > 200, stats
+    res2 = model.recognize_features(feats, flens)
+    W, b = over["decoder.output_layer.weight"], over["decoder.output_layer.bias"]
+    gaps = []
+    for i in range(len(clips)):
+        n = int(r["token_num"][i])
+        lg = r["hidden"][i, :n] @ W.T + b
+        assert lg.argmax(-1).tolist() == res2["raw_ids"][i], f"clip {i}: token ids differ with the confident output layer"
+        t2 = lg.topk(2, dim=-1).values
+        gaps.append(t2[:, 0] - t2[:, 1])
+    gaps = torch.cat(gaps)
+    assert float((gaps > 1e-3).float().mean()) >= 0.999
+    print(f"[{f32_mode}] confident output layer: {gaps.numel()} tokens identical, oracle top-2 gap min {float(gaps.min()):.3f} "
+          f"median {float(gaps.median()):.1f}, {stats['distinct_classes']} classes")
 
 
 def test_bf16_operand_mode_stays_close_to_fp32_mode(cuda):
