@@ -2513,10 +2513,10 @@ pf_stream* pf_stream_create(pf_encoder* eh, pf_predictor* ph, pf_decoder* dh, co
     const int K = d->cfg.kernel_size;
     const int dec_left = (K - 1) / 2 + (d->cfg.sanm_shift > 0 ? d->cfg.sanm_shift : 0);
     if (c.n_streams < 1 || c.chunk_left < 0 || c.chunk_cur < 1 || c.chunk_right < 0 || c.enc_look_back < 0 ||
-        c.dec_look_back < 0 || c.max_frames < c.chunk_cur || c.max_tokens < 1 || c.max_tokens > 24 ||
+        c.dec_look_back < 0 || c.max_frames < c.chunk_cur || c.max_tokens < 1 || c.max_tokens > 96 ||
         e->cfg.tp_blocks != 0 || e->cfg.d_model != 512 || d->cfg.d_model != 512 || p->cfg.d_model != 512 ||
         dec_left != K - 1) {
-        set_error("stream: unsupported config (d_model 512, look_back >= 0 (finite), max_tokens <= 24, causal decoder "
+        set_error("stream: unsupported config (d_model 512, look_back >= 0 (finite), max_tokens <= 96, causal decoder "
                   "FSMN i.e. sanm_shfit == (kernel_size-1)/2 as in paraformer_streaming/template.yaml:62)");
         return nullptr;
     }
@@ -2525,7 +2525,7 @@ pf_stream* pf_stream_create(pf_encoder* eh, pf_predictor* ph, pf_decoder* dh, co
     // weight (:347-357). The token capacity must cover that, or tokens would be dropped silently (stream.hip clamps
     // n_fired); the hipGraph cache key packs n_frames into 10 bits
     if (c.max_tokens < c.chunk_right + c.max_frames + 2 || c.max_frames >= 1024) {
-        set_error("stream: max_tokens (" + std::to_string(c.max_tokens) + ", limit 24) must cover chunk_right + max_frames + 2 = " +
+        set_error("stream: max_tokens (" + std::to_string(c.max_tokens) + "; the decoder's token rows per step are capped at 96) must cover chunk_right + max_frames + 2 = " +
                   std::to_string(c.chunk_right + c.max_frames + 2) + " possible fires per step; max_frames must stay below 1024");
         return nullptr;
     }

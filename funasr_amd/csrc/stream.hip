@@ -265,9 +265,13 @@ int launch_cif_chunk(const CifChunkArgs& a, hipStream_t stream) {
 }
 
 int launch_dec_fsmn_chunk(const DecFsmnChunkArgs& a, hipStream_t stream) {
-    PF_REQUIRE(a.C % 4 == 0 && a.N <= 24, "dec_fsmn_chunk: N <= 24 tokens per chunk");
+    // the token rows of a step live in registers beside the carried context: the kernel is instantiated for 24 (the 600 ms
+    // geometry: <= 17 fires per step), 48 and 96 token rows (e.g. chunk_size [0, 20, 10]: <= 43)
+    PF_REQUIRE(a.C % 4 == 0 && a.N <= 96, "dec_fsmn_chunk: at most 96 token rows per step");
     dim3 grid(ceil_div(a.C / 4, 128), a.S), block(128);
-    hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 24>), grid, block, 0, stream, a);
+    if (a.N <= 24) hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 24>), grid, block, 0, stream, a);
+    else if (a.N <= 48) hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 48>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 96>), grid, block, 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

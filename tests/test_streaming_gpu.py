@@ -178,7 +178,8 @@ def test_stream_other_chunk_geometries_match_reference_sessions(cuda, use_graph)
         sb.close()
 
 
-@pytest.mark.parametrize("chunk,enc_lb,dec_lb", [([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1)])
+@pytest.mark.parametrize("chunk,enc_lb,dec_lb", [([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1),
+                                                 ([0, 20, 10], 2, 1), ([0, 16, 8], 1, 1)])      # > 24 possible fires per step
 def test_stream_other_chunk_geometries_vs_streaming_oracle(cuda, chunk, enc_lb, dec_lb):
     """chunk_size / look-back settings other than the golden session's, against the (reference-pinned) streaming oracle
     on random online features: token ids and counts equal, encoder window within 1e-3."""

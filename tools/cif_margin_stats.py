@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Statistics behind the "CIF fire indices bit-exact" claim (SURVEY 7 / cif_predictor.py:835-846): over many clips, how close
+do the prefix sums of the CIF weights come to an integer (the fire decision margin), and how far apart are the GPU's and the
+CPU oracle's prefix sums at the same frame? A fire index can only differ where |ps_gpu - ps_cpu| exceeds the margin.
+
+GPU: the product path (frontend -> 50-block encoder -> CifPredictorV2) in its default mode; CPU: oracle/paraformer_oracle.py
+on the same clips (fp32 ATen kernels, prefix sums in float64 like cif_wo_hidden_v1). Prints one JSON object."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--clips", type=int, default=1024)
+ap.add_argument("--seconds", type=float, default=10.0)
+ap.add_argument("--gpu-batch", type=int, default=128)
+ap.add_argument("--cpu-batch", type=int, default=16)
+ap.add_argument("--precision", default=None)
+args = ap.parse_args()
+
+from funasr_amd import synth
+from funasr_amd.paraformer import Paraformer
+from funasr_amd.wav_frontend import WavFrontend
+from oracle import paraformer_oracle as O
+
+dev = torch.device("cuda:0")
+cfg = synth.PARAFORMER_LARGE
+sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
+model = Paraformer.from_config(cfg)
+model.load_state_dict(sd, strict=False)
+model = model.to(dev).set_precision(args.precision)
+shift, scale = synth.synthetic_cmvn(560)
+cmvn = torch.stack([shift, scale])
+fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0, device=dev)
+n = int(args.seconds * 16000)
+clips = [synth.speech_like(n, seed=20000 + i) for i in range(args.clips)]
+
+t0 = time.time()
+g_alpha, g_fire, g_tok = [], [], []
+for b0 in range(0, args.clips, args.gpu_batch):
+    batch = clips[b0: b0 + args.gpu_batch]
+    feats, flens = fe(torch.stack(batch).to(dev), [n] * len(batch))
+    res = model.recognize_features(feats, flens, return_intermediate=True)
+    g_alpha.append(res["alphas"].cpu()); g_fire.append(torch.floor(res["peaks"].cpu()) >= 1); g_tok += res["token_num"]
+g_alpha, g_fire = torch.cat(g_alpha), torch.cat(g_fire)
+t_gpu = time.time() - t0
+
+t0 = time.time()
+margins, deltas, a_err = [], [], []
+fire_mismatch_clips = token_count_mismatch = at_risk = frames = 0
+worst_ratio = float("inf")
+with torch.no_grad():
+    for b0 in range(0, args.clips, args.cpu_batch):
+        f, fl = O.wav_frontend(clips[b0: b0 + args.cpu_batch], cmvn)
+        enc, olens = O.sanm_encoder(f, fl, sd, cfg["encoder"], "encoder.")
+        _, token_num, alphas, peaks = O.cif_predictor(enc, olens, sd, cfg["predictor"], "predictor.")
+        for j in range(alphas.shape[0]):
+            i = b0 + j
+            a_c = alphas[j]
+            a_g = g_alpha[i, : a_c.numel()]
+            ps_c, ps_g = torch.cumsum(a_c.double(), 0), torch.cumsum(a_g.double(), 0)
+            fr = ps_c - torch.floor(ps_c)
+            m = torch.minimum(fr, 1 - fr)[ps_c > 0.5]
+            d = (ps_g - ps_c).abs()[ps_c > 0.5]
+            margins.append(m); deltas.append(d); a_err.append((a_g - a_c).abs().max())
+            frames += m.numel()
+            at_risk += int((m < 4 * d).sum())
+            worst_ratio = min(worst_ratio, float((m / d.clamp_min(1e-12)).min()))
+            fc = torch.floor(peaks[j]) >= 1
+            fire_mismatch_clips += int(not torch.equal(fc, g_fire[i, : fc.numel()]))
+            token_count_mismatch += int(int(token_num[j].round()) != g_tok[i])
+t_cpu = time.time() - t0
+margins, deltas = torch.cat(margins), torch.cat(deltas)
+edges = [0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 0.5000001]
+
+
+def hist(x):
+    return {f"[{edges[k]:g}, {edges[k + 1]:g})": int(((x >= edges[k]) & (x < edges[k + 1])).sum()) for k in range(len(edges) - 1)}
+
+
+print(json.dumps({
+    "what": "CIF fire decision margins vs GPU-CPU prefix-sum differences", "clips": args.clips, "clip_seconds": args.seconds,
+    "mode": model.encoder._mode(), "frames_compared": frames, "tokens": int(sum(g_tok)),
+    "clips_with_different_fire_indices": fire_mismatch_clips, "clips_with_different_token_count": token_count_mismatch,
+    "alpha_max_abs_diff": float(torch.stack(a_err).max()),
+    "prefix_sum_abs_diff": {"max": float(deltas.max()), "median": float(deltas.median()), "p99": float(deltas.quantile(0.99))},
+    "margin_to_integer": {"min": float(margins.min()), "p0.1": float(margins.quantile(0.001)), "median": float(margins.median())},
+    "frames_with_margin_below_4x_prefix_sum_diff": at_risk, "min_margin_over_diff_ratio": worst_ratio,
+    "margin_histogram": hist(margins), "prefix_sum_diff_histogram": hist(deltas),
+    "expected_frames_within_diff_of_an_integer": float((2 * deltas).sum()),     # uniform fractional parts: P(margin < d) = 2 d
+    "gpu_seconds": round(t_gpu, 2), "cpu_oracle_seconds": round(t_cpu, 1), "cpu_threads": torch.get_num_threads()}))
