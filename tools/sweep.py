@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="assemble, decode and collect one batch at a time")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--enc-option", action="append", default=[], metavar="KEY=VALUE", help="encoder schedule options (pf_encoder_set_option)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = 0 if args.dist_backend == "gloo" else int(os.environ.get("LOCAL_RANK", 0))
@@ -72,6 +73,9 @@ def main():
     if world > 1:
         dp.broadcast_model(model)
     model.set_precision(args.precision) if hasattr(model, "set_precision") else model.encoder.set_precision(args.precision)
+    for kv in args.enc_option:
+        key, _, val = kv.partition("=")
+        model.encoder.set_option(key, int(val))
     sh, sc = synth.synthetic_cmvn(560)
     fe = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0, device=dev)
 
