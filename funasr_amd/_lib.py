@@ -101,6 +101,9 @@ SIGNATURES = {
     "pf_encoder_set_precision": (C.c_int, [_vp, _i32]),
     "pf_encoder_set_row_packing": (C.c_int, [_vp, _i32]),
     "pf_encoder_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "pf_encoder_debug_poison": (C.c_int, [_vp, _i32]),
+    "pf_decoder_debug_poison": (C.c_int, [_vp, _i32]),
+    "pf_predictor_debug_poison": (C.c_int, [_vp, _i32]),
     "pf_encoder_set_vad_mask": (C.c_int, [_vp, _vp, _i32]),
     "pf_encoder_forward": (C.c_int, [_vp, _vp, _pi32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "pf_predictor_create": (_vp, [C.POINTER(pf_predictor_config)]),

@@ -1472,6 +1472,31 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     set_error("encoder_set_option: unknown key " + k);
     return -1;
 }
+/* test hook: fill every activation workspace of the handle with `byte` (0x7B: huge FINITE fp16 / fp32 patterns). A forward
+ * must not depend on what earlier batches left in the workspaces -- whatever it reads past its own rows is masked exactly --
+ * so results before and after poisoning are bitwise equal (tests/test_stateless_gpu.py). Synchronises. */
+static int poison(std::initializer_list<DevBuf*> bufs, int byte) {
+    PF_HIP_TRY(hipDeviceSynchronize());
+    for (DevBuf* b : bufs) if (b->p && b->cap) PF_HIP_TRY(hipMemset(b->p, byte, b->cap));
+    PF_HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+int pf_encoder_debug_poison(pf_encoder* eh, int32_t byte) {
+    Encoder* e = reinterpret_cast<Encoder*>(eh);
+    PF_REQUIRE(e, "encoder_debug_poison: null");
+    return poison({&e->x, &e->xn, &e->qkv, &e->mem, &e->ctx, &e->ffn, &e->xn16, &e->qkv16, &e->ctx16, &e->ffn16, &e->q2, &e->k2, &e->vt2}, byte);
+}
+int pf_decoder_debug_poison(pf_decoder* dh, int32_t byte) {
+    Decoder* d = reinterpret_cast<Decoder*>(dh);
+    PF_REQUIRE(d, "decoder_debug_poison: null");
+    return poison({&d->x, &d->t1, &d->t2, &d->ffn, &d->ffn2, &d->q, &d->kv, &d->ctx, &d->pval, &d->pidx, &d->hid, &d->t16, &d->ffn16,
+                   &d->ffn2_16, &d->q16, &d->kv16, &d->ctx16, &d->mem16, &d->hid16, &d->k2, &d->vt2, &d->ids_packed}, byte);
+}
+int pf_predictor_debug_poison(pf_predictor* ph, int32_t byte) {
+    Predictor* p = reinterpret_cast<Predictor*>(ph);
+    PF_REQUIRE(p, "predictor_debug_poison: null");
+    return poison({&p->col, &p->conv, &p->alphas, &p->peaks, &p->rems, &p->flags, &p->nfires}, byte);
+}
 int pf_encoder_set_row_packing(pf_encoder* eh, int32_t extra_rows) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);
     PF_REQUIRE(e, "encoder_set_row_packing: null handle");

@@ -342,6 +342,11 @@ int pf_stream_peek(pf_stream* s, float* cif_alpha_host, float* cif_hidden_host, 
 int pf_frontend_fbank(pf_frontend* f, const float* wav_dev, int64_t n_samples, float* fbank_dev, void* stream);
 int pf_frontend_lfr_cmvn(pf_frontend* f, const float* frames_dev, int32_t T, int32_t rows, float* out_dev, void* stream);
 
+/* Test hooks: fill every activation workspace of the handle with `byte` (use 0x7B: huge finite fp16 / fp32 patterns). A
+ * forward must not depend on what earlier batches left there (tests/test_stateless_gpu.py). Synchronise. */
+int pf_encoder_debug_poison(pf_encoder* e, int32_t byte);
+int pf_decoder_debug_poison(pf_decoder* d, int32_t byte);
+int pf_predictor_debug_poison(pf_predictor* p, int32_t byte);
 /* -------------------------------------------------------------------------------- single kernels (tests / bench)
  * Thin wrappers over the individual gfx950 kernels so that parity tests and the roofline bench can drive one
  * kernel at a time through the same ABI. All pointers are device pointers. */

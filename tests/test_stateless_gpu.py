@@ -1,0 +1,52 @@
+"""A forward must not depend on what earlier batches left in the handle's workspaces. The kernels read past their own rows in a
+few places by design (the last 32-key tile of a sequence, the 32 slack rows behind the K planes, the slack columns of V^T,
+clamped tile rows): whatever is read there must be masked EXACTLY. The test fills every activation workspace with a huge finite
+pattern (0x7B bytes: fp16 61280, fp32 1.3e36) between two runs of the same input and requires bitwise-equal results -- for the
+shapes where a 1-rank and a 2-rank corpus sweep (different predecessors of a clip) were seen to disagree."""
+import pytest
+import torch
+
+from funasr_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _poison(model, byte=0x7B):
+    lib = _lib.load()
+    for mod, fn in ((model.encoder, lib.pf_encoder_debug_poison), (model.decoder, lib.pf_decoder_debug_poison),
+                    (model.predictor, lib.pf_predictor_debug_poison)):
+        if getattr(mod, "_handle", None) is not None:
+            _lib.check(fn(mod._handle, byte), "debug_poison")
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "fp32", "bf16x3"])
+@pytest.mark.parametrize("frames", [[103], [52], [109], [36, 103], [500, 103, 7], [16], [255, 256, 257]])
+def test_results_do_not_depend_on_stale_workspace_content(cuda, mode, frames):
+    from funasr_amd.paraformer import Paraformer
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=3, dec_blocks=2, vocab=8404)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=4, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
+    model = model.to(cuda).set_precision(mode)
+    g = torch.Generator().manual_seed(sum(frames))
+    T = max(frames)
+    feats = (torch.randn(len(frames), T, 560, generator=g) * 0.8).to(cuda)
+    for b, n in enumerate(frames):
+        feats[b, n:] = 0
+    # a bigger batch first, so that the workspaces are larger than this batch needs and hold another batch's data
+    big = (torch.randn(3, 300, 560, generator=g) * 0.8).to(cuda)
+    model.recognize_features(big, [300, 280, 120])
+    runs = []
+    for poison in (None, 0x7B, 0x00, 0x7B):
+        if poison is not None:
+            _poison(model, poison)
+        for all_rows in (False, True):
+            r = model.recognize_features(feats, frames, return_intermediate=all_rows)
+            runs.append((poison, all_rows, r))
+    base = {False: runs[0][2], True: runs[1][2]}
+    for poison, all_rows, r in runs[2:]:
+        ref = base[all_rows]
+        assert r["token_num"] == ref["token_num"], (poison, all_rows)
+        assert r["raw_ids"] == ref["raw_ids"], (poison, all_rows)
+        if all_rows:
+            assert torch.equal(r["enc"], ref["enc"]), f"encoder output depends on stale workspace content (poison {poison})"
+            assert torch.equal(r["alphas"], ref["alphas"])

@@ -22,6 +22,20 @@ from funasr_amd.paraformer import Paraformer
 from funasr_amd.wav_frontend import WavFrontend
 from oracle import paraformer_oracle as O
 
+def host_cores() -> int:
+    """min(affinity mask, cgroup quota): an OpenMP pool larger than the container's CPU quota runs ~100x slower"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+torch.set_num_threads(host_cores())
 dev = torch.device("cuda:0")
 cfg = synth.PARAFORMER_LARGE
 sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
