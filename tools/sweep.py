@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="assemble, decode and collect one batch at a time")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--trace-hash", default=None, help="debug: write per-clip bit hashes of the features, encoder output and CIF "
+                    "weights to this JSON file (rank r appends .r)")
     ap.add_argument("--enc-option", action="append", default=[], metavar="KEY=VALUE", help="encoder schedule options (pf_encoder_set_option)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -115,6 +117,7 @@ def main():
         clips[i] = arena[off: off + lens[i]]
         off += lens[i]
     timing = {"stage": 0.0, "enqueue": 0.0, "collect": 0.0}
+    trace_rows = []
     paraformer = hasattr(model, "enqueue_features")
 
     def launch(batch):
@@ -126,6 +129,11 @@ def main():
         timing["stage"] += time.perf_counter() - t
         t = time.perf_counter()
         feats, flens = fe(wav, L)
+        if args.trace_hash is not None and paraformer:
+            hb = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+            r = model.recognize_features(feats, flens, return_intermediate=True)
+            trace_rows.append({"clips": list(batch), "wav": hb(wav), "feats": hb(feats), "enc": hb(r["enc"]), "alphas": hb(r["alphas"]),
+                               "embeds": hb(r["embeds"]), "tok": r["token_num"], "ids": r["raw_ids"]})
         if paraformer:
             pending = model.enqueue_features(feats, flens)
         elif args.model == "sensevoice":
@@ -198,6 +206,9 @@ def main():
                           "padding_efficiency_rank0": round(mine_s / padded, 3),
                           "tokens_rank0": sum(len(v) for v in hyps.values()),
                           "host_seconds_rank0": {k: round(v, 3) for k, v in timing.items()}}), flush=True)
+    if args.trace_hash is not None:
+        with open(f"{args.trace_hash}.{rank}", "w") as f:
+            json.dump(trace_rows, f)
     if world > 1:
         dist.destroy_process_group()
 
