@@ -11,6 +11,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -261,10 +262,44 @@ static int check_device() {
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Host -> device uploads of per-call metadata (lengths, row maps, frame counts). hipMemcpyAsync from PAGEABLE host memory
+// may read its source when the copy command EXECUTES, not when the call returns -- with a busy queue (e.g. a second process
+// on the GPU) a std::vector local or a caller's ctypes array is gone or rewritten by then, and the kernel behind it sees
+// garbage (observed: a wrong frame count in the frontend, i.e. features that differed from run to run). Every such upload
+// therefore goes through a ring of PINNED staging slots owned by the library: the bytes are copied into a slot at call time,
+// the DMA reads the slot, and a slot is reused only after the event recorded behind its copy has completed.
+struct StageRing {
+    struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+    Slot slots[16];
+    int next = 0;
+    std::mutex mu;
+    int upload(void* dst, const void* src, size_t bytes, hipStream_t s) {
+        if (bytes == 0) return 0;
+        std::lock_guard<std::mutex> lock(mu);
+        Slot& sl = slots[next];
+        next = (next + 1) % 16;
+        if (sl.busy) { PF_HIP_TRY(hipEventSynchronize(sl.ev)); sl.busy = false; }
+        if (sl.cap < bytes) {
+            if (sl.p) (void)hipHostFree(sl.p);
+            sl.p = nullptr; sl.cap = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            PF_HIP_TRY(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
+            sl.cap = want;
+        }
+        if (!sl.ev) PF_HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        memcpy(sl.p, src, bytes);
+        PF_HIP_TRY(hipMemcpyAsync(dst, sl.p, bytes, hipMemcpyHostToDevice, s));
+        PF_HIP_TRY(hipEventRecord(sl.ev, s));
+        sl.busy = true;
+        return 0;
+    }
+};
+static StageRing g_stage;
+static int upload_h2d(void* dst, const void* src, size_t bytes, hipStream_t s) { return g_stage.upload(dst, src, bytes, s); }
+
 static int upload_lens(DevBuf& buf, const int32_t* host, int B, hipStream_t s) {
     if (buf.ensure(sizeof(int32_t) * (size_t)B)) return -2;
-    PF_HIP_TRY(hipMemcpyAsync(buf.p, host, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, s));
-    return 0;
+    return upload_h2d(buf.p, host, sizeof(int32_t) * (size_t)B, s);
 }
 
 // Instrumented launch helpers ---------------------------------------------------------------------------
@@ -1363,7 +1398,7 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
         if (nfr[b] > max_fr) max_fr = nfr[b];
     }
     if (f->nfr.ensure(sizeof(int32_t) * B)) return -2;
-    PF_HIP_TRY(hipMemcpyAsync(f->nfr.p, nfr.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    if (upload_h2d(f->nfr.p, nfr.data(), sizeof(int32_t) * B, s)) return -2;
     float* fb = fbank_out;
     if (!fb) {
         if (f->fbank.ensure(sizeof(float) * (size_t)B * max_fr * f->cfg.n_mels)) return -2;
@@ -1643,8 +1678,8 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
             for (int t = 0; t < rows; ++t) e->h_map[(size_t)e->h_offs[b] + t] = b * T + t;
         }
         if (e->offs_dev.ensure(sizeof(int32_t) * ((size_t)B + 1)) || e->map_dev.ensure(sizeof(int32_t) * M)) return -2;
-        PF_HIP_TRY(hipMemcpyAsync(e->offs_dev.p, e->h_offs.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, s));
-        PF_HIP_TRY(hipMemcpyAsync(e->map_dev.p, e->h_map.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
+        if (upload_h2d(e->offs_dev.p, e->h_offs.data(), sizeof(int32_t) * ((size_t)B + 1), s) ||
+            upload_h2d(e->map_dev.p, e->h_map.data(), sizeof(int32_t) * M, s)) return -2;
         if ((rc = launch_scale_add_pe_rows(xs, pe, x0, e->map_dev.as<int>(), (int)M, T, Din, scale, s))) return rc;
         e->cur_offs = e->offs_dev.as<int>();
         e->cur_M = (int)M;
@@ -1875,7 +1910,7 @@ int pf_predictor_timestamp(pf_predictor* ph, const float* hidden, const int32_t*
     int rc;
     if ((rc = upload_lens(p->lens, lens_host, B, s))) return rc;
     if (p->tok_dev.ensure(sizeof(int) * (size_t)B)) return -2;
-    PF_HIP_TRY(hipMemcpyAsync(p->tok_dev.p, token_num_host, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, s));
+    if (upload_h2d(p->tok_dev.p, token_num_host, sizeof(int32_t) * (size_t)B, s)) return -2;
     const float* src = hidden;
     if (p->c3.use_cif1_cnn) {                                   // the head sees relu(cif_conv1d(hidden)) instead (:317-320)
         if (p->col.ensure(sizeof(float) * M * taps * D) || p->conv.ensure(sizeof(float) * M * D)) return -2;
@@ -2150,8 +2185,8 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
             for (int b = 0; b < B; ++b) for (int t = 0; t < tok_lens[b]; ++t) d->h_map[(size_t)d->h_offs[b] + t] = b * N + t;
             if (d->offs_dev.ensure(sizeof(int32_t) * ((size_t)B + 1)) || d->map_dev.ensure(sizeof(int32_t) * (size_t)Mq_pad) ||
                 d->ids_packed.ensure(sizeof(int32_t) * (size_t)Mq_pad)) return -2;
-            PF_HIP_TRY(hipMemcpyAsync(d->offs_dev.p, d->h_offs.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, s));
-            PF_HIP_TRY(hipMemcpyAsync(d->map_dev.p, d->h_map.data(), sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, s));
+            if (upload_h2d(d->offs_dev.p, d->h_offs.data(), sizeof(int32_t) * ((size_t)B + 1), s) ||
+                upload_h2d(d->map_dev.p, d->h_map.data(), sizeof(int32_t) * (size_t)total, s)) return -2;
             if ((rc = launch_gather_rows(embeds, D, Mq_pad, d->map_dev.as<int>(), x, total, D, s))) return rc;
             pack = true; offs_dev = d->offs_dev.as<int>(); Mq = total;
         }
@@ -3053,7 +3088,7 @@ int pf_k_cif(const float* alphas, const float* hidden, int32_t B, int32_t T, int
         rm.ensure(sizeof(float) * (size_t)B * Te) || ff.ensure(sizeof(int) * (size_t)B * Te) ||
         ln.ensure(sizeof(int) * (size_t)B)) return -2;
     std::vector<int> lens(B, T);
-    PF_HIP_TRY(hipMemcpyAsync(ln.p, lens.data(), sizeof(int) * B, hipMemcpyHostToDevice, s));
+    if (upload_h2d(ln.p, lens.data(), sizeof(int) * B, s)) return -2;
     PF_HIP_TRY(hipMemcpy2DAsync(al.p, sizeof(float) * Te, alphas, sizeof(float) * T, sizeof(float) * T, B,
                                 hipMemcpyDeviceToDevice, s));
     CifScanArgs sa{};
