@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="assemble, decode and collect one batch at a time")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--stage-sync", type=int, default=0, help="debug: 1 = synchronize after staging the waveforms, 2 = after the "
+                    "frontend, 3 = hand the frontend a device-side clone of the staged batch, 4 = blocking H2D copies")
     ap.add_argument("--trace-hash", default=None, help="debug: write per-clip bit hashes of the features, encoder output and CIF "
                     "weights to this JSON file (rank r appends .r)")
     ap.add_argument("--enc-option", action="append", default=[], metavar="KEY=VALUE", help="encoder schedule options (pf_encoder_set_option)")
@@ -125,10 +127,16 @@ def main():
         L = [lens[i] for i in batch]
         wav = torch.zeros(len(batch), max(L), device=dev)
         for j, i in enumerate(batch):
-            wav[j, : L[j]].copy_(clips[i], non_blocking=True)
+            wav[j, : L[j]].copy_(clips[i], non_blocking=args.stage_sync != 4)
+        if args.stage_sync == 1:
+            torch.cuda.synchronize()
+        if args.stage_sync == 3:
+            wav = wav.clone()
         timing["stage"] += time.perf_counter() - t
         t = time.perf_counter()
         feats, flens = fe(wav, L)
+        if args.stage_sync == 2:
+            torch.cuda.synchronize()
         if args.trace_hash is not None and paraformer:
             hb = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
             r = model.recognize_features(feats, flens, return_intermediate=True)
