@@ -27,7 +27,15 @@ while time.time() < start_at:
     time.sleep(0.01)
 bad = []
 t0 = time.time()
-for it in range(iters):
+budget = float(os.environ.get("REPRO_SECONDS", "0"))
+it = -1
+while True:
+    it += 1
+    if budget > 0:
+        if time.time() - t0 > budget:
+            break
+    elif it >= iters:
+        break
     k = it % len(lens)
     wav = torch.zeros(1, lens[k], device=dev)
     wav[0, : lens[k]].copy_(pinned[k], non_blocking=True)
@@ -40,4 +48,4 @@ for it in range(iters):
         wav_ok = bool(torch.equal(wav[0].cpu(), host[k]))
         bad.append({"iter": it, "clip": k, "n_diff": int(idx.shape[0]), "max": float(d.max()), "wav_final_ok": wav_ok,
                     "rows": sorted(set(idx[:, 1].tolist()))[:10], "n_rows": len(set(idx[:, 1].tolist())), "T": f.shape[1]})
-print(json.dumps({"tag": tag, "sync_before": sync_before, "iters": iters, "seconds": round(time.time() - t0, 2), "mismatches": len(bad), "first": bad[:6]}))
+print(json.dumps({"tag": tag, "sync_before": sync_before, "iters": it, "seconds": round(time.time() - t0, 2), "mismatches": len(bad), "first": bad[:6]}))
