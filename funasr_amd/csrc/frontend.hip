@@ -46,6 +46,17 @@ __device__ __forceinline__ void bfly4(float2 (&v)[4], const float2 (&tw)[3]) {
 // only ever touches its own slice and its DS operations execute in order. Everything that does not change from frame to
 // frame lives in registers for the life of the wave: window coefficients, stage twiddles, and the weights of the (at
 // most two) mel-triangle pieces this lane accumulates.
+// VAR (experiment): how the wave orders its LDS write phase before the read phase of the next exchange
+//   0 = compiler scheduling barrier only (DS operations of one wave execute in order)
+//   1 = additionally s_waitcnt lgkmcnt(0) (workgroup-scope fence) at every exchange
+//   2 = a workgroup barrier at every exchange
+template <int VAR>
+__device__ __forceinline__ void lds_phase() {
+    if constexpr (VAR == 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+    if constexpr (VAR == 2) { __syncthreads(); }
+    __builtin_amdgcn_wave_barrier();
+}
+template <int VAR>
 __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_frames) {
     __shared__ float2 zs[WAVES_PER_BLOCK][NFFT / 2];          // exchange buffer / spectrum Z in natural order
     __shared__ float ps[WAVES_PER_BLOCK][NBIN + 7];           // power spectrum (+ zero tail for clamped piece reads)
@@ -111,13 +122,15 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
     };
     float ne[4], no[4];
     fetch(wave_id, ne, no);
-    for (int g = wave_id; g < total_frames; g += n_waves) {
+    for (int g0 = blockIdx.x * WAVES_PER_BLOCK; g0 < total_frames; g0 += n_waves) {      // (workgroup-uniform trip count)
+        const int g = g0 + wave;
         const int b = g / p.max_frames, f = g - b * p.max_frames;
         float xe[4], xo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xe[j] = ne[j]; xo[j] = no[j]; }
         fetch(g + n_waves, ne, no);
-        if (f >= p.n_frames[b]) continue;                      // wave-uniform
+        const bool live = g < total_frames && f < p.n_frames[b];   // wave-uniform
+        if (VAR != 2 && !live) continue;
 
         // ---- scale; DC removal (feature-window.cc:186-196)
         float s = 0.f;
@@ -153,29 +166,29 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
         bfly4(v, tw0);                                         // over d3; lane = p & 63
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * r + lane] = v[r];
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = z[64 * (lane >> 4) + 16 * r + (lane & 15)];
         bfly4(v, tw1);                                         // over d2
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * (lane >> 4) + 16 * r + (lane & 15)] = v[r];
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = z[64 * (lane >> 4) + 16 * ((lane >> 2) & 3) + 4 * r + (lane & 3)];
         bfly4(v, tw2);                                         // over d1
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * (lane >> 4) + 16 * ((lane >> 2) & 3) + 4 * r + (lane & 3)] = v[r];
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = z[4 * lane + r];
         bfly4(v, one);                                         // over d0 (no twiddles)
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
         // element (lane, r) is Z[digit-reversed position]: natural order into LDS
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
 
         // ---- real-input split X[k] = E + W_512^k O,  E = (Z[k] + conj Z[256-k]) / 2,  O = -i (Z[k] - conj Z[256-k]) / 2
         //      and the power spectrum, computed as abs() then square like torchaudio's spectrum.abs().pow(2)
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
                 pw[256] = m2 * m2;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
 
         // ---- mel projection: this lane's (<= 2) triangle pieces, then the pieces of its (<= 2) mel bins in fixed order
 #pragma unroll
@@ -205,19 +218,19 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
             for (int t = 0; t < 8; ++t) e = fmaf(pwgt[q][t], pw[pk0[q] + t], e);
             pt[lane + 64 * q] = e;
         }
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
         float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = lane + 64 * q;
-            if (m < p.n_mels) {
+            if (m < p.n_mels && live) {
                 float e = 0.f;
                 for (int c = 0; c < mcount[q]; ++c) e += pt[mfirst[q] + c];
                 e = fmaxf(e, 1.1920928955078125e-07f);         // feature-fbank.cc:102-106
                 out[m] = logf(e);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        lds_phase<VAR>();
     }
 }
 
@@ -265,7 +278,12 @@ int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t
     // persistent waves: enough workgroups to fill every CU several times over, each wave strides over the frames
     long long blocks = (total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks > 256 * 4) blocks = 256 * 4;      // 4 workgroups x 4 waves per CU = the 128-VGPR occupancy
-    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    static const int var = getenv("PF_FBANK_VAR") ? atoi(getenv("PF_FBANK_VAR")) : 0;
+    if (var == 2) {
+        // every wave of a workgroup must run the same number of iterations: round the frame count up to whole rounds
+        hipLaunchKernelGGL(fbank_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    } else if (var == 1) hipLaunchKernelGGL(fbank_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    else hipLaunchKernelGGL(fbank_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
