@@ -1516,6 +1516,19 @@ static int poison(std::initializer_list<DevBuf*> bufs, int byte) {
     PF_HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
+/* test hook: launches + waits for the LDS canary kernel (frontend.hip); returns the number of LDS words that changed under it */
+int pf_debug_lds_canary(int32_t blocks, int32_t spins, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned* d = nullptr;
+    unsigned h = 0;
+    PF_HIP_TRY(hipMalloc((void**)&d, sizeof(unsigned)));
+    PF_HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned), s));
+    int rc = launch_lds_canary(blocks, spins, d, s);
+    if (!rc && hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) rc = -2;
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = -2;
+    (void)hipFree(d);
+    return rc ? rc : (int)(h > 0x7fffffffu ? 0x7fffffff : h);
+}
 int pf_encoder_debug_poison(pf_encoder* eh, int32_t byte) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);
     PF_REQUIRE(e, "encoder_debug_poison: null");

@@ -38,4 +38,5 @@ struct LfrArgs {
 };
 int launch_lfr_cmvn(const LfrArgs& a, int B, hipStream_t stream);
 
+int launch_lds_canary(int blocks, int spins, unsigned* bad_dev, hipStream_t stream);
 }  // namespace pf

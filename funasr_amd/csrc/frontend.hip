@@ -264,7 +264,30 @@ __global__ __launch_bounds__(256) void lfr_cmvn_kernel(LfrArgs p) {
     *reinterpret_cast<float4*>(p.out + ((size_t)b * p.T_out + t) * D + c) = o;
 }
 
+// Test kernel: every workgroup fills its 14 KB of static LDS with a per-workgroup pattern, idles, and checks it again. Another
+// kernel on the same CU must never change it (LDS is private to a workgroup); a count > 0 means some co-resident kernel wrote
+// outside its own LDS allocation.
+__global__ __launch_bounds__(256) void lds_canary_kernel(int spins, unsigned* bad) {
+    __shared__ unsigned buf[3616];
+    const unsigned pat = 0x9e3779b9u * (blockIdx.x + 1);
+    for (int i = threadIdx.x; i < 3616; i += 256) buf[i] = pat ^ (unsigned)i;
+    __syncthreads();
+    unsigned n = 0;
+    for (int k = 0; k < spins; ++k) {
+        __builtin_amdgcn_s_sleep(64);
+        for (int i = threadIdx.x; i < 3616; i += 256) n += buf[i] != (pat ^ (unsigned)i);
+        __syncthreads();
+    }
+    if (n) atomicAdd(bad, n);
+}
+
 }  // namespace
+
+int launch_lds_canary(int blocks, int spins, unsigned* bad_dev, hipStream_t stream) {
+    hipLaunchKernelGGL(lds_canary_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, spins, bad_dev);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream) {
     PF_REQUIRE(a.frame_len <= 512 && a.frame_len > 0, "fbank: frame length must be <= 512 samples");
