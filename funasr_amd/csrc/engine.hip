@@ -1410,6 +1410,7 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
+    a.dbg = g_fbank_dbg;
     int rc;
     {
         double bytes = 0;
@@ -1516,6 +1517,9 @@ static int poison(std::initializer_list<DevBuf*> bufs, int byte) {
     PF_HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
+static float* g_fbank_dbg = nullptr;
+/* test hook: device buffer of 900 floats per fbank frame that the next frontend forwards fill with intermediates (NULL: off) */
+int pf_debug_set_fbank_dump(float* dev) { g_fbank_dbg = dev; return 0; }
 /* test hook: launches + waits for the LDS canary kernel (frontend.hip); returns the number of LDS words that changed under it */
 int pf_debug_lds_canary(int32_t blocks, int32_t spins, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -162,6 +162,13 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
             v[j] = make_float2(ye * win_e[j], yo * win_o[j]);
         }
 
+        if (p.dbg && live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p.dbg[(size_t)g * 900 + 2 * (lane + 64 * j)] = v[j].x;
+                p.dbg[(size_t)g * 900 + 2 * (lane + 64 * j) + 1] = v[j].y;
+            }
+        }
         // ---- 256-point complex FFT, radix-4 DIF; position p = 64 d3 + 16 d2 + 4 d1 + d0
         bfly4(v, tw0);                                         // over d3; lane = p & 63
 #pragma unroll
@@ -210,6 +217,11 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
         }
         lds_phase<VAR>();
 
+        if (p.dbg && live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p.dbg[(size_t)g * 900 + 512 + lane + 64 * j] = pw[lane + 64 * j];
+            if (lane == 0) p.dbg[(size_t)g * 900 + 768] = pw[256];
+        }
         // ---- mel projection: this lane's (<= 2) triangle pieces, then the pieces of its (<= 2) mel bins in fixed order
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -219,6 +231,10 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
             pt[lane + 64 * q] = e;
         }
         lds_phase<VAR>();
+        if (p.dbg && live) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) p.dbg[(size_t)g * 900 + 769 + lane + 64 * q] = pt[lane + 64 * q];
+        }
         float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
