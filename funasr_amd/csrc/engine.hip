@@ -31,6 +31,7 @@ const char* get_error() { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------------ profiling
 // Optional hipEvent instrumentation of the dominant kernels (bench.py roofline line).
 struct ProfRec { hipEvent_t a, b; int kind; double work; };
+static float* g_fbank_dbg = nullptr;      // pf_debug_set_fbank_dump
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_ev_pool;
@@ -1517,7 +1518,6 @@ static int poison(std::initializer_list<DevBuf*> bufs, int byte) {
     PF_HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
-static float* g_fbank_dbg = nullptr;
 /* test hook: device buffer of 900 floats per fbank frame that the next frontend forwards fill with intermediates (NULL: off) */
 int pf_debug_set_fbank_dump(float* dev) { g_fbank_dbg = dev; return 0; }
 /* test hook: launches + waits for the LDS canary kernel (frontend.hip); returns the number of LDS words that changed under it */
