@@ -196,6 +196,24 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
         lds_phase<VAR>();
+        if constexpr (VAR == 3) {
+            // experiment: read the four values back; rewrite while any lane of the wave sees something else
+            for (int tries = 0; tries < 8; ++tries) {
+                bool bad = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float2 t = z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)];
+                    bad |= __builtin_bit_cast(unsigned, t.x) != __builtin_bit_cast(unsigned, v[r].x) ||
+                           __builtin_bit_cast(unsigned, t.y) != __builtin_bit_cast(unsigned, v[r].y);
+                }
+                if (!__any(bad)) break;
+                if (p.dbg && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(p.dbg) + 897, 1u);      // (frame 0's spare words)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        }
 
         // ---- real-input split X[k] = E + W_512^k O,  E = (Z[k] + conj Z[256-k]) / 2,  O = -i (Z[k] - conj Z[256-k]) / 2
         //      and the power spectrum, computed as abs() then square like torchaudio's spectrum.abs().pow(2)
@@ -321,7 +339,8 @@ int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t
     if (var == 2) {
         // every wave of a workgroup must run the same number of iterations: round the frame count up to whole rounds
         hipLaunchKernelGGL(fbank_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
-    } else if (var == 1) hipLaunchKernelGGL(fbank_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    } else if (var == 3) hipLaunchKernelGGL(fbank_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    else if (var == 1) hipLaunchKernelGGL(fbank_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
     else hipLaunchKernelGGL(fbank_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
     PF_HIP_TRY(hipGetLastError());
     return 0;
