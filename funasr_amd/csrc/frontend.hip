@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
         if (p.dbg && live) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                p.dbg[(size_t)g * 900 + 2 * (lane + 64 * j)] = v[j].x;
-                p.dbg[(size_t)g * 900 + 2 * (lane + 64 * j) + 1] = v[j].y;
+                p.dbg[(size_t)g * 2400 + 2 * (lane + 64 * j)] = v[j].x;
+                p.dbg[(size_t)g * 2400 + 2 * (lane + 64 * j) + 1] = v[j].y;
             }
         }
         // ---- 256-point complex FFT, radix-4 DIF; position p = 64 d3 + 16 d2 + 4 d1 + d0
@@ -196,6 +196,20 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
         lds_phase<VAR>();
+        if (p.dbg && live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pos = 64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4);
+                p.dbg[(size_t)g * 2400 + 900 + 2 * pos] = v[r].x;                 // what the lane holds
+                p.dbg[(size_t)g * 2400 + 900 + 2 * pos + 1] = v[r].y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 t = z[lane + 64 * j];                                   // what LDS holds right after the write
+                p.dbg[(size_t)g * 2400 + 1412 + 2 * (lane + 64 * j)] = t.x;
+                p.dbg[(size_t)g * 2400 + 1412 + 2 * (lane + 64 * j) + 1] = t.y;
+            }
+        }
         if constexpr (VAR == 3) {
             // experiment: read the four values back; rewrite while any lane of the wave sees something else
             for (int tries = 0; tries < 8; ++tries) {
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
                            __builtin_bit_cast(unsigned, t.y) != __builtin_bit_cast(unsigned, v[r].y);
                 }
                 if (!__any(bad)) break;
-                if (p.dbg && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(p.dbg) + 897, 1u);      // (frame 0's spare words)
+                if (p.dbg && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(p.dbg) + 2399, 1u);      // (frame 0's spare words)
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
@@ -237,8 +251,14 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
 
         if (p.dbg && live) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) p.dbg[(size_t)g * 900 + 512 + lane + 64 * j] = pw[lane + 64 * j];
-            if (lane == 0) p.dbg[(size_t)g * 900 + 768] = pw[256];
+            for (int j = 0; j < 4; ++j) p.dbg[(size_t)g * 2400 + 512 + lane + 64 * j] = pw[lane + 64 * j];
+            if (lane == 0) p.dbg[(size_t)g * 2400 + 768] = pw[256];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float2 t = z[lane + 64 * j];                                   // what LDS holds after the power stage
+                p.dbg[(size_t)g * 2400 + 1924 + 2 * (lane + 64 * j)] = t.x;
+                p.dbg[(size_t)g * 2400 + 1924 + 2 * (lane + 64 * j) + 1] = t.y;
+            }
         }
         // ---- mel projection: this lane's (<= 2) triangle pieces, then the pieces of its (<= 2) mel bins in fixed order
 #pragma unroll
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
         lds_phase<VAR>();
         if (p.dbg && live) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) p.dbg[(size_t)g * 900 + 769 + lane + 64 * q] = pt[lane + 64 * q];
+            for (int q = 0; q < 2; ++q) p.dbg[(size_t)g * 2400 + 769 + lane + 64 * q] = pt[lane + 64 * q];
         }
         float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
 #pragma unroll
