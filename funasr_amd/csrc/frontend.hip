@@ -56,8 +56,9 @@ __device__ __forceinline__ void lds_phase() {
     if constexpr (VAR == 2) { __syncthreads(); }
     __builtin_amdgcn_wave_barrier();
 }
-template <int VAR>
-__global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_frames) {
+template <int VAR, int WPB = 4>
+__global__ __launch_bounds__(WPB * 64, 4) void fbank_kernel(FbankArgs p, int total_frames) {
+    constexpr int WAVES_PER_BLOCK = WPB;
     __shared__ float2 zs[WAVES_PER_BLOCK][NFFT / 2];          // exchange buffer / spectrum Z in natural order
     __shared__ float ps[WAVES_PER_BLOCK][NBIN + 7];           // power spectrum (+ zero tail for clamped piece reads)
     __shared__ float part[WAVES_PER_BLOCK][MAX_PIECES];       // partial sums of the mel pieces
@@ -356,7 +357,10 @@ int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t
     long long blocks = (total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks > 256 * 4) blocks = 256 * 4;      // 4 workgroups x 4 waves per CU = the 128-VGPR occupancy
     static const int var = getenv("PF_FBANK_VAR") ? atoi(getenv("PF_FBANK_VAR")) : 0;
-    if (var == 2) {
+    if (var == 5) {          // one wave per workgroup
+        long long b1 = total < 256 * 16 ? total : 256 * 16;
+        hipLaunchKernelGGL((fbank_kernel<0, 1>), dim3((unsigned)b1), dim3(64), 0, stream, a, (int)total);
+    } else if (var == 2) {
         // every wave of a workgroup must run the same number of iterations: round the frame count up to whole rounds
         hipLaunchKernelGGL(fbank_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
     } else if (var == 3) hipLaunchKernelGGL(fbank_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
