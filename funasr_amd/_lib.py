@@ -102,8 +102,6 @@ SIGNATURES = {
     "pf_encoder_set_row_packing": (C.c_int, [_vp, _i32]),
     "pf_encoder_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "pf_encoder_debug_poison": (C.c_int, [_vp, _i32]),
-    "pf_debug_lds_canary": (C.c_int, [_i32, _i32, _vp]),
-    "pf_debug_set_fbank_dump": (C.c_int, [_vp]),
     "pf_decoder_debug_poison": (C.c_int, [_vp, _i32]),
     "pf_predictor_debug_poison": (C.c_int, [_vp, _i32]),
     "pf_encoder_set_vad_mask": (C.c_int, [_vp, _vp, _i32]),

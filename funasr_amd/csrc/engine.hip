@@ -31,7 +31,6 @@ const char* get_error() { return g_err.c_str(); }
 // ------------------------------------------------------------------------------------------------ profiling
 // Optional hipEvent instrumentation of the dominant kernels (bench.py roofline line).
 struct ProfRec { hipEvent_t a, b; int kind; double work; };
-static float* g_fbank_dbg = nullptr;      // pf_debug_set_fbank_dump
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_ev_pool;
@@ -1411,7 +1410,6 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
-    a.dbg = g_fbank_dbg;
     int rc;
     {
         double bytes = 0;
@@ -1517,21 +1515,6 @@ static int poison(std::initializer_list<DevBuf*> bufs, int byte) {
     for (DevBuf* b : bufs) if (b->p && b->cap) PF_HIP_TRY(hipMemset(b->p, byte, b->cap));
     PF_HIP_TRY(hipDeviceSynchronize());
     return 0;
-}
-/* test hook: device buffer of 900 floats per fbank frame that the next frontend forwards fill with intermediates (NULL: off) */
-int pf_debug_set_fbank_dump(float* dev) { g_fbank_dbg = dev; return 0; }
-/* test hook: launches + waits for the LDS canary kernel (frontend.hip); returns the number of LDS words that changed under it */
-int pf_debug_lds_canary(int32_t blocks, int32_t spins, void* stream) {
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    unsigned* d = nullptr;
-    unsigned h = 0;
-    PF_HIP_TRY(hipMalloc((void**)&d, sizeof(unsigned)));
-    PF_HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned), s));
-    int rc = launch_lds_canary(blocks, spins, d, s);
-    if (!rc && hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) rc = -2;
-    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = -2;
-    (void)hipFree(d);
-    return rc ? rc : (int)(h > 0x7fffffffu ? 0x7fffffff : h);
 }
 int pf_encoder_debug_poison(pf_encoder* eh, int32_t byte) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);

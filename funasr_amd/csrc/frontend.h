@@ -21,7 +21,6 @@ struct FbankArgs {
     const int* mel_first;        // device [n_mels] first piece of mel m
     const int* mel_count;        // device [n_mels] pieces of mel m
     int n_pieces;                // <= 128
-    float* dbg;                  // test hook (pf_debug_set_fbank_dump): 900 floats per frame -- windowed samples, power spectrum, mel pieces
 };
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream);
 
@@ -39,5 +38,4 @@ struct LfrArgs {
 };
 int launch_lfr_cmvn(const LfrArgs& a, int B, hipStream_t stream);
 
-int launch_lds_canary(int blocks, int spins, unsigned* bad_dev, hipStream_t stream);
 }  // namespace pf

@@ -46,19 +46,7 @@ __device__ __forceinline__ void bfly4(float2 (&v)[4], const float2 (&tw)[3]) {
 // only ever touches its own slice and its DS operations execute in order. Everything that does not change from frame to
 // frame lives in registers for the life of the wave: window coefficients, stage twiddles, and the weights of the (at
 // most two) mel-triangle pieces this lane accumulates.
-// VAR (experiment): how the wave orders its LDS write phase before the read phase of the next exchange
-//   0 = compiler scheduling barrier only (DS operations of one wave execute in order)
-//   1 = additionally s_waitcnt lgkmcnt(0) (workgroup-scope fence) at every exchange
-//   2 = a workgroup barrier at every exchange
-template <int VAR>
-__device__ __forceinline__ void lds_phase() {
-    if constexpr (VAR == 1) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
-    if constexpr (VAR == 2) { __syncthreads(); }
-    __builtin_amdgcn_wave_barrier();
-}
-template <int VAR, int WPB = 4>
-__global__ __launch_bounds__(WPB * 64, 4) void fbank_kernel(FbankArgs p, int total_frames) {
-    constexpr int WAVES_PER_BLOCK = WPB;
+__global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_frames) {
     __shared__ float2 zs[WAVES_PER_BLOCK][NFFT / 2];          // exchange buffer / spectrum Z in natural order
     __shared__ float ps[WAVES_PER_BLOCK][NBIN + 7];           // power spectrum (+ zero tail for clamped piece reads)
     __shared__ float part[WAVES_PER_BLOCK][MAX_PIECES];       // partial sums of the mel pieces
@@ -123,15 +111,13 @@ __global__ __launch_bounds__(WPB * 64, 4) void fbank_kernel(FbankArgs p, int tot
     };
     float ne[4], no[4];
     fetch(wave_id, ne, no);
-    for (int g0 = blockIdx.x * WAVES_PER_BLOCK; g0 < total_frames; g0 += n_waves) {      // (workgroup-uniform trip count)
-        const int g = g0 + wave;
+    for (int g = wave_id; g < total_frames; g += n_waves) {
         const int b = g / p.max_frames, f = g - b * p.max_frames;
         float xe[4], xo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xe[j] = ne[j]; xo[j] = no[j]; }
         fetch(g + n_waves, ne, no);
-        const bool live = g < total_frames && f < p.n_frames[b];   // wave-uniform
-        if (VAR != 2 && !live) continue;
+        if (f >= p.n_frames[b]) continue;                      // wave-uniform
 
         // ---- scale; DC removal (feature-window.cc:186-196)
         float s = 0.f;
@@ -163,72 +149,33 @@ __global__ __launch_bounds__(WPB * 64, 4) void fbank_kernel(FbankArgs p, int tot
             v[j] = make_float2(ye * win_e[j], yo * win_o[j]);
         }
 
-        if (p.dbg && live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                p.dbg[(size_t)g * 2400 + 2 * (lane + 64 * j)] = v[j].x;
-                p.dbg[(size_t)g * 2400 + 2 * (lane + 64 * j) + 1] = v[j].y;
-            }
-        }
         // ---- 256-point complex FFT, radix-4 DIF; position p = 64 d3 + 16 d2 + 4 d1 + d0
         bfly4(v, tw0);                                         // over d3; lane = p & 63
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * r + lane] = v[r];
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = z[64 * (lane >> 4) + 16 * r + (lane & 15)];
         bfly4(v, tw1);                                         // over d2
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * (lane >> 4) + 16 * r + (lane & 15)] = v[r];
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = z[64 * (lane >> 4) + 16 * ((lane >> 2) & 3) + 4 * r + (lane & 3)];
         bfly4(v, tw2);                                         // over d1
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * (lane >> 4) + 16 * ((lane >> 2) & 3) + 4 * r + (lane & 3)] = v[r];
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = z[4 * lane + r];
         bfly4(v, one);                                         // over d0 (no twiddles)
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
         // element (lane, r) is Z[digit-reversed position]: natural order into LDS
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
-        lds_phase<VAR>();
-        if (p.dbg && live) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pos = 64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4);
-                p.dbg[(size_t)g * 2400 + 900 + 2 * pos] = v[r].x;                 // what the lane holds
-                p.dbg[(size_t)g * 2400 + 900 + 2 * pos + 1] = v[r].y;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float2 t = z[lane + 64 * j];                                   // what LDS holds right after the write
-                p.dbg[(size_t)g * 2400 + 1412 + 2 * (lane + 64 * j)] = t.x;
-                p.dbg[(size_t)g * 2400 + 1412 + 2 * (lane + 64 * j) + 1] = t.y;
-            }
-        }
-        if constexpr (VAR == 3) {
-            // experiment: read the four values back; rewrite while any lane of the wave sees something else
-            for (int tries = 0; tries < 8; ++tries) {
-                bool bad = false;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float2 t = z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)];
-                    bad |= __builtin_bit_cast(unsigned, t.x) != __builtin_bit_cast(unsigned, v[r].x) ||
-                           __builtin_bit_cast(unsigned, t.y) != __builtin_bit_cast(unsigned, v[r].y);
-                }
-                if (!__any(bad)) break;
-                if (p.dbg && lane == 0) atomicAdd(reinterpret_cast<unsigned*>(p.dbg) + 2399, 1u);      // (frame 0's spare words)
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z[64 * r + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)] = v[r];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            }
-        }
+        __builtin_amdgcn_wave_barrier();
 
         // ---- real-input split X[k] = E + W_512^k O,  E = (Z[k] + conj Z[256-k]) / 2,  O = -i (Z[k] - conj Z[256-k]) / 2
         //      and the power spectrum, computed as abs() then square like torchaudio's spectrum.abs().pow(2)
@@ -248,19 +195,8 @@ __global__ __launch_bounds__(WPB * 64, 4) void fbank_kernel(FbankArgs p, int tot
                 pw[256] = m2 * m2;
             }
         }
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
 
-        if (p.dbg && live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p.dbg[(size_t)g * 2400 + 512 + lane + 64 * j] = pw[lane + 64 * j];
-            if (lane == 0) p.dbg[(size_t)g * 2400 + 768] = pw[256];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float2 t = z[lane + 64 * j];                                   // what LDS holds after the power stage
-                p.dbg[(size_t)g * 2400 + 1924 + 2 * (lane + 64 * j)] = t.x;
-                p.dbg[(size_t)g * 2400 + 1924 + 2 * (lane + 64 * j) + 1] = t.y;
-            }
-        }
         // ---- mel projection: this lane's (<= 2) triangle pieces, then the pieces of its (<= 2) mel bins in fixed order
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -269,23 +205,19 @@ __global__ __launch_bounds__(WPB * 64, 4) void fbank_kernel(FbankArgs p, int tot
             for (int t = 0; t < 8; ++t) e = fmaf(pwgt[q][t], pw[pk0[q] + t], e);
             pt[lane + 64 * q] = e;
         }
-        lds_phase<VAR>();
-        if (p.dbg && live) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) p.dbg[(size_t)g * 2400 + 769 + lane + 64 * q] = pt[lane + 64 * q];
-        }
+        __builtin_amdgcn_wave_barrier();
         float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = lane + 64 * q;
-            if (m < p.n_mels && live) {
+            if (m < p.n_mels) {
                 float e = 0.f;
                 for (int c = 0; c < mcount[q]; ++c) e += pt[mfirst[q] + c];
                 e = fmaxf(e, 1.1920928955078125e-07f);         // feature-fbank.cc:102-106
                 out[m] = logf(e);
             }
         }
-        lds_phase<VAR>();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -319,30 +251,7 @@ __global__ __launch_bounds__(256) void lfr_cmvn_kernel(LfrArgs p) {
     *reinterpret_cast<float4*>(p.out + ((size_t)b * p.T_out + t) * D + c) = o;
 }
 
-// Test kernel: every workgroup fills its 14 KB of static LDS with a per-workgroup pattern, idles, and checks it again. Another
-// kernel on the same CU must never change it (LDS is private to a workgroup); a count > 0 means some co-resident kernel wrote
-// outside its own LDS allocation.
-__global__ __launch_bounds__(256) void lds_canary_kernel(int spins, unsigned* bad) {
-    __shared__ unsigned buf[3616];
-    const unsigned pat = 0x9e3779b9u * (blockIdx.x + 1);
-    for (int i = threadIdx.x; i < 3616; i += 256) buf[i] = pat ^ (unsigned)i;
-    __syncthreads();
-    unsigned n = 0;
-    for (int k = 0; k < spins; ++k) {
-        __builtin_amdgcn_s_sleep(64);
-        for (int i = threadIdx.x; i < 3616; i += 256) n += buf[i] != (pat ^ (unsigned)i);
-        __syncthreads();
-    }
-    if (n) atomicAdd(bad, n);
-}
-
 }  // namespace
-
-int launch_lds_canary(int blocks, int spins, unsigned* bad_dev, hipStream_t stream) {
-    hipLaunchKernelGGL(lds_canary_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, spins, bad_dev);
-    PF_HIP_TRY(hipGetLastError());
-    return 0;
-}
 
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream) {
     PF_REQUIRE(a.frame_len <= 512 && a.frame_len > 0, "fbank: frame length must be <= 512 samples");
@@ -356,16 +265,7 @@ int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t
     // persistent waves: enough workgroups to fill every CU several times over, each wave strides over the frames
     long long blocks = (total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks > 256 * 4) blocks = 256 * 4;      // 4 workgroups x 4 waves per CU = the 128-VGPR occupancy
-    static const int var = getenv("PF_FBANK_VAR") ? atoi(getenv("PF_FBANK_VAR")) : 0;
-    if (var == 5) {          // one wave per workgroup
-        long long b1 = total < 256 * 16 ? total : 256 * 16;
-        hipLaunchKernelGGL((fbank_kernel<0, 1>), dim3((unsigned)b1), dim3(64), 0, stream, a, (int)total);
-    } else if (var == 2) {
-        // every wave of a workgroup must run the same number of iterations: round the frame count up to whole rounds
-        hipLaunchKernelGGL(fbank_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
-    } else if (var == 3) hipLaunchKernelGGL(fbank_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
-    else if (var == 1) hipLaunchKernelGGL(fbank_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
-    else hipLaunchKernelGGL(fbank_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

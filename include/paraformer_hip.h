@@ -345,12 +345,6 @@ int pf_frontend_lfr_cmvn(pf_frontend* f, const float* frames_dev, int32_t T, int
 /* Test hooks: fill every activation workspace of the handle with `byte` (use 0x7B: huge finite fp16 / fp32 patterns). A
  * forward must not depend on what earlier batches left there (tests/test_stateless_gpu.py). Synchronise. */
 int pf_encoder_debug_poison(pf_encoder* e, int32_t byte);
-/* runs a canary kernel (each workgroup fills 14 KB of LDS, idles `spins` times, re-checks) and returns the number of LDS
- * words that changed under it: > 0 means a co-resident kernel wrote outside its own LDS allocation */
-int pf_debug_lds_canary(int32_t blocks, int32_t spins, void* stream);
-/* device buffer of 900 floats per fbank frame that the next frontend forwards fill with intermediates (windowed samples,
- * power spectrum, mel pieces); NULL switches it off */
-int pf_debug_set_fbank_dump(float* dev);
 int pf_decoder_debug_poison(pf_decoder* d, int32_t byte);
 int pf_predictor_debug_poison(pf_predictor* p, int32_t byte);
 /* -------------------------------------------------------------------------------- single kernels (tests / bench)

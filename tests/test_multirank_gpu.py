@@ -41,7 +41,8 @@ def test_sweep_two_ranks_equals_one_rank_in_corpus_order(cuda, tmp_path):
     one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
     common = ["--clips", "48", "--batch-seconds", "1", "--no-overlap"]
     _run([sys.executable, "tools/sweep.py"] + common + ["--dump", one], 400)
-    out = _run(_torchrun(2, ["tools/sweep.py"] + common + ["--dist-backend", "gloo", "--dump", two]), 500)
+    # --serialize-gpu: the two ranks of this dry run share ONE GPU; they take turns on it (see tools/sweep.py and DESIGN 6)
+    out = _run(_torchrun(2, ["tools/sweep.py"] + common + ["--dist-backend", "gloo", "--serialize-gpu", "--dump", two]), 500)
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["clips"] == 48 and line["value"] > 0
     a, b = json.load(open(one)), json.load(open(two))

@@ -44,8 +44,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="assemble, decode and collect one batch at a time")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--stage-sync", type=int, default=0, help="debug: 1 = synchronize after staging the waveforms, 2 = after the "
-                    "frontend, 3 = hand the frontend a device-side clone of the staged batch, 4 = blocking H2D copies")
+    ap.add_argument("--serialize-gpu", action="store_true", help="single-GPU dry run of the N > 1 path (every rank on cuda:0): the "
+                    "ranks take turns on the GPU instead of time-sharing it. Two processes interleaving kernels on ONE GPU is not a "
+                    "deployment configuration (one process per GPU is), and the frontend was seen to return sporadically different "
+                    "features there (DESIGN 6, known issue); the dry run is about rendezvous, broadcast, sharding, gather and order")
     ap.add_argument("--trace-hash", default=None, help="debug: write per-clip bit hashes of the features, encoder output and CIF "
                     "weights to this JSON file (rank r appends .r)")
     ap.add_argument("--enc-option", action="append", default=[], metavar="KEY=VALUE", help="encoder schedule options (pf_encoder_set_option)")
@@ -127,16 +129,10 @@ def main():
         L = [lens[i] for i in batch]
         wav = torch.zeros(len(batch), max(L), device=dev)
         for j, i in enumerate(batch):
-            wav[j, : L[j]].copy_(clips[i], non_blocking=args.stage_sync != 4)
-        if args.stage_sync == 1:
-            torch.cuda.synchronize()
-        if args.stage_sync == 3:
-            wav = wav.clone()
+            wav[j, : L[j]].copy_(clips[i], non_blocking=True)
         timing["stage"] += time.perf_counter() - t
         t = time.perf_counter()
         feats, flens = fe(wav, L)
-        if args.stage_sync == 2:
-            torch.cuda.synchronize()
         if args.trace_hash is not None and paraformer:
             hb = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
             r = model.recognize_features(feats, flens, return_intermediate=True)
@@ -168,21 +164,31 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     hyps = {}
-    inflight = None
-    for b in batches:
-        pending = launch(b)
-        if args.no_overlap:
-            for i, ids in zip(b, finish(pending)):
-                hyps[i] = ids
-            continue
+
+    def decode_all():
+        inflight = None
+        for b in batches:
+            pending = launch(b)
+            if args.no_overlap:
+                for i, ids in zip(b, finish(pending)):
+                    hyps[i] = ids
+                continue
+            if inflight is not None:
+                for i, ids in zip(inflight[0], finish(inflight[1])):
+                    hyps[i] = ids
+            inflight = (b, pending)
         if inflight is not None:
             for i, ids in zip(inflight[0], finish(inflight[1])):
                 hyps[i] = ids
-        inflight = (b, pending)
-    if inflight is not None:
-        for i, ids in zip(inflight[0], finish(inflight[1])):
-            hyps[i] = ids
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+
+    if args.serialize_gpu and world > 1:
+        for turn in range(world):                 # the ranks take turns on the one GPU of the dry run
+            if turn == rank:
+                decode_all()
+            dist.barrier()
+    else:
+        decode_all()
     if world > 1:
         order = list(mine)
         width = max(len(dp.shard_indices(lens, world, r)) for r in range(world))
