@@ -92,11 +92,16 @@ def build_model(cfg, rank, world, device):
         sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
         model.load_state_dict(sd, strict=False)
     model = model.to(device)
+    bcast_s = 0.0
     if world > 1:
         from funasr_amd import dp
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
         arena_bytes = dp.broadcast_model(model, src=0)          # ONE packed fp32 arena over RCCL (~880 MB)
-        trace(f"rank {rank}: weight arena broadcast, {arena_bytes / 1e6:.0f} MB")
-    return model, arena_bytes
+        torch.cuda.synchronize()
+        bcast_s = time.perf_counter() - tb
+        trace(f"rank {rank}: weight arena broadcast, {arena_bytes / 1e6:.0f} MB in {bcast_s:.2f} s")
+    return model, arena_bytes, bcast_s
 
 
 def read_prof(lib, steps):
@@ -134,7 +139,7 @@ def main():
     lib = _lib.load()
     cfg = synth.PARAFORMER_LARGE
     trace("library loaded, building model")
-    model, arena_bytes = build_model(cfg, rank, world, device)
+    model, arena_bytes, bcast_s = build_model(cfg, rank, world, device)
     trace("model on device")
     shift, scale = synth.synthetic_cmvn(560)
     frontend = WavFrontend(cmvn=torch.stack([shift, scale]), lfr_m=7, lfr_n=6, dither=0.0, device=device)
@@ -213,7 +218,16 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     trace(f"timed region done: {dt:.3f} s for {args.steps} steps")
+    per_rank_ms = None
     if world > 1:
+        # every rank's own time for the same K steps (the line's `value` uses the maximum): first-contact diagnostics for the
+        # 8-GPU run -- a slow rank (clock / power) or a slow broadcast shows up here, not in the aggregate
+        cdev = "cpu" if args.dist_backend == "gloo" else device
+        mine = torch.tensor([dt / args.steps * 1e3, bcast_s], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(float(t[0]), 2) for t in allr]
+        bcast_all = [round(float(t[1]), 3) for t in allr]
         dt = max_over_ranks(dt)
     audio_s = world * B * args.seconds * args.steps
     value = audio_s / dt
@@ -278,7 +292,8 @@ def main():
                    "tokens_per_clip": round(sum(res["token_num"]) / len(res["token_num"]), 1),
                    "tokens_max": max(res["token_num"]), "tokens_min": min(res["token_num"]),
                    "rccl_ranks": world, "weight_arena_bytes_broadcast": arena_bytes,
-                   "hypothesis_gather_bytes_per_rank_per_step": (B * (N_PAD + 1) * 4) if world > 1 else 0},
+                   "hypothesis_gather_bytes_per_rank_per_step": (B * (N_PAD + 1) * 4) if world > 1 else 0,
+                   "per_rank_ms_per_step": per_rank_ms, "weight_broadcast_seconds_per_rank": bcast_all if world > 1 else None},
         "roofline": roofline, "kernels": kernels,
     }
     line["config"]["output_layer"] = ("random-init" if confident is None else

@@ -58,6 +58,8 @@ def test_bench_two_ranks_prints_one_whole_job_line(cuda):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["rccl_ranks"] == 2 and d["config"]["weight_arena_bytes_broadcast"] > 8e8
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2 and max(d["config"]["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=1e-2)
+    assert len(d["config"]["weight_broadcast_seconds_per_rank"]) == 2 and all(t > 0 for t in d["config"]["weight_broadcast_seconds_per_rank"])
     assert d["config"]["hypothesis_gather_bytes_per_rank_per_step"] == 64 * 513 * 4
     # whole-job aggregate: both ranks' clips over the max-over-ranks time
     assert abs(d["value"] - 2 * 64 * 30.0 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01

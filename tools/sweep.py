@@ -120,8 +120,20 @@ def main():
         arena[off: off + lens[i]] = clips[i]
         clips[i] = arena[off: off + lens[i]]
         off += lens[i]
-    timing = {"stage": 0.0, "enqueue": 0.0, "collect": 0.0}
+    timing = {"stage": 0.0, "enqueue": 0.0, "collect": 0.0, "enqueue_waiting_for_gpu": 0.0}
     trace_rows = []
+    if hasattr(model, "calc_predictor"):
+        # the one host synchronisation inside enqueue_features is the CIF token count (it sizes the decoder, like the .item() at
+        # cif_predictor.py:311): time spent there is the host WAITING for the encoder of this batch, not host work
+        inner = model.calc_predictor
+
+        def timed_predictor(*a, **k):
+            t = time.perf_counter()
+            out = inner(*a, **k)
+            timing["enqueue_waiting_for_gpu"] += time.perf_counter() - t
+            return out
+        model.calc_predictor = timed_predictor
+    gpu_events = []
     paraformer = hasattr(model, "enqueue_features")
 
     def launch(batch):
@@ -132,6 +144,8 @@ def main():
             wav[j, : L[j]].copy_(clips[i], non_blocking=True)
         timing["stage"] += time.perf_counter() - t
         t = time.perf_counter()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         feats, flens = fe(wav, L)
         if args.trace_hash is not None and paraformer:
             hb = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
@@ -144,6 +158,8 @@ def main():
             pending = model.recognize_features(feats, flens, "auto", "woitn")
         else:
             pending = model.recognize_features(feats, flens)
+        ev1.record()
+        gpu_events.append((ev0, ev1))
         timing["enqueue"] += time.perf_counter() - t
         return pending
 
@@ -160,6 +176,7 @@ def main():
     torch.cuda.synchronize()
     for k in timing:
         timing[k] = 0.0
+    gpu_events.clear()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -219,7 +236,11 @@ def main():
                           "batches_rank0": len(batches), "batch_budget": (f"{args.batch_seconds} s" if args.batch_seconds > 0 else f"{args.batch_rows} rows"),
                           "padding_efficiency_rank0": round(mine_s / padded, 3),
                           "tokens_rank0": sum(len(v) for v in hyps.values()),
-                          "host_seconds_rank0": {k: round(v, 3) for k, v in timing.items()}}), flush=True)
+                          "host_seconds_rank0": {k: round(v, 3) for k, v in timing.items()},
+                          # GPU time between the first and the last kernel of every batch (events on the launch stream): when it
+                          # adds up to the wall time the sweep is GPU-bound and `enqueue` is back-pressure, not host work
+                          "gpu_seconds_rank0": round(sum(a.elapsed_time(b) for a, b in gpu_events) * 1e-3, 3),
+                          "enqueue_host_work_rank0": round(timing["enqueue"] - timing["enqueue_waiting_for_gpu"], 3)}), flush=True)
     if args.trace_hash is not None:
         with open(f"{args.trace_hash}.{rank}", "w") as f:
             json.dump(trace_rows, f)
