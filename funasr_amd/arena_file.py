@@ -34,10 +34,16 @@ def source_stamp(path: str):
 def save_arena(model_or_state: Union[torch.nn.Module, Dict[str, torch.Tensor]], path: str, dtype: str = "float32",
                source: str = None) -> int:
     """-> bytes written. Layout: MAGIC | u64 header length | header JSON | padding to 64 | data. `source`: the checkpoint
-    file this arena mirrors (its size / mtime go into the header, see source_stamp)."""
+    file this arena mirrors (its size / mtime go into the header, see source_stamp); default: a `model.pt` beside `path`."""
     if dtype not in ("float32", "bfloat16"):
         raise ValueError("arena dtype must be 'float32' or 'bfloat16'")
     sd = model_or_state.state_dict() if isinstance(model_or_state, torch.nn.Module) else model_or_state
+    if source is None:
+        # an arena written beside a checkpoint mirrors that checkpoint: stamp it, or load_model_dir would take it for a stale
+        # leftover and fall back to the slow torch.load path
+        beside = os.path.join(os.path.dirname(os.path.abspath(path)), "model.pt")
+        if os.path.exists(beside):
+            source = beside
     index, off = [], 0
     for name, t in sd.items():
         if not torch.is_floating_point(t):

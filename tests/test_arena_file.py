@@ -49,9 +49,12 @@ def test_model_directory_prefers_the_arena_file(tmp_path):
     info = make_model_dir(d)
     ref, _ = AutoModel.build_model(model=d, device="cpu")
     pt = os.path.join(d, "model.pt")
-    save_arena(ref, os.path.join(d, "model.arena"))              # unstamped: the checkpoint beside it wins
-    assert load_model_dir(d)["init_param"].endswith("model.pt")
-    save_arena(ref, os.path.join(d, "model.arena"), source=pt)   # stamped twin of model.pt: preferred
+    from funasr_amd.arena_file import read_arena_header
+    save_arena(ref.state_dict(), str(tmp_path / "elsewhere.arena"))            # no checkpoint beside it: no stamp
+    assert "source" not in read_arena_header(str(tmp_path / "elsewhere.arena"))
+    save_arena(ref, os.path.join(d, "model.arena"))              # written beside model.pt the documented way: stamped as its twin
+    assert load_model_dir(d)["init_param"].endswith("model.arena")
+    save_arena(ref, os.path.join(d, "model.arena"), source=pt)   # explicitly stamped twin of model.pt: preferred
     assert load_model_dir(d)["init_param"].endswith("model.arena")
     sd = torch.load(pt, map_location="cpu", weights_only=True)   # the checkpoint is replaced (fine-tune / new download) ...
     torch.save({k: v + 1 for k, v in sd.items()} if all(torch.is_tensor(v) for v in sd.values()) else sd, pt)
