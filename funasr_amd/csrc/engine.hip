@@ -2877,9 +2877,11 @@ int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2
     g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
     g.C2 = reinterpret_cast<unsigned short*>(C2); g.ldc2 = ldc2; g.c_plane = (size_t)c_plane; g.cscale = cscale;
     g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = tile & 0xfff;
-    if (tile & 0x1000) {          // measurement hook: operands in the K-blocked layout [K / 32][rows][32] (lda = ldw = 32)
-        g.a_kstep = (long)M * 32; g.w_kstep = (long)N * 32;
-    }
+    // measurement hook: operands in the K-blocked layout [K / 32][rows][32]: 0x1000 both (lda = ldw = 32), 0x2000 W only
+    // (ldw = 32, lda = K), 0x4000 A only
+    if (tile & 0x1000) { g.a_kstep = (long)M * 32; g.w_kstep = (long)N * 32; }
+    if (tile & 0x2000) { g.w_kstep = (long)N * 32; g.ldw = 32; g.lda = K; }
+    if (tile & 0x4000) { g.a_kstep = (long)M * 32; g.lda = 32; g.ldw = K; }
     int rc;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2(g, s);
     for (int i = 0; i < 3; ++i) if ((rc = launch_gemm_f16x2(g, s))) return rc;

@@ -276,13 +276,21 @@ def kblocked(p2: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=None, add2=None, scale_exp: int = 0,
-               out_planes=False, out_scale_exp: int = 0, tile: int = 0, time_iters: int = 0, kblock: bool = False):
+               out_planes=False, out_scale_exp: int = 0, tile: int = 0, time_iters: int = 0, kblock=False):
     """a2 [2, M, K], w2 [2, N, K] fp16 planes (ops.split2; scale_exp = the SUM of their scale exponents) -> fp32 [M, N]
     (or the planes [2, M, N] of the result * 2**out_scale_exp); fp32-class accuracy from three fp16 MFMA products per
     operand pair. With time_iters > 0 returns (out, ms per launch)."""
     lib = _lib.load()
     assert a2.dtype == torch.float16 and w2.dtype == torch.float16 and a2.is_contiguous() and w2.is_contiguous()
-    if kblock:                                   # operands made by kblocked(): [2, K / 32, rows, 32]
+    if kblock == "w":                            # only W made by kblocked()
+        _, M, K = a2.shape
+        N, ld = w2.shape[2], K
+        tile |= 0x2000
+    elif kblock == "a":
+        _, kb, M, _ = a2.shape
+        K, N, ld = kb * 32, w2.shape[1], 32
+        tile |= 0x4000
+    elif kblock:                                 # operands made by kblocked(): [2, K / 32, rows, 32]
         _, kb, M, _ = a2.shape
         K, N, ld = kb * 32, w2.shape[2], 32
         assert w2.shape[1] == kb

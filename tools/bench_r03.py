@@ -42,9 +42,10 @@ if "gemm" in which:
         row = {}
         ref = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=2, **kw)
         a2k, w2k = ops.kblocked(a2), ops.kblocked(w2)
-        for label, tile, kb in (("wide", 2, False), ("wide_kblock", 2, True), ("narrow", 1, False), ("narrow_kblock", 1, True),
-                                ("wide_again", 2, False), ("wide_kblock_again", 2, True)):
-            aa, ww = (a2k, w2k) if kb else (a2, w2)
+        for label, tile, kb in (("wide", 2, False), ("wide_kblock", 2, True), ("wide_wblock", 2, "w"), ("wide_ablock", 2, "a"),
+                                ("wide_again", 2, False), ("wide_kblock_again", 2, True), ("wide_wblock_again", 2, "w")):
+            aa = a2k if kb in (True, "a") else a2
+            ww = w2k if kb in (True, "w") else w2
             out = ops.gemm_f16x2(aa, ww, b, scale_exp=20, tile=tile, kblock=kb, **kw)
             ms = best(lambda: ops.gemm_f16x2(aa, ww, b, scale_exp=20, tile=tile, time_iters=20, kblock=kb, **kw)[1])
             row[label] = (round(ms * 1e3, 1), bool(torch.equal(out, ref)))
@@ -72,4 +73,20 @@ if "row" in which:
             row[f"row_fused{'_nt' if nt else ''}"] = round(best(lambda: ops.gemm_f16x2_row(a2, w2, b, add1=add1, add2=add2, scale_exp=20, ln=(gamma, beta, 1e-12),
                                                                                           out_scale_exp=7, a_nt=nt, time_iters=20)[2]) * 1e3, 1)
         row["row_no_ln"] = round(best(lambda: ops.gemm_f16x2_row(a2, w2, b, add1=add1, add2=add2, scale_exp=20, time_iters=20)[2]) * 1e3, 1)
+        print(json.dumps({name: row}), flush=True)
+
+if "dec" in which:
+    # decoder token-side shapes (11 008 token rows = 64 clips x 172 tokens): which block shape is fastest at this M?
+    Md = 11008
+    for name, N, K, kw in (("dec_w1", 2048, 512, dict(relu=True)), ("dec_w2", 512, 2048, {}), ("dec_q_planes", 512, 512, dict(out_planes=True, out_scale_exp=6)),
+                           ("dec_out_resid", 512, 512, dict(resid=True))):
+        a = torch.randn(Md, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev)
+        a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+        kw = dict(kw)
+        if kw.pop("resid", False):
+            kw["add2"] = torch.randn(Md, N, device=dev)
+        row = {}
+        tiles = (("auto", 0), ("wide", 2), ("narrow", 1), ("pair", 5)) + ((("small128", 3),) if not kw.get("out_planes") else ())
+        for label, tile in tiles:
+            row[label] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20, **kw)[1]) * 1e3, 1)
         print(json.dumps({name: row}), flush=True)
