@@ -250,14 +250,15 @@ def main():
         # dominant kernel: the split-operand GEMM. `achieved` = algorithmic (fp32-equivalent) 2MNK flops per second; the
         # kernel executes PRODUCTS 16-bit MFMA flops per algorithmic flop, so its ceiling is the dense 16-bit peak / PRODUCTS
         gemm = prof["gemm_split"]
-        kname = "gemm_f16x2_kernel" if args.precision == "f16x2" else "gemm_split3_kernel"
+        # f16x2: the tile kernel and its full-row form (gemm_f16x2_row_kernel: linear_out / w_2 with the fused LayerNorm)
+        kname = "gemm_f16x2_" if args.precision == "f16x2" else "gemm_split3_kernel"
         peak = PEAK_16BIT_MFMA_TFLOPS / PRODUCTS[args.precision]
     else:
         gemm, kname = prof["gemm_f32_mfma"], "gemm_f32_mfma_kernel"
         peak = PEAK_16BIT_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
     ach = gemm["work_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12 if gemm["ms_per_step"] > 0 else 0.0
     pmc = pmc_traffic(kname)
-    roofline = dict(bound="mfma", kernel=kname, achieved=round(ach, 2), peak=round(peak, 1),
+    roofline = dict(bound="mfma", kernel=("gemm_f16x2_kernel + gemm_f16x2_row_kernel" if kname == "gemm_f16x2_" else kname), achieved=round(ach, 2), peak=round(peak, 1),
                     unit="TFLOP/s", frac=round(ach / peak, 4), traffic=pmc[0] if pmc else None,
                     traffic_unit="HBM bytes per launch (PMC)", traffic_source=pmc[1] if pmc else None,
                     flops_per_launch=gemm["work_per_step"] / max(gemm["launches_per_step"], 1),

@@ -475,6 +475,14 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     const long wide_blocks = m_tiles * (a.N / 256), narrow_blocks = m_tiles * ceil_div(a.N, 128);
     const double cost_wide = (double)((wide_blocks + n_cu - 1) / n_cu), cost_narrow = 0.57 * (double)((narrow_blocks + n_cu - 1) / n_cu);
     const bool wide = a.tile == 2 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
+    if constexpr (OUT == 0) {
+        // fp32 output: the 128 x 128 four-wave shape (two workgroups per CU, 0.55 of a 256 x 256 block's time per round of
+        // 2 n_cu blocks: tools/bench_r03.py `dec`) wins where the larger shapes leave CUs idle -- the decoder's token-side GEMMs
+        // (M ~ 11 k rows: 82 vs 86-89 us) and short ragged batches. Bitwise equal to the other shapes like them.
+        const long small_blocks = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
+        const double cost_small = 0.55 * (double)((small_blocks + 2 * n_cu - 1) / (2 * n_cu));
+        if (a.tile == 0 && cost_small < (wide ? cost_wide : cost_narrow)) return launch_tile<2, 2, MODE, 0, 0, 0, 2>(a, stream);
+    }
     // SCHED 2 on the 256 x 256 shape (both k-steps' fragments requested up front, DMA pieces early): 0-10 % faster there
     return wide ? launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
 }

@@ -78,6 +78,12 @@ def main():
         print(f"| {k} | {n} | {fr:.3f} | {wr:.3f} |")
         if k in fetch and k in write:
             traffic[k] = dict(launches=n, read_bytes_per_launch=fr * 1e6, write_bytes_per_launch=wr * 1e6)
+    tot_r = sum(fetch[k][0] for k in fetch) * 1024 * 2 / 1e9
+    tot_w = sum(write[k][0] for k in write) * 1024 / 1e9
+    n_attn = max((fetch[k][1] for k in fetch if k.startswith("attention_f16x2")), default=0)
+    print(f"\nwhole run: {tot_r:.1f} GB read (corrected) + {tot_w:.1f} GB written over every kernel; the run holds "
+          f"{n_attn} attention_f16x2 launches = {n_attn / 66.0:.2f} steps of 50 self- + 16 cross-attentions "
+          f"=> {(tot_r + tot_w) / max(n_attn / 66.0, 1e-9):.1f} GB of HBM traffic per step")
     # matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (32 per v_mfma_*_32x32x16);
     # against duration x 1024 SIMDs x the 2.4 GHz peak clock it is the fraction of the dense-MFMA peak the kernel used
     mfma = pmc_table(root, "pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
