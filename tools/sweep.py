@@ -120,19 +120,8 @@ def main():
         arena[off: off + lens[i]] = clips[i]
         clips[i] = arena[off: off + lens[i]]
         off += lens[i]
-    timing = {"stage": 0.0, "enqueue": 0.0, "collect": 0.0, "enqueue_waiting_for_gpu": 0.0}
+    timing = {"stage": 0.0, "enqueue": 0.0, "collect": 0.0}
     trace_rows = []
-    if hasattr(model, "calc_predictor"):
-        # the one host synchronisation inside enqueue_features is the CIF token count (it sizes the decoder, like the .item() at
-        # cif_predictor.py:311): time spent there is the host WAITING for the encoder of this batch, not host work
-        inner = model.calc_predictor
-
-        def timed_predictor(*a, **k):
-            t = time.perf_counter()
-            out = inner(*a, **k)
-            timing["enqueue_waiting_for_gpu"] += time.perf_counter() - t
-            return out
-        model.calc_predictor = timed_predictor
     gpu_events = []
     paraformer = hasattr(model, "enqueue_features")
 
@@ -239,8 +228,7 @@ def main():
                           "host_seconds_rank0": {k: round(v, 3) for k, v in timing.items()},
                           # GPU time between the first and the last kernel of every batch (events on the launch stream): when it
                           # adds up to the wall time the sweep is GPU-bound and `enqueue` is back-pressure, not host work
-                          "gpu_seconds_rank0": round(sum(a.elapsed_time(b) for a, b in gpu_events) * 1e-3, 3),
-                          "enqueue_host_work_rank0": round(timing["enqueue"] - timing["enqueue_waiting_for_gpu"], 3)}), flush=True)
+                          "gpu_seconds_rank0": round(sum(a.elapsed_time(b) for a, b in gpu_events) * 1e-3, 3)}), flush=True)
     if args.trace_hash is not None:
         with open(f"{args.trace_hash}.{rank}", "w") as f:
             json.dump(trace_rows, f)
