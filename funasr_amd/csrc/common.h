@@ -274,6 +274,10 @@ struct GemmRowArgs {
     int M, N, K;                                        // N == 512, K % 32 == 0
     int relu;
     int a_nt;                                           // non-temporal hint on the A panel's loads (measurement hook)
+    // FSMN form (fs_v != nullptr, R1 == nullptr, ln_g != nullptr, M % 16 == 0): the first addend is the FSMN memory block of
+    // the fp32 rows fs_v [M, 512] (row stride ldfv) with taps fs_w [512, 11] (left padding 5), computed in the epilogue;
+    // fs_lo / fs_hi (device int32 [M / 16]): the valid input rows [lo, hi) of the sequence that owns each 16-row group
+    const float* fs_v; int ldfv; const float* fs_w; const int* fs_lo; const int* fs_hi;
 };
 bool gemm_f16x2_row_applicable(int N, int K);
 int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream);

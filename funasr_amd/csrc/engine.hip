@@ -467,6 +467,11 @@ struct Encoder {
     // the residual adds AND the LayerNorm that follows (norm2; the NEXT block's norm1), bitwise equal to the separate kernels.
     // fuse_row = 0 restores the separate launches (A/B measurements, tests)
     int fuse_row = 1;
+    // fsmn_fused = 1: the FSMN memory block is computed in linear_out's full-row epilogue (kernel 11, no shift, fuse_row on)
+    int fsmn_fused = 1;
+    DevBuf fs_grp;                      // int32 [2][M / 16]: valid v rows [lo, hi) of the sequence owning each 16-row group
+    std::vector<int32_t> h_fs;
+    const int* cur_fs = nullptr; int cur_fs_groups = 0;
     int attn_variant = 3;               // attention_f16x2.hip schedule (3: lazy rescale)
     int row_nt = 1;                     // non-temporal A loads in the full-row GEMMs: 0 none, 1 linear_out (K = 512), 2 linear_out and w_2
     int gemm_tile = 0;                  // Gemm2Args.tile of the block's GEMMs (0: by shape; 5: 128 x 256, two workgroups per CU)
@@ -671,8 +676,12 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         };
         const bool fuse = e->fuse_row && gemm_f16x2_row_applicable(D, D) && gemm_f16x2_row_applicable(D, F);
         auto gemm_row = [&](const unsigned short* A, int lda, int ea, const unsigned short* W, int ew, const float* bias, int K,
-                            const float* R1, const float* R2, int ldr2, const float* lg, const float* lb, int ey) {
+                            const float* R1, const float* R2, int ldr2, const float* lg, const float* lb, int ey,
+                            const float* fs_v = nullptr) {
             GemmRowArgs g{};
+            if (fs_v) {
+                g.fs_v = fs_v; g.ldfv = D; g.fs_w = w.fsmn_w; g.fs_lo = e->cur_fs; g.fs_hi = e->cur_fs + e->cur_fs_groups;
+            }
             g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)D * K;
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = D; g.R2 = R2; g.ldr2 = ldr2; g.C = x; g.ldc = D;
             g.ln_g = lg; g.ln_b = lb; g.ln_eps = c.ln_eps;
@@ -698,11 +707,15 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             ProfScope ps(PROF_GEMM3, 2.0 * M * 3.0 * D * w.in_pad, s);
             if ((rc = launch_gemm_f16x2(g, s))) return rc;
         }
-        FsmnArgs fa{};
-        fa.in = vbuf; fa.ldin = D; fa.w = w.fsmn_w; fa.R = nullptr; fa.ldr = 0; fa.out = mem; fa.ldo = D;
-        fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size; fa.offs = e->cur_offs;
-        fa.left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
-        if ((rc = fsmn(fa, s))) return rc;
+        // FSMN memory on the fp32 v projection: inside linear_out's epilogue (gemm_f16x2_row.hip) or as its own launch
+        const bool fs_fused = fuse && e->fsmn_fused && e->cur_fs && c.kernel_size == 11 && c.sanm_shift <= 0 && M % 16 == 0;
+        if (!fs_fused) {
+            FsmnArgs fa{};
+            fa.in = vbuf; fa.ldin = D; fa.w = w.fsmn_w; fa.R = nullptr; fa.ldr = 0; fa.out = mem; fa.ldo = D;
+            fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size; fa.offs = e->cur_offs;
+            fa.left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
+            if ((rc = fsmn(fa, s))) return rc;
+        }
         {
             Attn2Args aa{};
             aa.qoffs = aa.koffs = e->cur_offs; aa.Tq = e->cur_offs ? T : 0;
@@ -717,7 +730,8 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         const float* resid2 = (w.in_dim == D) ? x_in : nullptr;
         if (fuse) {
             // linear_out + fsmn memory + residual -> x, and norm2(x) -> the planes w_1 reads, in one launch
-            if ((rc = gemm_row(ctx2, D, w.e_v, w.out_w2, w.ew_out, w.out_b, D, mem, resid2, ld_in, w.n2g, w.n2b, w.e_x2))) return rc;
+            if ((rc = gemm_row(ctx2, D, w.e_v, w.out_w2, w.ew_out, w.out_b, D, fs_fused ? nullptr : mem, resid2, ld_in, w.n2g, w.n2b,
+                               w.e_x2, fs_fused ? vbuf : nullptr))) return rc;
         } else {
             if ((rc = gemm2(ctx2, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid2, ld_in))) return rc;
             ProfScope ps(PROF_LN, 8.0 * M * (double)D, s);
@@ -1501,6 +1515,7 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     PF_REQUIRE(e && key, "encoder_set_option: null");
     const std::string k = key;
     if (k == "fuse_row") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fuse_row is 0 or 1"); e->fuse_row = value; return 0; }
+    if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
     if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5, "encoder_set_option: gemm_tile is 0, 1, 2 or 5"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
@@ -1655,6 +1670,19 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         e->ctx.ensure(sizeof(float) * M * D) || e->ffn.ensure(sizeof(float) * M * Fbuf))
         return -2;
     if ((rc = upload_lens(e->lens, lens_host, B, s))) return rc;
+    e->cur_fs = nullptr;
+    if (x2 && e->fuse_row && e->fsmn_fused) {
+        // every sequence starts on a 16-row boundary in both layouts, so a 16-row group has one owner
+        const int G = (int)(M / 16);
+        e->h_fs.assign((size_t)2 * G, 0);
+        for (int b = 0; b < B; ++b) {
+            const int start = pack ? e->h_offs[b] : b * Tp, end = pack ? e->h_offs[b + 1] : (b + 1) * Tp;
+            for (int g = start / 16; g < end / 16; ++g) { e->h_fs[g] = start; e->h_fs[(size_t)G + g] = start + lens_host[b]; }
+        }
+        if (e->fs_grp.ensure(sizeof(int32_t) * 2 * G)) return -2;
+        if (upload_h2d(e->fs_grp.p, e->h_fs.data(), sizeof(int32_t) * 2 * G, s)) return -2;
+        e->cur_fs = e->fs_grp.as<int>(); e->cur_fs_groups = G;
+    }
     e->cur_mask_mode = 0;
     if (e->vad_mask) {
         PF_REQUIRE(e->precision == 0 && (int)e->h_vad.size() == B, "encoder: the VAD-masked encoder runs in the fp32 mode with one vad position per sequence");
@@ -2946,6 +2974,23 @@ int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void
     g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
     g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
     g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K; g.relu = relu; g.a_nt = a_nt;
+    if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
+    return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
+}
+/* the FSMN form of the full-row kernel: the first addend is the FSMN memory block (11 taps, left padding 5) of fs_v [M, 512],
+ * valid input rows [fs_lo[g], fs_hi[g]) per 16-row group g; M % 16 == 0, LayerNorm epilogue required */
+int pf_k_gemm_f16x2_row_fsmn(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                             const float* bias, const float* fs_v, int32_t ldfv, const float* fs_w, const int32_t* fs_lo,
+                             const int32_t* fs_hi, const float* R2, int32_t ldr2, float* C, int32_t ldc, const float* ln_g,
+                             const float* ln_b, float ln_eps, void* Y2, int64_t y_plane, float yscale, float* Yf, int32_t M, int32_t K,
+                             int32_t a_nt, int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GemmRowArgs g{};
+    g.A = reinterpret_cast<const unsigned short*>(A2); g.lda = lda; g.a_plane = (size_t)a_plane;
+    g.W = reinterpret_cast<const unsigned short*>(W2); g.ldw = ldw; g.w_plane = (size_t)w_plane; g.oscale = oscale;
+    g.bias = bias; g.fs_v = fs_v; g.ldfv = ldfv; g.fs_w = fs_w; g.fs_lo = fs_lo; g.fs_hi = fs_hi; g.R2 = R2; g.ldr2 = ldr2;
+    g.C = C; g.ldc = ldc; g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
+    g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K; g.a_nt = a_nt;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
     return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
 }

@@ -7,6 +7,12 @@
 // two fp16 planes the next GEMM consumes. That deletes the stand-alone LayerNorm launch and its re-read of the residual
 // stream (67 MB per launch at B T = 32768), and every A panel is fetched by exactly one workgroup.
 //
+// FSMN form (linear_out only; MODE bit 2): the first addend is not read from memory but COMPUTED here -- the FSMN memory block
+//     fsmn_memory = mask (conv_k11(pad(mask v)) + mask v)             funasr/models/sanm/attention.py:216-239
+// over the fp32 v projection (11 taps along time, per channel), with fsmn_kernel's fma chain (rowwise.hip): the separate
+// launch, its output tensor and its re-read here (187 + 67 MB per block at B T = 32768) are gone; a workgroup reads the v rows
+// of its 128 output rows plus a 5-row halo on each side.
+//
 // Arithmetic: the products, their k order and the epilogue's operation order are those of gemm_f16x2_kernel; the row
 // statistics are summed in layernorm_kernel's order (common.h ln_*: 4-column chunks, chunk l + chunk l + 64, xor butterfly
 // 32, 16 .. 1 over l). The fused result is therefore BITWISE the result of gemm_f16x2 followed by layernorm_kernel (tested).
@@ -34,9 +40,13 @@ constexpr int RW_ELD = 132;                                         // slab row 
 constexpr int RW_SLAB_B = 8 * 32 * RW_ELD * 4;                      // 135168
 constexpr int RW_LDS_B = 2 * RW_STAGE_B;                            // 163840 = the CU's whole LDS
 constexpr int RW_P_FLOATS = RW_BM * 4 * 32;                         // statistics exchange [row][wave column][lane]: 64 KB
+constexpr int RW_FS_KS = 11, RW_FS_LP = 5;                          // FSMN taps / left padding (the offline encoder's kernel 11)
+constexpr int RW_FSW_OFF_B = RW_SLAB_B;                             // FSMN taps [11][512] floats behind the slabs: 22 KB
 static_assert(RW_SLAB_B <= RW_LDS_B && (RW_P_FLOATS + 2 * RW_BM) * 4 <= RW_LDS_B, "epilogue LDS");
+static_assert(RW_FSW_OFF_B + RW_FS_KS * RW_BN * 4 <= RW_LDS_B, "FSMN taps do not fit behind the slabs");
 
-// MODE bit 0: R1 addend, bit 1: R2 addend (v = v + R1, then v = R2 + v, like gemm_f16x2_kernel); LN: LayerNorm epilogue
+// MODE bit 0: R1 addend, bit 1: R2 addend (v = v + R1, then v = R2 + v, like gemm_f16x2_kernel), bit 2: the first addend is
+// the FSMN memory block of p.fs_v computed in place (excludes bit 0); LN: LayerNorm epilogue
 template <int MODE, bool LN, bool A_NT>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
     constexpr int WM = 2, WN = 4;
@@ -130,10 +140,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
     // ---- epilogue, part 1: accumulators (C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) +
     //      4 (lane >> 5)) -> wave-private slab -> float4 pieces of rows: half-wave h takes rows 16 h .. 16 h + 15 of the
     //      32-row tile, lane c4 its columns 4 c4 .. 4 c4 + 3 of the wave's 128; the finished values stay in registers
-    constexpr bool HAS_R1 = (MODE & 1) != 0, HAS_R2 = (MODE & 2) != 0;
+    constexpr bool HAS_R1 = (MODE & 1) != 0, HAS_R2 = (MODE & 2) != 0, FSMN = (MODE & 4) != 0;
+    static_assert(!(HAS_R1 && FSMN), "the FSMN form computes the first addend");
     __syncthreads();
     float* smf = reinterpret_cast<float*>(smem);
     float* slab = smf + wave * (32 * RW_ELD);
+    const float* fsw = reinterpret_cast<const float*>(smem + RW_FSW_OFF_B);      // [tap][512]
+    if constexpr (FSMN) {
+        // taps [512][11] -> LDS [11][512]: thread = channel (consecutive threads, consecutive LDS words)
+        float* dst = reinterpret_cast<float*>(smem + RW_FSW_OFF_B);
+#pragma unroll
+        for (int j = 0; j < RW_FS_KS; ++j) dst[j * RW_BN + tid] = p.fs_w[(size_t)tid * RW_FS_KS + j];
+        __syncthreads();
+    }
     const int c4 = idx, rsub = hh;
     const int col = wc * 128 + c4 * 4;
     const float oscale = p.oscale_dev ? p.oscale * *p.oscale_dev : p.oscale;
@@ -148,6 +167,67 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
             for (int r = 0; r < 16; ++r)
                 slab[((r & 3) + 8 * (r >> 2) + 4 * hh) * RW_ELD + jj * 32 + idx] = acc[i][jj][r];
         const int row0 = m0 + wr * 64 + i * 32 + rsub * 16;
+        if constexpr (FSMN) {
+            // this half-wave's 16 rows are one 16-row group of one sequence: valid v rows [lo, hi) (sequence start .. start +
+            // len), everything else -- other sequences, padding rows, rows outside the batch -- counts as zero input, and
+            // output rows >= hi get no memory. Four output rows at a time over a sliding window of 14 v rows (26 per tile).
+            const int grp = row0 >> 4;
+            const bool gok = row0 < p.M;
+            const int lo = gok ? p.fs_lo[grp] : 0, hi = gok ? p.fs_hi[grp] : 0;
+            float4 win[16 + RW_FS_KS - 1];
+            auto load_row = [&](int k) {
+                const int vr = row0 - RW_FS_LP + k;
+                const bool ok = vr >= lo && vr < hi;
+                const float4 t = *reinterpret_cast<const float4*>(p.fs_v + (size_t)(ok ? vr : (lo < hi ? lo : 0)) * p.ldfv + col);
+                win[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+#pragma unroll
+            for (int k = 0; k < RW_FS_KS - 1; ++k) load_row(k);
+#pragma unroll
+            for (int h4 = 0; h4 < 4; ++h4) {
+                float4 r2[4], fa[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    load_row(RW_FS_KS - 1 + h4 * 4 + t);
+                    fa[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (HAS_R2) {
+                        const int row = row0 + h4 * 4 + t;
+                        r2[t] = *reinterpret_cast<const float4*>(p.R2 + (size_t)(row < p.M ? row : p.M - 1) * p.ldr2 + col);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RW_FS_KS; ++j) {
+                    const float4 wj = *reinterpret_cast<const float4*>(fsw + j * RW_BN + col);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 x = win[h4 * 4 + t + j];
+                        fa[t].x = fmaf(wj.x, x.x, fa[t].x); fa[t].y = fmaf(wj.y, x.y, fa[t].y);
+                        fa[t].z = fmaf(wj.z, x.z, fa[t].z); fa[t].w = fmaf(wj.w, x.w, fa[t].w);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = row0 + h4 * 4 + t;
+                    const float4 c = win[h4 * 4 + t + RW_FS_LP];                  // the (masked) input row itself
+                    float4 mem = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < hi) mem = make_float4(fa[t].x + c.x, fa[t].y + c.y, fa[t].z + c.z, fa[t].w + c.w);
+                    const float4 vt = *reinterpret_cast<const float4*>(slab + (rsub * 16 + h4 * 4 + t) * RW_ELD + c4 * 4);
+                    float o[4] = {vt.x * oscale + bias4.x, vt.y * oscale + bias4.y, vt.z * oscale + bias4.z,
+                                  vt.w * oscale + bias4.w};
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                    }
+                    o[0] = o[0] + mem.x; o[1] = o[1] + mem.y; o[2] = o[2] + mem.z; o[3] = o[3] + mem.w;
+                    if constexpr (HAS_R2) { o[0] = r2[t].x + o[0]; o[1] = r2[t].y + o[1]; o[2] = r2[t].z + o[2]; o[3] = r2[t].w + o[3]; }
+                    const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+                    ov[i][h4 * 4 + t] = o4;
+                    if (p.C && row < p.M) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = o4;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             float4 v[8], r1[8], r2[8];
@@ -277,6 +357,11 @@ int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream) {
         else PF_REQUIRE(a.ldyf % 4 == 0 && ((uintptr_t)a.Yf & 15) == 0, "gemm_f16x2_row: fp32 LayerNorm output alignment");
     } else {
         PF_REQUIRE(a.C, "gemm_f16x2_row: nothing to write");
+    }
+    if (a.fs_v) {
+        PF_REQUIRE(!a.R1 && a.fs_w && a.fs_lo && a.fs_hi && a.ldfv % 4 == 0 && ((uintptr_t)a.fs_v & 15) == 0 && a.M % 16 == 0 && ln,
+                   "gemm_f16x2_row: the FSMN form needs taps, the 16-row group bounds, M % 16 == 0, the LayerNorm epilogue and no R1");
+        return a.R2 ? launch_row_m<6, true>(a, stream) : launch_row_m<4, true>(a, stream);
     }
     const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
     switch (mode * 2 + (ln ? 1 : 0)) {

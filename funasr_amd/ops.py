@@ -346,6 +346,32 @@ def gemm_f16x2_row(a2: torch.Tensor, w2: torch.Tensor, bias=None, add1=None, add
     return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
 
 
+def gemm_f16x2_row_fsmn(a2: torch.Tensor, w2: torch.Tensor, bias, v: torch.Tensor, taps: torch.Tensor, lo: torch.Tensor,
+                        hi: torch.Tensor, add2=None, scale_exp: int = 0, ln=None, out_scale_exp: int = 0, ln_planes: bool = True,
+                        want_c: bool = True, a_nt: bool = False, time_iters: int = 0):
+    """FSMN form of the full-row kernel: c = (a w^T + bias) + fsmn_memory(v), add2 + c, y = LayerNorm(c). v fp32 [M, 512], taps
+    [512, 11]; lo / hi int32 [M / 16]: valid v rows [lo, hi) of the sequence owning each 16-row group. Returns (c or None, y[, ms])."""
+    lib = _lib.load()
+    assert a2.dtype == torch.float16 and w2.dtype == torch.float16 and a2.is_contiguous() and w2.is_contiguous()
+    _, M, K = a2.shape
+    assert w2.shape[1] == 512 and w2.shape[2] == K and M % 16 == 0 and ln is not None
+    assert v.dtype == torch.float32 and v.shape == (M, 512) and v.stride(1) == 1 and taps.shape == (512, 11) and taps.is_contiguous()
+    assert lo.dtype == torch.int32 and hi.dtype == torch.int32 and lo.numel() == M // 16 and hi.numel() == M // 16
+    dev = a2.device
+    c = torch.empty(M, 512, device=dev, dtype=torch.float32) if want_c else None
+    g, b, eps = ln
+    y2 = torch.empty(2, M, 512, device=dev, dtype=torch.float16) if ln_planes else None
+    yf = None if ln_planes else torch.empty(M, 512, device=dev, dtype=torch.float32)
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_gemm_f16x2_row_fsmn(_ptr(a2), K, M * K, _ptr(w2), K, 512 * K, float(2.0 ** -scale_exp), _ptr(bias),
+                                            _ptr(v), v.stride(0), _ptr(taps), _ptr(lo), _ptr(hi),
+                                            _ptr(add2), add2.stride(0) if add2 is not None else 0, _ptr(c), 512, _ptr(g), _ptr(b),
+                                            float(eps), _ptr(y2), M * 512, float(2.0 ** out_scale_exp), _ptr(yf), M, K, int(a_nt),
+                                            int(time_iters), C.byref(ms), _stream()), "pf_k_gemm_f16x2_row_fsmn")
+    y = y2 if y2 is not None else yf
+    return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
+
+
 def layernorm_planes(x: torch.Tensor, gamma, beta, eps: float, scale_exp: int = 0, time_iters: int = 0):
     """LayerNorm over the last dim of fp32 [M, D] -> fp16 planes [2, M, D] of y * 2**scale_exp (layernorm_kernel, plane output)."""
     lib = _lib.load()

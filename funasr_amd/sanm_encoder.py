@@ -112,7 +112,8 @@ class _SANMEncoderBase(HipModule):
 
     def set_option(self, key: str, value: int):
         """Schedule options of the f16x2 mode (`pf_encoder_set_option`): "fuse_row" (1 default: linear_out / w_2 with the
-        residual adds and the following LayerNorm in the GEMM epilogue; 0: separate launches, bitwise equal), "attn_variant"
+        residual adds and the following LayerNorm in the GEMM epilogue; 0: separate launches, bitwise equal), "fsmn_fused" (1
+        default: the FSMN memory block computed inside linear_out's epilogue; 0: its own launch, bitwise equal), "attn_variant"
         (3 default: lazy rescale; 1 pipelined; 0 plain)."""
         if not hasattr(self, "_options"):
             self._options = {}

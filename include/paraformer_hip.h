@@ -379,6 +379,14 @@ int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void
                         const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc,
                         const float* ln_g, const float* ln_b, float ln_eps, void* Y2, int64_t y_plane, float yscale, float* Yf,
                         int32_t M, int32_t K, int32_t relu, int32_t a_nt, int32_t iters, float* ms_out, void* stream);
+/* FSMN form of the full-row kernel: the first addend is the FSMN memory block (11 taps [512, 11], left padding 5;
+ * funasr/models/sanm/attention.py:216-239) of the fp32 rows fs_v [M, 512], computed in the epilogue; fs_lo / fs_hi (device
+ * int32 [M / 16]): valid input rows [lo, hi) of the sequence that owns each 16-row group. M % 16 == 0; ln_g / ln_b required */
+int pf_k_gemm_f16x2_row_fsmn(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,
+                             const float* bias, const float* fs_v, int32_t ldfv, const float* fs_w, const int32_t* fs_lo,
+                             const int32_t* fs_hi, const float* R2, int32_t ldr2, float* C, int32_t ldc, const float* ln_g,
+                             const float* ln_b, float ln_eps, void* Y2, int64_t y_plane, float yscale, float* Yf, int32_t M, int32_t K,
+                             int32_t a_nt, int32_t iters, float* ms_out, void* stream);
 /* LayerNorm writing the two fp16 planes of y * scale (what the f16x2 GEMMs read) */
 int pf_k_layernorm_planes(const float* x, int32_t ldx, const float* gamma, const float* beta, void* y2, int32_t ldy, int64_t plane,
                           float scale, int32_t M, int32_t D, float eps, int32_t iters, float* ms_out, void* stream);

@@ -214,6 +214,75 @@ def test_row_form_is_bitwise_gemm_then_layernorm(cuda, M, K, r1, r2):
     assert (got - ln64).abs().max().item() < 2e-5 * max(1.0, ln64.abs().max().item())
 
 
+@pytest.mark.parametrize("slots,lens", [
+    ([64, 64, 64], [64, 50, 1]),                       # padded layout: equal 16-aligned slots
+    ([16, 112, 48, 704, 16], [3, 100, 48, 690, 16]),   # packed layout: ragged slots, a full one, one shorter than the halo
+    ([2048] * 16, [2048, 2047, 1500, 17, 16, 15, 6, 5, 4, 1, 2000, 1999, 1024, 1023, 640, 128]),
+])
+@pytest.mark.parametrize("r2", [True, False])
+def test_row_form_with_fsmn_in_the_epilogue_is_bitwise_fsmn_then_row(cuda, slots, lens, r2):
+    """FSMN form of gemm_f16x2_row.hip: the memory block (funasr/models/sanm/attention.py:216-239: 11-tap depthwise conv over
+    the masked v rows + the masked rows themselves, masked again) computed in linear_out's epilogue returns the bits of
+    fsmn_kernel followed by the row kernel with the memory as first addend. Rows behind a sequence's length hold garbage."""
+    from funasr_amd import ops
+    M = sum(slots)
+    a2, w2, se, g = _operands(M, 512, 512, cuda, seed=21)
+    bias = torch.randn(512, generator=g).to(cuda)
+    add2 = (torch.randn(M, 512, generator=g) * 10 + 2).to(cuda) if r2 else None
+    gamma = (torch.rand(512, generator=g) * 2 + 0.1).to(cuda)
+    beta = torch.randn(512, generator=g).to(cuda)
+    taps = (torch.randn(512, 11, generator=g) * 0.3).to(cuda)
+    v = (torch.randn(M, 512, generator=g) * 2).to(cuda)
+    eps, ey = 1e-12, 7
+    mem = torch.empty(M, 512, device=cuda)
+    lo = torch.empty(M // 16, dtype=torch.int32)
+    hi = torch.empty(M // 16, dtype=torch.int32)
+    start = 0
+    for rows, n in zip(slots, lens):
+        v[start + n:start + rows] = 3.0e30                                    # must be masked, as input and as output
+        one = ops.fsmn(v[start:start + rows].view(1, rows, 512), taps, torch.tensor([n], dtype=torch.int32, device=cuda), 5)
+        mem[start:start + rows] = one[0]
+        lo[start // 16:(start + rows) // 16] = start
+        hi[start // 16:(start + rows) // 16] = start + n
+        start += rows
+    assert mem.abs().max().item() < 1e6 and all(mem[sum(slots[:i]) + n:sum(slots[:i + 1])].abs().max().item() == 0
+                                                for i, n in enumerate(lens) if n < slots[i])
+    c_ref, y_ref = ops.gemm_f16x2_row(a2, w2, bias, add1=mem, add2=add2, scale_exp=se, ln=(gamma, beta, eps), out_scale_exp=ey)
+    lo, hi = lo.to(cuda), hi.to(cuda)
+    for nt in (False, True):
+        c, y = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps),
+                                       out_scale_exp=ey, a_nt=nt)
+        assert torch.equal(c, c_ref), "fp32 result of the FSMN form differs from fsmn_kernel + row kernel"
+        assert torch.equal(y, y_ref), "LayerNorm planes of the FSMN form differ"
+    nc, yf = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False,
+                                     want_c=False)
+    assert nc is None and torch.equal(yf, ops.layernorm(c_ref, gamma, beta, eps))
+
+
+@pytest.mark.parametrize("frames", [[103], [36, 103, 500], [255, 256, 257, 16]])
+@pytest.mark.parametrize("packing", ["padded", "all_rows", 1])
+def test_encoder_schedule_options_are_bitwise_equal(cuda, frames, packing):
+    """fuse_row / fsmn_fused only move work between launches: the encoder output has the same bits with either setting, in the
+    padded and the packed row layouts (SANMEncoder.forward, funasr/models/sanm/encoder.py:374-451)"""
+    from funasr_amd import synth
+    from funasr_amd.sanm_encoder import SANMEncoder
+    ec = dict(synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=3)["encoder"])
+    enc = SANMEncoder(**ec, input_layer="pe")
+    enc.load_state_dict(synth.encoder_state_dict(ec, seed=11), strict=False)
+    enc = enc.to(cuda).set_precision("f16x2")
+    enc.set_row_packing({"padded": None, "all_rows": SANMEncoder.ALL_ROWS}.get(packing, packing))
+    g = torch.Generator().manual_seed(sum(frames))
+    feats = (torch.randn(len(frames), max(frames), 560, generator=g) * 0.8).to(cuda)
+    lens = torch.tensor(frames, dtype=torch.int32)
+    outs = {}
+    for fuse_row, fsmn_fused in ((0, 0), (1, 0), (1, 1)):
+        enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused)
+        outs[(fuse_row, fsmn_fused)] = enc(feats, lens)[0].clone()
+    assert torch.isfinite(outs[(0, 0)]).all() and outs[(0, 0)].abs().max().item() > 0.1
+    assert torch.equal(outs[(1, 0)], outs[(0, 0)]), "fuse_row changes the encoder's bits"
+    assert torch.equal(outs[(1, 1)], outs[(0, 0)]), "fsmn_fused changes the encoder's bits"
+
+
 def _row_in_place(ops, a2, w2, bias, add1, x, se, gamma, beta, eps, ey):
     import ctypes as C
     from funasr_amd import _lib

@@ -90,3 +90,32 @@ if "dec" in which:
         for label, tile in tiles:
             row[label] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20, **kw)[1]) * 1e3, 1)
         print(json.dumps({name: row}), flush=True)
+
+if "fsmnrow" in which:
+    # linear_out at the bench shape: fsmn_kernel + row kernel (memory as first addend) vs the FSMN form (memory in the epilogue)
+    B, T = 64, 512
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(M, 512, device=dev); w = torch.randn(512, 512, device=dev) * 512 ** -0.5; b = torch.randn(512, device=dev)
+    a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+    v = torch.randn(M, 512, device=dev); taps = torch.randn(512, 11, device=dev) * 0.3; x = torch.randn(M, 512, device=dev)
+    gamma = torch.rand(512, device=dev) + 0.5; beta = torch.randn(512, device=dev)
+    lens = torch.full((B,), 500, dtype=torch.int32, device=dev)
+    lo = (torch.arange(M // 16, dtype=torch.int32) // (T // 16) * T).to(dev); hi = lo + 500
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def fsmn_ms():
+        ops.fsmn(v.view(B, T, 512), taps, lens, 5)
+        ev0.record()
+        for _ in range(20):
+            ops.fsmn(v.view(B, T, 512), taps, lens, 5)
+        ev1.record(); torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / 20
+    mem = ops.fsmn(v.view(B, T, 512), taps, lens, 5).view(M, 512)
+    ln = (gamma, beta, 1e-12)
+    c0, y0 = ops.gemm_f16x2_row(a2, w2, b, add1=mem, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, a_nt=True)
+    c1, y1 = ops.gemm_f16x2_row_fsmn(a2, w2, b, v, taps, lo, hi, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, a_nt=True)
+    row = {"bitwise": bool(torch.equal(c0, c1) and torch.equal(y0, y1)), "fsmn_kernel": round(best(fsmn_ms) * 1e3, 1)}
+    for rep in ("", "_again"):
+        row["row_r1" + rep] = round(best(lambda: ops.gemm_f16x2_row(a2, w2, b, add1=mem, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, a_nt=True, time_iters=20)[2]) * 1e3, 1)
+        row["row_fsmn" + rep] = round(best(lambda: ops.gemm_f16x2_row_fsmn(a2, w2, b, v, taps, lo, hi, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, a_nt=True, time_iters=20)[2]) * 1e3, 1)
+    print(json.dumps({"linear_out_us_M32768": row}), flush=True)
