@@ -1517,7 +1517,7 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     if (k == "fuse_row") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fuse_row is 0 or 1"); e->fuse_row = value; return 0; }
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
-    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5, "encoder_set_option: gemm_tile is 0, 1, 2 or 5"); e->gemm_tile = value; return 0; }
+    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6, "encoder_set_option: gemm_tile is 0, 1, 2, 5 or 6"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
     set_error("encoder_set_option: unknown key " + k);
     return -1;

@@ -17,6 +17,7 @@
 //   256 x 256 (wave = 2 x 4 MFMA tiles): 12 ds_read_b128 + 24 MFMA per 16-deep step, 64-KB stages, 2/3 of the L2 -> LDS
 //                                         bytes per flop: the shape for N >= 1024
 #include "common.h"
+#include <type_traits>
 
 namespace pf {
 
@@ -31,9 +32,11 @@ template <int WM, int WN, int WGM = 4, int KS_ = 32> struct Geo2 {
     static constexpr int BM = WGM * WM * 32, BN = 2 * WN * 32;
     static constexpr int KS = KS_, ROWB = 2 * KS, CPR = ROWB / 16, RPP = 1024 / ROWB;
     static constexpr int SWZ = CPR == 4 ? 2 : 3;                // rows per 256 B of LDS = 1 << SWZ: the swizzle changes that often
-    static constexpr int NSTG = KS == 16 ? 3 : 2;
     static constexpr int A_PLANE_B = BM * ROWB, B_PLANE_B = BN * ROWB;
     static constexpr int STAGE_B = 2 * (A_PLANE_B + B_PLANE_B);
+    // stages: two 32-deep ones; 16-deep: a ring of three (the two-workgroup shape) or, with eight waves, as many as the CU's
+    // 160 KB hold (five 32-KB stages of the 256 x 256 block: four of them in flight, see the deep-ring loop)
+    static constexpr int NSTG = KS == 16 ? (WGM == 4 ? (163840 / STAGE_B > 6 ? 6 : 163840 / STAGE_B) : 3) : 2;
     static constexpr int NPIECE = STAGE_B / 1024;               // 48 / 64 (24 in the 16-deep 128 x 256 shape)
     static constexpr int A_PIECES = 2 * BM / RPP;
     static constexpr int PPW = NPIECE / NW;                     // 6 / 8
@@ -118,7 +121,88 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     for (int st = 0; st < 2; ++st) coff[st] = ((2 * st + hh) ^ f) * 16;
 
     const int nk = p.K / KS;
-    if constexpr (KS_ == 16) {
+    if constexpr (KS_ == 16 && WGM == 4) {
+        // deep ring (one 512-thread workgroup per CU). With two 32-deep stages only ONE stage (64 KB) is in flight while the
+        // other is multiplied, and the wait at the top of a stage is for a load issued one stage (1.3 us of MFMA work at full
+        // rate) earlier -- less than a loaded HBM round trip, so the matrix pipes wait for memory every stage. Here R = NSTG
+        // 16-deep stages: at step kt stage kt is in registers, stage kt + 1 is being read from LDS into the other fragment
+        // set, stages kt + 2 .. kt + R are in flight (R - 1 stages = 128 KB), and a load has R - 1 steps to land. One barrier
+        // per step: it publishes stage kt + 1 (every wave waited for its own pieces of it) and frees stage kt's buffer (every
+        // wave's fragment reads of it are complete) for stage kt + R. Same products in the same k order: bitwise equal.
+        constexpr int R = G::NSTG;
+        auto wait_landed = [&](int rem) {          // my pieces of a stage have landed when at most min(R - 2, rem) later stages are outstanding
+            if (rem >= R - 2) glds_wait_but<(R - 2) * PPW>();
+            else if (rem == 3) glds_wait_but<3 * PPW>();
+            else if (rem == 2) glds_wait_but<2 * PPW>();
+            else if (rem == 1) glds_wait_but<PPW>();
+            else glds_wait_all();
+        };
+        auto frags = [&](f16x8 (&a)[WM][2], f16x8 (&b)[WN][2], int buf) {
+            const unsigned char* sb = smem + buf * STAGE_B;
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl) {      // the lo planes first: the first product is lo * hi
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    a[i][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * A_PLANE_B + aoff + i * 32 * ROWB + coff[0]));
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj)
+                    b[jj][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[0]));
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < R; ++st) {
+            if (st < nk) {
+#pragma unroll
+                for (int i = 0; i < PPW; ++i) piece(i, st, st);
+            }
+        }
+        // stage 0: R - 1 later stages were issued (or nk - 1)
+        if (nk - 1 >= R - 1) glds_wait_but<(R - 1) * PPW>(); else wait_landed(nk - 1);
+        __syncthreads();
+        f16x8 a0[WM][2], b0[WN][2], a1[WM][2], b1[WN][2];
+        frags(a0, b0, 0);
+        int buf = 0;                               // kt % R
+        // `more`: a stage follows (compile-time, so that the fragment reads and the MFMAs share one basic block and the
+        // compiler's lgkmcnt waits stay exact -- behind a branch join it waits for the just-issued reads before the first MFMA)
+        auto step = [&](auto more, int kt, f16x8 (&a)[WM][2], f16x8 (&b)[WN][2], f16x8 (&an)[WM][2], f16x8 (&bn)[WN][2]) {
+            const int nbuf = buf + 1 == R ? 0 : buf + 1;
+            if constexpr (decltype(more)::value) {
+                wait_landed(nk - 2 - kt);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of stage kt are complete
+                __syncthreads();
+                if (kt + R < nk) {
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i) piece(i, buf, kt + R);
+                }
+                frags(an, bn, nbuf);
+                __builtin_amdgcn_sched_barrier(0);     // the reads go out before the MFMAs (a step's worth of time to land)
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[jj][0], acc[i][jj], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[jj][1], acc[i][jj], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[jj][0], acc[i][jj], 0, 0, 0);
+            buf = nbuf;
+        };
+        typedef std::integral_constant<bool, true> More;
+        typedef std::integral_constant<bool, false> Last;
+        for (int kt = 0; kt + 2 < nk; kt += 2) {   // K % 32 == 0: an even number of 16-deep steps
+            step(More{}, kt, a0, b0, a1, b1);
+            step(More{}, kt + 1, a1, b1, a0, b0);
+        }
+        step(More{}, nk - 2, a0, b0, a1, b1);
+        step(Last{}, nk - 1, a1, b1, a0, b0);
+    } else if constexpr (KS_ == 16) {
         // ring of three 16-deep stages: stage kt + 2 is issued while stage kt is multiplied; a wave's pieces retire in order, so
         // "at most PPW outstanding" means its pieces of stage kt have landed; the barrier then covers the other waves' pieces
         // and frees the buffer of stage kt - 1 (= the one stage kt + 2 goes into)
@@ -442,6 +526,9 @@ int launch_tile(const Gemm2Args& a, hipStream_t stream) {
 // the 128 x 256 four-wave shape, two workgroups per CU (tile 5; N % 256 == 0)
 template <int MODE, int OUT>
 int launch_pair(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 0, 2, 16>(a, stream); }
+// the 256 x 256 eight-wave shape over a deep ring of 16-deep stages (tile 6; N % 256 == 0)
+template <int MODE, int OUT>
+int launch_ring(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 0, 4, 16>(a, stream); }
 template <int MODE, int OUT>
 int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
@@ -575,11 +662,13 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
                    ((uintptr_t)a.Qp & 15) == 0 && ((uintptr_t)a.Kp & 15) == 0 && ((uintptr_t)a.VT & 15) == 0,
                    "gemm_f16x2: QKV outputs");
         if (a.tile == 5) return launch_pair<0, 2>(a, stream);
+        if (a.tile == 6) return launch_ring<0, 2>(a, stream);
         return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);
     }
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");
         if (a.tile == 5 && a.N % 256 == 0) return launch_pair<0, 1>(a, stream);
+        if (a.tile == 6 && a.N % 256 == 0) return launch_ring<0, 1>(a, stream);
         return launch_one<0, 1>(a, stream);
     }
     if (a.tile == 5 && a.N % 256 == 0) {
@@ -588,6 +677,14 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
             case 1: return launch_pair<1, 0>(a, stream);
             case 2: return launch_pair<2, 0>(a, stream);
             default: return launch_pair<3, 0>(a, stream);
+        }
+    }
+    if (a.tile == 6 && a.N % 256 == 0) {
+        switch (mode) {
+            case 0: return launch_ring<0, 0>(a, stream);
+            case 1: return launch_ring<1, 0>(a, stream);
+            case 2: return launch_ring<2, 0>(a, stream);
+            default: return launch_ring<3, 0>(a, stream);
         }
     }
     switch (mode) {

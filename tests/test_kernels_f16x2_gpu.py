@@ -82,6 +82,8 @@ def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
             assert torch.equal(auto, narrow)
             pair = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=5, **kw)
             assert torch.equal(pair, narrow), f"128x256 two-workgroups-per-CU shape differs {sorted(kw)}"
+            ring = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=6, **kw)
+            assert torch.equal(ring, narrow), f"256x256 deep-ring shape differs {sorted(kw)}"
 
 
 @pytest.mark.parametrize("M", [70, 4000, 32768])
@@ -97,6 +99,7 @@ def test_gemm_f16x2_plane_output(cuda, M):
     p_w = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=2)
     p_p = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=5)
     assert torch.equal(p_n, p_w) and torch.equal(p_p, p_w)
+    assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=6), p_w)
     assert torch.isfinite(p_w.float()).all()
     val = _planes_value(p_w) * 2.0 ** -eo
     # the split adds <= 2^-22 of the element (+ the subnormal floor 2^-25 in the scaled domain)
@@ -119,8 +122,10 @@ def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
     q_mul, k_mul, v_mul = 128 ** -0.5 * 2.0 ** 7, 2.0 ** 6, 2.0 ** 5
     out = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form)
     pair = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=5)
+    ring = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=6)
     for key in ("q2", "k2", "v", "vt"):
         assert (out[key] is None and pair[key] is None) or torch.equal(out[key], pair[key]), f"128x256 shape: {key} differs"
+        assert (out[key] is None and ring[key] is None) or torch.equal(out[key], ring[key]), f"deep-ring shape: {key} differs"
     ref, mag = _gemm_ref(a2, w2, se, bias)
     segs = dict(k=0, v=1) if kv_form else dict(q=0, k=1, v=2)
 

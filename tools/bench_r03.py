@@ -42,8 +42,10 @@ if "gemm" in which:
         row = {}
         ref = ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=2, **kw)
         a2k, w2k = ops.kblocked(a2), ops.kblocked(w2)
-        for label, tile, kb in (("wide", 2, False), ("wide_kblock", 2, True), ("wide_wblock", 2, "w"), ("wide_ablock", 2, "a"),
-                                ("wide_again", 2, False), ("wide_kblock_again", 2, True), ("wide_wblock_again", 2, "w")):
+        variants = (("wide", 2, False), ("ring", 6, False), ("wide_again", 2, False), ("ring_again", 6, False)) if "ring" in which else \
+                   (("wide", 2, False), ("wide_kblock", 2, True), ("wide_wblock", 2, "w"), ("wide_ablock", 2, "a"),
+                    ("wide_again", 2, False), ("wide_kblock_again", 2, True), ("wide_wblock_again", 2, "w"))
+        for label, tile, kb in variants:
             aa = a2k if kb in (True, "a") else a2
             ww = w2k if kb in (True, "w") else w2
             out = ops.gemm_f16x2(aa, ww, b, scale_exp=20, tile=tile, kblock=kb, **kw)
@@ -54,7 +56,7 @@ if "gemm" in which:
     a = torch.randn(M, 512, device=dev); w = torch.randn(1536, 512, device=dev) * 512 ** -0.5; b = torch.randn(1536, device=dev)
     a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
     row = {label: round(best(lambda: ops.gemm_f16x2_qkv(a2, w2, b, 512, 20, 2.0 ** 4, 2.0 ** 6, 2.0 ** 6, tile=tile, time_iters=20)["ms"]) * 1e3, 1)
-           for label, tile in (("wide", 0), ("wide_again", 0))}
+           for label, tile in (("wide", 0), ("ring", 6), ("wide_again", 0), ("ring_again", 6))}
     print(json.dumps({"qkv_form_us": row}), flush=True)
 
 if "row" in which:
