@@ -153,3 +153,35 @@ def host_i32(x, n=None):
     if n is not None and len(vals) != n:
         raise ValueError(f"expected {n} lengths, got {len(vals)}")
     return (C.c_int32 * len(vals))(*vals), vals
+
+
+class HostCopyRing:
+    """Device -> pinned-host copies that a later `wait()` can consume without waiting for work enqueued AFTER the copy: the copy
+    and an event are put on the stream at enqueue time (a plain `.cpu()` at collect time is ordered behind everything enqueued
+    since, i.e. behind the whole next batch of a pipelined serving loop). A small ring of pinned buffers per (shape, dtype);
+    a buffer is reused `depth` copies later, so at most `depth - 1` batches may be in flight between enqueue and collect."""
+
+    def __init__(self, depth: int = 4):
+        self.depth, self._bufs, self._next = depth, {}, {}
+
+    def start(self, t: torch.Tensor):
+        key = (tuple(t.shape), t.dtype)
+        ring = self._bufs.setdefault(key, [])
+        i = self._next.get(key, 0)
+        if len(ring) <= i:
+            ring.append(torch.empty(t.shape, dtype=t.dtype, pin_memory=True))
+        self._next[key] = (i + 1) % self.depth
+        if len(self._bufs) > 64:                                    # ragged serving loops: do not grow without bound
+            self._bufs = {key: ring}
+            self._next = {key: self._next[key]}
+        host = ring[i]
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
+        return host, ev
+
+    @staticmethod
+    def wait(handle) -> torch.Tensor:
+        host, ev = handle
+        ev.synchronize()
+        return host

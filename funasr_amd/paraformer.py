@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .audio import load_audio_list
+from .hip_module import HostCopyRing
 from .register import tables
 from .timestamps import cif_token_spans
 from .tokenizer import sentence_postprocess
@@ -119,6 +120,9 @@ class Paraformer(nn.Module):
         if max(tok) >= 1:                                            # model.py:615-616
             ids, _ = self.decoder.greedy(enc, olens, embeds, tok)
         pending = dict(tok=tok, ids=ids, B=enc.shape[0])
+        if ids is not None:
+            # the batch's single D2H copy goes on the stream now: collect() then waits for THIS batch only
+            pending["ids_host"] = (ids, self.__dict__.setdefault("_host_ring", HostCopyRing()).start(ids))
         if return_intermediate:
             pending["extra"] = dict(enc=enc, olens=olens, embeds=embeds, alphas=alphas, peaks=peaks)
         return pending
@@ -127,7 +131,9 @@ class Paraformer(nn.Module):
         tok, B = pending["tok"], pending["B"]
         raw: List[List[int]] = [[] for _ in range(B)]
         if pending["ids"] is not None:
-            ids_host = pending["ids"].cpu()                          # the single D2H copy of the batch
+            # the single D2H copy of the batch: started at enqueue time when this class enqueued these very ids
+            early = pending.get("ids_host")
+            ids_host = HostCopyRing.wait(early[1]) if early is not None and early[0] is pending["ids"] else pending["ids"].cpu()
             raw = [ids_host[b, : tok[b]].tolist() for b in range(B)]
         drop = (self.sos, self.eos, self.blank_id)
         out = dict(token_num=tok, raw_ids=raw, ids=[[t for t in r if t not in drop] for r in raw])

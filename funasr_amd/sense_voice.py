@@ -12,11 +12,13 @@ from __future__ import annotations
 import time
 from typing import List
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from .audio import load_audio_list
 from .ctc import CTC
+from .hip_module import HostCopyRing
 from .register import tables
 from . import sanm_encoder as _sanm_encoder  # noqa: F401
 from . import wav_frontend as _wav_frontend  # noqa: F401
@@ -101,22 +103,44 @@ class SenseVoiceSmall(nn.Module):
         lens = torch.as_tensor(speech_lengths).to(torch.int32).cpu() + 4
         return torch.cat((q.to(speech.dtype), speech), dim=1).contiguous(), lens
 
-    def recognize_features(self, speech: torch.Tensor, speech_lengths, language: str = "auto",
-                           textnorm: str = "woitn", return_intermediate: bool = False, ban_ids=None):
+    def enqueue_features(self, speech: torch.Tensor, speech_lengths, language: str = "auto", textnorm: str = "woitn",
+                         return_intermediate: bool = False, ban_ids=None):
+        """[B, T, 560] features -> query frames, encoder, CTC projection with the fused arg-max and the batch's one D2H copy
+        (frame ids into pinned memory) ENQUEUED on the current HIP stream, no host synchronisation. `collect()` waits for that
+        copy only; a serving loop enqueues batch i+1 before collecting batch i, so the GPU never waits for the host-side
+        collapse of repeated frames (model.py:1013-1016)."""
         x, lens = self.prepend_queries(speech, speech_lengths, language, textnorm)
         if hasattr(self.encoder, "set_row_packing"):
             # the CTC head reads rows < len only (model.py:1014): in the f16x2 mode the padding rows are not computed at all
             self.encoder.set_row_packing(self.encoder.ALL_ROWS if return_intermediate else 0)
         enc, olens = self.encoder(x, lens)
-        frame_ids = self.ctc.argmax(enc, ban_ids=ban_ids).cpu()     # one D2H copy for the batch
-        ids: List[List[int]] = []
-        for b in range(enc.shape[0]):
-            y = torch.unique_consecutive(frame_ids[b, : int(olens[b])], dim=-1)     # model.py:1013-1016
-            ids.append([int(t) for t in y.tolist() if t != self.blank_id])
-        out = dict(ids=ids, frame_ids=[frame_ids[b, : int(olens[b])].tolist() for b in range(enc.shape[0])])
+        frame_ids = self.ctc.argmax(enc, ban_ids=ban_ids)
+        pending = dict(frame_ids=self.__dict__.setdefault("_host_ring", HostCopyRing()).start(frame_ids),
+                       olens=[int(v) for v in lens.tolist()])       # == olens (no subsampling), already on the host
         if return_intermediate:
-            out.update(enc=enc, olens=olens)
+            pending["extra"] = dict(enc=enc, olens=olens)
+        return pending
+
+    def collect(self, pending: dict) -> dict:
+        frame_ids = HostCopyRing.wait(pending["frame_ids"]).numpy()
+        olens = pending["olens"]
+        ids: List[List[int]] = []
+        frames: List[List[int]] = []
+        blank = self.blank_id
+        for b, n in enumerate(olens):
+            row = frame_ids[b, :n]
+            keep = np.ones(n, dtype=bool)
+            keep[1:] = row[1:] != row[:-1]                           # unique_consecutive (model.py:1013-1016)
+            y = row[keep]
+            ids.append(y[y != blank].tolist())
+            frames.append(row.tolist())
+        out = dict(ids=ids, frame_ids=frames)
+        out.update(pending.get("extra", {}))
         return out
+
+    def recognize_features(self, speech: torch.Tensor, speech_lengths, language: str = "auto",
+                           textnorm: str = "woitn", return_intermediate: bool = False, ban_ids=None):
+        return self.collect(self.enqueue_features(speech, speech_lengths, language, textnorm, return_intermediate, ban_ids))
 
     @staticmethod
     def post(timestamp):

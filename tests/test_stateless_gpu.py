@@ -50,3 +50,40 @@ def test_results_do_not_depend_on_stale_workspace_content(cuda, mode, frames):
         if all_rows:
             assert torch.equal(r["enc"], ref["enc"]), f"encoder output depends on stale workspace content (poison {poison})"
             assert torch.equal(r["alphas"], ref["alphas"])
+
+
+@pytest.mark.parametrize("family", ["paraformer", "sensevoice"])
+def test_pipelined_enqueue_collect_equals_one_batch_at_a_time(cuda, family):
+    """The serving loop enqueues batch i+1 (and i+2) before batch i's ids reach the host; each batch's single D2H copy is put
+    on the stream at enqueue time into a ring of pinned buffers (HostCopyRing). Three different batches in flight give exactly
+    what one-at-a-time `recognize_features` gives (funasr/models/paraformer/model.py:596-642, sense_voice/model.py:1008-1016)."""
+    if family == "paraformer":
+        from funasr_amd.paraformer import Paraformer
+        cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=3, dec_blocks=2, vocab=8404)
+        model = Paraformer.from_config(cfg)
+        model.load_state_dict(synth.paraformer_state_dict(cfg, seed=4, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
+    else:
+        from funasr_amd.sense_voice import SenseVoiceSmall
+        cfg = synth.tiny(synth.SENSEVOICE_SMALL, enc_blocks=2, tp_blocks=2, vocab=997)
+        model = SenseVoiceSmall.from_config(cfg)
+        model.load_state_dict(synth.sensevoice_state_dict(cfg, seed=4), strict=False)
+    model = model.to(cuda)
+    g = torch.Generator().manual_seed(77)
+    batches = []
+    for frames in ([103, 52, 80], [103, 60, 7], [103, 103, 99], [40, 12, 33]):          # two shapes share a pinned buffer
+        feats = (torch.randn(len(frames), max(frames), 560, generator=g) * 0.8).to(cuda)
+        for b, n in enumerate(frames):
+            feats[b, n:] = 0
+        batches.append((feats, frames))
+    one_by_one = [model.recognize_features(f, n) for f, n in batches]
+    assert any(len(x) > 0 for r in one_by_one for x in r["ids"])
+    pending = [model.enqueue_features(f, n) for f, n in batches[:3]]
+    got = [model.collect(pending[0])]
+    pending.append(model.enqueue_features(*batches[3]))
+    got += [model.collect(p) for p in pending[1:]]
+    for r, ref in zip(got, one_by_one):
+        assert r["ids"] == ref["ids"]
+        if family == "paraformer":
+            assert r["token_num"] == ref["token_num"] and r["raw_ids"] == ref["raw_ids"]
+        else:
+            assert r["frame_ids"] == ref["frame_ids"]

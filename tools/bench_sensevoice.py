@@ -41,20 +41,29 @@ def main():
     wav = torch.stack(clips).to(dev)
     lens = [n] * args.batch
 
-    def step(precision=None):
+    def enqueue():
         feats, flens = fe(wav, lens)
-        return model.recognize_features(feats, flens, "auto", "woitn")
+        return model.enqueue_features(feats, flens, "auto", "woitn")
+
+    def run_steps(k):
+        """k batches, software-pipelined like a serving loop (and like bench.py's Paraformer loop): batch i+1 is enqueued before
+        batch i's frame ids are collapsed on the host; every batch is fully processed and collected inside the call"""
+        pending = enqueue()
+        for _ in range(k - 1):
+            nxt = enqueue()
+            model.collect(pending)
+            pending = nxt
+        return model.collect(pending)
 
     out = {}
     modes = args.modes.split(",")
     for mode in modes:
         model.set_precision(mode)
-        for _ in range(args.warmup):
-            res = step()
+        if args.warmup > 0:
+            run_steps(args.warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = step()
+        res = run_steps(args.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out[mode] = dict(value=round(args.batch * args.seconds * args.steps / dt, 1), ms_per_step=round(dt / args.steps * 1e3, 2),

@@ -136,7 +136,7 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         feats, flens = fe(wav, L)
-        if args.trace_hash is not None and paraformer:
+        if args.trace_hash is not None and args.model == "paraformer":
             hb = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
             r = model.recognize_features(feats, flens, return_intermediate=True)
             trace_rows.append({"clips": list(batch), "wav": hb(wav), "feats": hb(feats), "enc": hb(r["enc"]), "alphas": hb(r["alphas"]),
