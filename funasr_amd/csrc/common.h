@@ -278,7 +278,12 @@ struct GemmRowArgs {
     // the fp32 rows fs_v [M, 512] (row stride ldfv) with taps fs_w [512, 11] (left padding 5), computed in the epilogue;
     // fs_lo / fs_hi (device int32 [M / 16]): the valid input rows [lo, hi) of the sequence that owns each 16-row group
     const float* fs_v; int ldfv; const float* fs_w; const int* fs_lo; const int* fs_hi;
+    // rows per block: 0 = by the row count (whole rounds over the CUs: 128, or 96 where that needs less time), 128 = the
+    // 2 x 4-wave kernel (gemm_f16x2_row.hip), 96 / 129 = the 1 x 8-wave kernel (gemm_f16x2_row8.hip) with 96 / 128 rows.
+    // Every choice gives the same bits.
+    int block_rows;
 };
+int launch_gemm_f16x2_row8(const GemmRowArgs& a, int bm, hipStream_t stream);
 bool gemm_f16x2_row_applicable(int N, int K);
 int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream);
 // fp32 [M, N] * scale -> two fp16 planes [M, ldy]; columns N..ldy-1 are written as zero

@@ -469,6 +469,7 @@ struct Encoder {
     int fuse_row = 1;
     // fsmn_fused = 1: the FSMN memory block is computed in linear_out's full-row epilogue (kernel 11, no shift, fuse_row on)
     int fsmn_fused = 1;
+    int row_bm = 0;                     // GemmRowArgs.block_rows of the full-row GEMMs (0: by the row count)
     DevBuf fs_grp;                      // int32 [2][M / 16]: valid v rows [lo, hi) of the sequence owning each 16-row group
     std::vector<int32_t> h_fs;
     const int* cur_fs = nullptr; int cur_fs_groups = 0;
@@ -686,7 +687,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = D; g.R2 = R2; g.ldr2 = ldr2; g.C = x; g.ldc = D;
             g.ln_g = lg; g.ln_b = lb; g.ln_eps = c.ln_eps;
             if (lg) { g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(ey); }
-            g.M = M; g.N = D; g.K = K; g.a_nt = e->row_nt >= (K == D ? 1 : 2);
+            g.M = M; g.N = D; g.K = K; g.a_nt = e->row_nt >= (K == D ? 1 : 2); g.block_rows = e->row_bm;
             ProfScope ps(PROF_GEMM3, 2.0 * M * (double)D * K, s);
             return launch_gemm_f16x2_row(g, s);
         };
@@ -1516,6 +1517,7 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     const std::string k = key;
     if (k == "fuse_row") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fuse_row is 0 or 1"); e->fuse_row = value; return 0; }
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
+    if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129, "encoder_set_option: row_bm is 0, 96, 128 or 129"); e->row_bm = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
     if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6, "encoder_set_option: gemm_tile is 0, 1, 2, 5 or 6"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
@@ -2973,7 +2975,8 @@ int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void
     g.W = reinterpret_cast<const unsigned short*>(W2); g.ldw = ldw; g.w_plane = (size_t)w_plane; g.oscale = oscale;
     g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
     g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
-    g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K; g.relu = relu; g.a_nt = a_nt;
+    g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K; g.relu = relu;
+    g.a_nt = a_nt & 1; g.block_rows = a_nt >> 8;          // bits 8..: GemmRowArgs.block_rows (0 by row count, 96, 128, 129)
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
     return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
 }
@@ -2990,7 +2993,8 @@ int pf_k_gemm_f16x2_row_fsmn(const void* A2, int32_t lda, int64_t a_plane, const
     g.W = reinterpret_cast<const unsigned short*>(W2); g.ldw = ldw; g.w_plane = (size_t)w_plane; g.oscale = oscale;
     g.bias = bias; g.fs_v = fs_v; g.ldfv = ldfv; g.fs_w = fs_w; g.fs_lo = fs_lo; g.fs_hi = fs_hi; g.R2 = R2; g.ldr2 = ldr2;
     g.C = C; g.ldc = ldc; g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
-    g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K; g.a_nt = a_nt;
+    g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K;
+    g.a_nt = a_nt & 1; g.block_rows = a_nt >> 8;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
     return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
 }

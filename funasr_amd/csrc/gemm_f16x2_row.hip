@@ -358,11 +358,30 @@ int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream) {
     } else {
         PF_REQUIRE(a.C, "gemm_f16x2_row: nothing to write");
     }
-    if (a.fs_v) {
+    if (a.fs_v)
         PF_REQUIRE(!a.R1 && a.fs_w && a.fs_lo && a.fs_hi && a.ldfv % 4 == 0 && ((uintptr_t)a.fs_v & 15) == 0 && a.M % 16 == 0 && ln,
                    "gemm_f16x2_row: the FSMN form needs taps, the 16-row group bounds, M % 16 == 0, the LayerNorm epilogue and no R1");
-        return a.R2 ? launch_row_m<6, true>(a, stream) : launch_row_m<4, true>(a, stream);
+    // block height by the time the block count costs in WHOLE rounds over the CUs (one block per CU): 22 528 rows are 176
+    // blocks of 128 rows = one round with 80 CUs idle, or 235 blocks of 96 rows = one round of 0.78 the time
+    // (tools/bench_r03.py `row8`). Both kernels give the same bits, so the choice may depend on the batch's row count.
+    int bm = a.block_rows;
+    if (bm == 0) {
+        static const int n_cu = [] {
+            int dev = 0, n = 256;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                n = pr.multiProcessorCount;
+            return n;
+        }();
+        const double cost128 = (double)ceil_div(ceil_div(a.M, 128), n_cu), cost96 = 0.80 * (double)ceil_div(ceil_div(a.M, 96), n_cu);
+        bm = cost96 < cost128 - 0.02 ? 96 : 128;
     }
+    if (bm != 128) {
+        PF_REQUIRE(bm == 96 || bm == 129, "gemm_f16x2_row: block_rows is 0, 96, 128 or 129");
+        const int rc = launch_gemm_f16x2_row8(a, bm == 96 ? 96 : 128, stream);
+        if (rc != -3) return rc;                      // -3: form not built in that height
+    }
+    if (a.fs_v) return a.R2 ? launch_row_m<6, true>(a, stream) : launch_row_m<4, true>(a, stream);
     const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
     switch (mode * 2 + (ln ? 1 : 0)) {
         case 0: return launch_row_m<0, false>(a, stream);

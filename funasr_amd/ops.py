@@ -316,10 +316,11 @@ def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=N
 
 def gemm_f16x2_row(a2: torch.Tensor, w2: torch.Tensor, bias=None, add1=None, add2=None, scale_exp: int = 0, relu=False,
                    ln=None, out_scale_exp: int = 0, ln_planes: bool = True, want_c: bool = True, a_nt: bool = False,
-                   time_iters: int = 0):
+                   time_iters: int = 0, block_rows: int = 0):
     """Full-row form (gemm_f16x2_row.hip, N = 512): c = relu?(a w^T + bias) + add1, add2 + c; with ln = (gamma, beta, eps)
     also y = LayerNorm(c) as fp16 planes [2, M, 512] of y * 2**out_scale_exp (ln_planes) or fp32 [M, 512].
-    Returns (c or None, y or None[, ms])."""
+    block_rows: 0 by the row count, 128 the 2 x 4-wave kernel, 96 / 129 the 1 x 8-wave kernel (gemm_f16x2_row8.hip) with 96 /
+    128 rows per block. Returns (c or None, y or None[, ms])."""
     lib = _lib.load()
     assert a2.dtype == torch.float16 and w2.dtype == torch.float16 and a2.is_contiguous() and w2.is_contiguous()
     _, M, K = a2.shape
@@ -340,7 +341,8 @@ def gemm_f16x2_row(a2: torch.Tensor, w2: torch.Tensor, bias=None, add1=None, add
                                        _ptr(add1), add1.stride(0) if add1 is not None else 0,
                                        _ptr(add2), add2.stride(0) if add2 is not None else 0,
                                        _ptr(c), 512, _ptr(g), _ptr(b), float(eps), _ptr(y2), M * 512, float(2.0 ** out_scale_exp),
-                                       _ptr(yf), M, K, int(relu), int(a_nt), int(time_iters), C.byref(ms), _stream()),
+                                       _ptr(yf), M, K, int(relu), int(bool(a_nt)) | (int(block_rows) << 8), int(time_iters),
+                                       C.byref(ms), _stream()),
                "pf_k_gemm_f16x2_row")
     y = y2 if y2 is not None else yf
     return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
@@ -348,7 +350,7 @@ def gemm_f16x2_row(a2: torch.Tensor, w2: torch.Tensor, bias=None, add1=None, add
 
 def gemm_f16x2_row_fsmn(a2: torch.Tensor, w2: torch.Tensor, bias, v: torch.Tensor, taps: torch.Tensor, lo: torch.Tensor,
                         hi: torch.Tensor, add2=None, scale_exp: int = 0, ln=None, out_scale_exp: int = 0, ln_planes: bool = True,
-                        want_c: bool = True, a_nt: bool = False, time_iters: int = 0):
+                        want_c: bool = True, a_nt: bool = False, time_iters: int = 0, block_rows: int = 0):
     """FSMN form of the full-row kernel: c = (a w^T + bias) + fsmn_memory(v), add2 + c, y = LayerNorm(c). v fp32 [M, 512], taps
     [512, 11]; lo / hi int32 [M / 16]: valid v rows [lo, hi) of the sequence owning each 16-row group. Returns (c or None, y[, ms])."""
     lib = _lib.load()
@@ -366,8 +368,9 @@ def gemm_f16x2_row_fsmn(a2: torch.Tensor, w2: torch.Tensor, bias, v: torch.Tenso
     _lib.check(lib.pf_k_gemm_f16x2_row_fsmn(_ptr(a2), K, M * K, _ptr(w2), K, 512 * K, float(2.0 ** -scale_exp), _ptr(bias),
                                             _ptr(v), v.stride(0), _ptr(taps), _ptr(lo), _ptr(hi),
                                             _ptr(add2), add2.stride(0) if add2 is not None else 0, _ptr(c), 512, _ptr(g), _ptr(b),
-                                            float(eps), _ptr(y2), M * 512, float(2.0 ** out_scale_exp), _ptr(yf), M, K, int(a_nt),
-                                            int(time_iters), C.byref(ms), _stream()), "pf_k_gemm_f16x2_row_fsmn")
+                                            float(eps), _ptr(y2), M * 512, float(2.0 ** out_scale_exp), _ptr(yf), M, K,
+                                            int(bool(a_nt)) | (int(block_rows) << 8), int(time_iters), C.byref(ms), _stream()),
+               "pf_k_gemm_f16x2_row_fsmn")
     y = y2 if y2 is not None else yf
     return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
 

@@ -114,7 +114,8 @@ class _SANMEncoderBase(HipModule):
         """Schedule options of the f16x2 mode (`pf_encoder_set_option`): "fuse_row" (1 default: linear_out / w_2 with the
         residual adds and the following LayerNorm in the GEMM epilogue; 0: separate launches, bitwise equal), "fsmn_fused" (1
         default: the FSMN memory block computed inside linear_out's epilogue; 0: its own launch, bitwise equal), "attn_variant"
-        (3 default: lazy rescale; 1 pipelined; 0 plain)."""
+        (3 default: lazy rescale; 1 pipelined; 0 plain), "row_bm" (rows per block of the full-row GEMMs: 0 default = by the
+        batch's row count, 96 / 128 / 129 forced; bitwise equal)."""
         if not hasattr(self, "_options"):
             self._options = {}
         self._options[str(key)] = int(value)

@@ -205,6 +205,18 @@ def test_row_form_is_bitwise_gemm_then_layernorm(cuda, M, K, r1, r2):
     assert torch.equal(c, c_ref) and torch.equal(yf, yf_ref)
     c_only, none = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se)
     assert none is None and torch.equal(c_only, c_ref)
+    # every block height (0: chosen by the row count; 128: the 2 x 4-wave kernel; 96 / 129: the 1 x 8-wave kernel) gives the same bits
+    for br in (0, 128, 96, 129):
+        c, y = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, ln=(gamma, beta, eps), out_scale_exp=ey,
+                                  block_rows=br, a_nt=(br == 96))
+        assert torch.equal(c, c_ref) and torch.equal(y, y_ref), f"block_rows {br}"
+    if r2 and not r1:
+        for br in (96, 129):
+            c, none = ops.gemm_f16x2_row(a2, w2, bias, add2=add2, scale_exp=se, block_rows=br)
+            assert none is None and torch.equal(c, c_ref), f"block_rows {br} without LayerNorm"
+            nc, yf = ops.gemm_f16x2_row(a2, w2, bias, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False, want_c=False,
+                                        block_rows=br)
+            assert nc is None and torch.equal(yf, yf_ref)
     nc, y_only = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, ln=(gamma, beta, eps), out_scale_exp=ey, want_c=False)
     assert nc is None and torch.equal(y_only, y_ref)
     # in place: C aliases the second addend (the encoder's residual stream)
@@ -262,6 +274,10 @@ def test_row_form_with_fsmn_in_the_epilogue_is_bitwise_fsmn_then_row(cuda, slots
     nc, yf = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False,
                                      want_c=False)
     assert nc is None and torch.equal(yf, ops.layernorm(c_ref, gamma, beta, eps))
+    for br in (0, 128, 96, 129):
+        c, y = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps),
+                                       out_scale_exp=ey, block_rows=br)
+        assert torch.equal(c, c_ref) and torch.equal(y, y_ref), f"FSMN form, block_rows {br}"
 
 
 @pytest.mark.parametrize("frames", [[103], [36, 103, 500], [255, 256, 257, 16]])
@@ -280,12 +296,13 @@ def test_encoder_schedule_options_are_bitwise_equal(cuda, frames, packing):
     feats = (torch.randn(len(frames), max(frames), 560, generator=g) * 0.8).to(cuda)
     lens = torch.tensor(frames, dtype=torch.int32)
     outs = {}
-    for fuse_row, fsmn_fused in ((0, 0), (1, 0), (1, 1)):
-        enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused)
-        outs[(fuse_row, fsmn_fused)] = enc(feats, lens)[0].clone()
-    assert torch.isfinite(outs[(0, 0)]).all() and outs[(0, 0)].abs().max().item() > 0.1
-    assert torch.equal(outs[(1, 0)], outs[(0, 0)]), "fuse_row changes the encoder's bits"
-    assert torch.equal(outs[(1, 1)], outs[(0, 0)]), "fsmn_fused changes the encoder's bits"
+    for fuse_row, fsmn_fused, row_bm in ((0, 0, 0), (1, 0, 128), (1, 1, 128), (1, 1, 96), (1, 0, 96), (1, 1, 129), (1, 1, 0)):
+        enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused).set_option("row_bm", row_bm)
+        outs[(fuse_row, fsmn_fused, row_bm)] = enc(feats, lens)[0].clone()
+    base = outs[(0, 0, 0)]
+    assert torch.isfinite(base).all() and base.abs().max().item() > 0.1
+    for key, out in outs.items():
+        assert torch.equal(out, base), f"(fuse_row, fsmn_fused, row_bm) = {key} changes the encoder's bits"
 
 
 def _row_in_place(ops, a2, w2, bias, add1, x, se, gamma, beta, eps, ey):

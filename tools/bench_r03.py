@@ -121,3 +121,22 @@ if "fsmnrow" in which:
         row["row_r1" + rep] = round(best(lambda: ops.gemm_f16x2_row(a2, w2, b, add1=mem, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, a_nt=True, time_iters=20)[2]) * 1e3, 1)
         row["row_fsmn" + rep] = round(best(lambda: ops.gemm_f16x2_row_fsmn(a2, w2, b, v, taps, lo, hi, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, a_nt=True, time_iters=20)[2]) * 1e3, 1)
     print(json.dumps({"linear_out_us_M32768": row}), flush=True)
+
+if "row8" in which:
+    # block heights of the full-row kernel at the SenseVoice row count (22 528 = 0.69 of a round of 128-row blocks) and at
+    # the headline's (32 768 = one round): 128 = 2 x 4 waves, 129 = 1 x 8 waves x 128 rows, 96 = 1 x 8 waves x 96 rows
+    for Mr in (22528, 32768, 37120):
+        for K in (512, 2048):
+            a = torch.randn(Mr, K, device=dev); w = torch.randn(512, K, device=dev) * K ** -0.5; b = torch.randn(512, device=dev)
+            a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+            x = torch.randn(Mr, 512, device=dev); gamma = torch.rand(512, device=dev) + 0.5; beta = torch.randn(512, device=dev)
+            ln = (gamma, beta, 1e-12)
+            ref = ops.gemm_f16x2_row(a2, w2, b, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, block_rows=128)
+            row = {}
+            for rep in ("", "_again"):
+                for br in (128, 129, 96, 0):
+                    out = ops.gemm_f16x2_row(a2, w2, b, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, block_rows=br, a_nt=(K == 512))
+                    ms = best(lambda: ops.gemm_f16x2_row(a2, w2, b, add2=x, scale_exp=20, ln=ln, out_scale_exp=7, block_rows=br,
+                                                         a_nt=(K == 512), time_iters=20)[2])
+                    row[f"bm{br}{rep}"] = (round(ms * 1e3, 1), bool(torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])))
+            print(json.dumps({f"row_M{Mr}_K{K}": row}), flush=True)
