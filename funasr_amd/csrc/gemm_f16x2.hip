@@ -663,6 +663,46 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
                    "gemm_f16x2: QKV outputs");
         if (a.tile == 5) return launch_pair<0, 2>(a, stream);
         if (a.tile == 6) return launch_ring<0, 2>(a, stream);
+        if (a.tile == 3) return launch_tile<2, 2, 0, 2, 0, 0, 2>(a, stream);     // 128 x 128, four waves, two workgroups per CU
+        if (a.tile == 0) {
+            // Shape by the row count, in units of one round of 256 x 256 blocks (tools/bench_r03.py `qkvsplit`, N = 1536):
+            //   256 x 256 only: whole rounds -- 528 blocks (M = 22 528) cost 3, not 2.06;
+            //   128 x 128 (four waves, two workgroups per CU, out of phase): 0.6 per round of 2 n_cu blocks, and fractional
+            //     rounds cost fractions -- 134 us instead of 154 at M = 22 528, 212 instead of 178 at M = 32 768;
+            //   head / tail split: the whole rounds as 256 x 256 blocks, the rows behind them as 128 x 128 blocks in a second
+            //     launch (+0.65: a launch boundary and one small round) -- 198 us instead of 218 at M = 33 536.
+            // Row ranges are independent and all shapes give the same bits (tested), so the choice may depend on M.
+            static const int n_cu = [] {
+                int dev = 0, n = 256;
+                hipDeviceProp_t pr;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                    n = pr.multiProcessorCount;
+                return n;
+            }();
+            const int nN = a.N / 256, m_tiles = ceil_div(a.M, 256);
+            const long blocks = (long)m_tiles * nN, full = blocks / n_cu, rem = blocks % n_cu;
+            const double cost_wide = (double)(full + (rem ? 1 : 0));
+            const double r_small = (double)ceil_div(a.M, 128) * (a.N / 128) / (2.0 * n_cu);
+            const double cost_small = 0.6 * (r_small > 1.0 ? r_small : 1.0);
+            const int head_tiles = (int)(full * n_cu / nN);
+            const int tail_rows = a.M - head_tiles * 256;
+            double cost_split = 1e30;
+            if (full >= 2 && rem > 0 && tail_rows > 0 && (long)ceil_div(tail_rows, 128) * (a.N / 128) <= 2L * n_cu) cost_split = (double)full + 0.65;
+            if (cost_small < cost_wide && cost_small <= cost_split) return launch_tile<2, 2, 0, 2, 0, 0, 2>(a, stream);
+            if (cost_split < cost_wide) {
+                Gemm2Args h = a, t = a;
+                const size_t r0 = (size_t)head_tiles * 256;
+                h.M = (int)r0;
+                t.M = tail_rows;
+                t.A = a.A + r0 * a.lda;
+                if (a.C) t.C = a.C + r0 * a.ldc;
+                if (a.Qp) t.Qp = a.Qp + r0 * a.qkv_D;
+                t.Kp = a.Kp + r0 * a.qkv_D;
+                t.VT = a.VT + r0;
+                const int rc = launch_tile<2, 4, 0, 2, 0, 2>(h, stream);
+                return rc ? rc : launch_tile<2, 2, 0, 2, 0, 0, 2>(t, stream);
+            }
+        }
         return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);
     }
     if (a.C2) {

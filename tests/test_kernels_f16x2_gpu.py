@@ -109,7 +109,7 @@ def test_gemm_f16x2_plane_output(cuda, M):
     assert ((val - f32).abs() <= 2.0 ** -22 * f32.abs() + 2.0 ** -25 * 2.0 ** -eo).all()
 
 
-@pytest.mark.parametrize("M,K", [(80, 512), (512, 576), (4096, 512), (32768, 512)])
+@pytest.mark.parametrize("M,K", [(80, 512), (512, 576), (4096, 512), (32768, 512), (22528, 512), (33536, 512)])
 @pytest.mark.parametrize("kv_form", [False, True])
 def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
     """the fused q|k|v projection writing the attention kernel's operands: Q / K planes, fp32 V, transposed V planes whose
@@ -122,6 +122,11 @@ def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
     q_mul, k_mul, v_mul = 128 ** -0.5 * 2.0 ** 7, 2.0 ** 6, 2.0 ** 5
     out = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form)
     pair = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=5)
+    # tile 0 (above) picks by the row count: 128 x 128 blocks at M = 22 528, whole rounds of 256 x 256 blocks + a 128 x 128 tail at M = 33 536; 2: 256 x 256 only; 3: 128 x 128 only
+    for tile in (2, 3):
+        one = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=tile)
+        for key in ("q2", "k2", "v", "vt"):
+            assert (out[key] is None and one[key] is None) or torch.equal(out[key], one[key]), f"tile {tile}: {key} differs"
     ring = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=6)
     for key in ("q2", "k2", "v", "vt"):
         assert (out[key] is None and pair[key] is None) or torch.equal(out[key], pair[key]), f"128x256 shape: {key} differs"

@@ -140,3 +140,14 @@ if "row8" in which:
                                                          a_nt=(K == 512), time_iters=20)[2])
                     row[f"bm{br}{rep}"] = (round(ms * 1e3, 1), bool(torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])))
             print(json.dumps({f"row_M{Mr}_K{K}": row}), flush=True)
+
+if "qkvsplit" in which:
+    # QKV form at row counts that leave a nearly empty last round of 256 x 256 blocks: tile 0 = head / tail split, 2 = no split
+    for Mr in (22528, 32768, 33536):
+        a = torch.randn(Mr, 512, device=dev); w = torch.randn(1536, 512, device=dev) * 512 ** -0.5; b = torch.randn(1536, device=dev)
+        a2, w2 = ops.split2(a, 8), ops.split2(w, 12)
+        row = {}
+        for rep in ("", "_again"):
+            for label, tile in (("wide_only", 2), ("auto", 0), ("small_only", 3)):
+                row[label + rep] = round(best(lambda: ops.gemm_f16x2_qkv(a2, w2, b, 512, 20, 2.0 ** 4, 2.0 ** 6, 2.0 ** 6, tile=tile, time_iters=20)["ms"]) * 1e3, 1)
+        print(json.dumps({f"qkv_form_M{Mr}": row}), flush=True)

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-clips", type=int, default=4)
     ap.add_argument("--modes", default="f16x2,fp32,bf16", help="arithmetic modes to time; the first is the reported one")
+    ap.add_argument("--enc-option", action="append", default=[], metavar="KEY=VALUE", help="A/B runs: encoder schedule options "
+                    "(pf_encoder_set_option), e.g. row_bm=128 gemm_tile=2 = the block shapes before the row-count-aware choice")
     args = ap.parse_args()
     from funasr_amd import synth
     from funasr_amd.sense_voice import SenseVoiceSmall
@@ -32,6 +34,9 @@ def main():
     model = SenseVoiceSmall.from_config(cfg)
     model.load_state_dict(sd, strict=False)
     model = model.to(dev)
+    for kv in args.enc_option:
+        k, v = kv.split("=")
+        model.encoder.set_option(k, int(v))
     sh, sc = synth.synthetic_cmvn(560)
     cmvn = torch.stack([sh, sc])
     fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0, device=dev)
