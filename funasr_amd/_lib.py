@@ -144,6 +144,7 @@ SIGNATURES = {
     "pf_stream_destroy": (None, [_vp]),
     "pf_stream_set_pe": (C.c_int, [_vp, _vp, _i32]),
     "pf_stream_reset": (C.c_int, [_vp, _vp]),
+    "pf_stream_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "pf_stream_step": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pi32, _pi32, _vp, _vp]),
     "pf_stream_peek": (C.c_int, [_vp, _vp, _vp, _pi32]),
     "pf_frontend_fbank": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),

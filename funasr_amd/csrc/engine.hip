@@ -79,6 +79,7 @@ struct Tensor {
 
 struct TensorTable {
     std::map<std::string, Tensor> t;
+    unsigned long long version = 0;    // bumped by every set(): consumers that cache derived data (streaming f16x2 step) compare it
     ~TensorTable() {
         for (auto& kv : t) if (kv.second.d) (void)hipFree(kv.second.d);
         for (auto& kv : b16) if (kv.second) (void)hipFree(kv.second);
@@ -118,6 +119,7 @@ struct TensorTable {
         auto it = t.find(name);
         if (it == t.end()) { set_error(std::string("unknown tensor name: ") + name); return -1; }
         Tensor& x = it->second;
+        ++version;
         if (numel != x.numel) {
             set_error(std::string("tensor ") + name + ": expected " + std::to_string(x.numel) + " elements, got " +
                       std::to_string(numel));
@@ -518,6 +520,36 @@ static int encoder_resolve(Encoder* e) {
     return 0;
 }
 
+// f16x2 mode: weight planes with their exponents and the exponents of the activation planes of every block (once per
+// weight set; load-time reductions with host round trips -- never inside a graph capture)
+static int encoder_prepare_x2(Encoder* e, hipStream_t s) {
+    const pf_encoder_config& c = e->cfg;
+    const int D = c.d_model, F = c.ffn_dim;
+    const float dk_scale = powf((float)(D / c.n_heads), -0.5f);
+    for (auto& w : e->layers) {
+        if (w.qkv_w2) continue;
+        const std::string qkv_name = w.prefix + "self_attn.linear_q_k_v.weight";
+        w.qkv_w2 = e->tt.get_split2(qkv_name, 3 * D, w.in_pad, &w.ew_qkv, s);
+        w.out_w2 = e->tt.get_split2(w.prefix + "self_attn.linear_out.weight", D, D, &w.ew_out, s);
+        w.w1_2 = e->tt.get_split2(w.prefix + "feed_forward.w_1.weight", F, D, &w.ew_1, s);
+        w.w2_2 = e->tt.get_split2(w.prefix + "feed_forward.w_2.weight", D, F, &w.ew_2, s);
+        if (!w.qkv_w2 || !w.out_w2 || !w.w1_2 || !w.w2_2) return -2;
+        // a-priori bounds -> plane exponents. LayerNorm: |y| <= sqrt(D) max|gamma| + max|beta|; a Linear over inputs
+        // bounded by b: |W x + c| <= b max_n sum_k |W[n, k]| + |c[n]|; attention output <= max |v|; relu only shrinks
+        float g1, b1, g2, b2, bq, bk, bv, bh;
+        if (TensorTable::dev_absmax(w.n1g, w.in_dim, &g1, s) || TensorTable::dev_absmax(w.n1b, w.in_dim, &b1, s) ||
+            TensorTable::dev_absmax(w.n2g, D, &g2, s) || TensorTable::dev_absmax(w.n2b, D, &b2, s)) return -2;
+        const float bx1 = sqrtf((float)w.in_dim) * g1 + b1, bx2 = sqrtf((float)D) * g2 + b2;
+        if (TensorTable::dev_linear_bound(w.qkv_w, D, w.in_pad, w.in_pad, w.qkv_b, bx1, &bq, s) ||
+            TensorTable::dev_linear_bound(w.qkv_w + (size_t)D * w.in_pad, D, w.in_pad, w.in_pad, w.qkv_b + D, bx1, &bk, s) ||
+            TensorTable::dev_linear_bound(w.qkv_w + (size_t)2 * D * w.in_pad, D, w.in_pad, w.in_pad, w.qkv_b + 2 * D, bx1, &bv, s) ||
+            TensorTable::dev_linear_bound(w.w1, F, D, D, w.b1, bx2, &bh, s)) return -2;
+        w.e_x1 = exp_for_bound(bx1); w.e_x2 = exp_for_bound(bx2);
+        w.e_q = exp_for_bound(bq * dk_scale); w.e_k = exp_for_bound(bk); w.e_v = exp_for_bound(bv); w.e_h = exp_for_bound(bh);
+    }
+    return 0;
+}
+
 // SinusoidalPositionEncoder.encode (embedding.py:396-420) with libm; used only when the caller passes no table
 static int encoder_default_pe(Encoder* e, int T, hipStream_t s) {
     const int D = e->cfg.input_dim;
@@ -545,6 +577,7 @@ static int encoder_default_pe(Encoder* e, int T, hipStream_t s) {
 struct EncChunkCtx {
     float* ring; int cap; const StreamDev* st; int append_rows;
     const int* lens;     // device [B]: every window row is valid in a chunk
+    bool x2 = false;     // the block's four GEMMs on the fp16 matrix cores (two-plane operands, gemm_f16x2.hip), fp32 results
 };
 
 // mode 3 only: `xn_ready` = the planes of norm1(x_in) already lie in xn16 (written by the previous block's w_2 epilogue);
@@ -748,10 +781,40 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         }
         return gemm2(ffn2, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D);
     }
+    // Streaming step in its f16x2 form (cc->x2, pf_stream_set_option "gemm_mode" 3): the block's four GEMMs take two-plane
+    // fp16 operands with the a-priori exponents of the offline f16x2 mode (encoder_prepare_x2) and write fp32, so the FSMN,
+    // the few-query attention over the K/V ring and the ring itself stay the fp32 kernels of the default step. The attention
+    // output (a convex combination of v rows, ring rows included: the same projection of earlier frames) is bounded by v's bound.
+    const bool x2c = cc && cc->x2;
+    unsigned short* xn2c = e->xn16.as<unsigned short>();
+    unsigned short* ctx2c = e->ctx16.as<unsigned short>();
+    unsigned short* ffn2c = e->ffn16.as<unsigned short>();
+    auto gemm2c = [&](const unsigned short* A, int lda, int ea, const unsigned short* W, int ew, const float* bias, float* C, int ldc,
+                      unsigned short* C2, int ec, int N, int K, int relu, const float* R1, int ldr1, const float* R2, int ldr2) {
+        Gemm2Args g{};
+        g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)N * K;
+        g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
+        g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = N; g.c_plane = (size_t)M * N; g.cscale = pow2f(ec);
+        g.M = M; g.N = N; g.K = K; g.relu = relu;
+        ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
+        return launch_gemm_f16x2(g, s);
+    };
+    auto ln_planes = [&](const float* src, int ld, const float* g, const float* b, int dim, int dim_pad, int ex) {
+        ProfScope ps(PROF_LN, 8.0 * M * (double)dim, s);
+        return launch_layernorm(src, ld, g, b, reinterpret_cast<float*>(xn2c), dim_pad, M, dim, dim_pad, c.ln_eps, s, 3, 0,
+                                (size_t)M * dim_pad, pow2f(ex));
+    };
+    if (x2c && (!w.qkv_w2 || !w.out_w2 || !w.w1_2 || !w.w2_2)) { set_error("encoder: streaming f16x2 step without prepared weight planes"); return -1; }
     // norm1 -> fused QKV projection
-    if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
-    if ((rc = gemm_simple(xn, w.in_pad, w.qkv_w, w.in_pad, w.qkv_b, qkv, 3 * D, M, 3 * D, w.in_pad, 0, nullptr, 0,
-                          nullptr, 0, s))) return rc;
+    if (x2c) {
+        if ((rc = ln_planes(x_in, ld_in, w.n1g, w.n1b, w.in_dim, w.in_pad, w.e_x1))) return rc;
+        if ((rc = gemm2c(xn2c, w.in_pad, w.e_x1, w.qkv_w2, w.ew_qkv, w.qkv_b, qkv, 3 * D, nullptr, 0, 3 * D, w.in_pad, 0, nullptr, 0,
+                         nullptr, 0))) return rc;
+    } else {
+        if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
+        if ((rc = gemm_simple(xn, w.in_pad, w.qkv_w, w.in_pad, w.qkv_b, qkv, 3 * D, M, 3 * D, w.in_pad, 0, nullptr, 0,
+                              nullptr, 0, s))) return rc;
+    }
     // FSMN memory on the un-split V projection (attention.py:216-239,322-323)
     FsmnArgs fa{};
     fa.in = qkv + 2 * D; fa.ldin = 3 * D; fa.w = w.fsmn_w; fa.R = nullptr; fa.ldr = 0; fa.out = mem; fa.ldo = D;
@@ -786,6 +849,14 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
     }
     // out projection + fsmn memory (+ residual when in == out, encoder.py:120-137)
     const float* resid = (w.in_dim == D) ? x_in : nullptr;
+    if (x2c) {
+        if ((rc = launch_split2(ctx, D, ctx2c, D, (size_t)M * D, M, D, pow2f(w.e_v), s))) return rc;
+        if ((rc = gemm2c(ctx2c, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid, ld_in))) return rc;
+        // norm2 -> FFN -> residual: w_1 hands its relu output to w_2 as planes, like the offline mode
+        if ((rc = ln_planes(x, D, w.n2g, w.n2b, D, D, w.e_x2))) return rc;
+        if ((rc = gemm2c(xn2c, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2c, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
+        return gemm2c(ffn2c, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D);
+    }
     if ((rc = gemm_simple(ctx, D, w.out_w, D, w.out_b, x, D, M, D, D, 0, mem, D, resid, ld_in, s))) return rc;
     // norm2 -> FFN -> residual (encoder.py:141-146)
     if ((rc = layernorm(x, D, w.n2g, w.n2b, xn, D, M, D, D, c.ln_eps, s))) return rc;
@@ -1120,6 +1191,15 @@ struct Stream {
     std::map<int, int> seen;
     unsigned long long graph_epoch = 0;                      // g_ws_epoch the graphs were captured under
     bool use_graph = true;
+    // gemm_mode 3 (pf_stream_set_option): every GEMM of the step on the fp16 matrix cores with two-plane operands
+    // (gemm_f16x2.hip; fp32 results, fp32-class accuracy like the offline f16x2 mode); attention, FSMN, CIF, the K/V rings and
+    // every LayerNorm statistic stay the fp32 kernels of the default step. Exponents come from a-priori bounds: the decoder's
+    // memory is THIS encoder's after_norm output (|y| <= sqrt(D) max|gamma| + max|beta|), so nothing is chosen per step.
+    bool x2 = false;
+    unsigned long long ver_e = ~0ull, ver_d = ~0ull;         // TensorTable versions the prepared exponents / planes belong to
+    int e_mem = 0, e_an = 0;
+    std::vector<int> e_ctx;                                  // per decoder layer: exponent of the cross-attention output planes
+    DevBuf mem2;                                             // planes of the step's encoder output [2][S * Wmax, D]
     ~Stream() {
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
         if (h_ids) (void)hipHostFree(h_ids);
@@ -1142,6 +1222,45 @@ static int stream_reset(Stream* st, hipStream_t s) {
     return rc ? -2 : 0;
 }
 
+// gemm_mode 3: weight planes and exponents of both handles (load-time reductions with host round trips: outside any capture)
+static int stream_prepare_x2(Stream* st, hipStream_t s) {
+    Encoder* e = st->e; Decoder* d = st->d;
+    int rc;
+    if (!e->resolved && (rc = encoder_resolve(e))) return rc;
+    if (!d->resolved && (rc = decoder_resolve(d))) return rc;
+    const pf_decoder_config& dc = d->cfg;
+    const int D = e->cfg.d_model;
+    if (D / e->cfg.n_heads != 128 || D % 256 != 0 || e->cfg.ffn_dim % 256 != 0 || dc.ffn_dim % 256 != 0 || dc.d_model != D ||
+        dc.vocab_size <= 0) {
+        set_error("stream: gemm_mode 3 (f16x2) needs d_model / n_heads == 128, d_model % 256 == 0, ffn_dim % 256 == 0");
+        return -1;
+    }
+    if ((rc = encoder_prepare_x2(e, s))) return rc;
+    for (int l = 0; l < dc.n_blocks; ++l)
+        if ((rc = dec_layer_x2(d, d->layers[l], dec_layer_prefix(d->contextual, dc.n_blocks, l), true, s))) return rc;
+    if ((rc = dec_layer_x2(d, d->last, "decoders3.0.", false, s))) return rc;
+    float g, b;
+    if (TensorTable::dev_absmax(e->tt.get("after_norm.weight"), D, &g, s) || TensorTable::dev_absmax(e->tt.get("after_norm.bias"), D, &b, s)) return -2;
+    const float bmem = sqrtf((float)D) * g + b;
+    st->e_mem = exp_for_bound(bmem);
+    st->e_ctx.assign((size_t)dc.n_blocks, 0);
+    for (int l = 0; l < dc.n_blocks; ++l)      // |attention output| <= max |v|,  v = Wv m + bv
+        st->e_ctx[l] = exp_for_bound(bmem * d->layers[l].kv_l1b[2] + d->layers[l].kv_l1b[3]);
+    if (TensorTable::dev_absmax(d->tt.get("after_norm.weight"), D, &g, s) || TensorTable::dev_absmax(d->tt.get("after_norm.bias"), D, &b, s)) return -2;
+    st->e_an = exp_for_bound(sqrtf((float)D) * g + b);
+    int ew_v = 0;
+    if (!d->tt.get_split2("output_layer.weight", dc.vocab_size, D, &ew_v, s)) return -2;
+    st->ver_e = e->tt.version; st->ver_d = d->tt.version;
+    return 0;
+}
+static bool stream_x2_ready(const Stream* st) {
+    const Encoder* e = st->e; const Decoder* d = st->d;
+    if (!e->resolved || !d->resolved || st->ver_e != e->tt.version || st->ver_d != d->tt.version) return false;
+    for (auto& w : e->layers) if (!w.qkv_w2 || !w.out_w2 || !w.w1_2 || !w.w2_2) return false;
+    for (auto& w : d->layers) if (!w.x2_ready) return false;
+    return d->last.x2_ready && d->tt.b16.count("output_layer.weight#split2") != 0 && (int)st->e_ctx.size() == d->cfg.n_blocks;
+}
+
 // enqueue one chunk on `s` (no host synchronisation, no allocation after the first call with this shape)
 static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t s) {
     Encoder* e = st->e; Predictor* p = st->p; Decoder* d = st->d;
@@ -1160,6 +1279,10 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             e->qkv.ensure(sizeof(float) * Mz * 3 * D) || e->mem.ensure(sizeof(float) * Mz * D) ||
             e->ctx.ensure(sizeof(float) * Mz * D) || e->ffn.ensure(sizeof(float) * Mz * Fbuf))
             return -2;
+        if (st->x2 && (e->xn16.ensure(sizeof(unsigned short) * 2 * Mz * (Dpad > D ? Dpad : D)) ||
+                       e->ctx16.ensure(sizeof(unsigned short) * 2 * Mz * D) || e->ffn16.ensure(sizeof(unsigned short) * 2 * Mz * F) ||
+                       st->mem2.ensure(sizeof(unsigned short) * 2 * Mz * D)))
+            return -2;
     }
     if ((rc = launch_fill_int(st->lensW.as<int>(), S, W, s))) return rc;
     // ---- window: [cached rows | x * sqrt(d) + PE]  (scama/encoder.py:496-503)
@@ -1174,7 +1297,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     const size_t ring_layer = (size_t)S * st->enc_cap * 2 * D;
     for (size_t l = 0; l < e->layers.size(); ++l) {
         EncChunkCtx cc{st->enc_cap > 0 ? st->enc_ring.as<float>() + l * ring_layer : nullptr, st->enc_cap, dev, append_rows,
-                       st->lensW.as<int>()};
+                       st->lensW.as<int>(), st->x2};
         if (l == 0) rc = encoder_block(e, e->layers[0], st->win.as<float>(), Din, x, S, W, s, &cc);
         else rc = encoder_block(e, e->layers[l], x, D, x, S, W, s, &cc);
         if (rc) return rc;
@@ -1220,21 +1343,44 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     float* dx = d->x.as<float>();
     float* t1 = d->t1.as<float>();
     float* t2 = d->t2.as<float>();
+    const bool x2 = st->x2;
+    unsigned short* t2p = nullptr;       // gemm_mode 3: LayerNorm-output planes of the token rows, cross-attention output planes,
+    unsigned short* c2p = nullptr;       // planes of the step's encoder output (the cross-attention memory)
+    const unsigned short* mem2 = nullptr;
+    if (x2) {
+        if (d->t16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D) || d->ffn16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * dc.ffn_dim) ||
+            d->ctx16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D))
+            return -2;
+        t2p = d->t16.as<unsigned short>(); c2p = d->ctx16.as<unsigned short>();
+        if ((rc = launch_split2(enc_out, D, st->mem2.as<unsigned short>(), D, (size_t)Mk * D, Mk, D, pow2f(st->e_mem), s))) return rc;
+        mem2 = st->mem2.as<unsigned short>();
+    }
     PF_HIP_TRY(hipMemcpyAsync(dx, st->embeds.p, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     const size_t dring_layer = (size_t)S * st->dec_cap * 2 * D;
     const size_t dfsmn_layer = (size_t)S * (dc.kernel_size - 1) * D;
     for (int l = 0; l < dc.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
-        if ((rc = dec_ffn(d, w, dx, t2, Mq, s))) return rc;
+        if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
         if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
         DecFsmnChunkArgs fa{};
         fa.in = t1; fa.resid = dx; fa.out = dx; fa.w = w.fsmn_w; fa.state = st->dec_fsmn.as<float>() + l * dfsmn_layer;
         fa.n_valid = st->n_fired.as<int>(); fa.S = S; fa.N = Nmax; fa.C = D;
         if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
-        if ((rc = layernorm(dx, D, w.n3g, w.n3b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
-        if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
-        if ((rc = gemm_simple(enc_out, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
-                              nullptr, 0, s))) return rc;
+        if (x2) {
+            {
+                ProfScope ps(PROF_LN, 8.0 * Mq * (double)D, s);
+                if ((rc = launch_layernorm(dx, D, w.n3g, w.n3b, reinterpret_cast<float*>(t2p), D, Mq, D, D, dc.ln_eps, s, 3, 0,
+                                           (size_t)Mq * D, pow2f(w.e_n3)))) return rc;
+            }
+            if ((rc = gemm2_simple(t2p, D, Mq, w.e_n3, w.q_2, w.ew_q, w.q_b, d->q.as<float>(), D, D, D, 0, nullptr, 0, s))) return rc;
+            if ((rc = gemm2_simple(mem2, D, Mk, st->e_mem, w.kv_2, w.ew_kv, w.kv_b, d->kv.as<float>(), 2 * D, 2 * D, D, 0, nullptr, 0, s)))
+                return rc;
+        } else {
+            if ((rc = layernorm(dx, D, w.n3g, w.n3b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
+            if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
+            if ((rc = gemm_simple(enc_out, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
+                                  nullptr, 0, s))) return rc;
+        }
         AttnArgs at{};
         at.Q = d->q.as<float>(); at.ldq = D; at.O = d->ctx.as<float>(); at.ldo = D; at.B = S; at.H = dc.n_heads;
         at.Tq = Nmax; at.scale = powf((float)(D / dc.n_heads), -0.5f);
@@ -1259,7 +1405,10 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             ra.wp_dev = st->dec_wp.as<int>(); ra.gate_dev = st->n_fired.as<int>();
             if ((rc = launch_ring_append(ra, s))) return rc;
         }
-        if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, dx, D, Mq, D, D, 0, nullptr, 0, dx, D, s))) return rc;
+        if (x2) {
+            if ((rc = launch_split2(d->ctx.as<float>(), D, c2p, D, (size_t)Mq * D, Mq, D, pow2f(st->e_ctx[l]), s))) return rc;
+            if ((rc = gemm2_simple(c2p, D, Mq, st->e_ctx[l], w.o_2, w.ew_o, w.o_b, dx, D, D, D, 0, dx, D, s))) return rc;
+        } else if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, dx, D, Mq, D, D, 0, nullptr, 0, dx, D, s))) return rc;
     }
     if (st->dec_cap > 0) {
         StreamAdvanceArgs ad{};
@@ -1267,11 +1416,35 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         ad.S = S; ad.dec_rows = W; ad.dec_cap = st->dec_cap;
         if ((rc = launch_stream_advance_dec(ad, s))) return rc;
     }
-    if ((rc = dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
-    if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), d->hid.as<float>(), D, Mq,
-                        D, D, dc.ln_eps, s))) return rc;
-    if ((rc = vocab_project(d->hid.as<float>(), Mq, D, d->tt.get("output_layer.weight"), d->tt.get("output_layer.bias"),
-                            V, nullptr, st->ids.as<int32_t>(), d->pval, d->pidx, s))) return rc;
+    if ((rc = x2 ? dec_ffn_x2(d, d->last, dx, t2, Mq, s) : dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
+    if (x2) {
+        // after_norm writes two-plane operands, the vocabulary projection runs with the row arg-max fused into its epilogue
+        // (the offline greedy route of decoder_forward_impl)
+        auto wv = d->tt.b16.find("output_layer.weight#split2");
+        if (wv == d->tt.b16.end()) { set_error("stream: f16x2 step without prepared vocabulary planes"); return -1; }
+        const int ew_v = d->tt.exp2.at("output_layer.weight#split2");
+        {
+            ProfScope ps(PROF_LN, 8.0 * Mq * (double)D, s);
+            if ((rc = launch_layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), reinterpret_cast<float*>(t2p), D,
+                                       Mq, D, D, dc.ln_eps, s, 3, 0, (size_t)Mq * D, pow2f(st->e_an)))) return rc;
+        }
+        const int nparts = gemm_f16x2_argmax_parts(Mq, V);
+        if (d->pval.ensure(sizeof(float) * (size_t)Mq * nparts) || d->pidx.ensure(sizeof(int) * (size_t)Mq * nparts)) return -2;
+        Gemm2Args g{};
+        g.A = t2p; g.lda = D; g.a_plane = (size_t)Mq * D; g.W = wv->second; g.ldw = D; g.w_plane = (size_t)V * D;
+        g.oscale = pow2f(-(st->e_an + ew_v)); g.bias = d->tt.get("output_layer.bias"); g.M = Mq; g.N = V; g.K = D;
+        g.amax_val = d->pval.as<float>(); g.amax_idx = d->pidx.as<int>(); g.amax_ld = nparts;
+        {
+            ProfScope ps(PROF_GEMM3, 2.0 * Mq * (double)V * D, s);
+            if ((rc = launch_gemm_f16x2(g, s))) return rc;
+        }
+        if ((rc = launch_argmax_reduce(d->pval.as<float>(), d->pidx.as<int>(), nparts, nparts, st->ids.as<int32_t>(), nullptr, Mq, s))) return rc;
+    } else {
+        if ((rc = layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), d->hid.as<float>(), D, Mq,
+                            D, D, dc.ln_eps, s))) return rc;
+        if ((rc = vocab_project(d->hid.as<float>(), Mq, D, d->tt.get("output_layer.weight"), d->tt.get("output_layer.bias"),
+                                V, nullptr, st->ids.as<int32_t>(), d->pval, d->pidx, s))) return rc;
+    }
     PF_HIP_TRY(hipMemcpyAsync(st->h_ids, st->ids.p, sizeof(int32_t) * (size_t)Mq, hipMemcpyDeviceToHost, s));
     PF_HIP_TRY(hipMemcpyAsync(st->h_n, st->n_fired.p, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, s));
     return 0;
@@ -1618,28 +1791,7 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         if (e->q2.cap != cap_q) PF_HIP_TRY(hipMemsetAsync(e->q2.p, 0, e->q2.cap, s));
         if (e->k2.cap != cap_k) PF_HIP_TRY(hipMemsetAsync(e->k2.p, 0, e->k2.cap, s));
         if (e->vt2.cap != cap_v) PF_HIP_TRY(hipMemsetAsync(e->vt2.p, 0, e->vt2.cap, s));
-        const float dk_scale = powf((float)(D / c.n_heads), -0.5f);
-        for (auto& w : e->layers) {
-            if (w.qkv_w2) continue;
-            const std::string qkv_name = w.prefix + "self_attn.linear_q_k_v.weight";
-            w.qkv_w2 = e->tt.get_split2(qkv_name, 3 * D, w.in_pad, &w.ew_qkv, s);
-            w.out_w2 = e->tt.get_split2(w.prefix + "self_attn.linear_out.weight", D, D, &w.ew_out, s);
-            w.w1_2 = e->tt.get_split2(w.prefix + "feed_forward.w_1.weight", F, D, &w.ew_1, s);
-            w.w2_2 = e->tt.get_split2(w.prefix + "feed_forward.w_2.weight", D, F, &w.ew_2, s);
-            if (!w.qkv_w2 || !w.out_w2 || !w.w1_2 || !w.w2_2) return -2;
-            // a-priori bounds -> plane exponents. LayerNorm: |y| <= sqrt(D) max|gamma| + max|beta|; a Linear over inputs
-            // bounded by b: |W x + c| <= b max_n sum_k |W[n, k]| + |c[n]|; attention output <= max |v|; relu only shrinks
-            float g1, b1, g2, b2, bq, bk, bv, bh;
-            if (TensorTable::dev_absmax(w.n1g, w.in_dim, &g1, s) || TensorTable::dev_absmax(w.n1b, w.in_dim, &b1, s) ||
-                TensorTable::dev_absmax(w.n2g, D, &g2, s) || TensorTable::dev_absmax(w.n2b, D, &b2, s)) return -2;
-            const float bx1 = sqrtf((float)w.in_dim) * g1 + b1, bx2 = sqrtf((float)D) * g2 + b2;
-            if (TensorTable::dev_linear_bound(w.qkv_w, D, w.in_pad, w.in_pad, w.qkv_b, bx1, &bq, s) ||
-                TensorTable::dev_linear_bound(w.qkv_w + (size_t)D * w.in_pad, D, w.in_pad, w.in_pad, w.qkv_b + D, bx1, &bk, s) ||
-                TensorTable::dev_linear_bound(w.qkv_w + (size_t)2 * D * w.in_pad, D, w.in_pad, w.in_pad, w.qkv_b + 2 * D, bx1, &bv, s) ||
-                TensorTable::dev_linear_bound(w.w1, F, D, D, w.b1, bx2, &bh, s)) return -2;
-            w.e_x1 = exp_for_bound(bx1); w.e_x2 = exp_for_bound(bx2);
-            w.e_q = exp_for_bound(bq * dk_scale); w.e_k = exp_for_bound(bk); w.e_v = exp_for_bound(bv); w.e_h = exp_for_bound(bh);
-        }
+        if ((rc = encoder_prepare_x2(e, s))) return rc;
     }
     if (e->precision == 1) {
         if (e->xn16.ensure(sizeof(unsigned short) * M * (Dpad > D ? Dpad : D)) || e->qkv16.ensure(sizeof(unsigned short) * M * 3 * D) ||
@@ -2693,6 +2845,27 @@ int pf_stream_set_pe(pf_stream* sh, const float* pe, int32_t rows) {
     return 0;
 }
 
+/* "gemm_mode": 0 = the step's GEMMs on the fp32 weight-streaming / fp32-MFMA kernels (default: the latency path of a few
+ * streams), 3 = on the fp16 matrix cores with two-plane operands (gemm_f16x2.hip: fp32-class results, the throughput path of
+ * many lock-step streams). Prepares the weight planes (synchronises), drops the captured graphs. */
+int pf_stream_set_option(pf_stream* sh, const char* key, int32_t value) {
+    Stream* st = reinterpret_cast<Stream*>(sh);
+    PF_REQUIRE(st && key, "stream_set_option: null");
+    const std::string k = key;
+    if (k != "gemm_mode") { set_error("stream_set_option: unknown key " + k); return -1; }
+    PF_REQUIRE(value == 0 || value == 3, "stream_set_option: gemm_mode is 0 (fp32 kernels) or 3 (f16x2)");
+    PF_HIP_TRY(hipStreamSynchronize(st->stream));
+    if (value == 3) {
+        int rc = stream_prepare_x2(st, st->stream);
+        if (rc) return rc;
+    }
+    st->x2 = value == 3;
+    for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+    st->graphs.clear();
+    st->seen.clear();
+    return 0;
+}
+
 int pf_stream_reset(pf_stream* sh, void* stream) {
     Stream* st = reinterpret_cast<Stream*>(sh);
     PF_REQUIRE(st, "stream_reset: null");
@@ -2721,6 +2894,14 @@ int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t 
         PF_HIP_TRY(hipMemcpyAsync(st->feats_in.p, feats, sizeof(float) * (size_t)S * n * Din, hipMemcpyDeviceToDevice, s));
     const int key = n | (is_final ? 1 << 10 : 0) | (tail_chunk ? 1 << 11 : 0);
     int rc;
+    if (st->x2 && !stream_x2_ready(st)) {
+        // a handle's weights changed since the planes / exponents were prepared (the old planes are freed): prepare again,
+        // drop the graphs that point at them
+        for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+        st->graphs.clear();
+        st->seen.clear();
+        if ((rc = stream_prepare_x2(st, s))) return rc;
+    }
     const bool graphable = st->use_graph && !g_prof_on;
     if (st->graph_epoch != g_ws_epoch) {
         // a workspace of the encoder / predictor / decoder handles moved since the capture (e.g. an offline batch grew

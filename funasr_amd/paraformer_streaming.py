@@ -121,11 +121,25 @@ class SANMEncoderChunkOpt(SANMEncoder):
 
 # ====================================================================================================== stream
 class StreamBatch:
-    """S independent streams advanced in lock-step over one (encoder, predictor, decoder) triple; all caches in HBM."""
+    """S independent streams advanced in lock-step over one (encoder, predictor, decoder) triple; all caches in HBM.
+
+    `precision`: "fp32" = the step's GEMMs on the fp32 kernels (weight-streaming GEMM for a handful of rows: the latency path
+    of one or a few streams); "f16x2" = on the fp16 matrix cores with two-plane operands and fp32 results (the offline
+    default's arithmetic: the throughput path of many lock-step streams, `pf_stream_set_option("gemm_mode", 3)`). None picks
+    "f16x2" from AUTO_F16X2_MIN_STREAMS streams on when that is set, else "fp32". The arithmetic is fixed per StreamBatch, so a
+    stream's result never depends on how many chunks its neighbours bring."""
+
+    AUTO_F16X2_MIN_STREAMS: Optional[int] = None
 
     def __init__(self, model: "ParaformerStreaming", n_streams: int = 1, chunk_size: Sequence[int] = (0, 10, 5),
                  encoder_chunk_look_back: int = 4, decoder_chunk_look_back: int = 1, max_frames: int = None,
-                 max_tokens: int = None, use_graph: bool = True, pe_rows: int = 8192):
+                 max_tokens: int = None, use_graph: bool = True, pe_rows: int = 8192, precision: Optional[str] = None):
+        if precision is None:
+            auto = self.AUTO_F16X2_MIN_STREAMS
+            precision = "f16x2" if (auto is not None and n_streams >= auto) else "fp32"
+        if precision not in ("fp32", "f16x2"):
+            raise ValueError(f"StreamBatch: precision must be 'fp32' or 'f16x2', got {precision!r}")
+        self.precision = precision
         self.model = model
         self.S, self.chunk_size = n_streams, list(chunk_size)
         # a step brings at most chunk_cur new frames plus the final flush of the look-ahead; CIF fires at most once per
@@ -137,12 +151,15 @@ class StreamBatch:
         _, hd = model.decoder._ensure_handle()
         self.dev = model.encoder._handle_device
         self.lib = lib
+        self._parts = ((model.encoder, he), (model.predictor, hp), (model.decoder, hd))
         cfg = _lib.pf_stream_config(n_streams, chunk_size[0], chunk_size[1], chunk_size[2], encoder_chunk_look_back,
                                     decoder_chunk_look_back, self.max_frames, self.max_tokens, int(use_graph))
         with torch.cuda.device(self.dev):
             self._h = _lib.check_handle(lib.pf_stream_create(he, hp, hd, C.byref(cfg)), "pf_stream_create")
             pe = sinusoidal_position_table(pe_rows, model.encoder._input_size).contiguous()
             _lib.check(lib.pf_stream_set_pe(self._h, pe.data_ptr(), pe_rows), "pf_stream_set_pe")
+            if precision == "f16x2":
+                _lib.check(lib.pf_stream_set_option(self._h, b"gemm_mode", 3), "pf_stream_set_option")
         self.pe_rows = pe_rows
         self.start_idx = 0
         self.keep = chunk_size[0] + chunk_size[2]
@@ -164,6 +181,10 @@ class StreamBatch:
         """feats [S, n, 560] (device) or None for a tail chunk -> (list of raw id lists per stream, enc [S, W, 512]?)"""
         n = 0 if tail_chunk else int(feats.shape[1])
         self._grow_pe(self.start_idx + n)
+        for m, h in self._parts:
+            if m._dirty:                       # weights changed on the live modules (load_state_dict, mark_dirty): push them
+                if m._ensure_handle()[1] != h:
+                    raise RuntimeError("StreamBatch: a module's handle was re-created (moved to another device?); build a new StreamBatch")
         ids = (C.c_int32 * (self.S * self.max_tokens))()
         cnt = (C.c_int32 * self.S)()
         W = self.keep + n

@@ -316,7 +316,7 @@ typedef struct pf_stream_config {
     int32_t enc_look_back;    /* encoder_chunk_look_back (chunks), 4 */
     int32_t dec_look_back;    /* decoder_chunk_look_back (chunks), 1 */
     int32_t max_frames;       /* most feature frames a step may bring (>= chunk_cur) */
-    int32_t max_tokens;       /* token rows decoded per stream per step (<= 24) */
+    int32_t max_tokens;       /* token rows decoded per stream per step (<= 96) */
     int32_t use_graph;        /* 1: capture + replay the step as a hipGraph */
 } pf_stream_config;
 
@@ -327,6 +327,12 @@ void pf_stream_destroy(pf_stream* s);
  * device pointer, [rows, input_dim]. Default: 4096 rows computed with libm. */
 int pf_stream_set_pe(pf_stream* s, const float* pe, int32_t rows);
 int pf_stream_reset(pf_stream* s, void* stream);
+/* "gemm_mode": 0 (default) = the step's GEMMs on the fp32 kernels (weight-streaming GEMM for a few rows: the latency path of
+ * one or a few streams); 3 = on the fp16 matrix cores with two-plane fp16 operands and fp32 results (the offline f16x2 mode's
+ * arithmetic, pf_encoder_set_precision 3: the throughput path of many lock-step streams). Attention, FSMN, CIF and the caches
+ * stay fp32 in both. The reference has one arithmetic (torch fp32, paraformer_streaming/model.py:552-763); both modes meet
+ * its parity bars. Synchronises, prepares the weight planes, drops captured graphs. */
+int pf_stream_set_option(pf_stream* s, const char* key, int32_t value);
 /* One chunk for every stream. feats_dev: [n_streams, n_frames, input_dim] un-scaled online features (ignored for a
  * tail chunk, which re-feeds the cached window, model.py:715-720). Outputs: ids_host int32 [n_streams, max_tokens]
  * (raw arg-max ids incl. sos/eos/blank), n_tokens_host int32 [n_streams]; optional enc_out_dev

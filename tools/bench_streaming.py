@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--streams", type=int, nargs="+", default=[1, 16, 64])
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", nargs="+", default=["fp32"], choices=["fp32", "f16x2"], help="GEMM arithmetic of the step "
+                    "(StreamBatch precision): fp32 kernels, or two-plane fp16 operands on the fp16 matrix cores (fp32-class results)")
+    ap.add_argument("--graph", nargs="+", type=int, default=[0, 1], help="0 eager, 1 hipGraph replay")
     args = ap.parse_args()
     from funasr_amd import synth
     from funasr_amd.paraformer_streaming import ParaformerStreaming, StreamBatch
@@ -31,30 +34,36 @@ def main():
     model = ParaformerStreaming.from_config(cfg)
     model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
     model = model.to(dev)
-    for S in args.streams:
-        for graph in (False, True):
-            sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=graph, pe_rows=16384)
-            g = torch.Generator().manual_seed(S)
-            feats = (torch.randn(S, 10, 560, generator=g) * 0.8).to(dev)
-            ntok = 0
-            for _ in range(args.warmup):
-                sb.step(feats)
-            torch.cuda.synchronize()
-            lat = []
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                t1 = time.perf_counter()
-                ids = sb.step(feats)
-                lat.append(time.perf_counter() - t1)
-                ntok += sum(len(r) for r in ids)
-            dt = time.perf_counter() - t0
-            lat.sort()
-            print(json.dumps({"metric": "streaming chunks/s (600 ms chunk, Paraformer-large-online)", "streams": S,
-                              "hipgraph": graph, "steps": args.steps, "chunks_per_s": round(S * args.steps / dt, 1),
-                              "audio_s_per_s": round(S * args.steps * 0.6 / dt, 1),
-                              "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3),
-                              "tokens_per_chunk": round(ntok / (S * args.steps), 2), "dtype": "f32"}), flush=True)
-            sb.close()
+    first_ids = {}
+    import itertools
+    for S, prec, graph in itertools.product(args.streams, args.precision, [bool(v) for v in args.graph]):
+        sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=graph, pe_rows=16384, precision=prec)
+        g = torch.Generator().manual_seed(S)
+        feats = (torch.randn(S, 10, 560, generator=g) * 0.8).to(dev)
+        ntok = 0
+        trace = []
+        for _ in range(args.warmup):
+            trace.append(sb.step(feats))
+        # the same session in every (precision, graph) setting: the warm-up steps' ids must agree (fp32-class arithmetic)
+        same = first_ids.setdefault(S, trace) == trace
+        torch.cuda.synchronize()
+        lat = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            ids = sb.step(feats)
+            lat.append(time.perf_counter() - t1)
+            ntok += sum(len(r) for r in ids)
+        dt = time.perf_counter() - t0
+        lat.sort()
+        print(json.dumps({"metric": "streaming chunks/s (600 ms chunk, Paraformer-large-online)", "streams": S,
+                          "hipgraph": graph, "steps": args.steps, "chunks_per_s": round(S * args.steps / dt, 1),
+                          "audio_s_per_s": round(S * args.steps * 0.6 / dt, 1),
+                          "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3),
+                          "tokens_per_chunk": round(ntok / (S * args.steps), 2),
+                          "dtype": "f32" if prec == "fp32" else "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMA products)",
+                          "precision": prec, "warmup_ids_equal_first_setting": same}), flush=True)
+        sb.close()
 
 
 if __name__ == "__main__":
