@@ -484,7 +484,9 @@ def run_streaming(device):
     model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
     model = model.to(device)
     rows = []
-    for S in (1, 64):
+    for S in (1, 64, 256):
+        # precision by the stream count (StreamBatch default): the fp32 weight-streaming step for a few streams, the f16x2 step
+        # (GEMMs on the fp16 matrix cores, fp32-class results) from StreamBatch.AUTO_F16X2_MIN_STREAMS streams on
         sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=True, pe_rows=16384)
         g = torch.Generator().manual_seed(S)
         feats = (torch.randn(S, 10, 560, generator=g) * 0.8).to(device)
@@ -499,10 +501,11 @@ def run_streaming(device):
             lat.append(time.perf_counter() - t1)
         dt = time.perf_counter() - t0
         lat.sort()
-        rows.append({"streams": S, "chunks_per_s": round(S * steps / dt, 1), "audio_s_per_s": round(S * steps * 0.6 / dt, 1),
+        rows.append({"streams": S, "precision": sb.precision, "chunks_per_s": round(S * steps / dt, 1), "audio_s_per_s": round(S * steps * 0.6 / dt, 1),
                      "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3)})
         sb.close()
-    return {"metric": "streaming step (600 ms chunk, Paraformer-large-online, hipGraph-captured), fp32", "configs": rows}
+    return {"metric": "streaming step (600 ms chunk, Paraformer-large-online, hipGraph-captured); fp32-class results in both "
+                      "precisions (fp32 kernels / f16x2 = two fp16 planes on the fp16 MFMA)", "configs": rows}
 
 
 def pmc_traffic(kernel: str):

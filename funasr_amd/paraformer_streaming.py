@@ -126,10 +126,12 @@ class StreamBatch:
     `precision`: "fp32" = the step's GEMMs on the fp32 kernels (weight-streaming GEMM for a handful of rows: the latency path
     of one or a few streams); "f16x2" = on the fp16 matrix cores with two-plane operands and fp32 results (the offline
     default's arithmetic: the throughput path of many lock-step streams, `pf_stream_set_option("gemm_mode", 3)`). None picks
-    "f16x2" from AUTO_F16X2_MIN_STREAMS streams on when that is set, else "fp32". The arithmetic is fixed per StreamBatch, so a
+    "f16x2" from AUTO_F16X2_MIN_STREAMS streams on, else "fp32": measured step times fp32 / f16x2 at chunk [0, 10, 5]
+    (profiles/r03v_bench_streaming.jsonl, r03w_*): S = 32 7.8 / 10.9 ms, 64 10.7 / 11.1, 96 15.6 / 11.6, 128 17.8 / 12.0,
+    192 25.9 / 13.8, 256 32.8 / 15.3 -- the two cross between 64 and 96 streams. The arithmetic is fixed per StreamBatch, so a
     stream's result never depends on how many chunks its neighbours bring."""
 
-    AUTO_F16X2_MIN_STREAMS: Optional[int] = None
+    AUTO_F16X2_MIN_STREAMS: Optional[int] = 80
 
     def __init__(self, model: "ParaformerStreaming", n_streams: int = 1, chunk_size: Sequence[int] = (0, 10, 5),
                  encoder_chunk_look_back: int = 4, decoder_chunk_look_back: int = 1, max_frames: int = None,

@@ -1,31 +1,29 @@
-"""The streaming step in its f16x2 form (StreamBatch(precision="f16x2"): every GEMM of the step on the fp16 matrix cores
-with two-plane operands, fp32 results; the throughput path of many lock-step streams) against the REFERENCE's
-ParaformerStreaming sessions and the default fp32 step. The cases live in tests/_stream_f16x2_cases.py and run one process
-each, so a GPU fault in one cannot take the suite with it."""
-import os
-import subprocess
-import sys
-
+"""The streaming step in its f16x2 form (StreamBatch(precision="f16x2"), pf_stream_set_option("gemm_mode", 3): every GEMM of
+the step on the fp16 matrix cores with two-plane operands, fp32 results; the throughput path of many lock-step streams)
+against the REFERENCE's ParaformerStreaming sessions, the reference-pinned streaming oracle and the default fp32 step.
+The cases live in tests/_stream_f16x2_cases.py (also runnable one process each: `python tests/_stream_f16x2_cases.py <case>`,
+how they first met the hardware, tools/gpu_shot_r03v.sh)."""
 import pytest
 
+from tests._stream_f16x2_cases import CASES, build, load
+
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-# Round 3 ran out of GPU minutes before these cases saw hardware: until their first run on an MI355X a failure is
-# recorded as xfail instead of stopping the suite; a pass shows up as XPASS. Remove the mark with the first green run.
-first_hardware_run_pending = pytest.mark.xfail(reason="staged without GPU minutes in round 3: first run on hardware pending", strict=False)
 
 
-def _case(name, timeout=300):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_stream_f16x2_cases.py"), name], cwd=ROOT,
-                       capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, (r.stdout[-1500:] + "\n" + r.stderr[-3000:])
-    return r.stdout
-
-
-@first_hardware_run_pending
-@pytest.mark.timeout(400)
-@pytest.mark.parametrize("name", ["golden_eager", "golden_graph", "geometries", "batch_independence_and_graph",
-                                  "many_streams_vs_fp32_step", "weight_reload", "oracle_geometry_many_tokens"])
+@pytest.mark.parametrize("name", sorted(CASES))
 def test_streaming_f16x2_case(cuda, name):
-    _case(name)
+    CASES[name](cuda)
+
+
+def test_default_precision_follows_the_stream_count(cuda):
+    """precision=None: the fp32 step for a few streams (latency), the f16x2 step from AUTO_F16X2_MIN_STREAMS on (throughput)"""
+    from funasr_amd.paraformer_streaming import StreamBatch
+    g, cfg, sd = load()
+    model = build(cfg, sd, cuda)
+    few = StreamBatch(model, 2, [0, 10, 5], 4, 1)
+    many = StreamBatch(model, StreamBatch.AUTO_F16X2_MIN_STREAMS, [0, 10, 5], 4, 1)
+    assert few.precision == "fp32" and many.precision == "f16x2"
+    with pytest.raises(ValueError):
+        StreamBatch(model, 1, [0, 10, 5], 4, 1, precision="bf16")
+    few.close()
+    many.close()
