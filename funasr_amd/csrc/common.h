@@ -252,6 +252,13 @@ struct Gemm2Args {
     // fused row arg-max (vocabulary projections): when amax_val != nullptr nothing is written to C / C2 but one partial
     // (max, lowest index of the max) per (row, wave column range): entry 2 * column_block + wave_column of row `row`
     float* amax_val; int* amax_idx; int amax_ld;
+    // split-K form (ksplit > 1; fp32 output only, K % (32 ksplit) == 0): the K range is cut into ksplit slices computed by
+    // ksplit times as many 128 x 128 blocks (grid.y = slice) into `part` [ksplit][M][N] (fp32, scaled by oscale), then ONE
+    // reduce launch sums the slices in slice order and applies bias / relu / R1 / R2 -> C. For GEMMs of at most a block per CU
+    // with a long K (the streaming step's w_2: M = 15 S rows, K = 2048), whose lone blocks run at a fraction of the matrix rate.
+    // Deterministic, but NOT the bits of the unsplit kernel (another summation order): a caller takes it always or never.
+    int ksplit; float* part;
+    int kslices;                                        // set by the launcher: what the kernel sees (slice = blockIdx.y)
 };
 // number of arg-max partials per row launch_gemm_f16x2 writes for an N-column problem
 int gemm_f16x2_argmax_parts(int M, int N);

@@ -452,6 +452,7 @@ struct Encoder {
     // mode 3 (f16x2): xn16 / ctx16 / ffn16 hold two fp16 planes each; q2 / k2 / vt2 are the attention operands the QKV
     // projection writes (k2 with 32 rows of slack per plane, vt2 rows of Mp + 64 columns: tiles may run past the last row)
     DevBuf q2, k2, vt2;
+    DevBuf splitk;                      // streaming f16x2 step: the split-K partials of w_2 [4][rows][d_model] (gemm_f16x2.hip)
     int Tp = 0;                         // rows per sequence of the current forward (T, or T rounded up to 16 in mode 3)
     // mode 3, packed row layout (pf_encoder_set_row_packing): sequence b occupies the slot [offs[b], offs[b + 1]) =
     // min(len_b + pack_extra, T) rows rounded up to 16, one slot right after the other; the rows behind are not computed
@@ -796,6 +797,9 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
         g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
         g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = N; g.c_plane = (size_t)M * N; g.cscale = pow2f(ec);
         g.M = M; g.N = N; g.K = K; g.relu = relu;
+        // the long-K projection (w_2) of a step is at most a block per CU: always in its split-K form here (by caller, whatever
+        // the stream count, so a stream's result does not depend on its neighbours)
+        if (C && K >= 4 * D && K % 128 == 0 && e->splitk.p) { g.ksplit = 4; g.part = e->splitk.as<float>(); }
         ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
         return launch_gemm_f16x2(g, s);
     };
@@ -908,6 +912,7 @@ struct Decoder {
     DevBuf dsc;              // f16x2 mode: [amax(memory), 2^e, 2^-e] chosen on the device per forward
     DevBuf dscl, dlb;        // per layer {k_mul, v_mul, 1/k_mul, 1/v_mul} (device-chosen) and the constants they come from
     DevBuf k2, vt2;          // cross-attention operands written by the KV form of linear_k_v (attention_f16x2.hip)
+    DevBuf splitk;           // streaming f16x2 step: split-K partials of the FFN's w_2
     bool lb_uploaded = false;
     int e_an = INT32_MIN;    // exponent of the after_norm output planes (f16x2 vocabulary projection)
     DevBuf asf_p;            // SeACo score filter: attention probabilities of sequence 0 [H, N, T]
@@ -998,12 +1003,13 @@ static int gemm3_simple(const unsigned short* A3, int lda, int M, const unsigned
 
 static int gemm2_simple(const unsigned short* A2, int lda, int M, int ea, const unsigned short* W2, int ew, const float* bias,
                         float* C, int ldc, int N, int K, int relu, const float* R2, int ldr2, hipStream_t s,
-                        const float* oscale_dev = nullptr) {
+                        const float* oscale_dev = nullptr, float* splitk_part = nullptr) {
     if (!W2) return -2;
     Gemm2Args g{};
     g.A = A2; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W2; g.ldw = K; g.w_plane = (size_t)N * K;
     g.oscale = pow2f(-(ea + ew)); g.oscale_dev = oscale_dev; g.bias = bias; g.R2 = R2; g.ldr2 = ldr2;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = relu;
+    if (splitk_part && K % 128 == 0) { g.ksplit = 4; g.part = splitk_part; }     // streaming step: w_2 in its split-K form
     ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
     return launch_gemm_f16x2(g, s);
 }
@@ -1040,7 +1046,7 @@ static int dec_layer_x2(Decoder* d, DecLayerW& w, const std::string& p, bool att
 }
 
 // f16x2 form of dec_ffn: both LayerNorms write two-plane fp16 operands, w_1 and w_2 run on the fp16 matrix cores
-static int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s) {
+static int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part = nullptr) {
     const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
     float* ffn = d->ffn.as<float>();
     unsigned short* t2p = d->t16.as<unsigned short>();
@@ -1057,7 +1063,7 @@ static int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out
         if ((rc = launch_layernorm(ffn, F, w.fng, w.fnb, reinterpret_cast<float*>(f2p), F, M, F, F, d->cfg.ln_eps, s, 3, 0,
                                    (size_t)M * F, pow2f(w.e_fn)))) return rc;
     }
-    return gemm2_simple(f2p, F, M, w.e_fn, w.w2_2, w.ew_2, nullptr, out, D, D, F, 0, nullptr, 0, s);
+    return gemm2_simple(f2p, F, M, w.e_fn, w.w2_2, w.ew_2, nullptr, out, D, D, F, 0, nullptr, 0, s, nullptr, splitk_part);
 }
 
 // w1_3 != nullptr (bf16x3 mode): norm1 writes the three planes and w_1 runs on the bf16 matrix cores
@@ -1281,7 +1287,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             return -2;
         if (st->x2 && (e->xn16.ensure(sizeof(unsigned short) * 2 * Mz * (Dpad > D ? Dpad : D)) ||
                        e->ctx16.ensure(sizeof(unsigned short) * 2 * Mz * D) || e->ffn16.ensure(sizeof(unsigned short) * 2 * Mz * F) ||
-                       st->mem2.ensure(sizeof(unsigned short) * 2 * Mz * D)))
+                       st->mem2.ensure(sizeof(unsigned short) * 2 * Mz * D) || e->splitk.ensure(sizeof(float) * 4 * Mz * D)))
             return -2;
     }
     if ((rc = launch_fill_int(st->lensW.as<int>(), S, W, s))) return rc;
@@ -1351,6 +1357,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         if (d->t16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D) || d->ffn16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * dc.ffn_dim) ||
             d->ctx16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D))
             return -2;
+        if (d->splitk.ensure(sizeof(float) * 4 * (size_t)Mq * D)) return -2;
         t2p = d->t16.as<unsigned short>(); c2p = d->ctx16.as<unsigned short>();
         if ((rc = launch_split2(enc_out, D, st->mem2.as<unsigned short>(), D, (size_t)Mk * D, Mk, D, pow2f(st->e_mem), s))) return rc;
         mem2 = st->mem2.as<unsigned short>();
@@ -1360,7 +1367,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     const size_t dfsmn_layer = (size_t)S * (dc.kernel_size - 1) * D;
     for (int l = 0; l < dc.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
-        if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
+        if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
         if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
         DecFsmnChunkArgs fa{};
         fa.in = t1; fa.resid = dx; fa.out = dx; fa.w = w.fsmn_w; fa.state = st->dec_fsmn.as<float>() + l * dfsmn_layer;
@@ -1416,7 +1423,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         ad.S = S; ad.dec_rows = W; ad.dec_cap = st->dec_cap;
         if ((rc = launch_stream_advance_dec(ad, s))) return rc;
     }
-    if ((rc = x2 ? dec_ffn_x2(d, d->last, dx, t2, Mq, s) : dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
+    if ((rc = x2 ? dec_ffn_x2(d, d->last, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
     if (x2) {
         // after_norm writes two-plane operands, the vocabulary projection runs with the row arg-max fused into its epilogue
         // (the offline greedy route of decoder_forward_impl)
@@ -3093,6 +3100,12 @@ int pf_k_gemm_f16x2(const void* A2, int32_t lda, int64_t a_plane, const void* W2
     if (tile & 0x1000) { g.a_kstep = (long)M * 32; g.w_kstep = (long)N * 32; }
     if (tile & 0x2000) { g.w_kstep = (long)N * 32; g.ldw = 32; g.lda = K; }
     if (tile & 0x4000) { g.a_kstep = (long)M * 32; g.lda = 32; g.ldw = K; }
+    // 0x8000: the split-K form (four slices + one reduce launch; fp32 output) with a scratch partial buffer owned by this hook
+    static DevBuf splitk_scratch;
+    if (tile & 0x8000) {
+        if (splitk_scratch.ensure(sizeof(float) * 4 * (size_t)M * N)) return -2;
+        g.ksplit = 4; g.part = splitk_scratch.as<float>();
+    }
     int rc;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2(g, s);
     for (int i = 0; i < 3; ++i) if ((rc = launch_gemm_f16x2(g, s))) return rc;

@@ -66,6 +66,16 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
     if (mblk >= nM) return;
     const int m0 = mblk * BM, n0 = nblk * BN;
+    if constexpr (OUT == 0 && MODE == 0) {
+        // split-K form: slice blockIdx.y multiplies columns [y K, (y + 1) K) of both operands (p.K is the slice length, the row
+        // strides are the full ones) into its own [M, N] partial
+        if (p.kslices > 1) {
+            const size_t z = blockIdx.y;
+            p.A += z * (size_t)p.K;
+            p.W += z * (size_t)p.K;
+            p.C += z * (size_t)p.M * (size_t)p.ldc;
+        }
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -508,6 +518,38 @@ __global__ __launch_bounds__(256) void rowl1_bound_kernel(const float* __restric
     if (lane == 0) atomicMax(out, __builtin_bit_cast(unsigned, bnd));
 }
 
+// split-K form, second launch: C = epilogue(sum over slices of part[z]) with the tile kernel's epilogue order (bias, relu, + R1,
+// R2 +); slices are added in slice order by one thread per float4 (deterministic). R1 / R2 may alias C.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int slices, size_t slice_stride, int M, int N,
+                                                            const float* __restrict__ bias, int relu, const float* R1, int ldr1,
+                                                            const float* R2, int ldr2, float* C, int ldc) {
+    const int n4 = N >> 2;
+    const size_t total = (size_t)M * n4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / n4), col = (int)(i % n4) * 4;
+        const float* src = part + (size_t)row * N + col;
+        float4 v = *reinterpret_cast<const float4*>(src);
+        for (int z = 1; z < slices; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * slice_stride);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (R1) {
+            const float4 r = *reinterpret_cast<const float4*>(R1 + (size_t)row * ldr1 + col);
+            v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w;
+        }
+        if (R2) {
+            const float4 r = *reinterpret_cast<const float4*>(R2 + (size_t)row * ldr2 + col);
+            v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
+        }
+        *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+    }
+}
+
 template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, int KS_ = 32>
 int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     typedef Geo2<WM, WN, WGM, KS_> G;
@@ -519,7 +561,8 @@ int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     }
     const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
     const int nMpad = (nM + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, KS_>), dim3((unsigned)nMpad * nN), dim3(WGM * 128), G::LDS_B, stream, a, nM, nN);
+    const unsigned gy = (OUT == 0 && MODE == 0 && a.kslices > 1) ? (unsigned)a.kslices : 1u;
+    hipLaunchKernelGGL((gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, KS_>), dim3((unsigned)nMpad * nN, gy), dim3(WGM * 128), G::LDS_B, stream, a, nM, nN);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -533,6 +576,9 @@ template <int MODE, int OUT>
 int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
     // and does not anyway: both shapes issue the same products in the same k order)
+    if constexpr (OUT == 1) {
+        if (a.tile == 3) return launch_tile<2, 2, MODE, 1, 0, 0, 2>(a, stream);   // 128 x 128, 4 waves (plane output)
+    }
     if constexpr (OUT == 0) {              // measurement hooks (tools/abl_gemm2.py)
         if (a.tile == 3) return launch_tile<2, 2, MODE, 0, 0, 0, 2>(a, stream);   // 128 x 128, 4 waves, two workgroups per CU
         if (a.tile >= 256) return (a.tile >> 8) == 1 ? launch_tile<2, 4, MODE, 0, 0, 1>(a, stream) : launch_tile<2, 4, MODE, 0, 0, 2>(a, stream);
@@ -569,6 +615,11 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
         const long small_blocks = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
         const double cost_small = 0.55 * (double)((small_blocks + 2 * n_cu - 1) / (2 * n_cu));
         if (a.tile == 0 && cost_small < (wide ? cost_wide : cost_narrow)) return launch_tile<2, 2, MODE, 0, 0, 0, 2>(a, stream);
+    }
+    if constexpr (OUT == 1) {
+        // plane output (w_1): the 128 x 128 shape only where the 256-row shapes leave most of the chip idle (the streaming step, short
+        // batches: M = 960 17 vs 27 us, 1920 21 vs 31, 3840 33 vs 34 -- profiles/r03y_small_ring_microbench.jsonl, fp32-output form)
+        if (a.tile == 0 && 2 * narrow_blocks <= n_cu) return launch_tile<2, 2, MODE, 1, 0, 0, 2>(a, stream);
     }
     // SCHED 2 on the 256 x 256 shape (both k-steps' fragments requested up front, DMA pieces early): 0-10 % faster there
     return wide ? launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
@@ -638,6 +689,27 @@ int gemm_f16x2_argmax_parts(int M, int N) { (void)M; return 2 * ceil_div(N, 256)
 
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
     PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f16x2: empty problem");
+    if (a.ksplit > 1) {
+        PF_REQUIRE(a.C && a.part && !a.C2 && !a.amax_val && a.qkv_D <= 0 && a.a_kstep <= 0 && a.w_kstep <= 0 &&
+                   a.K % (32 * a.ksplit) == 0 && a.N % 4 == 0 && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0 && ((uintptr_t)a.part & 15) == 0,
+                   "gemm_f16x2: the split-K form takes fp32 output, K % (32 ksplit) == 0, a partial buffer [ksplit][M][N]");
+        PF_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_plane % 8 == 0 && a.w_plane % 8 == 0 && ((uintptr_t)a.A & 15) == 0 &&
+                   ((uintptr_t)a.W & 15) == 0 && (a.K / a.ksplit) % 8 == 0, "gemm_f16x2: operand alignment");
+        if (a.bias) PF_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm_f16x2: bias alignment");
+        if (a.R1) PF_REQUIRE(a.ldr1 % 4 == 0 && ((uintptr_t)a.R1 & 15) == 0, "gemm_f16x2: R1 alignment");
+        if (a.R2) PF_REQUIRE(a.ldr2 % 4 == 0 && ((uintptr_t)a.R2 & 15) == 0, "gemm_f16x2: R2 alignment");
+        Gemm2Args p = a;
+        p.ksplit = 0; p.kslices = a.ksplit; p.K = a.K / a.ksplit;
+        p.C = a.part; p.ldc = a.N; p.bias = nullptr; p.relu = 0; p.R1 = nullptr; p.R2 = nullptr; p.tile = 0;
+        int rc = launch_tile<2, 2, 0, 0, 0, 0, 2>(p, stream);            // 128 x 128 blocks, two workgroups per CU
+        if (rc) return rc;
+        const size_t total = (size_t)a.M * (a.N >> 2);
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N,
+                           a.bias, a.relu, a.R1, a.ldr1, a.R2, a.ldr2, a.C, a.ldc);
+        PF_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (a.amax_val) {
         PF_REQUIRE(a.amax_idx && a.amax_ld >= gemm_f16x2_argmax_parts(a.M, a.N) && !a.R1 && !a.R2 && !a.relu && a.qkv_D <= 0,
                    "gemm_f16x2: the arg-max form takes bias only and needs amax_ld >= 2 ceil(N / 256)");

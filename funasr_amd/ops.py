@@ -276,12 +276,17 @@ def kblocked(p2: torch.Tensor) -> torch.Tensor:
 
 
 def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=None, add2=None, scale_exp: int = 0,
-               out_planes=False, out_scale_exp: int = 0, tile: int = 0, time_iters: int = 0, kblock=False):
+               out_planes=False, out_scale_exp: int = 0, tile: int = 0, time_iters: int = 0, kblock=False, split_k: bool = False,
+               out: torch.Tensor = None):
     """a2 [2, M, K], w2 [2, N, K] fp16 planes (ops.split2; scale_exp = the SUM of their scale exponents) -> fp32 [M, N]
     (or the planes [2, M, N] of the result * 2**out_scale_exp); fp32-class accuracy from three fp16 MFMA products per
-    operand pair. With time_iters > 0 returns (out, ms per launch)."""
+    operand pair. With time_iters > 0 returns (out, ms per launch). split_k: the four-slice split-K form (fp32 output; the
+    streaming step's long-K projections) -- deterministic, fp32-class, not the bits of the unsplit kernel."""
     lib = _lib.load()
     assert a2.dtype == torch.float16 and w2.dtype == torch.float16 and a2.is_contiguous() and w2.is_contiguous()
+    if split_k:
+        assert not out_planes and not kblock
+        tile |= 0x8000
     if kblock == "w":                            # only W made by kblocked()
         _, M, K = a2.shape
         N, ld = w2.shape[2], K
@@ -304,7 +309,9 @@ def gemm_f16x2(a2: torch.Tensor, w2: torch.Tensor, bias=None, relu=False, add1=N
         out = torch.empty(2, M, N, device=a2.device, dtype=torch.float16)
         c, ldc, c2, ldc2, cpl = None, 0, out, N, M * N
     else:
-        out = torch.empty(M, N, device=a2.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(M, N, device=a2.device, dtype=torch.float32)
+        assert out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.is_contiguous()     # may alias add1 / add2
         c, ldc, c2, ldc2, cpl = out, N, None, 0, 0
     _lib.check(lib.pf_k_gemm_f16x2(_ptr(a2), ld, M * K, _ptr(w2), ld, N * K, float(2.0 ** -scale_exp), _ptr(bias),
                                    _ptr(add1), add1.stride(0) if add1 is not None else 0,

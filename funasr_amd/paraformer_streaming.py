@@ -127,11 +127,11 @@ class StreamBatch:
     of one or a few streams); "f16x2" = on the fp16 matrix cores with two-plane operands and fp32 results (the offline
     default's arithmetic: the throughput path of many lock-step streams, `pf_stream_set_option("gemm_mode", 3)`). None picks
     "f16x2" from AUTO_F16X2_MIN_STREAMS streams on, else "fp32": measured step times fp32 / f16x2 at chunk [0, 10, 5]
-    (profiles/r03v_bench_streaming.jsonl, r03w_*): S = 32 7.8 / 10.9 ms, 64 10.7 / 11.1, 96 15.6 / 11.6, 128 17.8 / 12.0,
-    192 25.9 / 13.8, 256 32.8 / 15.3 -- the two cross between 64 and 96 streams. The arithmetic is fixed per StreamBatch, so a
+    (profiles/r03w_bench_streaming.jsonl / r03s_bench_streaming_splitk.jsonl): S = 8 6.6 / 8.1 ms, 32 7.8 / 8.2, 64 10.7 / 8.5,
+    128 17.8 / 9.7, 256 32.8 / 13.8 -- the two cross between 32 and 64 streams. The arithmetic is fixed per StreamBatch, so a
     stream's result never depends on how many chunks its neighbours bring."""
 
-    AUTO_F16X2_MIN_STREAMS: Optional[int] = 80
+    AUTO_F16X2_MIN_STREAMS: Optional[int] = 48
 
     def __init__(self, model: "ParaformerStreaming", n_streams: int = 1, chunk_size: Sequence[int] = (0, 10, 5),
                  encoder_chunk_look_back: int = 4, decoder_chunk_look_back: int = 1, max_frames: int = None,

@@ -86,6 +86,27 @@ def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
             assert torch.equal(ring, narrow), f"256x256 deep-ring shape differs {sorted(kw)}"
 
 
+@pytest.mark.parametrize("M", [15, 960, 3840])
+def test_gemm_f16x2_split_k_form(cuda, M):
+    """the streaming step's w_2 (K = 2048 over at most a block per CU): four K slices + one reduce launch -- fp32-class against
+    float64 like the unsplit kernel, deterministic, every epilogue form"""
+    from funasr_amd import ops
+    N, K = 512, 2048
+    a2, w2, se, g = _operands(M, N, K, cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    r1 = torch.randn(M, N, generator=g).to(cuda)
+    r2 = torch.randn(M, N, generator=g).to(cuda)
+    for kw in (dict(), dict(relu=True), dict(add2=r2), dict(relu=True, add1=r1, add2=r2)):
+        ref, mag = _gemm_ref(a2, w2, se, bias, kw.get("relu", False), kw.get("add1"), kw.get("add2"))
+        out = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, split_k=True, **kw)
+        _check(out, ref, mag, what=f"split-K {sorted(kw)}")
+        assert torch.equal(out, ops.gemm_f16x2(a2, w2, bias, scale_exp=se, split_k=True, **kw)), "split-K form is not deterministic"
+    # in place on the residual (C aliases R2), as the step uses it
+    x = r2.clone()
+    ops.gemm_f16x2(a2, w2, bias, scale_exp=se, split_k=True, add2=x, out=x)
+    assert torch.equal(x, ops.gemm_f16x2(a2, w2, bias, scale_exp=se, split_k=True, add2=r2))
+
+
 @pytest.mark.parametrize("M", [70, 4000, 32768])
 def test_gemm_f16x2_plane_output(cuda, M):
     """w_1's form: relu, result written as two fp16 planes of result * 2^e (the next GEMM's operand)"""
@@ -99,6 +120,9 @@ def test_gemm_f16x2_plane_output(cuda, M):
     p_w = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=2)
     p_p = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=5)
     assert torch.equal(p_n, p_w) and torch.equal(p_p, p_w)
+    # 128 x 128 four-wave shape (tile 0's pick where the 256-row shapes would leave most CUs idle, e.g. M = 70) and tile 0 itself
+    assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=3), p_w)
+    assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=0), p_w)
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=6), p_w)
     assert torch.isfinite(p_w.float()).all()
     val = _planes_value(p_w) * 2.0 ** -eo
