@@ -87,7 +87,10 @@ class CifPredictorV3(CifPredictorV2):
         super().__init__(idim, l_order, r_order, threshold=threshold, dropout=dropout, smooth_factor=smooth_factor,
                          noise_threshold=noise_threshold, tail_threshold=tail_threshold, tail_mask=True)
         if upsample_type not in ("cnn", "cnn_blstm"):
-            raise NotImplementedError(f"CifPredictorV3(HIP): upsample_type {upsample_type!r} is not built (cnn, cnn_blstm)")
+            # `cnn_attn` cannot run in the reference either: it hands the T-frame mask to an attention over the upsampled frames
+            # (bicif_paraformer/cif_predictor.py:251,327 -> size mismatch; tests/test_reference_unreachable_options.py)
+            raise NotImplementedError(f"CifPredictorV3(HIP): upsample_type {upsample_type!r} is not built (cnn, cnn_blstm; the "
+                                      "reference's cnn_attn fails on its own mask)")
         self.upsample_times, self.upsample_type, self.use_cif1_cnn = int(upsample_times), upsample_type, bool(use_cif1_cnn)
         self.smooth_factor2, self.noise_threshold2 = smooth_factor2, noise_threshold2
         self.upsample_cnn = ParamHolder((idim, idim, self.upsample_times), (idim,))

@@ -93,7 +93,10 @@ class ContextualParaformer(Paraformer):
         self.bias_encoder_type = kwargs.get("bias_encoder_type", "lstm")
         self.use_decoder_embedding = kwargs.get("use_decoder_embedding", False)
         if self.bias_encoder_type != "lstm":
-            raise NotImplementedError("ContextualParaformer(HIP): the published LSTM bias encoder is built ('mean' is not)")
+            # the reference's `mean` branch builds no bias_encoder, yet cal_decoder_with_predictor calls it unconditionally
+            # (contextual_paraformer/model.py:81-82,357,371): that option cannot decode there either (tests/test_reference_unreachable_options.py)
+            raise NotImplementedError("ContextualParaformer(HIP): bias_encoder_type must be 'lstm' (the published models); the "
+                                      "reference's 'mean' option has no inference path either (its decoder call needs bias_encoder)")
         if inner_dim != self.encoder.output_size():
             raise NotImplementedError("ContextualParaformer(HIP): inner_dim must equal the decoder width (the hotword "
                                       "embeddings are the bias decoder's keys and values)")
