@@ -164,7 +164,9 @@ def main_geometries():
     model, frontend, cfg, enc_conf = build()
     _, wav, n1 = clip()
     arrs, sessions = {}, []
-    for si, (chunk, enc_lb, dec_lb) in enumerate((([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1))):
+    # the last two bring more than 24 possible fires per step (the streaming decoder's former row cap)
+    for si, (chunk, enc_lb, dec_lb) in enumerate((([5, 10, 5], 2, 2), ([0, 8, 4], 1, 0), ([0, 10, 5], 0, 1),
+                                                  ([0, 20, 10], 2, 1), ([0, 16, 8], 1, 1))):
         frontend.cache_reset() if hasattr(frontend, "cache_reset") else None
         records = run(model, frontend, enc_conf, wav, n1, chunk, enc_lb, dec_lb)
         sessions.append(dict(chunk=chunk, enc_lb=enc_lb, dec_lb=dec_lb, n_chunks=len(records)))

@@ -93,7 +93,7 @@ def test_streaming_oracle_matches_reference_in_other_chunk_geometries():
     g, cfg, sd, wav, cmvn = load()
     gg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "streaming_geometries.npz"), allow_pickle=False)
     sessions = json.loads(str(gg["sessions"]))
-    assert [s["chunk"] for s in sessions] == [[5, 10, 5], [0, 8, 4], [0, 10, 5]]
+    assert [s["chunk"] for s in sessions] == [[5, 10, 5], [0, 8, 4], [0, 10, 5], [0, 20, 10], [0, 16, 8]]
     for si, s in enumerate(sessions):
         st = S.model_init(cfg, tuple(s["chunk"]), s["enc_lb"], s["dec_lb"])
         for i in range(s["n_chunks"]):
