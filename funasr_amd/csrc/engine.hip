@@ -1298,7 +1298,10 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     ea.keep = st->keep; ea.Din = Din; ea.pe_rows = st->pe_rows; ea.tail = tail; ea.scale = (float)sqrt((double)D);
     if ((rc = launch_stream_embed(ea, s))) return rc;
     // ---- encoder blocks on the window
-    const int append_rows = W - st->cfg.chunk_right > 0 ? W - st->cfg.chunk_right : 0;
+    // rows [0, W - chunk_right) of the window's K / V go to the ring. The reference takes them as k_h[:, :, :-(chunk_size[2])]
+    // (sanm/attention.py:345-346): with chunk_size[2] == 0 that slice is [:-0] = EMPTY, so such a geometry never caches
+    // anything and its look-back has no effect -- reproduced (oracle/fuzz_streaming_vs_reference.py found the difference)
+    const int append_rows = (st->cfg.chunk_right > 0 && W - st->cfg.chunk_right > 0) ? W - st->cfg.chunk_right : 0;
     float* x = e->x.as<float>();
     const size_t ring_layer = (size_t)S * st->enc_cap * 2 * D;
     for (size_t l = 0; l < e->layers.size(); ++l) {
@@ -2776,6 +2779,13 @@ pf_stream* pf_stream_create(pf_encoder* eh, pf_predictor* ph, pf_decoder* dh, co
     if (c.max_tokens < c.chunk_right + c.max_frames + 2 || c.max_frames >= 1024) {
         set_error("stream: max_tokens (" + std::to_string(c.max_tokens) + "; the decoder's token rows per step are capped at 96) must cover chunk_right + max_frames + 2 = " +
                   std::to_string(c.chunk_right + c.max_frames + 2) + " possible fires per step; max_frames must stay below 1024");
+        return nullptr;
+    }
+    if (c.chunk_left + c.chunk_right == 0) {
+        // the reference keeps x[:, -(chunk_size[0] + chunk_size[2]):] as the overlap window (scama/encoder.py:480-494): with both 0
+        // that is x[:, -0:] = the WHOLE window, so its window grows by every chunk and the CIF mask keeps decoding the first
+        // chunk_size[1] frames -- a degenerate session this handle does not reproduce; refuse instead of differing silently
+        set_error("stream: chunk_size[0] + chunk_size[2] == 0 is not supported (the reference's overlap window x[:, -0:] is the whole history in that geometry)");
         return nullptr;
     }
     int rc;

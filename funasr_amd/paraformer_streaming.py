@@ -136,6 +136,12 @@ class StreamBatch:
     def __init__(self, model: "ParaformerStreaming", n_streams: int = 1, chunk_size: Sequence[int] = (0, 10, 5),
                  encoder_chunk_look_back: int = 4, decoder_chunk_look_back: int = 1, max_frames: int = None,
                  max_tokens: int = None, use_graph: bool = True, pe_rows: int = 8192, precision: Optional[str] = None):
+        if len(chunk_size) != 3 or chunk_size[0] + chunk_size[2] == 0:
+            # scama/encoder.py:480-494 keeps xs_pad[:, -(chunk_size[0] + chunk_size[2]):] as the overlap window: with both 0 that
+            # slice is [-0:] = the whole window, i.e. the reference's window grows by every chunk and its CIF mask keeps decoding
+            # the first chunk_size[1] frames (tests/test_oracle_streaming.py pins that on the reference's own session)
+            raise ValueError("StreamBatch: chunk_size[0] + chunk_size[2] must be > 0 (the reference's overlap window is the whole "
+                             "history when both are 0: a degenerate session that is not reproduced)")
         if precision is None:
             auto = self.AUTO_F16X2_MIN_STREAMS
             precision = "f16x2" if (auto is not None and n_streams >= auto) else "fp32"

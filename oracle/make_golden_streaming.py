@@ -179,5 +179,29 @@ def main_geometries():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB)")
 
 
+def main_right0():
+    """chunk_size[2] == 0 with an encoder look-back: the reference's `[: -chunk_size[2]]` slice is empty there, i.e. nothing is
+    ever cached (sanm/attention.py:345-346) -> tests/golden/streaming_right0.npz (features, encoder window, tokens, flags)"""
+    model, frontend, cfg, enc_conf = build()
+    _, wav, n1 = clip()
+    arrs, sessions = {}, []
+    for si, (chunk, enc_lb, dec_lb) in enumerate((([5, 11, 0], 3, 0), ([0, 12, 0], 2, 1))):
+        records = run(model, frontend, enc_conf, wav, n1, chunk, enc_lb, dec_lb)
+        sessions.append(dict(chunk=chunk, enc_lb=enc_lb, dec_lb=dec_lb, n_chunks=len(records)))
+        for i, r in enumerate(records):
+            arrs[f"s{si}_feats_{i}"] = r["feats"].astype(np.float32)
+            arrs[f"s{si}_enc_{i}"] = r["enc"].astype(np.float32)
+            arrs[f"s{si}_tokens_{i}"] = np.asarray(r["tokens"], dtype=np.int64)
+            arrs[f"s{si}_flags_{i}"] = np.asarray([r["is_final"], r["tail"], r["start_idx"]], dtype=np.int64)
+    path = os.path.join(GOLD, "streaming_right0.npz")
+    np.savez_compressed(path, sessions=json.dumps(sessions), **arrs)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
 if __name__ == "__main__":
-    main_geometries() if "--geometries" in sys.argv else main()
+    if "--geometries" in sys.argv:
+        main_geometries()
+    elif "--right0" in sys.argv:
+        main_right0()
+    else:
+        main()

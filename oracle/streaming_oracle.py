@@ -133,7 +133,9 @@ def encoder_chunk(xs: Tensor, st: dict, sd: SD, cfg: dict, prefix: str = "encode
         q, k, v = torch.split(qkv, D, dim=-1)
         k_all, v_all = k, v
         if st["enc_look_back"] > 0 or st["enc_look_back"] == -1:
-            keep = k.shape[1] - cs[2]
+            # the reference slices k_h[:, :, :-(chunk_size[2])] (sanm/attention.py:345-346,356-357): with chunk_size[2] == 0 that
+            # is [:-0] = [:0], an EMPTY stride -- nothing is ever cached and a look-back setting has no effect
+            keep = k.shape[1] - cs[2] if cs[2] > 0 else 0
             k_stride, v_stride = k[:, :max(keep, 0)], v[:, :max(keep, 0)]
             if st["enc_kv"][li] is not None:
                 ck, cv = st["enc_kv"][li]

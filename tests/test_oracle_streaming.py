@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from funasr_amd import synth
@@ -107,3 +108,37 @@ def test_streaming_oracle_matches_reference_in_other_chunk_geometries():
                 ids = S.generate_chunk(feats, st, sd, cfg, bool(fin))
             assert ids == gg[f"s{si}_tokens_{i}"].tolist(), (s, i)
             assert st["start_idx"] == start_idx, (s, i)
+
+
+def test_streaming_oracle_reproduces_the_reference_when_chunk_right_is_zero():
+    """chunk_size[2] == 0 (found by oracle/fuzz_streaming_vs_reference.py): the reference's K/V stride is k_h[:, :, :-(0)] = EMPTY
+    (sanm/attention.py:345-346), so nothing is cached and the encoder look-back has no effect ([5, 11, 0], look-back 3); with
+    chunk_size[0] == 0 as well its overlap window x[:, -0:] is the WHOLE history ([0, 12, 0]: 43 tokens from the final 9-frame
+    chunk). Reference sessions: tests/golden/streaming_right0.npz (make_golden_streaming.py --right0)."""
+    import json
+    import numpy as np
+    import os
+    g, cfg, sd, wav, cmvn = load()
+    gg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "streaming_right0.npz"), allow_pickle=False)
+    sessions = json.loads(str(gg["sessions"]))
+    assert [s["chunk"] for s in sessions] == [[5, 11, 0], [0, 12, 0]]
+    for si, s in enumerate(sessions):
+        st = S.model_init(cfg, tuple(s["chunk"]), s["enc_lb"], s["dec_lb"])
+        for i in range(s["n_chunks"]):
+            fin, tail, start_idx = (int(v) for v in gg[f"s{si}_flags_{i}"])
+            assert not tail
+            trace = []
+            with torch.no_grad():
+                ids = S.generate_chunk(torch.from_numpy(gg[f"s{si}_feats_{i}"]), st, sd, cfg, bool(fin), trace)
+            assert ids == gg[f"s{si}_tokens_{i}"].tolist(), (s, i)
+            assert st["start_idx"] == start_idx, (s, i)
+            assert (trace[0]["enc"] - torch.from_numpy(gg[f"s{si}_enc_{i}"])).abs().max().item() < 1e-4, (s, i)
+    assert len(gg["s1_tokens_6"]) == 43 and gg["s1_feats_6"].shape[1] == 9          # the growing-window quirk at work
+
+
+def test_stream_batch_refuses_the_geometry_whose_reference_window_is_the_whole_history():
+    from funasr_amd.paraformer_streaming import ParaformerStreaming, StreamBatch
+    g, cfg, sd, wav, cmvn = load()
+    model = ParaformerStreaming.from_config(cfg)
+    with pytest.raises(ValueError, match="chunk_size"):
+        StreamBatch(model, 1, [0, 12, 0], 2, 1)
