@@ -101,3 +101,69 @@ def test_online_frontend_rejects_batches(frontend):
     fe, _ = frontend
     with pytest.raises(ValueError, match="batch size"):
         fe(torch.zeros(2, 1600), None, cache={}, is_final=False)
+
+
+def test_streaming_inference_chunk_loop_on_random_call_splits(frontend, monkeypatch):
+    """ParaformerStreaming.inference (product mirror) cut into random calls: which pieces reach the frontend, when the look-ahead
+    is flushed, when the < 960-sample tail chunk re-feeds the cached window, what is carried between calls -- against the
+    oracle's streaming_inference (the reference's loop, paraformer_streaming/model.py:688-752) with the network stubbed out on
+    both sides (the recorded decisions and features must agree)."""
+    from funasr_amd.paraformer_streaming import ParaformerStreaming
+    fe, cmvn = frontend
+    g = torch.Generator().manual_seed(23)
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=1, dec_blocks=1, vocab=30)
+    model = ParaformerStreaming.from_config(cfg)
+
+    class FakeStream:
+        def __init__(self, keep):
+            self.keep = keep
+
+        def close(self):
+            pass
+
+    for si in range(40):
+        chunk = [int(torch.randint(0, 2, (1,), generator=g)) * 5, int(torch.randint(4, 15, (1,), generator=g)), 0]
+        chunk[2] = int(torch.randint(1, chunk[1] // 2 + 2, (1,), generator=g))
+        stride = chunk[1] * 960
+        n_total = int(torch.randint(stride // 2, 5 * stride, (1,), generator=g))
+        if si % 5 == 0:
+            n_total = (n_total // stride + 1) * stride + int(torch.randint(0, 959, (1,), generator=g))     # a tail shorter than 960 samples
+        wav = synth.speech_like(n_total + 1, seed=100 + si)[:n_total]
+        cuts = sorted(set(int(v) for v in torch.randint(1, n_total, (int(torch.randint(0, 4, (1,), generator=g)),), generator=g)))
+        bounds = [0] + cuts + [n_total]
+        got, want = [], []
+
+        def init_cache(cache=None, **kw):
+            cache = {} if cache is None else cache
+            cache["_stream"] = FakeStream(chunk[0] + chunk[2])
+            cache["encoder"] = {"tail_chunk": False, "chunk_size": chunk}
+            cache["decoder"], cache["frontend"], cache["prev_samples"] = {}, {}, torch.empty(0)
+            return cache
+
+        def fake_generate(speech, speech_lengths=None, **kw):
+            c = kw["cache"]
+            got.append((None if c["encoder"]["tail_chunk"] else speech[0].clone(), bool(kw.get("is_final")), bool(c["encoder"]["tail_chunk"])))
+            return []
+
+        monkeypatch.setattr(model, "init_cache", init_cache)
+        monkeypatch.setattr(model, "generate_chunk", fake_generate)
+
+        def oracle_generate(feats, st, sd, cfg_, is_final, trace=None):
+            want.append((None if st["tail_chunk"] else feats[0].clone(), bool(is_final), bool(st["tail_chunk"])))
+            return []
+
+        monkeypatch.setattr(S, "generate_chunk", oracle_generate)
+        st = S.model_init(cfg, tuple(chunk), 1, 1)
+        cache = {}
+        for ci in range(len(bounds) - 1):
+            piece = wav[bounds[ci]:bounds[ci + 1]]
+            fin = ci == len(bounds) - 2
+            model.inference([piece], key=["u"], tokenizer=None, frontend=fe, cache=cache, is_final=fin, chunk_size=chunk,
+                            encoder_chunk_look_back=1, decoder_chunk_look_back=1)
+            S.streaming_inference(piece, st, {}, cfg, cmvn, fin)
+            if not fin:
+                assert torch.equal(cache["prev_samples"], st["prev_samples"]), (si, ci)
+        assert len(got) == len(want), (si, chunk, bounds, len(got), len(want))
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert a[1:] == b[1:], (si, k, a[1:], b[1:])
+            assert (a[0] is None and b[0] is None) or torch.equal(a[0], b[0]), (si, k)
