@@ -414,9 +414,13 @@ class AutoModel:
                 out.append({"key": key, "text": "", "timestamp": []})
                 continue
             durs = [segments[j][1] - segments[j][0] for j in order]
-            bs = max(batch_size, durs[0])
+            # the reference updates the budget IN PLACE (auto_model.py:924-928): once a recording's shortest segment exceeds
+            # it, the raised budget -- or the 0 of device="cpu" -- also applies to the recordings after it in the same call
+            # (found by tests/test_reference_vad_pipeline_differential.py against the reference's own loop)
+            batch_size = max(batch_size, durs[0])
             if kwargs["device"] == "cpu":
-                bs = 0
+                batch_size = 0
+            bs = batch_size
             decoded: List[dict] = []
             plan = self.plan_vad_batches(durs, bs, threshold_ms)
             if kwargs.get("batch_size_rows") and kwargs["device"] != "cpu":
