@@ -91,12 +91,16 @@ def prepare_data_iterator(data_in, input_len=None, data_type=None, key=None) -> 
             k = key if key is not None else os.path.splitext(os.path.basename(data_in))[0]
             data_list, key_list = [data_in], [k]
     elif isinstance(data_in, (list, tuple)):
+        # the reference's loop (:397-405) keeps ONE `key` variable: a given key (whatever object it is) labels every item, a file
+        # path sets it to its name, and the first random key is reused for the items after it -- reproduced as it is, the records'
+        # `key` fields are part of the drop-in surface (tests/test_reference_vad_pipeline_differential.py compares them)
         data_list = list(data_in)
         for d in data_in:
             if isinstance(d, str) and os.path.exists(d):
-                key_list.append(os.path.splitext(os.path.basename(d))[0])
-            else:
-                key_list.append(key if isinstance(key, str) else _rand_key())
+                key = os.path.splitext(os.path.basename(d))[0]
+            elif key is None:
+                key = _rand_key()
+            key_list.append(key)
     else:       # raw text (punctuation models), samples, features; a missing wav path is reported by audio.load_audio
         data_list = [data_in]
         key_list = [key if key is not None else _rand_key()]

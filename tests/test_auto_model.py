@@ -35,8 +35,13 @@ def test_prepare_data_iterator_forms(model_dir):
     assert k == ["utt0"] and data == [paths[0]]
     k, data = prepare_data_iterator(os.path.join(d, "wav.scp"))
     assert k == ["key_0", "key_1", "key_2"] and data == paths
+    # lists: the reference keeps ONE key variable over the items (auto_model.py:397-405) -- a path sets it to its name and an
+    # item without a name inherits whatever it holds; the first random key is reused (tests/test_reference_vad_pipeline_differential.py
+    # compares this function with the reference's own)
     k, data = prepare_data_iterator([paths[1], np.zeros(16000, dtype=np.float32)])
-    assert k[0] == "utt1" and k[1].startswith("rand_key_") and len(data) == 2
+    assert k == ["utt1", "utt1"] and len(data) == 2
+    k, data = prepare_data_iterator([np.zeros(16000, dtype=np.float32), np.zeros(8000, dtype=np.float32), paths[0]])
+    assert k[0].startswith("rand_key_") and k[1] == k[0] and k[2] == "utt0"
     # a string that is not a path is raw text for a punctuation model (auto_model.py:403-409); a missing wav path is
     # reported when the audio is loaded
     k, data = prepare_data_iterator("/nonexistent/a.wav")

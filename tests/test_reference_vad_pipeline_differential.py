@@ -100,3 +100,102 @@ def test_generate_with_vad_equals_the_reference_on_random_recordings(RefAutoMode
         with_punc += int(use_punc)
         sentence += int("sentence_timestamp" in call)
     assert checked > 200 and with_punc > 100 and sentence > 60
+
+
+class _EchoASR:
+    """one record per clip: text names the clip by its first sample and length; remembers the batches and the runtime
+    options it was called with"""
+    def __init__(self):
+        self.calls, self.seen = [], []
+
+    def parameters(self):
+        return iter([torch.zeros(1)])
+
+    def inference(self, data_in, key=None, **kwargs):
+        clips = [torch.as_tensor(c).reshape(-1) for c in data_in]
+        self.calls.append([int(c.shape[0]) for c in clips])
+        self.seen.append({k: kwargs.get(k) for k in ("hotword", "language", "batch_size", "use_itn")})
+        res = [{"key": k, "text": " ".join(f"w{int(round(float(c[0])))}" for _ in range(max(c.shape[0] // 4000, 1)))} for k, c in zip(key, clips)]
+        return res, {"batch_data_time": sum(c.shape[0] for c in clips) / 16000.0}
+
+
+def test_generate_without_vad_equals_the_reference(RefAutoModel, monkeypatch):
+    """AutoModel.generate / inference without a VAD model (auto_model.py:688-850): input forms (one tensor, lists of tensors /
+    numpy arrays), keys, static batch_size, runtime options handed to the model, per-result punctuation with raw_text"""
+    import numpy as np
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    g = torch.Generator().manual_seed(7)
+    for trial in range(120):
+        n = int(torch.randint(1, 9, (1,), generator=g))
+        clips = [torch.arange(int(torch.randint(1, 20, (1,), generator=g)) * 4000, dtype=torch.float32) + 100 * i for i in range(n)]
+        form = trial % 4
+        if form == 0:
+            make = lambda: clips[0].clone()
+            n_in = 1
+        elif form == 1:
+            make = lambda: [c.clone() for c in clips]
+            n_in = n
+        elif form == 2:
+            make = lambda: [c.numpy().copy() for c in clips]
+            n_in = n
+        else:
+            make = lambda: clips[0].numpy().copy()
+            n_in = 1
+        opts = dict(batch_size=int(torch.randint(1, 5, (1,), generator=g)))
+        call = {}
+        use_punc = trial % 2 == 1
+        if trial % 3 == 0 and not use_punc:
+            # (with a punctuation model the reference merges `key` into punc_kwargs, :734, and then passes it twice to the punc
+            # model's inference: TypeError -- this package's generate() accepts the combination)
+            call["key"] = [f"utt{j}" for j in range(n_in)] if n_in > 1 else "solo"
+        if trial % 5 == 1:
+            call.update(hotword="魔搭", language="zh")
+        if trial % 7 == 2:
+            call["batch_size"] = int(torch.randint(1, 4, (1,), generator=g))      # a runtime override of the static batch size
+        if trial % 4 == 1:
+            call["return_raw_text"] = True
+        a_asr, b_asr = _EchoASR(), _EchoASR()
+        ours = _ours(None, a_asr, _FakePunc() if use_punc else None, **opts)
+        theirs = _theirs(RefAutoModel, None, b_asr, _FakePunc() if use_punc else None, **opts)
+        got, want = ours.generate(make(), **call), theirs.generate(make(), **call)
+        assert a_asr.calls == b_asr.calls and a_asr.seen == b_asr.seen, (trial, opts, call, a_asr.calls, b_asr.calls, a_asr.seen, b_asr.seen)
+        if "key" in call:
+            assert [r["key"] for r in got] == [r["key"] for r in want], (trial, call)
+        else:
+            assert all(r["key"].startswith("rand_key_") for r in got) and all(r["key"].startswith("rand_key_") for r in want)
+        assert _strip(got) == _strip(want), (trial, opts, call)
+        # a second call on the same objects: runtime options of the first call must not stick (auto_model.py:1318-1359)
+        got2, want2 = ours.generate(make()), theirs.generate(make())
+        assert a_asr.seen[-1] == b_asr.seen[-1] and a_asr.calls == b_asr.calls, (trial, a_asr.seen[-1], b_asr.seen[-1])
+        assert _strip(got2) == _strip(want2)
+
+
+def test_prepare_data_iterator_equals_the_reference(RefAutoModel, tmp_path):
+    """funasr/auto/auto_model.py:347-415 on the input forms of the hot path: key lists and data lists equal (random keys
+    compared by their pattern of repetition)"""
+    import sys
+    import numpy as np
+    ref_prepare = sys.modules[RefAutoModel.__module__].prepare_data_iterator
+    from funasr_amd.auto_model import prepare_data_iterator
+    wavs = []
+    for i in range(3):
+        p = tmp_path / f"clip{i}.wav"
+        p.write_bytes(b"RIFF")
+        wavs.append(str(p))
+    scp = tmp_path / "wav.scp"
+    scp.write_text("".join(f"id{i} {w}\n" for i, w in enumerate(wavs)) + f"{wavs[0]}\n", encoding="utf-8")
+    jsonl = tmp_path / "list.jsonl"
+    jsonl.write_text('{"source": "a.wav", "key": "k0"}\n{"source": "b.wav"}\n', encoding="utf-8")
+    arr = np.zeros(100, dtype=np.float32)
+    cases = [(wavs[0], {}), (wavs[0], dict(key="mine")), (str(scp), {}), (str(jsonl), {}), ([wavs[1], arr, wavs[2], arr], {}),
+             ([arr, arr, wavs[0], arr], {}), ([arr, arr], dict(key="both")), ([arr, arr, arr], dict(key=["a", "b", "c"])),
+             ((arr, arr), {}), (arr, {}), (arr, dict(key="one")), ("今天天气不错", {}), (torch.zeros(10), dict(key="t"))]
+
+    def shape(keys):
+        names = {}
+        return [k if not (isinstance(k, str) and k.startswith("rand_key_")) else ("rand", names.setdefault(k, len(names))) for k in keys]
+    for data_in, kw in cases:
+        rk, rd = ref_prepare(data_in, **kw)
+        ok, od = prepare_data_iterator(data_in, **kw)
+        assert shape(ok) == shape(rk), (data_in if isinstance(data_in, str) else type(data_in), kw, ok, rk)
+        assert len(od) == len(rd) and all((a is b) or (isinstance(a, str) and a == b) for a, b in zip(od, rd)), (kw, od, rd)
