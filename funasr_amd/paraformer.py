@@ -105,6 +105,12 @@ class Paraformer(nn.Module):
         out, olens, _ = self.encoder(speech, speech_lengths)
         return out, olens
 
+    # what `inference` returns when no utterance of the batch predicts a token: the reference returns a BARE empty list there
+    # (model.py:615-616; bicif_paraformer/model.py:342-343, contextual_paraformer/model.py:460-461), which AutoModel.inference
+    # turns into ONE record {"text": ""} (auto_model.py:815-817); SeacoParaformer returns ([],) -- no record (its override)
+    def _nothing_decoded(self, meta_data):
+        return []
+
     def calc_predictor(self, encoder_out, encoder_out_lens):
         return self.predictor(encoder_out, None, None, ignore_id=self.ignore_id, lengths=encoder_out_lens)
 
@@ -220,7 +226,7 @@ class Paraformer(nn.Module):
         if len(key) < B:
             key = list(key) * B
         if max(res["token_num"]) < 1:
-            return [], meta_data
+            return self._nothing_decoded(meta_data)
         ibest_writer = None
         if kwargs.get("output_dir") is not None:                        # model.py:571-575
             if not hasattr(self, "writer"):
@@ -262,14 +268,14 @@ class Paraformer(nn.Module):
         if len(key) < B:
             key = list(key) * B
         if max(res["token_num"]) < 1:
-            return [], meta_data
+            return self._nothing_decoded(meta_data)
         drop = (self.eos, self.sos, self.blank_id)
         results = []
         for i in range(B):
             for hyp in res["nbest"][i]:
                 token_int = [t for t in hyp.yseq[1:-1] if t not in drop]
                 if tokenizer is None:
-                    results.append({"key": key[i], "token_int": token_int, "score": hyp.score})
+                    results.append({"key": key[i], "token_int": token_int})        # model.py:693: no score in the record
                     continue
                 token = tokenizer.ids2tokens(token_int)
                 text = tokenizer.tokens2text(token)

@@ -193,6 +193,9 @@ class SeacoParaformer(BiCifParaformer):
         return super().collect(pending)
 
     # ---------------------------------------------------------------------------------------------- AutoModel API
+    def _nothing_decoded(self, meta_data):
+        return ([],)                                # seaco_paraformer/model.py:486-487: a one-tuple, i.e. no record at all
+
     def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
         self.hotword_list = self.generate_hotwords_list(kwargs.get("hotword", None), tokenizer=tokenizer, frontend=frontend)
         return super().inference(data_in, data_lengths=data_lengths, key=key, tokenizer=tokenizer, frontend=frontend, **kwargs)
