@@ -242,9 +242,18 @@ class AutoModel:
             # this path, so keep the plumbing working and let inference() raise a clear error instead
             logging.warning("no GPU visible: the model is built on cpu, inference needs an AMD GPU")
             device = "cpu"
-        kwargs["device"] = device
-        if device == "cpu":
             kwargs["batch_size"] = 1
+        if kwargs.get("ngpu", 1) == 0:
+            device = "cpu"
+            kwargs["batch_size"] = 1
+        kwargs["device"] = device
+        try:                                                  # _resolve_ncpu + torch.set_num_threads (:46-53,563-566)
+            ncpu = max(int(kwargs.get("ncpu", 4)), 1)
+        except (TypeError, ValueError):
+            ncpu = 4
+        kwargs["ncpu"] = ncpu
+        if torch.get_num_threads() != ncpu:
+            torch.set_num_threads(ncpu)
         # tokenizer (:591-601)
         tokenizer = kwargs.get("tokenizer")
         vocab_size = -1
@@ -258,6 +267,7 @@ class AutoModel:
             if vocab_size == -1 and hasattr(tokenizer, "get_vocab_size"):
                 vocab_size = tokenizer.get_vocab_size()
         kwargs["tokenizer"] = tokenizer
+        kwargs["vocab_size"] = vocab_size                      # the models receive it with every inference call (:571,600)
         # frontend (:626-634)
         frontend = kwargs.get("frontend")
         kwargs["input_size"] = kwargs.get("input_size")

@@ -54,7 +54,8 @@ def test_prepare_data_iterator_forms(model_dir):
 def test_build_from_model_dir_on_cpu_and_loud_failure(model_dir):
     am = AutoModel(model=model_dir["dir"], device="cpu", disable_update=True)
     assert type(am.model).__name__ == "Paraformer"
-    assert am.kwargs["batch_size"] == 1 and am.kwargs["device"] == "cpu"
+    assert am.kwargs.get("batch_size", 1) == 1 and am.kwargs["device"] == "cpu"     # an explicit device="cpu" sets no batch_size (auto_model.py:551-561)
+    assert am.kwargs["ncpu"] == 4 and am.kwargs["vocab_size"] == len(VOCAB)
     assert am.kwargs["tokenizer"].get_num_vocabulary_size() == len(VOCAB)
     assert am.kwargs["frontend"].output_size() == 560 and tuple(am.kwargs["frontend"].cmvn.shape) == (2, 560)
     assert am.model.vocab_size == len(VOCAB)
