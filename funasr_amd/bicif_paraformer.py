@@ -21,6 +21,7 @@ from .tokenizer import sentence_postprocess
 @tables.register("model_classes", "BiCifParaformer")
 class BiCifParaformer(Paraformer):
     _always_timestamps = True
+    _unwrap_key_lists = False       # bicif_paraformer/model.py:347-414 and seaco_paraformer/model.py use `key[i]` as it comes
 
     @classmethod
     def from_config(cls, cfg: dict) -> "BiCifParaformer":
@@ -61,7 +62,9 @@ class BiCifParaformer(Paraformer):
         return out
 
     def _token_timestamps(self, res: dict, i: int, token, kwargs):
-        n = res["olens_host"][i] * self.predictor.upsample_times    # model.py:375-380
+        # the reference slices the upsampled weights with a literal 3 (bicif_paraformer/model.py:403-404, seaco_paraformer/
+        # model.py:554-555) -- the upsample factor of the published models -- whatever `upsample_times` says; kept
+        n = res["olens_host"][i] * 3
         return cif_token_spans(res["us_alphas_host"][i][:n], res["us_peaks_host"][i][:n], list(token),
                                vad_offset=kwargs.get("begin_time", 0))
 

@@ -87,6 +87,8 @@ class ContextualParaformerDecoder(ParaformerSANMDecoder):
 
 @tables.register("model_classes", "ContextualParaformer")
 class ContextualParaformer(Paraformer):
+    _unwrap_key_lists = False       # contextual_paraformer/model.py:463-540 uses `key[i]` as it comes
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         inner_dim = kwargs.get("inner_dim", 256)

@@ -32,6 +32,9 @@ from . import wav_frontend as _wav_frontend  # noqa: F401
 @tables.register("model_classes", "Paraformer")
 class Paraformer(nn.Module):
     _always_timestamps = False      # BiCifParaformer / SeACo return token timestamps on every call
+    # model.py:624-627 unwraps a list-of-lists `key` (what AutoModel hands over for list inputs with a key list) and repeats a
+    # short key list; the BiCif / SeACo / Contextual classes of the reference do neither (their records then carry the list)
+    _unwrap_key_lists = True
 
     def __init__(self, specaug: Optional[str] = None, specaug_conf: Optional[Dict] = None, normalize: str = None,
                  normalize_conf: Optional[Dict] = None, encoder: str = None, encoder_conf: Optional[Dict] = None,
@@ -221,10 +224,11 @@ class Paraformer(nn.Module):
         B = len(res["ids"])
         if key is None:
             key = [f"utt_{i}" for i in range(B)]
-        if isinstance(key[0], (list, tuple)):
-            key = key[0]
-        if len(key) < B:
-            key = list(key) * B
+        if self._unwrap_key_lists:
+            if isinstance(key[0], (list, tuple)):
+                key = key[0]
+            if len(key) < B:
+                key = list(key) * B
         if max(res["token_num"]) < 1:
             return self._nothing_decoded(meta_data)
         ibest_writer = None
@@ -263,10 +267,11 @@ class Paraformer(nn.Module):
         B = len(res["nbest"])
         if key is None:
             key = [f"utt_{i}" for i in range(B)]
-        if isinstance(key[0], (list, tuple)):
-            key = key[0]
-        if len(key) < B:
-            key = list(key) * B
+        if self._unwrap_key_lists:
+            if isinstance(key[0], (list, tuple)):
+                key = key[0]
+            if len(key) < B:
+                key = list(key) * B
         if max(res["token_num"]) < 1:
             return self._nothing_decoded(meta_data)
         drop = (self.eos, self.sos, self.blank_id)
