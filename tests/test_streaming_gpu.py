@@ -225,8 +225,6 @@ def test_graphs_survive_workspace_growth_by_an_offline_batch(cuda):
     ref.close()
 
 
-@pytest.mark.xfail(reason="chunk_size[2] == 0 handling was corrected after round 3's GPU minutes had run out (the fuzz against the "
-                          "reference found it on CPU): first hardware run pending", strict=False)
 @pytest.mark.parametrize("precision", ["fp32", "f16x2"])
 def test_stream_chunk_right_zero_matches_reference_session(cuda, precision):
     """chunk_size [5, 11, 0] with encoder look-back 3: the reference's K/V stride `[: -chunk_size[2]]` is empty there, so it
