@@ -19,7 +19,8 @@ Multi-GPU (utterance-level data parallelism, weak scaling): one process per GPU,
 broadcasts ONE packed arena over RCCL, every rank decodes its own 64 clips, hypotheses are gathered on rank 0
 inside the timed region. No collective touches the data path.
 
-Contract: python bench.py --gpus N --steps K --warmup W   (N>1 is launched through torch.distributed.run)
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: either under torch.distributed.run with N ranks, or bare --
+the script then re-executes itself as N ranks, funasr_amd.dp.ensure_ranks; a world size other than N is an error)
 prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields, incl. `roofline` and `cpu_baseline`).
 """
 from __future__ import annotations
@@ -116,9 +117,10 @@ def read_prof(lib, steps):
 
 def main():
     args = parse()
+    from funasr_amd.dp import ensure_ranks
+    world = ensure_ranks(args.gpus)        # --gpus N > 1 without a launcher: re-executes itself as N ranks; a mismatch is an error
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the HIP path is the only implementation")
     if args.dist_backend == "gloo":

@@ -10,10 +10,41 @@ exchanges are
 """
 from __future__ import annotations
 
+import os
+import socket
+import sys
 from typing import Callable, List, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+def ensure_ranks(n_gpus: int, argv: Sequence[str] = None) -> int:
+    """Make `python <script> --gpus N` by itself a job of N ranks (one process per GPU, the launch recipe the reference
+    spells out per GPU in examples/aishell/paraformer/run.sh:135-190). With N > 1 and no WORLD_SIZE in the environment
+    the calling script is re-executed under `torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 (this
+    call never returns in the parent: it exits with the job's status); under a launcher the world size must equal N --
+    a mismatch is an error, never a silent 1-rank run. Returns the world size this process is part of."""
+    world = os.environ.get("WORLD_SIZE")
+    if world is None:
+        if n_gpus <= 1:
+            return 1
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        argv = list(sys.argv if argv is None else argv)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + argv
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this host driver
+        import subprocess
+        raise SystemExit(subprocess.call(cmd, env=env))
+    world = int(world)
+    if world != max(1, n_gpus):
+        raise SystemExit(f"--gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line for a job "
+                         f"of another size (launch with --nproc-per-node {n_gpus}, or pass --gpus {world})")
+    return world
 
 
 def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:

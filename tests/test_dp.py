@@ -126,3 +126,31 @@ def test_row_budget_batch_planner():
     assert dp.encoder_rows(83, 245, 1, True) == 96 and dp.encoder_rows(83, 245, 1, False) == 256
     assert dp.encoder_rows(245, 245, 1, True) == 256            # the longest clip has no padding row behind it
     assert dp.plan_batches_by_rows([], 100) == []
+
+
+def test_ensure_ranks_relaunches_a_bare_command_and_refuses_mismatches(tmp_path):
+    """`python script.py --gpus 2` without a launcher becomes a 2-rank torch.distributed.run job on 127.0.0.1 (what bench.py and
+    tools/sweep.py do with --gpus N); a launcher that started another world size is an error, not a silent 1-rank run"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "job.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {root!r})
+        from funasr_amd.dp import ensure_ranks
+        n = int(sys.argv[sys.argv.index("--gpus") + 1])
+        world = ensure_ranks(n)
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        assert dist.get_world_size() == world == n
+        if dist.get_rank() == 0:
+            print("WORLD", world, flush=True)
+        dist.destroy_process_group()
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [l for l in r.stdout.splitlines() if l.startswith("WORLD")] == ["WORLD 2"]
+    r = subprocess.run([sys.executable, str(script), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -64,3 +64,24 @@ def test_bench_two_ranks_prints_one_whole_job_line(cuda):
     # whole-job aggregate: both ranks' clips over the max-over-ranks time
     assert abs(d["value"] - 2 * 64 * 30.0 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01
     assert "roofline" in d and d["roofline"]["frac"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_bare_command_launches_its_own_ranks(cuda):
+    """the driver's literal command, NO torchrun wrapper: `python bench.py --gpus 2 ...` must itself become a 2-rank job
+    (funasr_amd.dp.ensure_ranks) and print a 2-rank line -- round 3 printed n_gpus 1 here"""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo"],
+                       cwd=ROOT, env=dict(env_clean, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["parallelism"] == "utterance-dp2"
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2
+
+
+def test_bench_refuses_a_world_size_other_than_gpus(cuda):
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

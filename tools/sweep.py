@@ -30,6 +30,8 @@ def durations(n, seed=0):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="ranks (one per GPU); > 1 without a launcher re-executes the script under "
+                    "torch.distributed.run (funasr_amd.dp.ensure_ranks); 0 = whatever the launcher started")
     ap.add_argument("--clips", type=int, default=2000)
     ap.add_argument("--batch-seconds", type=float, default=0.0, help="padded audio seconds per batch (the reference's batch_size_s "
                     "policy); 0 = use --batch-rows")
@@ -53,6 +55,9 @@ def main():
     ap.add_argument("--enc-option", action="append", default=[], metavar="KEY=VALUE", help="encoder schedule options (pf_encoder_set_option)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus:
+        from funasr_amd.dp import ensure_ranks
+        world = ensure_ranks(args.gpus)
     local = 0 if args.dist_backend == "gloo" else int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
