@@ -20,7 +20,7 @@ timestamps shifted by the segment start); with a `punc_model` (CT-Transformer di
 punctuated once per recording (results that carry `words` keep their spelling, funasr_amd/punc_align.py) and
 `sentence_timestamp` cuts it into sentence records. The speaker branch raises. `vad_model` may also be a local FSMN-VAD
 model directory: the network runs on the GPU (funasr_amd/fsmn_vad.py), its decision logic on the host
-(funasr_amd/vad_decision.py). `generate` ends with the text-level hotword correction (funasr_amd/postprocess_hotwords.py).
+(funasr_amd/vad_decision.py). `generate` hands a requested text-level hotword correction to the reference's own module (`_text_hotword_step`).
 
 When the real package is importable, use `funasr.AutoModel` itself after `funasr_amd.install()`.
 """
@@ -196,6 +196,24 @@ def load_pretrained_model(path: str, model: torch.nn.Module, ignore_init_mismatc
     model.load_state_dict(out, strict=True)
 
 
+_TEXT_HOTWORD_KEYS = ("postprocess_hotwords", "postprocess_hotword_file")
+
+
+def _text_hotword_step(cfg):
+    """The text-level hotword correction that ends the reference's `generate` (funasr/auto/auto_model.py:742-748) is host-side
+    string replacement on the final text -- outside the hot path and not restated here. When a call asks for it,
+    the reference's OWN module does it (funasr.utils.postprocess_hotwords, importable wherever this package is installed into
+    a FunASR checkout via install()); without FunASR the request is refused instead of being ignored."""
+    if not any(cfg.get(k) for k in _TEXT_HOTWORD_KEYS):
+        return lambda results, cfg: results
+    try:
+        from funasr.utils.postprocess_hotwords import apply_postprocess_hotwords_to_results
+    except ImportError as e:
+        raise NotImplementedError("postprocess_hotwords= is FunASR's text-level post-processing (funasr/utils/postprocess_hotwords.py); "
+                                  "it needs the funasr package on the path (use funasr.AutoModel with funasr_amd.install())") from e
+    return apply_postprocess_hotwords_to_results
+
+
 class AutoModel:
     def __init__(self, **kwargs):
         if kwargs.get("spk_model") is not None:
@@ -314,7 +332,7 @@ class AutoModel:
 
     # ------------------------------------------------------------------------------------------------- generate
     def generate(self, input, input_len=None, progress_callback=None, **cfg):
-        from .postprocess_hotwords import apply_postprocess_hotwords_to_results
+        apply_postprocess_hotwords_to_results = _text_hotword_step(cfg)
         if getattr(self, "vad_model", None) is None:                        # :729-742
             results = self.inference(input, input_len=input_len, progress_callback=progress_callback, **cfg)
             punc_model = getattr(self, "punc_model", None)
