@@ -142,6 +142,22 @@ def test_pipeline_token_ids_equal_reference():
     assert (res["enc"] - t(g["enc"])).abs().max().item() < 1e-5
 
 
+from tests._full_config import check_against_full_config, full_config_fixture  # noqa: E402
+
+
+def test_oracle_equals_reference_modules_at_the_headline_configuration():
+    """The restatement against the reference's own modules where it matters: 50 + 16 blocks, T = 500, V = 8404
+    (sanm/encoder.py:392-461, paraformer/cif_predictor.py:253-314,818-908, paraformer/decoder.py:397-449)."""
+    g, cfg, sd, feats, lens = full_config_fixture()
+    torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        res = O.paraformer_greedy(feats, lens, sd, cfg)
+    d = check_against_full_config(g, res, enc_tol=2e-5, hid_tol=1e-4, alpha_tol=1e-6)      # measured: 0.0, 3.2e-5, 3.6e-7
+    assert d["flips"] == []          # same ATen kernels, same operation order: not even near-ties move
+    lg = res["logits"][:, ::32, ::7]
+    assert float((lg[:, : g["logit_rows"].shape[1]] - t(g["logit_rows"])).abs().max()) < 5e-5
+
+
 def test_sensevoice_encoder_and_ctc_match_reference():
     g = gold("sensevoice")
     cfg = json.loads(str(g["cfg"]))

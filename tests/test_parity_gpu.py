@@ -442,6 +442,32 @@ def test_full_size_batch_independence_and_fused_argmax(cuda, f32_mode):
         assert ids[b, : res["token_num"][b]].tolist() == res["raw_ids"][b]
 
 
+def test_full_configuration_vs_reference_modules(cuda, f32_mode):
+    """The HIP path against the REFERENCE's own SANMEncoder + CifPredictorV2 + ParaformerSANMDecoder at the headline
+    configuration -- 50 + 16 blocks, T = 500, vocabulary 8404, the bench's weights, two 30 s clips (tests/golden/full_config.npz,
+    oracle/make_golden_full.py; sanm/encoder.py:392-461, paraformer/cif_predictor.py:253-314,818-908, paraformer/decoder.py:
+    397-449). Bars (north_star): CIF fire frames and token counts bit-exact, encoder within 1e-3 (asserted 2e-4), decoder
+    hidden states within 1e-3, arg-max ids of the random-init output layer equal except where the reference's own top-2
+    logits are closer than 1e-4."""
+    from funasr_amd.paraformer import Paraformer
+    from tests._full_config import check_against_full_config, full_config_fixture
+    g, cfg, sd, feats, lens = full_config_fixture()
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(cuda).set_precision(f32_mode)
+    x, xl = feats.to(cuda), lens.to(cuda)
+    res = model.recognize_features(x, xl, return_intermediate=True)
+    hid, _ = model.decoder(res["enc"], res["olens"], res["embeds"], torch.tensor(res["token_num"]), return_hidden=True)
+    out = dict(enc=res["enc"].cpu(), alphas=res["alphas"].cpu(), peaks=res["peaks"].cpu(), token_num=res["token_num"],
+               raw_ids=res["raw_ids"], hidden=hid.cpu())
+    d = check_against_full_config(g, out, enc_tol=2e-4, hid_tol=1e-3, alpha_tol=5e-5)
+    print(f"[{f32_mode}] vs reference modules at 50+16 blocks, T=500: encoder max|d| {d['enc']:.2e}, alpha {d['alpha']:.2e}, "
+          f"decoder hidden {d['hidden']:.2e}, near-tie flips {d['flips']}")
+    # the production call (row-packed encoder, no intermediates) returns the same ids and counts
+    res2 = model.recognize_features(x, xl)
+    assert res2["raw_ids"] == res["raw_ids"] and res2["token_num"] == res["token_num"]
+
+
 def test_full_configuration_ragged_batch_vs_oracle(cuda, f32_mode):
     """The headline configuration itself -- Paraformer-large, 50 + 16 blocks, vocabulary 8404, T = 500 frames, B = 8 ragged
     30 s ... 9 s clips from waveforms -- against the CPU oracle clip by clip: encoder <= 1e-3 (north_star), CIF fire
