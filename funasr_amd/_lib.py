@@ -186,6 +186,8 @@ SIGNATURES = {
     "pf_prof_enable": (C.c_int, [C.c_int]),
     "pf_prof_reset": (C.c_int, []),
     "pf_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pf_prof_read_tags": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int64)]),
 }
 
 

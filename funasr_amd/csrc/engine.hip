@@ -30,7 +30,7 @@ const char* get_error() { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------------ profiling
 // Optional hipEvent instrumentation of the dominant kernels (bench.py roofline line).
-struct ProfRec { hipEvent_t a, b; int kind; double work; };
+struct ProfRec { hipEvent_t a, b; int kind; double work; const char* tag; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_ev_pool;
@@ -39,11 +39,12 @@ static hipEvent_t prof_event() {
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 struct ProfScope {
-    hipEvent_t a, b; hipStream_t s; int kind; double work; bool on;
-    ProfScope(int kind_, double work_, hipStream_t s_) : s(s_), kind(kind_), work(work_), on(g_prof_on) {
+    hipEvent_t a, b; hipStream_t s; int kind; double work; bool on; const char* tag;
+    // `tag_`: a string literal naming the call site ("enc.w1", ...): bench.py reports time / rate per tag (pf_prof_read_tag)
+    ProfScope(int kind_, double work_, hipStream_t s_, const char* tag_ = nullptr) : s(s_), kind(kind_), work(work_), on(g_prof_on), tag(tag_) {
         if (on) { a = prof_event(); b = prof_event(); (void)hipEventRecord(a, s); }
     }
-    ~ProfScope() { if (on) { (void)hipEventRecord(b, s); g_prof.push_back({a, b, kind, work}); } }
+    ~ProfScope() { if (on) { (void)hipEventRecord(b, s); g_prof.push_back({a, b, kind, work, tag}); } }
 };
 enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_FSMN = 2, PROF_LN = 3, PROF_FBANK = 4, PROF_GEMM3 = 5, PROF_KINDS = 6 };
 
@@ -706,7 +707,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
             g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = N; g.c_plane = (size_t)M * N; g.cscale = pow2f(ec);
             g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = e->gemm_tile;
-            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
+            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s, C2 ? "enc.w_1 (planes out)" : (K > D ? "enc.w_2" : "enc.linear_out"));
             return launch_gemm_f16x2(g, s);
         };
         const bool fuse = e->fuse_row && gemm_f16x2_row_applicable(D, D) && gemm_f16x2_row_applicable(D, F);
@@ -722,7 +723,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             g.ln_g = lg; g.ln_b = lb; g.ln_eps = c.ln_eps;
             if (lg) { g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(ey); }
             g.M = M; g.N = D; g.K = K; g.a_nt = e->row_nt >= (K == D ? 1 : 2); g.block_rows = e->row_bm;
-            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)D * K, s);
+            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)D * K, s, K > D ? "enc.w_2 row (+res +LN)" : "enc.linear_out row (+fsmn +res +LN)");
             return launch_gemm_f16x2_row(g, s);
         };
         if (!(fuse && xn_ready)) {
@@ -739,7 +740,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             g.qkv_D = D; g.Qp = q2; g.Kp = k2; g.qk_plane = (size_t)(M + 32) * D;
             g.VT = vt2; g.ldvt = ldvt; g.vt_plane = (size_t)D * ldvt;
             g.q_mul = dk_scale * pow2f(w.e_q); g.k_mul = pow2f(w.e_k); g.v_mul = pow2f(w.e_v); g.tile = e->gemm_tile;
-            ProfScope ps(PROF_GEMM3, 2.0 * M * 3.0 * D * w.in_pad, s);
+            ProfScope ps(PROF_GEMM3, 2.0 * M * 3.0 * D * w.in_pad, s, "enc.qkv (Q,K,V^T planes out)");
             if ((rc = launch_gemm_f16x2(g, s))) return rc;
         }
         // FSMN memory on the fp32 v projection: inside linear_out's epilogue (gemm_f16x2_row.hip) or as its own launch
@@ -759,7 +760,7 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             aa.O = ctx2; aa.ldo = D; aa.o_plane = (size_t)M * D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tp = T;
             aa.sscale = pow2f(-(w.e_q + w.e_k)); aa.oscale = pow2f(-10);      // ctx planes carry v's exponent
             aa.variant = e->attn_variant;
-            ProfScope ps(PROF_ATTN, 4.0 * B * (double)T * T * D, s);
+            ProfScope ps(PROF_ATTN, 4.0 * B * (double)T * T * D, s, "enc.self_attention");
             if ((rc = launch_attention_f16x2(aa, s))) return rc;
         }
         const float* resid2 = (w.in_dim == D) ? x_in : nullptr;
@@ -1505,6 +1506,24 @@ int pf_prof_reset(void) {
     return 0;
 }
 // totals for one kernel kind: 0 gemm (flops), 1 attention (flops), 2 fsmn (bytes), 3 layernorm (bytes), 4 fbank (bytes)
+// per call site: fills up to `cap` rows (tag pointer, kind, total ms, total work, launches) of the tagged records; returns the row count
+int pf_prof_read_tags(int cap, const char** tags, int* kinds, double* total_ms, double* total_work, int64_t* launches) {
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (!r.tag) continue;
+        int i = 0;
+        while (i < n && !(tags[i] == r.tag && kinds[i] == r.kind)) ++i;
+        if (i == n) {
+            if (n >= cap) continue;
+            tags[n] = r.tag; kinds[n] = r.kind; total_ms[n] = 0; total_work[n] = 0; launches[n] = 0; ++n;
+        }
+        if (hipEventSynchronize(r.b) != hipSuccess) { set_error("prof: event sync failed"); return -2; }
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) { set_error("prof: elapsed failed"); return -2; }
+        total_ms[i] += t; total_work[i] += r.work; ++launches[i];
+    }
+    return n;
+}
 int pf_prof_read(int kind, double* total_ms, double* total_work, int64_t* launches) {
     double ms = 0, work = 0;
     int64_t n = 0;
