@@ -132,14 +132,30 @@ __device__ __forceinline__ void store_split2x4_pair(unsigned short* p, size_t pl
 // and the fused residual + LayerNorm epilogue (gemm_f16x2_row.hip): both evaluate exactly these expression trees in the same
 // order (per 4-column chunk, then chunk l + chunk l + 64, then the 64-lane xor butterfly 32, 16, .. 1), so the fused epilogue
 // returns the bits of the stand-alone kernel.
-__device__ __forceinline__ float ln_sum4(const float4 v) { return (v.x + v.y) + (v.z + v.w); }
+// Contraction is OFF inside these helpers: under the default -ffp-contract=fast the compiler decides per call site whether
+// a * a + b * b becomes mul + fma or two muls and an add (it depends on how the surrounding code was vectorised), so two
+// kernels calling the same helper on the same values could round differently. With every product and sum rounded on its own
+// the helpers are ONE arithmetic, whatever kernel they are inlined into (the fused kernels are tested bitwise against the
+// stand-alone LayerNorm, and the choice between them may depend on the batch's row count).
+__device__ __forceinline__ float ln_sum4(const float4 v) {
+#pragma clang fp contract(off)
+    return (v.x + v.y) + (v.z + v.w);
+}
 __device__ __forceinline__ float ln_sqdev4(const float4 v, const float mean) {
+#pragma clang fp contract(off)
     const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
     return (a * a + b * b) + (cc * cc + d * d);
 }
-__device__ __forceinline__ float ln_mean(const float s, const int D) { return s / (float)D; }
-__device__ __forceinline__ float ln_rstd(const float q, const int D, const float eps) { return 1.0f / sqrtf(q / (float)D + eps); }
+__device__ __forceinline__ float ln_mean(const float s, const int D) {
+#pragma clang fp contract(off)
+    return s / (float)D;
+}
+__device__ __forceinline__ float ln_rstd(const float q, const int D, const float eps) {
+#pragma clang fp contract(off)
+    return 1.0f / sqrtf(q / (float)D + eps);
+}
 __device__ __forceinline__ float4 ln_apply4(const float4 v, const float mean, const float rstd, const float4 g, const float4 b) {
+#pragma clang fp contract(off)
     float4 o;
     o.x = (v.x - mean) * rstd * g.x + b.x;
     o.y = (v.y - mean) * rstd * g.y + b.y;
@@ -290,6 +306,28 @@ struct GemmRowArgs {
     // Every choice gives the same bits.
     int block_rows;
 };
+// The encoder block's feed-forward in one launch (gemm_f16x2_ffn.hip): C = R + (relu(X W1^T + b1) W2^T + b2), optionally followed
+// by LayerNorm(C) as planes (Y2) or fp32 (Yf). X2 / W1 / W2 are two-plane fp16 operands; the hidden activations get the plane
+// scale `hscale` (2^e_h) and never leave the registers. D == 512, F % 128 == 0.
+struct FfnArgs {
+    const unsigned short* X2; int ldx; size_t x_plane;    // [2][M, 512] planes of norm2(x) * 2^e_x
+    const unsigned short* W1; int ldw1; size_t w1_plane;  // [2][F, 512]
+    const unsigned short* W2; int ldw2; size_t w2_plane;  // [2][512, F]
+    const float* b1; const float* b2;                     // [F], [512] (b2 may be null)
+    float oscale1, hscale, oscale2;                       // 2^-(e_x + e_w1), 2^e_h, 2^-(e_h + e_w2)
+    const float* R; int ldr;                              // residual stream [M, 512]
+    float* C; int ldc;                                    // may alias R
+    const float* ln_g; const float* ln_b; float ln_eps;
+    unsigned short* Y2; int ldy2; size_t y_plane; float yscale;
+    float* Yf; int ldyf;
+    int M, D, F;
+    int abl;                                              // measurement only (tools/bench_ffn.py): see ffn_f16x2_kernel
+    // elements between the 32-deep K stages of an operand row; 0 = row-major planes (32). K-blocked operands [K / 32][rows][32]
+    // (ld* = 32, *_kstep = rows * 32): a 16-row DMA piece is one contiguous KB
+    size_t x_kstep, w1_kstep, w2_kstep;
+};
+bool ffn_f16x2_applicable(int D, int F);
+int launch_ffn_f16x2(const FfnArgs& a, hipStream_t stream);
 int launch_gemm_f16x2_row8(const GemmRowArgs& a, int bm, hipStream_t stream);
 bool gemm_f16x2_row_applicable(int N, int K);
 int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream);

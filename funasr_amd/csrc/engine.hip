@@ -68,6 +68,18 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
+// the fused feed-forward runs ONE 128-row workgroup per CU: take it where the workgroups fill whole rounds of the CUs to >= 85 %
+static bool ffn_fills_rounds(int M) {
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+        return n;
+    }();
+    const int blocks = ceil_div(M, 128), rounds = ceil_div(blocks, n_cu);
+    return blocks >= (int)(0.85 * rounds * n_cu);
+}
+
 struct Tensor {
     float* d = nullptr;      // device storage (library owned)
     int64_t numel = 0;       // expected element count of the SOURCE tensor
@@ -473,6 +485,12 @@ struct Encoder {
     int fuse_row = 1;
     // fsmn_fused = 1: the FSMN memory block is computed in linear_out's full-row epilogue (kernel 11, no shift, fuse_row on)
     int fsmn_fused = 1;
+    // ffn_fused: w_1 + ReLU + w_2 + residual (+ the next LayerNorm) as ONE launch (gemm_f16x2_ffn.hip), the hidden activations in
+    // registers. 1 = where the row count fills whole rounds of 128-row workgroups (the kernel runs one workgroup per CU; a last
+    // round that is mostly empty costs a full round -- the two-kernel pair has finer shapes for those batches), 2 = always,
+    // 0 = never. The fused launch returns the bits of the pair for the fp32 stream (tested).
+    int ffn_fused = 0;                  // (off until the exact-wait schedule of gemm_f16x2_ffn.hip beats the pair)
+    int ffn_abl = 0;                    // debugging hook: FfnArgs.abl
     int row_bm = 0;                     // GemmRowArgs.block_rows of the full-row GEMMs (0: by the row count)
     DevBuf fs_grp;                      // int32 [2][M / 16]: valid v rows [lo, hi) of the sequence owning each 16-row group
     std::vector<int32_t> h_fs;
@@ -773,6 +791,21 @@ static int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in,
             ProfScope ps(PROF_LN, 8.0 * M * (double)D, s);
             if ((rc = launch_layernorm(x, D, w.n2g, w.n2b, reinterpret_cast<float*>(xn2), D, M, D, D, c.ln_eps, s, 3, 0,
                                        (size_t)M * D, pow2f(w.e_x2)))) return rc;
+        }
+        if (fuse && e->ffn_fused && ffn_f16x2_applicable(D, F) && (e->ffn_fused == 2 || ffn_fills_rounds(M))) {
+            const bool ln = next && next->in_dim == D;
+            FfnArgs g{};
+            g.X2 = xn2; g.ldx = D; g.x_plane = (size_t)M * D; g.W1 = w.w1_2; g.ldw1 = D; g.w1_plane = (size_t)F * D;
+            g.W2 = w.w2_2; g.ldw2 = F; g.w2_plane = (size_t)D * F; g.b1 = w.b1; g.b2 = w.b2;
+            g.oscale1 = pow2f(-(w.e_x2 + w.ew_1)); g.hscale = pow2f(w.e_h); g.oscale2 = pow2f(-(w.e_h + w.ew_2));
+            g.R = x; g.ldr = D; g.C = x; g.ldc = D;
+            if (ln) {
+                g.ln_g = next->n1g; g.ln_b = next->n1b; g.ln_eps = c.ln_eps;
+                g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(next->e_x1);
+            }
+            g.M = M; g.D = D; g.F = F; g.abl = e->ffn_abl;
+            ProfScope ps(PROF_GEMM3, 2.0 * M * 2.0 * (double)D * F, s, "enc.ffn fused (w_1 +relu +w_2 +res +LN)");
+            return launch_ffn_f16x2(g, s);
         }
         if ((rc = gemm2(xn2, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
         if (fuse) {
@@ -1718,6 +1751,8 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     PF_REQUIRE(e && key, "encoder_set_option: null");
     const std::string k = key;
     if (k == "fuse_row") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fuse_row is 0 or 1"); e->fuse_row = value; return 0; }
+    if (k == "ffn_abl") { e->ffn_abl = value; return 0; }
+    if (k == "ffn_fused") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: ffn_fused is 0, 1 or 2"); e->ffn_fused = value; return 0; }
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129, "encoder_set_option: row_bm is 0, 96, 128 or 129"); e->row_bm = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
@@ -3202,6 +3237,26 @@ int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void
     g.a_nt = a_nt & 1; g.block_rows = a_nt >> 8;          // bits 8..: GemmRowArgs.block_rows (0 by row count, 96, 128, 129)
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
     return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
+}
+/* the encoder block's feed-forward in one launch (gemm_f16x2_ffn.hip): C = R + (relu(X W1^T + b1) W2^T + b2) [+ LayerNorm -> planes Y2
+ * or fp32 Yf]; operands are two-plane fp16 tensors ([2][M, 512], [2][F, 512], [2][512, F]), plane strides M 512 / F 512 / 512 F */
+int pf_k_ffn_f16x2(const void* X2, const void* W1, const void* W2, const float* b1, const float* b2, float oscale1, float hscale,
+                   float oscale2, const float* R, float* Cout, const float* ln_g, const float* ln_b, float ln_eps, void* Y2,
+                   float yscale, float* Yf, int32_t M, int32_t F, int32_t iters, float* ms_out, void* stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    FfnArgs g{};
+    g.abl = (F >> 24) & 15;                               // measurement-only variants (tools/bench_ffn.py)
+    const bool wkb = (F >> 28) & 1;                       // weights in the K-blocked layout [K / 32][rows][32]
+    F &= 0xffffff;
+    g.X2 = reinterpret_cast<const unsigned short*>(X2); g.ldx = 512; g.x_plane = (size_t)M * 512;
+    g.W1 = reinterpret_cast<const unsigned short*>(W1); g.ldw1 = 512; g.w1_plane = (size_t)F * 512;
+    g.W2 = reinterpret_cast<const unsigned short*>(W2); g.ldw2 = F; g.w2_plane = (size_t)512 * F;
+    g.b1 = b1; g.b2 = b2; g.oscale1 = oscale1; g.hscale = hscale; g.oscale2 = oscale2; g.R = R; g.ldr = 512; g.C = Cout; g.ldc = 512;
+    g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
+    g.y_plane = (size_t)M * 512; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.D = 512; g.F = F;
+    if (wkb) { g.ldw1 = 32; g.w1_kstep = (size_t)F * 32; g.ldw2 = 32; g.w2_kstep = (size_t)512 * 32; }
+    if (iters <= 0 || !ms_out) return launch_ffn_f16x2(g, s);
+    return time_launches([&] { return launch_ffn_f16x2(g, s); }, iters, ms_out, s);
 }
 /* the FSMN form of the full-row kernel: the first addend is the FSMN memory block (11 taps, left padding 5) of fs_v [M, 512],
  * valid input rows [fs_lo[g], fs_hi[g]) per 16-row group g; M % 16 == 0, LayerNorm epilogue required */

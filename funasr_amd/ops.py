@@ -355,6 +355,43 @@ def gemm_f16x2_row(a2: torch.Tensor, w2: torch.Tensor, bias=None, add1=None, add
     return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
 
 
+def ffn_f16x2(x2: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, b1: torch.Tensor, b2, resid: torch.Tensor, e_x: int, e_w1: int,
+              e_h: int, e_w2: int, ln=None, out_scale_exp: int = 0, ln_planes: bool = True, want_c: bool = True,
+              in_place: bool = False, time_iters: int = 0, abl: int = 0, w_kblocked: bool = False):
+    """The encoder block's feed-forward in one launch (gemm_f16x2_ffn.hip): c = resid + (relu(x w1^T + b1) w2^T + b2) with
+    x2 [2, M, 512], w1 [2, F, 512], w2 [2, 512, F] fp16 planes of x 2^e_x, w1 2^e_w1, w2 2^e_w2; the hidden activations are
+    split into planes of h 2^e_h in registers. With ln = (gamma, beta, eps) also y = LayerNorm(c) as planes [2, M, 512] of
+    y 2^out_scale_exp or fp32. in_place: c is written into `resid`. Returns (c or None, y or None[, ms])."""
+    lib = _lib.load()
+    for t_ in (x2, w1, w2):
+        assert t_.dtype == torch.float16 and t_.is_contiguous()
+    _, M, D = x2.shape
+    if w_kblocked:                               # weights made by kblocked(): [2, K / 32, rows, 32]
+        F = w1.shape[2]
+        assert D == 512 and tuple(w1.shape) == (2, 16, F, 32) and tuple(w2.shape) == (2, F // 32, 512, 32)
+    else:
+        F = w1.shape[1]
+        assert D == 512 and tuple(w1.shape) == (2, F, 512) and tuple(w2.shape) == (2, 512, F)
+    assert resid.dtype == torch.float32 and tuple(resid.shape) == (M, 512) and resid.is_contiguous()
+    dev = x2.device
+    c = resid if in_place else (torch.empty(M, 512, device=dev, dtype=torch.float32) if (want_c or ln is None) else None)
+    y2 = yf = g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln
+        if ln_planes:
+            y2 = torch.empty(2, M, 512, device=dev, dtype=torch.float16)
+        else:
+            yf = torch.empty(M, 512, device=dev, dtype=torch.float32)
+    ms = C.c_float(0)
+    _lib.check(lib.pf_k_ffn_f16x2(_ptr(x2), _ptr(w1), _ptr(w2), _ptr(b1), _ptr(b2), float(2.0 ** -(e_x + e_w1)), float(2.0 ** e_h),
+                                  float(2.0 ** -(e_h + e_w2)), _ptr(resid), _ptr(c), _ptr(g), _ptr(b), float(eps), _ptr(y2),
+                                  float(2.0 ** out_scale_exp), _ptr(yf), M, F | (int(abl) << 24) | (int(bool(w_kblocked)) << 28), int(time_iters), C.byref(ms), _stream()),
+               "pf_k_ffn_f16x2")
+    y = y2 if y2 is not None else yf
+    return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
+
+
 def gemm_f16x2_row_fsmn(a2: torch.Tensor, w2: torch.Tensor, bias, v: torch.Tensor, taps: torch.Tensor, lo: torch.Tensor,
                         hi: torch.Tensor, add2=None, scale_exp: int = 0, ln=None, out_scale_exp: int = 0, ln_planes: bool = True,
                         want_c: bool = True, a_nt: bool = False, time_iters: int = 0, block_rows: int = 0):

@@ -385,6 +385,14 @@ int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void
                         const float* bias, const float* R1, int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc,
                         const float* ln_g, const float* ln_b, float ln_eps, void* Y2, int64_t y_plane, float yscale, float* Yf,
                         int32_t M, int32_t K, int32_t relu, int32_t a_nt, int32_t iters, float* ms_out, void* stream);
+/* The encoder block's position-wise feed-forward in ONE launch (gemm_f16x2_ffn.hip; funasr/models/transformer/
+ * positionwise_feed_forward.py:14-34 with the residual add of sanm/encoder.py:141-146 and, optionally, the next LayerNorm):
+ * Cout = R + (relu(X W1^T + b1) W2^T + b2); with ln_g: Y2 (planes of LayerNorm(Cout) * yscale) or Yf (fp32). X2 [2][M, 512],
+ * W1 [2][F, 512], W2 [2][512, F] are two-plane fp16 operands (hi plane, then lo plane); oscale1 = 2^-(e_x + e_w1), hscale = the
+ * hidden activations' plane scale 2^e_h, oscale2 = 2^-(e_h + e_w2). F % 128 == 0. Cout may alias R. */
+int pf_k_ffn_f16x2(const void* X2, const void* W1, const void* W2, const float* b1, const float* b2, float oscale1, float hscale,
+                   float oscale2, const float* R, float* Cout, const float* ln_g, const float* ln_b, float ln_eps, void* Y2,
+                   float yscale, float* Yf, int32_t M, int32_t F, int32_t iters, float* ms_out, void* stream);
 /* FSMN form of the full-row kernel: the first addend is the FSMN memory block (11 taps [512, 11], left padding 5;
  * funasr/models/sanm/attention.py:216-239) of the fp32 rows fs_v [M, 512], computed in the epilogue; fs_lo / fs_hi (device
  * int32 [M / 16]): valid input rows [lo, hi) of the sequence that owns each 16-row group. M % 16 == 0; ln_g / ln_b required */

@@ -325,13 +325,15 @@ def test_encoder_schedule_options_are_bitwise_equal(cuda, frames, packing):
     feats = (torch.randn(len(frames), max(frames), 560, generator=g) * 0.8).to(cuda)
     lens = torch.tensor(frames, dtype=torch.int32)
     outs = {}
-    for fuse_row, fsmn_fused, row_bm in ((0, 0, 0), (1, 0, 128), (1, 1, 128), (1, 1, 96), (1, 0, 96), (1, 1, 129), (1, 1, 0)):
-        enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused).set_option("row_bm", row_bm)
-        outs[(fuse_row, fsmn_fused, row_bm)] = enc(feats, lens)[0].clone()
-    base = outs[(0, 0, 0)]
+    # ffn_fused: 0 the w_1 -> w_2 pair, 2 the one-launch feed-forward (gemm_f16x2_ffn.hip) whatever the row count, 1 by the row count
+    for fuse_row, fsmn_fused, row_bm, ffn_fused in ((0, 0, 0, 0), (1, 0, 128, 0), (1, 1, 128, 0), (1, 1, 96, 0), (1, 0, 96, 0), (1, 1, 129, 0),
+                                                    (1, 1, 0, 0), (1, 1, 0, 2), (1, 0, 128, 2), (1, 1, 0, 1)):
+        enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused).set_option("row_bm", row_bm).set_option("ffn_fused", ffn_fused)
+        outs[(fuse_row, fsmn_fused, row_bm, ffn_fused)] = enc(feats, lens)[0].clone()
+    base = outs[(0, 0, 0, 0)]
     assert torch.isfinite(base).all() and base.abs().max().item() > 0.1
     for key, out in outs.items():
-        assert torch.equal(out, base), f"(fuse_row, fsmn_fused, row_bm) = {key} changes the encoder's bits"
+        assert torch.equal(out, base), f"(fuse_row, fsmn_fused, row_bm, ffn_fused) = {key} changes the encoder's bits"
 
 
 def _row_in_place(ops, a2, w2, bias, add1, x, se, gamma, beta, eps, ey):
@@ -488,3 +490,83 @@ def test_ctc_planes_follow_a_weight_reload(cuda):
         agree = (ids[(rnd, "f16x2")] == ids[(rnd, "fp32")]).float().mean().item()
         assert agree > 0.98, f"load {rnd}: f16x2 ids disagree with fp32 ids ({agree:.3f})"
     assert not torch.equal(ids[(0, "fp32")], ids[(1, "fp32")])
+
+
+def _ffn_case(M, F, cuda, seed=0):
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(900 + seed + M + F)
+    e_x, e_w1, e_h, e_w2 = 8, 12, 6, 12
+    xn = torch.randn(M, 512, generator=g)                                              # a LayerNorm output
+    w1 = torch.randn(F, 512, generator=g) * 512 ** -0.5 * torch.linspace(0.5, 1.5, F)[:, None]
+    w2 = torch.randn(512, F, generator=g) * F ** -0.5 * torch.linspace(1.5, 0.5, 512)[:, None]
+    b1 = torch.randn(F, generator=g) * 0.3
+    b2 = torch.randn(512, generator=g)
+    resid = torch.randn(M, 512, generator=g) * 4 + 1
+    gamma = torch.rand(512, generator=g) * 2 + 0.1
+    beta = torch.randn(512, generator=g)
+    t = dict(x2=ops.split2(xn.to(cuda), e_x), w1=ops.split2(w1.to(cuda), e_w1), w2=ops.split2(w2.to(cuda), e_w2), b1=b1.to(cuda),
+             b2=b2.to(cuda), resid=resid.to(cuda), gamma=gamma.to(cuda), beta=beta.to(cuda), e=(e_x, e_w1, e_h, e_w2))
+    return t
+
+
+@pytest.mark.parametrize("M", [70, 128, 500, 4000, 32768])
+@pytest.mark.parametrize("F", [2048, 1024])
+def test_fused_ffn_vs_the_two_kernel_pair_and_float64(cuda, M, F):
+    """gemm_f16x2_ffn.hip: x + w_2(relu(w_1 xn)) and the next LayerNorm in one launch, the hidden activations in registers
+    (funasr/models/transformer/positionwise_feed_forward.py:14-34, sanm/encoder.py:141-146) against (a) the pair
+    gemm_f16x2 (plane output) -> gemm_f16x2_row it replaces: bitwise where the matrix core sums a swapped-operand product
+    identically, else within 2^-22 of the result's scale; (b) float64 with the hidden planes' own rounding."""
+    from funasr_amd import ops
+    t = _ffn_case(M, F, cuda)
+    e_x, e_w1, e_h, e_w2 = t["e"]
+    eps, ey = 1e-12, 7
+    # (a) the pair
+    h2 = ops.gemm_f16x2(t["x2"], t["w1"], t["b1"], relu=True, scale_exp=e_x + e_w1, out_planes=True, out_scale_exp=e_h)
+    c_ref, y_ref = ops.gemm_f16x2_row(h2, t["w2"], t["b2"], add2=t["resid"], scale_exp=e_h + e_w2, ln=(t["gamma"], t["beta"], eps),
+                                      out_scale_exp=ey)
+    c, y = ops.ffn_f16x2(t["x2"], t["w1"], t["w2"], t["b1"], t["b2"], t["resid"], e_x, e_w1, e_h, e_w2, ln=(t["gamma"], t["beta"], eps),
+                         out_scale_exp=ey)
+    scale = c_ref.abs().max().item()
+    d = (c - c_ref).abs().max().item()
+    bitwise = torch.equal(c, c_ref) and torch.equal(y, y_ref)
+    yv, yr = _planes_value(y) * 2.0 ** -ey, _planes_value(y_ref) * 2.0 ** -ey
+    print(f"[M={M} F={F}] fused vs pair: fp32 stream max |d| {d:.3e} (scale {scale:.2f}), LayerNorm planes max |d| "
+          f"{(yv - yr).abs().max().item():.3e}, bitwise {bitwise}")
+    # the block-level choice between the pair and the fused launch depends on the batch's row count (engine.hip ffn_fills_rounds),
+    # so a clip's bits must not depend on it: BITWISE, stream and planes
+    assert bitwise
+    # (b) float64 of what the kernel is specified to compute: hidden planes rounded like w_1's plane epilogue
+    x64, w164, w264 = _planes_value(t["x2"]), _planes_value(t["w1"]), _planes_value(t["w2"])
+    h64 = torch.relu((x64 @ w164.T) * 2.0 ** -(e_x + e_w1) + t["b1"].double())
+    mag1 = (x64.abs() @ w164.abs().T) * 2.0 ** -(e_x + e_w1)
+    ref = (h64 @ w264.T) * 2.0 ** -e_w2 + t["b2"].double() + t["resid"].double()
+    mag2 = (h64.abs() @ w264.abs().T) * 2.0 ** -e_w2 + (mag1 @ w264.abs().T) * 2.0 ** -e_w2
+    tol = 4e-7 * mag2 + 2.5e-7 * ref.abs() + 1e-6
+    assert ((c.double() - ref).abs() <= tol).all(), float(((c.double() - ref).abs() / tol).max())
+    ln64 = torch.nn.functional.layer_norm(ref, (512,), t["gamma"].double(), t["beta"].double(), eps)
+    assert (yv - ln64).abs().max().item() < 2e-5 * max(1.0, ln64.abs().max().item())
+    # forms: fp32 LayerNorm output, no LayerNorm, in place, no b2
+    c2, yf = ops.ffn_f16x2(t["x2"], t["w1"], t["w2"], t["b1"], t["b2"], t["resid"], e_x, e_w1, e_h, e_w2, ln=(t["gamma"], t["beta"], eps),
+                           ln_planes=False)
+    assert torch.equal(c2, c) and (yf.double() - ln64).abs().max().item() < 2e-5 * max(1.0, ln64.abs().max().item())
+    c3, none = ops.ffn_f16x2(t["x2"], t["w1"], t["w2"], t["b1"], t["b2"], t["resid"], e_x, e_w1, e_h, e_w2)
+    assert none is None and torch.equal(c3, c)
+    x_ip = t["resid"].clone()
+    c4, y4 = ops.ffn_f16x2(t["x2"], t["w1"], t["w2"], t["b1"], t["b2"], x_ip, e_x, e_w1, e_h, e_w2, ln=(t["gamma"], t["beta"], eps),
+                           out_scale_exp=ey, in_place=True)
+    assert c4 is x_ip and torch.equal(x_ip, c) and torch.equal(y4, y)
+    c5, _ = ops.ffn_f16x2(t["x2"], t["w1"], t["w2"], t["b1"], None, t["resid"], e_x, e_w1, e_h, e_w2)
+    assert ((c5.double() + t["b2"].double() - ref).abs() <= tol + 1e-6).all()
+
+
+def test_fused_ffn_rows_are_independent_and_deterministic(cuda):
+    """a row's result does not depend on the batch around it (the utterance-DP premise) and repeats bit for bit"""
+    from funasr_amd import ops
+    t = _ffn_case(1000, 2048, cuda, seed=3)
+    e = t["e"]
+    c, _ = ops.ffn_f16x2(t["x2"], t["w1"], t["w2"], t["b1"], t["b2"], t["resid"], *e)
+    c_again, _ = ops.ffn_f16x2(t["x2"], t["w1"], t["w2"], t["b1"], t["b2"], t["resid"], *e)
+    assert torch.equal(c, c_again)
+    sub = slice(130, 517)
+    cs, _ = ops.ffn_f16x2(t["x2"][:, sub].contiguous(), t["w1"], t["w2"], t["b1"], t["b2"], t["resid"][sub].contiguous(), *e)
+    assert torch.equal(cs, c[sub])
