@@ -566,6 +566,9 @@ int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
+// NOTE (round 4): the two opt-in shapes below stage their operands behind COUNTED vmcnt waits (glds_wait_but). LDS-DMA pieces of one
+// wave were found to retire out of issue order when their sources differ (gemm_f16x2_ffn.hip header): these shapes pass the warm
+// kernel tests but are NOT safe inside a long pipeline. Measurement hooks only; no default path takes them.
 // the 128 x 256 four-wave shape, two workgroups per CU (tile 5; N % 256 == 0)
 template <int MODE, int OUT>
 int launch_pair(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 0, 2, 16>(a, stream); }

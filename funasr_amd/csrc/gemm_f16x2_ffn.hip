@@ -33,6 +33,25 @@
 // The xn tile (256 KB for 128 rows: more than the CU's LDS) is re-streamed from L2 for every chunk: 768 KB of L2 -> LDS per
 // chunk and workgroup, 3.1 GB per launch at M = 32768 against 2.3 GB for the two-kernel pair -- and 0.27 GB of HBM traffic
 // (xn planes + residual in, residual + next planes out, 8 MB of weights) against 1.07 GB.
+//
+// STATE (round 4, measured; profiles/r04_ffn_*): correct -- bitwise the two-kernel pair on the fp32 stream AND the LayerNorm
+// planes at every row count, in place, inside the 50-block encoder -- but NOT faster: 435-460 us against 455-480 us for the
+// pair at M = 32768 (same box), so the engine keeps the pair (encoder option "ffn_fused" = 0) and this kernel is opt-in. Why:
+//   * the kernel is bound by L2 -> LDS latency x bytes in flight, not by the matrix pipe: with the LDS-DMA pieces removed it runs
+//     265-297 us (the MFMA + LDS-read floor; 187 us at 100 % of the matrix rate), with ONLY the pieces and barriers 396 us. One
+//     wave sustains ~12 GB/s of LDS-DMA whatever the source (16 KB per ~1.4 us round trip; tools/micro/ldsdma_rate.hip: 12 / 22 / 41
+//     / 75 GB/s per CU with 1 / 2 / 4 / 8 waves of 16 pieces each, L2-, Infinity-Cache- and HBM-resident spans alike), i.e.
+//     throughput = bytes in flight / 1.4 us, and 160 KB of LDS hold at most three 32-KB slots in flight next to the one being read.
+//   * three slots in flight need COUNTED waits ("all but my newest N pieces have landed"), and those are WRONG on this hardware:
+//     the LDS-DMA pieces of one wave do not retire in issue order when their sources differ (L2 hit / Infinity Cache / HBM), so
+//     s_waitcnt vmcnt(N) can return while an OLDER piece is still in flight and the stage is multiplied with the ring buffer's
+//     previous contents -- plausible numbers, a few corrupted workgroups per thousand, invisible to warm micro-tests and found
+//     by the 50-block encoder (ABL 12 keeps that schedule for the record: 410 us, wrong results). The same hazard sits in the
+//     opt-in deep-ring shapes of gemm_f16x2.hip (tile 5 / 6). Exact waits -- s_waitcnt vmcnt(0) on everything the wave has in
+//     flight, as every default kernel of this library does -- leave ONE stage of cover, which ties the pair.
+//   * what would be needed: one owner wave per ring buffer (exact waits with three slots in flight) without per-piece branches --
+//     tried: 950 basic blocks, 590 us -- or operands that bypass LDS-DMA (xn fragments by plain loads: no registers left), or an
+//     interleaving of the two products across chunks (uniform 1 KB of DMA per MFMA; needs ~270 VGPRs). Not done.
 #include "common.h"
 #include <type_traits>
 
