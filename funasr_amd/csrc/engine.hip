@@ -284,33 +284,65 @@ static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // therefore goes through a ring of PINNED staging slots owned by the library: the bytes are copied into a slot at call time,
 // the DMA reads the slot, and a slot is reused only after the event recorded behind its copy has completed.
 struct StageRing {
-    struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
-    Slot slots[16];
+    // One ring PER DEVICE (round-3 review): an event belongs to the device it was created on, so a process-global ring broke
+    // as soon as handles lived on two devices. Slots are portable pinned memory; a free slot (its event has completed) is
+    // preferred over waiting, and a wait for a busy slot happens OUTSIDE the lock so that one busy stream does not stall the
+    // uploads of every other handle and thread.
+    struct Slot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; bool claimed = false; };
+    static constexpr int N = 16;
+    Slot slots[N];
     int next = 0;
     std::mutex mu;
     int upload(void* dst, const void* src, size_t bytes, hipStream_t s) {
         if (bytes == 0) return 0;
-        std::lock_guard<std::mutex> lock(mu);
-        Slot& sl = slots[next];
-        next = (next + 1) % 16;
-        if (sl.busy) { PF_HIP_TRY(hipEventSynchronize(sl.ev)); sl.busy = false; }
-        if (sl.cap < bytes) {
-            if (sl.p) (void)hipHostFree(sl.p);
-            sl.p = nullptr; sl.cap = 0;
-            const size_t want = bytes + bytes / 4 + 256;
-            PF_HIP_TRY(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
-            sl.cap = want;
+        Slot* sl = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            for (int k = 0; k < N && !sl; ++k) {                     // first slot whose last copy has completed
+                Slot& c = slots[(next + k) % N];
+                if (c.claimed) continue;
+                if (c.busy && hipEventQuery(c.ev) != hipSuccess) continue;
+                c.busy = false; sl = &c; next = (next + k + 1) % N;
+            }
+            for (int k = 0; k < N && !sl; ++k) {                     // none free: take the oldest unclaimed one and wait for it below
+                Slot& c = slots[(next + k) % N];
+                if (!c.claimed) { sl = &c; next = (next + k + 1) % N; }
+            }
+            if (!sl) { set_error("upload: every staging slot is claimed by another thread"); return -2; }
+            sl->claimed = true;
         }
-        if (!sl.ev) PF_HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-        memcpy(sl.p, src, bytes);
-        PF_HIP_TRY(hipMemcpyAsync(dst, sl.p, bytes, hipMemcpyHostToDevice, s));
-        PF_HIP_TRY(hipEventRecord(sl.ev, s));
-        sl.busy = true;
-        return 0;
+        int rc = 0;
+        auto fail = [&](const char* what) { set_error(std::string("upload: ") + what); rc = -2; };
+        if (sl->busy) { if (hipEventSynchronize(sl->ev) != hipSuccess) fail("event wait"); sl->busy = false; }
+        if (!rc && sl->cap < bytes) {
+            if (sl->p) (void)hipHostFree(sl->p);
+            sl->p = nullptr; sl->cap = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            if (hipHostMalloc(&sl->p, want, hipHostMallocPortable) != hipSuccess) fail("pinned allocation"); else sl->cap = want;
+        }
+        if (!rc && !sl->ev && hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming) != hipSuccess) fail("event creation");
+        if (!rc) {
+            memcpy(sl->p, src, bytes);
+            if (hipMemcpyAsync(dst, sl->p, bytes, hipMemcpyHostToDevice, s) != hipSuccess) fail("hipMemcpyAsync");
+            else if (hipEventRecord(sl->ev, s) != hipSuccess) fail("event record");
+            else sl->busy = true;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        sl->claimed = false;
+        return rc;
     }
 };
-static StageRing g_stage;
-static int upload_h2d(void* dst, const void* src, size_t bytes, hipStream_t s) { return g_stage.upload(dst, src, bytes, s); }
+static StageRing* stage_ring_for_current_device() {
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<StageRing>> rings;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto& r = rings[dev];
+    if (!r) r.reset(new StageRing());
+    return r.get();
+}
+static int upload_h2d(void* dst, const void* src, size_t bytes, hipStream_t s) { return stage_ring_for_current_device()->upload(dst, src, bytes, s); }
 
 static int upload_lens(DevBuf& buf, const int32_t* host, int B, hipStream_t s) {
     if (buf.ensure(sizeof(int32_t) * (size_t)B)) return -2;

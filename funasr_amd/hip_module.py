@@ -158,8 +158,17 @@ def host_i32(x, n=None):
 class HostCopyRing:
     """Device -> pinned-host copies that a later `wait()` can consume without waiting for work enqueued AFTER the copy: the copy
     and an event are put on the stream at enqueue time (a plain `.cpu()` at collect time is ordered behind everything enqueued
-    since, i.e. behind the whole next batch of a pipelined serving loop). A small ring of pinned buffers per (shape, dtype);
-    a buffer is reused `depth` copies later, so at most `depth - 1` batches may be in flight between enqueue and collect."""
+    since, i.e. behind the whole next batch of a pipelined serving loop). A small ring of pinned buffers per (shape, dtype).
+    A slot is OUTSTANDING from `start()` until the caller has finished with the tensor `wait()` returned -- marked by the next
+    `wait()` / `start()` on the same handle being impossible, i.e. by `release()` or by waiting on a LATER handle of the same
+    ring position. `start()` never hands out an outstanding slot (round-3 review: a serving loop with `depth` or more
+    same-shape batches in flight silently read ids a later batch had overwritten): it takes a fresh pinned buffer instead."""
+
+    class _Slot:
+        __slots__ = ("buf", "outstanding")
+
+        def __init__(self, buf):
+            self.buf, self.outstanding = buf, False
 
     def __init__(self, depth: int = 4):
         self.depth, self._bufs, self._next = depth, {}, {}
@@ -167,21 +176,33 @@ class HostCopyRing:
     def start(self, t: torch.Tensor):
         key = (tuple(t.shape), t.dtype)
         ring = self._bufs.setdefault(key, [])
-        i = self._next.get(key, 0)
-        if len(ring) <= i:
-            ring.append(torch.empty(t.shape, dtype=t.dtype, pin_memory=True))
-        self._next[key] = (i + 1) % self.depth
         if len(self._bufs) > 64:                                    # ragged serving loops: do not grow without bound
             self._bufs = {key: ring}
-            self._next = {key: self._next[key]}
-        host = ring[i]
-        host.copy_(t, non_blocking=True)
+            self._next = {key: self._next.get(key, 0)}
+        i = self._next.get(key, 0) % max(1, len(ring)) if ring else 0
+        slot = None
+        for k in range(len(ring)):                                  # the next slot nobody is still reading
+            cand = ring[(i + k) % len(ring)]
+            if not cand.outstanding:
+                slot, i = cand, (i + k) % len(ring)
+                break
+        if slot is None:                                            # every slot is in flight: grow (never overwrite)
+            slot = HostCopyRing._Slot(torch.empty(t.shape, dtype=t.dtype, pin_memory=True))
+            ring.append(slot)
+            i = len(ring) - 1
+        self._next[key] = i + 1
+        slot.outstanding = True
+        slot.buf.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(t.device))
-        return host, ev
+        return slot, ev
 
     @staticmethod
     def wait(handle) -> torch.Tensor:
-        host, ev = handle
+        """The host tensor of a finished copy. The slot is handed back to the ring here: the caller must be done with the tensor
+        (or have copied what it needs -- `collect()` turns it into Python lists at once) before the next `start()` on this
+        ring may reuse it; callers that keep the tensor call `.clone()`."""
+        slot, ev = handle
         ev.synchronize()
-        return host
+        slot.outstanding = False
+        return slot.buf

@@ -18,6 +18,8 @@ cross-attention caches and the fused vocabulary arg-max, captured once in a hipG
 """
 from __future__ import annotations
 
+import logging
+
 import ctypes as C
 import time
 from typing import List, Optional, Sequence
@@ -132,6 +134,7 @@ class StreamBatch:
     stream's result never depends on how many chunks its neighbours bring."""
 
     AUTO_F16X2_MIN_STREAMS: Optional[int] = 48
+    _announced: set = set()
 
     def __init__(self, model: "ParaformerStreaming", n_streams: int = 1, chunk_size: Sequence[int] = (0, 10, 5),
                  encoder_chunk_look_back: int = 4, decoder_chunk_look_back: int = 1, max_frames: int = None,
@@ -145,6 +148,13 @@ class StreamBatch:
         if precision is None:
             auto = self.AUTO_F16X2_MIN_STREAMS
             precision = "f16x2" if (auto is not None and n_streams >= auto) else "fp32"
+            # the two arithmetics are both fp32-class but not bit-identical (CIF sums sit ~1e-5 from a threshold about once per
+            # thousand clips): say which one a deployment got, once per (count, choice), so that results are
+            # reproducible by pinning `precision=` (ParaformerStreaming.inference / AutoModel.generate: stream_precision="fp32" | "f16x2")
+            if (n_streams, precision) not in StreamBatch._announced:
+                StreamBatch._announced.add((n_streams, precision))
+                logging.getLogger("funasr_amd").info("StreamBatch: %d stream(s) -> precision %r chosen by stream count "
+                                                      "(pass precision= to pin it)", n_streams, precision)
         if precision not in ("fp32", "f16x2"):
             raise ValueError(f"StreamBatch: precision must be 'fp32' or 'f16x2', got {precision!r}")
         self.precision = precision
@@ -260,7 +270,7 @@ class ParaformerStreaming(Paraformer):
             old.close()
         cache["_stream"] = StreamBatch(self, 1, kwargs.get("chunk_size", [0, 10, 5]),
                                        kwargs.get("encoder_chunk_look_back", 0), kwargs.get("decoder_chunk_look_back", 0),
-                                       use_graph=kwargs.get("use_graph", True))
+                                       use_graph=kwargs.get("use_graph", True), precision=kwargs.get("stream_precision"))
         cache["encoder"] = {"tail_chunk": False, "chunk_size": kwargs.get("chunk_size", [0, 10, 5])}
         cache["decoder"] = {}
         cache["frontend"] = {}

@@ -51,6 +51,18 @@ def test_sweep_two_ranks_equals_one_rank_in_corpus_order(cuda, tmp_path):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.xfail(strict=False, reason="OPEN ISSUE (DESIGN 4, round 3): with TWO PROCESSES time-sharing one GPU the frontend sporadically returns a wrong "
+                                        "frame (~1e-4 of frames); one process per GPU -- the deployment -- is deterministic. Kept visible here, un-serialised.")
+def test_sweep_two_ranks_sharing_one_gpu_without_serialising(cuda, tmp_path):
+    """the same comparison as above WITHOUT --serialize-gpu: both ranks interleave their kernels on the one GPU"""
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    common = ["--clips", "48", "--batch-seconds", "1", "--no-overlap"]
+    _run([sys.executable, "tools/sweep.py"] + common + ["--dump", one], 400)
+    _run(_torchrun(2, ["tools/sweep.py"] + common + ["--dist-backend", "gloo", "--dump", two]), 500)
+    assert json.load(open(one)) == json.load(open(two))
+
+
+@pytest.mark.timeout(900)
 def test_bench_two_ranks_prints_one_whole_job_line(cuda):
     out = _run(_torchrun(2, ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo"]), 600)
     lines = [l for l in out.splitlines() if l.startswith("{")]

@@ -87,3 +87,22 @@ def test_pipelined_enqueue_collect_equals_one_batch_at_a_time(cuda, family):
             assert r["token_num"] == ref["token_num"] and r["raw_ids"] == ref["raw_ids"]
         else:
             assert r["frame_ids"] == ref["frame_ids"]
+
+
+def test_host_copy_ring_never_overwrites_a_copy_nobody_collected(cuda):
+    """round-3 review: with `depth` or more same-shape batches in flight the ring reused a pinned buffer that an earlier handle
+    still pointed to. A slot is now outstanding from start() to wait(), and start() grows the ring instead of overwriting."""
+    from funasr_amd.hip_module import HostCopyRing
+    ring = HostCopyRing(depth=2)
+    handles = [ring.start(torch.full((4, 7), i, dtype=torch.int32, device=cuda)) for i in range(9)]      # nine batches in flight
+    assert len({h[0].buf.data_ptr() for h in handles}) == 9
+    for i, h in enumerate(handles):
+        assert HostCopyRing.wait(h).eq(i).all()
+    # collected slots are reused: a steady pipeline of depth 2 stays at the buffers it has
+    n = len(ring._bufs[((4, 7), torch.int32)])
+    prev = ring.start(torch.zeros(4, 7, dtype=torch.int32, device=cuda))
+    for i in range(20):
+        cur = ring.start(torch.full((4, 7), i, dtype=torch.int32, device=cuda))
+        HostCopyRing.wait(prev)
+        prev = cur
+    assert len(ring._bufs[((4, 7), torch.int32)]) == n
