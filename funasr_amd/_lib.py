@@ -184,6 +184,17 @@ SIGNATURES = {
     "pf_k_lstm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pf_k_cif": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pf_k_gemm_f32_time": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
+    # utterance data parallelism at the C ABI (dp_rccl.hip)
+    "pf_dp_unique_id": (C.c_int, [_vp, _i32]),
+    "pf_dp_create": (_vp, [_vp, _i32, _i32, _i32]),
+    "pf_dp_destroy": (C.c_int, [_vp]),
+    "pf_dp_world": (C.c_int, [_vp]),
+    "pf_dp_rank": (C.c_int, [_vp]),
+    "pf_dp_broadcast_encoder": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "pf_dp_broadcast_predictor": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "pf_dp_broadcast_decoder": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "pf_dp_broadcast_ctc": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "pf_dp_gather_ids": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp]),
     # profiling hooks used by bench.py (not part of the reference boundary)
     "pf_prof_enable": (C.c_int, [C.c_int]),
     "pf_prof_reset": (C.c_int, []),

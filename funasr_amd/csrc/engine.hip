@@ -21,6 +21,7 @@
 #include "common.h"
 #include "frontend.h"
 #include "stream.h"
+#include "engine_tables.h"
 
 namespace pf {
 
@@ -88,6 +89,11 @@ struct Tensor {
     int kind = 0;            // 0 plain copy, 1 pad rows [rows, cols] -> [rows, cols_pad], 2 conv [O, I, K] -> [O, K*I],
                              // 3 upsampling conv, 4 tiled vector (see add_upsample / add_tiled)
     int rows = 0, cols = 0, cols_pad = 0, taps = 0;
+    size_t device_elems() const {       // floats of the device image (repacked layouts differ from the source count)
+        if (kind == 1) return (size_t)rows * cols_pad;
+        if (kind == 4) return (size_t)rows * cols;
+        return (size_t)numel;
+    }
 };
 
 struct TensorTable {
@@ -1526,6 +1532,16 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     return 0;
 }
 
+
+// ---- engine_tables.h: the handles' weight storage for dp_rccl.hip
+TensorTable* table_of(int kind, void* h);     // defined at the end of the file (needs every handle type)
+int handle_tensor_spans(int kind, void* handle, std::vector<TensorSpan>& out) {
+    TensorTable* tt = handle ? table_of(kind, handle) : nullptr;
+    if (!tt) { set_error("dp: null handle or unknown handle kind"); return -1; }
+    out.clear();
+    for (auto& kv : tt->t) out.push_back({kv.first, kv.second.d, kv.second.device_elems(), kv.second.set});
+    return 0;
+}
 }  // namespace pf
 
 using namespace pf;
@@ -3490,3 +3506,28 @@ int pf_k_gemm_f32_time(const float* A, int32_t lda, const float* W, int32_t ldw,
 }
 
 }  // extern "C"
+
+// ---- engine_tables.h, second half: needs every handle type
+namespace pf {
+TensorTable* table_of(int kind, void* h) {
+    switch (kind) {
+        case HANDLE_ENCODER: return &reinterpret_cast<Encoder*>(h)->tt;
+        case HANDLE_PREDICTOR: return &reinterpret_cast<Predictor*>(h)->tt;
+        case HANDLE_DECODER: return &reinterpret_cast<Decoder*>(h)->tt;
+        case HANDLE_CTC: return &reinterpret_cast<Ctc*>(h)->tt;
+        case HANDLE_VAD: return &reinterpret_cast<Vad*>(h)->tt;
+        default: return nullptr;
+    }
+}
+int handle_weights_replaced(int kind, void* handle) {
+    TensorTable* tt = handle ? table_of(kind, handle) : nullptr;
+    if (!tt) { set_error("dp: null handle or unknown handle kind"); return -1; }
+    for (auto& kv : tt->t) kv.second.set = true;
+    ++tt->version;
+    tt->drop_bf16();
+    if (kind == HANDLE_ENCODER) reinterpret_cast<Encoder*>(handle)->resolved = false;
+    if (kind == HANDLE_DECODER) reinterpret_cast<Decoder*>(handle)->resolved = false;
+    if (kind == HANDLE_PREDICTOR) reinterpret_cast<Predictor*>(handle)->packed = false;
+    return 0;
+}
+}  // namespace pf

@@ -200,3 +200,93 @@ def recognize_sharded(decode: Callable[[List[int]], List[List[int]]], lengths: S
         for k, i in enumerate(shard):
             out[i] = gathered[r][k]
     return out
+
+
+# --------------------------------------------------------------------------------------------- the same split at the C ABI
+class DeviceComm:
+    """RCCL communicator of the C ABI (include/paraformer_hip.h pf_dp_*, csrc/dp_rccl.hip): what a host WITHOUT torch.distributed
+    binds for the multi-GPU split -- the weights go rank `src` -> every rank straight into the module handles' HBM (one grouped
+    broadcast per handle: no packed host arena, no nn.Parameter copy, no re-upload), the hypotheses come back through
+    `pf_dp_gather_ids`. One process per GPU; the 128-byte unique id travels over any channel (`share_id`).
+
+    `share_id(id_or_None) -> id`: called with the id on rank 0 and with None elsewhere, returns the id on every rank."""
+
+    _KIND = {"pf_encoder": "encoder", "pf_predictor": "predictor", "pf_decoder": "decoder", "pf_ctc": "ctc"}
+
+    def __init__(self, world: int, rank: int, device: torch.device, share_id: Callable):
+        import ctypes as C
+        from . import _lib
+        self._lib, self.world, self.rank, self.device = _lib.load(), int(world), int(rank), torch.device(device)
+        ident = None
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            _lib.check(min(0, self._lib.pf_dp_unique_id(buf, 128)), "pf_dp_unique_id")
+            ident = bytes(buf)
+        ident = share_id(ident)
+        if not isinstance(ident, (bytes, bytearray)) or len(ident) != 128:
+            raise ValueError("DeviceComm: share_id must return the 128-byte id on every rank")
+        with torch.cuda.device(self.device):
+            self._h = _lib.check_handle(self._lib.pf_dp_create(C.c_char_p(bytes(ident)), 128, self.world, self.rank), "pf_dp_create")
+
+    @classmethod
+    def from_process_group(cls, device: torch.device) -> "DeviceComm":
+        """the id is shared through the default torch.distributed group (gloo or nccl: bootstrap only)"""
+        def share(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return cls(dist.get_world_size(), dist.get_rank(), device, share)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None:
+            self._lib.pf_dp_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def broadcast_module(self, m, src: int = 0) -> None:
+        """one HipModule (encoder / predictor / decoder / CTC mirror): rank `src`'s weights -> the handle of every rank, in place.
+        The HANDLE is authoritative afterwards; the nn.Parameters of the other ranks keep their old host-side values."""
+        from . import _lib
+        from .hip_module import stream_ptr
+        kind = self._KIND.get(getattr(m, "_prefix", ""))
+        if kind is None:
+            raise TypeError(f"DeviceComm.broadcast_module: {type(m).__name__} has no device handle of a known kind")
+        lib, h = m._ensure_handle()                       # root: pushes its parameters; others: creates the (empty) handle
+        with torch.cuda.device(self.device):
+            _lib.check(getattr(lib, "pf_dp_broadcast_" + kind)(self._h, h, int(src), stream_ptr()), "pf_dp_broadcast_" + kind)
+        m._dirty = False                                  # do not push the stale host parameters over the broadcast weights
+
+    def gather_ids(self, packed: torch.Tensor, dst: int = 0):
+        """packed: int32 device tensor, same shape on every rank -> on `dst` a [world, *shape] int32 device tensor, else None"""
+        from . import _lib
+        from .hip_module import stream_ptr
+        assert packed.dtype == torch.int32 and packed.is_cuda and packed.is_contiguous()
+        out = torch.empty((self.world,) + tuple(packed.shape), dtype=torch.int32, device=packed.device) if self.rank == dst else None
+        _lib.check(self._lib.pf_dp_gather_ids(self._h, packed.data_ptr(), packed.numel(), out.data_ptr() if out is not None else None,
+                                              int(dst), stream_ptr()), "pf_dp_gather_ids")
+        return out
+
+
+def broadcast_model_device(model: torch.nn.Module, comm: DeviceComm, src: int = 0) -> int:
+    """`broadcast_model` through the C ABI: every HipModule's weights go straight into its handle (DeviceComm.broadcast_module);
+    parameters that live outside the handles (e.g. SenseVoiceSmall.embed, the query-frame table the host gathers from) take the
+    torch.distributed route. Returns the bytes moved into handles."""
+    from .hip_module import HipModule
+    moved, inside = 0, set()
+    for m in model.modules():
+        if isinstance(m, HipModule) and getattr(m, "_prefix", "") in DeviceComm._KIND:
+            comm.broadcast_module(m, src)
+            for p in m.parameters():
+                inside.add(id(p))
+                moved += p.numel() * 4
+    rest = [p for p in model.parameters() if id(p) not in inside]
+    if rest and dist.is_available() and dist.is_initialized():
+        arena = _collective_device(pack_arena(rest))
+        dist.broadcast(arena, src=src)
+        unpack_arena(arena.to(rest[0].device), rest)
+    return moved

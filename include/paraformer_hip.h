@@ -343,6 +343,37 @@ int pf_stream_step(pf_stream* s, const float* feats_dev, int32_t n_frames, int32
 /* debug / parity: carried CIF state and position counter (any pointer may be NULL) */
 int pf_stream_peek(pf_stream* s, float* cif_alpha_host, float* cif_hidden_host, int32_t* start_idx_host);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Utterance-level data parallelism over the GPUs of one node (dp_rccl.hip): ONE PROCESS PER GPU, RCCL over xGMI.
+ * Replaces the reference's multi-GPU recipe -- one inference process per GPU over a split wav.scp, the outputs concatenated
+ * (examples/aishell/paraformer/run.sh:135-190) -- for hosts that bind this header directly; funasr_amd/dp.py is the same
+ * split on torch.distributed. The path shards over independent clips: there is NO collective on the data path. The two
+ * exchanges: the weights once (rank `root` -> every rank, written straight into the handles' device storage) and a gather of
+ * fixed-stride int32 hypotheses per batch.
+ *   rank 0:      n = pf_dp_unique_id(id, 128)            -> ship the 128 bytes to the other ranks (any channel: a file, MPI, a socket)
+ *   every rank:  hipSetDevice(local_rank); dp = pf_dp_create(id, 128, world, rank)     (collective: all ranks call it)
+ *                pf_dp_broadcast_encoder(dp, enc, 0, stream) ... _predictor / _decoder / _ctc   (collective; handles built from
+ *                                                                  the same config on every rank, tensors set on the root only)
+ *                per batch: pf_dp_gather_ids(dp, my_ids_dev, n, all_ids_dev_on_root, 0, stream)
+ * RCCL is loaded on first use (dlopen): without it every pf_dp_* call fails with pf_last_error() and nothing else changes. */
+typedef struct pf_dp pf_dp;
+/* rank 0 only: fills the 128-byte RCCL unique id; returns 128, or < 0 */
+int pf_dp_unique_id(void* id_out, int32_t cap);
+/* communicator of `world` ranks on the CURRENT device (one rank per device; collective). NULL on failure. */
+pf_dp* pf_dp_create(const void* unique_id, int32_t id_bytes, int32_t world, int32_t rank);
+int pf_dp_destroy(pf_dp* dp);
+int pf_dp_world(const pf_dp* dp);
+int pf_dp_rank(const pf_dp* dp);
+/* rank `root`'s weights -> the same handle on every rank, in place in library-owned HBM (one grouped broadcast over the
+ * handle's tensors); every tensor must be set on the root; on return (stream synchronised) the handle is ready on all ranks */
+int pf_dp_broadcast_encoder(pf_dp* dp, pf_encoder* e, int32_t root, void* stream);
+int pf_dp_broadcast_predictor(pf_dp* dp, pf_predictor* p, int32_t root, void* stream);
+int pf_dp_broadcast_decoder(pf_dp* dp, pf_decoder* d, int32_t root, void* stream);
+int pf_dp_broadcast_ctc(pf_dp* dp, pf_ctc* c, int32_t root, void* stream);
+/* ids_dev: `count` int32 on this rank's device (e.g. [B, 1 + n_pad]: token count, then ids); out_dev (root only):
+ * world * count int32, rank r's block at r * count. Enqueued on `stream`; does not synchronise. */
+int pf_dp_gather_ids(pf_dp* dp, const int32_t* ids_dev, int64_t count, int32_t* out_dev, int32_t root, void* stream);
+
 /* online frontend pieces (WavFrontendOnline, wav_frontend.py:395-505): log-mel of one buffer, and LFR + CMVN over a
  * frame buffer that already carries its left context */
 int pf_frontend_fbank(pf_frontend* f, const float* wav_dev, int64_t n_samples, float* fbank_dev, void* stream);

@@ -58,3 +58,20 @@ def test_modules_refuse_cpu_tensors():
     model = Paraformer.from_config(cfg)                      # parameters on cpu
     with pytest.raises(RuntimeError, match="AMD GPU"):
         model.encoder(torch.zeros(1, 8, 560), [8])
+
+
+def test_dp_entry_points_exist_and_fail_cleanly_without_a_gpu():
+    """include/paraformer_hip.h pf_dp_*: the C-ABI form of the multi-GPU split (weights broadcast into the handles, hypotheses
+    gathered). No GPU here: a communicator cannot be made, and the calls must say so instead of crashing."""
+    import ctypes as C
+    from funasr_amd import _lib
+    lib = _lib.load()
+    for name in ("pf_dp_unique_id", "pf_dp_create", "pf_dp_destroy", "pf_dp_world", "pf_dp_rank", "pf_dp_broadcast_encoder",
+                 "pf_dp_broadcast_predictor", "pf_dp_broadcast_decoder", "pf_dp_broadcast_ctc", "pf_dp_gather_ids"):
+        assert hasattr(lib, name), name
+    assert lib.pf_dp_world(None) == -1 and lib.pf_dp_rank(None) == -1 and lib.pf_dp_destroy(None) == 0
+    assert lib.pf_dp_create(None, 128, 1, 0) is None                       # bad arguments -> NULL + message
+    assert lib.pf_last_error()
+    buf = (C.c_char * 128)()
+    assert lib.pf_dp_unique_id(buf, 16) < 0                                # short buffer refused
+    assert lib.pf_dp_gather_ids(None, None, 4, None, 0, None) != 0

@@ -97,3 +97,30 @@ def test_bench_refuses_a_world_size_other_than_gpus(cuda):
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=ROOT,
                        env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_c_abi_communicator_broadcasts_into_the_handles_and_gathers(cuda):
+    """pf_dp_* (dp_rccl.hip) through RCCL itself, with the one rank a single-GPU box allows: unique id -> communicator ->
+    grouped in-place broadcast over an encoder handle's tensors (the handle must come out unchanged and usable, with every
+    derived plane re-made) -> gather of packed hypotheses. Multi-rank behaviour is RCCL's; what is ours is the handle plumbing."""
+    import torch
+    from funasr_amd import dp, synth
+    from funasr_amd.sanm_encoder import SANMEncoder
+    ec = dict(synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2)["encoder"])
+    enc = SANMEncoder(**ec, input_layer="pe")
+    enc.load_state_dict(synth.encoder_state_dict(ec, seed=5), strict=False)
+    enc = enc.to(cuda).set_precision("f16x2")
+    g = torch.Generator().manual_seed(3)
+    feats = (torch.randn(2, 40, 560, generator=g) * 0.8).to(cuda)
+    lens = torch.tensor([40, 23], dtype=torch.int32)
+    before = enc(feats, lens)[0].clone()
+    comm = dp.DeviceComm(1, 0, cuda, lambda ident: ident)
+    assert comm.world == 1 and comm.rank == 0
+    comm.broadcast_module(enc, src=0)
+    assert torch.equal(enc(feats, lens)[0], before)
+    packed = dp.pack_hypotheses([[5, 6, 7], [], [9]], 8, device=cuda).to(torch.int32).contiguous()
+    out = comm.gather_ids(packed, dst=0)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3, 9) and torch.equal(out[0], packed)
+    assert dp.unpack_hypotheses(out[0]) == [[5, 6, 7], [], [9]]
+    comm.close()
