@@ -294,9 +294,8 @@ class AutoModel:
             if fe_cls is None:
                 raise KeyError(f"frontend {frontend!r} is not registered: {sorted(tables.frontend_classes)}")
             fconf = dict(kwargs.get("frontend_conf") or {})
-            if float(fconf.get("dither", 0.0) or 0.0) != 0.0:
-                logging.warning("frontend_conf.dither=%s overridden to 0.0 (deterministic HIP frontend)", fconf["dither"])
-            fconf["dither"] = 0.0
+            # frontend_conf.dither is honoured (kaldi.fbank's per-sample Gaussian noise, drawn on the device from a seeded
+            # counter-based generator: funasr_amd/wav_frontend.py); configs that do not set it get this class's default 0
             frontend = fe_cls(device=None if device == "cpu" else device, **fconf)
             kwargs["input_size"] = frontend.output_size()
         kwargs["frontend"] = frontend

@@ -411,6 +411,7 @@ struct Frontend {
     DevBuf fbank, nfr;
     bool has_cmvn = false;
     int feat_dim() const { return cfg.n_mels * cfg.lfr_m; }
+    float dither = 0.f; unsigned long long dither_seed = 0; unsigned dither_calls = 0;   // pf_frontend_set_dither
 };
 
 static float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
@@ -1659,6 +1660,12 @@ int pf_frontend_set_cmvn(pf_frontend* fh, const float* shift, const float* scale
     return 0;
 }
 
+int pf_frontend_set_dither(pf_frontend* fh, float dither, uint64_t seed) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    PF_REQUIRE(f && dither >= 0.f, "frontend_set_dither: null handle or negative dither");
+    f->dither = dither; f->dither_seed = seed; f->dither_calls = 0;
+    return 0;
+}
 int pf_frontend_set_tables(pf_frontend* fh, const float* window, const float* mel) {
     Frontend* f = reinterpret_cast<Frontend*>(fh);
     PF_REQUIRE(f && window && mel, "frontend_set_tables: null");
@@ -1708,6 +1715,7 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
+    a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
     int rc;
     {
         double bytes = 0;
@@ -3108,6 +3116,7 @@ int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, 
     a.in_scale = f->cfg.upscale; a.preemph = f->cfg.preemph; a.window = f->window.as<float>();
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
+    a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
     return launch_fbank(a, 1, nfr, s);
 }
 

@@ -21,6 +21,13 @@ struct FbankArgs {
     const int* mel_first;        // device [n_mels] first piece of mel m
     const int* mel_count;        // device [n_mels] pieces of mel m
     int n_pieces;                // <= 128
+    // dither != 0: Gaussian noise of this standard deviation added to every sample OF EVERY FRAME (after the 2^15 scaling,
+    // before DC removal) -- kaldi.fbank's `dither`, wav_frontend.py:106,171-181: independent draws per (frame, sample), so the
+    // overlap of two frames gets two different noises. Counter-based generator (Philox4x32-10 keyed by seed, counted by
+    // (call, frame, sample pair)): the same seed and call index reproduce the features bit for bit.
+    float dither;
+    unsigned long long seed;     // key
+    unsigned int call;           // launch counter (a new noise field per forward, like the reference's advancing torch.randn)
 };
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream);
 

@@ -39,6 +39,29 @@ __device__ __forceinline__ void bfly4(float2 (&v)[4], const float2 (&tw)[3]) {
     v[3] = make_float2(y3.x * tw[2].x - y3.y * tw[2].y, y3.x * tw[2].y + y3.y * tw[2].x);
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter -> 4 x 32 random bits, no state. Two Box-Muller pairs -> 4 standard normals.
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void normal4(const unsigned (&u)[4], float (&z)[4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(u[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1)
+        const float u2 = ((float)(u[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
+    }
+}
+
 // One PERSISTENT wave per stream of frames. The 512-point real FFT is a 256-point complex FFT of z[n] = x[2n] + i x[2n+1]
 // (radix-4, decimation in frequency, 4 stages) followed by the real-input split: lane l holds z[l + 64 j] in registers,
 // the butterflies of every stage are lane-local, and between stages the wave regroups its 256 values through its own
@@ -46,6 +69,7 @@ __device__ __forceinline__ void bfly4(float2 (&v)[4], const float2 (&tw)[3]) {
 // only ever touches its own slice and its DS operations execute in order. Everything that does not change from frame to
 // frame lives in registers for the life of the wave: window coefficients, stage twiddles, and the weights of the (at
 // most two) mel-triangle pieces this lane accumulates.
+template <bool DITHER>
 __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_frames) {
     __shared__ float2 zs[WAVES_PER_BLOCK][NFFT / 2];          // exchange buffer / spectrum Z in natural order
     __shared__ float ps[WAVES_PER_BLOCK][NBIN + 7];           // power spectrum (+ zero tail for clamped piece reads)
@@ -119,14 +143,29 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
         fetch(g + n_waves, ne, no);
         if (f >= p.n_frames[b]) continue;                      // wave-uniform
 
-        // ---- scale; DC removal (feature-window.cc:186-196)
-        float s = 0.f;
+        // ---- scale; dither (kaldi.fbank: strided_input + randn * dither, before the DC removal); DC removal (feature-window.cc:186-196)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             xe[j] = xe[j] * p.in_scale;
             xo[j] = xo[j] * p.in_scale;
-            s += xe[j] + xo[j];
         }
+        if constexpr (DITHER) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {                   // one Philox call = 4 normals = the sample pairs j = 2 jj, 2 jj + 1
+                unsigned u[4];
+                float zn[4];
+                philox4x32((unsigned)g, (unsigned)(lane + 64 * jj), p.call, 0x5eedu, (unsigned)p.seed, (unsigned)(p.seed >> 32), u);
+                normal4(u, zn);
+                const int i0 = 2 * (lane + 64 * (2 * jj)), i1 = 2 * (lane + 64 * (2 * jj + 1));
+                if (i0 < p.frame_len) xe[2 * jj] += p.dither * zn[0];
+                if (i0 + 1 < p.frame_len) xo[2 * jj] += p.dither * zn[1];
+                if (i1 < p.frame_len) xe[2 * jj + 1] += p.dither * zn[2];
+                if (i1 + 1 < p.frame_len) xo[2 * jj + 1] += p.dither * zn[3];
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += xe[j] + xo[j];
         s = wave_sum(s);
         const float mean = s / (float)p.frame_len;
         // ---- pre-emphasis y[i] = x[i] - 0.97 x[i-1], x[-1] := x[0] (:204-215), then the window
@@ -265,7 +304,8 @@ int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t
     // persistent waves: enough workgroups to fill every CU several times over, each wave strides over the frames
     long long blocks = (total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks > 256 * 4) blocks = 256 * 4;      // 4 workgroups x 4 waves per CU = the 128-VGPR occupancy
-    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    if (a.dither != 0.f) hipLaunchKernelGGL(fbank_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
+    else hipLaunchKernelGGL(fbank_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, a, (int)total);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

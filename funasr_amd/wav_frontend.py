@@ -3,9 +3,11 @@
 Host-side mirror of funasr/frontends/wav_frontend.py:89-196 (`WavFrontend`, registered as "WavFrontend" /
 "wav_frontend" in `frontend_classes`), same constructor keywords, `output_size()`, and
 `forward(input [B, n], input_lengths [B]) -> (feats [B, T, n_mels*lfr_m], feats_lens [B])`.
-Differences, on purpose: the whole batch is one launch instead of a Python loop over utterances, the result stays
-in HBM, and `dither` must be 0 (the reference default of 1.0 adds Gaussian noise per sample and is therefore not
-reproducible; its own C++ runtime pins 0, runtime/onnxruntime/src/paraformer.cpp:24).
+Differences, on purpose: the whole batch is one launch instead of a Python loop over utterances and the result stays in
+HBM. `dither` (the reference default is 1.0: Gaussian noise per frame sample from torch.randn, wav_frontend.py:106,171-181)
+is drawn inside the fbank kernel from a counter-based generator keyed by `dither_seed`: the same seed reproduces the same
+feature sequence; parity with the reference's noise is statistical by nature. `dither=0` (this class's default, and what
+the reference's own C++ runtime pins, runtime/onnxruntime/src/paraformer.cpp:24) is the deterministic parity mode.
 """
 from __future__ import annotations
 
@@ -67,15 +69,15 @@ class WavFrontend(nn.Module):
                  frame_length: int = 25, frame_shift: int = 10, filter_length_min: int = -1,
                  filter_length_max: int = -1, lfr_m: int = 1, lfr_n: int = 1, dither: float = 0.0,
                  snip_edges: bool = True, upsacle_samples: bool = True, cmvn: torch.Tensor = None,
-                 device=None, **kwargs):
+                 device=None, dither_seed: int = None, **kwargs):
         super().__init__()
         if window != "hamming":
             raise NotImplementedError("only the hamming window of the Paraformer/SenseVoice recipes is built")
         if not snip_edges:
             raise NotImplementedError("snip_edges=False is not built")
-        if float(dither) != 0.0:
-            raise ValueError("dither must be 0.0: the HIP frontend is deterministic (the reference default 1.0 is "
-                             "random noise; its C++ runtime also uses 0, runtime/onnxruntime/src/paraformer.cpp:24)")
+        if float(dither) < 0.0:
+            raise ValueError("dither must be >= 0")
+        self.dither_seed = int(torch.initial_seed() if dither_seed is None else dither_seed) & 0xFFFFFFFFFFFFFFFF
         self.fs, self.window, self.n_mels = fs, window, n_mels
         self.frame_length, self.frame_shift = frame_length, frame_shift
         self.filter_length_min, self.filter_length_max = filter_length_min, filter_length_max
@@ -104,6 +106,8 @@ class WavFrontend(nn.Module):
             h = _lib.check_handle(lib.pf_frontend_create(C.byref(cfg)), "pf_frontend_create")
             w, mel = kaldi_tables(self.n_mels, win, float(self.fs))
             _lib.check(lib.pf_frontend_set_tables(h, w.data_ptr(), mel.data_ptr()), "pf_frontend_set_tables")
+            if float(self.dither) != 0.0:
+                _lib.check(lib.pf_frontend_set_dither(h, float(self.dither), self.dither_seed), "pf_frontend_set_dither")
             if self.cmvn is not None:
                 c = self.cmvn.to(torch.float32).contiguous().cpu()
                 dim = self.output_size()

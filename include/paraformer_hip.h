@@ -76,6 +76,11 @@ pf_frontend* pf_frontend_create(const pf_frontend_config* cfg);
 void pf_frontend_destroy(pf_frontend* f);
 /* CMVN rows of am.mvn (<AddShift>, <Rescale>; wav_frontend.py:15-60): y = (x + shift) * scale. n = n_mels*lfr_m */
 int pf_frontend_set_cmvn(pf_frontend* f, const float* shift_host, const float* scale_host, int32_t n);
+/* kaldi.fbank's `dither` (wav_frontend.py:106,171-181; the reference default is 1.0): Gaussian noise of that standard deviation
+ * on every sample of every frame, after the 2^15 scaling. 0 (default) = deterministic features. Noise comes from a counter-based
+ * generator keyed by `seed` and the number of forwards since this call: the same seed gives the same feature sequence. Parity
+ * with the reference is statistical by nature (its noise is torch.randn). */
+int pf_frontend_set_dither(pf_frontend* f, float dither, uint64_t seed);
 /* Optional: override the built-in Kaldi tables (float64 cos window, float32 mel triangles as in
  * kaldi-native-fbank feature-window.cc:25-47, mel-computations.cc:118-210) with caller-computed ones, e.g. the
  * float32 tables torchaudio.compliance.kaldi builds. window: [frame_length]; mel: dense [n_mels, 257]. */

@@ -56,7 +56,7 @@ def kaldi_mel_banks(num_bins: int, padded_window: int, sample_freq: float, low_f
 
 def kaldi_fbank(waveform: Tensor, num_mel_bins: int = 80, frame_length_ms: float = 25.0, frame_shift_ms: float = 10.0,
                 sample_frequency: float = 16000.0, preemphasis: float = 0.97, low_freq: float = 20.0,
-                high_freq: float = 0.0) -> Tensor:
+                high_freq: float = 0.0, dither: float = 0.0, generator=None) -> Tensor:
     """Kaldi `compute-fbank-feats` for a [n] float32 waveform (already scaled by 32768), options fixed to what
     WavFrontend passes (funasr/frontends/wav_frontend.py:171-181): dither 0, snip_edges, remove_dc_offset,
     hamming, power spectrum, log, energy_floor 0, no energy column. Evaluated the way
@@ -72,6 +72,10 @@ def kaldi_fbank(waveform: Tensor, num_mel_bins: int = 80, frame_length_ms: float
         return torch.zeros(0, num_mel_bins)
     m = 1 + (n - window_size) // window_shift                      # snip_edges (feature-window.cc:76-90)
     frames = wave.as_strided((m, window_size), (window_shift, 1)).clone()
+    if dither != 0.0:
+        # torchaudio.compliance.kaldi._get_window: strided_input + randn(strided_input.shape) * dither -- one draw per
+        # (frame, sample), before the DC removal (the reference default, wav_frontend.py:106; statistical parity only)
+        frames = frames + torch.randn(frames.shape, generator=generator) * dither
     frames = frames - frames.mean(dim=1, keepdim=True)              # remove_dc_offset (:186-196)
     prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)        # x[-1] := x[0]  (:204-215)
     frames = frames - preemphasis * prev

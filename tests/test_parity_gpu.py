@@ -632,3 +632,38 @@ def test_bf16_operand_decoder_stays_close_to_fp32_decoder(cuda):
     assert d.mean().item() < 0.03 * scale, (d.mean().item(), scale)
     same = (ids16.cpu()[valid] == ids32.cpu()[valid]).float().mean().item()
     assert same >= 0.7, same
+
+
+def test_frontend_dither_is_seeded_noise_with_the_reference_statistics(cuda):
+    """`dither` (kaldi.fbank, reference default 1.0: wav_frontend.py:106,171-181; torchaudio adds randn * dither to every sample of
+    every frame before the DC removal). The HIP frontend draws it from a counter-based generator: (a) dither = 0 is the
+    deterministic path, untouched; (b) one seed -> one feature sequence, another seed -> another; (c) parity is statistical: on
+    silence the log-mel energies are those of pure noise -- per-bin mean and spread equal the oracle's (torch.randn) within
+    sampling error; on speech-like audio the dithered features stay as close to the clean ones as the oracle's do."""
+    from funasr_amd.wav_frontend import WavFrontend
+    from oracle import paraformer_oracle as O
+    n = 16000 * 20
+    silence = torch.zeros(1, n)
+    speech = synth.speech_like(n, seed=7)[None]
+    def feats(w, dither, seed=11, calls=1):
+        fe = WavFrontend(cmvn=None, lfr_m=1, lfr_n=1, dither=dither, dither_seed=seed, device=cuda)
+        out = [fe(w.to(cuda), [n])[0][0].cpu() for _ in range(calls)]
+        return out if calls > 1 else out[0]
+    clean = feats(speech, 0.0)
+    assert torch.equal(clean, feats(speech, 0.0, seed=99))                          # (a)
+    a1, a2 = feats(speech, 1.0, seed=11, calls=2)
+    b1 = feats(speech, 1.0, seed=11)
+    c1 = feats(speech, 1.0, seed=12)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2) and not torch.equal(a1, c1)   # (b): seed + call index
+    g = torch.Generator().manual_seed(5)
+    ref_sil = O.kaldi_fbank(silence[0] * 32768, dither=1.0, generator=g)
+    got_sil = feats(silence, 1.0)
+    assert got_sil.shape == ref_sil.shape and got_sil.shape[0] > 1900
+    # (c) ~2000 frames: the per-bin mean of a log chi-square-like variable has a standard error of ~0.01-0.03
+    assert (got_sil.mean(0) - ref_sil.mean(0)).abs().max().item() < 0.08, (got_sil.mean(0) - ref_sil.mean(0)).abs().max().item()
+    assert (got_sil.std(0) / ref_sil.std(0) - 1).abs().max().item() < 0.15
+    ref_noisy = O.kaldi_fbank(speech[0] * 32768, dither=1.0, generator=g)
+    ref_clean = O.kaldi_fbank(speech[0] * 32768)
+    d_ref = (ref_noisy - ref_clean).abs().mean().item()
+    d_got = (a1 - clean).abs().mean().item()
+    assert d_got < 2.0 * d_ref + 1e-3 and d_got > 0.3 * d_ref, (d_got, d_ref)
