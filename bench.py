@@ -488,6 +488,28 @@ def run_sensevoice(device, args):
         dt = time.perf_counter() - t0
         out[mode] = dict(value=round(Bs * secs * steps / dt, 1), ms_per_step=round(dt / steps * 1e3, 2), res=r, mode=mode)
     main, ref32 = list(out.values())
+    # roofline of this leg's dominant kernel (the same split-operand GEMMs), from an instrumented pass in the main mode
+    roof = None
+    try:
+        from funasr_amd import _lib
+        lib = _lib.load()
+        model.set_precision(main["mode"])
+        run_steps(1)
+        torch.cuda.synchronize()
+        lib.pf_prof_reset(); lib.pf_prof_enable(1)
+        run_steps(steps)
+        torch.cuda.synchronize()
+        lib.pf_prof_enable(0)
+        prof = read_prof(lib, steps)
+        g = prof["gemm_split"] if main["mode"] in PRODUCTS else prof["gemm_f32_mfma"]
+        peak = PEAK_16BIT_MFMA_TFLOPS / PRODUCTS[main["mode"]] if main["mode"] in PRODUCTS else PEAK_F32_MFMA_TFLOPS
+        ach = g["work_per_step"] / (g["ms_per_step"] * 1e-3) / 1e12 if g["ms_per_step"] > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_f16x2_kernel + gemm_f16x2_row_kernel", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "launches_per_step": g["launches_per_step"], "gemm_ms_per_step": round(g["ms_per_step"], 2),
+                "attention_ms_per_step": round(prof["attention"]["ms_per_step"], 2), "traffic": None,
+                "by_call_site": read_prof_tags(lib, steps, peak)[:5]}
+    except Exception as e:                                   # noqa: BLE001  (the roofline of a secondary leg must not lose its line)
+        roof = {"error": repr(e)}
     ok, ncpu = None, 0
     if not args.no_cpu_baseline:
         from oracle import paraformer_oracle as O
@@ -503,7 +525,7 @@ def run_sensevoice(device, args):
             "config": {"workload": f"SenseVoiceSmall (70 SAN-M blocks, CTC 25055, random-init), {Bs} x {secs:g} s distinct clips, wav in HBM -> ids on host"},
             "fp32_mfma_mode": {"value": ref32["value"], "ms_per_step": ref32["ms_per_step"],
                                "clips_with_identical_ids_vs_main": f"{same}/{Bs}"},
-            "ids_equal_cpu_oracle": ok, "cpu_oracle_clips_checked": ncpu}
+            "roofline": roof, "ids_equal_cpu_oracle": ok, "cpu_oracle_clips_checked": ncpu}
 
 
 def run_streaming(device):
@@ -534,8 +556,31 @@ def run_streaming(device):
             lat.append(time.perf_counter() - t1)
         dt = time.perf_counter() - t0
         lat.sort()
-        rows.append({"streams": S, "precision": sb.precision, "chunks_per_s": round(S * steps / dt, 1), "audio_s_per_s": round(S * steps * 0.6 / dt, 1),
-                     "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3)})
+        row = {"streams": S, "precision": sb.precision, "chunks_per_s": round(S * steps / dt, 1), "audio_s_per_s": round(S * steps * 0.6 / dt, 1),
+               "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3)}
+        # what bounds the step: an eager, hipEvent-instrumented replay of the same step (the graph is bypassed while profiling is
+        # on) -- the instrumented kernels' launch count and their summed time against the step: a step of a few streams is a chain of
+        # ~600 dependent launches of 4-15 us (latency-bound: `roofline.bound` "launch-latency"), many streams are GEMM-bound
+        try:
+            from funasr_amd import _lib
+            lib = _lib.load()
+            lib.pf_prof_reset(); lib.pf_prof_enable(1)
+            for _ in range(4):
+                sb.step(feats)
+            torch.cuda.synchronize()
+            lib.pf_prof_enable(0)
+            prof = read_prof(lib, 4)
+            n = sum(v["launches_per_step"] for v in prof.values())
+            kms = sum(v["ms_per_step"] for v in prof.values())
+            gm = prof["gemm_split"] if sb.precision == "f16x2" else prof["gemm_f32_mfma"]
+            peak = PEAK_16BIT_MFMA_TFLOPS / 3 if sb.precision == "f16x2" else PEAK_F32_MFMA_TFLOPS
+            ach = gm["work_per_step"] / (gm["ms_per_step"] * 1e-3) / 1e12 if gm["ms_per_step"] > 0 else 0.0
+            row["roofline"] = {"bound": "launch-latency" if kms / max(n, 1) < 0.012 else "mfma", "instrumented_launches_per_step": n,
+                               "instrumented_kernel_ms_per_step": round(kms, 3), "us_per_instrumented_launch": round(kms / max(n, 1) * 1e3, 2),
+                               "gemm_tflops": round(ach, 1), "gemm_frac_of_mfma_peak": round(ach / peak, 4)}
+        except Exception as e:                               # noqa: BLE001
+            row["roofline"] = {"error": repr(e)}
+        rows.append(row)
         sb.close()
     return {"metric": "streaming step (600 ms chunk, Paraformer-large-online, hipGraph-captured); fp32-class results in both "
                       "precisions (fp32 kernels / f16x2 = two fp16 planes on the fp16 MFMA)", "configs": rows}
