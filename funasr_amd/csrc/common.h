@@ -187,6 +187,15 @@ __device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_byte_ad
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// the same with a uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (the saddr form): the per-piece part of the
+// address costs scalar ALU only and no address VGPRs
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;

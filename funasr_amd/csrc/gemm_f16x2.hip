@@ -132,20 +132,43 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
 
     const int nk = p.K / KS;
     if constexpr (KS_ == 16 && WGM == 4) {
-        // deep ring (one 512-thread workgroup per CU). With two 32-deep stages only ONE stage (64 KB) is in flight while the
-        // other is multiplied, and the wait at the top of a stage is for a load issued one stage (1.3 us of MFMA work at full
-        // rate) earlier -- less than a loaded HBM round trip, so the matrix pipes wait for memory every stage. Here R = NSTG
-        // 16-deep stages: at step kt stage kt is in registers, stage kt + 1 is being read from LDS into the other fragment
-        // set, stages kt + 2 .. kt + R are in flight (R - 1 stages = 128 KB), and a load has R - 1 steps to land. One barrier
-        // per step: it publishes stage kt + 1 (every wave waited for its own pieces of it) and frees stage kt's buffer (every
-        // wave's fragment reads of it are complete) for stage kt + R. Same products in the same k order: bitwise equal.
+        // Deep ring with EXACT waits (round 4). Five 32-KB buffers of 16-deep stages; at step kt stage kt is in registers, stage
+        // kt + 1 is read from LDS into the other fragment set, stages kt + 2 .. kt + 5 are in flight: four stages = 128 KB against
+        // the ONE 64-KB stage of the two-stage loop below, whose cover (64 KB / 1.4 us of loaded round trip = 46 GB/s per CU) is
+        // less than the block's own appetite at the full matrix rate. Four stages in flight cannot be waited for with
+        // counted vmcnt -- LDS-DMA pieces of one wave retire out of issue order when their sources differ (round 3's
+        // form of this loop did exactly that and is unsafe) -- so every stage has ONE owner: wave pair g = wave >> 1 issues all 32
+        // pieces of the stages s with s % 4 == g and is the only pair that waits for them, with vmcnt(0), when that stage is the
+        // only thing it has in flight (its next stage is issued right after the barrier that publishes this one). The pairs of a
+        // SIMD's two waves differ, so an owner's issue burst runs under its SIMD partner's MFMAs. Same products in the same k order
+        // as every other shape: bitwise equal (tested).
         constexpr int R = G::NSTG;
-        auto wait_landed = [&](int rem) {          // my pieces of a stage have landed when at most min(R - 2, rem) later stages are outstanding
-            if (rem >= R - 2) glds_wait_but<(R - 2) * PPW>();
-            else if (rem == 3) glds_wait_but<3 * PPW>();
-            else if (rem == 2) glds_wait_but<2 * PPW>();
-            else if (rem == 1) glds_wait_but<PPW>();
-            else glds_wait_all();
+        static_assert(R == 5 && G::NPIECE == 32 && G::A_PIECES == 16 && RPP == 32, "deep ring: five 32-KB stages of 32-row pieces");
+        const int grp = wave >> 1, hw = wave & 1;
+        const int prow = lane / CPR;
+        const unsigned chunkb = (unsigned)(((lane % CPR) ^ ((prow >> G::SWZ) & (CPR - 1))) * 16);
+        const unsigned ldsb = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+        const size_t a_step2 = (p.a_kstep > 0 ? (size_t)p.a_kstep : (size_t)KS) * 2, w_step2 = (p.w_kstep > 0 ? (size_t)p.w_kstep : (size_t)KS) * 2;
+        // this wave's piece i (0..15) of stage kt -> buffer `buf`: piece q = hw + 2 i of the stage (A plane 0 rows 32 q.., A plane 1,
+        // W plane 0, W plane 1; 8 pieces each)
+        auto issue = [&](int kt, int buf, int i) {
+            if constexpr (ABL == 3) return;
+            const unsigned dst = ldsb + (unsigned)buf * STAGE_B + (unsigned)(hw + 2 * i) * 1024;
+            if (i < 8) {
+                int row = m0 + (hw + 2 * (i & 3)) * RPP + prow;
+                row = row < p.M ? row : p.M - 1;
+                glds16s(reinterpret_cast<const char*>(p.A) + (size_t)(i >> 2) * p.a_plane * 2 + (size_t)kt * a_step2,
+                        (unsigned)row * (unsigned)p.lda * 2u + chunkb, dst);
+            } else {
+                int col = n0 + (hw + 2 * (i & 3)) * RPP + prow;
+                col = col < p.N ? col : p.N - 1;
+                glds16s(reinterpret_cast<const char*>(p.W) + (size_t)((i - 8) >> 2) * p.w_plane * 2 + (size_t)kt * w_step2,
+                        (unsigned)col * (unsigned)p.ldw * 2u + chunkb, dst);
+            }
+        };
+        auto issue_stage = [&](int kt, int buf) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) issue(kt, buf, i);
         };
         auto frags = [&](f16x8 (&a)[WM][2], f16x8 (&b)[WN][2], int buf) {
             const unsigned char* sb = smem + buf * STAGE_B;
@@ -162,16 +185,11 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
                     b[jj][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[0]));
             }
         };
-#pragma unroll
-        for (int st = 0; st < R; ++st) {
-            if (st < nk) {
-#pragma unroll
-                for (int i = 0; i < PPW; ++i) piece(i, st, st);
-            }
-        }
-        // stage 0: R - 1 later stages were issued (or nk - 1)
-        if (nk - 1 >= R - 1) glds_wait_but<(R - 1) * PPW>(); else wait_landed(nk - 1);
+        // prologue: pair g fills buffer g with stage g; stage 0 is published; pair 0 (nothing in flight any more) sends stage 4
+        if (grp < nk) issue_stage(grp, grp);
+        if (grp == 0) glds_wait_all();
         __syncthreads();
+        if (grp == 0 && 4 < nk) issue_stage(4, 4);
         f16x8 a0[WM][2], b0[WN][2], a1[WM][2], b1[WN][2];
         frags(a0, b0, 0);
         int buf = 0;                               // kt % R
@@ -180,14 +198,12 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
         auto step = [&](auto more, int kt, f16x8 (&a)[WM][2], f16x8 (&b)[WN][2], f16x8 (&an)[WM][2], f16x8 (&bn)[WN][2]) {
             const int nbuf = buf + 1 == R ? 0 : buf + 1;
             if constexpr (decltype(more)::value) {
-                wait_landed(nk - 2 - kt);
+                const bool own = grp == ((kt + 1) & 3);                // owner of stage kt + 1 (and of stage kt + 5)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of stage kt are complete
+                if (own) glds_wait_all();                              // stage kt + 1: the only thing this pair has in flight
                 __syncthreads();
-                if (kt + R < nk) {
-#pragma unroll
-                    for (int i = 0; i < PPW; ++i) piece(i, buf, kt + R);
-                }
                 frags(an, bn, nbuf);
+                if (own && kt + R < nk) issue_stage(kt + R, buf);      // into the buffer stage kt just left
                 __builtin_amdgcn_sched_barrier(0);     // the reads go out before the MFMAs (a step's worth of time to land)
             }
 #pragma unroll
@@ -566,9 +582,10 @@ int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
-// NOTE (round 4): the two opt-in shapes below stage their operands behind COUNTED vmcnt waits (glds_wait_but). LDS-DMA pieces of one
-// wave were found to retire out of issue order when their sources differ (gemm_f16x2_ffn.hip header): these shapes pass the warm
-// kernel tests but are NOT safe inside a long pipeline. Measurement hooks only; no default path takes them.
+// NOTE (round 4): the 128 x 256 shape below (tile 5) stages its operands behind COUNTED vmcnt waits (glds_wait_but). LDS-DMA pieces of
+// one wave were found to retire out of issue order when their sources differ (gemm_f16x2_ffn.hip header): it passes the warm kernel
+// tests but is NOT safe inside a long pipeline -- a measurement hook only. The deep ring (tile 6) was rebuilt on exact waits with one
+// owner wave pair per stage.
 // the 128 x 256 four-wave shape, two workgroups per CU (tile 5; N % 256 == 0)
 template <int MODE, int OUT>
 int launch_pair(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 0, 2, 16>(a, stream); }

@@ -91,18 +91,6 @@ __device__ __forceinline__ void ff_settle(floatx16 (&S)[4]) {
 __device__ __forceinline__ void ff_settle_a(floatx16& y) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(y)); }
 __device__ __forceinline__ f16x8 lds_frag(const unsigned char* p) { return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(p)); }
 
-// LDS-DMA piece with a scalar base and a per-lane 32-bit byte offset (the saddr form): the per-piece part of the address (plane,
-// row block, K stage, chunk) is uniform and lives in SGPRs, so a piece costs no vector ALU and no address VGPRs -- with the
-// 64-bit per-lane pointers of glds16 the compiler hoists ~30 address registers out of the chunk loop and spills them around it,
-// and a spill reload's vmcnt(0) drains the DMA ring (cdna guide 5.7).
-__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
-                 : "memory");
-}
-
 // ABL (measurement only, tools/bench_ffn.py): 1 = no LDS-DMA (operands are whatever the LDS holds), 2 = no first product,
 // 3 = no second product, 4 = no fragment reads in the loops, 5 = no xn pieces, 6 = no weight pieces, 7 = no W1 pieces, 8 = no W2 pieces
 // (5..8: timing only), 12 = COUNTED vmcnt waits (three slots in flight). Counted waits are WRONG on this hardware: LDS-DMA pieces
