@@ -116,7 +116,7 @@ def read_prof(lib, steps):
 
 
 def read_prof_tags(lib, steps, peak_tflops):
-    """per call site (ProfScope tags in engine.hip): ms per launch, fp32-equivalent TFLOP/s and its fraction of the mode's MFMA peak"""
+    """per call site (ProfScope tags in engine_encoder.hip): ms per launch, fp32-equivalent TFLOP/s and its fraction of the mode's MFMA peak"""
     cap = 32
     tags, kinds = (C.c_char_p * cap)(), (C.c_int * cap)()
     ms, work, n = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_int64 * cap)()

@@ -1,4 +1,4 @@
-"""SAN-M encoder on gfx950 (csrc: gemm_f32, attention_f32, rowwise kernels, scheduled by engine.hip).
+"""SAN-M encoder on gfx950 (csrc: gemm_f32, attention_f32, rowwise kernels, scheduled by engine_encoder.hip).
 
 Host-side mirrors of
   * `SANMEncoder` (funasr/models/sanm/encoder.py:187-461, `encoder_classes["SANMEncoder"]`): same constructor

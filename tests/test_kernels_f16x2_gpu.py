@@ -415,7 +415,7 @@ def test_split2_planes_and_subnormal_floor(cuda):
 
 @pytest.mark.parametrize("K,N", [(512, 2048), (2048, 512)])
 def test_f16x2_range_adversarial_scales(cuda, K, N):
-    """The a-priori plane exponents (engine.hip: LayerNorm output <= sqrt(D) max|gamma| + max|beta|; Linear <= b max_n sum_k |W| +
+    """The a-priori plane exponents (engine_encoder.hip: LayerNorm output <= sqrt(D) max|gamma| + max|beta|; Linear <= b max_n sum_k |W| +
     |c|) on trained-scale parameters: gamma = 30, weights x 100. No plane overflows when every input sits AT the bound, and
     inputs at 2^-20 of the bound keep the error inside the split's floor: |err| <= 2^-21 sum |a||w| (both operands' 2^-23 plus
     the dropped lo*lo term) + the subnormal step of each operand's scaled domain."""
@@ -532,7 +532,7 @@ def test_fused_ffn_vs_the_two_kernel_pair_and_float64(cuda, M, F):
     yv, yr = _planes_value(y) * 2.0 ** -ey, _planes_value(y_ref) * 2.0 ** -ey
     print(f"[M={M} F={F}] fused vs pair: fp32 stream max |d| {d:.3e} (scale {scale:.2f}), LayerNorm planes max |d| "
           f"{(yv - yr).abs().max().item():.3e}, bitwise {bitwise}")
-    # the block-level choice between the pair and the fused launch depends on the batch's row count (engine.hip ffn_fills_rounds),
+    # the block-level choice between the pair and the fused launch depends on the batch's row count (engine_internal.h ffn_fills_rounds),
     # so a clip's bits must not depend on it: BITWISE, stream and planes
     assert bitwise
     # (b) float64 of what the kernel is specified to compute: hidden planes rounded like w_1's plane epilogue
