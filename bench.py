@@ -231,8 +231,14 @@ def main():
         trace(f"warmup step {i} done")
 
     # ------------------------------------------------------------------------------- the timed region (no instrumentation)
-    from tools.gpu_telemetry import Sampler
-    sampler = Sampler(device=local_rank) if rank == 0 else None    # host thread polling librocm_smi64 every 20 ms: clock + socket power
+    sampler = None
+    if rank == 0:                                      # host thread polling librocm_smi64 every 20 ms: clock + socket power
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from gpu_telemetry import Sampler
+            sampler = Sampler(device=local_rank)
+        except Exception as e:                         # noqa: BLE001  (telemetry must never take the bench down)
+            trace(f"telemetry unavailable: {e!r}")
     sync()
     if sampler is not None:
         sampler.start()
