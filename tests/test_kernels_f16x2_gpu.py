@@ -17,6 +17,8 @@ import math
 import pytest
 import torch
 
+from funasr_amd import synth
+
 pytestmark = pytest.mark.gpu
 
 
@@ -570,3 +572,30 @@ def test_fused_ffn_rows_are_independent_and_deterministic(cuda):
     sub = slice(130, 517)
     cs, _ = ops.ffn_f16x2(t["x2"][:, sub].contiguous(), t["w1"], t["w2"], t["b1"], t["b2"], t["resid"][sub].contiguous(), *e)
     assert torch.equal(cs, c[sub])
+
+
+@pytest.mark.timeout(600)
+def test_optional_kernel_schedules_are_bitwise_inside_the_full_depth_encoder(cuda):
+    """The one-launch feed-forward (`ffn_fused` 2) and the deep-ring GEMM shape (`gemm_tile` 6) against the default schedule over
+    the WHOLE headline encoder -- 50 blocks, 64 x 500 frames, 12 800 workgroup executions of each kernel per pass, real
+    HBM / L2 / Infinity-Cache traffic. Round 4's first version of the fused kernel passed every kernel-level test above bit for
+    bit and still corrupted a few workgroups per thousand HERE: its counted vmcnt waits assumed that a wave's LDS-DMA pieces
+    retire in issue order, which they do not when their sources differ. Both optional schedules now wait exactly; this is the
+    test that would have caught it."""
+    from funasr_amd.paraformer import Paraformer
+    cfg = synth.PARAFORMER_LARGE
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
+    model = model.to(cuda).set_precision("f16x2")
+    g = torch.Generator().manual_seed(4)
+    feats = (torch.randn(64, 500, 560, generator=g) * 0.8).to(cuda)
+    lens = torch.full((64,), 500, dtype=torch.int32)
+    def run(**opts):
+        for k, v in {**dict(ffn_fused=0, gemm_tile=0), **opts}.items():
+            model.encoder.set_option(k, v)
+        return model.encode(feats, lens, all_rows=True)[0].clone()
+    base = run()
+    assert torch.isfinite(base).all()
+    for opts in (dict(ffn_fused=2), dict(gemm_tile=6), dict(ffn_fused=2), dict(gemm_tile=6)):
+        assert torch.equal(run(**opts), base), f"{opts} changes the encoder's bits at full depth"
+    run()
