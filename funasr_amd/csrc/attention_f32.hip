@@ -302,7 +302,48 @@ __global__ __launch_bounds__(256, 2) void attention_f32_dma_kernel(AttnArgs p) {
 //   O^T[d][q]  += V^T P : k slot kq of step s pairs key 4 kq + s on both operands, so B is the lane's own register s.
 // Each wave keeps online-softmax statistics over its keys; the four partial results meet in LDS and are combined in a
 // fixed order (flash-decoding merge). Exact fp32 products and accumulation, libm expf.
+// AttnArgs.fs_*: eight consecutive rows of one stream's FSMN memory block, thread = 4 channels -- fsmn_kernel<11, 5> of
+// rowwise.hip term by term (same taps order, same fma chain: the bits of the stand-alone launch), every row valid
+__device__ __forceinline__ void fewq_fsmn_rows(const AttnArgs& p, int b, int t0, int c4) {
+    constexpr int KS = 11, LP = 5, TT = 8;
+    float4 w[KS];
+    {
+        const float* wp = p.fs_w + (size_t)c4 * 4 * KS;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { w[j].x = wp[j]; w[j].y = wp[KS + j]; w[j].z = wp[2 * KS + j]; w[j].w = wp[3 * KS + j]; }
+    }
+    const size_t base = (size_t)b * p.fs_T;
+    float4 win[KS + TT - 1];
+#pragma unroll
+    for (int i = 0; i < KS + TT - 1; ++i) {
+        const int tt = t0 - LP + i;
+        win[i] = (tt >= 0 && tt < p.fs_T) ? *reinterpret_cast<const float4*>(p.fs_in + (base + tt) * p.fs_ldin + c4 * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        if (t0 + i < p.fs_T) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                acc.x = fmaf(w[j].x, win[i + j].x, acc.x);
+                acc.y = fmaf(w[j].y, win[i + j].y, acc.y);
+                acc.z = fmaf(w[j].z, win[i + j].z, acc.z);
+                acc.w = fmaf(w[j].w, win[i + j].w, acc.w);
+            }
+            const float4 c = win[i + LP];
+            *reinterpret_cast<float4*>(p.fs_out + (base + t0 + i) * p.fs_ldo + c4 * 4) =
+                make_float4(acc.x + c.x, acc.y + c.y, acc.z + c.z, acc.w + c.w);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
+    if (blockIdx.y >= p.H) {                                  // the FSMN workgroups (wave-uniform: no barrier is skipped by part of a block)
+        const int t0 = ((blockIdx.y - p.H) * gridDim.x + blockIdx.x) * 8;
+        if (t0 < p.fs_T && threadIdx.x * 4 < p.H * DK) fewq_fsmn_rows(p, blockIdx.z, t0, threadIdx.x);
+        return;
+    }
     __shared__ float red_o[4][16][DK + 1];
     __shared__ float red_m[4][16], red_l[4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -441,11 +482,19 @@ int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0, "attention: strides % 4");
     PF_REQUIRE(a.O || a.O3, "attention: null output");
     if (a.O3) PF_REQUIRE(a.o_plane % 4 == 0 && ((uintptr_t)a.O3 & 7) == 0, "attention: plane output alignment");
-    if (a.few_q && a.Tq <= 32 && !a.O3) {
-        hipLaunchKernelGGL(attention_f32_fewq_kernel, dim3(ceil_div(a.Tq, 16), a.H, a.B), dim3(256), 0, stream, a);
+    if (attention_takes_fewq(a)) {
+        const int gx = ceil_div(a.Tq, 16);
+        int fs_y = 0;
+        if (a.fs_in) {
+            PF_REQUIRE(a.fs_w && a.fs_out && a.fs_T > 0 && a.fs_ldin % 4 == 0 && a.fs_ldo % 4 == 0 && a.H * DK <= 1024,
+                       "attention: FSMN rider needs taps, an output, strides % 4 and <= 1024 channels");
+            fs_y = ceil_div(ceil_div(a.fs_T, 8), gx);
+        }
+        hipLaunchKernelGGL(attention_f32_fewq_kernel, dim3(gx, a.H + fs_y, a.B), dim3(256), 0, stream, a);
         PF_HIP_TRY(hipGetLastError());
         return 0;
     }
+    PF_REQUIRE(!a.fs_in, "attention: the FSMN rider exists in the few-query kernel only");
     dim3 grid(ceil_div(a.Tq, 128), a.H, a.B);
     // the K/V ring form of the streaming step (two sources, a few dozen keys) keeps the register-staged loader; the
     // offline form (one source) takes the LDS-DMA double-buffered kernel. Both do the same arithmetic in the same order.

@@ -318,17 +318,29 @@ __global__ __launch_bounds__(256) void argmax_reduce_kernel(const float* __restr
     }
 }
 
+// one workgroup per row: a thread walks columns tid, tid + 256, .. (eight loads in flight: with one wave per row the 131
+// dependent trips of an 8404-column row cost 37 us in the streaming step), first maximum wins at every merge
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int ldx, int M, int N,
                                                           int* __restrict__ ids) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x;
     const float* xr = x + (size_t)row * ldx;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = lane; j < N; j += 64) {
+    int j = threadIdx.x;
+    for (; j + 7 * 256 < N; j += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xr[j + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] > bv) { bv = v[u]; bi = j + 256 * u; }     // ascending columns per thread
+    }
+    for (; j < N; j += 256) {
         const float v = xr[j];
-        if (v > bv) { bv = v; bi = j; }     // ascending j per lane: first maximum wins
+        if (v > bv) { bv = v; bi = j; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -336,7 +348,14 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
         const int oi = __shfl_xor(bi, o, 64);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if (lane == 0) ids[row] = bi;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        ids[row] = bi;
+    }
 }
 
 }  // namespace
@@ -400,7 +419,7 @@ int launch_argmax_reduce(const float* pval, const int* pidx, int ld, int nparts,
 }
 
 int launch_argmax_rows(const float* x, int ldx, int M, int N, int* ids, hipStream_t stream) {
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, stream, x, ldx, M, N, ids);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, stream, x, ldx, M, N, ids);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -219,10 +219,26 @@ struct GemmArgs {
     int vec_epilogue;            // set by the launcher: all epilogue operands allow aligned float4 access
     int ab_bf16;                 // A and W hold bf16 (lda / ldw in ELEMENTS); fp32 accumulate and epilogue
     int c_bf16;                  // C is written as bf16 (ldc in elements)
+    // ---- small-M kernel only (gemm_skinny.hip): LayerNorm carried between GEMMs instead of a launch of its own (the streaming
+    // step is a chain of ~600 dependent launches; a stand-alone LayerNorm of 15 rows costs a whole launch slot).
+    // Producer side: ln_stats_out [M][N / 16][2] receives, per output row and 16-column block, (sum, sum of squares) of the
+    // FINISHED outputs (after bias / ReLU / addends); N % 16 == 0.
+    // Consumer side: ln_stats_in != nullptr makes the A operand LayerNorm(A) on the fly: row statistics from the K / 16 block
+    // partials (summed in a fixed order that depends on K only), a' = (a - mean) * rstd * gamma + beta applied to each loaded
+    // element; K is the normalised width (no padding columns).
+    // the four-workgroup form of a <= 32-row problem (see gemm_skinny.hip): slice tiles [tiles][16][rows of a tile][16] and one
+    // zeroed int per tile (the kernel leaves them zero); tiles = ceil(N / 16) * ceil(M / 16 or 32). Same bits as without.
+    float* ws_part; int* ws_count;
+    float* ln_stats_out;
+    const float* ln_stats_in; const float* ln_g; const float* ln_b; float ln_eps;
 };
 int launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 // small-M weight-streaming variant (gemm_skinny.hip); same contract, no fused arg-max
 bool gemm_skinny_applicable(const GemmArgs& a);
+// the small-M GEMM for up to 16 weight matrices sharing A / M / N / K / strides (gemm_skinny.hip): one launch, a row's bits
+// those of the single launches
+struct GemmBatch { int n; const float* W[16]; const float* bias[16]; float* C[16]; };
+int launch_gemm_skinny_batch(const GemmArgs& a, const GemmBatch& t, hipStream_t stream);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);
 
 int launch_cast_bf16(const float* x, unsigned short* y, size_t n, hipStream_t stream);
@@ -416,7 +432,13 @@ struct AttnArgs {
     // 1 = also causal (key <= query), 2 = also the VAD corner (transformer/utils/mask.py:38-52): queries before
     // vad_pos[b] - 1 do not see keys from vad_pos[b] on (when 0 < vad_pos[b] < Tk)
     int mask_mode; const int* vad_pos;
+    // few-query kernel only (the streaming step is a chain of dependent launches; the FSMN memory block reads the same V
+    // projection and is independent of the attention): fs_in != nullptr adds workgroups that compute the block's FSMN
+    // memory, the arithmetic of fsmn_kernel<11, 5> (rowwise.hip) with every one of the fs_T rows per stream valid:
+    // fs_out[b * fs_T + t] = fs_in[..] + sum_j fs_w[c][j] * fs_in[b * fs_T + t - 5 + j] over H * 128 channels
+    const float* fs_in; int fs_ldin; const float* fs_w; float* fs_out; int fs_ldo; int fs_T;
 };
+inline bool attention_takes_fewq(const AttnArgs& a) { return a.few_q && a.Tq <= 32 && !a.O3; }
 // true when launch_attention_f32 will take the few-query kernel AND perform the append itself
 inline bool attention_fuses_append(const AttnArgs& a) { return a.few_q && a.Tq <= 16 && !a.O3 && a.K2 && a.app_rows > 0; }
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);

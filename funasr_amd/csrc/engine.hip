@@ -103,8 +103,20 @@ int upload_lens(DevBuf& buf, const int32_t* host, int B, hipStream_t s) {
 
 int g_skinny_max_m = 0;
 thread_local bool g_stream_mode = false;
+thread_local float* g_ws_part = nullptr;
+thread_local int* g_ws_count = nullptr;
 int gemm(const GemmArgs& a, hipStream_t s) {
-    if ((g_stream_mode || a.M <= g_skinny_max_m) && gemm_skinny_applicable(a)) return launch_gemm_skinny(a, s);
+    if ((g_stream_mode || a.M <= g_skinny_max_m) && gemm_skinny_applicable(a)) {
+        // a long K behind few column tiles (w_2 of a step: 4 MB of weights through 32 workgroups): four workgroups per tile,
+        // bit for bit the one-workgroup result (gemm_skinny.hip), so the choice may look at the row count
+        if (g_ws_part && a.M <= 32 && a.K >= 1024 && ceil_div(a.N, 16) * ceil_div(a.M, a.M <= 16 ? 16 : 32) <= WS_TILES) {
+            GemmArgs w = a;
+            w.ws_part = g_ws_part; w.ws_count = g_ws_count;
+            return launch_gemm_skinny(w, s);
+        }
+        return launch_gemm_skinny(a, s);
+    }
+    if (a.ln_stats_in || a.ln_stats_out) { set_error("gemm: the LayerNorm-carrying form exists in the small-M kernel only"); return -1; }
     ProfScope ps(PROF_GEMM, 2.0 * a.M * (double)a.N * a.K, s);
     return launch_gemm_f32(a, s);
 }
@@ -132,6 +144,7 @@ int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3, int dk, b
     if (appended) *appended = false;
     AttnArgs f = a;
     f.few_q = 0;
+    if ((dk != 128 || x3) && f.fs_in) { set_error("attention: the FSMN rider exists in the few-query fp32 kernel only"); return -1; }
     if (dk != 128) { f.app_rows = 0; return launch_attention_small(f, dk, s); }      // CT-Transformer sized heads
     if (x3) { f.app_rows = 0; return launch_attention_split3(f, s); }
     f.few_q = (g_stream_mode || g_skinny_max_m > 0) ? 1 : 0;   // by caller (streaming step; g_skinny_max_m: test hook)

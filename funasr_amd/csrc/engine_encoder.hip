@@ -330,12 +330,28 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
         return launch_layernorm(src, ld, g, b, reinterpret_cast<float*>(xn2c), dim_pad, M, dim, dim_pad, c.ln_eps, s, 3, 0,
                                 (size_t)M * dim_pad, pow2f(ex));
     };
+    // fp32 step with the LayerNorms carried by the small-M GEMMs (EncChunkCtx.ln_stats): gemm() routes to gemm_skinny.hip in a step
+    const bool carry = cc && !x2c && cc->ln_stats && g_stream_mode && D % 16 == 0 && F % 16 == 0;
+    auto gemm_ln = [&](const float* A, int lda, const float* Wt, int ldw, const float* bias, float* C, int ldc, int N, int K, int relu,
+                       const float* R1, int ldr1, const float* R2, int ldr2, float* st_out, const float* st_in, const float* g_,
+                       const float* b_) {
+        GemmArgs g{};
+        g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
+        g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = relu;
+        g.ln_stats_out = st_out; g.ln_stats_in = st_in; g.ln_g = g_; g.ln_b = b_; g.ln_eps = c.ln_eps;
+        ProfScope ps(PROF_GEMM, 2.0 * M * (double)N * K, s);
+        return gemm(g, s);
+    };
     if (x2c && (!w.qkv_w2 || !w.out_w2 || !w.w1_2 || !w.w2_2)) { set_error("encoder: streaming f16x2 step without prepared weight planes"); return -1; }
     // norm1 -> fused QKV projection
     if (x2c) {
         if ((rc = ln_planes(x_in, ld_in, w.n1g, w.n1b, w.in_dim, w.in_pad, w.e_x1))) return rc;
         if ((rc = gemm2c(xn2c, w.in_pad, w.e_x1, w.qkv_w2, w.ew_qkv, w.qkv_b, qkv, 3 * D, nullptr, 0, 3 * D, w.in_pad, 0, nullptr, 0,
                          nullptr, 0))) return rc;
+    } else if (carry && cc->ln_in_ready) {
+        // norm1 on the fetch: the block before left the row partials of x in its w_2 epilogue
+        if ((rc = gemm_ln(x_in, ld_in, w.qkv_w, w.in_pad, w.qkv_b, qkv, 3 * D, 3 * D, w.in_pad, 0, nullptr, 0, nullptr, 0, nullptr,
+                          cc->ln_stats, w.n1g, w.n1b))) return rc;
     } else {
         if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
         if ((rc = gemm_simple(xn, w.in_pad, w.qkv_w, w.in_pad, w.qkv_b, qkv, 3 * D, M, 3 * D, w.in_pad, 0, nullptr, 0,
@@ -346,9 +362,13 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     fa.in = qkv + 2 * D; fa.ldin = 3 * D; fa.w = w.fsmn_w; fa.R = nullptr; fa.ldr = 0; fa.out = mem; fa.ldo = D;
     fa.lens = lens; fa.B = B; fa.T = T; fa.C = D; fa.K = c.kernel_size;
     fa.left_pad = (c.kernel_size - 1) / 2 + (c.sanm_shift > 0 ? c.sanm_shift : 0);
-    if ((rc = fsmn(fa, s))) return rc;
+    // streaming step: the memory block rides in the attention launch (AttnArgs.fs_*: same bits, one launch less in the chain)
+    const bool fsmn_rides = cc && cc->fsmn_rides && g_stream_mode && T <= 32 && D / c.n_heads == 128 && c.kernel_size == 11 &&
+                            fa.left_pad == 5 && D <= 1024;
+    if (!fsmn_rides && (rc = fsmn(fa, s))) return rc;
     // scaled dot-product attention over valid keys (attention.py:284-306,324-326)
     AttnArgs aa{};
+    if (fsmn_rides) { aa.fs_in = fa.in; aa.fs_ldin = fa.ldin; aa.fs_w = fa.w; aa.fs_out = fa.out; aa.fs_ldo = fa.ldo; aa.fs_T = T; }
     aa.Q = qkv; aa.ldq = 3 * D; aa.K = qkv + D; aa.ldk = 3 * D; aa.V = qkv + 2 * D; aa.ldv = 3 * D;
     aa.O = ctx; aa.ldo = D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tq = T; aa.Tk = T;
     aa.scale = powf((float)(D / c.n_heads), -0.5f);
@@ -382,6 +402,13 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
         if ((rc = ln_planes(x, D, w.n2g, w.n2b, D, D, w.e_x2))) return rc;
         if ((rc = gemm2c(xn2c, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2c, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
         return gemm2c(ffn2c, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D);
+    }
+    if (carry) {
+        // norm2 rides between linear_out and w_1; the next block's norm1 between w_2 and its QKV projection
+        const bool emit = cc->next && cc->next->in_dim == D;
+        if ((rc = gemm_ln(ctx, D, w.out_w, D, w.out_b, x, D, D, D, 0, mem, D, resid, ld_in, cc->ln_stats, nullptr, nullptr, nullptr))) return rc;
+        if ((rc = gemm_ln(x, D, w.w1, D, w.b1, ffn, F, F, D, 1, nullptr, 0, nullptr, 0, nullptr, cc->ln_stats, w.n2g, w.n2b))) return rc;
+        return gemm_ln(ffn, F, w.w2, F, w.b2, x, D, D, F, 0, nullptr, 0, x, D, emit ? cc->ln_stats : nullptr, nullptr, nullptr, nullptr);
     }
     if ((rc = gemm_simple(ctx, D, w.out_w, D, w.out_b, x, D, M, D, D, 0, mem, D, resid, ld_in, s))) return rc;
     // norm2 -> FFN -> residual (encoder.py:141-146)

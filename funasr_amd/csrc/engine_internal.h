@@ -286,10 +286,18 @@ int upload_lens(DevBuf& buf, const int32_t* host, int B, hipStream_t s);
 // weight-streaming kernel (whose K slicing depends on K only). g_skinny_max_m is a test hook for pf_k_gemm_f32.
 extern int g_skinny_max_m;
 extern thread_local bool g_stream_mode;
+// workspace of the calling stream handle for the four-workgroup form of the long-K small-M GEMMs (GemmArgs.ws_part / ws_count)
+extern thread_local float* g_ws_part;
+extern thread_local int* g_ws_count;
+constexpr int WS_TILES = 64;                                  // tiles the workspace covers (N = 512: 32 column tiles x <= 2 row tiles)
+constexpr size_t WS_PART_FLOATS = (size_t)WS_TILES * 16 * 512;
 struct StreamModeScope {
     bool prev;
-    StreamModeScope() : prev(g_stream_mode) { g_stream_mode = true; }
-    ~StreamModeScope() { g_stream_mode = prev; }
+    float* prev_part; int* prev_count;
+    explicit StreamModeScope(float* part = nullptr, int* count = nullptr) : prev(g_stream_mode), prev_part(g_ws_part), prev_count(g_ws_count) {
+        g_stream_mode = true; g_ws_part = part; g_ws_count = count;
+    }
+    ~StreamModeScope() { g_stream_mode = prev; g_ws_part = prev_part; g_ws_count = prev_count; }
 };
 
 // ================================================================================================ frontend
@@ -379,6 +387,13 @@ struct EncChunkCtx {
     float* ring; int cap; const StreamDev* st; int append_rows;
     const int* lens;     // device [B]: every window row is valid in a chunk
     bool x2 = false;     // the block's four GEMMs on the fp16 matrix cores (two-plane operands, gemm_f16x2.hip), fp32 results
+    // fp32 step: the LayerNorms ride in the small-M GEMMs on either side (gemm_skinny.hip: the producer's epilogue leaves per-row
+    // partial sums, the consumer normalises on the fetch). ln_stats = [rows][d_model / 16][2] scratch; ln_in_ready = the block that
+    // ran before left the statistics of this block's input there
+    float* ln_stats = nullptr;
+    bool ln_in_ready = false;
+    bool fsmn_rides = false;     // the FSMN memory block is computed by extra workgroups of the attention launch (AttnArgs.fs_*)
+    const EncLayerW* next = nullptr;
 };
 
 // =============================================================================================== predictor
@@ -462,6 +477,15 @@ struct Stream {
     // every LayerNorm statistic stay the fp32 kernels of the default step. Exponents come from a-priori bounds: the decoder's
     // memory is THIS encoder's after_norm output (|y| <= sqrt(D) max|gamma| + max|beta|), so nothing is chosen per step.
     bool x2 = false;
+    // fp32 step: LayerNorms carried by the small-M GEMMs: 0 never, 1 steps of <= 32 rows, 2 always (the default: a stream's bits
+    // must not depend on how many streams run beside it; measured S = 1 / 2 / 8 / 32: -6 / -4 / -2 / +5 % step time)
+    int ln_carry = 2;
+    bool fsmn_rides = true;                                  // encoder FSMN inside the attention launch (AttnArgs.fs_*)
+    DevBuf ln_stats;
+    bool wide_k = false;                                     // long-K N = 512 projections of a <= 32-row step over four workgroups per tile
+    DevBuf ws_part, ws_count;                                // their slice tiles and tile counters (GemmArgs.ws_part / ws_count)
+    DevBuf dec_ln_a, dec_ln_b, dec_ln_f;                     // decoder: block partials of the token rows (d_model wide twice, ffn wide)
+    bool kv_batched = true;                                  // fp32 step: the decoder's key/value projections of the encoder rows as one launch
     unsigned long long ver_e = ~0ull, ver_d = ~0ull;         // TensorTable versions the prepared exponents / planes belong to
     int e_mem = 0, e_an = 0;
     std::vector<int> e_ctx;                                  // per decoder layer: exponent of the cross-attention output planes

@@ -7,6 +7,19 @@ extern "C" {
 
 // -------------------------------------------------------------------------------------------- single kernels
 /* test hook: pf_k_gemm_f32 takes the small-M kernel for M <= m (default 0 = always the tile kernel) */
+/* the small-M kernel with a LayerNorm carried between two GEMMs (gemm_skinny.hip): stats_out [M][N / 16][2] receives the block
+ * partials of the finished outputs; stats_in [M][K / 16][2] (+ gamma, beta, eps) makes the A operand LayerNorm(A) on the fetch */
+int pf_k_gemm_skinny_ln(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R2, int32_t ldr2,
+                        float* Cout, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t relu, float* stats_out,
+                        const float* stats_in, const float* ln_g, const float* ln_b, float ln_eps, float* ws_part, int32_t* ws_count,
+                        void* stream) {
+    GemmArgs g{};
+    g.ws_part = ws_part; g.ws_count = ws_count;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R2 = R2; g.ldr2 = ldr2; g.C = Cout; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.relu = relu; g.ln_stats_out = stats_out; g.ln_stats_in = stats_in; g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps;
+    PF_REQUIRE(gemm_skinny_applicable(g), "gemm_skinny_ln: K % 16");
+    return launch_gemm_skinny(g, reinterpret_cast<hipStream_t>(stream));
+}
 int pf_set_skinny_max_m(int32_t m) { g_skinny_max_m = m; return 0; }
 
 int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R1,

@@ -64,7 +64,11 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     const int W = tail ? st->keep : st->keep + n;
     const int M = S * W, Nmax = st->Nmax;
     const StreamDev* dev = st->dev_state.as<StreamDev>();
-    StreamModeScope small_m_kernels;
+    if (st->wide_k && !st->ws_part.p) {
+        if (st->ws_part.ensure(sizeof(float) * WS_PART_FLOATS) || st->ws_count.ensure(sizeof(int) * WS_TILES)) return -2;
+        PF_HIP_TRY(hipMemset(st->ws_count.p, 0, sizeof(int) * WS_TILES));
+    }
+    StreamModeScope small_m_kernels(st->wide_k ? st->ws_part.as<float>() : nullptr, st->wide_k ? st->ws_count.as<int>() : nullptr);
     int rc;
     // ---- workspaces of the three handles (grow-only; the first eager call with a shape allocates)
     {
@@ -93,9 +97,18 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     const int append_rows = (st->cfg.chunk_right > 0 && W - st->cfg.chunk_right > 0) ? W - st->cfg.chunk_right : 0;
     float* x = e->x.as<float>();
     const size_t ring_layer = (size_t)S * st->enc_cap * 2 * D;
+    // (by the row count of the step: the 16- and 32-row forms of the kernel gain a launch, the 64-row form loses to its registers)
+    const bool carry = st->ln_carry && !st->x2 && D % 16 == 0 && (M <= 32 || st->ln_carry > 1);
+    if (carry && st->ln_stats.ensure(sizeof(float) * 2 * (size_t)S * st->Wmax * (D / 16))) return -2;
     for (size_t l = 0; l < e->layers.size(); ++l) {
         EncChunkCtx cc{st->enc_cap > 0 ? st->enc_ring.as<float>() + l * ring_layer : nullptr, st->enc_cap, dev, append_rows,
                        st->lensW.as<int>(), st->x2};
+        cc.fsmn_rides = st->fsmn_rides;
+        if (carry) {
+            cc.ln_stats = st->ln_stats.as<float>();
+            cc.ln_in_ready = l > 0 && e->layers[l].in_dim == D;     // block l - 1's w_2 left them
+            cc.next = l + 1 < e->layers.size() ? &e->layers[l + 1] : nullptr;
+        }
         if (l == 0) rc = encoder_block(e, e->layers[0], st->win.as<float>(), Din, x, S, W, s, &cc);
         else rc = encoder_block(e, e->layers[l], x, D, x, S, W, s, &cc);
         if (rc) return rc;
@@ -157,15 +170,69 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     PF_HIP_TRY(hipMemcpyAsync(dx, st->embeds.p, sizeof(float) * (size_t)Mq * D, hipMemcpyDeviceToDevice, s));
     const size_t dring_layer = (size_t)S * st->dec_cap * 2 * D;
     const size_t dfsmn_layer = (size_t)S * (dc.kernel_size - 1) * D;
+    // ---- fp32 step: every layer's key/value projection of the step's encoder rows in one launch, ahead of the token chain
+    const size_t kv_layer = (size_t)S * st->Wmax * 2 * D;
+    const bool kv_batched = !x2 && st->kv_batched && dc.n_blocks <= 16 && D % 16 == 0;
+    if (kv_batched) {
+        if (d->kv.ensure(sizeof(float) * kv_layer * dc.n_blocks)) return -2;
+        GemmArgs g{};
+        g.A = enc_out; g.lda = D; g.ldw = D; g.ldc = 2 * D; g.M = Mk; g.N = 2 * D; g.K = D;
+        GemmBatch t{};
+        t.n = dc.n_blocks;
+        for (int l = 0; l < dc.n_blocks; ++l) {
+            t.W[l] = d->layers[l].kv_w; t.bias[l] = d->layers[l].kv_b; t.C[l] = d->kv.as<float>() + l * kv_layer;
+        }
+        ProfScope ps(PROF_GEMM, 2.0 * Mk * (double)(2 * D) * D * dc.n_blocks, s);
+        if ((rc = launch_gemm_skinny_batch(g, t, s))) return rc;
+    }
+    // ---- fp32 step of a few token rows: the decoder's LayerNorms ride in the launches on either side (gemm_skinny.hip,
+    // DecFsmnChunkArgs.ln_*): 11 launches per layer become 6 with the batched projection above
+    const bool dcarry = st->ln_carry && !x2 && (Mq <= 32 || st->ln_carry > 1) && Nmax <= 24 && D % 16 == 0 && dc.ffn_dim % 16 == 0;
+    if (dcarry && (st->dec_ln_a.ensure(sizeof(float) * 2 * (size_t)Mq * (D / 16)) || st->dec_ln_b.ensure(sizeof(float) * 2 * (size_t)Mq * (D / 16)) ||
+                   st->dec_ln_f.ensure(sizeof(float) * 2 * (size_t)Mq * (dc.ffn_dim / 16))))
+        return -2;
+    float* sA = st->dec_ln_a.as<float>();
+    float* sB = st->dec_ln_b.as<float>();
+    float* sF = st->dec_ln_f.as<float>();
+    auto gemm_ln = [&](const float* A, int lda, const float* Wt, const float* bias, float* C, int N, int K, int relu, const float* R2,
+                       float* st_out, const float* st_in, const float* g_, const float* b_) {
+        GemmArgs g{};
+        g.A = A; g.lda = lda; g.W = Wt; g.ldw = K; g.bias = bias; g.R2 = R2; g.ldr2 = N; g.C = C; g.ldc = N; g.M = Mq; g.N = N; g.K = K;
+        g.relu = relu; g.ln_stats_out = st_out; g.ln_stats_in = st_in; g.ln_g = g_; g.ln_b = b_; g.ln_eps = dc.ln_eps;
+        ProfScope ps(PROF_GEMM, 2.0 * Mq * (double)N * K, s);
+        return gemm(g, s);
+    };
+    // FFN of a layer: norm1 from the partials the layer before left in sA (or its own launch), the FFN's inner norm between
+    // w_1 and w_2; `out_stats`: where w_2 leaves the partials of its output
+    auto ffn_carry = [&](const DecLayerW& w, bool a_ready, float* out_stats) {
+        const int F = dc.ffn_dim;
+        int r;
+        if (a_ready) r = gemm_ln(dx, D, w.w1, w.b1, d->ffn.as<float>(), F, D, 1, nullptr, sF, sA, w.n1g, w.n1b);
+        else {
+            if ((r = layernorm(dx, D, w.n1g, w.n1b, t1, D, Mq, D, D, dc.ln_eps, s))) return r;
+            r = gemm_ln(t1, D, w.w1, w.b1, d->ffn.as<float>(), F, D, 1, nullptr, sF, nullptr, nullptr, nullptr);
+        }
+        if (r) return r;
+        return gemm_ln(d->ffn.as<float>(), F, w.w2, nullptr, t2, D, F, 0, nullptr, out_stats, sF, w.fng, w.fnb);
+    };
     for (int l = 0; l < dc.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
-        if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
-        if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
+        float* kv_l = d->kv.as<float>() + (kv_batched ? l * kv_layer : 0);
         DecFsmnChunkArgs fa{};
         fa.in = t1; fa.resid = dx; fa.out = dx; fa.w = w.fsmn_w; fa.state = st->dec_fsmn.as<float>() + l * dfsmn_layer;
         fa.n_valid = st->n_fired.as<int>(); fa.S = S; fa.N = Nmax; fa.C = D;
-        if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
-        if (x2) {
+        if (dcarry) {
+            if ((rc = ffn_carry(w, l > 0, sA))) return rc;
+            fa.in = t2; fa.ln_stats_in = sA; fa.ln_g = w.n2g; fa.ln_b = w.n2b; fa.ln_eps = dc.ln_eps; fa.ln_stats_out = sB;
+            if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
+            if ((rc = gemm_ln(dx, D, w.q_w, w.q_b, d->q.as<float>(), D, D, 0, nullptr, nullptr, sB, w.n3g, w.n3b))) return rc;
+        } else {
+            if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
+            if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
+            if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
+        }
+        if (dcarry) {                      // (norm3 + the query projection: above)
+        } else if (x2) {
             {
                 ProfScope ps(PROF_LN, 8.0 * Mq * (double)D, s);
                 if ((rc = launch_layernorm(dx, D, w.n3g, w.n3b, reinterpret_cast<float*>(t2p), D, Mq, D, D, dc.ln_eps, s, 3, 0,
@@ -177,29 +244,29 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         } else {
             if ((rc = layernorm(dx, D, w.n3g, w.n3b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
             if ((rc = gemm_simple(t1, D, w.q_w, D, w.q_b, d->q.as<float>(), D, Mq, D, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
-            if ((rc = gemm_simple(enc_out, D, w.kv_w, D, w.kv_b, d->kv.as<float>(), 2 * D, Mk, 2 * D, D, 0, nullptr, 0,
-                                  nullptr, 0, s))) return rc;
         }
+        if (!x2 && !kv_batched &&
+            (rc = gemm_simple(enc_out, D, w.kv_w, D, w.kv_b, kv_l, 2 * D, Mk, 2 * D, D, 0, nullptr, 0, nullptr, 0, s))) return rc;
         AttnArgs at{};
         at.Q = d->q.as<float>(); at.ldq = D; at.O = d->ctx.as<float>(); at.ldo = D; at.B = S; at.H = dc.n_heads;
         at.Tq = Nmax; at.scale = powf((float)(D / dc.n_heads), -0.5f);
         if (st->dec_cap > 0) {
             float* ring = st->dec_ring.as<float>() + l * dring_layer;
             at.K = ring; at.ldk = 2 * D; at.V = ring + D; at.ldv = 2 * D; at.Tk = st->dec_cap;
-            at.K2 = d->kv.as<float>(); at.ldk2 = 2 * D; at.V2 = d->kv.as<float>() + D; at.ldv2 = 2 * D; at.T2 = W; at.n2 = W;
+            at.K2 = kv_l; at.ldk2 = 2 * D; at.V2 = kv_l + D; at.ldv2 = 2 * D; at.T2 = W; at.n2 = W;
             at.n1_dev = st->dec_valid.as<int>(); at.n1_stride = 1;
         } else {
-            at.K = d->kv.as<float>(); at.ldk = 2 * D; at.V = d->kv.as<float>() + D; at.ldv = 2 * D; at.Tk = W;
+            at.K = kv_l; at.ldk = 2 * D; at.V = kv_l + D; at.ldv = 2 * D; at.Tk = W;
             at.klens = st->lensW.as<int>();
         }
         bool appended = false;
-        if (st->dec_cap > 0) {
+        if (st->dec_cap > 0 && !kv_batched) {
             at.app_rows = W; at.app_r0 = 0; at.app_wp = st->dec_wp.as<int>(); at.app_wp_stride = 1; at.app_gate = st->n_fired.as<int>();
         }
         if ((rc = attention(at, 4.0 * S * (double)Nmax * W * D, s, false, 128, &appended))) return rc;
-        if (st->dec_cap > 0 && !appended) {
+        if (st->dec_cap > 0 && !appended && !kv_batched) {
             RingAppendArgs ra{};
-            ra.src = d->kv.as<float>(); ra.ldsrc = 2 * D; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
+            ra.src = kv_l; ra.ldsrc = 2 * D; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
             ra.ring = st->dec_ring.as<float>() + l * dring_layer; ra.cap = st->dec_cap; ra.S = S; ra.st = nullptr;
             ra.wp_dev = st->dec_wp.as<int>(); ra.gate_dev = st->n_fired.as<int>();
             if ((rc = launch_ring_append(ra, s))) return rc;
@@ -207,7 +274,18 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         if (x2) {
             if ((rc = launch_split2(d->ctx.as<float>(), D, c2p, D, (size_t)Mq * D, Mq, D, pow2f(st->e_ctx[l]), s))) return rc;
             if ((rc = gemm2_simple(c2p, D, Mq, st->e_ctx[l], w.o_2, w.ew_o, w.o_b, dx, D, D, D, 0, dx, D, s))) return rc;
+        } else if (dcarry) {
+            if ((rc = gemm_ln(d->ctx.as<float>(), D, w.o_w, w.o_b, dx, D, D, 0, dx, sA, nullptr, nullptr, nullptr))) return rc;
         } else if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, dx, D, Mq, D, D, 0, nullptr, 0, dx, D, s))) return rc;
+    }
+    if (st->dec_cap > 0 && kv_batched && dc.n_blocks > 0) {
+        // every layer's append in one launch (the rings are read by the attentions above, written here)
+        RingAppendArgs ra{};
+        ra.src = d->kv.as<float>(); ra.ldsrc = 2 * D; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
+        ra.ring = st->dec_ring.as<float>(); ra.cap = st->dec_cap; ra.S = S; ra.st = nullptr;
+        ra.wp_dev = st->dec_wp.as<int>(); ra.gate_dev = st->n_fired.as<int>();
+        ra.n_layers = dc.n_blocks; ra.src_layer = kv_layer; ra.ring_layer = dring_layer;
+        if ((rc = launch_ring_append(ra, s))) return rc;
     }
     if (st->dec_cap > 0) {
         StreamAdvanceArgs ad{};
@@ -215,8 +293,16 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         ad.S = S; ad.dec_rows = W; ad.dec_cap = st->dec_cap;
         if ((rc = launch_stream_advance_dec(ad, s))) return rc;
     }
-    if ((rc = x2 ? dec_ffn_x2(d, d->last, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
-    if (x2) {
+    if (dcarry) {
+        // decoders3's FFN, then after_norm on the fetch of the vocabulary projection (the hidden rows are not an output of a step)
+        if ((rc = ffn_carry(d->last, dc.n_blocks > 0, sA))) return rc;
+        if (d->pval.ensure(sizeof(float) * (size_t)Mq * V)) return -2;
+        if ((rc = gemm_ln(t2, D, d->tt.get("output_layer.weight"), d->tt.get("output_layer.bias"), d->pval.as<float>(), V, D, 0, nullptr,
+                          nullptr, sA, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias")))) return rc;
+        if ((rc = launch_argmax_rows(d->pval.as<float>(), V, Mq, V, st->ids.as<int32_t>(), s))) return rc;
+    } else if ((rc = x2 ? dec_ffn_x2(d, d->last, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
+    if (dcarry) {                          // (after_norm + the vocabulary projection: above)
+    } else if (x2) {
         // after_norm writes two-plane operands, the vocabulary projection runs with the row arg-max fused into its epilogue
         // (the offline greedy route of decoder_forward_impl)
         auto wv = d->tt.b16.find("output_layer.weight#split2");
@@ -380,14 +466,20 @@ int pf_stream_set_option(pf_stream* sh, const char* key, int32_t value) {
     Stream* st = reinterpret_cast<Stream*>(sh);
     PF_REQUIRE(st && key, "stream_set_option: null");
     const std::string k = key;
-    if (k != "gemm_mode") { set_error("stream_set_option: unknown key " + k); return -1; }
-    PF_REQUIRE(value == 0 || value == 3, "stream_set_option: gemm_mode is 0 (fp32 kernels) or 3 (f16x2)");
+    if (k != "gemm_mode" && k != "ln_carry" && k != "fsmn_rides" && k != "kv_batched" && k != "wide_k") { set_error("stream_set_option: unknown key " + k); return -1; }
+    PF_REQUIRE(k != "gemm_mode" || value == 0 || value == 3, "stream_set_option: gemm_mode is 0 (fp32 kernels) or 3 (f16x2)");
     PF_HIP_TRY(hipStreamSynchronize(st->stream));
-    if (value == 3) {
-        int rc = stream_prepare_x2(st, st->stream);
-        if (rc) return rc;
+    if (k == "ln_carry") st->ln_carry = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (k == "fsmn_rides") st->fsmn_rides = value != 0;
+    else if (k == "kv_batched") st->kv_batched = value != 0;
+    else if (k == "wide_k") st->wide_k = value != 0;
+    else {
+        if (value == 3) {
+            int rc = stream_prepare_x2(st, st->stream);
+            if (rc) return rc;
+        }
+        st->x2 = value == 3;
     }
-    st->x2 = value == 3;
     for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
     st->graphs.clear();
     st->seen.clear();

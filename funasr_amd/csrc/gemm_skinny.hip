@@ -25,12 +25,24 @@ constexpr int SK_KW = 16;    // waves per workgroup = K slices (a constant: a ro
 // the same for every RM / CN, so the choice changes speed only, never a bit of the result (tested).
 // Measured and dropped: four waves with four slices each in four accumulator sets (a quarter of the LDS partials; same
 // summation tree): S = 8 streams 8.2 vs 7.0 ms per step, S = 64 12.0 vs 11.0 -- the sixteen-wave form keeps more loads in flight.
-template <int RM, int CN>
-__global__ __launch_bounds__(SK_KW * 64) void gemm_skinny_kernel(GemmArgs p) {
+// LNIN: the A operand is LayerNorm(A), applied while the operands are fetched (GemmArgs.ln_stats_in). The row statistics come
+// from the producing GEMM's per-16-column partial sums (ln_stats_out below), so no workgroup re-reads a whole row to recompute
+// them -- round 2 folded the LayerNorm into the fetch WITH a recomputation per column workgroup and lost 1 ms per step to it.
+// mean = S / K, var = Q / K - mean^2 (one pass; the stand-alone kernel is two-pass: results differ in the last bits, fp32-class
+// either way), and every order of summation depends on K only -- never on M, RM or CN -- so a stream's bits stay
+// independent of its neighbours.
+// NW = waves per workgroup. 16: one workgroup owns a tile and all sixteen K slices. 4 (GemmArgs.ws_part): FOUR workgroups share
+// a tile, workgroup blockIdx.z takes slices 4 z .. 4 z + 3 -- for the long-K, N = 512 projections of a step (w_2: 4 MB of
+// weights behind 32 column tiles = 32 CUs at ~25 GB/s each, 10-18 us in the chain) this spreads the weight stream over 128
+// CUs. The sixteen slice tiles go to a workspace; the workgroup that arrives last at the tile's counter folds them in the order
+// of the one-workgroup form (slice 0 + 1 + .. + 15) and runs the epilogue: the bits do not depend on the form.
+template <int RM, int CN, bool LNIN, int NW>
+__device__ __forceinline__ void skinny_body(const GemmArgs& p) {
     constexpr int LD = CN * 16 + 1;                                        // padded row of the LDS partial tiles
-    extern __shared__ __attribute__((aligned(16))) float red[];          // [SK_KW][RM * 16][LD]
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [SK_KW][RM * 16][LD]  (NW == 16)
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wv = threadIdx.x >> 6;                                       // wave of the workgroup
+    const int wave = NW == SK_KW ? wv : (int)blockIdx.z * NW + wv;         // K slice
     const int i16 = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * (16 * RM);
     const int n0 = blockIdx.x * (16 * CN);
@@ -62,6 +74,92 @@ __global__ __launch_bounds__(SK_KW * 64) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+    auto ln4 = [&](float4 v, const float4 g, const float4 b, const float mean, const float rstd) {
+#pragma clang fp contract(off)
+        v.x = (v.x - mean) * rstd * g.x + b.x;
+        v.y = (v.y - mean) * rstd * g.y + b.y;
+        v.z = (v.z - mean) * rstd * g.z + b.z;
+        v.w = (v.w - mean) * rstd * g.w + b.w;
+        return v;
+    };
+    // one 16-wide k step: the four floats of a load feed four MFMAs, ascending k
+    auto mfma_step = [&](const float4 (&a)[RM], const float4 (&b)[CN]) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+    };
+    const int nit = ke > kb ? (ke - kb) >> 4 : 0;
+    int it = 0;
+
+    // LayerNorm statistics of the workgroup's rows: wave w reduces rows w, w + 16, .. (one load per lane and row, all rows'
+    // loads in flight together: a first version walked the partials serially per lane and gave back the launch it saved),
+    // butterfly 32 .. 1, (mean, rstd) through LDS. The order depends on K only. The wave's first k steps are fetched BEFORE
+    // the statistics so that their latency is not paid twice (with K = 512 that is the whole slice).
+    float ln_mean[RM], ln_rstd[RM];
+    if constexpr (LNIN) {
+        __shared__ float2 ln_ms[16 * RM];
+        const int nblk = p.K >> 4;
+        constexpr int U0 = RM * CN >= 8 ? 1 : 4;            // (registers of the 64-row tile)
+        const int u0 = nit >= U0 ? U0 : nit;               // (wave-uniform)
+        float4 a0[U0][RM], b0[U0][CN], g0[U0], h0[U0];
+#pragma unroll
+        for (int u = 0; u < U0; ++u) {
+            if (u < u0) {
+                const int k0 = kb + 16 * u;
+#pragma unroll
+                for (int i = 0; i < RM; ++i) a0[u][i] = *reinterpret_cast<const float4*>(ap[i] + k0);
+#pragma unroll
+                for (int j = 0; j < CN; ++j) b0[u][j] = *reinterpret_cast<const float4*>(wp[j] + k0);
+                g0[u] = *reinterpret_cast<const float4*>(p.ln_g + k0 + kq * 4);
+                h0[u] = *reinterpret_cast<const float4*>(p.ln_b + k0 + kq * 4);
+            }
+        }
+        constexpr int RW = 16 * RM / NW;                    // rows per wave
+        float sx[RW], sq[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            int arow = m0 + wv + NW * i;
+            arow = arow < p.M ? arow : p.M - 1;
+            const float2* st = reinterpret_cast<const float2*>(p.ln_stats_in) + (size_t)arow * nblk;
+            sx[i] = 0.f; sq[i] = 0.f;
+            for (int b = lane; b < nblk; b += 64) { const float2 t = st[b]; sx[i] += t.x; sq[i] += t.y; }
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sx[i] += __shfl_xor(sx[i], o, 64); sq[i] += __shfl_xor(sq[i], o, 64); }
+            const float mean = sx[i] / (float)p.K;
+            float var = sq[i] / (float)p.K - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            if (lane == 0) ln_ms[wv + NW * i] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RM; ++i) { const float2 t = ln_ms[i * 16 + i16]; ln_mean[i] = t.x; ln_rstd[i] = t.y; }
+#pragma unroll
+        for (int u = 0; u < U0; ++u) {
+            if (u < u0) {
+#pragma unroll
+                for (int i = 0; i < RM; ++i) a0[u][i] = ln4(a0[u][i], g0[u], h0[u], ln_mean[i], ln_rstd[i]);
+                mfma_step(a0[u], b0[u]);
+            }
+        }
+        it = u0;
+    }
+
     // U consecutive 16-wide k steps: all their loads first, then their MFMAs in ascending k (the summation order of the plain
     // loop). Written out because the compiler does not unroll a runtime-trip-count loop around MFMAs (convergent), and an
     // un-unrolled loop pays one memory latency per step -- eight in a row for a K = 2048 slice.
@@ -75,72 +173,148 @@ __global__ __launch_bounds__(SK_KW * 64) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < CN; ++j) b[u][j] = *reinterpret_cast<const float4*>(wp[j] + k0 + 16 * u);
         }
+        // the scheduler otherwise sinks loads between the MFMAs to save registers (two steps in flight: four dependent
+        // latencies for a K = 2048 slice); the registers are there (4 waves per SIMD whatever the count: 128 each)
+        if constexpr (RM * CN <= 2) __builtin_amdgcn_sched_barrier(0);      // (the 64-row tile keeps the compiler's rolling schedule)
+        if constexpr (LNIN) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {
+                const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + k0 + 16 * u + kq * 4);
+                const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + k0 + 16 * u + kq * 4);
 #pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].x, b[u][j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].y, b[u][j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].z, b[u][j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].w, b[u][j].w, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < RM; ++i) a[u][i] = ln4(a[u][i], g4, b4, ln_mean[i], ln_rstd[i]);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) mfma_step(a[u], b[u]);
     };
-    const int nit = ke > kb ? (ke - kb) >> 4 : 0;
-    int it = 0;
-    for (; it + 4 <= nit; it += 4) steps_of(std::integral_constant<int, 4>{}, kb + 16 * it);
-    if (it + 2 <= nit) { steps_of(std::integral_constant<int, 2>{}, kb + 16 * it); it += 2; }
-    if (it < nit) steps_of(std::integral_constant<int, 1>{}, kb + 16 * it);
+    if constexpr (RM * CN <= 2 && !LNIN)         // (a K = 2048 slice of the 16- and 32-row tiles in ONE round of loads)
+        for (; it + 8 <= nit; it += 8) steps_of(std::integral_constant<int, 8>{}, kb + 16 * it);
+    if constexpr (!(LNIN && RM * CN >= 8))       // (the LayerNorm form of the 64-row tile has no registers for four steps in flight)
+        for (; it + 4 <= nit; it += 4) steps_of(std::integral_constant<int, 4>{}, kb + 16 * it);
+    if (!(LNIN && RM * CN >= 8) && it + 2 <= nit) { steps_of(std::integral_constant<int, 2>{}, kb + 16 * it); it += 2; }
+    for (; it < nit; ++it) steps_of(std::integral_constant<int, 1>{}, kb + 16 * it);
 
-    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float* mine = red + (size_t)wave * (RM * 16 * LD);
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < CN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mine[(i * 16 + kq * 4 + r) * LD + j * 16 + i16] = acc[i][j][r];
-    __syncthreads();
-
-    // fixed-order sum of the K slices (wave 0 + 1 + ... + 15) + epilogue; consecutive threads -> consecutive columns of a row
-    for (int t = threadIdx.x; t < RM * CN * 256; t += SK_KW * 64) {
-        const int lr = t / (16 * CN), lc = t % (16 * CN);
+    // bias / ReLU / addends / store (+ the LayerNorm partials) of one finished output; consecutive threads -> consecutive
+    // columns of a row
+    auto finish = [&](float v, int lr, int lc) {
         const int row = m0 + lr, cc = n0 + lc;
         if (row < p.M && cc < p.N) {
-            float v = red[lr * LD + lc];
-#pragma unroll
-            for (int w = 1; w < SK_KW; ++w) v += red[(size_t)w * (RM * 16 * LD) + lr * LD + lc];
             if (p.bias) v += p.bias[cc];
             if (p.relu) v = fmaxf(v, 0.f);
             if (p.R1) v = v + p.R1[(size_t)row * p.ldr1 + cc];
             if (p.R2) v = p.R2[(size_t)row * p.ldr2 + cc] + v;
             p.C[(size_t)row * p.ldc + cc] = v;
+            if (p.ln_stats_out) {
+                // (sum, sum of squares) over this row's 16-column block: the 16 threads of the block are 16 consecutive,
+                // 16-aligned lanes and all active (N % 16 == 0); xor butterfly 8, 4, 2, 1
+                float sx = v, sq = v * v;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 16); sq += __shfl_xor(sq, o, 16); }
+                if ((lc & 15) == 0)
+                    reinterpret_cast<float2*>(p.ln_stats_out)[(size_t)row * (p.N >> 4) + (cc >> 4)] = make_float2(sx, sq);
+            }
+        }
+    };
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if constexpr (NW == SK_KW) {
+        float* mine = red + (size_t)wave * (RM * 16 * LD);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(i * 16 + kq * 4 + r) * LD + j * 16 + i16] = acc[i][j][r];
+        __syncthreads();
+        // fixed-order sum of the K slices (wave 0 + 1 + ... + 15) + epilogue
+        for (int t = threadIdx.x; t < RM * CN * 256; t += SK_KW * 64) {
+            const int lr = t / (16 * CN), lc = t % (16 * CN);
+            float v = red[lr * LD + lc];
+#pragma unroll
+            for (int w = 1; w < SK_KW; ++w) v += red[(size_t)w * (RM * 16 * LD) + lr * LD + lc];
+            finish(v, lr, lc);
+        }
+    } else {
+        static_assert(NW == SK_KW || CN == 1, "the four-workgroup form is built for 16-column tiles");
+        constexpr int TILE = RM * 256;                                     // floats of a slice tile
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        float* part = p.ws_part + (size_t)tile * SK_KW * TILE;
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(size_t)wave * TILE + (i * 16 + kq * 4 + r) * 16 + i16] = acc[i][0][r];
+        __shared__ int arrived;
+        __threadfence();                                                   // this thread's tile rows are visible device-wide ...
+        __syncthreads();                                                   // ... for every thread of the workgroup
+        if (threadIdx.x == 0) arrived = atomicAdd(p.ws_count + tile, 1);
+        __syncthreads();
+        if (arrived != SK_KW / NW - 1) return;                             // (uniform) not the last workgroup of the tile
+        __threadfence();                                                   // the other workgroups' rows, not stale lines
+        if (threadIdx.x == 0) p.ws_count[tile] = 0;                        // ready for the next launch (graph replays)
+        for (int t = threadIdx.x; t < TILE; t += NW * 64) {
+            float v = part[t];
+#pragma unroll
+            for (int w = 1; w < SK_KW; ++w) v += part[(size_t)w * TILE + t];
+            finish(v, t >> 4, t & 15);
         }
     }
 }
 
+template <int RM, int CN, bool LNIN>
+__global__ __launch_bounds__(SK_KW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_skinny_kernel(GemmArgs p) {
+    skinny_body<RM, CN, LNIN, SK_KW>(p);
+}
+template <int RM, bool LNIN>
+__global__ __launch_bounds__(256) void gemm_skinny_ws_kernel(GemmArgs p) { skinny_body<RM, 1, LNIN, 4>(p); }
+
+// the same GEMM for up to 16 weight matrices on ONE A operand (blockIdx.z picks W / bias / C): the streaming decoder's sixteen
+// key/value projections of the step's encoder rows do not depend on the token chain, so they leave it as one launch
 template <int RM, int CN>
-int launch_skinny(const GemmArgs& a, hipStream_t stream) {
+__global__ __launch_bounds__(SK_KW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_skinny_batch_kernel(GemmArgs p, GemmBatch t) {
+    p.W = t.W[blockIdx.z]; p.bias = t.bias[blockIdx.z]; p.C = t.C[blockIdx.z];
+    skinny_body<RM, CN, false, SK_KW>(p);
+}
+
+template <int RM, int CN>
+int launch_skinny_batch_t(const GemmArgs& a, const GemmBatch& t, hipStream_t stream) {
     constexpr int lds = SK_KW * RM * 16 * (CN * 16 + 1) * (int)sizeof(float);
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<RM, CN>),
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_batch_kernel<RM, CN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    dim3 grid(ceil_div(a.N, 16 * CN), ceil_div(a.M, 16 * RM), t.n), block(SK_KW * 64);
+    hipLaunchKernelGGL((gemm_skinny_batch_kernel<RM, CN>), grid, block, lds, stream, a, t);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int RM, int CN, bool LNIN>
+int launch_skinny_t(const GemmArgs& a, hipStream_t stream) {
+    constexpr int lds = SK_KW * RM * 16 * (CN * 16 + 1) * (int)sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<RM, CN, LNIN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
     dim3 grid(ceil_div(a.N, 16 * CN), ceil_div(a.M, 16 * RM)), block(SK_KW * 64);
-    hipLaunchKernelGGL((gemm_skinny_kernel<RM, CN>), grid, block, lds, stream, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<RM, CN, LNIN>), grid, block, lds, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
+}
+template <int RM>
+int launch_skinny_ws(const GemmArgs& a, hipStream_t stream) {
+    dim3 grid(ceil_div(a.N, 16), ceil_div(a.M, 16 * RM), 4), block(256);
+    if (a.ln_stats_in) hipLaunchKernelGGL((gemm_skinny_ws_kernel<RM, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_skinny_ws_kernel<RM, false>), grid, block, 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <int RM, int CN>
+int launch_skinny(const GemmArgs& a, hipStream_t stream) {
+    return a.ln_stats_in ? launch_skinny_t<RM, CN, true>(a, stream) : launch_skinny_t<RM, CN, false>(a, stream);
 }
 
 }  // namespace
@@ -151,9 +325,29 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 16 == 0, "gemm_skinny: K must be a multiple of 16");
     PF_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm_skinny: row strides must be multiples of 4 floats");
     PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && a.C, "gemm_skinny: operands must be 16-B aligned");
+    if (a.ln_stats_out) PF_REQUIRE(a.N % 16 == 0 && ((uintptr_t)a.ln_stats_out & 7) == 0, "gemm_skinny: LayerNorm partials need N % 16 == 0");
+    if (a.ln_stats_in) PF_REQUIRE(a.ln_g && a.ln_b && ((uintptr_t)a.ln_stats_in & 7) == 0 && ((uintptr_t)a.ln_g & 15) == 0 && ((uintptr_t)a.ln_b & 15) == 0,
+                                  "gemm_skinny: the LayerNorm-on-fetch form needs gamma, beta and the block partials");
+    if (a.ws_part) {
+        // four workgroups per tile (see skinny_body): the caller hands a workspace of gemm_skinny_ws_floats() floats and as many
+        // zeroed counters as tiles; same bits as the one-workgroup form
+        PF_REQUIRE(a.ws_count && a.M <= 32 && ((uintptr_t)a.ws_part & 15) == 0, "gemm_skinny: the four-workgroup form is for <= 32 rows");
+        return a.M <= 16 ? launch_skinny_ws<1>(a, stream) : launch_skinny_ws<2>(a, stream);
+    }
     if (a.M <= 16) return launch_skinny<1, 1>(a, stream);
     if (a.M <= 32) return launch_skinny<2, 1>(a, stream);
     return launch_skinny<4, 2>(a, stream);
+}
+
+int launch_gemm_skinny_batch(const GemmArgs& a, const GemmBatch& t, hipStream_t stream) {
+    PF_REQUIRE(t.n >= 1 && t.n <= 16, "gemm_skinny_batch: 1 .. 16 weight matrices");
+    PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 16 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && ((uintptr_t)a.A & 15) == 0,
+               "gemm_skinny_batch: K % 16, strides % 4, aligned A");
+    PF_REQUIRE(!a.ln_stats_in && !a.ln_stats_out && !a.amax_val && !a.R1 && !a.R2, "gemm_skinny_batch: plain epilogue (bias, relu) only");
+    for (int i = 0; i < t.n; ++i) PF_REQUIRE(t.W[i] && t.C[i] && ((uintptr_t)t.W[i] & 15) == 0, "gemm_skinny_batch: null or unaligned operand");
+    if (a.M <= 16) return launch_skinny_batch_t<1, 1>(a, t, stream);
+    if (a.M <= 32) return launch_skinny_batch_t<2, 1>(a, t, stream);
+    return launch_skinny_batch_t<4, 2>(a, t, stream);
 }
 
 }  // namespace pf

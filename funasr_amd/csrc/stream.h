@@ -32,6 +32,9 @@ struct RingAppendArgs {
     const StreamDev* st;             // uniform mode: write pointer = st->enc_wp
     const int* wp_dev;               // per-stream mode (st == nullptr): write pointer wp_dev[s]
     const int* gate_dev;             // per-stream mode: stream s is skipped when gate_dev[s] < 1
+    // the same append for n_layers (src, ring) pairs src_layer / ring_layer floats apart (0 / 1: one pair): the decoder's sixteen
+    // rings share the write pointers, and with the batched key/value projection every layer's rows outlive the token chain
+    int n_layers = 0; size_t src_layer = 0, ring_layer = 0;
 };
 int launch_ring_append(const RingAppendArgs& a, hipStream_t stream);
 
@@ -63,6 +66,11 @@ struct DecFsmnChunkArgs {
     float* state;              // [S, K-1, C] left context carried across chunks (in/out)
     const int* n_valid;        // [S] tokens fired this chunk
     int S, N, C;
+    // LayerNorms carried with the neighbouring small-M GEMMs (GemmArgs.ln_stats_*, gemm_skinny.hip): ln_stats_in [S * N][C / 16][2]
+    // = the block partials of `in`'s rows, which is then the LayerNorm's INPUT (norm2 applied on the fetch); ln_stats_out receives
+    // the partials of the output rows (for norm3 on the fetch of the query projection)
+    const float* ln_stats_in = nullptr; const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f;
+    float* ln_stats_out = nullptr;
 };
 int launch_dec_fsmn_chunk(const DecFsmnChunkArgs& a, hipStream_t stream);
 

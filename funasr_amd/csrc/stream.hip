@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256) void ring_append_kernel(RingAppendArgs p) {
     const int skip = p.rows > p.cap ? p.rows - p.cap : 0;      // only the newest `cap` rows can survive
     const int rows = p.rows - skip;
     const int total = p.S * rows * C4;
+    const float* src_l = p.src + (size_t)blockIdx.y * p.src_layer;
+    float* ring_l = p.ring + (size_t)blockIdx.y * p.ring_layer;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int c4 = i % C4, r = (i / C4) % rows, s = i / (C4 * rows);
         int wp;
@@ -67,8 +69,8 @@ __global__ __launch_bounds__(256) void ring_append_kernel(RingAppendArgs p) {
             wp = p.wp_dev[s];
         }
         const int dst = (wp + skip + r) % p.cap;
-        const float4 v = *reinterpret_cast<const float4*>(p.src + (size_t)(s * p.src_T + p.r0 + skip + r) * p.ldsrc + c4 * 4);
-        reinterpret_cast<float4*>(p.ring)[((size_t)s * p.cap + dst) * C4 + c4] = v;
+        const float4 v = *reinterpret_cast<const float4*>(src_l + (size_t)(s * p.src_T + p.r0 + skip + r) * p.ldsrc + c4 * 4);
+        reinterpret_cast<float4*>(ring_l)[((size_t)s * p.cap + dst) * C4 + c4] = v;
     }
 }
 
@@ -214,6 +216,137 @@ __global__ __launch_bounds__(128) void dec_fsmn_chunk_kernel(DecFsmnChunkArgs p)
     }
 }
 
+// The same block for at most 24 token rows (the 600 ms geometry), built for the latency of ONE stream: the kernel above walks a
+// stream's 24 rows x 11 taps in two waves (12-22 us in the step's chain); here 512 threads = (4 channels) x (4 groups of 6 rows),
+// every thread holds a 16-row window, the taps come in as eleven 16-B loads. Term by term the arithmetic of the kernel above
+// (same bits). LN: the LayerNorms on either side ride along (DecFsmnChunkArgs.ln_*): norm2 applied to `in` on the fetch from the
+// block partials w_2's epilogue left, the partials of the output rows left for norm3 on the fetch of the query projection.
+template <int KS, bool LN>
+__global__ __launch_bounds__(512) void dec_fsmn_chunk24_kernel(DecFsmnChunkArgs p) {
+    constexpr int NMAX = 24, G = 4, R = NMAX / G, WIN = KS - 1 + R;
+    const int s = blockIdx.x;
+    const int c4 = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool active = c4 * 4 < p.C;
+    __shared__ float2 ms[NMAX];
+    if constexpr (LN) {
+        if (p.ln_stats_in) {
+            // (mean, rstd) per token row: wave w reduces rows w, w + 8, w + 16 (one load per lane and row), butterfly 32 .. 1 --
+            // the reduction of gemm_skinny.hip's consumer
+            const int nblk = p.C >> 4;
+            float sx[3], sq[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int r = wave + 8 * i;
+                sx[i] = 0.f; sq[i] = 0.f;
+                if (r < p.N) {
+                    const float2* st = reinterpret_cast<const float2*>(p.ln_stats_in) + ((size_t)s * p.N + r) * nblk;
+                    for (int b = lane; b < nblk; b += 64) { const float2 t = st[b]; sx[i] += t.x; sq[i] += t.y; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { sx[i] += __shfl_xor(sx[i], o, 64); sq[i] += __shfl_xor(sq[i], o, 64); }
+                const float mean = sx[i] / (float)p.C;
+                float var = sq[i] / (float)p.C - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                if (lane == 0 && wave + 8 * i < p.N) ms[wave + 8 * i] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+            }
+        }
+    }
+    int n = p.n_valid[s];
+    n = n < p.N ? n : p.N;
+    const int cc = active ? c4 * 4 : 0;
+    // row i of the sequence [state (KS - 1 rows) | this chunk's rows], before the LayerNorm
+    auto seq_raw = [&](int i) -> float4 {
+        if (i < KS - 1) return *reinterpret_cast<const float4*>(p.state + ((size_t)s * (KS - 1) + i) * p.C + cc);
+        const int k = i - (KS - 1);
+        return k < p.N ? *reinterpret_cast<const float4*>(p.in + ((size_t)s * p.N + k) * p.C + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const int k0 = grp * R;
+    float4 win[WIN], res[R], nst[3];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) win[i] = seq_raw(k0 + i);
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        res[i] = k0 + i < p.N ? *reinterpret_cast<const float4*>(p.resid + ((size_t)s * p.N + k0 + i) * p.C + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // the new state = rows [n, n + KS - 1) of the sequence: this group fetches rows grp, grp + 4, grp + 8 of it now and writes
+    // them after every window of the workgroup has been read (the state is updated in place)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nst[i] = grp + G * i < KS - 1 ? seq_raw(n + grp + G * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w[KS];
+    {
+        float4 t[KS];                                       // 4 channels x KS taps, contiguous
+        const float4* wp = reinterpret_cast<const float4*>(p.w + (size_t)cc * KS);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) t[j] = wp[j];
+        const float* f = reinterpret_cast<const float*>(t);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { w[j].x = f[j]; w[j].y = f[KS + j]; w[j].z = f[2 * KS + j]; w[j].w = f[3 * KS + j]; }
+    }
+    // ms[]; and the state is updated in place: every load of it has RETURNED before any thread passes the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (LN) {
+        if (p.ln_stats_in) {
+            const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + cc);
+            const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + cc);
+            auto norm = [&](float4& v, int i) {             // i = sequence index; state rows were normalised when they were token rows
+#pragma clang fp contract(off)
+                const int k = i - (KS - 1);
+                if (k >= 0 && k < p.N) {
+                    const float2 t = ms[k];
+                    v.x = (v.x - t.x) * t.y * g4.x + b4.x;
+                    v.y = (v.y - t.x) * t.y * g4.y + b4.y;
+                    v.z = (v.z - t.x) * t.y * g4.z + b4.z;
+                    v.w = (v.w - t.x) * t.y * g4.w + b4.w;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) norm(win[i], k0 + i);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) norm(nst[i], n + grp + G * i);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int k = k0 + i;
+        if (k < p.N) {                                      // (uniform per group of two waves)
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                acc.x = fmaf(w[j].x, win[i + j].x, acc.x);
+                acc.y = fmaf(w[j].y, win[i + j].y, acc.y);
+                acc.z = fmaf(w[j].z, win[i + j].z, acc.z);
+                acc.w = fmaf(w[j].w, win[i + j].w, acc.w);
+            }
+            const float4 x = win[KS - 1 + i];
+            const float4 r = res[i];
+            float4 o;
+            o.x = r.x + (acc.x + x.x); o.y = r.y + (acc.y + x.y); o.z = r.z + (acc.z + x.z); o.w = r.w + (acc.w + x.w);
+            if (active) *reinterpret_cast<float4*>(p.out + ((size_t)s * p.N + k) * p.C + cc) = o;
+            if constexpr (LN) {
+                if (p.ln_stats_out) {
+                    // block partials of the output row: 16 channels = 4 consecutive lanes (C % 16 == 0: all four active or none)
+                    float sx = (o.x + o.y) + (o.z + o.w);
+                    float sq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                    sx += __shfl_xor(sx, 1, 64); sq += __shfl_xor(sq, 1, 64);
+                    sx += __shfl_xor(sx, 2, 64); sq += __shfl_xor(sq, 2, 64);
+                    if (active && (c4 & 3) == 0)
+                        reinterpret_cast<float2*>(p.ln_stats_out)[((size_t)s * p.N + k) * (p.C >> 4) + (c4 >> 2)] = make_float2(sx, sq);
+                }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (grp + G * i < KS - 1)
+                *reinterpret_cast<float4*>(p.state + ((size_t)s * (KS - 1) + grp + G * i) * p.C + cc) = nst[i];
+    }
+}
+
 __global__ void fill_int_kernel(int* p, int n, int v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -241,7 +374,7 @@ int launch_ring_append(const RingAppendArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.cols % 4 == 0 && a.ldsrc % 4 == 0, "ring_append: cols % 4");
     const int rows = a.rows > a.cap ? a.cap : a.rows;
     const int total = a.S * rows * (a.cols / 4);
-    hipLaunchKernelGGL(ring_append_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ring_append_kernel, dim3(ceil_div(total, 256), a.n_layers > 1 ? a.n_layers : 1), dim3(256), 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -269,7 +402,13 @@ int launch_dec_fsmn_chunk(const DecFsmnChunkArgs& a, hipStream_t stream) {
     // geometry: <= 17 fires per step), 48 and 96 token rows (e.g. chunk_size [0, 20, 10]: <= 43)
     PF_REQUIRE(a.C % 4 == 0 && a.N <= 96, "dec_fsmn_chunk: at most 96 token rows per step");
     dim3 grid(ceil_div(a.C / 4, 128), a.S), block(128);
-    if (a.N <= 24) hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 24>), grid, block, 0, stream, a);
+    if (a.ln_stats_in || a.ln_stats_out)
+        PF_REQUIRE(a.C % 16 == 0 && a.N <= 24 && a.C <= 512 && (!a.ln_stats_in || (a.ln_g && a.ln_b)),
+                   "dec_fsmn_chunk: the LayerNorm-carrying form needs C % 16 == 0, C <= 512, <= 24 token rows, gamma and beta");
+    if (a.N <= 24 && a.C <= 512 && a.C % 4 == 0 && ((uintptr_t)a.w & 15) == 0) {
+        if (a.ln_stats_in || a.ln_stats_out) hipLaunchKernelGGL((dec_fsmn_chunk24_kernel<11, true>), dim3(a.S), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((dec_fsmn_chunk24_kernel<11, false>), dim3(a.S), dim3(512), 0, stream, a);
+    } else if (a.N <= 24) hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 24>), grid, block, 0, stream, a);
     else if (a.N <= 48) hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 48>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((dec_fsmn_chunk_kernel<11, 96>), grid, block, 0, stream, a);
     PF_HIP_TRY(hipGetLastError());

@@ -182,6 +182,12 @@ class StreamBatch:
         self.start_idx = 0
         self.keep = chunk_size[0] + chunk_size[2]
 
+    def set_option(self, key: str, value: int):
+        """pf_stream_set_option: "gemm_mode" 0 | 3; the fp32 step's launch fusions (A/B switches, defaults on): "ln_carry" 0 | 1 | 2
+        (LayerNorms carried by the small-M GEMMs: never / steps of <= 32 rows / always), "fsmn_rides", "kv_batched"; "wide_k" (off)"""
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.pf_stream_set_option(self._h, key.encode(), int(value)), "pf_stream_set_option")
+
     def reset(self):
         _lib.check(self.lib.pf_stream_reset(self._h, None), "pf_stream_reset")
         self.start_idx = 0

@@ -392,6 +392,13 @@ int pf_predictor_debug_poison(pf_predictor* p, int32_t byte);
 /* -------------------------------------------------------------------------------- single kernels (tests / bench)
  * Thin wrappers over the individual gfx950 kernels so that parity tests and the roofline bench can drive one
  * kernel at a time through the same ABI. All pointers are device pointers. */
+/* small-M GEMM with a LayerNorm carried between GEMMs (the streaming step's fused LayerNorms): see gemm_skinny.hip.
+ * ws_part (>= tiles * 16 * 512 floats) + ws_count (one zeroed int32 per tile; tiles = ceil(N / 16) * ceil(M / 16 or 32)), M <= 32:
+ * the four-workgroups-per-tile form for long K, the same bits */
+int pf_k_gemm_skinny_ln(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R2, int32_t ldr2,
+                        float* Cout, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t relu, float* stats_out,
+                        const float* stats_in, const float* ln_g, const float* ln_b, float ln_eps, float* ws_part, int32_t* ws_count,
+                        void* stream);
 /* test hook: pf_k_gemm_f32 takes the small-M weight-streaming kernel (the streaming step's GEMM) for M <= m;
  * default 0 = the 128x128 tile kernel (the offline path's GEMM) */
 int pf_set_skinny_max_m(int32_t m);

@@ -67,6 +67,56 @@ def test_small_m_gemm_rows_do_not_depend_on_m(cuda):
         lib.pf_set_skinny_max_m(0)
 
 
+def test_small_m_gemm_carries_a_layernorm_between_two_gemms(cuda):
+    """gemm_skinny.hip, the streaming step's fused LayerNorms: the producer's epilogue leaves (sum, sum of squares) per row and
+    16-column block, the consumer normalises its A operand on the fetch from them. Against float64 LayerNorm + GEMM (fp32-class:
+    tolerance 2e-6 of the output range); the pair's rows are bitwise independent of M like the plain kernel's; and against the
+    stand-alone LayerNorm kernel + GEMM the difference is the last bits of a one-pass vs two-pass variance (< 2e-6)."""
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    D, F, eps = 512, 2048, 1e-12
+    x0 = torch.randn(200, D, generator=g) * 3 + 0.7          # a row mean that is not small against the spread
+    ctx = torch.randn(200, D, generator=g)
+    wo = torch.randn(D, D, generator=g) / math.sqrt(D)
+    bo = torch.randn(D, generator=g)
+    w1 = torch.randn(F, D, generator=g) / math.sqrt(D)
+    b1 = torch.randn(F, generator=g)
+    gam = torch.rand(D, generator=g) + 0.5
+    bet = torch.randn(D, generator=g)
+    dev = lambda t: t.to(cuda)
+    full = None
+    for M in (200, 1, 15, 16, 20, 33, 64, 65):
+        x, st = ops.gemm_small_m_ln(dev(ctx[:M].contiguous()), dev(wo), dev(bo), add2=dev(x0[:M].contiguous()), want_stats=True)
+        h, none = ops.gemm_small_m_ln(x, dev(w1), dev(b1), relu=True, stats_in=st, ln=(dev(gam), dev(bet), eps))
+        assert none is None
+        if full is None:
+            full = (x.cpu(), st.cpu(), h.cpu())
+            xr = x0.double() + (ctx.double() @ wo.double().T + bo.double())
+            assert _rel(full[0], xr) < 2e-6
+            blocks = full[0].double().view(200, D // 16, 16)
+            assert (full[1][..., 0].double() - blocks.sum(-1)).abs().max() < 1e-4
+            assert (full[1][..., 1].double() - (blocks ** 2).sum(-1)).abs().max() < 2e-3
+            xn = torch.nn.functional.layer_norm(full[0].double(), (D,), gam.double(), bet.double(), eps)
+            hr = torch.relu(xn @ w1.double().T + b1.double())
+            assert _rel(full[2], hr) < 2e-6
+            xn_k = ops.layernorm(x, dev(gam), dev(bet), eps)
+            h_k, _ = ops.gemm_small_m_ln(xn_k, dev(w1), dev(b1), relu=True)
+            assert _rel(full[2], h_k.cpu()) < 2e-6
+        else:
+            assert torch.equal(x.cpu(), full[0][:M]) and torch.equal(st.cpu(), full[1][:M]) and torch.equal(h.cpu(), full[2][:M]), M
+        if M <= 32:
+            # the four-workgroups-per-tile form (long K behind few column tiles): the same bits, with and without the LayerNorm forms
+            w2 = torch.randn(D, F, generator=torch.Generator().manual_seed(M)) / math.sqrt(F)
+            for kw in (dict(), dict(want_stats=True), dict(add2=x, relu=True)):
+                y0, s0 = ops.gemm_small_m_ln(h, dev(w2), dev(bo), **kw)
+                y1, s1 = ops.gemm_small_m_ln(h, dev(w2), dev(bo), four_workgroups=True, **kw)
+                assert torch.equal(y0, y1) and (s0 is None or torch.equal(s0, s1)), (M, kw)
+            x4, st4 = ops.gemm_small_m_ln(dev(ctx[:M].contiguous()), dev(wo), dev(bo), add2=dev(x0[:M].contiguous()), want_stats=True,
+                                          four_workgroups=True)
+            h4, _ = ops.gemm_small_m_ln(x4, dev(w1), dev(b1), relu=True, stats_in=st4, ln=(dev(gam), dev(bet), eps), four_workgroups=True)
+            assert torch.equal(x4, x) and torch.equal(st4, st) and torch.equal(h4, h), M
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (500, 1536, 576), (333, 2048, 512), (1000, 512, 2048), (70, 130, 192)])
 def test_gemm_bf16_operands_fp32_accumulate(cuda, M, N, K):
     """bf16-operand mode: against fp64 on the SAME bf16-rounded operands only the fp32 accumulation differs."""

@@ -244,3 +244,36 @@ def test_stream_chunk_right_zero_matches_reference_session(cuda, precision):
         assert sb.peek()["start_idx"] == start_idx
         assert (enc.cpu() - torch.from_numpy(gg[f"s0_enc_{i}"])).abs().max().item() < 1e-3, i
     sb.close()
+
+
+def test_step_launch_fusions_leave_the_session_unchanged(cuda):
+    """pf_stream_set_option "fsmn_rides" (the encoder's FSMN memory inside the attention launch) and "kv_batched" (the decoder's
+    sixteen key/value projections as one launch) and "wide_k" (four workgroups per tile for the long-K projections) are re-arrangements of the same arithmetic: bitwise equal encoder rows and the same
+    tokens. "ln_carry" (LayerNorms applied on the fetch of the next small-M GEMM from block partials the GEMM before left) replaces a
+    two-pass variance by a one-pass one: fp32-class agreement (1e-4 on rows of magnitude ~1) and the same tokens."""
+    from funasr_amd.paraformer_streaming import StreamBatch
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+
+    def session(opts, S=1):
+        sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=True, precision="fp32")
+        for k, v in opts.items():
+            sb.set_option(k, v)
+        out = []
+        for i in range(int(g["n_chunks"])):
+            fin, tail, _ = (int(v) for v in g[f"flags_{i}"])
+            feats = None if tail else torch.from_numpy(g[f"feats_{i}"]).repeat(S, 1, 1).to(cuda)
+            ids, enc = sb.step(feats, is_final=bool(fin), tail_chunk=bool(tail), return_enc=True)
+            out.append((ids[0], enc[0].cpu()))
+        sb.close()
+        return out
+
+    for S in (1, 3):
+        plain = session({"ln_carry": 0, "fsmn_rides": 0, "kv_batched": 0, "wide_k": 0}, S)
+        for opts in ({"ln_carry": 0, "fsmn_rides": 1, "kv_batched": 0, "wide_k": 0}, {"ln_carry": 0, "fsmn_rides": 0, "kv_batched": 1, "wide_k": 0},
+                     {"ln_carry": 0, "fsmn_rides": 0, "kv_batched": 0, "wide_k": 1}):
+            for a, b in zip(plain, session(opts, S)):
+                assert a[0] == b[0] and torch.equal(a[1], b[1]), (S, opts)
+        for a, b in zip(plain, session({"ln_carry": 1, "fsmn_rides": 1, "kv_batched": 1, "wide_k": 1}, S)):
+            assert a[0] == b[0], S
+            assert (a[1] - b[1]).abs().max().item() < 1e-4, S

@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--precision", nargs="+", default=["fp32"], choices=["fp32", "f16x2"], help="GEMM arithmetic of the step "
                     "(StreamBatch precision): fp32 kernels, or two-plane fp16 operands on the fp16 matrix cores (fp32-class results)")
     ap.add_argument("--graph", nargs="+", type=int, default=[0, 1], help="0 eager, 1 hipGraph replay")
+    ap.add_argument("--ln-carry", nargs="+", type=int, default=[1], help="fp32 step: 1 = LayerNorms carried by the small-M GEMMs "
+                    "(default), 0 = stand-alone LayerNorm launches")
+    ap.add_argument("--set", nargs="*", default=[], metavar="KEY=VALUE", help="pf_stream_set_option pairs applied to every "
+                    "configuration (fsmn_rides, kv_batched: A/B of the step's launch fusions)")
     args = ap.parse_args()
     from funasr_amd import synth
     from funasr_amd.paraformer_streaming import ParaformerStreaming, StreamBatch
@@ -36,8 +40,13 @@ def main():
     model = model.to(dev)
     first_ids = {}
     import itertools
-    for S, prec, graph in itertools.product(args.streams, args.precision, [bool(v) for v in args.graph]):
+    for S, prec, graph, carry in itertools.product(args.streams, args.precision, [bool(v) for v in args.graph], args.ln_carry):
+        if prec != "fp32" and carry != args.ln_carry[0]:
+            continue
         sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=graph, pe_rows=16384, precision=prec)
+        sb.set_option("ln_carry", carry)
+        for kv in args.set:
+            sb.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         g = torch.Generator().manual_seed(S)
         feats = (torch.randn(S, 10, 560, generator=g) * 0.8).to(dev)
         ntok = 0
@@ -62,7 +71,7 @@ def main():
                           "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3),
                           "tokens_per_chunk": round(ntok / (S * args.steps), 2),
                           "dtype": "f32" if prec == "fp32" else "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMA products)",
-                          "precision": prec, "warmup_ids_equal_first_setting": same}), flush=True)
+                          "precision": prec, "ln_carry": bool(carry) if prec == "fp32" else None, "options": args.set, "warmup_ids_equal_first_setting": same}), flush=True)
         sb.close()
 
 
