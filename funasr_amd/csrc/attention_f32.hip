@@ -440,19 +440,23 @@ __global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
     if (kq == 0) { red_m[wave][i16] = m_run; red_l[wave][i16] = l_run; }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int t = tid + 256 * e;
-        const int qq = t >> 7, d = t & 127;
+    for (int e = 0; e < 2; ++e) {
+        const int t = tid + 256 * e;                      // 16 queries x 32 float4
+        const int qq = t >> 5, d = (t & 31) * 4;
         if (q0 + qq >= p.Tq) continue;
         float m = fmaxf(fmaxf(red_m[0][qq], red_m[1][qq]), fmaxf(red_m[2][qq], red_m[3][qq]));
-        float l = 0.f, acc = 0.f;
+        float l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {                     // fixed order; a wave without keys has m = -inf, weight 0
             const float wgt = expf(red_m[w][qq] - m);
             l += red_l[w][qq] * wgt;
-            acc += red_o[w][qq][d] * wgt;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += red_o[w][qq][d + u] * wgt;
         }
-        p.O[((size_t)b * p.Tq + q0 + qq) * p.ldo + head * DK + d] = acc / l;
+        const float o[4] = {acc[0] / l, acc[1] / l, acc[2] / l, acc[3] / l};
+        const size_t row = (size_t)b * p.Tq + q0 + qq;
+        if (p.O2) store_split2x4(p.O2 + row * p.ldo2 + head * DK + d, p.o2_plane, o, p.o2_scale);
+        else *reinterpret_cast<float4*>(p.O + row * p.ldo + head * DK + d) = make_float4(o[0], o[1], o[2], o[3]);
     }
     // ring append (attention.py:343-361: the cache keeps the last rows): every wave of this -- the only -- workgroup of
     // (stream, head) passed the barrier above, i.e. has its ring rows in registers; other heads own other columns
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0, "attention: empty problem");
     PF_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0, "attention: strides % 4");
-    PF_REQUIRE(a.O || a.O3, "attention: null output");
+    PF_REQUIRE(a.O || a.O3 || a.O2, "attention: null output");
     if (a.O3) PF_REQUIRE(a.o_plane % 4 == 0 && ((uintptr_t)a.O3 & 7) == 0, "attention: plane output alignment");
     if (attention_takes_fewq(a)) {
         const int gx = ceil_div(a.Tq, 16);
@@ -490,11 +494,12 @@ int launch_attention_f32(const AttnArgs& a, hipStream_t stream) {
                        "attention: FSMN rider needs taps, an output, strides % 4 and <= 1024 channels");
             fs_y = ceil_div(ceil_div(a.fs_T, 8), gx);
         }
+        if (a.O2) PF_REQUIRE(a.ldo2 % 4 == 0 && a.o2_plane % 4 == 0 && ((uintptr_t)a.O2 & 7) == 0, "attention: plane output alignment");
         hipLaunchKernelGGL(attention_f32_fewq_kernel, dim3(gx, a.H + fs_y, a.B), dim3(256), 0, stream, a);
         PF_HIP_TRY(hipGetLastError());
         return 0;
     }
-    PF_REQUIRE(!a.fs_in, "attention: the FSMN rider exists in the few-query kernel only");
+    PF_REQUIRE(!a.fs_in && !a.O2, "attention: the FSMN rider and the two-plane output exist in the few-query kernel only");
     dim3 grid(ceil_div(a.Tq, 128), a.H, a.B);
     // the K/V ring form of the streaming step (two sources, a few dozen keys) keeps the register-staged loader; the
     // offline form (one source) takes the LDS-DMA double-buffered kernel. Both do the same arithmetic in the same order.

@@ -299,6 +299,10 @@ struct Gemm2Args {
     // with a long K (the streaming step's w_2: M = 15 S rows, K = 2048), whose lone blocks run at a fraction of the matrix rate.
     // Deterministic, but NOT the bits of the unsplit kernel (another summation order): a caller takes it always or never.
     int ksplit; float* part;
+    // split-K form only: ln_g != nullptr folds the LayerNorm that follows into the second launch (launch_splitk_reduce_ln,
+    // rowwise.hip: the bits of the two launches): LayerNorm(C) goes to ln_y as fp32 (ln_out 0, row stride ln_ldy) or as two fp16
+    // planes of result * ln_oscale (ln_out 3, ln_plane elements apart). N <= 512, no relu, no R1.
+    const float* ln_g; const float* ln_b; float ln_eps; float* ln_y; int ln_ldy; int ln_out; size_t ln_plane; float ln_oscale;
     int kslices;                                        // set by the launcher: what the kernel sees (slice = blockIdx.y)
 };
 // number of arg-max partials per row launch_gemm_f16x2 writes for an N-column problem
@@ -377,6 +381,9 @@ int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* 
 // b * seq_out + t reads input row b * seq_in + t
 // out_mode 1 / in_bf16: y / x is a bf16 buffer (ldy / ldx in elements); out_mode 2: y receives the three bf16 planes
 // of the result (split3), `plane` elements apart; statistics are always fp32
+int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R2, int ldr2,
+                            float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
+                            size_t plane, float oscale, hipStream_t stream);
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
                      int M, int D, int Dpad, float eps, hipStream_t stream, int out_mode = 0, int in_bf16 = 0,
                      size_t plane = 0, float oscale = 1.f, int seq_out = 0, int seq_in = 0, const int* out_map = nullptr);
@@ -437,6 +444,9 @@ struct AttnArgs {
     // memory, the arithmetic of fsmn_kernel<11, 5> (rowwise.hip) with every one of the fs_T rows per stream valid:
     // fs_out[b * fs_T + t] = fs_in[..] + sum_j fs_w[c][j] * fs_in[b * fs_T + t - 5 + j] over H * 128 channels
     const float* fs_in; int fs_ldin; const float* fs_w; float* fs_out; int fs_ldo; int fs_T;
+    // few-query kernel only: O2 != nullptr writes the result as the two fp16 planes of result * o2_scale (split2, o2_plane
+    // elements apart, row stride ldo2) -- the out-projection's operand in the f16x2 step -- instead of O (the bits of O + split2)
+    unsigned short* O2; int ldo2; size_t o2_plane; float o2_scale;
 };
 inline bool attention_takes_fewq(const AttnArgs& a) { return a.few_q && a.Tq <= 32 && !a.O3; }
 // true when launch_attention_f32 will take the few-query kernel AND perform the append itself

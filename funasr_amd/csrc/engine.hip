@@ -144,7 +144,7 @@ int attention(const AttnArgs& a, double flops, hipStream_t s, bool x3, int dk, b
     if (appended) *appended = false;
     AttnArgs f = a;
     f.few_q = 0;
-    if ((dk != 128 || x3) && f.fs_in) { set_error("attention: the FSMN rider exists in the few-query fp32 kernel only"); return -1; }
+    if ((dk != 128 || x3) && (f.fs_in || f.O2)) { set_error("attention: the FSMN rider exists in the few-query fp32 kernel only"); return -1; }
     if (dk != 128) { f.app_rows = 0; return launch_attention_small(f, dk, s); }      // CT-Transformer sized heads
     if (x3) { f.app_rows = 0; return launch_attention_split3(f, s); }
     f.few_q = (g_stream_mode || g_skinny_max_m > 0) ? 1 : 0;   // by caller (streaming step; g_skinny_max_m: test hook)

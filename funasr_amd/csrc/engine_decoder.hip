@@ -127,7 +127,8 @@ int dec_layer_x2(Decoder* d, DecLayerW& w, const std::string& p, bool attn, hipS
 }
 
 // f16x2 form of dec_ffn: both LayerNorms write two-plane fp16 operands, w_1 and w_2 run on the fp16 matrix cores
-int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part) {
+// ln (streaming step, split-K w_2): the LayerNorm that follows the block rides in w_2's second launch (Gemm2Args.ln_*)
+int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part, const FoldedLn* ln) {
     const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
     float* ffn = d->ffn.as<float>();
     unsigned short* t2p = d->t16.as<unsigned short>();
@@ -144,6 +145,17 @@ int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M
         if ((rc = launch_layernorm(ffn, F, w.fng, w.fnb, reinterpret_cast<float*>(f2p), F, M, F, F, d->cfg.ln_eps, s, 3, 0,
                                    (size_t)M * F, pow2f(w.e_fn)))) return rc;
     }
+    if (ln && splitk_part && F % 128 == 0) {
+        Gemm2Args g{};
+        g.A = f2p; g.lda = F; g.a_plane = (size_t)M * F; g.W = w.w2_2; g.ldw = F; g.w_plane = (size_t)D * F;
+        g.oscale = pow2f(-(w.e_fn + w.ew_2)); g.C = out; g.ldc = D; g.M = M; g.N = D; g.K = F; g.ksplit = 4; g.part = splitk_part;
+        g.ln_g = ln->g; g.ln_b = ln->b; g.ln_eps = d->cfg.ln_eps; g.ln_y = ln->y; g.ln_ldy = D; g.ln_out = ln->out; g.ln_plane = (size_t)M * D;
+        g.ln_oscale = ln->oscale;
+        if (!w.w2_2) return -2;
+        ProfScope ps(PROF_GEMM3, 2.0 * M * (double)D * F, s);
+        return launch_gemm_f16x2(g, s);
+    }
+    if (ln) { set_error("decoder: LayerNorm folding needs the split-K form of w_2"); return -1; }
     return gemm2_simple(f2p, F, M, w.e_fn, w.w2_2, w.ew_2, nullptr, out, D, D, F, 0, nullptr, 0, s, nullptr, splitk_part);
 }
 

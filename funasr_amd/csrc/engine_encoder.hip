@@ -312,8 +312,10 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     unsigned short* xn2c = e->xn16.as<unsigned short>();
     unsigned short* ctx2c = e->ctx16.as<unsigned short>();
     unsigned short* ffn2c = e->ffn16.as<unsigned short>();
+    // ln_next: the block after this one -- its norm1 is folded into the second launch of the split-K form (planes -> xn2c)
     auto gemm2c = [&](const unsigned short* A, int lda, int ea, const unsigned short* W, int ew, const float* bias, float* C, int ldc,
-                      unsigned short* C2, int ec, int N, int K, int relu, const float* R1, int ldr1, const float* R2, int ldr2) {
+                      unsigned short* C2, int ec, int N, int K, int relu, const float* R1, int ldr1, const float* R2, int ldr2,
+                      const EncLayerW* ln_next = nullptr) {
         Gemm2Args g{};
         g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)N * K;
         g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
@@ -322,6 +324,11 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
         // the long-K projection (w_2) of a step is at most a block per CU: always in its split-K form here (by caller, whatever
         // the stream count, so a stream's result does not depend on its neighbours)
         if (C && K >= 4 * D && K % 128 == 0 && e->splitk.p) { g.ksplit = 4; g.part = e->splitk.as<float>(); }
+        if (ln_next) {
+            if (g.ksplit <= 1 || N != D || R1) { set_error("encoder: LayerNorm folding needs the split-K form of an N = d_model projection"); return -1; }
+            g.ln_g = ln_next->n1g; g.ln_b = ln_next->n1b; g.ln_eps = c.ln_eps; g.ln_y = reinterpret_cast<float*>(xn2c); g.ln_ldy = D;
+            g.ln_out = 3; g.ln_plane = (size_t)M * D; g.ln_oscale = pow2f(ln_next->e_x1);
+        }
         ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
         return launch_gemm_f16x2(g, s);
     };
@@ -345,7 +352,8 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     if (x2c && (!w.qkv_w2 || !w.out_w2 || !w.w1_2 || !w.w2_2)) { set_error("encoder: streaming f16x2 step without prepared weight planes"); return -1; }
     // norm1 -> fused QKV projection
     if (x2c) {
-        if ((rc = ln_planes(x_in, ld_in, w.n1g, w.n1b, w.in_dim, w.in_pad, w.e_x1))) return rc;
+        // (norm1's planes already written by the block before: the second launch of its w_2, see gemm2c)
+        if (!cc->x2_in_ready && (rc = ln_planes(x_in, ld_in, w.n1g, w.n1b, w.in_dim, w.in_pad, w.e_x1))) return rc;
         if ((rc = gemm2c(xn2c, w.in_pad, w.e_x1, w.qkv_w2, w.ew_qkv, w.qkv_b, qkv, 3 * D, nullptr, 0, 3 * D, w.in_pad, 0, nullptr, 0,
                          nullptr, 0))) return rc;
     } else if (carry && cc->ln_in_ready) {
@@ -386,6 +394,9 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     if (cc && cc->cap > 0 && cc->append_rows > 0) {
         aa.app_rows = cc->append_rows; aa.app_r0 = 0; aa.app_wp = &cc->st->enc_wp; aa.app_wp_stride = 0; aa.app_gate = nullptr;
     }
+    // f16x2 step: the attention writes the out-projection's operand planes itself (no split2 launch)
+    const bool o2 = x2c && cc->x2_attn_planes && g_stream_mode && T <= 32 && D / c.n_heads == 128;
+    if (o2) { aa.O2 = ctx2c; aa.ldo2 = D; aa.o2_plane = (size_t)M * D; aa.o2_scale = pow2f(w.e_v); }
     if ((rc = attention(aa, 4.0 * B * (double)T * T * D, s, false, D / c.n_heads, &appended))) return rc;
     if (cc && cc->cap > 0 && cc->append_rows > 0 && !appended) {
         RingAppendArgs ra{};
@@ -396,12 +407,12 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     // out projection + fsmn memory (+ residual when in == out, encoder.py:120-137)
     const float* resid = (w.in_dim == D) ? x_in : nullptr;
     if (x2c) {
-        if ((rc = launch_split2(ctx, D, ctx2c, D, (size_t)M * D, M, D, pow2f(w.e_v), s))) return rc;
+        if (!o2 && (rc = launch_split2(ctx, D, ctx2c, D, (size_t)M * D, M, D, pow2f(w.e_v), s))) return rc;
         if ((rc = gemm2c(ctx2c, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid, ld_in))) return rc;
         // norm2 -> FFN -> residual: w_1 hands its relu output to w_2 as planes, like the offline mode
         if ((rc = ln_planes(x, D, w.n2g, w.n2b, D, D, w.e_x2))) return rc;
         if ((rc = gemm2c(xn2c, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2c, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
-        return gemm2c(ffn2c, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D);
+        return gemm2c(ffn2c, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D, cc->x2_out_next);
     }
     if (carry) {
         // norm2 rides between linear_out and w_1; the next block's norm1 between w_2 and its QKV projection

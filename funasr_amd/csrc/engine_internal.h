@@ -392,6 +392,10 @@ struct EncChunkCtx {
     // ran before left the statistics of this block's input there
     float* ln_stats = nullptr;
     bool ln_in_ready = false;
+    // f16x2 step: norm1 of the block after this one rides in the second launch of this block's split-K w_2 (launch_splitk_reduce_ln)
+    const EncLayerW* x2_out_next = nullptr;
+    bool x2_in_ready = false;
+    bool x2_attn_planes = false; // f16x2 step: the attention writes the out-projection's operand planes (AttnArgs.O2)
     bool fsmn_rides = false;     // the FSMN memory block is computed by extra workgroups of the attention launch (AttnArgs.fs_*)
     const EncLayerW* next = nullptr;
 };
@@ -485,6 +489,7 @@ struct Stream {
     bool wide_k = false;                                     // long-K N = 512 projections of a <= 32-row step over four workgroups per tile
     DevBuf ws_part, ws_count;                                // their slice tiles and tile counters (GemmArgs.ws_part / ws_count)
     DevBuf dec_ln_a, dec_ln_b, dec_ln_f;                     // decoder: block partials of the token rows (d_model wide twice, ffn wide)
+    bool ln_folded = true;                                   // f16x2 step: LayerNorms folded into the split-K reductions, attention writes planes
     bool kv_batched = true;                                  // fp32 step: the decoder's key/value projections of the encoder rows as one launch
     unsigned long long ver_e = ~0ull, ver_d = ~0ull;         // TensorTable versions the prepared exponents / planes belong to
     int e_mem = 0, e_an = 0;
@@ -538,7 +543,9 @@ int gemm2_simple(const unsigned short* A2, int lda, int M, int ea, const unsigne
                         float* C, int ldc, int N, int K, int relu, const float* R2, int ldr2, hipStream_t s,
                         const float* oscale_dev = nullptr, float* splitk_part = nullptr);
 int dec_layer_x2(Decoder* d, DecLayerW& w, const std::string& p, bool attn, hipStream_t s);
-int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part = nullptr);
+struct FoldedLn { const float* g; const float* b; float* y; int out; float oscale; };   // out: 0 fp32 rows, 3 two fp16 planes of y * oscale
+int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part = nullptr,
+               const FoldedLn* ln = nullptr);
 int dec_ffn(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s,
                    const unsigned short* w1_3 = nullptr);
 int decoder_forward_bf16(Decoder* d, const float* memory, int B, int T, int N, int32_t* ids, float* hidden_out,

@@ -104,6 +104,13 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         EncChunkCtx cc{st->enc_cap > 0 ? st->enc_ring.as<float>() + l * ring_layer : nullptr, st->enc_cap, dev, append_rows,
                        st->lensW.as<int>(), st->x2};
         cc.fsmn_rides = st->fsmn_rides;
+        cc.x2_attn_planes = st->x2 && st->ln_folded;
+        if (st->x2 && st->ln_folded && F >= 4 * D && F % 128 == 0) {
+            // (the condition of gemm2c's split-K form; block l + 1 must take the folded planes: same width, no padding columns)
+            const bool nxt = l + 1 < e->layers.size() && e->layers[l + 1].in_dim == D && e->layers[l + 1].in_pad == D;
+            cc.x2_out_next = nxt ? &e->layers[l + 1] : nullptr;
+            cc.x2_in_ready = l > 0 && e->layers[l].in_dim == D && e->layers[l].in_pad == D;
+        }
         if (carry) {
             cc.ln_stats = st->ln_stats.as<float>();
             cc.ln_in_ready = l > 0 && e->layers[l].in_dim == D;     // block l - 1's w_2 left them
@@ -227,8 +234,10 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
             if ((rc = gemm_ln(dx, D, w.q_w, w.q_b, d->q.as<float>(), D, D, 0, nullptr, nullptr, sB, w.n3g, w.n3b))) return rc;
         } else {
-            if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
-            if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
+            const bool fold = x2 && st->ln_folded && dc.ffn_dim % 128 == 0;       // norm2 in the second launch of the split-K w_2
+            const FoldedLn n2{w.n2g, w.n2b, t1, 0, 1.f};
+            if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s, d->splitk.as<float>(), fold ? &n2 : nullptr) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
+            if (!fold && (rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
             if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
         }
         if (dcarry) {                      // (norm3 + the query projection: above)
@@ -263,6 +272,8 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         if (st->dec_cap > 0 && !kv_batched) {
             at.app_rows = W; at.app_r0 = 0; at.app_wp = st->dec_wp.as<int>(); at.app_wp_stride = 1; at.app_gate = st->n_fired.as<int>();
         }
+        const bool o2 = x2 && st->ln_folded && Nmax <= 32;
+        if (o2) { at.O2 = c2p; at.ldo2 = D; at.o2_plane = (size_t)Mq * D; at.o2_scale = pow2f(st->e_ctx[l]); }
         if ((rc = attention(at, 4.0 * S * (double)Nmax * W * D, s, false, 128, &appended))) return rc;
         if (st->dec_cap > 0 && !appended && !kv_batched) {
             RingAppendArgs ra{};
@@ -272,7 +283,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             if ((rc = launch_ring_append(ra, s))) return rc;
         }
         if (x2) {
-            if ((rc = launch_split2(d->ctx.as<float>(), D, c2p, D, (size_t)Mq * D, Mq, D, pow2f(st->e_ctx[l]), s))) return rc;
+            if (!o2 && (rc = launch_split2(d->ctx.as<float>(), D, c2p, D, (size_t)Mq * D, Mq, D, pow2f(st->e_ctx[l]), s))) return rc;
             if ((rc = gemm2_simple(c2p, D, Mq, st->e_ctx[l], w.o_2, w.ew_o, w.o_b, dx, D, D, D, 0, dx, D, s))) return rc;
         } else if (dcarry) {
             if ((rc = gemm_ln(d->ctx.as<float>(), D, w.o_w, w.o_b, dx, D, D, 0, dx, sA, nullptr, nullptr, nullptr))) return rc;
@@ -293,6 +304,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         ad.S = S; ad.dec_rows = W; ad.dec_cap = st->dec_cap;
         if ((rc = launch_stream_advance_dec(ad, s))) return rc;
     }
+    bool an_folded = false;
     if (dcarry) {
         // decoders3's FFN, then after_norm on the fetch of the vocabulary projection (the hidden rows are not an output of a step)
         if ((rc = ffn_carry(d->last, dc.n_blocks > 0, sA))) return rc;
@@ -300,7 +312,13 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         if ((rc = gemm_ln(t2, D, d->tt.get("output_layer.weight"), d->tt.get("output_layer.bias"), d->pval.as<float>(), V, D, 0, nullptr,
                           nullptr, sA, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias")))) return rc;
         if ((rc = launch_argmax_rows(d->pval.as<float>(), V, Mq, V, st->ids.as<int32_t>(), s))) return rc;
-    } else if ((rc = x2 ? dec_ffn_x2(d, d->last, dx, t2, Mq, s, d->splitk.as<float>()) : dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
+    } else if (x2) {
+        // decoders3's FFN; after_norm's planes (the vocabulary projection's operand) from the second launch of its split-K w_2
+        const bool fold = st->ln_folded && dc.ffn_dim % 128 == 0;
+        const FoldedLn an{d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), reinterpret_cast<float*>(t2p), 3, pow2f(st->e_an)};
+        if ((rc = dec_ffn_x2(d, d->last, dx, t2, Mq, s, d->splitk.as<float>(), fold ? &an : nullptr))) return rc;
+        an_folded = fold;
+    } else if ((rc = dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
     if (dcarry) {                          // (after_norm + the vocabulary projection: above)
     } else if (x2) {
         // after_norm writes two-plane operands, the vocabulary projection runs with the row arg-max fused into its epilogue
@@ -308,7 +326,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         auto wv = d->tt.b16.find("output_layer.weight#split2");
         if (wv == d->tt.b16.end()) { set_error("stream: f16x2 step without prepared vocabulary planes"); return -1; }
         const int ew_v = d->tt.exp2.at("output_layer.weight#split2");
-        {
+        if (!an_folded) {
             ProfScope ps(PROF_LN, 8.0 * Mq * (double)D, s);
             if ((rc = launch_layernorm(t2, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), reinterpret_cast<float*>(t2p), D,
                                        Mq, D, D, dc.ln_eps, s, 3, 0, (size_t)Mq * D, pow2f(st->e_an)))) return rc;
@@ -466,13 +484,14 @@ int pf_stream_set_option(pf_stream* sh, const char* key, int32_t value) {
     Stream* st = reinterpret_cast<Stream*>(sh);
     PF_REQUIRE(st && key, "stream_set_option: null");
     const std::string k = key;
-    if (k != "gemm_mode" && k != "ln_carry" && k != "fsmn_rides" && k != "kv_batched" && k != "wide_k") { set_error("stream_set_option: unknown key " + k); return -1; }
+    if (k != "gemm_mode" && k != "ln_carry" && k != "fsmn_rides" && k != "kv_batched" && k != "wide_k" && k != "ln_folded") { set_error("stream_set_option: unknown key " + k); return -1; }
     PF_REQUIRE(k != "gemm_mode" || value == 0 || value == 3, "stream_set_option: gemm_mode is 0 (fp32 kernels) or 3 (f16x2)");
     PF_HIP_TRY(hipStreamSynchronize(st->stream));
     if (k == "ln_carry") st->ln_carry = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (k == "fsmn_rides") st->fsmn_rides = value != 0;
     else if (k == "kv_batched") st->kv_batched = value != 0;
     else if (k == "wide_k") st->wide_k = value != 0;
+    else if (k == "ln_folded") st->ln_folded = value != 0;
     else {
         if (value == 3) {
             int rc = stream_prepare_x2(st, st->stream);

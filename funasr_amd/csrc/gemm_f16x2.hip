@@ -723,6 +723,11 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         p.C = a.part; p.ldc = a.N; p.bias = nullptr; p.relu = 0; p.R1 = nullptr; p.R2 = nullptr; p.tile = 0;
         int rc = launch_tile<2, 2, 0, 0, 0, 0, 2>(p, stream);            // 128 x 128 blocks, two workgroups per CU
         if (rc) return rc;
+        if (a.ln_g) {
+            PF_REQUIRE(!a.relu && !a.R1 && a.ln_b && a.ln_y, "gemm_f16x2: the split-K + LayerNorm form takes bias and R2 only");
+            return launch_splitk_reduce_ln(a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N, a.bias, a.R2, a.ldr2, a.C, a.ldc, a.ln_g, a.ln_b,
+                                           a.ln_eps, a.ln_y, a.ln_ldy, a.ln_out, a.ln_plane, a.ln_oscale, stream);
+        }
         const size_t total = (size_t)a.M * (a.N >> 2);
         const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N,

@@ -98,6 +98,80 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// The second launch of a split-K GEMM (gemm_f16x2.hip) and the LayerNorm that follows it as one: a row's slices are added in
+// slice order, + bias, R2 + (the epilogue order of splitk_reduce_kernel), the finished row goes to C (fp32) and -- normalised by
+// the statements of layernorm_kernel above, same lane-to-chunk map, same reductions: the bits of the two launches -- to y.
+// One wave per row; OUT as above (0 fp32, 3 two fp16 planes of result * oscale).
+template <int NV, int OUT>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ part, int slices, size_t slice_stride, int M, int D,
+                                                               const float* __restrict__ bias, const float* R2, int ldr2, float* C, int ldc,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               float* __restrict__ y, int ldy, size_t plane, float oscale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nchunk = D >> 2;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) {
+            const float* src = part + (size_t)row * D + 4 * c;
+            float4 t = *reinterpret_cast<const float4*>(src);
+            for (int z = 1; z < slices; ++z) {
+                const float4 u = *reinterpret_cast<const float4*>(src + (size_t)z * slice_stride);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c);
+                t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+            }
+            if (R2) {
+                const float4 r = *reinterpret_cast<const float4*>(R2 + (size_t)row * ldr2 + 4 * c);
+                t.x = r.x + t.x; t.y = r.y + t.y; t.z = r.z + t.z; t.w = r.w + t.w;
+            }
+            *reinterpret_cast<float4*>(C + (size_t)row * ldc + 4 * c) = t;
+            v[j] = t;
+            s += ln_sum4(t);
+        } else {
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    s = wave_sum(s);
+    const float mean = ln_mean(s, D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nchunk) q += ln_sqdev4(v[j], mean);
+    }
+    q = wave_sum(q);
+    const float rstd = ln_rstd(q, D, eps);
+    float* yr = y + (size_t)row * ldy;
+    unsigned short* yb = reinterpret_cast<unsigned short*>(y) + (size_t)row * ldy;
+    const bool wide_st = OUT == 3 && D % 8 == 0 && ldy % 8 == 0 && plane % 8 == 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nchunk) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c);
+            const float4 b = *reinterpret_cast<const float4*>(beta + 4 * c);
+            o = ln_apply4(v[j], mean, rstd, g, b);
+        }
+        if (4 * c < D) {
+            if constexpr (OUT == 3) {
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                if (wide_st) store_split2x4_pair(yb + 4 * c, plane, ov, oscale, lane);
+                else store_split2x4(yb + 4 * c, plane, ov, oscale);
+            } else {
+                *reinterpret_cast<float4*>(yr + 4 * c) = o;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_add_pe_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ pe, float* __restrict__ y,
                                                            int T, int D4, float scale, size_t total4) {
@@ -284,6 +358,22 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     else if (nv <= 3) PF_LN(3);
     else PF_LN(8);
 #undef PF_LN
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R2, int ldr2,
+                            float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
+                            size_t plane, float oscale, hipStream_t stream) {
+    PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 512 && slices >= 1 && part && C && y && gamma && beta, "splitk_reduce_ln: D % 4, D <= 512");
+    PF_REQUIRE(ldc % 4 == 0 && ldy % 4 == 0 && (!R2 || ldr2 % 4 == 0) && slice_stride % 4 == 0 && (out_mode == 0 || out_mode == 3),
+               "splitk_reduce_ln: strides % 4; fp32 or two-plane output");
+    PF_REQUIRE(((uintptr_t)part & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+               (!R2 || ((uintptr_t)R2 & 15) == 0), "splitk_reduce_ln: operands must be 16-B aligned");
+    dim3 grid(ceil_div(M, 4)), block(256);
+    // (NV = 2 like launch_layernorm picks for D <= 512: the same lane-to-chunk map, hence the same bits)
+    if (out_mode == 3) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 3>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
+    else hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 0>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

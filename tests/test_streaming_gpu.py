@@ -255,8 +255,8 @@ def test_step_launch_fusions_leave_the_session_unchanged(cuda):
     g, cfg, sd, wav = load()
     model = build(cfg, sd, cuda)
 
-    def session(opts, S=1):
-        sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=True, precision="fp32")
+    def session(opts, S=1, precision="fp32"):
+        sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=True, precision=precision)
         for k, v in opts.items():
             sb.set_option(k, v)
         out = []
@@ -277,3 +277,8 @@ def test_step_launch_fusions_leave_the_session_unchanged(cuda):
         for a, b in zip(plain, session({"ln_carry": 1, "fsmn_rides": 1, "kv_batched": 1, "wide_k": 1}, S)):
             assert a[0] == b[0], S
             assert (a[1] - b[1]).abs().max().item() < 1e-4, S
+        # the f16x2 step: "ln_folded" (LayerNorms in the second launch of the split-K projections, attention writing the operand
+        # planes of the out-projection) and the FSMN rider repeat the separate launches' arithmetic: the same bits
+        plain2 = session({"ln_folded": 0, "fsmn_rides": 0}, S, "f16x2")
+        for a, b in zip(plain2, session({"ln_folded": 1, "fsmn_rides": 1}, S, "f16x2")):
+            assert a[0] == b[0] and torch.equal(a[1], b[1]), S
