@@ -229,9 +229,11 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
         step(More{}, nk - 2, a0, b0, a1, b1);
         step(Last{}, nk - 1, a1, b1, a0, b0);
     } else if constexpr (KS_ == 16) {
-        // ring of three 16-deep stages: stage kt + 2 is issued while stage kt is multiplied; a wave's pieces retire in order, so
-        // "at most PPW outstanding" means its pieces of stage kt have landed; the barrier then covers the other waves' pieces
-        // and frees the buffer of stage kt - 1 (= the one stage kt + 2 goes into)
+        // ring of three 16-deep stages: stage kt + 2 is issued while stage kt is multiplied. MEASUREMENT HOOK ONLY (tile 5, never
+        // chosen by shape): the counted wait below assumes that a wave's LDS-DMA pieces retire in issue order, so that "at most
+        // PPW outstanding" means its pieces of stage kt have landed. Round 4 showed that assumption false on this hardware when
+        // the pieces come from different sources (gemm_f16x2_ffn.hip header: a few stale workgroups per thousand at 50-block
+        // depth); the shapes the engine picks wait with vmcnt(0) or by buffer ownership (the deep ring below).
 #pragma unroll
         for (int i = 0; i < PPW; ++i) piece(i, 0, 0);
         if (nk > 1) {
