@@ -336,7 +336,14 @@ int pf_stream_reset(pf_stream* s, void* stream);
  * one or a few streams); 3 = on the fp16 matrix cores with two-plane fp16 operands and fp32 results (the offline f16x2 mode's
  * arithmetic, pf_encoder_set_precision 3: the throughput path of many lock-step streams). Attention, FSMN, CIF and the caches
  * stay fp32 in both. The reference has one arithmetic (torch fp32, paraformer_streaming/model.py:552-763); both modes meet
- * its parity bars. Synchronises, prepares the weight planes, drops captured graphs. */
+ * its parity bars. Synchronises, prepares the weight planes, drops captured graphs.
+ * A/B switches of the step's launch fusions (defaults in brackets; all but "ln_carry" return the bits of the
+ * separate launches): "ln_carry" [2] fp32 step: LayerNorms carried between the small-M GEMMs (0 never, 1 steps of <= 32 rows,
+ * 2 always; one-pass variance: fp32-class, not the bits of the stand-alone LayerNorm); "fsmn_rides" [1] the encoder's FSMN memory
+ * block inside the attention launch; "kv_batched" [1] fp32 step: the decoder's key/value projections of the step's encoder rows
+ * and the ring appends as one launch each; "ln_folded" [1] f16x2 step: LayerNorms in the second launch of the split-K
+ * projections, attention writing the out-projection's operand planes; "wide_k" [0] four workgroups per tile for the long-K
+ * projections of a <= 32-row step (bitwise, slower: measured and kept off). */
 int pf_stream_set_option(pf_stream* s, const char* key, int32_t value);
 /* One chunk for every stream. feats_dev: [n_streams, n_frames, input_dim] un-scaled online features (ignored for a
  * tail chunk, which re-feeds the cached window, model.py:715-720). Outputs: ids_host int32 [n_streams, max_tokens]
