@@ -301,7 +301,8 @@ struct Gemm2Args {
     int ksplit; float* part;
     // split-K form only: ln_g != nullptr folds the LayerNorm that follows into the second launch (launch_splitk_reduce_ln,
     // rowwise.hip: the bits of the two launches): LayerNorm(C) goes to ln_y as fp32 (ln_out 0, row stride ln_ldy) or as two fp16
-    // planes of result * ln_oscale (ln_out 3, ln_plane elements apart). N <= 512, no relu, no R1.
+    // planes of result * ln_oscale (ln_out 3, ln_plane elements apart). N <= 512, no relu.
+    // Without ln_g the split-K form may write the planes of the result * cscale (C2 / ldc2 / c_plane: w_1 -> w_2) instead of C.
     const float* ln_g; const float* ln_b; float ln_eps; float* ln_y; int ln_ldy; int ln_out; size_t ln_plane; float ln_oscale;
     int kslices;                                        // set by the launcher: what the kernel sees (slice = blockIdx.y)
 };
@@ -381,8 +382,8 @@ int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* 
 // b * seq_out + t reads input row b * seq_in + t
 // out_mode 1 / in_bf16: y / x is a bf16 buffer (ldy / ldx in elements); out_mode 2: y receives the three bf16 planes
 // of the result (split3), `plane` elements apart; statistics are always fp32
-int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R2, int ldr2,
-                            float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
+int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R1, int ldr1,
+                            const float* R2, int ldr2, float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
                             size_t plane, float oscale, hipStream_t stream);
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
                      int M, int D, int Dpad, float eps, hipStream_t stream, int out_mode = 0, int in_bf16 = 0,

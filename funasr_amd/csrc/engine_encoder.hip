@@ -312,10 +312,11 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     unsigned short* xn2c = e->xn16.as<unsigned short>();
     unsigned short* ctx2c = e->ctx16.as<unsigned short>();
     unsigned short* ffn2c = e->ffn16.as<unsigned short>();
-    // ln_next: the block after this one -- its norm1 is folded into the second launch of the split-K form (planes -> xn2c)
+    // ln: the LayerNorm that follows the projection, folded into the second launch of the split-K form (planes -> xn2c)
+    struct LnFold { const float* g; const float* b; int e; };
     auto gemm2c = [&](const unsigned short* A, int lda, int ea, const unsigned short* W, int ew, const float* bias, float* C, int ldc,
                       unsigned short* C2, int ec, int N, int K, int relu, const float* R1, int ldr1, const float* R2, int ldr2,
-                      const EncLayerW* ln_next = nullptr) {
+                      const LnFold* ln = nullptr) {
         Gemm2Args g{};
         g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)N * K;
         g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
@@ -324,10 +325,13 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
         // the long-K projection (w_2) of a step is at most a block per CU: always in its split-K form here (by caller, whatever
         // the stream count, so a stream's result does not depend on its neighbours)
         if (C && K >= 4 * D && K % 128 == 0 && e->splitk.p) { g.ksplit = 4; g.part = e->splitk.as<float>(); }
-        if (ln_next) {
-            if (g.ksplit <= 1 || N != D || R1) { set_error("encoder: LayerNorm folding needs the split-K form of an N = d_model projection"); return -1; }
-            g.ln_g = ln_next->n1g; g.ln_b = ln_next->n1b; g.ln_eps = c.ln_eps; g.ln_y = reinterpret_cast<float*>(xn2c); g.ln_ldy = D;
-            g.ln_out = 3; g.ln_plane = (size_t)M * D; g.ln_oscale = pow2f(ln_next->e_x1);
+        // a step of few rows leaves most CUs idle and a block's K loop runs at ~0.85 us per 32-deep stage whatever the block count:
+        // the K = d_model projections in four slices too (x2_short_k: by the handle's stream count, never by the step's data)
+        if (cc->x2_short_k && K % 128 == 0 && e->splitk.p) { g.ksplit = 4; g.part = e->splitk.as<float>(); }
+        if (ln) {
+            if (g.ksplit <= 1 || N != D) { set_error("encoder: LayerNorm folding needs the split-K form of an N = d_model projection"); return -1; }
+            g.ln_g = ln->g; g.ln_b = ln->b; g.ln_eps = c.ln_eps; g.ln_y = reinterpret_cast<float*>(xn2c); g.ln_ldy = D;
+            g.ln_out = 3; g.ln_plane = (size_t)M * D; g.ln_oscale = pow2f(ln->e);
         }
         ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s);
         return launch_gemm_f16x2(g, s);
@@ -408,11 +412,16 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     const float* resid = (w.in_dim == D) ? x_in : nullptr;
     if (x2c) {
         if (!o2 && (rc = launch_split2(ctx, D, ctx2c, D, (size_t)M * D, M, D, pow2f(w.e_v), s))) return rc;
-        if ((rc = gemm2c(ctx2c, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid, ld_in))) return rc;
+        // (short-K split: norm2's planes come from linear_out's second launch)
+        const LnFold n2{w.n2g, w.n2b, w.e_x2};
+        const bool fold2 = cc->x2_short_k && cc->x2_fold && D % 128 == 0 && e->splitk.p;
+        if ((rc = gemm2c(ctx2c, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid, ld_in, fold2 ? &n2 : nullptr))) return rc;
         // norm2 -> FFN -> residual: w_1 hands its relu output to w_2 as planes, like the offline mode
-        if ((rc = ln_planes(x, D, w.n2g, w.n2b, D, D, w.e_x2))) return rc;
+        if (!fold2 && (rc = ln_planes(x, D, w.n2g, w.n2b, D, D, w.e_x2))) return rc;
         if ((rc = gemm2c(xn2c, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2c, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
-        return gemm2c(ffn2c, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D, cc->x2_out_next);
+        const LnFold n1n{cc->x2_out_next ? cc->x2_out_next->n1g : nullptr, cc->x2_out_next ? cc->x2_out_next->n1b : nullptr,
+                         cc->x2_out_next ? cc->x2_out_next->e_x1 : 0};
+        return gemm2c(ffn2c, F, w.e_h, w.w2_2, w.ew_2, w.b2, x, D, nullptr, 0, D, F, 0, nullptr, 0, x, D, cc->x2_out_next ? &n1n : nullptr);
     }
     if (carry) {
         // norm2 rides between linear_out and w_1; the next block's norm1 between w_2 and its QKV projection

@@ -395,6 +395,8 @@ struct EncChunkCtx {
     // f16x2 step: norm1 of the block after this one rides in the second launch of this block's split-K w_2 (launch_splitk_reduce_ln)
     const EncLayerW* x2_out_next = nullptr;
     bool x2_in_ready = false;
+    bool x2_short_k = false;     // f16x2 step of few rows: the K = d_model projections in the four-slice split-K form too
+    bool x2_fold = false;        // (with x2_short_k) norm2 from linear_out's second launch
     bool x2_attn_planes = false; // f16x2 step: the attention writes the out-projection's operand planes (AttnArgs.O2)
     bool fsmn_rides = false;     // the FSMN memory block is computed by extra workgroups of the attention launch (AttnArgs.fs_*)
     const EncLayerW* next = nullptr;
@@ -489,6 +491,11 @@ struct Stream {
     bool wide_k = false;                                     // long-K N = 512 projections of a <= 32-row step over four workgroups per tile
     DevBuf ws_part, ws_count;                                // their slice tiles and tile counters (GemmArgs.ws_part / ws_count)
     DevBuf dec_ln_a, dec_ln_b, dec_ln_f;                     // decoder: block partials of the token rows (d_model wide twice, ffn wide)
+    // f16x2 step: the K = d_model projections in four K slices when the handle's rows (streams x window) leave most CUs idle
+    // (<= 2048 rows): 1 = that rule, 0 = never, 2 = always. By the handle, never by a step's data. OFF: measured at S = 64 the
+    // GEMMs drop from 19 to 15.5 us (a 128 x 128 block costs ~12 us before its first K stage counts) and the 100 extra
+    // reduce launches of 7.5 us give it all back (7.79 vs 7.81 ms per step; S = 16: -5 %, S = 128: +0.3 %).
+    int short_k = 0;
     bool ln_folded = true;                                   // f16x2 step: LayerNorms folded into the split-K reductions, attention writes planes
     bool kv_batched = true;                                  // fp32 step: the decoder's key/value projections of the encoder rows as one launch
     unsigned long long ver_e = ~0ull, ver_d = ~0ull;         // TensorTable versions the prepared exponents / planes belong to

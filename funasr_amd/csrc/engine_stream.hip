@@ -56,6 +56,11 @@ static bool stream_x2_ready(const Stream* st) {
     return d->last.x2_ready && d->tt.b16.count("output_layer.weight#split2") != 0 && (int)st->e_ctx.size() == d->cfg.n_blocks;
 }
 
+// the f16x2 step's K = d_model projections in the split-K form: by the handle's size (streams x largest window), see Stream.short_k
+static bool stream_short_k(const Stream* st) {
+    return st->short_k == 2 || (st->short_k == 1 && (size_t)st->S * st->Wmax <= 2048);
+}
+
 // enqueue one chunk on `s` (no host synchronisation, no allocation after the first call with this shape)
 static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t s) {
     Encoder* e = st->e; Predictor* p = st->p; Decoder* d = st->d;
@@ -80,7 +85,8 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             return -2;
         if (st->x2 && (e->xn16.ensure(sizeof(unsigned short) * 2 * Mz * (Dpad > D ? Dpad : D)) ||
                        e->ctx16.ensure(sizeof(unsigned short) * 2 * Mz * D) || e->ffn16.ensure(sizeof(unsigned short) * 2 * Mz * F) ||
-                       st->mem2.ensure(sizeof(unsigned short) * 2 * Mz * D) || e->splitk.ensure(sizeof(float) * 4 * Mz * D)))
+                       st->mem2.ensure(sizeof(unsigned short) * 2 * Mz * D) ||
+                       e->splitk.ensure(sizeof(float) * 4 * Mz * (stream_short_k(st) ? (F > 3 * D ? F : 3 * D) : D))))
             return -2;
     }
     if ((rc = launch_fill_int(st->lensW.as<int>(), S, W, s))) return rc;
@@ -105,6 +111,8 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
                        st->lensW.as<int>(), st->x2};
         cc.fsmn_rides = st->fsmn_rides;
         cc.x2_attn_planes = st->x2 && st->ln_folded;
+        cc.x2_short_k = st->x2 && stream_short_k(st);
+        cc.x2_fold = st->ln_folded;
         if (st->x2 && st->ln_folded && F >= 4 * D && F % 128 == 0) {
             // (the condition of gemm2c's split-K form; block l + 1 must take the folded planes: same width, no padding columns)
             const bool nxt = l + 1 < e->layers.size() && e->layers[l + 1].in_dim == D && e->layers[l + 1].in_pad == D;
@@ -484,7 +492,7 @@ int pf_stream_set_option(pf_stream* sh, const char* key, int32_t value) {
     Stream* st = reinterpret_cast<Stream*>(sh);
     PF_REQUIRE(st && key, "stream_set_option: null");
     const std::string k = key;
-    if (k != "gemm_mode" && k != "ln_carry" && k != "fsmn_rides" && k != "kv_batched" && k != "wide_k" && k != "ln_folded") { set_error("stream_set_option: unknown key " + k); return -1; }
+    if (k != "gemm_mode" && k != "ln_carry" && k != "fsmn_rides" && k != "kv_batched" && k != "wide_k" && k != "ln_folded" && k != "short_k") { set_error("stream_set_option: unknown key " + k); return -1; }
     PF_REQUIRE(k != "gemm_mode" || value == 0 || value == 3, "stream_set_option: gemm_mode is 0 (fp32 kernels) or 3 (f16x2)");
     PF_HIP_TRY(hipStreamSynchronize(st->stream));
     if (k == "ln_carry") st->ln_carry = value < 0 ? 0 : value > 2 ? 2 : value;
@@ -492,6 +500,7 @@ int pf_stream_set_option(pf_stream* sh, const char* key, int32_t value) {
     else if (k == "kv_batched") st->kv_batched = value != 0;
     else if (k == "wide_k") st->wide_k = value != 0;
     else if (k == "ln_folded") st->ln_folded = value != 0;
+    else if (k == "short_k") st->short_k = value < 0 ? 0 : value > 2 ? 2 : value;
     else {
         if (value == 3) {
             int rc = stream_prepare_x2(st, st->stream);

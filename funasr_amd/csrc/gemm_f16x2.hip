@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256) void rowl1_bound_kernel(const float* __restric
 // R2 +); slices are added in slice order by one thread per float4 (deterministic). R1 / R2 may alias C.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int slices, size_t slice_stride, int M, int N,
                                                             const float* __restrict__ bias, int relu, const float* R1, int ldr1,
-                                                            const float* R2, int ldr2, float* C, int ldc) {
+                                                            const float* R2, int ldr2, float* C, int ldc, unsigned short* C2, int ldc2,
+                                                            size_t c_plane, float cscale) {
     const int n4 = N >> 2;
     const size_t total = (size_t)M * n4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -564,7 +565,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             const float4 r = *reinterpret_cast<const float4*>(R2 + (size_t)row * ldr2 + col);
             v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
         }
-        *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+        if (C2) {                                   // the planes of the result * cscale (the next GEMM's operand)
+            const float o[4] = {v.x, v.y, v.z, v.w};
+            store_split2x4(C2 + (size_t)row * ldc2 + col, c_plane, o, cscale);
+        } else {
+            *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+        }
     }
 }
 
@@ -712,9 +718,11 @@ int gemm_f16x2_argmax_parts(int M, int N) { (void)M; return 2 * ceil_div(N, 256)
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
     PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f16x2: empty problem");
     if (a.ksplit > 1) {
-        PF_REQUIRE(a.C && a.part && !a.C2 && !a.amax_val && a.qkv_D <= 0 && a.a_kstep <= 0 && a.w_kstep <= 0 &&
-                   a.K % (32 * a.ksplit) == 0 && a.N % 4 == 0 && a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0 && ((uintptr_t)a.part & 15) == 0,
-                   "gemm_f16x2: the split-K form takes fp32 output, K % (32 ksplit) == 0, a partial buffer [ksplit][M][N]");
+        PF_REQUIRE((a.C || a.C2) && a.part && !a.amax_val && a.qkv_D <= 0 && a.a_kstep <= 0 && a.w_kstep <= 0 &&
+                   a.K % (32 * a.ksplit) == 0 && a.N % 4 == 0 && ((uintptr_t)a.part & 15) == 0,
+                   "gemm_f16x2: the split-K form needs K % (32 ksplit) == 0 and a partial buffer [ksplit][M][N]");
+        if (a.C2) PF_REQUIRE(!a.ln_g && a.ldc2 % 4 == 0 && a.c_plane % 4 == 0 && ((uintptr_t)a.C2 & 7) == 0, "gemm_f16x2: split-K plane output alignment");
+        else PF_REQUIRE(a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_f16x2: split-K output alignment");
         PF_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_plane % 8 == 0 && a.w_plane % 8 == 0 && ((uintptr_t)a.A & 15) == 0 &&
                    ((uintptr_t)a.W & 15) == 0 && (a.K / a.ksplit) % 8 == 0, "gemm_f16x2: operand alignment");
         if (a.bias) PF_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm_f16x2: bias alignment");
@@ -722,18 +730,18 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         if (a.R2) PF_REQUIRE(a.ldr2 % 4 == 0 && ((uintptr_t)a.R2 & 15) == 0, "gemm_f16x2: R2 alignment");
         Gemm2Args p = a;
         p.ksplit = 0; p.kslices = a.ksplit; p.K = a.K / a.ksplit;
-        p.C = a.part; p.ldc = a.N; p.bias = nullptr; p.relu = 0; p.R1 = nullptr; p.R2 = nullptr; p.tile = 0;
+        p.C = a.part; p.ldc = a.N; p.C2 = nullptr; p.bias = nullptr; p.relu = 0; p.R1 = nullptr; p.R2 = nullptr; p.tile = 0;
         int rc = launch_tile<2, 2, 0, 0, 0, 0, 2>(p, stream);            // 128 x 128 blocks, two workgroups per CU
         if (rc) return rc;
         if (a.ln_g) {
-            PF_REQUIRE(!a.relu && !a.R1 && a.ln_b && a.ln_y, "gemm_f16x2: the split-K + LayerNorm form takes bias and R2 only");
-            return launch_splitk_reduce_ln(a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N, a.bias, a.R2, a.ldr2, a.C, a.ldc, a.ln_g, a.ln_b,
+            PF_REQUIRE(!a.relu && a.ln_b && a.ln_y, "gemm_f16x2: the split-K + LayerNorm form takes bias and the addends, no relu");
+            return launch_splitk_reduce_ln(a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N, a.bias, a.R1, a.ldr1, a.R2, a.ldr2, a.C, a.ldc, a.ln_g, a.ln_b,
                                            a.ln_eps, a.ln_y, a.ln_ldy, a.ln_out, a.ln_plane, a.ln_oscale, stream);
         }
         const size_t total = (size_t)a.M * (a.N >> 2);
         const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N,
-                           a.bias, a.relu, a.R1, a.ldr1, a.R2, a.ldr2, a.C, a.ldc);
+                           a.bias, a.relu, a.R1, a.ldr1, a.R2, a.ldr2, a.C, a.ldc, a.C2, a.ldc2, a.c_plane, a.cscale);
         PF_HIP_TRY(hipGetLastError());
         return 0;
     }

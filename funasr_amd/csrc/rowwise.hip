@@ -104,9 +104,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // One wave per row; OUT as above (0 fp32, 3 two fp16 planes of result * oscale).
 template <int NV, int OUT>
 __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ part, int slices, size_t slice_stride, int M, int D,
-                                                               const float* __restrict__ bias, const float* R2, int ldr2, float* C, int ldc,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                               float* __restrict__ y, int ldy, size_t plane, float oscale) {
+                                                               const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2,
+                                                               float* C, int ldc, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
+                                                               size_t plane, float oscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -126,6 +127,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __re
             if (bias) {
                 const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c);
                 t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+            }
+            if (R1) {
+                const float4 r = *reinterpret_cast<const float4*>(R1 + (size_t)row * ldr1 + 4 * c);
+                t.x = t.x + r.x; t.y = t.y + r.y; t.z = t.z + r.z; t.w = t.w + r.w;
             }
             if (R2) {
                 const float4 r = *reinterpret_cast<const float4*>(R2 + (size_t)row * ldr2 + 4 * c);
@@ -362,18 +367,19 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     return 0;
 }
 
-int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R2, int ldr2,
-                            float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
+int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R1, int ldr1,
+                            const float* R2, int ldr2, float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
                             size_t plane, float oscale, hipStream_t stream) {
     PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 512 && slices >= 1 && part && C && y && gamma && beta, "splitk_reduce_ln: D % 4, D <= 512");
-    PF_REQUIRE(ldc % 4 == 0 && ldy % 4 == 0 && (!R2 || ldr2 % 4 == 0) && slice_stride % 4 == 0 && (out_mode == 0 || out_mode == 3),
+    PF_REQUIRE(ldc % 4 == 0 && ldy % 4 == 0 && (!R2 || ldr2 % 4 == 0) && (!R1 || (ldr1 % 4 == 0 && ((uintptr_t)R1 & 15) == 0)) &&
+                   slice_stride % 4 == 0 && (out_mode == 0 || out_mode == 3),
                "splitk_reduce_ln: strides % 4; fp32 or two-plane output");
     PF_REQUIRE(((uintptr_t)part & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
                (!R2 || ((uintptr_t)R2 & 15) == 0), "splitk_reduce_ln: operands must be 16-B aligned");
     dim3 grid(ceil_div(M, 4)), block(256);
     // (NV = 2 like launch_layernorm picks for D <= 512: the same lane-to-chunk map, hence the same bits)
-    if (out_mode == 3) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 3>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
-    else hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 0>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
+    if (out_mode == 3) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 3>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R1, ldr1, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
+    else hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 0>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R1, ldr1, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

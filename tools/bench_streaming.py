@@ -56,6 +56,13 @@ def main():
         # the same session in every (precision, graph) setting: the warm-up steps' ids must agree (fp32-class arithmetic)
         same = first_ids.setdefault(S, trace) == trace
         torch.cuda.synchronize()
+        tel = None
+        try:                                      # shader clock / socket power of the timed region (tools/gpu_telemetry.py)
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from gpu_telemetry import Sampler
+            tel = Sampler(0, period_s=0.005).start()
+        except Exception:
+            tel = None
         lat = []
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -64,6 +71,7 @@ def main():
             lat.append(time.perf_counter() - t1)
             ntok += sum(len(r) for r in ids)
         dt = time.perf_counter() - t0
+        tstat = tel.stop() if tel is not None else {}
         lat.sort()
         print(json.dumps({"metric": "streaming chunks/s (600 ms chunk, Paraformer-large-online)", "streams": S,
                           "hipgraph": graph, "steps": args.steps, "chunks_per_s": round(S * args.steps / dt, 1),
@@ -71,7 +79,7 @@ def main():
                           "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3),
                           "tokens_per_chunk": round(ntok / (S * args.steps), 2),
                           "dtype": "f32" if prec == "fp32" else "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMA products)",
-                          "precision": prec, "ln_carry": bool(carry) if prec == "fp32" else None, "options": args.set, "warmup_ids_equal_first_setting": same}), flush=True)
+                          "sclk_mhz_mean": tstat.get("sclk_mhz_mean"), "power_w_mean": tstat.get("power_w_mean"), "precision": prec, "ln_carry": bool(carry) if prec == "fp32" else None, "options": args.set, "warmup_ids_equal_first_setting": same}), flush=True)
         sb.close()
 
 
