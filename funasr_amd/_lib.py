@@ -165,7 +165,8 @@ SIGNATURES = {
                                        _i32, _i32, C.POINTER(C.c_float), _vp]),
     "pf_k_gemm_f16x2_row": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _f32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32,
                                       _vp, _i64, _f32, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
-    "pf_k_gemm_skinny_ln": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]),
+    "pf_k_gemm_skinny_ln": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "pf_k_ln_consts": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pf_k_ffn_f16x2": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _f32, _vp, _i32, _i32, _i32,
                                  C.POINTER(C.c_float), _vp]),
     "pf_k_gemm_f16x2_row_fsmn": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _f32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32,

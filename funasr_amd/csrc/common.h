@@ -223,14 +223,17 @@ struct GemmArgs {
     // step is a chain of ~600 dependent launches; a stand-alone LayerNorm of 15 rows costs a whole launch slot).
     // Producer side: ln_stats_out [M][N / 16][2] receives, per output row and 16-column block, (sum, sum of squares) of the
     // FINISHED outputs (after bias / ReLU / addends); N % 16 == 0.
-    // Consumer side: ln_stats_in != nullptr makes the A operand LayerNorm(A) on the fly: row statistics from the K / 16 block
-    // partials (summed in a fixed order that depends on K only), a' = (a - mean) * rstd * gamma + beta applied to each loaded
-    // element; K is the normalised width (no padding columns).
+    // Consumer side: ln_stats_in != nullptr computes C = W LayerNorm(A) + bias as rstd (W (gamma A) - mean c1) + c2 with the row's
+    // (mean, rstd) from the K / 16 block partials (summed in an order that depends on K only; K <= 2048 = the normalised width,
+    // no padding columns) and the per-weight constants ln_c1 = W gamma, ln_c2 = W beta + bias ([N] each, launch_ln_consts; `bias`
+    // is then ignored). ln_g = gamma multiplies the A fragments in the loop; ln_g == nullptr: the producer stored gamma A
+    // (out_gamma). Producer side also: out_gamma [N] != nullptr stores C * out_gamma (the partials stay those of C).
+    const float* ln_c1; const float* ln_c2; const float* out_gamma;
     // the four-workgroup form of a <= 32-row problem (see gemm_skinny.hip): slice tiles [tiles][16][rows of a tile][16] and one
     // zeroed int per tile (the kernel leaves them zero); tiles = ceil(N / 16) * ceil(M / 16 or 32). Same bits as without.
     float* ws_part; int* ws_count;
     float* ln_stats_out;
-    const float* ln_stats_in; const float* ln_g; const float* ln_b; float ln_eps;
+    const float* ln_stats_in; const float* ln_g; float ln_eps;
 };
 int launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 // small-M weight-streaming variant (gemm_skinny.hip); same contract, no fused arg-max
@@ -238,6 +241,10 @@ bool gemm_skinny_applicable(const GemmArgs& a);
 // the small-M GEMM for up to 16 weight matrices sharing A / M / N / K / strides (gemm_skinny.hip): one launch, a row's bits
 // those of the single launches
 struct GemmBatch { int n; const float* W[16]; const float* bias[16]; float* C[16]; };
+// c1[n] = sum_k gamma[k] W[n][k], c2[n] = sum_k beta[k] W[n][k] + bias[n] (bias may be null): the constants of the LayerNorm form
+// of the small-M GEMM (rowwise.hip; one wave per n, fixed summation order)
+int launch_ln_consts(const float* W, int ldw, int N, int K, const float* gamma, const float* beta, const float* bias, float* c1, float* c2,
+                     hipStream_t stream);
 int launch_gemm_skinny_batch(const GemmArgs& a, const GemmBatch& t, hipStream_t stream);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);
 

@@ -343,13 +343,14 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     };
     // fp32 step with the LayerNorms carried by the small-M GEMMs (EncChunkCtx.ln_stats): gemm() routes to gemm_skinny.hip in a step
     const bool carry = cc && !x2c && cc->ln_stats && g_stream_mode && D % 16 == 0 && F % 16 == 0;
+    // (st_in != nullptr: the LayerNorm form with gamma g_ and the pair's constants cst = c1 [N], then c2)
     auto gemm_ln = [&](const float* A, int lda, const float* Wt, int ldw, const float* bias, float* C, int ldc, int N, int K, int relu,
                        const float* R1, int ldr1, const float* R2, int ldr2, float* st_out, const float* st_in, const float* g_,
-                       const float* b_) {
+                       const float* cst) {
         GemmArgs g{};
         g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
         g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.relu = relu;
-        g.ln_stats_out = st_out; g.ln_stats_in = st_in; g.ln_g = g_; g.ln_b = b_; g.ln_eps = c.ln_eps;
+        g.ln_stats_out = st_out; g.ln_stats_in = st_in; g.ln_g = g_; g.ln_eps = c.ln_eps; g.ln_c1 = cst; g.ln_c2 = cst ? cst + N : nullptr;
         ProfScope ps(PROF_GEMM, 2.0 * M * (double)N * K, s);
         return gemm(g, s);
     };
@@ -363,7 +364,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     } else if (carry && cc->ln_in_ready) {
         // norm1 on the fetch: the block before left the row partials of x in its w_2 epilogue
         if ((rc = gemm_ln(x_in, ld_in, w.qkv_w, w.in_pad, w.qkv_b, qkv, 3 * D, 3 * D, w.in_pad, 0, nullptr, 0, nullptr, 0, nullptr,
-                          cc->ln_stats, w.n1g, w.n1b))) return rc;
+                          cc->ln_stats, w.n1g, cc->ln_c_qkv))) return rc;
     } else {
         if ((rc = layernorm(x_in, ld_in, w.n1g, w.n1b, xn, w.in_pad, M, w.in_dim, w.in_pad, c.ln_eps, s))) return rc;
         if ((rc = gemm_simple(xn, w.in_pad, w.qkv_w, w.in_pad, w.qkv_b, qkv, 3 * D, M, 3 * D, w.in_pad, 0, nullptr, 0,
@@ -427,7 +428,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
         // norm2 rides between linear_out and w_1; the next block's norm1 between w_2 and its QKV projection
         const bool emit = cc->next && cc->next->in_dim == D;
         if ((rc = gemm_ln(ctx, D, w.out_w, D, w.out_b, x, D, D, D, 0, mem, D, resid, ld_in, cc->ln_stats, nullptr, nullptr, nullptr))) return rc;
-        if ((rc = gemm_ln(x, D, w.w1, D, w.b1, ffn, F, F, D, 1, nullptr, 0, nullptr, 0, nullptr, cc->ln_stats, w.n2g, w.n2b))) return rc;
+        if ((rc = gemm_ln(x, D, w.w1, D, w.b1, ffn, F, F, D, 1, nullptr, 0, nullptr, 0, nullptr, cc->ln_stats, w.n2g, cc->ln_c_w1))) return rc;
         return gemm_ln(ffn, F, w.w2, F, w.b2, x, D, D, F, 0, nullptr, 0, x, D, emit ? cc->ln_stats : nullptr, nullptr, nullptr, nullptr);
     }
     if ((rc = gemm_simple(ctx, D, w.out_w, D, w.out_b, x, D, M, D, D, 0, mem, D, resid, ld_in, s))) return rc;

@@ -392,6 +392,8 @@ struct EncChunkCtx {
     // ran before left the statistics of this block's input there
     float* ln_stats = nullptr;
     bool ln_in_ready = false;
+    const float* ln_c_qkv = nullptr;   // the LayerNorm form's constants of this block's QKV projection: c1 [3 d_model], then c2
+    const float* ln_c_w1 = nullptr;    // of w_1: c1 [ffn_dim], then c2
     // f16x2 step: norm1 of the block after this one rides in the second launch of this block's split-K w_2 (launch_splitk_reduce_ln)
     const EncLayerW* x2_out_next = nullptr;
     bool x2_in_ready = false;
@@ -490,6 +492,11 @@ struct Stream {
     DevBuf ln_stats;
     bool wide_k = false;                                     // long-K N = 512 projections of a <= 32-row step over four workgroups per tile
     DevBuf ws_part, ws_count;                                // their slice tiles and tile counters (GemmArgs.ws_part / ws_count)
+    // constants c1 = W gamma, c2 = W beta + bias of every LayerNorm -> GEMM pair of the fp32 step (launch_ln_consts), prepared from
+    // the handles' weights (ln_ver_*: their TensorTable versions then). Encoder block l: [qkv c1, c2 | w_1 c1, c2]; decoder layer l
+    // (and decoders3 as layer n_blocks): [w_1 c1, c2 | w_2 c1, c2 | linear_q c1, c2]; then the vocabulary projection's c1, c2.
+    DevBuf ln_consts;
+    uint64_t ln_ver_e = ~0ull, ln_ver_d = ~0ull;
     DevBuf dec_ln_a, dec_ln_b, dec_ln_f;                     // decoder: block partials of the token rows (d_model wide twice, ffn wide)
     // f16x2 step: the K = d_model projections in four K slices when the handle's rows (streams x window) leave most CUs idle
     // (<= 2048 rows): 1 = that rule, 0 = never, 2 = always. By the handle, never by a step's data. OFF: measured at S = 64 the

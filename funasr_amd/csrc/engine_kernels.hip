@@ -11,14 +11,19 @@ extern "C" {
  * partials of the finished outputs; stats_in [M][K / 16][2] (+ gamma, beta, eps) makes the A operand LayerNorm(A) on the fetch */
 int pf_k_gemm_skinny_ln(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R2, int32_t ldr2,
                         float* Cout, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t relu, float* stats_out,
-                        const float* stats_in, const float* ln_g, const float* ln_b, float ln_eps, float* ws_part, int32_t* ws_count,
-                        void* stream) {
+                        const float* stats_in, const float* ln_g, const float* ln_c, float ln_eps, const float* out_gamma, float* ws_part,
+                        int32_t* ws_count, void* stream) {
     GemmArgs g{};
-    g.ws_part = ws_part; g.ws_count = ws_count;
+    g.ws_part = ws_part; g.ws_count = ws_count; g.ln_c1 = ln_c; g.ln_c2 = ln_c ? ln_c + N : nullptr; g.out_gamma = out_gamma;
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.R2 = R2; g.ldr2 = ldr2; g.C = Cout; g.ldc = ldc;
-    g.M = M; g.N = N; g.K = K; g.relu = relu; g.ln_stats_out = stats_out; g.ln_stats_in = stats_in; g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps;
+    g.M = M; g.N = N; g.K = K; g.relu = relu; g.ln_stats_out = stats_out; g.ln_stats_in = stats_in; g.ln_g = ln_g; g.ln_eps = ln_eps;
     PF_REQUIRE(gemm_skinny_applicable(g), "gemm_skinny_ln: K % 16");
     return launch_gemm_skinny(g, reinterpret_cast<hipStream_t>(stream));
+}
+/* c[0 .. N) = W gamma, c[N .. 2 N) = W beta + bias: the constants of pf_k_gemm_skinny_ln's LayerNorm form (rowwise.hip) */
+int pf_k_ln_consts(const float* W, int32_t ldw, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias, float* c,
+                   void* stream) {
+    return launch_ln_consts(W, ldw, N, K, gamma, beta, bias, c, c + N, reinterpret_cast<hipStream_t>(stream));
 }
 int pf_set_skinny_max_m(int32_t m) { g_skinny_max_m = m; return 0; }
 

@@ -56,6 +56,45 @@ static bool stream_x2_ready(const Stream* st) {
     return d->last.x2_ready && d->tt.b16.count("output_layer.weight#split2") != 0 && (int)st->e_ctx.size() == d->cfg.n_blocks;
 }
 
+// ---- constants of the fp32 step's LayerNorm -> GEMM pairs (Stream.ln_consts)
+static size_t ln_enc_stride(const Stream* st) { return 2 * ((size_t)3 * st->e->cfg.d_model + st->e->cfg.ffn_dim); }
+static size_t ln_dec_stride(const Stream* st) { return 2 * ((size_t)st->d->cfg.ffn_dim + 2 * st->d->cfg.d_model); }
+static size_t ln_dec_base(const Stream* st) { return ln_enc_stride(st) * st->e->layers.size(); }
+static size_t ln_voc_base(const Stream* st) { return ln_dec_base(st) + ln_dec_stride(st) * (st->d->cfg.n_blocks + 1); }
+static bool stream_ln_ready(const Stream* st) {
+    return st->ln_consts.p && st->e->resolved && st->d->resolved && st->ln_ver_e == st->e->tt.version && st->ln_ver_d == st->d->tt.version;
+}
+static int stream_prepare_ln_consts(Stream* st, hipStream_t s) {
+    Encoder* e = st->e; Decoder* d = st->d;
+    int rc;
+    if (!e->resolved && (rc = encoder_resolve(e))) return rc;
+    if (!d->resolved && (rc = decoder_resolve(d))) return rc;
+    const int D = e->cfg.d_model, F = e->cfg.ffn_dim, Fd = d->cfg.ffn_dim, V = d->cfg.vocab_size;
+    if (st->ln_consts.ensure(sizeof(float) * (ln_voc_base(st) + 2 * (size_t)V))) return -2;
+    float* base = st->ln_consts.as<float>();
+    for (size_t l = 0; l < e->layers.size(); ++l) {
+        const EncLayerW& w = e->layers[l];
+        float* c = base + l * ln_enc_stride(st);
+        if (w.in_dim == D && (rc = launch_ln_consts(w.qkv_w, w.in_pad, 3 * D, D, w.n1g, w.n1b, w.qkv_b, c, c + 3 * D, s))) return rc;
+        c += 2 * 3 * D;
+        if ((rc = launch_ln_consts(w.w1, D, F, D, w.n2g, w.n2b, w.b1, c, c + F, s))) return rc;
+    }
+    for (int l = 0; l <= d->cfg.n_blocks; ++l) {
+        const DecLayerW& w = l < d->cfg.n_blocks ? d->layers[l] : d->last;
+        float* c = base + ln_dec_base(st) + l * ln_dec_stride(st);
+        if ((rc = launch_ln_consts(w.w1, D, Fd, D, w.n1g, w.n1b, w.b1, c, c + Fd, s))) return rc;
+        c += 2 * Fd;
+        if ((rc = launch_ln_consts(w.w2, Fd, D, Fd, w.fng, w.fnb, nullptr, c, c + D, s))) return rc;
+        c += 2 * D;
+        if (l < d->cfg.n_blocks && (rc = launch_ln_consts(w.q_w, D, D, D, w.n3g, w.n3b, w.q_b, c, c + D, s))) return rc;
+    }
+    float* cv = base + ln_voc_base(st);
+    if ((rc = launch_ln_consts(d->tt.get("output_layer.weight"), D, V, D, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"),
+                               d->tt.get("output_layer.bias"), cv, cv + V, s))) return rc;
+    st->ln_ver_e = e->tt.version; st->ln_ver_d = d->tt.version;
+    return 0;
+}
+
 // the f16x2 step's K = d_model projections in the split-K form: by the handle's size (streams x largest window), see Stream.short_k
 static bool stream_short_k(const Stream* st) {
     return st->short_k == 2 || (st->short_k == 1 && (size_t)st->S * st->Wmax <= 2048);
@@ -104,7 +143,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     float* x = e->x.as<float>();
     const size_t ring_layer = (size_t)S * st->enc_cap * 2 * D;
     // (by the row count of the step: the 16- and 32-row forms of the kernel gain a launch, the 64-row form loses to its registers)
-    const bool carry = st->ln_carry && !st->x2 && D % 16 == 0 && (M <= 32 || st->ln_carry > 1);
+    const bool carry = st->ln_carry && !st->x2 && D % 16 == 0 && (M <= 32 || st->ln_carry > 1) && stream_ln_ready(st);
     if (carry && st->ln_stats.ensure(sizeof(float) * 2 * (size_t)S * st->Wmax * (D / 16))) return -2;
     for (size_t l = 0; l < e->layers.size(); ++l) {
         EncChunkCtx cc{st->enc_cap > 0 ? st->enc_ring.as<float>() + l * ring_layer : nullptr, st->enc_cap, dev, append_rows,
@@ -120,6 +159,8 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             cc.x2_in_ready = l > 0 && e->layers[l].in_dim == D && e->layers[l].in_pad == D;
         }
         if (carry) {
+            cc.ln_c_qkv = st->ln_consts.as<float>() + l * ln_enc_stride(st);
+            cc.ln_c_w1 = cc.ln_c_qkv + 2 * 3 * D;
             cc.ln_stats = st->ln_stats.as<float>();
             cc.ln_in_ready = l > 0 && e->layers[l].in_dim == D;     // block l - 1's w_2 left them
             cc.next = l + 1 < e->layers.size() ? &e->layers[l + 1] : nullptr;
@@ -202,33 +243,39 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     }
     // ---- fp32 step of a few token rows: the decoder's LayerNorms ride in the launches on either side (gemm_skinny.hip,
     // DecFsmnChunkArgs.ln_*): 11 launches per layer become 6 with the batched projection above
-    const bool dcarry = st->ln_carry && !x2 && (Mq <= 32 || st->ln_carry > 1) && Nmax <= 24 && D % 16 == 0 && dc.ffn_dim % 16 == 0;
+    const bool dcarry = st->ln_carry && !x2 && (Mq <= 32 || st->ln_carry > 1) && Nmax <= 24 && D % 16 == 0 && dc.ffn_dim % 16 == 0 &&
+                        dc.ffn_dim <= 2048 && stream_ln_ready(st);
     if (dcarry && (st->dec_ln_a.ensure(sizeof(float) * 2 * (size_t)Mq * (D / 16)) || st->dec_ln_b.ensure(sizeof(float) * 2 * (size_t)Mq * (D / 16)) ||
                    st->dec_ln_f.ensure(sizeof(float) * 2 * (size_t)Mq * (dc.ffn_dim / 16))))
         return -2;
     float* sA = st->dec_ln_a.as<float>();
     float* sB = st->dec_ln_b.as<float>();
     float* sF = st->dec_ln_f.as<float>();
+    // st_in != nullptr: the LayerNorm form (gemm_skinny.hip) with the pair's constants c (c1 [N], then c2); g_ = gamma, or nullptr when
+    // the producer stored gamma a (out_g of ITS call: the gamma of the LayerNorm that follows)
     auto gemm_ln = [&](const float* A, int lda, const float* Wt, const float* bias, float* C, int N, int K, int relu, const float* R2,
-                       float* st_out, const float* st_in, const float* g_, const float* b_) {
+                       float* st_out, const float* st_in, const float* g_, const float* c, const float* out_g = nullptr) {
         GemmArgs g{};
         g.A = A; g.lda = lda; g.W = Wt; g.ldw = K; g.bias = bias; g.R2 = R2; g.ldr2 = N; g.C = C; g.ldc = N; g.M = Mq; g.N = N; g.K = K;
-        g.relu = relu; g.ln_stats_out = st_out; g.ln_stats_in = st_in; g.ln_g = g_; g.ln_b = b_; g.ln_eps = dc.ln_eps;
+        g.relu = relu; g.ln_stats_out = st_out; g.ln_stats_in = st_in; g.ln_g = g_; g.ln_eps = dc.ln_eps;
+        g.ln_c1 = c; g.ln_c2 = c ? c + N : nullptr; g.out_gamma = out_g;
         ProfScope ps(PROF_GEMM, 2.0 * Mq * (double)N * K, s);
         return gemm(g, s);
     };
     // FFN of a layer: norm1 from the partials the layer before left in sA (or its own launch), the FFN's inner norm between
     // w_1 and w_2; `out_stats`: where w_2 leaves the partials of its output
-    auto ffn_carry = [&](const DecLayerW& w, bool a_ready, float* out_stats) {
+    // (w_1 stores relu(..) * gamma of the FFN's inner norm: w_2's loop then multiplies nothing)
+    auto ffn_carry = [&](const DecLayerW& w, int l, bool a_ready, float* out_stats) {
         const int F = dc.ffn_dim;
+        const float* c = st->ln_consts.as<float>() + ln_dec_base(st) + (size_t)l * ln_dec_stride(st);
         int r;
-        if (a_ready) r = gemm_ln(dx, D, w.w1, w.b1, d->ffn.as<float>(), F, D, 1, nullptr, sF, sA, w.n1g, w.n1b);
+        if (a_ready) r = gemm_ln(dx, D, w.w1, w.b1, d->ffn.as<float>(), F, D, 1, nullptr, sF, sA, w.n1g, c, w.fng);
         else {
             if ((r = layernorm(dx, D, w.n1g, w.n1b, t1, D, Mq, D, D, dc.ln_eps, s))) return r;
-            r = gemm_ln(t1, D, w.w1, w.b1, d->ffn.as<float>(), F, D, 1, nullptr, sF, nullptr, nullptr, nullptr);
+            r = gemm_ln(t1, D, w.w1, w.b1, d->ffn.as<float>(), F, D, 1, nullptr, sF, nullptr, nullptr, nullptr, w.fng);
         }
         if (r) return r;
-        return gemm_ln(d->ffn.as<float>(), F, w.w2, nullptr, t2, D, F, 0, nullptr, out_stats, sF, w.fng, w.fnb);
+        return gemm_ln(d->ffn.as<float>(), F, w.w2, nullptr, t2, D, F, 0, nullptr, out_stats, sF, nullptr, c + 2 * F);
     };
     for (int l = 0; l < dc.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
@@ -237,10 +284,11 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         fa.in = t1; fa.resid = dx; fa.out = dx; fa.w = w.fsmn_w; fa.state = st->dec_fsmn.as<float>() + l * dfsmn_layer;
         fa.n_valid = st->n_fired.as<int>(); fa.S = S; fa.N = Nmax; fa.C = D;
         if (dcarry) {
-            if ((rc = ffn_carry(w, l > 0, sA))) return rc;
+            if ((rc = ffn_carry(w, l, l > 0, sA))) return rc;
             fa.in = t2; fa.ln_stats_in = sA; fa.ln_g = w.n2g; fa.ln_b = w.n2b; fa.ln_eps = dc.ln_eps; fa.ln_stats_out = sB;
             if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
-            if ((rc = gemm_ln(dx, D, w.q_w, w.q_b, d->q.as<float>(), D, D, 0, nullptr, nullptr, sB, w.n3g, w.n3b))) return rc;
+            if ((rc = gemm_ln(dx, D, w.q_w, w.q_b, d->q.as<float>(), D, D, 0, nullptr, nullptr, sB, w.n3g,
+                              st->ln_consts.as<float>() + ln_dec_base(st) + (size_t)l * ln_dec_stride(st) + 2 * dc.ffn_dim + 2 * D))) return rc;
         } else {
             const bool fold = x2 && st->ln_folded && dc.ffn_dim % 128 == 0;       // norm2 in the second launch of the split-K w_2
             const FoldedLn n2{w.n2g, w.n2b, t1, 0, 1.f};
@@ -315,10 +363,10 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     bool an_folded = false;
     if (dcarry) {
         // decoders3's FFN, then after_norm on the fetch of the vocabulary projection (the hidden rows are not an output of a step)
-        if ((rc = ffn_carry(d->last, dc.n_blocks > 0, sA))) return rc;
+        if ((rc = ffn_carry(d->last, dc.n_blocks, dc.n_blocks > 0, sA))) return rc;
         if (d->pval.ensure(sizeof(float) * (size_t)Mq * V)) return -2;
         if ((rc = gemm_ln(t2, D, d->tt.get("output_layer.weight"), d->tt.get("output_layer.bias"), d->pval.as<float>(), V, D, 0, nullptr,
-                          nullptr, sA, d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias")))) return rc;
+                          nullptr, sA, d->tt.get("after_norm.weight"), st->ln_consts.as<float>() + ln_voc_base(st)))) return rc;
         if ((rc = launch_argmax_rows(d->pval.as<float>(), V, Mq, V, st->ids.as<int32_t>(), s))) return rc;
     } else if (x2) {
         // decoders3's FFN; after_norm's planes (the vocabulary projection's operand) from the second launch of its split-K w_2
@@ -549,6 +597,14 @@ int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t 
         st->graphs.clear();
         st->seen.clear();
         if ((rc = stream_prepare_x2(st, s))) return rc;
+    }
+    if (!st->x2 && st->ln_carry && !stream_ln_ready(st)) {
+        // first step, or a handle's weights changed: the LayerNorm -> GEMM constants follow them (graphs hold no stale values, only
+        // the buffer's address -- which may have moved)
+        for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+        st->graphs.clear();
+        st->seen.clear();
+        if ((rc = stream_prepare_ln_consts(st, s))) return rc;
     }
     const bool graphable = st->use_graph && !g_prof_on;
     if (st->graph_epoch != g_ws_epoch) {

@@ -25,18 +25,18 @@ constexpr int SK_KW = 16;    // waves per workgroup = K slices (a constant: a ro
 // the same for every RM / CN, so the choice changes speed only, never a bit of the result (tested).
 // Measured and dropped: four waves with four slices each in four accumulator sets (a quarter of the LDS partials; same
 // summation tree): S = 8 streams 8.2 vs 7.0 ms per step, S = 64 12.0 vs 11.0 -- the sixteen-wave form keeps more loads in flight.
-// LNIN: the A operand is LayerNorm(A), applied while the operands are fetched (GemmArgs.ln_stats_in). The row statistics come
-// from the producing GEMM's per-16-column partial sums (ln_stats_out below), so no workgroup re-reads a whole row to recompute
-// them -- round 2 folded the LayerNorm into the fetch WITH a recomputation per column workgroup and lost 1 ms per step to it.
-// mean = S / K, var = Q / K - mean^2 (one pass; the stand-alone kernel is two-pass: results differ in the last bits, fp32-class
-// either way), and every order of summation depends on K only -- never on M, RM or CN -- so a stream's bits stay
-// independent of its neighbours.
+// LNIN: C = W LayerNorm(A) + bias without a LayerNorm launch and without normalising A (GemmArgs.ln_stats_in; the algebra is at
+// the statistics' loads below). The row statistics come from the producing GEMM's per-16-column partial sums (ln_stats_out), so
+// no workgroup re-reads a row to recompute them -- round 2 folded the LayerNorm into the fetch WITH a recomputation per column
+// workgroup and lost 1 ms per step to it. mean = S / K, var = Q / K - mean^2 (one pass; the stand-alone kernel is two-pass:
+// results differ in the last bits, fp32-class either way), and every order of summation depends on K only -- never on M, RM or
+// CN -- so a stream's bits stay independent of its neighbours.
 // NW = waves per workgroup. 16: one workgroup owns a tile and all sixteen K slices. 4 (GemmArgs.ws_part): FOUR workgroups share
 // a tile, workgroup blockIdx.z takes slices 4 z .. 4 z + 3 -- for the long-K, N = 512 projections of a step (w_2: 4 MB of
 // weights behind 32 column tiles = 32 CUs at ~25 GB/s each, 10-18 us in the chain) this spreads the weight stream over 128
 // CUs. The sixteen slice tiles go to a workspace; the workgroup that arrives last at the tile's counter folds them in the order
 // of the one-workgroup form (slice 0 + 1 + .. + 15) and runs the epilogue: the bits do not depend on the form.
-template <int RM, int CN, bool LNIN, int NW>
+template <int RM, int CN, int LNIN, int NW>      // LNIN: 0 plain, 1 LayerNorm form with gamma applied in the loop, 2 with gamma a stored by the producer
 __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
     constexpr int LD = CN * 16 + 1;                                        // padded row of the LDS partial tiles
     extern __shared__ __attribute__((aligned(16))) float red[];          // [SK_KW][RM * 16][LD]  (NW == 16)
@@ -74,14 +74,6 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    auto ln4 = [&](float4 v, const float4 g, const float4 b, const float mean, const float rstd) {
-#pragma clang fp contract(off)
-        v.x = (v.x - mean) * rstd * g.x + b.x;
-        v.y = (v.y - mean) * rstd * g.y + b.y;
-        v.z = (v.z - mean) * rstd * g.z + b.z;
-        v.w = (v.w - mean) * rstd * g.w + b.w;
-        return v;
-    };
     // one 16-wide k step: the four floats of a load feed four MFMAs, ascending k
     auto mfma_step = [&](const float4 (&a)[RM], const float4 (&b)[CN]) {
 #pragma unroll
@@ -104,60 +96,27 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
     const int nit = ke > kb ? (ke - kb) >> 4 : 0;
     int it = 0;
 
-    // LayerNorm statistics of the workgroup's rows: wave w reduces rows w, w + 16, .. (one load per lane and row, all rows'
-    // loads in flight together: a first version walked the partials serially per lane and gave back the launch it saved),
-    // butterfly 32 .. 1, (mean, rstd) through LDS. The order depends on K only. The wave's first k steps are fetched BEFORE
-    // the statistics so that their latency is not paid twice (with K = 512 that is the whole slice).
-    float ln_mean[RM], ln_rstd[RM];
+    // LNIN (GemmArgs.ln_stats_in): C = W LayerNorm(a) + bias without touching a: with (mean, rstd) of the row,
+    //   W (gamma (a - mean) rstd + beta) = rstd (W (gamma a) - mean c1) + c2,   c1 = W gamma,  c2 = W beta + bias
+    // (c1, c2: per-weight constants, launch_ln_consts). So the loop multiplies the A fragments by gamma (or not at all when the
+    // producer stored gamma a already: ln_g == nullptr) and the row statistics are needed by the EPILOGUE only: their block
+    // partials are fetched first thing and reduced after the last MFMA -- no latency of theirs lies on the path of the
+    // operands (the first form applied (a - mean) rstd gamma + beta on the fetch: +1.8 us at K = 512, +5 us at K = 2048, two
+    // rounds of loads). Partials: wave w holds rows w, w + NW, .. (<= 2 loads per lane and row: K <= 2048), butterfly 32 .. 1 in
+    // an order that depends on K only.
+    constexpr int RW = LNIN ? 16 * RM / NW : 1;            // rows per wave
+    __shared__ float2 ln_ms[LNIN ? 16 * RM : 1];
+    float2 st0[RW], st1[RW];
     if constexpr (LNIN) {
-        __shared__ float2 ln_ms[16 * RM];
         const int nblk = p.K >> 4;
-        constexpr int U0 = RM * CN >= 8 ? 1 : 4;            // (registers of the 64-row tile)
-        const int u0 = nit >= U0 ? U0 : nit;               // (wave-uniform)
-        float4 a0[U0][RM], b0[U0][CN], g0[U0], h0[U0];
-#pragma unroll
-        for (int u = 0; u < U0; ++u) {
-            if (u < u0) {
-                const int k0 = kb + 16 * u;
-#pragma unroll
-                for (int i = 0; i < RM; ++i) a0[u][i] = *reinterpret_cast<const float4*>(ap[i] + k0);
-#pragma unroll
-                for (int j = 0; j < CN; ++j) b0[u][j] = *reinterpret_cast<const float4*>(wp[j] + k0);
-                g0[u] = *reinterpret_cast<const float4*>(p.ln_g + k0 + kq * 4);
-                h0[u] = *reinterpret_cast<const float4*>(p.ln_b + k0 + kq * 4);
-            }
-        }
-        constexpr int RW = 16 * RM / NW;                    // rows per wave
-        float sx[RW], sq[RW];
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             int arow = m0 + wv + NW * i;
             arow = arow < p.M ? arow : p.M - 1;
             const float2* st = reinterpret_cast<const float2*>(p.ln_stats_in) + (size_t)arow * nblk;
-            sx[i] = 0.f; sq[i] = 0.f;
-            for (int b = lane; b < nblk; b += 64) { const float2 t = st[b]; sx[i] += t.x; sq[i] += t.y; }
+            st0[i] = lane < nblk ? st[lane] : make_float2(0.f, 0.f);
+            st1[i] = lane + 64 < nblk ? st[lane + 64] : make_float2(0.f, 0.f);
         }
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { sx[i] += __shfl_xor(sx[i], o, 64); sq[i] += __shfl_xor(sq[i], o, 64); }
-            const float mean = sx[i] / (float)p.K;
-            float var = sq[i] / (float)p.K - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            if (lane == 0) ln_ms[wv + NW * i] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RM; ++i) { const float2 t = ln_ms[i * 16 + i16]; ln_mean[i] = t.x; ln_rstd[i] = t.y; }
-#pragma unroll
-        for (int u = 0; u < U0; ++u) {
-            if (u < u0) {
-#pragma unroll
-                for (int i = 0; i < RM; ++i) a0[u][i] = ln4(a0[u][i], g0[u], h0[u], ln_mean[i], ln_rstd[i]);
-                mfma_step(a0[u], b0[u]);
-            }
-        }
-        it = u0;
     }
 
     // U consecutive 16-wide k steps: all their loads first, then their MFMAs in ascending k (the summation order of the plain
@@ -173,38 +132,67 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
 #pragma unroll
             for (int j = 0; j < CN; ++j) b[u][j] = *reinterpret_cast<const float4*>(wp[j] + k0 + 16 * u);
         }
+        float4 gq[LNIN == 1 ? U : 1];
+        if constexpr (LNIN == 1) {
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u) gq[u] = *reinterpret_cast<const float4*>(p.ln_g + k0 + 16 * u + kq * 4);
+            }
+        }
         // the scheduler otherwise sinks loads between the MFMAs to save registers (two steps in flight: four dependent
         // latencies for a K = 2048 slice); the registers are there (4 waves per SIMD whatever the count: 128 each)
         if constexpr (RM * CN <= 2) __builtin_amdgcn_sched_barrier(0);      // (the 64-row tile keeps the compiler's rolling schedule)
-        if constexpr (LNIN) {
+        if constexpr (LNIN == 1) {
+            {                                              // a <- gamma a; one rounding, the same in every tile shape
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + k0 + 16 * u + kq * 4);
-                const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + k0 + 16 * u + kq * 4);
+                for (int u = 0; u < U; ++u) {
+                    const float4 g4 = gq[u];
 #pragma unroll
-                for (int i = 0; i < RM; ++i) a[u][i] = ln4(a[u][i], g4, b4, ln_mean[i], ln_rstd[i]);
+                    for (int i = 0; i < RM; ++i) { a[u][i].x *= g4.x; a[u][i].y *= g4.y; a[u][i].z *= g4.z; a[u][i].w *= g4.w; }
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) mfma_step(a[u], b[u]);
     };
-    if constexpr (RM * CN <= 2 && !LNIN)         // (a K = 2048 slice of the 16- and 32-row tiles in ONE round of loads)
+    if constexpr (RM * CN == 1 || (RM * CN == 2 && LNIN != 1))   // (a K = 2048 slice of the 16- and 32-row tiles in ONE round of loads)
         for (; it + 8 <= nit; it += 8) steps_of(std::integral_constant<int, 8>{}, kb + 16 * it);
     if constexpr (!(LNIN && RM * CN >= 8))       // (the LayerNorm form of the 64-row tile has no registers for four steps in flight)
         for (; it + 4 <= nit; it += 4) steps_of(std::integral_constant<int, 4>{}, kb + 16 * it);
-    if (!(LNIN && RM * CN >= 8) && it + 2 <= nit) { steps_of(std::integral_constant<int, 2>{}, kb + 16 * it); it += 2; }
+    for (; (LNIN && RM * CN >= 8) && it + 2 <= nit; it += 2) steps_of(std::integral_constant<int, 2>{}, kb + 16 * it);
+    if (it + 2 <= nit) { steps_of(std::integral_constant<int, 2>{}, kb + 16 * it); it += 2; }
     for (; it < nit; ++it) steps_of(std::integral_constant<int, 1>{}, kb + 16 * it);
 
+    if constexpr (LNIN) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            float sx = st0[i].x + st1[i].x, sq = st0[i].y + st1[i].y;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sq += __shfl_xor(sq, o, 64); }
+            const float mean = sx / (float)p.K;
+            float var = sq / (float)p.K - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            if (lane == 0) ln_ms[wv + NW * i] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+        }
+        // (visible to the epilogue's threads through the barrier that also publishes the slice tiles)
+    }
     // bias / ReLU / addends / store (+ the LayerNorm partials) of one finished output; consecutive threads -> consecutive
     // columns of a row
     auto finish = [&](float v, int lr, int lc) {
         const int row = m0 + lr, cc = n0 + lc;
         if (row < p.M && cc < p.N) {
-            if (p.bias) v += p.bias[cc];
+            if constexpr (LNIN) {
+#pragma clang fp contract(off)
+                const float2 ms = ln_ms[lr];
+                v = ms.y * (v - ms.x * p.ln_c1[cc]) + p.ln_c2[cc];          // (c2 holds the bias)
+            } else {
+                if (p.bias) v += p.bias[cc];
+            }
             if (p.relu) v = fmaxf(v, 0.f);
             if (p.R1) v = v + p.R1[(size_t)row * p.ldr1 + cc];
             if (p.R2) v = p.R2[(size_t)row * p.ldr2 + cc] + v;
-            p.C[(size_t)row * p.ldc + cc] = v;
+            // (out_gamma: the consumer's gamma applied to the stored value; the partials below stay those of v)
+            p.C[(size_t)row * p.ldc + cc] = p.out_gamma ? v * p.out_gamma[cc] : v;
             if (p.ln_stats_out) {
                 // (sum, sum of squares) over this row's 16-column block: the 16 threads of the block are 16 consecutive,
                 // 16-aligned lanes and all active (N % 16 == 0); xor butterfly 8, 4, 2, 1
@@ -260,11 +248,11 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
     }
 }
 
-template <int RM, int CN, bool LNIN>
+template <int RM, int CN, int LNIN>
 __global__ __launch_bounds__(SK_KW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_skinny_kernel(GemmArgs p) {
     skinny_body<RM, CN, LNIN, SK_KW>(p);
 }
-template <int RM, bool LNIN>
+template <int RM, int LNIN>
 __global__ __launch_bounds__(256) void gemm_skinny_ws_kernel(GemmArgs p) { skinny_body<RM, 1, LNIN, 4>(p); }
 
 // the same GEMM for up to 16 weight matrices on ONE A operand (blockIdx.z picks W / bias / C): the streaming decoder's sixteen
@@ -272,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_ws_kernel(GemmArgs p) { skinn
 template <int RM, int CN>
 __global__ __launch_bounds__(SK_KW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_skinny_batch_kernel(GemmArgs p, GemmBatch t) {
     p.W = t.W[blockIdx.z]; p.bias = t.bias[blockIdx.z]; p.C = t.C[blockIdx.z];
-    skinny_body<RM, CN, false, SK_KW>(p);
+    skinny_body<RM, CN, 0, SK_KW>(p);
 }
 
 template <int RM, int CN>
@@ -290,7 +278,7 @@ int launch_skinny_batch_t(const GemmArgs& a, const GemmBatch& t, hipStream_t str
     return 0;
 }
 
-template <int RM, int CN, bool LNIN>
+template <int RM, int CN, int LNIN>
 int launch_skinny_t(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = SK_KW * RM * 16 * (CN * 16 + 1) * (int)sizeof(float);
     static bool configured = false;
@@ -307,14 +295,16 @@ int launch_skinny_t(const GemmArgs& a, hipStream_t stream) {
 template <int RM>
 int launch_skinny_ws(const GemmArgs& a, hipStream_t stream) {
     dim3 grid(ceil_div(a.N, 16), ceil_div(a.M, 16 * RM), 4), block(256);
-    if (a.ln_stats_in) hipLaunchKernelGGL((gemm_skinny_ws_kernel<RM, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((gemm_skinny_ws_kernel<RM, false>), grid, block, 0, stream, a);
+    if (a.ln_stats_in && a.ln_g) hipLaunchKernelGGL((gemm_skinny_ws_kernel<RM, 1>), grid, block, 0, stream, a);
+    else if (a.ln_stats_in) hipLaunchKernelGGL((gemm_skinny_ws_kernel<RM, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_skinny_ws_kernel<RM, 0>), grid, block, 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
 template <int RM, int CN>
 int launch_skinny(const GemmArgs& a, hipStream_t stream) {
-    return a.ln_stats_in ? launch_skinny_t<RM, CN, true>(a, stream) : launch_skinny_t<RM, CN, false>(a, stream);
+    if (a.ln_stats_in) return a.ln_g ? launch_skinny_t<RM, CN, 1>(a, stream) : launch_skinny_t<RM, CN, 2>(a, stream);
+    return launch_skinny_t<RM, CN, 0>(a, stream);
 }
 
 }  // namespace
@@ -326,8 +316,9 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm_skinny: row strides must be multiples of 4 floats");
     PF_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && a.C, "gemm_skinny: operands must be 16-B aligned");
     if (a.ln_stats_out) PF_REQUIRE(a.N % 16 == 0 && ((uintptr_t)a.ln_stats_out & 7) == 0, "gemm_skinny: LayerNorm partials need N % 16 == 0");
-    if (a.ln_stats_in) PF_REQUIRE(a.ln_g && a.ln_b && ((uintptr_t)a.ln_stats_in & 7) == 0 && ((uintptr_t)a.ln_g & 15) == 0 && ((uintptr_t)a.ln_b & 15) == 0,
-                                  "gemm_skinny: the LayerNorm-on-fetch form needs gamma, beta and the block partials");
+    if (a.ln_stats_in) PF_REQUIRE(a.ln_c1 && a.ln_c2 && ((uintptr_t)a.ln_stats_in & 7) == 0 && ((uintptr_t)a.ln_g & 15) == 0 && a.K <= 2048,
+                                  "gemm_skinny: the LayerNorm form needs the block partials, the constants c1 / c2 (launch_ln_consts) and K <= 2048");
+    if (a.out_gamma) PF_REQUIRE(a.ln_stats_out, "gemm_skinny: out_gamma goes with ln_stats_out");
     if (a.ws_part) {
         // four workgroups per tile (see skinny_body): the caller hands a workspace of gemm_skinny_ws_floats() floats and as many
         // zeroed counters as tiles; same bits as the one-workgroup form

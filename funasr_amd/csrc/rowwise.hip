@@ -177,6 +177,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __re
     }
 }
 
+// constants of the LayerNorm form of the small-M GEMM (gemm_skinny.hip): one wave per weight row n
+__global__ __launch_bounds__(256) void ln_consts_kernel(const float* __restrict__ W, int ldw, int N, int K, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ bias,
+                                                        float* __restrict__ c1, float* __restrict__ c2) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = W + (size_t)n * ldw;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + k);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + k);
+        const float4 b = *reinterpret_cast<const float4*>(beta + k);
+        s1 += (wv.x * g.x + wv.y * g.y) + (wv.z * g.z + wv.w * g.w);
+        s2 += (wv.x * b.x + wv.y * b.y) + (wv.z * b.z + wv.w * b.w);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { c1[n] = s1; c2[n] = s2 + (bias ? bias[n] : 0.f); }
+}
+
 __global__ __launch_bounds__(256) void scale_add_pe_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ pe, float* __restrict__ y,
                                                            int T, int D4, float scale, size_t total4) {
@@ -380,6 +401,15 @@ int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, 
     // (NV = 2 like launch_layernorm picks for D <= 512: the same lane-to-chunk map, hence the same bits)
     if (out_mode == 3) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 3>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R1, ldr1, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
     else hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 0>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R1, ldr1, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_ln_consts(const float* W, int ldw, int N, int K, const float* gamma, const float* beta, const float* bias, float* c1, float* c2,
+                     hipStream_t stream) {
+    PF_REQUIRE(W && gamma && beta && c1 && c2 && N > 0 && K > 0 && K % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)W & 15) == 0 &&
+               ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0, "ln_consts: K % 4, 16-B aligned operands");
+    hipLaunchKernelGGL(ln_consts_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, stream, W, ldw, N, K, gamma, beta, bias, c1, c2);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -45,18 +45,25 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add1=None, add
 
 
 def gemm_small_m_ln(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add2=None, stats_in=None, ln=None, want_stats=False,
-                    four_workgroups=False):
-    """The small-M GEMM with a LayerNorm carried between GEMMs (gemm_skinny.hip): with stats_in [M, K / 16, 2] and
-    ln = (gamma, beta, eps) the A operand is LayerNorm(a); want_stats returns the [M, N / 16, 2] block partials (sum, sum of
-    squares) of the finished outputs. four_workgroups (M <= 32): four workgroups share a tile's sixteen K slices, the same bits.
-    Returns (out, stats or None)."""
+                    four_workgroups=False, out_gamma=None, a_has_gamma=False):
+    """The small-M GEMM with a LayerNorm carried between GEMMs (gemm_skinny.hip). want_stats returns the [M, N / 16, 2] block
+    partials (sum, sum of squares) of the finished outputs; out_gamma [N]: the stored outputs are out * out_gamma (the partials stay
+    those of out). With stats_in [M, K / 16, 2] and ln = (gamma, beta, eps): out = w LayerNorm(a) + bias, evaluated as
+    rstd (w (gamma a) - mean c1) + c2 with c1 = w gamma, c2 = w beta + bias (pf_k_ln_consts); a_has_gamma: `a` holds gamma a already.
+    four_workgroups (M <= 32): four workgroups share a tile's sixteen K slices, the same bits. Returns (out, stats or None)."""
     lib = _lib.load()
     _f32c(a, "a"), _f32c(w, "w")
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     stats = torch.empty(M, N // 16, 2, device=a.device, dtype=torch.float32) if want_stats else None
-    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    g, eps, cst = None, 0.0, None
+    if ln is not None:
+        g, b, eps = ln
+        cst = torch.empty(2 * N, device=a.device, dtype=torch.float32)
+        _lib.check(lib.pf_k_ln_consts(_ptr(w), w.stride(0), N, K, _ptr(g), _ptr(b), _ptr(bias), _ptr(cst), _stream()), "pf_k_ln_consts")
+        if a_has_gamma:
+            g = None
     ws = cnt = None
     if four_workgroups:
         tiles = ((N + 15) // 16) * ((M + (15 if M <= 16 else 31)) // (16 if M <= 16 else 32))
@@ -64,8 +71,8 @@ def gemm_small_m_ln(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add
         cnt = torch.zeros(tiles, device=a.device, dtype=torch.int32)
     _lib.check(lib.pf_k_gemm_skinny_ln(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias),
                                        _ptr(add2), add2.stride(0) if add2 is not None else 0, _ptr(out), N, M, N, K, int(relu),
-                                       _ptr(stats), _ptr(stats_in), _ptr(g), _ptr(b), float(eps), _ptr(ws), _ptr(cnt), _stream()),
-               "pf_k_gemm_skinny_ln")
+                                       _ptr(stats), _ptr(stats_in), _ptr(g), _ptr(cst), float(eps), _ptr(out_gamma), _ptr(ws), _ptr(cnt),
+                                       _stream()), "pf_k_gemm_skinny_ln")
     if cnt is not None:
         assert int(cnt.abs().sum()) == 0, "the tile counters must be left at zero"
     return out, stats

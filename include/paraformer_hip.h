@@ -400,12 +400,17 @@ int pf_predictor_debug_poison(pf_predictor* p, int32_t byte);
  * Thin wrappers over the individual gfx950 kernels so that parity tests and the roofline bench can drive one
  * kernel at a time through the same ABI. All pointers are device pointers. */
 /* small-M GEMM with a LayerNorm carried between GEMMs (the streaming step's fused LayerNorms): see gemm_skinny.hip.
+ * stats_out [M][N / 16][2]: the block partials (sum, sum of squares) of the finished outputs; out_gamma [N] (with stats_out): the
+ * stored values are C * out_gamma. stats_in [M][K / 16][2] + ln_c (2 N floats from pf_k_ln_consts): C = W LayerNorm(A) + bias
+ * evaluated as rstd (W (gamma A) - mean c1) + c2; ln_g = gamma, or NULL when A already holds gamma A.
  * ws_part (>= tiles * 16 * 512 floats) + ws_count (one zeroed int32 per tile; tiles = ceil(N / 16) * ceil(M / 16 or 32)), M <= 32:
  * the four-workgroups-per-tile form for long K, the same bits */
 int pf_k_gemm_skinny_ln(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R2, int32_t ldr2,
                         float* Cout, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t relu, float* stats_out,
-                        const float* stats_in, const float* ln_g, const float* ln_b, float ln_eps, float* ws_part, int32_t* ws_count,
-                        void* stream);
+                        const float* stats_in, const float* ln_g, const float* ln_c, float ln_eps, const float* out_gamma, float* ws_part,
+                        int32_t* ws_count, void* stream);
+int pf_k_ln_consts(const float* W, int32_t ldw, int32_t N, int32_t K, const float* gamma, const float* beta, const float* bias, float* c,
+                   void* stream);
 /* test hook: pf_k_gemm_f32 takes the small-M weight-streaming kernel (the streaming step's GEMM) for M <= m;
  * default 0 = the 128x128 tile kernel (the offline path's GEMM) */
 int pf_set_skinny_max_m(int32_t m);

@@ -102,6 +102,11 @@ def test_small_m_gemm_carries_a_layernorm_between_two_gemms(cuda):
             xn_k = ops.layernorm(x, dev(gam), dev(bet), eps)
             h_k, _ = ops.gemm_small_m_ln(xn_k, dev(w1), dev(b1), relu=True)
             assert _rel(full[2], h_k.cpu()) < 2e-6
+            # the producer may store gamma-scaled outputs (partials unchanged); the consumer then multiplies nothing in its loop
+            xg, stg = ops.gemm_small_m_ln(dev(ctx), dev(wo), dev(bo), add2=dev(x0), want_stats=True, out_gamma=dev(gam))
+            assert torch.equal(stg, st) and torch.equal(xg.cpu(), (full[0] * gam))
+            hg, _ = ops.gemm_small_m_ln(xg, dev(w1), dev(b1), relu=True, stats_in=stg, ln=(dev(gam), dev(bet), eps), a_has_gamma=True)
+            assert _rel(hg.cpu(), hr) < 2e-6
         else:
             assert torch.equal(x.cpu(), full[0][:M]) and torch.equal(st.cpu(), full[1][:M]) and torch.equal(h.cpu(), full[2][:M]), M
         if M <= 32:
