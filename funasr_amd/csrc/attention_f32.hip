@@ -352,6 +352,24 @@ __global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
     const int n1 = p.K2 ? p.n1_dev[b * p.n1_stride] : p.klens[b];
     const int klen = p.K2 ? n1 + p.n2 : n1;
 
+    // the ring append (below) copies rows of (K2, V2) that nothing in this kernel produces: fetch them now, store them at the end
+    const bool do_app = p.app_rows > 0 && gridDim.x == 1 && p.K2;
+    const int app_skip = p.app_rows > p.Tk ? p.app_rows - p.Tk : 0;   // only the newest `cap` rows can survive
+    const int app_n = (p.app_rows - app_skip) * 64;                    // 32 float4 of K and 32 of V per row
+    float4 appv[4];
+    if (do_app) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + 256 * e;
+            if (i < app_n) {
+                const int r = i >> 6, c = i & 63, c4 = (c & 31) * 4;
+                const size_t src = (size_t)b * p.T2 + p.app_r0 + app_skip + r;
+                appv[e] = c < 32 ? *reinterpret_cast<const float4*>(p.K2 + src * p.ldk2 + head * DK + c4)
+                                 : *reinterpret_cast<const float4*>(p.V2 + src * p.ldv2 + head * DK + c4);
+            }
+        }
+    }
+
     float4 qf[8];
     {
         int qrow = q0 + i16;
@@ -460,21 +478,18 @@ __global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
     }
     // ring append (attention.py:343-361: the cache keeps the last rows): every wave of this -- the only -- workgroup of
     // (stream, head) passed the barrier above, i.e. has its ring rows in registers; other heads own other columns
-    if (p.app_rows > 0 && gridDim.x == 1 && p.K2 && (!p.app_gate || p.app_gate[b] >= 1)) {
+    if (do_app && (!p.app_gate || p.app_gate[b] >= 1)) {
         const int cap = p.Tk;
-        const int skip = p.app_rows > cap ? p.app_rows - cap : 0;   // only the newest `cap` rows can survive
-        const int rows = p.app_rows - skip;
         const int wp = p.app_wp[b * p.app_wp_stride];
-        for (int i = tid; i < rows * 64; i += 256) {              // 32 float4 of K and 32 of V per row
-            const int r = i >> 6, c = i & 63, c4 = (c & 31) * 4;
-            const size_t src = (size_t)b * p.T2 + p.app_r0 + skip + r;
-            const size_t dst = (size_t)b * cap + (wp + skip + r) % cap;
-            if (c < 32)
-                *reinterpret_cast<float4*>(const_cast<float*>(p.K) + dst * p.ldk + head * DK + c4) =
-                    *reinterpret_cast<const float4*>(p.K2 + src * p.ldk2 + head * DK + c4);
-            else
-                *reinterpret_cast<float4*>(const_cast<float*>(p.V) + dst * p.ldv + head * DK + c4) =
-                    *reinterpret_cast<const float4*>(p.V2 + src * p.ldv2 + head * DK + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + 256 * e;
+            if (i < app_n) {
+                const int r = i >> 6, c = i & 63, c4 = (c & 31) * 4;
+                const size_t dst = (size_t)b * cap + (wp + app_skip + r) % cap;
+                float* base = c < 32 ? const_cast<float*>(p.K) + dst * p.ldk : const_cast<float*>(p.V) + dst * p.ldv;
+                *reinterpret_cast<float4*>(base + head * DK + c4) = appv[e];
+            }
         }
     }
 }

@@ -458,7 +458,10 @@ struct AttnArgs {
 };
 inline bool attention_takes_fewq(const AttnArgs& a) { return a.few_q && a.Tq <= 32 && !a.O3; }
 // true when launch_attention_f32 will take the few-query kernel AND perform the append itself
-inline bool attention_fuses_append(const AttnArgs& a) { return a.few_q && a.Tq <= 16 && !a.O3 && a.K2 && a.app_rows > 0; }
+inline bool attention_fuses_append(const AttnArgs& a) {
+    // (the kernel holds the rows to append in four float4 per thread: min(app_rows, Tk) <= 16)
+    return a.few_q && a.Tq <= 16 && !a.O3 && a.K2 && a.app_rows > 0 && (a.app_rows < a.Tk ? a.app_rows : a.Tk) <= 16;
+}
 int launch_attention_f32(const AttnArgs& a, hipStream_t stream);
 // bf16 Q/K/V in, bf16 O out (strides in elements), fp32 softmax statistics and accumulators
 int launch_attention_bf16(const AttnArgs& a, hipStream_t stream);
