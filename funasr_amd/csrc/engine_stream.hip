@@ -95,6 +95,11 @@ static int stream_prepare_ln_consts(Stream* st, hipStream_t s) {
     return 0;
 }
 
+static int stream_token_rows(const Stream* st, int W, int is_final) {
+    const int fires = W + 1 + (is_final ? 1 : 0);
+    return fires < st->Nmax ? fires : st->Nmax;
+}
+
 // the f16x2 step's K = d_model projections in the split-K form: by the handle's size (streams x largest window), see Stream.short_k
 static bool stream_short_k(const Stream* st) {
     return st->short_k == 2 || (st->short_k == 1 && (size_t)st->S * st->Wmax <= 2048);
@@ -106,7 +111,10 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     const pf_encoder_config& ec = e->cfg;
     const int S = st->S, D = ec.d_model, F = ec.ffn_dim, Din = ec.input_dim, Dpad = round_up(Din, 64);
     const int W = tail ? st->keep : st->keep + n;
-    const int M = S * W, Nmax = st->Nmax;
+    // token rows per stream of THIS step: the integrate-and-fire loop runs over the carried remainder, the W window frames and (final
+    // step) the tail weight, and fires at most once per iteration (cif_chunk_kernel) -- the 600 ms geometry's 15-frame window gives
+    // 16 rows (one 16-row tile of the small-M kernels) where the handle's capacity is 23
+    const int M = S * W, Nmax = stream_token_rows(st, W, is_final);
     const StreamDev* dev = st->dev_state.as<StreamDev>();
     if (st->wide_k && !st->ws_part.p) {
         if (st->ws_part.ensure(sizeof(float) * WS_PART_FLOATS) || st->ws_count.ensure(sizeof(int) * WS_TILES)) return -2;
@@ -639,7 +647,12 @@ int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t 
         PF_HIP_TRY(hipMemcpyAsync(enc_out, st->enc_out.p, sizeof(float) * (size_t)S * W * D, hipMemcpyDeviceToDevice, s));
     PF_HIP_TRY(hipStreamSynchronize(s));
     st->start_idx += tail_chunk ? st->keep : n;
-    memcpy(ids_host, st->h_ids, sizeof(int32_t) * (size_t)S * st->Nmax);
+    // the step ran stream_token_rows() rows per stream; the caller's layout is [n_streams, max_tokens]
+    const int rows = stream_token_rows(st, W, is_final);
+    for (int i = 0; i < S; ++i) {
+        memcpy(ids_host + (size_t)i * st->Nmax, st->h_ids + (size_t)i * rows, sizeof(int32_t) * (size_t)rows);
+        for (int k = rows; k < st->Nmax; ++k) ids_host[(size_t)i * st->Nmax + k] = 0;
+    }
     memcpy(n_tokens_host, st->h_n, sizeof(int32_t) * (size_t)S);
     return 0;
 }
