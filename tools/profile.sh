@@ -19,6 +19,7 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-for
 echo "pmc_mfma rc=$?" >> "$OUT/pmc_mfma.log"
 cd - > /dev/null
 python tools/summarize_prof.py "$OUT" "$TAG" > "$OUT/summary.md" 2>&1
+cp "profiles/${TAG}_traffic.json" "$OUT/" 2>/dev/null     # (written next to the other profiles: only gpurun_out/ travels back)
 # keep the merged-back payload small: per-dispatch traces can be tens of MB
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
 find "$OUT" -name '*counter_collection.csv' -size +8M -delete
