@@ -136,14 +136,15 @@ def case_many_streams_vs_fp32_step(dev):
     print(f"max |enc f16x2 - enc fp32| = {worst:.3e}")
 
 
-def case_weight_reload(dev):
-    """the prepared planes / exponents follow a weight reload on the live handles (TensorTable version): a StreamBatch created
-    before load_state_dict gives the results of a model built from the new weights"""
+def case_weight_reload(dev, precision="f16x2"):
+    """the prepared planes / exponents (f16x2 step) and the LayerNorm -> GEMM constants (fp32 step, Stream.ln_consts) follow a weight
+    reload on the live handles (TensorTable version): a StreamBatch created before load_state_dict gives the results of a model built
+    from the new weights"""
     from funasr_amd.paraformer_streaming import StreamBatch
     g, cfg, sd = load()
     sd2 = synth.paraformer_state_dict(cfg, seed=int(g["seed"]) + 1, cif_bias=float(g["cif_bias"]))
     model = build(cfg, sd, dev)
-    sb = StreamBatch(model, 2, [0, 10, 5], 4, 1, use_graph=True, precision="f16x2")
+    sb = StreamBatch(model, 2, [0, 10, 5], 4, 1, use_graph=True, precision=precision)
     feats = [torch.from_numpy(g[f"feats_{i}"]).repeat(2, 1, 1).to(dev) for i in range(4)]
     for f in feats:
         sb.step(f)
@@ -152,11 +153,15 @@ def case_weight_reload(dev):
     got = [sb.step(f, return_enc=True) for f in feats]
     sb.close()
     fresh = build(cfg, sd2, dev)
-    sr = StreamBatch(fresh, 2, [0, 10, 5], 4, 1, use_graph=False, precision="f16x2")
+    sr = StreamBatch(fresh, 2, [0, 10, 5], 4, 1, use_graph=False, precision=precision)
     ref = [sr.step(f, return_enc=True) for f in feats]
     sr.close()
     for i, (a, b) in enumerate(zip(got, ref)):
         assert a[0] == b[0] and torch.equal(a[1], b[1]), i
+
+
+def case_weight_reload_fp32_step(dev):
+    case_weight_reload(dev, "fp32")
 
 
 def case_oracle_geometry_many_tokens(dev):
