@@ -147,6 +147,8 @@ SIGNATURES = {
     "pf_stream_reset": (C.c_int, [_vp, _vp]),
     "pf_stream_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "pf_stream_step": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pi32, _pi32, _vp, _vp]),
+    "pf_stream_step_begin": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pf_stream_step_end": (C.c_int, [_vp, _pi32, _pi32]),
     "pf_stream_peek": (C.c_int, [_vp, _vp, _vp, _pi32]),
     "pf_frontend_fbank": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "pf_frontend_lfr_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),

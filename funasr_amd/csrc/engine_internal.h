@@ -490,6 +490,7 @@ struct Stream {
     int ln_carry = 2;
     bool fsmn_rides = true;                                  // encoder FSMN inside the attention launch (AttnArgs.fs_*)
     DevBuf ln_stats;
+    bool pending = false; int pending_rows = 0;              // a step enqueued by pf_stream_step_begin and not yet collected
     bool wide_k = false;                                     // long-K N = 512 projections of a <= 32-row step over four workgroups per tile
     DevBuf ws_part, ws_count;                                // their slice tiles and tile counters (GemmArgs.ws_part / ws_count)
     // constants c1 = W gamma, c2 = W beta + bias of every LayerNorm -> GEMM pair of the fp32 step (launch_ln_consts), prepared from

@@ -581,9 +581,22 @@ int pf_stream_reset(pf_stream* sh, void* stream) {
 
 int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t is_final, int32_t tail_chunk,
                    int32_t* ids_host, int32_t* n_tokens_host, float* enc_out, void* stream) {
+    PF_REQUIRE(sh && ids_host && n_tokens_host, "stream_step: null argument");
+    int rc = pf_stream_step_begin(sh, feats, n_frames, is_final, tail_chunk, enc_out, stream);
+    if (rc) return rc;
+    return pf_stream_step_end(sh, ids_host, n_tokens_host);
+}
+
+/* the two halves of pf_stream_step: _begin enqueues the step on the handle's own HIP stream and returns without waiting, _end waits
+ * for it and hands the ids / counts over. Several handles (each over its OWN encoder / predictor / decoder handles: the workspaces
+ * belong to those) may have a step in flight at a time: a step of a few dozen streams leaves most of the chip idle, and steps of
+ * independent handles overlap there. */
+int pf_stream_step_begin(pf_stream* sh, const float* feats, int32_t n_frames, int32_t is_final, int32_t tail_chunk, float* enc_out,
+                         void* stream) {
     Stream* st = reinterpret_cast<Stream*>(sh);
     hipStream_t us = reinterpret_cast<hipStream_t>(stream);
-    PF_REQUIRE(st && ids_host && n_tokens_host, "stream_step: null argument");
+    PF_REQUIRE(st, "stream_step: null argument");
+    PF_REQUIRE(!st->pending, "stream_step_begin: the previous step of this handle was not collected (pf_stream_step_end)");
     const int n = tail_chunk ? 0 : n_frames;
     PF_REQUIRE(tail_chunk || (feats && n >= 1 && n <= st->cfg.max_frames), "stream_step: n_frames out of range");
     PF_REQUIRE(!tail_chunk || st->keep > 0, "stream_step: a tail chunk needs chunk_left + chunk_right > 0");
@@ -645,10 +658,21 @@ int pf_stream_step(pf_stream* sh, const float* feats, int32_t n_frames, int32_t 
     }
     if (enc_out)
         PF_HIP_TRY(hipMemcpyAsync(enc_out, st->enc_out.p, sizeof(float) * (size_t)S * W * D, hipMemcpyDeviceToDevice, s));
-    PF_HIP_TRY(hipStreamSynchronize(s));
     st->start_idx += tail_chunk ? st->keep : n;
+    st->pending = true;
+    st->pending_rows = stream_token_rows(st, W, is_final);
+    return 0;
+}
+
+int pf_stream_step_end(pf_stream* sh, int32_t* ids_host, int32_t* n_tokens_host) {
+    Stream* st = reinterpret_cast<Stream*>(sh);
+    PF_REQUIRE(st && ids_host && n_tokens_host, "stream_step_end: null argument");
+    PF_REQUIRE(st->pending, "stream_step_end: no step in flight");
+    st->pending = false;
+    PF_HIP_TRY(hipStreamSynchronize(st->stream));
+    const int S = st->S;
     // the step ran stream_token_rows() rows per stream; the caller's layout is [n_streams, max_tokens]
-    const int rows = stream_token_rows(st, W, is_final);
+    const int rows = st->pending_rows;
     for (int i = 0; i < S; ++i) {
         memcpy(ids_host + (size_t)i * st->Nmax, st->h_ids + (size_t)i * rows, sizeof(int32_t) * (size_t)rows);
         for (int k = rows; k < st->Nmax; ++k) ids_host[(size_t)i * st->Nmax + k] = 0;

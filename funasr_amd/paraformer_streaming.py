@@ -203,14 +203,18 @@ class StreamBatch:
     def step(self, feats: Optional[torch.Tensor], is_final: bool = False, tail_chunk: bool = False,
              return_enc: bool = False):
         """feats [S, n, 560] (device) or None for a tail chunk -> (list of raw id lists per stream, enc [S, W, 512]?)"""
+        self.step_begin(feats, is_final, tail_chunk, return_enc)
+        return self.step_end()
+
+    def step_begin(self, feats: Optional[torch.Tensor], is_final: bool = False, tail_chunk: bool = False, return_enc: bool = False):
+        """Enqueue the step on the handle's own HIP stream and return at once (pf_stream_step_begin); step_end() collects it.
+        StreamBatches over DIFFERENT model objects may each have a step in flight: steps of a few dozen streams overlap on the chip."""
         n = 0 if tail_chunk else int(feats.shape[1])
         self._grow_pe(self.start_idx + n)
         for m, h in self._parts:
             if m._dirty:                       # weights changed on the live modules (load_state_dict, mark_dirty): push them
                 if m._ensure_handle()[1] != h:
                     raise RuntimeError("StreamBatch: a module's handle was re-created (moved to another device?); build a new StreamBatch")
-        ids = (C.c_int32 * (self.S * self.max_tokens))()
-        cnt = (C.c_int32 * self.S)()
         W = self.keep + n
         enc = torch.empty(self.S, W, 512, device=self.dev, dtype=torch.float32) if return_enc else None
         f = None
@@ -219,10 +223,19 @@ class StreamBatch:
             if f.shape[0] != self.S:
                 raise ValueError(f"expected {self.S} streams, got {f.shape[0]}")
         with torch.cuda.device(self.dev):
-            _lib.check(self.lib.pf_stream_step(self._h, f.data_ptr() if f is not None else None, n, int(is_final),
-                                               int(tail_chunk), ids, cnt, enc.data_ptr() if enc is not None else None,
-                                               stream_ptr()), "pf_stream_step")
+            _lib.check(self.lib.pf_stream_step_begin(self._h, f.data_ptr() if f is not None else None, n, int(is_final),
+                                                     int(tail_chunk), enc.data_ptr() if enc is not None else None,
+                                                     stream_ptr()), "pf_stream_step_begin")
         self.start_idx += self.keep if tail_chunk else n
+        self._inflight = (f, enc, return_enc)            # (the features stay alive until the step has read them)
+
+    def step_end(self):
+        f, enc, return_enc = self._inflight
+        self._inflight = None
+        ids = (C.c_int32 * (self.S * self.max_tokens))()
+        cnt = (C.c_int32 * self.S)()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.pf_stream_step_end(self._h, ids, cnt), "pf_stream_step_end")
         out = [[int(ids[s * self.max_tokens + k]) for k in range(int(cnt[s]))] for s in range(self.S)]
         return (out, enc) if return_enc else out
 

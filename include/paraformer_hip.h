@@ -352,6 +352,12 @@ int pf_stream_set_option(pf_stream* s, const char* key, int32_t value);
  * SYNCHRONISES (returns host values). */
 int pf_stream_step(pf_stream* s, const float* feats_dev, int32_t n_frames, int32_t is_final, int32_t tail_chunk,
                    int32_t* ids_host, int32_t* n_tokens_host, float* enc_out_dev, void* stream);
+/* pf_stream_step in two halves: _begin enqueues the step on the handle's own HIP stream and returns at once, _end waits for it and
+ * fills ids_host / n_tokens_host. Handles built over DIFFERENT encoder / predictor / decoder handles may each have a step in
+ * flight: steps of a few dozen streams leave most of the chip idle and overlap there (tools/bench_streaming.py --replicas). */
+int pf_stream_step_begin(pf_stream* s, const float* feats_dev, int32_t n_frames, int32_t is_final, int32_t tail_chunk,
+                         float* enc_out_dev, void* stream);
+int pf_stream_step_end(pf_stream* s, int32_t* ids_host, int32_t* n_tokens_host);
 /* debug / parity: carried CIF state and position counter (any pointer may be NULL) */
 int pf_stream_peek(pf_stream* s, float* cif_alpha_host, float* cif_hidden_host, int32_t* start_idx_host);
 

@@ -282,3 +282,28 @@ def test_step_launch_fusions_leave_the_session_unchanged(cuda):
         plain2 = session({"ln_folded": 0, "fsmn_rides": 0}, S, "f16x2")
         for a, b in zip(plain2, session({"ln_folded": 1, "fsmn_rides": 1}, S, "f16x2")):
             assert a[0] == b[0] and torch.equal(a[1], b[1]), S
+
+
+def test_two_handles_with_a_step_in_flight_each(cuda):
+    """pf_stream_step_begin / _end: two StreamBatches over two model objects (own handles, own workspaces, own HIP streams) run
+    their steps concurrently; each returns what it returns alone. A second begin on a handle before its end is refused."""
+    from funasr_amd.paraformer_streaming import StreamBatch
+    g, cfg, sd, wav = load()
+    m1, m2 = build(cfg, sd, cuda), build(cfg, sd, cuda)
+    alone = StreamBatch(m1, 2, [0, 10, 5], 4, 1, use_graph=True)
+    feats = [torch.from_numpy(g[f"feats_{i}"]) for i in range(int(g["n_chunks"])) if not int(g[f"flags_{i}"][1])]
+    pair = [torch.cat([f, 0.5 * f], 0).to(cuda) for f in feats]
+    ref = [alone.step(f, return_enc=True) for f in pair]
+    alone.close()
+    a, b = StreamBatch(m1, 2, [0, 10, 5], 4, 1, use_graph=True), StreamBatch(m2, 2, [0, 10, 5], 4, 1, use_graph=True)
+    for i, f in enumerate(pair):
+        a.step_begin(f, return_enc=True)
+        b.step_begin(f, return_enc=True)
+        if i == 0:
+            with pytest.raises(RuntimeError):
+                a.step_begin(f)
+        ra, rb = a.step_end(), b.step_end()
+        for r in (ra, rb):
+            assert r[0] == ref[i][0] and torch.equal(r[1], ref[i][1]), i
+    a.close()
+    b.close()

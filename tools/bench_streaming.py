@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--graph", nargs="+", type=int, default=[0, 1], help="0 eager, 1 hipGraph replay")
     ap.add_argument("--ln-carry", nargs="+", type=int, default=[1], help="fp32 step: 1 = LayerNorms carried by the small-M GEMMs "
                     "(default), 0 = stand-alone LayerNorm launches")
+    ap.add_argument("--replicas", type=int, nargs="+", default=[1], help="R independent handles (own model objects, own HIP streams), "
+                    "each with --streams streams, a step of every replica in flight at a time: R x S streams per wall step")
     ap.add_argument("--set", nargs="*", default=[], metavar="KEY=VALUE", help="pf_stream_set_option pairs applied to every "
                     "configuration (fsmn_rides, kv_batched: A/B of the step's launch fusions)")
     args = ap.parse_args()
@@ -35,18 +37,35 @@ def main():
     dev = torch.device("cuda:0")
     cfg = copy.deepcopy(synth.PARAFORMER_LARGE)
     cfg["decoder"]["sanm_shfit"] = 5
-    model = ParaformerStreaming.from_config(cfg)
-    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
-    model = model.to(dev)
+    sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
+    models = []
+    for _ in range(max(args.replicas)):
+        m = ParaformerStreaming.from_config(cfg)
+        m.load_state_dict(sd, strict=False)
+        models.append(m.to(dev))
+    model = models[0]
     first_ids = {}
     import itertools
-    for S, prec, graph, carry in itertools.product(args.streams, args.precision, [bool(v) for v in args.graph], args.ln_carry):
+    for S, prec, graph, carry, R in itertools.product(args.streams, args.precision, [bool(v) for v in args.graph], args.ln_carry, args.replicas):
         if prec != "fp32" and carry != args.ln_carry[0]:
             continue
-        sb = StreamBatch(model, S, [0, 10, 5], 4, 1, use_graph=graph, pe_rows=16384, precision=prec)
-        sb.set_option("ln_carry", carry)
-        for kv in args.set:
-            sb.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        sbs = [StreamBatch(models[r], S, [0, 10, 5], 4, 1, use_graph=graph, pe_rows=16384, precision=prec) for r in range(R)]
+        for b in sbs:
+            b.set_option("ln_carry", carry)
+            for kv in args.set:
+                b.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+
+        class _All:                                   # every replica's step in flight, then every replica collected
+            def step(self, f):
+                for b in sbs:
+                    b.step_begin(f)
+                outs = [b.step_end() for b in sbs]
+                return outs[0]
+
+            def close(self):
+                for b in sbs:
+                    b.close()
+        sb = _All()
         g = torch.Generator().manual_seed(S)
         feats = (torch.randn(S, 10, 560, generator=g) * 0.8).to(dev)
         ntok = 0
@@ -74,8 +93,8 @@ def main():
         tstat = tel.stop() if tel is not None else {}
         lat.sort()
         print(json.dumps({"metric": "streaming chunks/s (600 ms chunk, Paraformer-large-online)", "streams": S,
-                          "hipgraph": graph, "steps": args.steps, "chunks_per_s": round(S * args.steps / dt, 1),
-                          "audio_s_per_s": round(S * args.steps * 0.6 / dt, 1),
+                          "replicas": R, "hipgraph": graph, "steps": args.steps, "chunks_per_s": round(R * S * args.steps / dt, 1),
+                          "audio_s_per_s": round(R * S * args.steps * 0.6 / dt, 1),
                           "step_ms_p50": round(lat[len(lat) // 2] * 1e3, 3), "step_ms_p99": round(lat[int(len(lat) * 0.99)] * 1e3, 3),
                           "tokens_per_chunk": round(ntok / (S * args.steps), 2),
                           "dtype": "f32" if prec == "fp32" else "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMA products)",
