@@ -576,6 +576,7 @@ int pf_stream_reset(pf_stream* sh, void* stream) {
     int rc = stream_reset(st, st->stream);
     if (rc) return rc;
     PF_HIP_TRY(hipStreamSynchronize(st->stream));
+    st->pending = false;                                     // (a step in flight is dropped with the session it belonged to)
     return 0;
 }
 
