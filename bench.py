@@ -154,6 +154,7 @@ def main():
 
     from funasr_amd import _lib, dp, synth
     from funasr_amd.wav_frontend import WavFrontend
+    dp.guard_shared_gpu(world, all_on_one=args.dist_backend == "gloo")
 
     lib = _lib.load()
     cfg = synth.PARAFORMER_LARGE

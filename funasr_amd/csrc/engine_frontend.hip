@@ -116,6 +116,23 @@ int pf_frontend_set_dither(pf_frontend* fh, float dither, uint64_t seed) {
     f->dither = dither; f->dither_seed = seed; f->dither_calls = 0;
     return 0;
 }
+int pf_frontend_set_verify(pf_frontend* fh, int32_t on) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    PF_REQUIRE(f, "frontend_set_verify: null handle");
+    if (on && !f->faults.p) {
+        if (f->faults.ensure(sizeof(unsigned int))) return -2;
+        PF_HIP_TRY(hipMemset(f->faults.p, 0, sizeof(unsigned int)));
+    }
+    f->verify = on ? 1 : 0;
+    return 0;
+}
+int pf_frontend_faults(pf_frontend* fh, uint32_t* count_host) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    PF_REQUIRE(f && count_host, "frontend_faults: null");
+    *count_host = 0;
+    if (f->faults.p) PF_HIP_TRY(hipMemcpy(count_host, f->faults.p, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return 0;
+}
 int pf_frontend_set_tables(pf_frontend* fh, const float* window, const float* mel) {
     Frontend* f = reinterpret_cast<Frontend*>(fh);
     PF_REQUIRE(f && window && mel, "frontend_set_tables: null");
@@ -166,6 +183,7 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
+    a.verify = f->verify; a.faults = f->verify ? f->faults.as<unsigned int>() : nullptr;
     int rc;
     {
         double bytes = 0;
@@ -218,6 +236,7 @@ int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, 
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
+    a.verify = f->verify; a.faults = f->verify ? f->faults.as<unsigned int>() : nullptr;
     return launch_fbank(a, 1, nfr, s);
 }
 

@@ -309,6 +309,7 @@ struct Frontend {
     bool has_cmvn = false;
     int feat_dim() const { return cfg.n_mels * cfg.lfr_m; }
     float dither = 0.f; unsigned long long dither_seed = 0; unsigned dither_calls = 0;   // pf_frontend_set_dither
+    int verify = 0; DevBuf faults;                                                       // pf_frontend_set_verify (FbankArgs.verify)
 };
 // =============================================================================================== encoder
 struct EncLayerW {

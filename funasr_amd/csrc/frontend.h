@@ -28,6 +28,10 @@ struct FbankArgs {
     float dither;
     unsigned long long seed;     // key
     unsigned int call;           // launch counter (a new noise field per forward, like the reference's advancing torch.randn)
+    // verify != 0: every frame is evaluated (at least) twice from its samples in registers and re-evaluated until two consecutive
+    // results agree; disagreements are counted in *faults (device, may be null). For GPUs shared with another process that runs
+    // LDS-DMA-heavy kernels: there a frame's LDS exchange is disturbed about once per 10^4 frames (open issue).
+    int verify; unsigned int* faults;
 };
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream);
 

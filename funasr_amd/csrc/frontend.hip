@@ -163,9 +163,15 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
                 if (i1 + 1 < p.frame_len) xo[2 * jj + 1] += p.dither * zn[3];
             }
         }
+        // the frame from its (scaled, dithered) samples in registers to this lane's <= 2 mel outputs; every exchange through the
+        // wave's LDS region. A pure function of xe / xo: compute() twice gives the same bits unless the LDS was disturbed (verify)
+        auto compute = [&](float (&res)[2]) {
+        float ce[4], co[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ce[j] = xe[j]; co[j] = xo[j]; }
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += xe[j] + xo[j];
+        for (int j = 0; j < 4; ++j) s += ce[j] + co[j];
         s = wave_sum(s);
         const float mean = s / (float)p.frame_len;
         // ---- pre-emphasis y[i] = x[i] - 0.97 x[i-1], x[-1] := x[0] (:204-215), then the window
@@ -173,18 +179,18 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i0 = 2 * (lane + 64 * j);
-            xe[j] = i0 < p.frame_len ? xe[j] - mean : 0.f;
-            xo[j] = i0 + 1 < p.frame_len ? xo[j] - mean : 0.f;
-            prev_lane[j] = __shfl(xo[j], (lane + 63) & 63, 64);   // lane 0 receives lane 63's odd sample of the SAME j
+            ce[j] = i0 < p.frame_len ? ce[j] - mean : 0.f;
+            co[j] = i0 + 1 < p.frame_len ? co[j] - mean : 0.f;
+            prev_lane[j] = __shfl(co[j], (lane + 63) & 63, 64);   // lane 0 receives lane 63's odd sample of the SAME j
         }
         float2 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // for lane 0 the predecessor of sample 128 j is lane 63's odd sample of j - 1; sample 0 precedes itself
             float pe = prev_lane[j];
-            if (lane == 0) pe = j == 0 ? xe[0] : prev_lane[j - 1];
-            const float ye = __fsub_rn(xe[j], __fmul_rn(p.preemph, pe));
-            const float yo = __fsub_rn(xo[j], __fmul_rn(p.preemph, xe[j]));
+            if (lane == 0) pe = j == 0 ? ce[0] : prev_lane[j - 1];
+            const float ye = __fsub_rn(ce[j], __fmul_rn(p.preemph, pe));
+            const float yo = __fsub_rn(co[j], __fmul_rn(p.preemph, ce[j]));
             v[j] = make_float2(ye * win_e[j], yo * win_o[j]);
         }
 
@@ -245,16 +251,38 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
             pt[lane + 64 * q] = e;
         }
         __builtin_amdgcn_wave_barrier();
-        float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int m = lane + 64 * q;
+            res[q] = 0.f;
             if (m < p.n_mels) {
                 float e = 0.f;
                 for (int c = 0; c < mcount[q]; ++c) e += pt[mfirst[q] + c];
                 e = fmaxf(e, 1.1920928955078125e-07f);         // feature-fbank.cc:102-106
-                out[m] = logf(e);
+                res[q] = logf(e);
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        };
+        float r0[2];
+        compute(r0);
+        if (p.verify) {
+            // cross-check (FbankArgs.verify): recompute until two consecutive evaluations agree in every lane; each disagreement
+            // is counted. The frame's inputs never left the registers, so only a disturbed exchange can make two runs differ.
+            for (int tries = 0; tries < 4; ++tries) {
+                float r1[2];
+                compute(r1);
+                const bool same = __float_as_uint(r0[0]) == __float_as_uint(r1[0]) && __float_as_uint(r0[1]) == __float_as_uint(r1[1]);
+                r0[0] = r1[0]; r0[1] = r1[1];
+                if (__all(same)) break;
+                if (lane == 0 && p.faults) atomicAdd(p.faults, 1u);
+            }
+        }
+        float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = lane + 64 * q;
+            if (m < p.n_mels) out[m] = r0[q];
         }
         __builtin_amdgcn_wave_barrier();
     }

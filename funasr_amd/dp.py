@@ -47,6 +47,18 @@ def ensure_ranks(n_gpus: int, argv: Sequence[str] = None) -> int:
     return world
 
 
+def guard_shared_gpu(world: int, all_on_one: bool = False) -> bool:
+    """More ranks than GPUs (or the dry run that puts every rank on GPU 0): the fbank kernel's cross-check goes on for frontends
+    created after this call (WavFrontend(verify=None) reads PF_FRONTEND_VERIFY). With two processes interleaving their kernels on
+    one GPU a frame's in-LDS exchange comes back disturbed about once per 10^4 frames (tools/two_rank_frontend_check.sh:
+    1 of 4 un-serialised two-rank sweeps differed without the check, 0 of 4 with it, 7 frames caught); one process per GPU -- the
+    deployment -- has never shown it, so the check stays off there. Returns whether ranks share a GPU."""
+    shared = world > 1 and (all_on_one or world > max(1, torch.cuda.device_count()))
+    if shared:
+        os.environ.setdefault("PF_FRONTEND_VERIFY", "1")
+    return shared
+
+
 def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:
     """Length-sorted round-robin deal (like the length sort of auto_model.py:917-918): rank r gets the clips at
     positions r, r+world, ... of the descending-length order, so every rank sees the same length mix."""

@@ -14,6 +14,8 @@ from __future__ import annotations
 import ctypes as C
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -69,8 +71,11 @@ class WavFrontend(nn.Module):
                  frame_length: int = 25, frame_shift: int = 10, filter_length_min: int = -1,
                  filter_length_max: int = -1, lfr_m: int = 1, lfr_n: int = 1, dither: float = 0.0,
                  snip_edges: bool = True, upsacle_samples: bool = True, cmvn: torch.Tensor = None,
-                 device=None, dither_seed: int = None, **kwargs):
+                 device=None, dither_seed: int = None, verify: bool = None, **kwargs):
         super().__init__()
+        # verify: the fbank kernel evaluates every frame twice and repeats until two runs agree (pf_frontend_set_verify): for a GPU
+        # this process SHARES with another one. None = on exactly when the launcher says so (PF_FRONTEND_VERIFY=1)
+        self.verify = bool(int(os.environ.get("PF_FRONTEND_VERIFY", "0"))) if verify is None else bool(verify)
         if window != "hamming":
             raise NotImplementedError("only the hamming window of the Paraformer/SenseVoice recipes is built")
         if not snip_edges:
@@ -91,6 +96,14 @@ class WavFrontend(nn.Module):
     def output_size(self) -> int:
         return self.n_mels * self.lfr_m
 
+    def faults(self) -> int:
+        """disagreements the cross-check (verify=True) has seen on this handle (pf_frontend_faults); 0 without a handle"""
+        if self._handle is None:
+            return 0
+        n = C.c_uint32(0)
+        _lib.check(_lib.load().pf_frontend_faults(self._handle, C.byref(n)), "pf_frontend_faults")
+        return int(n.value)
+
     # ------------------------------------------------------------------------------------------------ internals
     def _ensure_handle(self, dev: torch.device):
         lib = _lib.load()
@@ -108,6 +121,8 @@ class WavFrontend(nn.Module):
             _lib.check(lib.pf_frontend_set_tables(h, w.data_ptr(), mel.data_ptr()), "pf_frontend_set_tables")
             if float(self.dither) != 0.0:
                 _lib.check(lib.pf_frontend_set_dither(h, float(self.dither), self.dither_seed), "pf_frontend_set_dither")
+            if self.verify:
+                _lib.check(lib.pf_frontend_set_verify(h, 1), "pf_frontend_set_verify")
             if self.cmvn is not None:
                 c = self.cmvn.to(torch.float32).contiguous().cpu()
                 dim = self.output_size()

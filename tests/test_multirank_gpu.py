@@ -22,8 +22,8 @@ def _port():
     return p
 
 
-def _run(cmd, timeout):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(cmd, timeout, **extra_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     return r.stdout
@@ -51,14 +51,27 @@ def test_sweep_two_ranks_equals_one_rank_in_corpus_order(cuda, tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.xfail(strict=False, reason="OPEN ISSUE (DESIGN 4, round 3): with TWO PROCESSES time-sharing one GPU the frontend sporadically returns a wrong "
-                                        "frame (~1e-4 of frames); one process per GPU -- the deployment -- is deterministic. Kept visible here, un-serialised.")
 def test_sweep_two_ranks_sharing_one_gpu_without_serialising(cuda, tmp_path):
-    """the same comparison as above WITHOUT --serialize-gpu: both ranks interleave their kernels on the one GPU"""
+    """the same comparison WITHOUT --serialize-gpu: both ranks interleave their kernels on the one GPU. In that configuration a
+    frame's in-LDS exchange inside fbank_kernel comes back disturbed about once per 10^4 frames (one process per GPU has
+    never shown it). Ranks that share a GPU therefore run the frontend with its cross-check on (dp.guard_shared_gpu ->
+    pf_frontend_set_verify: every frame evaluated twice from registers, repeated until two runs agree): round 4 measured 0 of 4
+    such sweeps differing with the check (7 frames caught), 1 of 4 without."""
     one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
     common = ["--clips", "48", "--batch-seconds", "1", "--no-overlap"]
     _run([sys.executable, "tools/sweep.py"] + common + ["--dump", one], 400)
     _run(_torchrun(2, ["tools/sweep.py"] + common + ["--dist-backend", "gloo", "--dump", two]), 500)
+    assert json.load(open(one)) == json.load(open(two))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.xfail(strict=False, reason="OPEN ISSUE (DESIGN 4): the ROOT CAUSE of the disturbed exchange is unknown; without the cross-check two "
+                                        "processes time-sharing one GPU sporadically get a wrong frame. Kept visible here.")
+def test_sweep_two_ranks_sharing_one_gpu_without_the_cross_check(cuda, tmp_path):
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    common = ["--clips", "48", "--batch-seconds", "1", "--no-overlap"]
+    _run([sys.executable, "tools/sweep.py"] + common + ["--dump", one], 400)
+    _run(_torchrun(2, ["tools/sweep.py"] + common + ["--dist-backend", "gloo", "--dump", two]), 500, PF_FRONTEND_VERIFY="0")
     assert json.load(open(one)) == json.load(open(two))
 
 

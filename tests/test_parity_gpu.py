@@ -667,3 +667,21 @@ def test_frontend_dither_is_seeded_noise_with_the_reference_statistics(cuda):
     d_ref = (ref_noisy - ref_clean).abs().mean().item()
     d_got = (a1 - clean).abs().mean().item()
     assert d_got < 2.0 * d_ref + 1e-3 and d_got > 0.3 * d_ref, (d_got, d_ref)
+
+
+
+def test_frontend_cross_check_returns_the_same_features(cuda):
+    """WavFrontend(verify=True): fbank_kernel evaluates every frame twice from its samples in registers and repeats until two runs
+    agree (pf_frontend_set_verify; for GPUs shared between processes). Alone on the GPU nothing disagrees and the features are the
+    bits of the plain kernel."""
+    from funasr_amd import synth
+    from funasr_amd.wav_frontend import WavFrontend
+    sh, sc = synth.synthetic_cmvn(560)
+    wav = torch.stack([synth.speech_like(48000, seed=3 + i) for i in range(4)]).to(cuda)
+    lens = [48000, 31000, 16000, 400]
+    plain = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0, device=cuda, verify=False)
+    check = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0, device=cuda, verify=True)
+    a, la = plain(wav, lens)
+    b, lb = check(wav, lens)
+    assert torch.equal(a, b) and torch.equal(torch.as_tensor(la), torch.as_tensor(lb))
+    assert check.faults() == 0 and plain.faults() == 0

@@ -48,4 +48,4 @@ while True:
         wav_ok = bool(torch.equal(wav[0].cpu(), host[k]))
         bad.append({"iter": it, "clip": k, "n_diff": int(idx.shape[0]), "max": float(d.max()), "wav_final_ok": wav_ok,
                     "rows": sorted(set(idx[:, 1].tolist()))[:10], "n_rows": len(set(idx[:, 1].tolist())), "T": f.shape[1]})
-print(json.dumps({"tag": tag, "sync_before": sync_before, "iters": it, "seconds": round(time.time() - t0, 2), "mismatches": len(bad), "first": bad[:6]}))
+print(json.dumps({"tag": tag, "verify": bool(fe.verify), "faults_seen_by_the_cross_check": fe.faults(), "sync_before": sync_before, "iters": it, "seconds": round(time.time() - t0, 2), "mismatches": len(bad), "first": bad[:6]}))

@@ -67,6 +67,7 @@ def main():
         dist.init_process_group(backend=args.dist_backend, **({} if args.dist_backend == "gloo" else {"device_id": dev}))
     from funasr_amd import dp, synth
     from funasr_amd.wav_frontend import WavFrontend
+    dp.guard_shared_gpu(world, all_on_one=args.dist_backend == "gloo")
 
     if args.model == "paraformer":
         from funasr_amd.paraformer import Paraformer
@@ -234,6 +235,7 @@ def main():
                           # GPU time between the first and the last kernel of every batch (events on the launch stream): when it
                           # adds up to the wall time the sweep is GPU-bound and `enqueue` is back-pressure, not host work
                           "gpu_seconds_rank0": round(sum(a.elapsed_time(b) for a, b in gpu_events) * 1e-3, 3)}), flush=True)
+    print(f"[sweep] rank {rank}: frontend cross-check {'on' if fe.verify else 'off'}, disagreements seen: {fe.faults()}", file=sys.stderr, flush=True)
     if args.trace_hash is not None:
         with open(f"{args.trace_hash}.{rank}", "w") as f:
             json.dump(trace_rows, f)
