@@ -93,6 +93,7 @@ SIGNATURES = {
     "pf_frontend_set_dither": (C.c_int, [_vp, _f32, C.c_uint64]),
     "pf_frontend_set_verify": (C.c_int, [_vp, _i32]),
     "pf_frontend_faults": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "pf_frontend_fault_log": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "pf_frontend_set_tables": (C.c_int, [_vp, _vp, _vp]),
     "pf_frontend_num_fbank_frames": (_i32, [_vp, _i64]),
     "pf_frontend_num_frames": (_i32, [_vp, _i64]),

@@ -120,8 +120,8 @@ int pf_frontend_set_verify(pf_frontend* fh, int32_t on) {
     Frontend* f = reinterpret_cast<Frontend*>(fh);
     PF_REQUIRE(f, "frontend_set_verify: null handle");
     if (on && !f->faults.p) {
-        if (f->faults.ensure(sizeof(unsigned int))) return -2;
-        PF_HIP_TRY(hipMemset(f->faults.p, 0, sizeof(unsigned int)));
+        if (f->faults.ensure(sizeof(unsigned int) * 68)) return -2;          // [0] count, [4 + 4 k ..]: log of the first 16
+        PF_HIP_TRY(hipMemset(f->faults.p, 0, sizeof(unsigned int) * 68));
     }
     f->verify = on ? 1 : 0;
     return 0;
@@ -131,6 +131,13 @@ int pf_frontend_faults(pf_frontend* fh, uint32_t* count_host) {
     PF_REQUIRE(f && count_host, "frontend_faults: null");
     *count_host = 0;
     if (f->faults.p) PF_HIP_TRY(hipMemcpy(count_host, f->faults.p, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return 0;
+}
+int pf_frontend_fault_log(pf_frontend* fh, uint32_t* log_host) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    PF_REQUIRE(f && log_host, "frontend_fault_log: null");
+    for (int i = 0; i < 64; ++i) log_host[i] = 0;
+    if (f->faults.p) PF_HIP_TRY(hipMemcpy(log_host, f->faults.as<unsigned int>() + 4, sizeof(unsigned int) * 64, hipMemcpyDeviceToHost));
     return 0;
 }
 int pf_frontend_set_tables(pf_frontend* fh, const float* window, const float* mel) {

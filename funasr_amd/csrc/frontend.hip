@@ -265,17 +265,32 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
         __builtin_amdgcn_wave_barrier();
         };
         float r0[2];
+        unsigned long long t_a = p.verify ? __builtin_amdgcn_s_memtime() : 0ull;
         compute(r0);
+        unsigned long long t_b = p.verify ? __builtin_amdgcn_s_memtime() : 0ull;
         if (p.verify) {
             // cross-check (FbankArgs.verify): recompute until two consecutive evaluations agree in every lane; each disagreement
             // is counted. The frame's inputs never left the registers, so only a disturbed exchange can make two runs differ.
             for (int tries = 0; tries < 4; ++tries) {
                 float r1[2];
                 compute(r1);
+                const unsigned long long t_c = __builtin_amdgcn_s_memtime();
                 const bool same = __float_as_uint(r0[0]) == __float_as_uint(r1[0]) && __float_as_uint(r0[1]) == __float_as_uint(r1[1]);
                 r0[0] = r1[0]; r0[1] = r1[1];
                 if (__all(same)) break;
-                if (lane == 0 && p.faults) atomicAdd(p.faults, 1u);
+                const unsigned long long diff_mask = __ballot(!same);
+                if (lane == 0 && p.faults) {
+                    // diagnostics (pf_frontend_fault_log): shader-clock cycles of the two evaluations that disagreed and the frame --
+                    // an evaluation that was suspended in the middle (another process's turn on the CU) shows as a long one
+                    const unsigned k = atomicAdd(p.faults, 1u);
+                    if (k < 16) {
+                        p.faults[4 + 4 * k] = (unsigned)(t_b - t_a); p.faults[5 + 4 * k] = (unsigned)(t_c - t_b);
+                        p.faults[6 + 4 * k] = (unsigned)g;
+                        // retry number | lanes whose outputs differ (count << 8) | first such lane << 16
+                        p.faults[7 + 4 * k] = (unsigned)tries | ((unsigned)__popcll(diff_mask) << 8) | ((unsigned)(__ffsll((long long)diff_mask) - 1) << 16);
+                    }
+                }
+                t_a = t_b; t_b = t_c;
             }
         }
         float* out = p.fbank + ((size_t)b * p.max_frames + f) * p.n_mels;

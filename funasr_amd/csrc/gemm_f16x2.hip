@@ -612,6 +612,10 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
         if (a.tile >= 256) return (a.tile >> 8) == 1 ? launch_tile<2, 4, MODE, 0, 0, 1>(a, stream) : launch_tile<2, 4, MODE, 0, 0, 2>(a, stream);
     }
     if constexpr (MODE == 0 && OUT == 0) {
+        // ablation builds of the 128 x 128 four-wave shape (tools/repro_inproc.py: which part of it disturbs a co-resident
+        // frontend): 0x82 = no epilogue, 0x83 = no operand DMA
+        if (a.tile == 0x82) return launch_tile<2, 2, 0, 0, 2, 0, 2>(a, stream);
+        if (a.tile == 0x83) return launch_tile<2, 2, 0, 0, 3, 0, 2>(a, stream);
         if (a.tile >= 16) {                 // ablation builds of the wide tile: bits 4.. = ABL
             switch (a.tile >> 4) {
                 case 1: return launch_tile<2, 4, 0, 0, 1>(a, stream);

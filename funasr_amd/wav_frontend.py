@@ -104,6 +104,14 @@ class WavFrontend(nn.Module):
         _lib.check(_lib.load().pf_frontend_faults(self._handle, C.byref(n)), "pf_frontend_faults")
         return int(n.value)
 
+    def fault_log(self):
+        """the first 16 disagreements: (cycles of the first evaluation, cycles of the second, frame index, retry) each"""
+        if self._handle is None:
+            return []
+        buf = (C.c_uint32 * 64)()
+        _lib.check(_lib.load().pf_frontend_fault_log(self._handle, buf), "pf_frontend_fault_log")
+        return [tuple(int(buf[4 * k + i]) for i in range(4)) for k in range(min(16, self.faults()))]
+
     # ------------------------------------------------------------------------------------------------ internals
     def _ensure_handle(self, dev: torch.device):
         lib = _lib.load()

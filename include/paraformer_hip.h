@@ -87,6 +87,9 @@ int pf_frontend_set_dither(pf_frontend* f, float dither, uint64_t seed);
  * deployment this library is built for -- has never shown it. pf_frontend_faults: disagreements seen since the handle was made. */
 int pf_frontend_set_verify(pf_frontend* f, int32_t on);
 int pf_frontend_faults(pf_frontend* f, uint32_t* count_host);
+/* diagnostics: for the first 16 disagreements, 4 x uint32 each: shader-clock cycles of the two evaluations that disagreed, the
+ * frame index, the retry number (an evaluation suspended in the middle -- another process's turn on the CU -- shows as a long one) */
+int pf_frontend_fault_log(pf_frontend* f, uint32_t* log_host_64);
 /* Optional: override the built-in Kaldi tables (float64 cos window, float32 mel triangles as in
  * kaldi-native-fbank feature-window.cc:25-47, mel-computations.cc:118-210) with caller-computed ones, e.g. the
  * float32 tables torchaudio.compliance.kaldi builds. window: [frame_length]; mel: dense [n_mels, 257]. */

@@ -235,7 +235,7 @@ def main():
                           # GPU time between the first and the last kernel of every batch (events on the launch stream): when it
                           # adds up to the wall time the sweep is GPU-bound and `enqueue` is back-pressure, not host work
                           "gpu_seconds_rank0": round(sum(a.elapsed_time(b) for a, b in gpu_events) * 1e-3, 3)}), flush=True)
-    print(f"[sweep] rank {rank}: frontend cross-check {'on' if fe.verify else 'off'}, disagreements seen: {fe.faults()}", file=sys.stderr, flush=True)
+    print(f"[sweep] rank {rank}: frontend cross-check {'on' if fe.verify else 'off'}, disagreements seen: {fe.faults()} log(cycles a, cycles b, frame, retry)={fe.fault_log()}", file=sys.stderr, flush=True)
     if args.trace_hash is not None:
         with open(f"{args.trace_hash}.{rank}", "w") as f:
             json.dump(trace_rows, f)
