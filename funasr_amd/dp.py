@@ -48,15 +48,11 @@ def ensure_ranks(n_gpus: int, argv: Sequence[str] = None) -> int:
 
 
 def guard_shared_gpu(world: int, all_on_one: bool = False) -> bool:
-    """More ranks than GPUs (or the dry run that puts every rank on GPU 0): the fbank kernel's cross-check goes on for frontends
-    created after this call (WavFrontend(verify=None) reads PF_FRONTEND_VERIFY). With two processes interleaving their kernels on
-    one GPU a frame's in-LDS exchange comes back disturbed about once per 10^4 frames (tools/two_rank_frontend_check.sh:
-    1 of 4 un-serialised two-rank sweeps differed without the check, 0 of 4 with it, 7 frames caught); one process per GPU -- the
-    deployment -- has never shown it, so the check stays off there. Returns whether ranks share a GPU."""
-    shared = world > 1 and (all_on_one or world > max(1, torch.cuda.device_count()))
-    if shared:
-        os.environ.setdefault("PF_FRONTEND_VERIFY", "1")
-    return shared
+    """Whether ranks share a GPU (more ranks than GPUs, or the dry run that puts every rank on GPU 0). Round 3 saw the frontend return a
+    sporadically wrong frame in that configuration; round 4 found the cause (packed-fp32 VALU instructions of fbank_kernel next to
+    waves of the 128 x 128 f16x2 GEMM on one CU) and builds the non-matrix kernels without those instructions (csrc/Makefile), so
+    nothing needs switching on here any more. PF_FRONTEND_VERIFY=1 still turns the fbank kernel's cross-check on for a whole job."""
+    return world > 1 and (all_on_one or world > max(1, torch.cuda.device_count()))
 
 
 def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:

@@ -81,10 +81,10 @@ int pf_frontend_set_cmvn(pf_frontend* f, const float* shift_host, const float* s
  * generator keyed by `seed` and the number of forwards since this call: the same seed gives the same feature sequence. Parity
  * with the reference is statistical by nature (its noise is torch.randn). */
 int pf_frontend_set_dither(pf_frontend* f, float dither, uint64_t seed);
-/* Cross-check of the fbank kernel's in-LDS exchanges (off by default): every frame is evaluated twice from its samples in
- * registers and re-evaluated until two consecutive results agree in every lane. For a GPU SHARED with another process that runs
- * LDS-DMA-heavy kernels, where about one frame in 10^4 comes back with a disturbed exchange; one process per GPU -- the
- * deployment this library is built for -- has never shown it. pf_frontend_faults: disagreements seen since the handle was made. */
+/* Cross-check of the fbank kernel (off by default): every frame is evaluated twice from its samples in registers and re-evaluated
+ * until two consecutive results agree in every lane. It is how round 4 located the 'two-process frontend fault' (packed-fp32
+ * VALU instructions next to waves of the 128 x 128 f16x2 GEMM; fixed at build level) and stays as a diagnostic. pf_frontend_faults:
+ * disagreements seen since the handle was made. */
 int pf_frontend_set_verify(pf_frontend* f, int32_t on);
 int pf_frontend_faults(pf_frontend* f, uint32_t* count_host);
 /* diagnostics: for the first 16 disagreements, 4 x uint32 each: shader-clock cycles of the two evaluations that disagreed, the

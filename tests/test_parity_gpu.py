@@ -685,3 +685,33 @@ def test_frontend_cross_check_returns_the_same_features(cuda):
     b, lb = check(wav, lens)
     assert torch.equal(a, b) and torch.equal(torch.as_tensor(la), torch.as_tensor(lb))
     assert check.faults() == 0 and plain.faults() == 0
+
+
+def test_frontend_next_to_the_small_block_f16x2_gemm_on_a_second_stream(cuda):
+    """The configuration that made fbank_kernel fault: this library's 128 x 128 f16x2 GEMM on a second HIP stream of the
+    same process while the frontend runs. With the non-matrix kernels built without packed-fp32 instructions every frontend call
+    returns the bits it returns alone, and the cross-check sees nothing (before: thousands of disagreements per second)."""
+    import time
+    from funasr_amd import ops, synth
+    from funasr_amd.wav_frontend import WavFrontend
+    g = torch.Generator().manual_seed(0)
+    sh, sc = synth.synthetic_cmvn(560)
+    fe = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0, device=cuda, verify=True)
+    wav = synth.speech_like(235000, seed=7).to(cuda)[None]
+    ref = fe(wav, [235000])[0].clone()
+    side = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(side):
+        a = ops.split2(torch.randn(1024, 512, generator=g).to(cuda), 8)
+        w = ops.split2((torch.randn(2048, 512, generator=g) * 512 ** -0.5).to(cuda), 12)
+        b = torch.zeros(2048, device=cuda)
+    torch.cuda.synchronize()
+    t0, calls = time.time(), 0
+    while time.time() - t0 < 3.0:
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                ops.gemm_f16x2(a, w, b, scale_exp=20, tile=3)
+        for _ in range(4):
+            assert torch.equal(fe(wav, [235000])[0], ref)
+            calls += 1
+    torch.cuda.synchronize()
+    assert calls > 1000 and fe.faults() == 0, (calls, fe.faults())
