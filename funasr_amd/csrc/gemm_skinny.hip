@@ -35,7 +35,9 @@ constexpr int SK_KW = 16;    // waves per workgroup = K slices (a constant: a ro
 // a tile, workgroup blockIdx.z takes slices 4 z .. 4 z + 3 -- for the long-K, N = 512 projections of a step (w_2: 4 MB of
 // weights behind 32 column tiles = 32 CUs at ~25 GB/s each, 10-18 us in the chain) this spreads the weight stream over 128
 // CUs. The sixteen slice tiles go to a workspace; the workgroup that arrives last at the tile's counter folds them in the order
-// of the one-workgroup form (slice 0 + 1 + .. + 15) and runs the epilogue: the bits do not depend on the form.
+// of the one-workgroup form (slice 0 + 1 + .. + 15) and runs the epilogue: the bits do not depend on the form. MEASURED SLOWER (17.9 vs
+// 10.4 us for w_2: the device-scope fence of the hand-over -- the four workgroups may sit on different XCDs -- costs more than the
+// spread saves) and therefore off by default (stream option "wide_k"); kept with its tests as the record of that experiment.
 template <int RM, int CN, int LNIN, int NW>      // LNIN: 0 plain, 1 LayerNorm form with gamma applied in the loop, 2 with gamma a stored by the producer
 __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
     constexpr int LD = CN * 16 + 1;                                        // padded row of the LDS partial tiles
