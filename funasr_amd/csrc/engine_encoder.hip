@@ -327,7 +327,8 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
         if (C && K >= 4 * D && K % 128 == 0 && e->splitk.p) { g.ksplit = 4; g.part = e->splitk.as<float>(); }
         // a step of few rows leaves most CUs idle and a block's K loop runs at ~0.85 us per 32-deep stage whatever the block count:
         // the K = d_model projections in four slices too (x2_short_k: by the handle's stream count, never by the step's data)
-        if (cc->x2_short_k && K % 128 == 0 && e->splitk.p) { g.ksplit = 4; g.part = e->splitk.as<float>(); }
+        // (x2_short_k 1: only where the split's second launch REPLACES a LayerNorm launch -- linear_out + norm2; 2: every projection)
+        if ((cc->x2_short_k == 2 || (cc->x2_short_k == 1 && ln)) && K % 128 == 0 && e->splitk.p) { g.ksplit = 4; g.part = e->splitk.as<float>(); }
         if (ln) {
             if (g.ksplit <= 1 || N != D) { set_error("encoder: LayerNorm folding needs the split-K form of an N = d_model projection"); return -1; }
             g.ln_g = ln->g; g.ln_b = ln->b; g.ln_eps = c.ln_eps; g.ln_y = reinterpret_cast<float*>(xn2c); g.ln_ldy = D;
@@ -415,7 +416,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
         if (!o2 && (rc = launch_split2(ctx, D, ctx2c, D, (size_t)M * D, M, D, pow2f(w.e_v), s))) return rc;
         // (short-K split: norm2's planes come from linear_out's second launch)
         const LnFold n2{w.n2g, w.n2b, w.e_x2};
-        const bool fold2 = cc->x2_short_k && cc->x2_fold && D % 128 == 0 && e->splitk.p;
+        const bool fold2 = cc->x2_short_k != 0 && cc->x2_fold && D % 128 == 0 && e->splitk.p;
         if ((rc = gemm2c(ctx2c, D, w.e_v, w.out_w2, w.ew_out, w.out_b, x, D, nullptr, 0, D, D, 0, mem, D, resid, ld_in, fold2 ? &n2 : nullptr))) return rc;
         // norm2 -> FFN -> residual: w_1 hands its relu output to w_2 as planes, like the offline mode
         if (!fold2 && (rc = ln_planes(x, D, w.n2g, w.n2b, D, D, w.e_x2))) return rc;

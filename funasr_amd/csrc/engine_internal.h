@@ -398,7 +398,7 @@ struct EncChunkCtx {
     // f16x2 step: norm1 of the block after this one rides in the second launch of this block's split-K w_2 (launch_splitk_reduce_ln)
     const EncLayerW* x2_out_next = nullptr;
     bool x2_in_ready = false;
-    bool x2_short_k = false;     // f16x2 step of few rows: the K = d_model projections in the four-slice split-K form too
+    int x2_short_k = 0;          // f16x2 step of few rows: K = d_model projections in the four-slice split-K form too (1: linear_out only, 2: all)
     bool x2_fold = false;        // (with x2_short_k) norm2 from linear_out's second launch
     bool x2_attn_planes = false; // f16x2 step: the attention writes the out-projection's operand planes (AttnArgs.O2)
     bool fsmn_rides = false;     // the FSMN memory block is computed by extra workgroups of the attention launch (AttnArgs.fs_*)
@@ -500,11 +500,12 @@ struct Stream {
     DevBuf ln_consts;
     uint64_t ln_ver_e = ~0ull, ln_ver_d = ~0ull;
     DevBuf dec_ln_a, dec_ln_b, dec_ln_f;                     // decoder: block partials of the token rows (d_model wide twice, ffn wide)
-    // f16x2 step: the K = d_model projections in four K slices when the handle's rows (streams x window) leave most CUs idle
-    // (<= 2048 rows): 1 = that rule, 0 = never, 2 = always. By the handle, never by a step's data. OFF: measured at S = 64 the
-    // GEMMs drop from 19 to 15.5 us (a 128 x 128 block costs ~12 us before its first K stage counts) and the 100 extra
-    // reduce launches of 7.5 us give it all back (7.79 vs 7.81 ms per step; S = 16: -5 %, S = 128: +0.3 %).
-    int short_k = 0;
+    // f16x2 step, handles of <= 2048 rows (streams x largest window: most CUs idle): K = d_model projections in the four-slice split-K
+    // form. 3 (default) = linear_out only -- its second launch computes norm2 and so REPLACES a launch: S = 64 7.91 -> 7.67 ms;
+    // 1 = every K = d_model projection (measured break-even: the GEMMs drop from 19 to 15.5 us -- a 128 x 128 block costs ~12 us before
+    // its first K stage counts -- and the 100 extra reduce launches of 7.5 us give it back), 2 = that for any handle size, 0 = never.
+    // By the handle, never by a step's data.
+    int short_k = 3;
     bool ln_folded = true;                                   // f16x2 step: LayerNorms folded into the split-K reductions, attention writes planes
     bool kv_batched = true;                                  // fp32 step: the decoder's key/value projections of the encoder rows as one launch
     unsigned long long ver_e = ~0ull, ver_d = ~0ull;         // TensorTable versions the prepared exponents / planes belong to

@@ -102,7 +102,8 @@ static int stream_token_rows(const Stream* st, int W, int is_final) {
 
 // the f16x2 step's K = d_model projections in the split-K form: by the handle's size (streams x largest window), see Stream.short_k
 static bool stream_short_k(const Stream* st) {
-    return st->short_k == 2 || (st->short_k == 1 && (size_t)st->S * st->Wmax <= 2048);
+    // 1: every K = d_model projection when the handle is small, 2: always, 3: linear_out only (its second launch replaces norm2's) when small
+    return st->short_k == 2 || ((st->short_k == 1 || st->short_k == 3) && (size_t)st->S * st->Wmax <= 2048);
 }
 
 // enqueue one chunk on `s` (no host synchronisation, no allocation after the first call with this shape)
@@ -158,7 +159,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
                        st->lensW.as<int>(), st->x2};
         cc.fsmn_rides = st->fsmn_rides;
         cc.x2_attn_planes = st->x2 && st->ln_folded;
-        cc.x2_short_k = st->x2 && stream_short_k(st);
+        cc.x2_short_k = (st->x2 && stream_short_k(st)) ? (st->short_k >= 3 ? 1 : 2) : 0;
         cc.x2_fold = st->ln_folded;
         if (st->x2 && st->ln_folded && F >= 4 * D && F % 128 == 0) {
             // (the condition of gemm2c's split-K form; block l + 1 must take the folded planes: same width, no padding columns)
@@ -556,7 +557,7 @@ int pf_stream_set_option(pf_stream* sh, const char* key, int32_t value) {
     else if (k == "kv_batched") st->kv_batched = value != 0;
     else if (k == "wide_k") st->wide_k = value != 0;
     else if (k == "ln_folded") st->ln_folded = value != 0;
-    else if (k == "short_k") st->short_k = value < 0 ? 0 : value > 2 ? 2 : value;
+    else if (k == "short_k") st->short_k = value < 0 ? 0 : value > 3 ? 3 : value;
     else {
         if (value == 3) {
             int rc = stream_prepare_x2(st, st->stream);

@@ -351,7 +351,9 @@ int pf_stream_reset(pf_stream* s, void* stream);
  * 2 always; one-pass variance: fp32-class, not the bits of the stand-alone LayerNorm); "fsmn_rides" [1] the encoder's FSMN memory
  * block inside the attention launch; "kv_batched" [1] fp32 step: the decoder's key/value projections of the step's encoder rows
  * and the ring appends as one launch each; "ln_folded" [1] f16x2 step: LayerNorms in the second launch of the split-K
- * projections, attention writing the out-projection's operand planes; "wide_k" [0] four workgroups per tile for the long-K
+ * projections, attention writing the out-projection's operand planes; "short_k" [3] f16x2 step of a small handle (<= 2048 rows):
+ * linear_out in the four-slice split-K form with norm2 in its second launch (0 never, 1 / 2 every K = d_model projection: break-even);
+ * "wide_k" [0] four workgroups per tile for the long-K
  * projections of a <= 32-row step (bitwise, slower: measured and kept off). */
 int pf_stream_set_option(pf_stream* s, const char* key, int32_t value);
 /* One chunk for every stream. feats_dev: [n_streams, n_frames, input_dim] un-scaled online features (ignored for a

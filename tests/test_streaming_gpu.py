@@ -279,9 +279,14 @@ def test_step_launch_fusions_leave_the_session_unchanged(cuda):
             assert (a[1] - b[1]).abs().max().item() < 1e-4, S
         # the f16x2 step: "ln_folded" (LayerNorms in the second launch of the split-K projections, attention writing the operand
         # planes of the out-projection) and the FSMN rider repeat the separate launches' arithmetic: the same bits
-        plain2 = session({"ln_folded": 0, "fsmn_rides": 0}, S, "f16x2")
-        for a, b in zip(plain2, session({"ln_folded": 1, "fsmn_rides": 1}, S, "f16x2")):
+        plain2 = session({"ln_folded": 0, "fsmn_rides": 0, "short_k": 0}, S, "f16x2")
+        for a, b in zip(plain2, session({"ln_folded": 1, "fsmn_rides": 1, "short_k": 0}, S, "f16x2")):
             assert a[0] == b[0] and torch.equal(a[1], b[1]), S
+        # "short_k" 3 (the default of small handles): linear_out in the four-slice split-K form, norm2 in its second launch -- another
+        # summation order, fp32-class: the same tokens, encoder rows within 1e-4
+        for a, b in zip(plain2, session({}, S, "f16x2")):
+            assert a[0] == b[0], S
+            assert (a[1] - b[1]).abs().max().item() < 1e-4, S
 
 
 def test_two_handles_with_a_step_in_flight_each(cuda):
