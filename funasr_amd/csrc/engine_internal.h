@@ -507,6 +507,10 @@ struct Stream {
     // By the handle, never by a step's data.
     int short_k = 3;
     bool ln_folded = true;                                   // f16x2 step: LayerNorms folded into the split-K reductions, attention writes planes
+    // f16x2 step: the decoder layers' key/value weights concatenated to ONE [n_blocks * 2 d_model, d_model] matrix (planes with one
+    // exponent; prepared with the other planes): one GEMM instead of n_blocks, one ring append instead of n_blocks
+    DevBuf kvcat_w, kvcat_b, kvcat_2;
+    int kvcat_e = 0;
     bool kv_batched = true;                                  // fp32 step: the decoder's key/value projections of the encoder rows as one launch
     unsigned long long ver_e = ~0ull, ver_d = ~0ull;         // TensorTable versions the prepared exponents / planes belong to
     int e_mem = 0, e_an = 0;

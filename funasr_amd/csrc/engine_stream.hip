@@ -45,6 +45,19 @@ static int stream_prepare_x2(Stream* st, hipStream_t s) {
     st->e_an = exp_for_bound(sqrtf((float)D) * g + b);
     int ew_v = 0;
     if (!d->tt.get_split2("output_layer.weight", dc.vocab_size, D, &ew_v, s)) return -2;
+    // the layers' linear_k_v weights as one matrix (Stream.kvcat_*): rows [l * 2 D, (l + 1) * 2 D) = layer l
+    if (dc.n_blocks > 0) {
+        const size_t rows = (size_t)dc.n_blocks * 2 * D, n = rows * D;
+        if (st->kvcat_w.ensure(sizeof(float) * n) || st->kvcat_b.ensure(sizeof(float) * rows) || st->kvcat_2.ensure(sizeof(unsigned short) * 2 * n)) return -2;
+        for (int l = 0; l < dc.n_blocks; ++l) {
+            PF_HIP_TRY(hipMemcpyAsync(st->kvcat_w.as<float>() + (size_t)l * 2 * D * D, d->layers[l].kv_w, sizeof(float) * 2 * D * D, hipMemcpyDeviceToDevice, s));
+            PF_HIP_TRY(hipMemcpyAsync(st->kvcat_b.as<float>() + (size_t)l * 2 * D, d->layers[l].kv_b, sizeof(float) * 2 * D, hipMemcpyDeviceToDevice, s));
+        }
+        float amax = 0.f;
+        if (TensorTable::dev_absmax(st->kvcat_w.as<float>(), n, &amax, s)) return -2;
+        st->kvcat_e = amax > 0.f ? 14 - (int)floorf(log2f(amax)) : 0;
+        if ((rc = launch_split2(st->kvcat_w.as<float>(), D, st->kvcat_2.as<unsigned short>(), D, n, (int)rows, D, ldexpf(1.f, st->kvcat_e), s))) return rc;
+    }
     st->ver_e = e->tt.version; st->ver_d = d->tt.version;
     return 0;
 }
@@ -250,6 +263,15 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         ProfScope ps(PROF_GEMM, 2.0 * Mk * (double)(2 * D) * D * dc.n_blocks, s);
         if ((rc = launch_gemm_skinny_batch(g, t, s))) return rc;
     }
+    // ---- f16x2 step: the same in one GEMM over the concatenated weight planes (Stream.kvcat_*): layer l's K | V are columns
+    // [l * 2 D, (l + 1) * 2 D) of a [rows, n_blocks * 2 D] result
+    const bool kv_cat = x2 && st->kv_batched && dc.n_blocks > 0 && st->kvcat_2.p;
+    const int kv_ld = kv_cat ? dc.n_blocks * 2 * D : 2 * D;
+    if (kv_cat) {
+        if (d->kv.ensure(sizeof(float) * (size_t)S * st->Wmax * kv_ld)) return -2;
+        if ((rc = gemm2_simple(mem2, D, Mk, st->e_mem, st->kvcat_2.as<unsigned short>(), st->kvcat_e, st->kvcat_b.as<float>(), d->kv.as<float>(), kv_ld,
+                               kv_ld, D, 0, nullptr, 0, s))) return rc;
+    }
     // ---- fp32 step of a few token rows: the decoder's LayerNorms ride in the launches on either side (gemm_skinny.hip,
     // DecFsmnChunkArgs.ln_*): 11 launches per layer become 6 with the batched projection above
     const bool dcarry = st->ln_carry && !x2 && (Mq <= 32 || st->ln_carry > 1) && Nmax <= 24 && D % 16 == 0 && dc.ffn_dim % 16 == 0 &&
@@ -288,7 +310,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     };
     for (int l = 0; l < dc.n_blocks; ++l) {
         const DecLayerW& w = d->layers[l];
-        float* kv_l = d->kv.as<float>() + (kv_batched ? l * kv_layer : 0);
+        float* kv_l = d->kv.as<float>() + (kv_batched ? l * kv_layer : kv_cat ? (size_t)l * 2 * D : 0);
         DecFsmnChunkArgs fa{};
         fa.in = t1; fa.resid = dx; fa.out = dx; fa.w = w.fsmn_w; fa.state = st->dec_fsmn.as<float>() + l * dfsmn_layer;
         fa.n_valid = st->n_fired.as<int>(); fa.S = S; fa.N = Nmax; fa.C = D;
@@ -313,7 +335,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
                                            (size_t)Mq * D, pow2f(w.e_n3)))) return rc;
             }
             if ((rc = gemm2_simple(t2p, D, Mq, w.e_n3, w.q_2, w.ew_q, w.q_b, d->q.as<float>(), D, D, D, 0, nullptr, 0, s))) return rc;
-            if ((rc = gemm2_simple(mem2, D, Mk, st->e_mem, w.kv_2, w.ew_kv, w.kv_b, d->kv.as<float>(), 2 * D, 2 * D, D, 0, nullptr, 0, s)))
+            if (!kv_cat && (rc = gemm2_simple(mem2, D, Mk, st->e_mem, w.kv_2, w.ew_kv, w.kv_b, d->kv.as<float>(), 2 * D, 2 * D, D, 0, nullptr, 0, s)))
                 return rc;
         } else {
             if ((rc = layernorm(dx, D, w.n3g, w.n3b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
@@ -327,20 +349,20 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         if (st->dec_cap > 0) {
             float* ring = st->dec_ring.as<float>() + l * dring_layer;
             at.K = ring; at.ldk = 2 * D; at.V = ring + D; at.ldv = 2 * D; at.Tk = st->dec_cap;
-            at.K2 = kv_l; at.ldk2 = 2 * D; at.V2 = kv_l + D; at.ldv2 = 2 * D; at.T2 = W; at.n2 = W;
+            at.K2 = kv_l; at.ldk2 = kv_ld; at.V2 = kv_l + D; at.ldv2 = kv_ld; at.T2 = W; at.n2 = W;
             at.n1_dev = st->dec_valid.as<int>(); at.n1_stride = 1;
         } else {
-            at.K = kv_l; at.ldk = 2 * D; at.V = kv_l + D; at.ldv = 2 * D; at.Tk = W;
+            at.K = kv_l; at.ldk = kv_ld; at.V = kv_l + D; at.ldv = kv_ld; at.Tk = W;
             at.klens = st->lensW.as<int>();
         }
         bool appended = false;
-        if (st->dec_cap > 0 && !kv_batched) {
+        if (st->dec_cap > 0 && !kv_batched && !kv_cat) {
             at.app_rows = W; at.app_r0 = 0; at.app_wp = st->dec_wp.as<int>(); at.app_wp_stride = 1; at.app_gate = st->n_fired.as<int>();
         }
         const bool o2 = x2 && st->ln_folded && Nmax <= 32;
         if (o2) { at.O2 = c2p; at.ldo2 = D; at.o2_plane = (size_t)Mq * D; at.o2_scale = pow2f(st->e_ctx[l]); }
         if ((rc = attention(at, 4.0 * S * (double)Nmax * W * D, s, false, 128, &appended))) return rc;
-        if (st->dec_cap > 0 && !appended && !kv_batched) {
+        if (st->dec_cap > 0 && !appended && !kv_batched && !kv_cat) {
             RingAppendArgs ra{};
             ra.src = kv_l; ra.ldsrc = 2 * D; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
             ra.ring = st->dec_ring.as<float>() + l * dring_layer; ra.cap = st->dec_cap; ra.S = S; ra.st = nullptr;
@@ -354,13 +376,13 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
             if ((rc = gemm_ln(d->ctx.as<float>(), D, w.o_w, w.o_b, dx, D, D, 0, dx, sA, nullptr, nullptr, nullptr))) return rc;
         } else if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, dx, D, Mq, D, D, 0, nullptr, 0, dx, D, s))) return rc;
     }
-    if (st->dec_cap > 0 && kv_batched && dc.n_blocks > 0) {
+    if (st->dec_cap > 0 && (kv_batched || kv_cat) && dc.n_blocks > 0) {
         // every layer's append in one launch (the rings are read by the attentions above, written here)
         RingAppendArgs ra{};
-        ra.src = d->kv.as<float>(); ra.ldsrc = 2 * D; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
+        ra.src = d->kv.as<float>(); ra.ldsrc = kv_ld; ra.src_T = W; ra.r0 = 0; ra.rows = W; ra.cols = 2 * D;
         ra.ring = st->dec_ring.as<float>(); ra.cap = st->dec_cap; ra.S = S; ra.st = nullptr;
         ra.wp_dev = st->dec_wp.as<int>(); ra.gate_dev = st->n_fired.as<int>();
-        ra.n_layers = dc.n_blocks; ra.src_layer = kv_layer; ra.ring_layer = dring_layer;
+        ra.n_layers = dc.n_blocks; ra.src_layer = kv_cat ? (size_t)2 * D : kv_layer; ra.ring_layer = dring_layer;
         if ((rc = launch_ring_append(ra, s))) return rc;
     }
     if (st->dec_cap > 0) {
