@@ -389,7 +389,7 @@ int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* 
 // b * seq_out + t reads input row b * seq_in + t
 // out_mode 1 / in_bf16: y / x is a bf16 buffer (ldy / ldx in elements); out_mode 2: y receives the three bf16 planes
 // of the result (split3), `plane` elements apart; statistics are always fp32
-int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R1, int ldr1,
+int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, int relu, const float* R1, int ldr1,
                             const float* R2, int ldr2, float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
                             size_t plane, float oscale, hipStream_t stream);
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,

@@ -128,7 +128,8 @@ int dec_layer_x2(Decoder* d, DecLayerW& w, const std::string& p, bool attn, hipS
 
 // f16x2 form of dec_ffn: both LayerNorms write two-plane fp16 operands, w_1 and w_2 run on the fp16 matrix cores
 // ln (streaming step, split-K w_2): the LayerNorm that follows the block rides in w_2's second launch (Gemm2Args.ln_*)
-int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part, const FoldedLn* ln) {
+// fold_fn (with splitk_part of 4 * M * ffn_dim floats): the FFN's inner norm rides in the second launch of a split-K w_1
+int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part, const FoldedLn* ln, bool fold_fn) {
     const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
     float* ffn = d->ffn.as<float>();
     unsigned short* t2p = d->t16.as<unsigned short>();

@@ -566,7 +566,7 @@ int gemm2_simple(const unsigned short* A2, int lda, int M, int ea, const unsigne
 int dec_layer_x2(Decoder* d, DecLayerW& w, const std::string& p, bool attn, hipStream_t s);
 struct FoldedLn { const float* g; const float* b; float* y; int out; float oscale; };   // out: 0 fp32 rows, 3 two fp16 planes of y * oscale
 int dec_ffn_x2(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s, float* splitk_part = nullptr,
-               const FoldedLn* ln = nullptr);
+               const FoldedLn* ln = nullptr, bool fold_fn = false);
 int dec_ffn(Decoder* d, const DecLayerW& w, const float* x, float* out, int M, hipStream_t s,
                    const unsigned short* w1_3 = nullptr);
 int decoder_forward_bf16(Decoder* d, const float* memory, int B, int T, int N, int32_t* ids, float* hidden_out,

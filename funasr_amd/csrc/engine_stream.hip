@@ -108,6 +108,11 @@ static int stream_prepare_ln_consts(Stream* st, hipStream_t s) {
     return 0;
 }
 
+// f16x2 step: the decoder FFN's inner LayerNorm (ffn_dim wide) in the second launch of a split-K w_1 -- replaces a launch, for
+// handles small enough that the extra blocks find idle CUs (the rule of short_k)
+static bool stream_short_k(const Stream* st);
+static bool x2_fold_fn(const Stream* st) { return st->ln_folded && stream_short_k(st); }
+
 static int stream_token_rows(const Stream* st, int W, int is_final) {
     const int fires = W + 1 + (is_final ? 1 : 0);
     return fires < st->Nmax ? fires : st->Nmax;
@@ -240,7 +245,8 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         if (d->t16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D) || d->ffn16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * dc.ffn_dim) ||
             d->ctx16.ensure(sizeof(unsigned short) * 2 * (size_t)Mq * D))
             return -2;
-        if (d->splitk.ensure(sizeof(float) * 4 * (size_t)Mq * D)) return -2;
+        // (the decoder FFN's inner norm folded into a split-K w_1 needs ffn_dim-wide slices: small handles only, like short_k)
+        if (d->splitk.ensure(sizeof(float) * 4 * (size_t)Mq * (x2_fold_fn(st) ? dc.ffn_dim : D))) return -2;
         t2p = d->t16.as<unsigned short>(); c2p = d->ctx16.as<unsigned short>();
         if ((rc = launch_split2(enc_out, D, st->mem2.as<unsigned short>(), D, (size_t)Mk * D, Mk, D, pow2f(st->e_mem), s))) return rc;
         mem2 = st->mem2.as<unsigned short>();
@@ -323,7 +329,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         } else {
             const bool fold = x2 && st->ln_folded && dc.ffn_dim % 128 == 0;       // norm2 in the second launch of the split-K w_2
             const FoldedLn n2{w.n2g, w.n2b, t1, 0, 1.f};
-            if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s, d->splitk.as<float>(), fold ? &n2 : nullptr) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
+            if ((rc = x2 ? dec_ffn_x2(d, w, dx, t2, Mq, s, d->splitk.as<float>(), fold ? &n2 : nullptr, x2_fold_fn(st)) : dec_ffn(d, w, dx, t2, Mq, s))) return rc;
             if (!fold && (rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, dc.ln_eps, s))) return rc;
             if ((rc = launch_dec_fsmn_chunk(fa, s))) return rc;
         }
@@ -403,7 +409,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         // decoders3's FFN; after_norm's planes (the vocabulary projection's operand) from the second launch of its split-K w_2
         const bool fold = st->ln_folded && dc.ffn_dim % 128 == 0;
         const FoldedLn an{d->tt.get("after_norm.weight"), d->tt.get("after_norm.bias"), reinterpret_cast<float*>(t2p), 3, pow2f(st->e_an)};
-        if ((rc = dec_ffn_x2(d, d->last, dx, t2, Mq, s, d->splitk.as<float>(), fold ? &an : nullptr))) return rc;
+        if ((rc = dec_ffn_x2(d, d->last, dx, t2, Mq, s, d->splitk.as<float>(), fold ? &an : nullptr, x2_fold_fn(st)))) return rc;
         an_folded = fold;
     } else if ((rc = dec_ffn(d, d->last, dx, t2, Mq, s))) return rc;
     if (dcarry) {                          // (after_norm + the vocabulary projection: above)

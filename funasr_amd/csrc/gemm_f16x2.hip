@@ -722,11 +722,11 @@ int gemm_f16x2_argmax_parts(int M, int N) { (void)M; return 2 * ceil_div(N, 256)
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
     PF_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_f16x2: empty problem");
     if (a.ksplit > 1) {
-        PF_REQUIRE((a.C || a.C2) && a.part && !a.amax_val && a.qkv_D <= 0 && a.a_kstep <= 0 && a.w_kstep <= 0 &&
+        PF_REQUIRE((a.C || a.C2 || a.ln_g) && a.part && !a.amax_val && a.qkv_D <= 0 && a.a_kstep <= 0 && a.w_kstep <= 0 &&
                    a.K % (32 * a.ksplit) == 0 && a.N % 4 == 0 && ((uintptr_t)a.part & 15) == 0,
                    "gemm_f16x2: the split-K form needs K % (32 ksplit) == 0 and a partial buffer [ksplit][M][N]");
         if (a.C2) PF_REQUIRE(!a.ln_g && a.ldc2 % 4 == 0 && a.c_plane % 4 == 0 && ((uintptr_t)a.C2 & 7) == 0, "gemm_f16x2: split-K plane output alignment");
-        else PF_REQUIRE(a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0, "gemm_f16x2: split-K output alignment");
+        else PF_REQUIRE((a.ln_g && !a.C) || (a.ldc % 4 == 0 && ((uintptr_t)a.C & 15) == 0), "gemm_f16x2: split-K output alignment");
         PF_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_plane % 8 == 0 && a.w_plane % 8 == 0 && ((uintptr_t)a.A & 15) == 0 &&
                    ((uintptr_t)a.W & 15) == 0 && (a.K / a.ksplit) % 8 == 0, "gemm_f16x2: operand alignment");
         if (a.bias) PF_REQUIRE(((uintptr_t)a.bias & 15) == 0, "gemm_f16x2: bias alignment");
@@ -738,8 +738,8 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         int rc = launch_tile<2, 2, 0, 0, 0, 0, 2>(p, stream);            // 128 x 128 blocks, two workgroups per CU
         if (rc) return rc;
         if (a.ln_g) {
-            PF_REQUIRE(!a.relu && a.ln_b && a.ln_y, "gemm_f16x2: the split-K + LayerNorm form takes bias and the addends, no relu");
-            return launch_splitk_reduce_ln(a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N, a.bias, a.R1, a.ldr1, a.R2, a.ldr2, a.C, a.ldc, a.ln_g, a.ln_b,
+            PF_REQUIRE(a.ln_b && a.ln_y, "gemm_f16x2: the split-K + LayerNorm form needs beta and an output");
+            return launch_splitk_reduce_ln(a.part, a.ksplit, (size_t)a.M * a.N, a.M, a.N, a.bias, a.relu, a.R1, a.ldr1, a.R2, a.ldr2, a.C, a.ldc, a.ln_g, a.ln_b,
                                            a.ln_eps, a.ln_y, a.ln_ldy, a.ln_out, a.ln_plane, a.ln_oscale, stream);
         }
         const size_t total = (size_t)a.M * (a.N >> 2);

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // One wave per row; OUT as above (0 fp32, 3 two fp16 planes of result * oscale).
 template <int NV, int OUT>
 __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ part, int slices, size_t slice_stride, int M, int D,
-                                                               const float* __restrict__ bias, const float* R1, int ldr1, const float* R2, int ldr2,
-                                                               float* C, int ldc, const float* __restrict__ gamma,
+                                                               const float* __restrict__ bias, int relu, const float* R1, int ldr1, const float* R2,
+                                                               int ldr2, float* C, int ldc, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float* __restrict__ y, int ldy,
                                                                size_t plane, float oscale) {
     const int lane = threadIdx.x & 63;
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __re
                 const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c);
                 t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
             }
+            if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
             if (R1) {
                 const float4 r = *reinterpret_cast<const float4*>(R1 + (size_t)row * ldr1 + 4 * c);
                 t.x = t.x + r.x; t.y = t.y + r.y; t.z = t.z + r.z; t.w = t.w + r.w;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __re
                 const float4 r = *reinterpret_cast<const float4*>(R2 + (size_t)row * ldr2 + 4 * c);
                 t.x = r.x + t.x; t.y = r.y + t.y; t.z = r.z + t.z; t.w = r.w + t.w;
             }
-            *reinterpret_cast<float4*>(C + (size_t)row * ldc + 4 * c) = t;
+            if (C) *reinterpret_cast<float4*>(C + (size_t)row * ldc + 4 * c) = t;
             v[j] = t;
             s += ln_sum4(t);
         } else {
@@ -388,19 +389,24 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     return 0;
 }
 
-int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, const float* R1, int ldr1,
-                            const float* R2, int ldr2, float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy, int out_mode,
-                            size_t plane, float oscale, hipStream_t stream) {
-    PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 512 && slices >= 1 && part && C && y && gamma && beta, "splitk_reduce_ln: D % 4, D <= 512");
-    PF_REQUIRE(ldc % 4 == 0 && ldy % 4 == 0 && (!R2 || ldr2 % 4 == 0) && (!R1 || (ldr1 % 4 == 0 && ((uintptr_t)R1 & 15) == 0)) &&
+int launch_splitk_reduce_ln(const float* part, int slices, size_t slice_stride, int M, int D, const float* bias, int relu, const float* R1, int ldr1,
+                            const float* R2, int ldr2, float* C, int ldc, const float* gamma, const float* beta, float eps, float* y, int ldy,
+                            int out_mode, size_t plane, float oscale, hipStream_t stream) {
+    PF_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048 && slices >= 1 && part && y && gamma && beta, "splitk_reduce_ln: D % 4, D <= 2048");
+    PF_REQUIRE((!C || ldc % 4 == 0) && ldy % 4 == 0 && (!R2 || ldr2 % 4 == 0) && (!R1 || (ldr1 % 4 == 0 && ((uintptr_t)R1 & 15) == 0)) &&
                    slice_stride % 4 == 0 && (out_mode == 0 || out_mode == 3),
                "splitk_reduce_ln: strides % 4; fp32 or two-plane output");
     PF_REQUIRE(((uintptr_t)part & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
                (!R2 || ((uintptr_t)R2 & 15) == 0), "splitk_reduce_ln: operands must be 16-B aligned");
     dim3 grid(ceil_div(M, 4)), block(256);
-    // (NV = 2 like launch_layernorm picks for D <= 512: the same lane-to-chunk map, hence the same bits)
-    if (out_mode == 3) hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 3>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R1, ldr1, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
-    else hipLaunchKernelGGL((splitk_reduce_ln_kernel<2, 0>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, R1, ldr1, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale);
+    // (NV as launch_layernorm picks it -- 2 up to 512 columns, 8 above 768: the same lane-to-chunk map, hence the same bits)
+#define PF_RLN(NV_, OUT_) hipLaunchKernelGGL((splitk_reduce_ln_kernel<NV_, OUT_>), grid, block, 0, stream, part, slices, slice_stride, M, D, bias, relu, \
+                                             R1, ldr1, R2, ldr2, C, ldc, gamma, beta, eps, y, ldy, plane, oscale)
+    const int nv = ceil_div(D / 4, 64);
+    PF_REQUIRE(nv <= 2 || nv > 3, "splitk_reduce_ln: widths of 513 .. 768 columns are not instantiated");
+    if (nv <= 2) { if (out_mode == 3) PF_RLN(2, 3); else PF_RLN(2, 0); }
+    else { if (out_mode == 3) PF_RLN(8, 3); else PF_RLN(8, 0); }
+#undef PF_RLN
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
