@@ -316,6 +316,10 @@ struct Gemm2Args {
 // number of arg-max partials per row launch_gemm_f16x2 writes for an N-column problem
 int gemm_f16x2_argmax_parts(int M, int N);
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream);
+// the four-wave 256 x 256 shape (gemm_f16x2_w4.hip; Gemm2Args.tile 7): bitwise the results of the other shapes.
+// abl (measurement only): 0 product, 1 no global stores, 2 no epilogue, 3 no epilogue and no operand DMA
+bool gemm_f16x2_w4_ok(const Gemm2Args& a);
+int launch_gemm_f16x2_w4(const Gemm2Args& a, int abl, hipStream_t stream);
 // Full-row form for N == 512 (gemm_f16x2_row.hip): one workgroup per 128 complete rows, epilogue
 //   v = relu?(A W^T * oscale + bias);  v = v + R1;  v = R2 + v;  C = v (fp32, optional);
 //   ln_g != nullptr: y = LayerNorm(v; ln_g, ln_b, ln_eps) -> two fp16 planes of y * yscale at Y2, or fp32 at Yf

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,11 +44,23 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        // PF_RCCL_LIB (environment) names the one library to try instead of the default candidates -- a site with its own RCCL
+        // build, and the CPU test of the no-RCCL path (tests/test_abi.py)
+        const char* forced = getenv("PF_RCCL_LIB");
+        std::string why;
+        auto attempt = [&](const char* name) {
             r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.so) break;
-        }
-        if (!r.so) { r.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+            if (!r.so) {
+                const char* e = dlerror();                      // ONE call: dlerror() clears the state it returns
+                why += std::string(why.empty() ? "" : "; ") + (e ? e : "dlopen failed");
+            }
+            return r.so != nullptr;
+        };
+        if (forced && *forced) attempt(forced);
+        else
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if (attempt(name)) break;
+        if (!r.so) { r.err = "RCCL not found: " + why; return; }
         auto sym = [&](const char* n) { void* p = dlsym(r.so, n); if (!p && r.err.empty()) r.err = std::string("RCCL lacks ") + n; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
@@ -136,6 +149,13 @@ int pf_dp_broadcast_encoder(pf_dp* dh, pf_encoder* h, int32_t root, void* stream
 int pf_dp_broadcast_predictor(pf_dp* dh, pf_predictor* h, int32_t root, void* stream) { return broadcast_handle(dh, pf::HANDLE_PREDICTOR, h, root, stream); }
 int pf_dp_broadcast_decoder(pf_dp* dh, pf_decoder* h, int32_t root, void* stream) { return broadcast_handle(dh, pf::HANDLE_DECODER, h, root, stream); }
 int pf_dp_broadcast_ctc(pf_dp* dh, pf_ctc* h, int32_t root, void* stream) { return broadcast_handle(dh, pf::HANDLE_CTC, h, root, stream); }
+
+int pf_dp_broadcast_raw(pf_dp* dh, void* buf_dev, int64_t bytes, int32_t root, void* stream) {
+    Dp* d = reinterpret_cast<Dp*>(dh);
+    if (!d || !buf_dev || bytes <= 0) return fail("dp: null communicator / buffer or empty broadcast");
+    if (root < 0 || root >= d->world) return fail("dp: root outside the communicator");
+    return nccl_ok(rccl()->Broadcast(buf_dev, buf_dev, (size_t)bytes, /*ncclInt8*/ 0, root, d->comm, reinterpret_cast<hipStream_t>(stream)), "ncclBroadcast");
+}
 
 int pf_dp_gather_ids(pf_dp* dh, const int32_t* ids_dev, int64_t count, int32_t* out_dev, int32_t root, void* stream) {
     Dp* d = reinterpret_cast<Dp*>(dh);

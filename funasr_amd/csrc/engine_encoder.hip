@@ -526,7 +526,7 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129, "encoder_set_option: row_bm is 0, 96, 128 or 129"); e->row_bm = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
-    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6, "encoder_set_option: gemm_tile is 0, 1, 2, 5 or 6"); e->gemm_tile = value; return 0; }
+    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6 or 7"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
     set_error("encoder_set_option: unknown key " + k);
     return -1;
