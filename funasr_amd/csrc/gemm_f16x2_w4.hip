@@ -13,11 +13,13 @@
 //   * LDS reads per MFMA drop by a third (16 ds_read_b128 per 48 MFMAs against 12 per 24) and the NEXT step's fragments
 //     are read under the current step's MFMAs, one read per two MFMAs, placed by hand (every instruction of the K loop is
 //     issued from volatile asm in source order: with one wave per SIMD nothing else fills the matrix pipe's shadow);
-//   * a ring of four 32-KB stages (16 deep), three of them in flight: a stage has three steps (~2 us) to land;
+//   * a ring of five 32-KB stages (16 deep; the whole LDS), four of them in flight: a stage has three to four steps
+//     (2-3 us) to land (the first build of this file had four stages and two to three steps: the loop + DMA ran 180 us
+//     against 132 us for the loop alone at M = 32768, w_1);
 //   * EXACT waits: LDS-DMA pieces of one wave were seen to retire out of issue order when their sources differ (DESIGN,
 //     round 4), so counted vmcnt waits are not used. Stage s belongs to wave s % 4, which issues all 32 pieces of it -- one
-//     piece per MFMA gap -- and is the only wave that waits for it (vmcnt(0), two steps later, when it has nothing else
-//     in flight); wave w always fills ring buffer w;
+//     piece per MFMA gap -- and is the only wave that waits for it (vmcnt(0), three steps later, when it has nothing else
+//     in flight);
 //   * one barrier among four waves per step instead of one among eight per stage.
 //
 // LDS (KS = 16 layout of gemm_f16x2.hip): a stage = [A hi | A lo | W hi | W lo] x 256 rows x 32 B, moved by 1-KB pieces of
@@ -34,8 +36,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int W4_PLANE_B = 256 * 32;              // one plane of a stage: 256 rows x 32 B
 constexpr int W4_STAGE_B = 4 * W4_PLANE_B;        // 32 KB
-constexpr int W4_RING = 4;
-constexpr int W4_LDS_B = W4_RING * W4_STAGE_B;    // 128 KB
+constexpr int W4_RING = 5;
+constexpr int W4_LDS_B = W4_RING * W4_STAGE_B;    // 160 KB: the whole LDS of a CU
 static_assert(4 * 32 * (4 * 32 + 4) * 4 <= W4_LDS_B, "epilogue slabs alias the ring");
 
 struct W4Frags { f16x8 al[4], ah[4], bh[4], bl[4]; };      // A lo / hi tiles (rows), W hi / lo tiles (columns)
@@ -106,6 +108,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
             int col = n0 + 32 * j + prow;
             col = col < p.N ? col : p.N - 1;
             vw[j] = (unsigned)col * (unsigned)p.ldw * 2u + chunkb;
+            if constexpr (NODMA == 2) {
+                // TIMING ONLY (wrong results): every piece reads ONE contiguous KB, the access pattern a K-blocked operand layout
+                // [K / 16][rows][16] would give -- same bytes, same L2 footprint per stage, 8 whole lines per piece instead of 32 quarter lines
+                int r0 = m0 + 32 * j; r0 = r0 < p.M - 40 ? r0 : (p.M > 40 ? p.M - 40 : 0);
+                int c0 = n0 + 32 * j; c0 = c0 < p.N - 40 ? c0 : (p.N > 40 ? p.N - 40 : 0);
+                va[j] = (unsigned)r0 * (unsigned)p.lda * 2u + (unsigned)lane * 16u;
+                vw[j] = (unsigned)c0 * (unsigned)p.ldw * 2u + (unsigned)lane * 16u;
+            }
         }
     }
     const char* const a_hi = reinterpret_cast<const char*>(p.A);
@@ -116,8 +126,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
     // piece I (0..31) of stage `kt` -> ring buffer at byte address `buf`
     auto piece = [&](auto I, int kt, unsigned buf, int own) {
         constexpr int i = decltype(I)::value;
-        if constexpr (NODMA) return;
-        const size_t ko = (size_t)kt * 32;
+        if constexpr (NODMA == 1) return;
+        const size_t ko = (size_t)kt * (NODMA == 2 ? 1024 : 32);
         if constexpr (i < 8) w4_piece<i * 1024>(a_hi + ko, va[i & 7], buf, own);
         else if constexpr (i < 16) w4_piece<i * 1024>(a_lo + ko, va[i & 7], buf, own);
         else if constexpr (i < 24) w4_piece<i * 1024>(w_hi + ko, vw[i & 7], buf, own);
@@ -139,18 +149,23 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
 
     const int nk = p.K / 16;                      // K % 64 == 0 (launcher)
 
-    // ---- prologue: wave w fills buffer w with stage w; stage 0 is published and read; stage 1 is published
+    // ---- prologue: wave w fills buffer w with stage w; stage 0 is published; wave 0 (nothing in flight any more) sends stage 4;
+    //      stage 0 is read; stage 1 is published
     {
         const unsigned buf = lds0 + (unsigned)wave * W4_STAGE_B;
         const int own = __builtin_amdgcn_readfirstlane(wave < nk ? 1 : 0);
         [&]<int... I>(std::integer_sequence<int, I...>) { (piece(std::integral_constant<int, I>{}, wave, buf, own), ...); }(std::make_integer_sequence<int, 32>{});
     }
-    if constexpr (!NODMA) w4_wait_dma_if(wave == 0);
+    if constexpr (NODMA != 1) w4_wait_dma_if(wave == 0);
     __builtin_amdgcn_s_barrier();
+    {
+        const int own = __builtin_amdgcn_readfirstlane((wave == 0 && 4 < nk) ? 1 : 0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (piece(std::integral_constant<int, I>{}, 4, lds0 + 4u * W4_STAGE_B, own), ...); }(std::make_integer_sequence<int, 32>{});
+    }
     W4Frags f0, f1;
     [&]<int... I>(std::integer_sequence<int, I...>) { (frag_read(std::integral_constant<int, I>{}, f0, fa0, fb0), ...); }(std::make_integer_sequence<int, 16>{});
     w4_reads_done(f0);
-    if constexpr (!NODMA) w4_wait_dma_if(wave == 1);
+    if constexpr (NODMA != 1) w4_wait_dma_if(wave == 1);
     __builtin_amdgcn_s_barrier();
 
     floatx16 acc[4][4];
@@ -162,14 +177,18 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     w4_settle(acc);
 
-    // ---- one 16-deep step. C = kt % 4 (compile time): stage kt is in `x`, stage kt + 1 (ring buffer (C + 1) % 4) is read
-    //      into `y` under the MFMAs, one read per two MFMAs; wave C also issues stage kt + 4 into ring buffer C, one piece per gap
+    // ---- one 16-deep step. C = kt % 4 (compile time): stage kt is in `x`; stage kt + 1 (ring buffer `rb` = (kt + 1) % 5) is read
+    //      into `y` under the MFMAs, one read per two MFMAs; wave (C + 1) % 4 -- the owner of stage kt + 5, which waited for its
+    //      previous stage at the end of the last step -- issues that stage into the buffer stage kt just left (`ib` = kt % 5),
+    //      one piece per MFMA gap; at the end the owner of stage kt + 2 waits for it (the only thing it has in flight) and the
+    //      barrier publishes it. Four stages in flight: a stage has three to four steps to land.
+    int ib = 0, rb = 1;                            // kt % 5, (kt + 1) % 5
     auto step = [&](auto Cc, int kt, W4Frags& x, W4Frags& y) {
         constexpr int C = decltype(Cc)::value;
-        const unsigned nb = (unsigned)(((C + 1) & 3) * W4_STAGE_B);
+        const unsigned nb = (unsigned)rb * W4_STAGE_B;
         const unsigned fa = fa0 + nb, fb = fb0 + nb;
-        const unsigned buf = lds0 + (unsigned)(C * W4_STAGE_B);
-        const int own = __builtin_amdgcn_readfirstlane((wave == C && kt + 4 < nk) ? 1 : 0);
+        const unsigned buf = lds0 + (unsigned)ib * W4_STAGE_B;
+        const int own = __builtin_amdgcn_readfirstlane((wave == ((C + 1) & 3) && kt + 5 < nk) ? 1 : 0);
         [&]<int... G>(std::integer_sequence<int, G...>) {
             ([&] {
                 constexpr int g = G, P = g >> 4, t = g & 15, i = t >> 2, j = t & 3;
@@ -178,12 +197,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
                 else if constexpr (P == 1) w4_mfma(acc[i][j], x.ah[i], x.bl[j]);
                 else w4_mfma(acc[i][j], x.ah[i], x.bh[j]);
                 if constexpr ((g & 1) == 0 && g < 32) frag_read(std::integral_constant<int, (g >> 1)>{}, y, fa, fb);
-                if constexpr (g >= 15 && g < 47) piece(std::integral_constant<int, g - 15>{}, kt + 4, buf, own);
+                if constexpr (g < 32) piece(std::integral_constant<int, g>{}, kt + 5, buf, own);
             }(), ...);
         }(std::make_integer_sequence<int, 48>{});
         w4_reads_done(y);
-        if constexpr (!NODMA) w4_wait_dma_if(wave == ((C + 2) & 3));      // stage kt + 2: the only one this wave has in flight
+        if constexpr (NODMA != 1) w4_wait_dma_if(wave == ((C + 2) & 3));      // stage kt + 2: the only one this wave has in flight
         __builtin_amdgcn_s_barrier();
+        ib = rb;
+        rb = rb == W4_RING - 1 ? 0 : rb + 1;
     };
     for (int kt0 = 0; kt0 < nk; kt0 += 4) {
         step(std::integral_constant<int, 0>{}, kt0, f0, f1);
@@ -231,6 +252,7 @@ int launch_gemm_f16x2_w4(const Gemm2Args& a, int abl, hipStream_t stream) {
     if (abl == 1) return launch_w4<0, 0, 1>(a, stream);
     if (abl == 2) return launch_w4<0, 0, 2>(a, stream);
     if (abl == 3) return launch_w4<0, 0, 2, 1>(a, stream);
+    if (abl == 4) return launch_w4<0, 0, 2, 2>(a, stream);     // no epilogue, contiguous-KB DMA pattern (timing only)
     switch (mode) {
         case 0: return launch_w4<0, 0>(a, stream);
         case 1: return launch_w4<1, 0>(a, stream);
