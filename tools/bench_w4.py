@@ -78,7 +78,7 @@ def timing():
             a2, w2, b = operands(N, K, data=data)
             row = {"shape": name, "data": data, "M": M}
             for label, tile in (("t2_full", 2), ("t2_nostore", 2 + 16), ("t2_noepi", 2 + 32), ("t2_loop", 2 + 48),
-                                ("t7_full", 7), ("t7_nostore", 0x17), ("t7_noepi", 0x27), ("t7_loop", 0x37), ("t7_noepi_contigdma", 0x47)):
+                                ("t7_full", 7), ("t7_nostore", 0x17), ("t7_noepi", 0x27), ("t7_loop", 0x37), ("t7_noepi_nowait", 0x47), ("t7_noepi_plainloads", 0x57), ("t7_noepi_salu_only", 0x67)):
                 row[label] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20)[1]), 1)
             if name == "w1":
                 for label, tile in (("t2_planes", 2), ("t7_planes", 7)):
