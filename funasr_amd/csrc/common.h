@@ -320,6 +320,9 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream);
 // abl (measurement only): 0 product, 1 no global stores, 2 no epilogue, 3 no epilogue and no operand DMA
 bool gemm_f16x2_w4_ok(const Gemm2Args& a);
 int launch_gemm_f16x2_w4(const Gemm2Args& a, int abl, hipStream_t stream);
+struct GemmRowArgs;
+bool gemm_f16x2_w4_row_ok(const GemmRowArgs& a);
+int launch_gemm_f16x2_w4_row(const GemmRowArgs& a, hipStream_t stream);
 // Full-row form for N == 512 (gemm_f16x2_row.hip): one workgroup per 128 complete rows, epilogue
 //   v = relu?(A W^T * oscale + bias);  v = v + R1;  v = R2 + v;  C = v (fp32, optional);
 //   ln_g != nullptr: y = LayerNorm(v; ln_g, ln_b, ln_eps) -> two fp16 planes of y * yscale at Y2, or fp32 at Yf

@@ -296,7 +296,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             return launch_ffn_f16x2(g, s);
         }
         if ((rc = gemm2(xn2, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
-        if (fuse) {
+        if (fuse && encoder_w2_row_form(e, M)) {
             // w_2 + residual -> x, and (when a block follows directly) its norm1(x) -> the planes its QKV projection reads
             const bool ln = next && next->in_dim == D;
             return gemm_row(ffn2, F, w.e_h, w.w2_2, w.ew_2, w.b2, F, nullptr, x, D, ln ? next->n1g : nullptr, ln ? next->n1b : nullptr,
@@ -524,7 +524,8 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     if (k == "ffn_abl") { e->ffn_abl = value; return 0; }
     if (k == "ffn_fused") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: ffn_fused is 0, 1 or 2"); e->ffn_fused = value; return 0; }
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
-    if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129, "encoder_set_option: row_bm is 0, 96, 128 or 129"); e->row_bm = value; return 0; }
+    if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129 || value == 130, "encoder_set_option: row_bm is 0, 96, 128, 129 or 130"); e->row_bm = value; return 0; }
+    if (k == "w2_row") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: w2_row is 0, 1 or 2"); e->w2_row = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
     if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6 or 7"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
@@ -700,6 +701,7 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         e->cur_offs = e->offs_dev.as<int>();
         e->cur_M = (int)M;
         const int total = (int)e->layers.size();
+        const int w2_rows = (int)M;
         bool xn_ready = false;
         for (int l = 0; l < total && !rc; ++l) {
             // the next block's norm1 rides in this block's w_2 epilogue unless another op sits between them (SenseVoice's after_norm)
@@ -707,7 +709,7 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
             const EncLayerW* next = (l + 1 < total && !boundary) ? &e->layers[l + 1] : nullptr;
             rc = l == 0 ? encoder_block(e, e->layers[0], x0, Din, x, B, max_rows, s, nullptr, false, next)
                         : encoder_block(e, e->layers[l], x, D, x, B, max_rows, s, nullptr, xn_ready, next);
-            xn_ready = next != nullptr && next->in_dim == D;
+            xn_ready = next != nullptr && next->in_dim == D && encoder_w2_row_form(e, w2_rows);
             if (!rc && boundary)
                 rc = layernorm(x, D, e->tt.get("after_norm.weight"), e->tt.get("after_norm.bias"), x, D, (int)M, D, D, c.ln_eps, s);
         }
@@ -730,6 +732,7 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         return 0;
     };
     if (nrun == 0) return unpad_copy(x0, Din);
+    const int w2_rows = B * Tp;
     bool xn_ready = false;
     for (int l = 0; l < nrun; ++l) {
         // SANMVadEncoder: `encoders0` and all but the last of `encoders` are causal, the last one takes the VAD corner
@@ -738,7 +741,7 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
         const EncLayerW* next = (l + 1 < nrun && !boundary) ? &e->layers[l + 1] : nullptr;
         if (l == 0) rc = encoder_block(e, e->layers[0], x0, Din, x, B, Tp, s, nullptr, false, next);
         else rc = encoder_block(e, e->layers[l], x, D, x, B, Tp, s, nullptr, xn_ready, next);
-        xn_ready = next != nullptr && next->in_dim == D;
+        xn_ready = next != nullptr && next->in_dim == D && encoder_w2_row_form(e, w2_rows);
         e->cur_mask_mode = 0;
         if (rc) return rc;
         if (c.tp_blocks > 0 && l + 1 == c.n_blocks && (run_blocks < 0 || nrun > c.n_blocks)) {

@@ -365,6 +365,11 @@ struct Encoder {
     int ffn_fused = 0;                  // (off until the exact-wait schedule of gemm_f16x2_ffn.hip beats the pair)
     int ffn_abl = 0;                    // debugging hook: FfnArgs.abl
     int row_bm = 0;                     // GemmRowArgs.block_rows of the full-row GEMMs (0: by the row count)
+    // w_2: 1 = full-row form (residual + the next norm1 in the epilogue), 0 = a 256 x 256 tile GEMM (+ residual) and the next norm1 as
+    // its own launch, 2 (default) = the tile form where its 256-row blocks fill whole rounds of the CUs to >= 85 % (the 128 x 512
+    // row block re-streams the 4-MB W panel for every 128 rows: 1.28 GB of L2 -> LDS per launch at M = 32768 against 1.0 GB; same-call
+    // A/B 55.0 -> 53.8 ms per step, profiles/r05k_ab_w2_row.txt). Every choice gives the same bits (tested).
+    int w2_row = 2;
     DevBuf fs_grp;                      // int32 [2][M / 16]: valid v rows [lo, hi) of the sequence owning each 16-row group
     std::vector<int32_t> h_fs;
     const int* cur_fs = nullptr; int cur_fs_groups = 0;
@@ -384,6 +389,19 @@ static inline float pow2f(int e) { return ldexpf(1.f, e); }
 
 // per-layer streaming context: attention additionally sees the cached K/V ring of this layer and the first
 // `append_rows` K/V rows of the window are appended to it afterwards (attention.py:343-361)
+// the form of the block's w_2 projection (Encoder.w2_row): true = full-row kernel, false = tile GEMM + separate LayerNorm launch
+static inline bool encoder_w2_row_form(const Encoder* e, int M) {
+    if (e->w2_row != 2) return e->w2_row == 1;
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+        return n;
+    }();
+    const int blocks = ceil_div(M, 256) * (e->cfg.d_model / 256), rounds = ceil_div(blocks, n_cu);
+    return !(e->cfg.d_model % 256 == 0 && blocks >= (int)(0.85 * rounds * n_cu));
+}
+
 struct EncChunkCtx {
     float* ring; int cap; const StreamDev* st; int append_rows;
     const int* lens;     // device [B]: every window row is valid in a chunk

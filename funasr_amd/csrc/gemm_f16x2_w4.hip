@@ -4,7 +4,10 @@
 // AGPRs, and TWO 16-deep k-steps' operand fragments (2 x 64 VGPRs) alive at a time. Same call sites as the other shapes
 // (funasr/models/transformer/positionwise_feed_forward.py:14-34, funasr/models/sanm/attention.py:256,306); the same products
 // in the same k order per output element and the shared epilogue (gemm_f16x2_epilogue.h), so results are BITWISE those of
-// every other shape (tested: tests/test_kernels_f16x2_gpu.py, tools/bench_w4.py parity).
+// every other shape (tested: tests/test_kernels_f16x2_gpu.py, tools/bench_w4.py parity). Two wave grids over the same K loop:
+//   2 x 2: the 256 x 256 tile form (gemm_f16x2.hip's epilogue: fp32 / planes / QKV form), Gemm2Args.tile 7;
+//   1 x 4: the 128 x 512 full-row form (gemm_f16x2_row.hip's epilogue: residuals, FSMN memory block, LayerNorm, planes; run once
+//          per 64-row half of the block), GemmRowArgs.block_rows 130.
 //
 // Why another shape (round 5). The eight-wave shapes read ALL fragments of a 32-deep stage right behind the stage's barrier,
 // with both waves of every SIMD waiting for them at the same time: 192 ds_read_b128 (768 LDS cycles) per 3072 cycles of
@@ -27,6 +30,7 @@
 //     contiguous pattern). Uniform issue by all waves is what the exact wait allows only with ONE stage in flight.
 #include "common.h"
 #include "gemm_f16x2_epilogue.h"
+#include "gemm_f16x2_row_epilogue.h"
 
 namespace pf {
 
@@ -34,10 +38,17 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int W4_PLANE_B = 256 * 64;              // one plane of a 32-deep stage: 256 rows x 64 B
-constexpr int W4_STAGE_B = 4 * W4_PLANE_B;        // 64 KB: [A hi | A lo | W hi | W lo]
-constexpr int W4_LDS_B = 2 * W4_STAGE_B;          // 128 KB
-static_assert(4 * 32 * (4 * 32 + 4) * 4 <= W4_LDS_B, "epilogue slabs alias the stages");
+// wave grid GM x GN (GM GN == 4), every wave a 128 x 128 quadrant. A 32-deep stage = [A hi | A lo | W hi | W lo] of 64-B rows
+template <int GM_, int GN_> struct W4Geo {
+    static constexpr int GM = GM_, GN = GN_;
+    static constexpr int BM = GM * 128, BN = GN * 128;
+    static constexpr int A_PLANE_B = BM * 64, W_PLANE_B = BN * 64;
+    static constexpr int STAGE_B = 2 * (A_PLANE_B + W_PLANE_B);      // 64 KB (2 x 2) / 80 KB (1 x 4)
+    static constexpr int NPW = STAGE_B / 1024 / 4;                   // 1-KB pieces per wave and stage: 16 / 20
+    static constexpr int TA = BM / 64, TW = BN / 64;                 // this wave's pieces per A / W plane: 4 / 2 and 4 / 8
+    static constexpr int LDS_B = 2 * STAGE_B;
+    static_assert(GM * GN == 4 && NPW == 2 * (TA + TW), "four waves");
+};
 
 struct W4Frags { f16x8 al[4], ah[4], bh[4], bl[4]; };      // A lo / hi tiles (rows), W hi / lo tiles (columns)
 
@@ -60,114 +71,86 @@ __device__ __forceinline__ void w4_settle(floatx16 (&acc)[4][4]) {
                  : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
                    "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]));
 }
-// one 1-KB LDS-DMA piece: uniform 64-bit base + 32-bit per-lane byte offset, destination lds_buf + LOFF. `own` (uniform) == 0
-// skips it: the branch lives INSIDE the statement, so the K loop stays one basic block for the compiler -- with a C++ branch
-// per step variant the register allocator shuffled and spilled the 256 accumulation registers at every join (1500 dwords of
-// scratch in the first build of this file).
-// TIMING ONLY: the same statement with a plain load into a scratch register (KIND 4) or with no memory instruction at all (KIND 5):
-// what of a piece's cost is the LDS-DMA instruction, what the scalar work around it
-template <int LOFF, int KIND> __device__ __forceinline__ void w4_piece_probe(const char* sbase, unsigned voff, unsigned lds_buf, int own) {
-    uint4 sink;
-    if constexpr (KIND == 4)
-        asm volatile("s_cmp_lg_u32 %5, 0\n\ts_cbranch_scc0 .Lw4_skipp_%=\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_dwordx4 %0, %1, %2\n.Lw4_skipp_%=:"
-                     : "=v"(sink) : "v"(voff), "s"(sbase), "s"(lds_buf), "n"(LOFF), "s"(own) : "memory", "scc");
+// one 1-KB LDS-DMA piece: uniform 64-bit base + 32-bit per-lane byte offset, destination lds_buf + LOFF. No branch, no compare:
+// a piece costs the issuing wave ~17 cycles of scalar work and ~19 of VMEM issue that one MFMA's shadow has to hold
+// (profiles/r05h_w4_piece_cost_probes.jsonl), so the stages that issue nothing are a separate copy of the loop body.
+template <int LOFF, bool NT> __device__ __forceinline__ void w4_piece(const char* sbase, unsigned voff, unsigned lds_buf) {
+    if constexpr (NT)
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds_buf), "n"(LOFF) : "memory", "scc");
     else
-        asm volatile("s_cmp_lg_u32 %4, 0\n\ts_cbranch_scc0 .Lw4_skipp_%=\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n.Lw4_skipp_%=:"
-                     : : "v"(voff), "s"(sbase), "s"(lds_buf), "n"(LOFF), "s"(own) : "memory", "scc");
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_buf), "n"(LOFF) : "memory", "scc");
+    // (m0 is reserved: the compiler keeps nothing in it)
 }
-template <int LOFF> __device__ __forceinline__ void w4_piece(const char* sbase, unsigned voff, unsigned lds_buf, int own) {
-    asm volatile("s_cmp_lg_u32 %4, 0\n\ts_cbranch_scc0 .Lw4_skip_%=\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n.Lw4_skip_%=:"
-                 :
-                 : "v"(voff), "s"(sbase), "s"(lds_buf), "n"(LOFF), "s"(own)
-                 : "memory", "scc");   // (m0 is reserved: the compiler keeps nothing in it)
-}
-// EABL: the shared epilogue's measurement switch (0 product, 1 no global stores, 2 no epilogue); NODMA: no LDS-DMA pieces and
-// no waits for them (the MFMA + fragment-read loop alone: tools/bench_w4.py)
-template <int MODE, int OUT, int EABL, int NODMA, int PSP = 3>
-__global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int nM, int nN) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int L = blockIdx.x;
-    const int xcd = L & 7, j8 = L >> 3;
-    const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
-    if (mblk >= nM) return;
-    const int m0 = mblk * 256, n0 = nblk * 256;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+// The K loop of both forms: acc += A[m0 .., :] W[n0 .., :]^T over p.K (a multiple of 32, >= 64), this wave's quadrant (wr, wc).
+// NODMA (timing only): 1 = no LDS-DMA pieces and no waits for them (the MFMA + fragment-read loop alone)
+template <class G, int NODMA, bool A_NT>
+__device__ __forceinline__ void w4_kloop(const unsigned short* A, int lda, size_t a_plane, const unsigned short* W, int ldw, size_t w_plane,
+                                         int M, int N, int K, int m0, int n0, unsigned char* smem, int wave, int wr, int wc, int lane,
+                                         floatx16 (&acc)[4][4]) {
     const int hh = lane >> 5, idx = lane & 31;
-
-    // ---- DMA sources. A stage is 64 pieces of 1 KB = 16 rows x 64 B of one plane (lane l -> row l / 4, physical chunk l % 4
-    //      <- the logical chunk the read-side swizzle expects there); wave w issues pieces w + 4 i, i = 0..15: plane i / 4,
-    //      rows 16 (w + 4 (i % 4)) ..
-    unsigned va[4], vw[4];
+    // ---- DMA sources. A stage is STAGE_B / 1024 pieces of 16 rows x 64 B of one plane (lane l -> row l / 4, physical chunk l % 4
+    //      <- the logical chunk the read-side swizzle expects there), linear in LDS; wave w issues pieces w + 4 i: the A planes'
+    //      row groups 16 (w + 4 t) .. first, then the W planes'
+    unsigned va[G::TA], vw[G::TW];
     {
         const int prow = lane >> 2;
         const unsigned chunkb = (unsigned)(((lane & 3) ^ ((prow >> 2) & 3)) * 16);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < G::TA; ++t) {
             int row = m0 + 16 * (wave + 4 * t) + prow;
-            row = row < p.M ? row : p.M - 1;
-            va[t] = (unsigned)row * (unsigned)p.lda * 2u + chunkb;
+            row = row < M ? row : M - 1;
+            va[t] = (unsigned)row * (unsigned)lda * 2u + chunkb;
+        }
+#pragma unroll
+        for (int t = 0; t < G::TW; ++t) {
             int col = n0 + 16 * (wave + 4 * t) + prow;
-            col = col < p.N ? col : p.N - 1;
-            vw[t] = (unsigned)col * (unsigned)p.ldw * 2u + chunkb;
+            col = col < N ? col : N - 1;
+            vw[t] = (unsigned)col * (unsigned)ldw * 2u + chunkb;
         }
     }
-    const char* const a_hi = reinterpret_cast<const char*>(p.A);
-    const char* const a_lo = a_hi + p.a_plane * 2;
-    const char* const w_hi = reinterpret_cast<const char*>(p.W);
-    const char* const w_lo = w_hi + p.w_plane * 2;
+    const char* const a_hi = reinterpret_cast<const char*>(A);
+    const char* const a_lo = a_hi + a_plane * 2;
+    const char* const w_hi = reinterpret_cast<const char*>(W);
+    const char* const w_lo = w_hi + w_plane * 2;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const unsigned ldsw = lds0 + (unsigned)wave * 1024;
-    // this wave's piece I (0..15) of stage `js` -> the stage buffer at byte address `buf` (+ wave KB)
-    auto piece = [&](auto I, int js, unsigned buf, int own) {
+    // this wave's piece I (0 .. NPW - 1) of stage `js` -> the stage buffer at byte address `buf` (+ wave KB)
+    auto piece = [&](auto I, int js, unsigned buf) {
         constexpr int i = decltype(I)::value;
         if constexpr (NODMA == 1) return;
         const size_t ko = (size_t)js * 64;
-        constexpr int LOFF = ((i >> 2) * 16 + 4 * (i & 3)) * 1024;
-        if constexpr (NODMA >= 4) {
-            if constexpr ((i >> 2) == 0) w4_piece_probe<LOFF, NODMA>(a_hi + ko, va[i & 3], buf, own);
-            else if constexpr ((i >> 2) == 1) w4_piece_probe<LOFF, NODMA>(a_lo + ko, va[i & 3], buf, own);
-            else if constexpr ((i >> 2) == 2) w4_piece_probe<LOFF, NODMA>(w_hi + ko, vw[i & 3], buf, own);
-            else w4_piece_probe<LOFF, NODMA>(w_lo + ko, vw[i & 3], buf, own);
-        } else if constexpr ((i >> 2) == 0) w4_piece<LOFF>(a_hi + ko, va[i & 3], buf, own);
-        else if constexpr ((i >> 2) == 1) w4_piece<LOFF>(a_lo + ko, va[i & 3], buf, own);
-        else if constexpr ((i >> 2) == 2) w4_piece<LOFF>(w_hi + ko, vw[i & 3], buf, own);
-        else w4_piece<LOFF>(w_lo + ko, vw[i & 3], buf, own);
+        if constexpr (i < G::TA) w4_piece<4096 * i, A_NT>(a_hi + ko, va[i], buf);
+        else if constexpr (i < 2 * G::TA) w4_piece<G::A_PLANE_B + 4096 * (i - G::TA), A_NT>(a_lo + ko, va[i - G::TA], buf);
+        else if constexpr (i < 2 * G::TA + G::TW) w4_piece<2 * G::A_PLANE_B + 4096 * (i - 2 * G::TA), false>(w_hi + ko, vw[i - 2 * G::TA], buf);
+        else w4_piece<2 * G::A_PLANE_B + G::W_PLANE_B + 4096 * (i - 2 * G::TA - G::TW), false>(w_lo + ko, vw[i - 2 * G::TA - G::TW], buf);
     };
 
     // ---- fragment addresses: lane (idx, hh) reads row idx of a 32-row tile, logical chunk 2 st + hh of k-step st
     const unsigned fsw = (unsigned)((idx >> 2) & 3);
     const unsigned fa0 = lds0 + (unsigned)((wr * 128 + idx) * 64);
-    const unsigned fb0 = lds0 + 2 * W4_PLANE_B + (unsigned)((wc * 128 + idx) * 64);
+    const unsigned fb0 = lds0 + 2 * G::A_PLANE_B + (unsigned)((wc * 128 + idx) * 64);
     // read R (0..15) of a k-step: A lo tiles, W hi tiles (the first product's operands), A hi tiles, W lo tiles
     auto frag_read = [&](auto Rr, W4Frags& f, unsigned fa, unsigned fb) {
         constexpr int r = decltype(Rr)::value;
-        if constexpr (r < 4) w4_read<W4_PLANE_B + (r & 3) * 2048>(f.al[r & 3], fa);
+        if constexpr (r < 4) w4_read<G::A_PLANE_B + (r & 3) * 2048>(f.al[r & 3], fa);
         else if constexpr (r < 8) w4_read<(r & 3) * 2048>(f.bh[r & 3], fb);
         else if constexpr (r < 12) w4_read<(r & 3) * 2048>(f.ah[r & 3], fa);
-        else w4_read<W4_PLANE_B + (r & 3) * 2048>(f.bl[r & 3], fb);
+        else w4_read<G::W_PLANE_B + (r & 3) * 2048>(f.bl[r & 3], fb);
     };
     auto coff = [&](int st) { return (unsigned)(((2 * st + hh) ^ fsw) * 16); };
 
-    const int ns = p.K / 32;                      // stages
+    const int ns = K / 32;                        // stages (>= 2)
 
     // ---- prologue: stage 0 lands and is published; its first k-step is read; stage 1 is on its way
-    [&]<int... I>(std::integer_sequence<int, I...>) { (piece(std::integral_constant<int, I>{}, 0, ldsw, 1), ...); }(std::make_integer_sequence<int, 16>{});
+    [&]<int... I>(std::integer_sequence<int, I...>) { (piece(std::integral_constant<int, I>{}, 0, ldsw), ...); }(std::make_integer_sequence<int, G::NPW>{});
     if constexpr (NODMA == 0) glds_wait_all();
     __builtin_amdgcn_s_barrier();
     W4Frags f0, f1;
     [&]<int... I>(std::integer_sequence<int, I...>) { (frag_read(std::integral_constant<int, I>{}, f0, fa0 + coff(0), fb0 + coff(0)), ...); }(std::make_integer_sequence<int, 16>{});
-    {
-        const int own = __builtin_amdgcn_readfirstlane(1 < ns ? 1 : 0);
-        [&]<int... I>(std::integer_sequence<int, I...>) { (piece(std::integral_constant<int, I>{}, 1, ldsw + W4_STAGE_B, own), ...); }(std::make_integer_sequence<int, 16>{});
-    }
+    [&]<int... I>(std::integer_sequence<int, I...>) { (piece(std::integral_constant<int, I>{}, 1, ldsw + G::STAGE_B), ...); }(std::make_integer_sequence<int, G::NPW>{});
     w4_reads_done(f0);
 
-    floatx16 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -177,18 +160,22 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
     w4_settle(acc);
 
     // ---- one 16-deep k-step: 48 MFMAs on `x`; the next k-step's fragments are read into `y` from (fa, fb), one read per two
-    //      MFMAs; ISSUE: this wave's 16 pieces of stage `js` go out, one per three MFMA gaps, if `own`
-    auto kstep = [&](auto Issue, W4Frags& x, W4Frags& y, unsigned fa, unsigned fb, int js, unsigned buf, int own) {
+    //      MFMAs; ISSUE: this wave's pieces of stage `js` go out, spread evenly over the 48 MFMA gaps
+    auto kstep = [&](auto Issue, W4Frags& x, W4Frags& y, unsigned fa, unsigned fb, int js, unsigned buf) {
         constexpr bool ISSUE = decltype(Issue)::value;
-        [&]<int... G>(std::integer_sequence<int, G...>) {
+        [&]<int... Gp>(std::integer_sequence<int, Gp...>) {
             ([&] {
-                constexpr int g = G, P = g >> 4, t = g & 15, i = t >> 2, j = t & 3;
+                constexpr int g = Gp, P = g >> 4, t = g & 15, i = t >> 2, j = t & 3;
                 // the two small products first, hi * hi last -- the order of every other shape
                 if constexpr (P == 0) w4_mfma(acc[i][j], x.al[i], x.bh[j]);
                 else if constexpr (P == 1) w4_mfma(acc[i][j], x.ah[i], x.bl[j]);
                 else w4_mfma(acc[i][j], x.ah[i], x.bh[j]);
                 if constexpr ((g & 1) == 0 && g < 32) frag_read(std::integral_constant<int, (g >> 1)>{}, y, fa, fb);
-                if constexpr (ISSUE && g % PSP == (PSP == 1 ? 0 : 1) && g / PSP < 16) piece(std::integral_constant<int, g / PSP>{}, js, buf, own);
+                // piece q goes behind MFMA (48 q) / NPW + 1: g carries piece q iff that holds for q = ((g - 1) NPW + 47) / 48
+                if constexpr (ISSUE && g >= 1) {
+                    constexpr int q = ((g - 1) * G::NPW + 47) / 48;
+                    if constexpr (q < G::NPW && (48 * q) / G::NPW + 1 == g) piece(std::integral_constant<int, q>{}, js, buf);
+                }
             }(), ...);
         }(std::make_integer_sequence<int, 48>{});
         w4_reads_done(y);
@@ -196,61 +183,135 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
     // stage j (buffer j & 1): first k-step from f0 while its second k-step is read into f1; everything in flight (stage j + 1)
     // lands; the barrier publishes stage j + 1 and frees buffer j & 1 (its last reads have returned); second k-step from f1
     // while stage j + 1's first k-step is read into f0 and stage j + 2 goes into the freed buffer
-    for (int j = 0; j < ns; ++j) {
-        const unsigned cur = (unsigned)(j & 1) * W4_STAGE_B, nxt = W4_STAGE_B - cur;
-        kstep(std::false_type{}, f0, f1, fa0 + cur + coff(1), fb0 + cur + coff(1), 0, 0u, 0);
+    auto stage = [&](auto Issue, int j) {
+        const unsigned cur = (unsigned)(j & 1) * G::STAGE_B, nxt = G::STAGE_B - cur;
+        kstep(std::false_type{}, f0, f1, fa0 + cur + coff(1), fb0 + cur + coff(1), 0, 0u);
         if constexpr (NODMA == 0) glds_wait_all();
         __builtin_amdgcn_s_barrier();
-        const int own = __builtin_amdgcn_readfirstlane(j + 2 < ns ? 1 : 0);
-        kstep(std::true_type{}, f1, f0, fa0 + nxt + coff(0), fb0 + nxt + coff(0), j + 2, ldsw + cur, own);
-    }
+        kstep(Issue, f1, f0, fa0 + nxt + coff(0), fb0 + nxt + coff(0), j + 2, ldsw + cur);
+    };
+    for (int j = 0; j < ns - 2; ++j) stage(std::true_type{}, j);
+    stage(std::false_type{}, ns - 2);
+    stage(std::false_type{}, ns - 1);             // (its second k-step reads one k-step past the end into f0: never multiplied)
     w4_settle(acc);
+}
+
+// EABL: the shared epilogue's measurement switch (0 product, 1 no global stores, 2 no epilogue)
+template <int MODE, int OUT, int EABL, int NODMA>
+__global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int nM, int nN) {
+    typedef W4Geo<2, 2> G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = blockIdx.x;
+    const int xcd = L & 7, j8 = L >> 3;
+    const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
+    if (mblk >= nM) return;
+    const int m0 = mblk * G::BM, n0 = nblk * G::BN;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    floatx16 acc[4][4];
+    w4_kloop<G, NODMA, false>(p.A, p.lda, p.a_plane, p.W, p.ldw, p.w_plane, p.M, p.N, p.K, m0, n0, smem, wave, wr, wc, lane, acc);
     gemm2_epilogue<4, 4, 4, MODE, OUT, EABL>(p, acc, smem, m0, n0, nblk, wave, wr, wc, lane);
 }
 
-template <int MODE, int OUT, int EABL = 0, int NODMA = 0, int PSP = 3>
+// full-row form (N == 512): one workgroup = 128 complete rows, wave w = columns 128 w ..; the row epilogue runs once per 64-row half
+template <int MODE, bool LN, bool A_NT>
+__global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_row_kernel(GemmRowArgs p) {
+    typedef W4Geo<1, 4> G;
+    static_assert(G::LDS_B == RW_LDS_B && G::BM == RW_BM && G::BN == RW_BN, "the row epilogue's LDS plan");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m0 = blockIdx.x * G::BM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    floatx16 acc[4][4];
+    w4_kloop<G, 0, A_NT>(p.A, p.lda, p.a_plane, p.W, p.ldw, p.w_plane, p.M, G::BN, p.K, m0, 0, smem, wave, 0, wave, lane, acc);
+    gemm2_row_epilogue<MODE, LN, 256, 4, 0>(p, acc, smem, m0, tid, wave, 0, wave, lane, true);
+    gemm2_row_epilogue<MODE, LN, 256, 4, 2>(p, acc, smem, m0, tid, wave, 1, wave, lane, false);
+}
+
+template <int MODE, int OUT, int EABL = 0, int NODMA = 0>
 int launch_w4(const Gemm2Args& a, hipStream_t stream) {
+    typedef W4Geo<2, 2> G;
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_w4_kernel<MODE, OUT, EABL, NODMA, PSP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_B));
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_w4_kernel<MODE, OUT, EABL, NODMA>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
         configured = true;
     }
-    const int nM = ceil_div(a.M, 256), nN = ceil_div(a.N, 256);
+    const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
     const int nMpad = (nM + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_f16x2_w4_kernel<MODE, OUT, EABL, NODMA, PSP>), dim3((unsigned)nMpad * nN), dim3(256), W4_LDS_B, stream, a, nM, nN);
+    hipLaunchKernelGGL((gemm_f16x2_w4_kernel<MODE, OUT, EABL, NODMA>), dim3((unsigned)nMpad * nN), dim3(256), G::LDS_B, stream, a, nM, nN);
     PF_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int MODE, bool LN, bool A_NT>
+int launch_w4_row_t(const GemmRowArgs& a, hipStream_t stream) {
+    typedef W4Geo<1, 4> G;
+    static bool configured = false;
+    if (!configured) {
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_w4_row_kernel<MODE, LN, A_NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_f16x2_w4_row_kernel<MODE, LN, A_NT>), dim3((unsigned)ceil_div(a.M, G::BM)), dim3(256), G::LDS_B, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+template <int MODE, bool LN>
+int launch_w4_row_m(const GemmRowArgs& a, hipStream_t stream) {
+    return a.a_nt ? launch_w4_row_t<MODE, LN, true>(a, stream) : launch_w4_row_t<MODE, LN, false>(a, stream);
 }
 
 }  // namespace
 
 bool gemm_f16x2_w4_ok(const Gemm2Args& a) {
     // rows / columns are clamped in the DMA sources and masked in the epilogue like the other shapes; 32-bit per-lane byte offsets
-    return a.K % 32 == 0 && a.N % 256 == 0 && a.kslices <= 1 && a.ksplit <= 1 && !a.amax_val && a.a_kstep <= 0 && a.w_kstep <= 0 &&
+    return a.K % 32 == 0 && a.K >= 64 && a.N % 256 == 0 && a.kslices <= 1 && a.ksplit <= 1 && !a.amax_val && a.a_kstep <= 0 && a.w_kstep <= 0 &&
            (size_t)a.M * (size_t)a.lda * 2 < (1ull << 32) && (size_t)a.N * (size_t)a.ldw * 2 < (1ull << 32);
 }
 
 // abl (measurement only): 0 product, 1 no global stores, 2 no epilogue, 3 no epilogue and no operand DMA (the loop alone)
 int launch_gemm_f16x2_w4(const Gemm2Args& a, int abl, hipStream_t stream) {
-    PF_REQUIRE(gemm_f16x2_w4_ok(a), "gemm_f16x2 (four-wave shape): needs K % 32 == 0, N % 256 == 0 and operands below 4 GB");
+    PF_REQUIRE(gemm_f16x2_w4_ok(a), "gemm_f16x2 (four-wave shape): needs K % 32 == 0, K >= 64, N % 256 == 0 and operands below 4 GB");
     const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
     if (a.qkv_D > 0) return launch_w4<0, 2>(a, stream);
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");
+        if (abl == 1) return launch_w4<0, 1, 1>(a, stream);
         return launch_w4<0, 1>(a, stream);
     }
     if (abl == 1) return launch_w4<0, 0, 1>(a, stream);
     if (abl == 2) return launch_w4<0, 0, 2>(a, stream);
     if (abl == 3) return launch_w4<0, 0, 2, 1>(a, stream);
-    if (abl == 4) return launch_w4<0, 0, 2, 3>(a, stream);        // no epilogue; pieces issued, never waited for (timing only)
-    if (abl == 5) return launch_w4<0, 0, 2, 4>(a, stream);        // no epilogue; plain loads into a scratch register instead of LDS-DMA (timing only)
-    if (abl == 6) return launch_w4<0, 0, 2, 5>(a, stream);        // no epilogue; only the scalar work of a piece (timing only)
     switch (mode) {
         case 0: return launch_w4<0, 0>(a, stream);
         case 1: return launch_w4<1, 0>(a, stream);
         case 2: return launch_w4<2, 0>(a, stream);
         default: return launch_w4<3, 0>(a, stream);
+    }
+}
+
+bool gemm_f16x2_w4_row_ok(const GemmRowArgs& a) {
+    return a.N == 512 && a.K % 32 == 0 && a.K >= 64 && (size_t)a.M * (size_t)a.lda * 2 < (1ull << 32) && (size_t)a.ldw * 1024 < (1ull << 32);
+}
+
+// the four-wave full-row form; the caller (launch_gemm_f16x2_row) has checked the arguments
+int launch_gemm_f16x2_w4_row(const GemmRowArgs& a, hipStream_t stream) {
+    PF_REQUIRE(gemm_f16x2_w4_row_ok(a), "gemm_f16x2_row (four-wave shape): needs N == 512, K % 32 == 0, K >= 64 and operands below 4 GB");
+    const bool ln = a.ln_g != nullptr;
+    if (a.fs_v) return a.R2 ? launch_w4_row_m<6, true>(a, stream) : launch_w4_row_m<4, true>(a, stream);
+    const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
+    switch (mode * 2 + (ln ? 1 : 0)) {
+        case 0: return launch_w4_row_m<0, false>(a, stream);
+        case 1: return launch_w4_row_m<0, true>(a, stream);
+        case 2: return launch_w4_row_m<1, false>(a, stream);
+        case 3: return launch_w4_row_m<1, true>(a, stream);
+        case 4: return launch_w4_row_m<2, false>(a, stream);
+        case 5: return launch_w4_row_m<2, true>(a, stream);
+        case 6: return launch_w4_row_m<3, false>(a, stream);
+        default: return launch_w4_row_m<3, true>(a, stream);
     }
 }
 

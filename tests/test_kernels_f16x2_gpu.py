@@ -86,6 +86,9 @@ def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
             assert torch.equal(pair, narrow), f"128x256 two-workgroups-per-CU shape differs {sorted(kw)}"
             ring = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=6, **kw)
             assert torch.equal(ring, narrow), f"256x256 deep-ring shape differs {sorted(kw)}"
+            if K >= 64:
+                four = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=7, **kw)
+                assert torch.equal(four, narrow), f"four-wave 256x256 shape (gemm_f16x2_w4.hip) differs {sorted(kw)}"
 
 
 @pytest.mark.parametrize("M", [15, 960, 3840])
@@ -126,6 +129,7 @@ def test_gemm_f16x2_plane_output(cuda, M):
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=3), p_w)
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=0), p_w)
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=6), p_w)
+    assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=7), p_w), "four-wave shape"
     assert torch.isfinite(p_w.float()).all()
     val = _planes_value(p_w) * 2.0 ** -eo
     # the split adds <= 2^-22 of the element (+ the subnormal floor 2^-25 in the scaled domain)
@@ -154,7 +158,9 @@ def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
         for key in ("q2", "k2", "v", "vt"):
             assert (out[key] is None and one[key] is None) or torch.equal(out[key], one[key]), f"tile {tile}: {key} differs"
     ring = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=6)
+    four = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=7)
     for key in ("q2", "k2", "v", "vt"):
+        assert (out[key] is None and four[key] is None) or torch.equal(out[key], four[key]), f"four-wave shape: {key} differs"
         assert (out[key] is None and pair[key] is None) or torch.equal(out[key], pair[key]), f"128x256 shape: {key} differs"
         assert (out[key] is None and ring[key] is None) or torch.equal(out[key], ring[key]), f"deep-ring shape: {key} differs"
     ref, mag = _gemm_ref(a2, w2, se, bias)
@@ -237,12 +243,12 @@ def test_row_form_is_bitwise_gemm_then_layernorm(cuda, M, K, r1, r2):
     c_only, none = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se)
     assert none is None and torch.equal(c_only, c_ref)
     # every block height (0: chosen by the row count; 128: the 2 x 4-wave kernel; 96 / 129: the 1 x 8-wave kernel) gives the same bits
-    for br in (0, 128, 96, 129):
+    for br in (0, 128, 96, 129, 130):             # 130: the four-wave 1 x 4 grid (gemm_f16x2_w4.hip)
         c, y = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, ln=(gamma, beta, eps), out_scale_exp=ey,
                                   block_rows=br, a_nt=(br == 96))
         assert torch.equal(c, c_ref) and torch.equal(y, y_ref), f"block_rows {br}"
     if r2 and not r1:
-        for br in (96, 129):
+        for br in (96, 129, 130):
             c, none = ops.gemm_f16x2_row(a2, w2, bias, add2=add2, scale_exp=se, block_rows=br)
             assert none is None and torch.equal(c, c_ref), f"block_rows {br} without LayerNorm"
             nc, yf = ops.gemm_f16x2_row(a2, w2, bias, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False, want_c=False,
@@ -305,7 +311,7 @@ def test_row_form_with_fsmn_in_the_epilogue_is_bitwise_fsmn_then_row(cuda, slots
     nc, yf = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False,
                                      want_c=False)
     assert nc is None and torch.equal(yf, ops.layernorm(c_ref, gamma, beta, eps))
-    for br in (0, 128, 96, 129):
+    for br in (0, 128, 96, 129, 130):
         c, y = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps),
                                        out_scale_exp=ey, block_rows=br)
         assert torch.equal(c, c_ref) and torch.equal(y, y_ref), f"FSMN form, block_rows {br}"
@@ -328,10 +334,17 @@ def test_encoder_schedule_options_are_bitwise_equal(cuda, frames, packing):
     lens = torch.tensor(frames, dtype=torch.int32)
     outs = {}
     # ffn_fused: 0 the w_1 -> w_2 pair, 2 the one-launch feed-forward (gemm_f16x2_ffn.hip) whatever the row count, 1 by the row count
+    # (the test model's few rows always take w_2's full-row form: w2_row = 2 is the default choice by row count)
     for fuse_row, fsmn_fused, row_bm, ffn_fused in ((0, 0, 0, 0), (1, 0, 128, 0), (1, 1, 128, 0), (1, 1, 96, 0), (1, 0, 96, 0), (1, 1, 129, 0),
-                                                    (1, 1, 0, 0), (1, 1, 0, 2), (1, 0, 128, 2), (1, 1, 0, 1)):
+                                                    (1, 1, 0, 0), (1, 1, 0, 2), (1, 0, 128, 2), (1, 1, 0, 1), (1, 1, 130, 0), (1, 0, 130, 0)):
         enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused).set_option("row_bm", row_bm).set_option("ffn_fused", ffn_fused)
         outs[(fuse_row, fsmn_fused, row_bm, ffn_fused)] = enc(feats, lens)[0].clone()
+    # w_2 as a tile GEMM + its own LayerNorm launch (w2_row 0) against the full-row form (1), and the four-wave GEMM shape (gemm_tile 7)
+    enc.set_option("fuse_row", 1).set_option("fsmn_fused", 1).set_option("row_bm", 0).set_option("ffn_fused", 0)
+    for w2_row, gemm_tile in ((0, 0), (1, 0), (0, 7), (1, 7), (2, 7)):
+        enc.set_option("w2_row", w2_row).set_option("gemm_tile", gemm_tile)
+        outs[("w2_row", w2_row, "gemm_tile", gemm_tile)] = enc(feats, lens)[0].clone()
+    enc.set_option("w2_row", 2).set_option("gemm_tile", 0)
     base = outs[(0, 0, 0, 0)]
     assert torch.isfinite(base).all() and base.abs().max().item() > 0.1
     for key, out in outs.items():
@@ -591,11 +604,12 @@ def test_optional_kernel_schedules_are_bitwise_inside_the_full_depth_encoder(cud
     feats = (torch.randn(64, 500, 560, generator=g) * 0.8).to(cuda)
     lens = torch.full((64,), 500, dtype=torch.int32)
     def run(**opts):
-        for k, v in {**dict(ffn_fused=0, gemm_tile=0), **opts}.items():
+        for k, v in {**dict(ffn_fused=0, gemm_tile=0, w2_row=2, row_bm=0), **opts}.items():
             model.encoder.set_option(k, v)
         return model.encode(feats, lens, all_rows=True)[0].clone()
     base = run()
     assert torch.isfinite(base).all()
-    for opts in (dict(ffn_fused=2), dict(gemm_tile=6), dict(ffn_fused=2), dict(gemm_tile=6)):
+    for opts in (dict(ffn_fused=2), dict(gemm_tile=6), dict(ffn_fused=2), dict(gemm_tile=6), dict(w2_row=1), dict(gemm_tile=7, row_bm=130),
+                 dict(gemm_tile=7, w2_row=1, row_bm=130)):
         assert torch.equal(run(**opts), base), f"{opts} changes the encoder's bits at full depth"
     run()

@@ -78,7 +78,7 @@ def timing():
             a2, w2, b = operands(N, K, data=data)
             row = {"shape": name, "data": data, "M": M}
             for label, tile in (("t2_full", 2), ("t2_nostore", 2 + 16), ("t2_noepi", 2 + 32), ("t2_loop", 2 + 48),
-                                ("t7_full", 7), ("t7_nostore", 0x17), ("t7_noepi", 0x27), ("t7_loop", 0x37), ("t7_noepi_nowait", 0x47), ("t7_noepi_plainloads", 0x57), ("t7_noepi_salu_only", 0x67)):
+                                ("t7_full", 7), ("t7_nostore", 0x17), ("t7_noepi", 0x27), ("t7_loop", 0x37), ("t7_loop2", 0x37)):
                 row[label] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20)[1]), 1)
             if name == "w1":
                 for label, tile in (("t2_planes", 2), ("t7_planes", 7)):
@@ -91,6 +91,36 @@ def timing():
             row["exec_TFLOPs_t2_full"] = round(fl / row["t2_full"] / 1e6)
             row["exec_TFLOPs_t7_full"] = round(fl / row["t7_full"] / 1e6)
             row["exec_TFLOPs_t7_loop"] = round(fl / row["t7_loop"] / 1e6)
+            print(json.dumps(row), flush=True)
+
+
+def rows():
+    """the full-row forms (N = 512): block_rows 128 (eight waves 2 x 4), 129 (eight waves 1 x 8) and 130 (four waves 1 x 4): bitwise
+    equality and us per launch at M = 32768 for w_2 (K = 2048, residual + LayerNorm planes) and linear_out (K = 512, FSMN form)"""
+    g = torch.Generator(device=dev).manual_seed(11)
+    gam, bet = torch.rand(512, device=dev, generator=g) + 0.5, torch.randn(512, device=dev, generator=g)
+    for data in ("random", "zeros"):
+        for name, K in (("w2_row", 2048), ("out_row", 512)):
+            a2, w2, b = operands(512, K, data=data)
+            res = torch.randn(M, 512, device=dev, generator=g)
+            row = {"shape": name, "data": data, "M": M}
+            ref = ops.gemm_f16x2_row(a2, w2, b, add2=res, scale_exp=20, ln=(gam, bet, 1e-12), out_scale_exp=8, block_rows=128)
+            for br in (128, 129, 130):
+                c, y = ops.gemm_f16x2_row(a2, w2, b, add2=res, scale_exp=20, ln=(gam, bet, 1e-12), out_scale_exp=8, block_rows=br)
+                row[f"bits_{br}"] = bool(torch.equal(c, ref[0]) and torch.equal(y, ref[1]))
+                row[f"us_{br}"] = round(best(lambda: ops.gemm_f16x2_row(a2, w2, b, add2=res, scale_exp=20, ln=(gam, bet, 1e-12), out_scale_exp=8,
+                                                                        block_rows=br, a_nt=(K == 512), time_iters=20)[2]), 1)
+            if K == 512:
+                v = torch.randn(M, 512, device=dev, generator=g)
+                taps = torch.randn(512, 11, device=dev, generator=g) * 0.3
+                lo = (torch.arange(M // 16, device=dev, dtype=torch.int32) // 32) * 512
+                hi = lo + 500
+                reff = ops.gemm_f16x2_row_fsmn(a2, w2, b, v, taps, lo, hi, add2=res, scale_exp=20, ln=(gam, bet, 1e-12), out_scale_exp=8, block_rows=128)
+                for br in (128, 130):
+                    c, y = ops.gemm_f16x2_row_fsmn(a2, w2, b, v, taps, lo, hi, add2=res, scale_exp=20, ln=(gam, bet, 1e-12), out_scale_exp=8, block_rows=br)
+                    row[f"fsmn_bits_{br}"] = bool(torch.equal(c, reff[0]) and torch.equal(y, reff[1]))
+                    row[f"fsmn_us_{br}"] = round(best(lambda: ops.gemm_f16x2_row_fsmn(a2, w2, b, v, taps, lo, hi, add2=res, scale_exp=20, ln=(gam, bet, 1e-12),
+                                                                                    out_scale_exp=8, block_rows=br, a_nt=True, time_iters=20)[2]), 1)
             print(json.dumps(row), flush=True)
 
 
@@ -148,7 +178,7 @@ if __name__ == "__main__":
     rc = 0
     for w in what:
         print(json.dumps({"section": w}), flush=True)
-        r = {"parity": parity, "time": timing, "peak": peak, "sustained": sustained}[w]()
+        r = {"parity": parity, "time": timing, "peak": peak, "sustained": sustained, "rows": rows}[w]()
         if w == "parity" and not r:
             rc = 1
     sys.exit(rc)
