@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libparaformer_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
+ABI_VERSION = 2            # PF_ABI_VERSION of include/paraformer_hip.h
+
 _lock = threading.Lock()
 _lib = None
 
@@ -202,7 +204,13 @@ SIGNATURES = {
     "pf_dp_broadcast_predictor": (C.c_int, [_vp, _vp, _i32, _vp]),
     "pf_dp_broadcast_decoder": (C.c_int, [_vp, _vp, _i32, _vp]),
     "pf_dp_broadcast_ctc": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "pf_paraformer_create": (_vp, [_vp, _vp, _vp]),
+    "pf_paraformer_destroy": (None, [_vp]),
+    "pf_paraformer_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "pf_paraformer_encoder_out": (_vp, [_vp]),
+    "pf_paraformer_embeds": (_vp, [_vp]),
     "pf_dp_gather_ids": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp]),
+    "pf_dp_broadcast_raw": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     # profiling hooks used by bench.py (not part of the reference boundary)
     "pf_prof_enable": (C.c_int, [C.c_int]),
     "pf_prof_reset": (C.c_int, []),
@@ -239,6 +247,9 @@ def load():
             fn = getattr(lib, name)   # AttributeError = ABI drift between header and library
             fn.restype = res
             fn.argtypes = args
+        if lib.pf_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} reports ABI version {lib.pf_abi_version()}, this package binds version {ABI_VERSION}: "
+                              f"rebuild it (`make -C {CSRC_DIR}`)")
         _lib = lib
         return lib
 

@@ -698,8 +698,8 @@ int pf_stream_step_end(pf_stream* sh, int32_t* ids_host, int32_t* n_tokens_host)
     Stream* st = reinterpret_cast<Stream*>(sh);
     PF_REQUIRE(st && ids_host && n_tokens_host, "stream_step_end: null argument");
     PF_REQUIRE(st->pending, "stream_step_end: no step in flight");
+    PF_HIP_TRY(hipStreamSynchronize(st->stream));            // a failed synchronisation leaves the step pending (the caller may retry / reset)
     st->pending = false;
-    PF_HIP_TRY(hipStreamSynchronize(st->stream));
     const int S = st->S;
     // the step ran stream_token_rows() rows per stream; the caller's layout is [n_streams, max_tokens]
     const int rows = st->pending_rows;

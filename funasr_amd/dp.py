@@ -282,19 +282,25 @@ class DeviceComm:
 
 def broadcast_model_device(model: torch.nn.Module, comm: DeviceComm, src: int = 0) -> int:
     """`broadcast_model` through the C ABI: every HipModule's weights go straight into its handle (DeviceComm.broadcast_module);
-    parameters that live outside the handles (e.g. SenseVoiceSmall.embed, the query-frame table the host gathers from) take the
-    torch.distributed route. Returns the bytes moved into handles."""
-    from .hip_module import HipModule
+    parameters that live outside the handles (e.g. SenseVoiceSmall.embed, the query-frame table the host gathers from) go
+    through the same communicator as one packed raw buffer (pf_dp_broadcast_raw) -- no torch.distributed needed, which is the
+    point of DeviceComm. Returns the bytes moved into handles (each parameter counted once)."""
+    from . import _lib
+    from .hip_module import HipModule, stream_ptr
     moved, inside = 0, set()
     for m in model.modules():
         if isinstance(m, HipModule) and getattr(m, "_prefix", "") in DeviceComm._KIND:
             comm.broadcast_module(m, src)
             for p in m.parameters():
-                inside.add(id(p))
-                moved += p.numel() * 4
+                if id(p) not in inside:                   # nested HipModules share parameters with their parent
+                    inside.add(id(p))
+                    moved += p.numel() * 4
     rest = [p for p in model.parameters() if id(p) not in inside]
-    if rest and dist.is_available() and dist.is_initialized():
-        arena = _collective_device(pack_arena(rest))
-        dist.broadcast(arena, src=src)
+    if rest:
+        arena = pack_arena(rest).to(comm.device)
+        with torch.cuda.device(comm.device):
+            _lib.check(comm._lib.pf_dp_broadcast_raw(comm._h, arena.data_ptr(), arena.numel() * arena.element_size(), int(src), stream_ptr()),
+                       "pf_dp_broadcast_raw")
+            torch.cuda.current_stream().synchronize()
         unpack_arena(arena.to(rest[0].device), rest)
     return moved

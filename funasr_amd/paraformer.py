@@ -17,7 +17,10 @@ import torch
 import torch.nn as nn
 
 from .audio import load_audio_list
-from .hip_module import HostCopyRing
+import ctypes as C
+
+from . import _lib
+from .hip_module import HostCopyRing, host_i32, stream_ptr
 from .register import tables
 from .timestamps import cif_token_spans
 from .tokenizer import sentence_postprocess
@@ -67,6 +70,7 @@ class Paraformer(nn.Module):
         self.ctc_weight = ctc_weight
         self.beam_search = None
         self.nbest = 1
+        self._one_call = True                                # enqueue_features through pf_paraformer_forward where the model is the plain one
         if kwargs.get("precision"):                      # model_conf: {precision: f16x2 | fp32 | bf16x3 | bf16}
             self.set_precision(kwargs["precision"])
 
@@ -117,11 +121,56 @@ class Paraformer(nn.Module):
     def calc_predictor(self, encoder_out, encoder_out_lens):
         return self.predictor(encoder_out, None, None, ignore_id=self.ignore_id, lengths=encoder_out_lens)
 
+    # ---- the one-call route (include/paraformer_hip.h pf_paraformer_forward): the plain offline model -- CifPredictorV2, the
+    #      ParaformerSANMDecoder with its own output layer -- hands the whole chain to the library; subclasses with other predictors /
+    #      decoders and callers that want the intermediate tensors keep the module-by-module chain below (bitwise the same ids)
+    def _one_call_ok(self) -> bool:
+        return (getattr(self, "_one_call", True) and type(self).__name__ in ("Paraformer", "ParaformerHip") and type(self.predictor).__name__ == "CifPredictorV2"
+                and type(self.decoder).__name__ == "ParaformerSANMDecoder" and hasattr(self.encoder, "_apply_settings"))
+
+    def _pipeline(self):
+        lib, he = self.encoder._ensure_handle()
+        _, hp = self.predictor._ensure_handle()
+        _, hd = self.decoder._ensure_handle()
+        key = (int(he or 0), int(hp or 0), int(hd or 0))
+        cur = self.__dict__.get("_pipe")
+        if cur is None or cur[0] != key:
+            if cur is not None:
+                lib.pf_paraformer_destroy(cur[1])
+            h = _lib.check_handle(lib.pf_paraformer_create(he, hp, hd), "pf_paraformer_create")
+            self.__dict__["_pipe"] = cur = (key, h)
+        return lib, cur[1]
+
     def enqueue_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
         """[B, T, 560] features -> everything up to the fused arg-max ENQUEUED on the current HIP stream. The only host
         synchronisation inside is the CIF token count (it sizes the decoder, like the .item() at cif_predictor.py:311).
         `collect()` brings the ids to the host; a serving loop enqueues batch i+1 before collecting batch i, so the
         GPU never waits for the host-side post-processing."""
+        if not return_intermediate and self._one_call_ok():
+            lib, h = self._pipeline()
+            enc_m = self.encoder
+            enc_m.set_row_packing(max(1, int(self.predictor.r_order)))
+            lib_e, he = enc_m._ensure_handle()
+            enc_m._apply_settings(lib_e, he)
+            self.decoder._apply_settings()
+            dev = enc_m._handle_device
+            xs = speech.to(device=dev, dtype=torch.float32).contiguous()
+            B, T, Din = xs.shape
+            if Din != enc_m._input_size:
+                raise ValueError(f"expected feature dim {enc_m._input_size}, got {Din}")
+            lens_c, _ = host_i32(speech_lengths, B)
+            tok_c = (C.c_int32 * B)()
+            ids = torch.empty(B, T + 1, device=dev, dtype=torch.int32)          # a CIF fires at most once per frame (+ the tail)
+            pe = enc_m._pe_table(T, dev)
+            with torch.cuda.device(dev):
+                n = lib.pf_paraformer_forward(h, xs.data_ptr(), lens_c, B, T, pe.data_ptr(), ids.data_ptr(), T + 1, tok_c, None, None, stream_ptr())
+            if n < 0:
+                _lib.check(n, "pf_paraformer_forward")
+            tok = [int(v) for v in tok_c]
+            pending = dict(tok=tok, ids=ids if n >= 1 else None, B=B, keep=(xs, lens_c))
+            if n >= 1:
+                pending["ids_host"] = (ids, self.__dict__.setdefault("_host_ring", HostCopyRing()).start(ids))
+            return pending
         enc, olens = self.encode(speech, speech_lengths, all_rows=return_intermediate)
         embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
         tok = [int(round(v)) for v in token_num.tolist()]           # pre_token_length.round().long(), model.py:614

@@ -94,10 +94,14 @@ class ParaformerSANMDecoder(HipModule):
         return _lib.pf_decoder_config(self.vocab_size if self.output_layer is not None else 0, self.d_model, self.attention_heads, self.linear_units,
                                       self.att_layer_num, self.kernel_size, self.sanm_shfit, 1e-12)
 
-    def _run(self, hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits: bool, want_ids: bool, want_hidden: bool = False):
+    def _apply_settings(self):
         lib, h = self._ensure_handle()
         _lib.check(lib.pf_decoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[self._mode()]),
                    "pf_decoder_set_precision")
+        return lib, h
+
+    def _run(self, hs_pad, hlens, ys_in_pad, ys_in_lens, want_logits: bool, want_ids: bool, want_hidden: bool = False):
+        lib, h = self._apply_settings()
         dev = self._handle_device
         mem = hs_pad.to(device=dev, dtype=torch.float32).contiguous()
         emb = ys_in_pad.to(device=dev, dtype=torch.float32).contiguous()

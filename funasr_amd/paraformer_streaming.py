@@ -180,6 +180,7 @@ class StreamBatch:
                 _lib.check(lib.pf_stream_set_option(self._h, b"gemm_mode", 3), "pf_stream_set_option")
         self.pe_rows = pe_rows
         self.start_idx = 0
+        self._inflight = None
         self.keep = chunk_size[0] + chunk_size[2]
 
     def set_option(self, key: str, value: int):
@@ -191,6 +192,7 @@ class StreamBatch:
     def reset(self):
         _lib.check(self.lib.pf_stream_reset(self._h, None), "pf_stream_reset")
         self.start_idx = 0
+        self._inflight = None                            # (the C side drops a step in flight with the session it belonged to)
 
     def _grow_pe(self, need: int):
         if need <= self.pe_rows:
@@ -230,6 +232,8 @@ class StreamBatch:
         self._inflight = (f, enc, return_enc)            # (the features stay alive until the step has read them)
 
     def step_end(self):
+        if getattr(self, "_inflight", None) is None:
+            raise RuntimeError("step_end(): no step in flight (call step_begin() first; reset() drops a pending step)")
         f, enc, return_enc = self._inflight
         self._inflight = None
         ids = (C.c_int32 * (self.S * self.max_tokens))()

@@ -130,14 +130,18 @@ class _SANMEncoderBase(HipModule):
             self._pe = sinusoidal_position_table(max(T, 512), self._input_size, device=dev)
         return self._pe
 
-    def _run(self, xs_pad: torch.Tensor, ilens, run_blocks: int = -1):
-        lib, h = self._ensure_handle()
+    def _apply_settings(self, lib, h):
+        """precision, row packing and schedule options of this module -> the handle (before every forward through it)"""
         _lib.check(lib.pf_encoder_set_precision(h, {"fp32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}[self._mode()]),
                    "pf_encoder_set_precision")
         pack = getattr(self, "_row_packing", self.ALL_ROWS)
         _lib.check(lib.pf_encoder_set_row_packing(h, -1 if pack is None else int(pack)), "pf_encoder_set_row_packing")
         for key, value in getattr(self, "_options", {}).items():
             _lib.check(lib.pf_encoder_set_option(h, key.encode(), int(value)), "pf_encoder_set_option")
+
+    def _run(self, xs_pad: torch.Tensor, ilens, run_blocks: int = -1):
+        lib, h = self._ensure_handle()
+        self._apply_settings(lib, h)
         dev = self._handle_device
         xs = xs_pad.to(device=dev, dtype=torch.float32).contiguous()
         B, T, Din = xs.shape

@@ -49,7 +49,10 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 1
+/* 2 (round 5): everything added since the first release is covered by one number a dlsym-binding host can test -- pf_dp_*
+ * (incl. pf_dp_broadcast_raw), pf_stream_step_begin / _end, pf_frontend_set_dither / _verify, pf_paraformer_forward, the
+ * pf_k_* measurement entries. A library reporting 1 has none of them. */
+#define PF_ABI_VERSION 2
 
 const char* pf_last_error(void);
 int pf_abi_version(void);
@@ -243,6 +246,29 @@ int pf_decoder_set_precision(pf_decoder* d, int32_t mode);
 int pf_decoder_forward(pf_decoder* d, const float* memory_dev, const int32_t* mem_lens_host,
                        const float* embeds_dev, const int32_t* tok_lens_host, int32_t B, int32_t T, int32_t N,
                        float* logits_dev, int32_t* ids_dev, float* hidden_dev, void* stream);
+/* ------------------------------------------------------------------------------------------------ offline pipeline
+ * The whole offline forward in one call: what Paraformer.inference runs between the frontend and the tokenizer
+ * (funasr/models/paraformer/model.py:286-346, 614-616, 642), at the tensor boundary the reference exports for this path
+ * (funasr/models/paraformer/export_meta.py:44-68: speech f32 [B, T, 560], speech_lengths i32 [B] -> logits, token_num; the
+ * arg-max is fused here, so token ids come back). The object borrows the three module handles (they must outlive it; a
+ * CifPredictorV2 / V3 predictor and a plain ParaformerSANMDecoder) and owns the intermediate buffers; precision, row packing
+ * and schedule options are whatever the module handles are set to. Bitwise the chain pf_encoder_forward -> pf_predictor_alphas
+ * -> pf_predictor_embeds -> pf_decoder_forward. */
+typedef struct pf_paraformer pf_paraformer;
+pf_paraformer* pf_paraformer_create(pf_encoder* e, pf_predictor* p, pf_decoder* d);
+void pf_paraformer_destroy(pf_paraformer* m);
+/* feats_dev [B, T, input_dim], lens_host [B], pe_dev as pf_encoder_forward. Outputs: token_num_host [B] (rounded CIF counts,
+ * written after the call's ONE host synchronisation); ids_dev int32 [B, ids_ld] (may be NULL), row b valid in
+ * [0, token_num[b]); alphas_dev / peaks_dev [B, T + 1] (may be NULL: kept internally). Returns N = the batch's largest token
+ * count (0: nothing fired, ids untouched -- model.py:615-616), or < 0. Everything behind the token count is only ENQUEUED. */
+int pf_paraformer_forward(pf_paraformer* m, const float* feats_dev, const int32_t* lens_host, int32_t B, int32_t T,
+                          const float* pe_dev, int32_t* ids_dev, int32_t ids_ld, int32_t* token_num_host,
+                          float* alphas_dev, float* peaks_dev, void* stream);
+/* the last forward's encoder output [B, T, d_model] / acoustic embeddings [B, N, d_model] (library-owned; valid until the
+ * next forward of this object) */
+const float* pf_paraformer_encoder_out(const pf_paraformer* m);
+const float* pf_paraformer_embeds(const pf_paraformer* m);
+
 /* SeACo attention-score filter (funasr/models/seaco_paraformer/model.py:323-335 over paraformer/decoder.py:485-513
  * `forward_asf6`): blocks 0 .. n_blocks_before - 1 of the (bias) decoder in full, then block n_blocks_before up to its
  * cross-attention probabilities over the T memory rows (the hotword embeddings); scores_dev [T] receives their sum over
@@ -399,6 +425,9 @@ int pf_dp_broadcast_encoder(pf_dp* dp, pf_encoder* e, int32_t root, void* stream
 int pf_dp_broadcast_predictor(pf_dp* dp, pf_predictor* p, int32_t root, void* stream);
 int pf_dp_broadcast_decoder(pf_dp* dp, pf_decoder* d, int32_t root, void* stream);
 int pf_dp_broadcast_ctc(pf_dp* dp, pf_ctc* c, int32_t root, void* stream);
+/* any device buffer (parameters that live outside the module handles): rank `root`'s bytes -> every rank, in place. Enqueued on
+ * `stream`; does not synchronise. */
+int pf_dp_broadcast_raw(pf_dp* dp, void* buf_dev, int64_t bytes, int32_t root, void* stream);
 /* ids_dev: `count` int32 on this rank's device (e.g. [B, 1 + n_pad]: token count, then ids); out_dev (root only):
  * world * count int32, rank r's block at r * count. Enqueued on `stream`; does not synchronise. */
 int pf_dp_gather_ids(pf_dp* dp, const int32_t* ids_dev, int64_t count, int32_t* out_dev, int32_t root, void* stream);

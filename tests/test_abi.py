@@ -41,7 +41,7 @@ def test_ctypes_prototypes_cover_the_header():
 
 def test_load_and_version_and_no_cpu_fallback():
     lib = _lib.load()
-    assert lib.pf_abi_version() == 1
+    assert lib.pf_abi_version() == 2
     if lib.pf_device_count() == 0:
         cfg = _lib.pf_encoder_config(560, 512, 4, 2048, 2, 0, 11, 0, 1e-12)
         h = lib.pf_encoder_create(ctypes.byref(cfg))
@@ -67,7 +67,7 @@ def test_dp_entry_points_exist_and_fail_cleanly_without_a_gpu():
     from funasr_amd import _lib
     lib = _lib.load()
     for name in ("pf_dp_unique_id", "pf_dp_create", "pf_dp_destroy", "pf_dp_world", "pf_dp_rank", "pf_dp_broadcast_encoder",
-                 "pf_dp_broadcast_predictor", "pf_dp_broadcast_decoder", "pf_dp_broadcast_ctc", "pf_dp_gather_ids"):
+                 "pf_dp_broadcast_predictor", "pf_dp_broadcast_decoder", "pf_dp_broadcast_ctc", "pf_dp_gather_ids", "pf_dp_broadcast_raw"):
         assert hasattr(lib, name), name
     assert lib.pf_dp_world(None) == -1 and lib.pf_dp_rank(None) == -1 and lib.pf_dp_destroy(None) == 0
     assert lib.pf_dp_create(None, 128, 1, 0) is None                       # bad arguments -> NULL + message
@@ -75,3 +75,25 @@ def test_dp_entry_points_exist_and_fail_cleanly_without_a_gpu():
     buf = (C.c_char * 128)()
     assert lib.pf_dp_unique_id(buf, 16) < 0                                # short buffer refused
     assert lib.pf_dp_gather_ids(None, None, 4, None, 0, None) != 0
+    assert lib.pf_dp_broadcast_raw(None, None, 4, 0, None) != 0
+
+
+def test_dp_reports_a_missing_rccl_instead_of_crashing():
+    """with no loadable RCCL the first pf_dp_* call must return the 'RCCL not found' error (dlerror() was called twice,
+    the second call returns NULL -> std::string + nullptr). PF_RCCL_LIB names the one library to try; a fresh process because the
+    loader runs once."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C\n"
+            "from funasr_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "buf = (C.c_char * 128)()\n"
+            "rc = lib.pf_dp_unique_id(buf, 128)\n"
+            "assert rc < 0, rc\n"
+            "msg = _lib.last_error()\n"
+            "assert 'RCCL not found' in msg and 'no_such_rccl' in msg, msg\n"
+            "assert lib.pf_dp_create(buf, 128, 1, 0) is None and 'RCCL not found' in _lib.last_error()\n"
+            "print('ok')\n")
+    env = dict(os.environ, PF_RCCL_LIB="/nonexistent/libno_such_rccl.so", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -251,6 +251,61 @@ def test_pipeline_token_ids_equal_reference(cuda, f32_mode):
         assert res["raw_ids"][b] == g["raw_ids"][b, :n].tolist()
 
 
+def test_one_call_forward_is_bitwise_the_module_chain(cuda, f32_mode):
+    """include/paraformer_hip.h pf_paraformer_forward (the reference's export boundary, funasr/models/paraformer/export_meta.py:44-68:
+    speech + speech_lengths -> token ids + token_num) against the module-by-module chain Paraformer.inference runs
+    (funasr/models/paraformer/model.py:286-346, 614-616, 642): token counts, ids, alphas and peaks bit for bit -- through the
+    Python route (`enqueue_features`) and through ctypes directly, ragged lengths, and a batch in which nothing fires."""
+    import ctypes as C
+    from funasr_amd import _lib
+    from funasr_amd.hip_module import host_i32, stream_ptr
+    from funasr_amd.paraformer import Paraformer
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=3, dec_blocks=2, vocab=97)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=5, cif_bias=-0.3), strict=False)
+    model = model.to(cuda).set_precision(f32_mode)
+    g = torch.Generator().manual_seed(8)
+    feats = (torch.randn(5, 77, 560, generator=g) * 0.7).to(cuda)
+    lens = torch.tensor([77, 60, 33, 77, 9], dtype=torch.int32)
+    model._one_call = False
+    chain = model.recognize_features(feats, lens, return_intermediate=False)
+    inter = model.recognize_features(feats, lens, return_intermediate=True)
+    model._one_call = True
+    assert model._one_call_ok()
+    one = model.recognize_features(feats, lens)
+    assert one["token_num"] == chain["token_num"] == inter["token_num"] and max(one["token_num"]) >= 1
+    assert one["raw_ids"] == chain["raw_ids"] and one["ids"] == chain["ids"]
+    # ctypes, with the optional outputs
+    lib, h = model._pipeline()
+    B, T = feats.shape[:2]
+    lens_c, _ = host_i32(lens, B)
+    tok = (C.c_int32 * B)()
+    ids = torch.full((B, T + 1), -7, device=cuda, dtype=torch.int32)
+    alphas = torch.empty(B, T + 1, device=cuda)
+    peaks = torch.empty(B, T + 1, device=cuda)
+    pe = model.encoder._pe_table(T, feats.device)
+    model.encoder.set_row_packing(model.encoder.ALL_ROWS)
+    model.encoder._apply_settings(*model.encoder._ensure_handle())
+    n = lib.pf_paraformer_forward(h, feats.data_ptr(), lens_c, B, T, pe.data_ptr(), ids.data_ptr(), T + 1, tok, alphas.data_ptr(), peaks.data_ptr(), stream_ptr())
+    assert n == max(inter["token_num"]) and list(tok) == inter["token_num"]      # (the same row layout as `inter`: every row)
+    torch.cuda.synchronize()
+    for b, k in enumerate(inter["token_num"]):
+        assert ids[b, :k].cpu().tolist() == inter["raw_ids"][b]
+    assert torch.equal(alphas, inter["alphas"]) and torch.equal(peaks, inter["peaks"])
+    enc_ptr = lib.pf_paraformer_encoder_out(h)
+    assert enc_ptr
+    # nothing fires: zero features of length 1 give alphas far below the threshold -> N = 0, ids untouched (model.py:615-616)
+    model2 = Paraformer.from_config(cfg)
+    model2.load_state_dict(synth.paraformer_state_dict(cfg, seed=5, cif_bias=-9.0), strict=False)
+    model2 = model2.to(cuda).set_precision(f32_mode)
+    none = model2.recognize_features(feats[:2, :4], torch.tensor([4, 3], dtype=torch.int32))
+    assert none["token_num"] == [0, 0] and none["raw_ids"] == [[], []]
+    # too small an id buffer is an error, not an overrun
+    small = torch.empty(B, 1, device=cuda, dtype=torch.int32)
+    rc = lib.pf_paraformer_forward(h, feats.data_ptr(), lens_c, B, T, pe.data_ptr(), small.data_ptr(), 1, tok, None, None, stream_ptr())
+    assert (rc < 0 and "ids_ld" in _lib.last_error()) or max(tok) <= 1
+
+
 def test_pred_timestamp_follows_the_reference_call(cuda):
     """Paraformer.inference(pred_timestamp=True) (paraformer/model.py:668-681): per utterance the reference calls
     ts_prediction_lfr6_standard(pre_peak_index[i], alphas[i], tokens, vad_offset=begin_time, upsample_rate=1) -- cif_peak
