@@ -89,6 +89,8 @@ SIGNATURES = {
     "pf_last_error": (C.c_char_p, []),
     "pf_abi_version": (C.c_int, []),
     "pf_device_count": (C.c_int, []),
+    "pf_set_concurrency_guard": (C.c_int, [_i32]),
+    "pf_concurrency_guard": (C.c_int, []),
     "pf_frontend_create": (_vp, [C.POINTER(pf_frontend_config)]),
     "pf_frontend_destroy": (None, [_vp]),
     "pf_frontend_set_cmvn": (C.c_int, [_vp, _vp, _vp, _i32]),

@@ -677,6 +677,9 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
     const bool x3 = d->precision == 2 && asf_layer < 0 && !cx;
     const bool x2 = d->precision == 3 && asf_layer < 0 && !cx;      // the score filter / hotword branch run on the fp32 kernels
     const int Tp = round_up(T, 16), Mkp = B * Tp;           // f16x2: padded key rows per sequence
+    // profiling scopes count algorithmic work: valid memory rows, valid (token, frame) pairs
+    double mem_rows = 0, tok_mem = 0;
+    for (int b = 0; b < B; ++b) { mem_rows += mem_lens[b]; tok_mem += (double)mem_lens[b] * tok_lens[b]; }
     const unsigned short* mem3 = nullptr;
     const unsigned short* mem2 = nullptr;
     float* dsc = nullptr;
@@ -787,7 +790,7 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
                 g.oscale = pow2f(-w.ew_kv); g.oscale_dev = dsc + 2; g.bias = w.kv_b; g.M = Mkp; g.N = 2 * D; g.K = D;
                 g.qkv_D = D; g.kv_form = 1; g.Kp = k2; g.qk_plane = ((size_t)Mkp + 32) * D; g.VT = vt2; g.ldvt = Mkp + 64;
                 g.vt_plane = (size_t)D * (Mkp + 64); g.k_mul = 1.f; g.v_mul = 1.f; g.kv_mul_dev = lsc;
-                ProfScope ps(PROF_GEMM3, 2.0 * Mkp * 2.0 * D * D, s);
+                ProfScope ps(PROF_GEMM3, 2.0 * mem_rows * 2.0 * D * D, s);
                 if ((rc = launch_gemm_f16x2(g, s))) return rc;
             }
             {
@@ -798,7 +801,7 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
                 aa.klens = d->mem_lens.as<int>(); aa.B = B; aa.H = c.n_heads; aa.Tp = Tp; aa.Tq = N; aa.qoffs = offs_dev;
                 aa.sscale = pow2f(-w.e_q); aa.sscale_dev = lsc + 2; aa.oscale = pow2f(-10);        // ctx planes carry v's scale
                 aa.variant = 3;                                                                   // lazy rescale (attention_f16x2.hip)
-                ProfScope ps(PROF_ATTN, 4.0 * B * (double)N * T * D, s);
+                ProfScope ps(PROF_ATTN, 4.0 * tok_mem * D, s);
                 if ((rc = launch_attention_f16x2(aa, s))) return rc;
             }
             if ((rc = gemm2_simple(d->ctx16.as<unsigned short>(), D, Mq, 0, w.o_2, w.ew_o, w.o_b, x, D, D, D, 0, x, D, s, lsc + 3)))

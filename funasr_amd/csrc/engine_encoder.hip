@@ -95,6 +95,9 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     // EncoderLayerSANM.forward (sanm/encoder.py:72-148), normalize_before, no concat_after
     const pf_encoder_config& c = e->cfg;
     const int M = (e->cur_offs && !cc) ? e->cur_M : B * T, D = c.d_model, F = c.ffn_dim;
+    // profiling scopes count algorithmic work: valid frames, not the rows the padded / packed layouts compute
+    const double Mw = (!cc && e->prof_rows > 0) ? e->prof_rows : (double)M;
+    const double Aw = (!cc && e->prof_sq > 0) ? 4.0 * e->prof_sq * c.d_model : 4.0 * B * (double)T * T * c.d_model;
     float* xn = e->xn.as<float>();
     float* qkv = e->qkv.as<float>();
     float* mem = e->mem.as<float>();
@@ -213,7 +216,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
             g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = N; g.c_plane = (size_t)M * N; g.cscale = pow2f(ec);
             g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = e->gemm_tile;
-            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)N * K, s, C2 ? "enc.w_1 (planes out)" : (K > D ? "enc.w_2" : "enc.linear_out"));
+            ProfScope ps(PROF_GEMM3, 2.0 * Mw * (double)N * K, s, C2 ? "enc.w_1 (planes out)" : (K > D ? "enc.w_2" : "enc.linear_out"));
             return launch_gemm_f16x2(g, s);
         };
         const bool fuse = e->fuse_row && gemm_f16x2_row_applicable(D, D) && gemm_f16x2_row_applicable(D, F);
@@ -229,7 +232,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             g.ln_g = lg; g.ln_b = lb; g.ln_eps = c.ln_eps;
             if (lg) { g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(ey); }
             g.M = M; g.N = D; g.K = K; g.a_nt = e->row_nt >= (K == D ? 1 : 2); g.block_rows = e->row_bm;
-            ProfScope ps(PROF_GEMM3, 2.0 * M * (double)D * K, s, K > D ? "enc.w_2 row (+res +LN)" : "enc.linear_out row (+fsmn +res +LN)");
+            ProfScope ps(PROF_GEMM3, 2.0 * Mw * (double)D * K, s, K > D ? "enc.w_2 row (+res +LN)" : "enc.linear_out row (+fsmn +res +LN)");
             return launch_gemm_f16x2_row(g, s);
         };
         if (!(fuse && xn_ready)) {
@@ -246,7 +249,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             g.qkv_D = D; g.Qp = q2; g.Kp = k2; g.qk_plane = (size_t)(M + 32) * D;
             g.VT = vt2; g.ldvt = ldvt; g.vt_plane = (size_t)D * ldvt;
             g.q_mul = dk_scale * pow2f(w.e_q); g.k_mul = pow2f(w.e_k); g.v_mul = pow2f(w.e_v); g.tile = e->gemm_tile;
-            ProfScope ps(PROF_GEMM3, 2.0 * M * 3.0 * D * w.in_pad, s, "enc.qkv (Q,K,V^T planes out)");
+            ProfScope ps(PROF_GEMM3, 2.0 * Mw * 3.0 * D * w.in_dim, s, "enc.qkv (Q,K,V^T planes out)");
             if ((rc = launch_gemm_f16x2(g, s))) return rc;
         }
         // FSMN memory on the fp32 v projection: inside linear_out's epilogue (gemm_f16x2_row.hip) or as its own launch
@@ -266,7 +269,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             aa.O = ctx2; aa.ldo = D; aa.o_plane = (size_t)M * D; aa.klens = lens; aa.B = B; aa.H = c.n_heads; aa.Tp = T;
             aa.sscale = pow2f(-(w.e_q + w.e_k)); aa.oscale = pow2f(-10);      // ctx planes carry v's exponent
             aa.variant = e->attn_variant;
-            ProfScope ps(PROF_ATTN, 4.0 * B * (double)T * T * D, s, "enc.self_attention");
+            ProfScope ps(PROF_ATTN, Aw, s, "enc.self_attention");
             if ((rc = launch_attention_f16x2(aa, s))) return rc;
         }
         const float* resid2 = (w.in_dim == D) ? x_in : nullptr;
@@ -292,7 +295,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
                 g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(next->e_x1);
             }
             g.M = M; g.D = D; g.F = F; g.abl = e->ffn_abl;
-            ProfScope ps(PROF_GEMM3, 2.0 * M * 2.0 * (double)D * F, s, "enc.ffn fused (w_1 +relu +w_2 +res +LN)");
+            ProfScope ps(PROF_GEMM3, 2.0 * Mw * 2.0 * (double)D * F, s, "enc.ffn fused (w_1 +relu +w_2 +res +LN)");
             return launch_ffn_f16x2(g, s);
         }
         if ((rc = gemm2(xn2, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
@@ -584,6 +587,8 @@ int pf_encoder_forward(pf_encoder* eh, const float* xs, const int32_t* lens_host
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     PF_REQUIRE(e && xs && lens_host && out && B > 0 && T > 0, "encoder_forward: null/empty argument");
     for (int b = 0; b < B; ++b) PF_REQUIRE(lens_host[b] >= 1 && lens_host[b] <= T, "encoder_forward: lens out of range");
+    e->prof_rows = e->prof_sq = 0;
+    for (int b = 0; b < B; ++b) { e->prof_rows += lens_host[b]; e->prof_sq += (double)lens_host[b] * lens_host[b]; }
     int rc;
     if (!e->resolved && (rc = encoder_resolve(e))) return rc;
     const pf_encoder_config& c = e->cfg;

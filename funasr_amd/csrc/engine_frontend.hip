@@ -1,4 +1,5 @@
 // C-ABI layer, frontend family: pf_frontend_* (WavFrontend / WavFrontendOnline, funasr/frontends/wav_frontend.py).
+#include <atomic>
 #include "engine_internal.h"
 
 namespace pf {
@@ -70,6 +71,25 @@ int frontend_default_tables(Frontend* f) {
 
 using namespace pf;
 
+namespace pf {
+// Process-wide fence (round 5): fbank_kernel's cross-check switches itself on for every frontend handle once the process has said
+// that other work may share a CU with the frontend -- pf_set_concurrency_guard(1) (funasr_amd.dp.guard_shared_gpu: ranks sharing a
+// GPU) or an asynchronous streaming step (pf_stream_step_begin: a second stream's kernels can meet the frontend on the chip). The
+// two-stream fault of rounds 3 / 4 has a mitigation (no packed-fp32 VALU in the non-matrix kernels, csrc/Makefile), not a root
+// cause: until a reproducer pins it, the 0.4 % of a step the second evaluation costs is paid wherever the trigger can exist.
+static std::atomic<int> g_concurrency_guard{0};
+void note_concurrent_streams() { g_concurrency_guard.store(1, std::memory_order_relaxed); }
+static int frontend_verify_on(Frontend* f) {
+    if (f->verify) return 1;
+    if (!g_concurrency_guard.load(std::memory_order_relaxed)) return 0;
+    if (!f->faults.p) {
+        if (f->faults.ensure(sizeof(unsigned int) * 68)) return 0;
+        if (hipMemset(f->faults.p, 0, sizeof(unsigned int) * 68) != hipSuccess) return 0;
+    }
+    return 1;
+}
+}  // namespace pf
+
 extern "C" {
 
 // -------------------------------------------------------------------------------------------------- frontend
@@ -116,6 +136,9 @@ int pf_frontend_set_dither(pf_frontend* fh, float dither, uint64_t seed) {
     f->dither = dither; f->dither_seed = seed; f->dither_calls = 0;
     return 0;
 }
+int pf_set_concurrency_guard(int32_t on) { g_concurrency_guard.store(on ? 1 : 0, std::memory_order_relaxed); return 0; }
+int pf_concurrency_guard(void) { return g_concurrency_guard.load(std::memory_order_relaxed); }
+
 int pf_frontend_set_verify(pf_frontend* fh, int32_t on) {
     Frontend* f = reinterpret_cast<Frontend*>(fh);
     PF_REQUIRE(f, "frontend_set_verify: null handle");
@@ -190,7 +213,7 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
-    a.verify = f->verify; a.faults = f->verify ? f->faults.as<unsigned int>() : nullptr;
+    a.verify = frontend_verify_on(f); a.faults = a.verify ? f->faults.as<unsigned int>() : nullptr;
     int rc;
     {
         double bytes = 0;
@@ -243,7 +266,7 @@ int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, 
     a.twiddle = f->twiddle.as<float2>(); a.piece_w = f->piece_w.as<float>(); a.piece_k0 = f->piece_k0.as<int>();
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
-    a.verify = f->verify; a.faults = f->verify ? f->faults.as<unsigned int>() : nullptr;
+    a.verify = frontend_verify_on(f); a.faults = a.verify ? f->faults.as<unsigned int>() : nullptr;
     return launch_fbank(a, 1, nfr, s);
 }
 

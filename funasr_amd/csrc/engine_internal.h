@@ -375,6 +375,9 @@ struct Encoder {
     const int* cur_fs = nullptr; int cur_fs_groups = 0;
     int attn_variant = 3;               // attention_f16x2.hip schedule (3: lazy rescale)
     int row_nt = 1;                     // non-temporal A loads in the full-row GEMMs: 0 none, 1 linear_out (K = 512), 2 linear_out and w_2
+    // work of the profiling scopes (bench.py roofline) in ALGORITHMIC rows: sum of the batch's valid frames and of their squares
+    // (SURVEY 8d counts per valid frame; the padded layout computes Tp = ceil16(T) rows per sequence). 0: use the computed rows.
+    double prof_rows = 0, prof_sq = 0;
     int gemm_tile = 0;                  // Gemm2Args.tile of the block's GEMMs (0: by shape; 5: 128 x 256, two workgroups per CU)
 };
 
@@ -401,6 +404,9 @@ static inline bool encoder_w2_row_form(const Encoder* e, int M) {
     const int blocks = ceil_div(M, 256) * (e->cfg.d_model / 256), rounds = ceil_div(blocks, n_cu);
     return !(e->cfg.d_model % 256 == 0 && blocks >= (int)(0.85 * rounds * n_cu));
 }
+
+// engine_frontend.hip: from now on every frontend handle of the process cross-checks its fbank frames (another stream may share a CU)
+void note_concurrent_streams();
 
 struct EncChunkCtx {
     float* ring; int cap; const StreamDev* st; int append_rows;

@@ -690,6 +690,7 @@ int pf_stream_step_begin(pf_stream* sh, const float* feats, int32_t n_frames, in
         PF_HIP_TRY(hipMemcpyAsync(enc_out, st->enc_out.p, sizeof(float) * (size_t)S * W * D, hipMemcpyDeviceToDevice, s));
     st->start_idx += tail_chunk ? st->keep : n;
     st->pending = true;
+    note_concurrent_streams();                               // an asynchronous step: other handles' kernels may now meet it on the chip
     st->pending_rows = stream_token_rows(st, W, is_final);
     return 0;
 }

@@ -48,11 +48,15 @@ def ensure_ranks(n_gpus: int, argv: Sequence[str] = None) -> int:
 
 
 def guard_shared_gpu(world: int, all_on_one: bool = False) -> bool:
-    """Whether ranks share a GPU (more ranks than GPUs, or the dry run that puts every rank on GPU 0). Round 3 saw the frontend return a
-    sporadically wrong frame in that configuration; round 4 found the cause (packed-fp32 VALU instructions of fbank_kernel next to
-    waves of the 128 x 128 f16x2 GEMM on one CU) and builds the non-matrix kernels without those instructions (csrc/Makefile), so
-    nothing needs switching on here any more. PF_FRONTEND_VERIFY=1 still turns the fbank kernel's cross-check on for a whole job."""
-    return world > 1 and (all_on_one or world > max(1, torch.cuda.device_count()))
+    """Whether ranks share a GPU (more ranks than GPUs, or the dry run that puts every rank on GPU 0). Rounds 3 / 4 saw the frontend
+    return a sporadically wrong 16-lane pass in that configuration; what round 4 found is a MITIGATION (no packed-fp32 VALU
+    instructions in the non-matrix kernels, csrc/Makefile: 0 faults in 97 k calls), not a root cause -- so where the trigger can
+    exist the fbank kernel's cross-check is switched on for the whole process (pf_set_concurrency_guard; 0.4 % of a step)."""
+    shared = world > 1 and (all_on_one or world > max(1, torch.cuda.device_count()))
+    if shared:
+        from . import _lib
+        _lib.load().pf_set_concurrency_guard(1)
+    return shared
 
 
 def shard_indices(lengths: Sequence[int], world: int, rank: int) -> List[int]:

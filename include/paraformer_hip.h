@@ -59,6 +59,12 @@ int pf_abi_version(void);
 /* number of visible HIP devices (0 when there is no GPU); never fails */
 int pf_device_count(void);
 
+/* Process-wide fence: once on, every frontend handle runs fbank_kernel's cross-check (each frame evaluated twice until two runs
+ * agree, pf_frontend_set_verify) whatever its own setting. The library switches it on itself at the first asynchronous streaming
+ * step (pf_stream_step_begin); hosts that put several ranks or streams on one GPU call pf_set_concurrency_guard(1). */
+int pf_set_concurrency_guard(int32_t on);
+int pf_concurrency_guard(void);
+
 /* ------------------------------------------------------------------------------------------------ frontend */
 typedef struct pf_frontend pf_frontend;
 

@@ -15,6 +15,12 @@ ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--gpu-batch", type=int, default=128)
 ap.add_argument("--cpu-batch", type=int, default=16)
 ap.add_argument("--precision", default=None)
+ap.add_argument("--dump", default=None, help="GPU phase only: write alphas / fires / token counts of the clips to this file (torch.save)")
+ap.add_argument("--compare", default=None, help="CPU phase only: read a --dump file (made on a GPU box) and run the oracle on the same clips here")
+ap.add_argument("--oracle-features", action="store_true", help="GPU phase: feed the ORACLE frontend's features (computed on the host) to the GPU "
+                "encoder, so that the comparison isolates the neural path from the fbank FFT's fp32 round-off")
+ap.add_argument("--first", type=int, default=0, help="--compare: first clip of the slice this process takes")
+ap.add_argument("--count", type=int, default=0, help="--compare: clips in the slice (0 = all); slices run as parallel processes")
 args = ap.parse_args()
 
 from funasr_amd import synth
@@ -36,35 +42,51 @@ def host_cores() -> int:
 
 
 torch.set_num_threads(host_cores())
-dev = torch.device("cuda:0")
 cfg = synth.PARAFORMER_LARGE
 sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
-model = Paraformer.from_config(cfg)
-model.load_state_dict(sd, strict=False)
-model = model.to(dev).set_precision(args.precision)
 shift, scale = synth.synthetic_cmvn(560)
 cmvn = torch.stack([shift, scale])
-fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0, device=dev)
+if args.compare:
+    blob = torch.load(args.compare)
+    args.clips, args.seconds = blob["clips"], blob["seconds"]
+    g_alpha, g_fire, g_tok, t_gpu, mode_name = blob["alphas"], blob["fires"], blob["tok"], blob["gpu_seconds"], blob["mode"]
 n = int(args.seconds * 16000)
-clips = [synth.speech_like(n, seed=20000 + i) for i in range(args.clips)]
-
-t0 = time.time()
-g_alpha, g_fire, g_tok = [], [], []
-for b0 in range(0, args.clips, args.gpu_batch):
-    batch = clips[b0: b0 + args.gpu_batch]
-    feats, flens = fe(torch.stack(batch).to(dev), [n] * len(batch))
-    res = model.recognize_features(feats, flens, return_intermediate=True)
-    g_alpha.append(res["alphas"].cpu()); g_fire.append(torch.floor(res["peaks"].cpu()) >= 1); g_tok += res["token_num"]
-g_alpha, g_fire = torch.cat(g_alpha), torch.cat(g_fire)
-t_gpu = time.time() - t0
+lo = args.first if args.compare else 0
+hi = min(args.clips, lo + args.count) if (args.compare and args.count > 0) else args.clips
+clips = {i: synth.speech_like(n, seed=20000 + i) for i in range(lo, hi)}
+if not args.compare:
+    dev = torch.device("cuda:0")
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).set_precision(args.precision)
+    mode_name = model.encoder._mode()
+    fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0, device=dev)
+    t0 = time.time()
+    g_alpha, g_fire, g_tok = [], [], []
+    for b0 in range(0, args.clips, args.gpu_batch):
+        batch = [clips[i] for i in range(b0, min(args.clips, b0 + args.gpu_batch))]
+        if args.oracle_features:
+            feats, flens = O.wav_frontend(batch, cmvn)
+            feats = feats.to(dev)
+        else:
+            feats, flens = fe(torch.stack(batch).to(dev), [n] * len(batch))
+        res = model.recognize_features(feats, flens, return_intermediate=True)
+        g_alpha.append(res["alphas"].cpu()); g_fire.append(torch.floor(res["peaks"].cpu()) >= 1); g_tok += res["token_num"]
+    g_alpha, g_fire = torch.cat(g_alpha), torch.cat(g_fire)
+    t_gpu = time.time() - t0
+    if args.dump:
+        torch.save(dict(clips=args.clips, seconds=args.seconds, alphas=g_alpha, fires=g_fire, tok=g_tok, gpu_seconds=t_gpu,
+                        mode=mode_name + (" on the oracle frontend's features" if args.oracle_features else "")), args.dump)
+        print(json.dumps({"dumped": args.dump, "clips": args.clips, "seconds": args.seconds, "gpu_seconds": round(t_gpu, 2), "mode": mode_name}))
+        sys.exit(0)
 
 t0 = time.time()
 margins, deltas, a_err = [], [], []
 fire_mismatch_clips = token_count_mismatch = at_risk = frames = 0
 worst_ratio = float("inf")
 with torch.no_grad():
-    for b0 in range(0, args.clips, args.cpu_batch):
-        f, fl = O.wav_frontend(clips[b0: b0 + args.cpu_batch], cmvn)
+    for b0 in range(lo, hi, args.cpu_batch):
+        f, fl = O.wav_frontend([clips[i] for i in range(b0, min(hi, b0 + args.cpu_batch))], cmvn)
         enc, olens = O.sanm_encoder(f, fl, sd, cfg["encoder"], "encoder.")
         _, token_num, alphas, peaks = O.cif_predictor(enc, olens, sd, cfg["predictor"], "predictor.")
         for j in range(alphas.shape[0]):
@@ -92,8 +114,8 @@ def hist(x):
 
 
 print(json.dumps({
-    "what": "CIF fire decision margins vs GPU-CPU prefix-sum differences", "clips": args.clips, "clip_seconds": args.seconds,
-    "mode": model.encoder._mode(), "frames_compared": frames, "tokens": int(sum(g_tok)),
+    "what": "CIF fire decision margins vs GPU-CPU prefix-sum differences", "clips": hi - lo, "first_clip": lo, "clip_seconds": args.seconds,
+    "mode": mode_name, "frames_compared": frames, "tokens": int(sum(g_tok[lo:hi])),
     "clips_with_different_fire_indices": fire_mismatch_clips, "clips_with_different_token_count": token_count_mismatch,
     "alpha_max_abs_diff": float(torch.stack(a_err).max()),
     "prefix_sum_abs_diff": {"max": float(deltas.max()), "median": float(deltas.median()), "p99": float(deltas.quantile(0.99))},

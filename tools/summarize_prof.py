@@ -52,7 +52,8 @@ def pmc_table(root, sub, counter):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
-    print(f"# rocprofv3 summary `{tag}`  (python bench.py --steps 3 --warmup 1 --no-cpu-baseline)\n")
+    cmd = " ".join(sys.argv[3:]) or "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-bf16"
+    print(f"# rocprofv3 summary `{tag}`  ({cmd})\n")
     rows = stats_table(root)
     print("## kernel time (rocprofv3 --kernel-trace --stats)\n")
     print("| kernel | calls | total ms | avg us | % |")
@@ -78,12 +79,20 @@ def main():
         print(f"| {k} | {n} | {fr:.3f} | {wr:.3f} |")
         if k in fetch and k in write:
             traffic[k] = dict(launches=n, read_bytes_per_launch=fr * 1e6, write_bytes_per_launch=wr * 1e6)
-    tot_r = sum(fetch[k][0] for k in fetch) * 1024 * 2 / 1e9
-    tot_w = sum(write[k][0] for k in write) * 1024 / 1e9
+    # per-step figure: ONLY this library's kernels (the output-layer calibration outside the clock runs torch / rocBLAS kernels), and
+    # only meaningful when the run held ONE mode (tools/profile.sh passes --no-secondary --no-bf16; r04q mixed five modes and two
+    # other workloads into one quotient). Steps = attention_f16x2 launches / 66 (50 self- + 16 cross-attentions per offline step).
+    foreign = ("at::", "Cijk_", "__amd_rocclr", "rocprim", "hipcub", "elementwise", "void at")
+    own = lambda k: not any(k.startswith(f) or f in k[:24] for f in foreign)
+    tot_r = sum(fetch[k][0] for k in fetch if own(k)) * 1024 * 2 / 1e9
+    tot_w = sum(write[k][0] for k in write if own(k)) * 1024 / 1e9
+    oth = (sum(fetch[k][0] for k in fetch if not own(k)) * 2 + sum(write[k][0] for k in write if not own(k))) * 1024 / 1e9
     n_attn = max((fetch[k][1] for k in fetch if k.startswith("attention_f16x2")), default=0)
-    print(f"\nwhole run: {tot_r:.1f} GB read (corrected) + {tot_w:.1f} GB written over every kernel; the run holds "
-          f"{n_attn} attention_f16x2 launches = {n_attn / 66.0:.2f} steps of 50 self- + 16 cross-attentions "
-          f"=> {(tot_r + tot_w) / max(n_attn / 66.0, 1e-9):.1f} GB of HBM traffic per step")
+    modes = sorted({k.split("<")[0] for k in fetch if k.startswith(("attention_f32", "attention_bf16", "attention_split3", "gemm_split3"))})
+    print(f"\nthis library's kernels: {tot_r:.1f} GB read (corrected) + {tot_w:.1f} GB written (torch / rocBLAS / runtime kernels outside "
+          f"the clock: {oth:.1f} GB more); the run holds {n_attn} attention_f16x2 launches = {n_attn / 66.0:.2f} steps of 50 self- + 16 "
+          f"cross-attentions => {(tot_r + tot_w) / max(n_attn / 66.0, 1e-9):.1f} GB of HBM traffic per step"
+          + (f"  -- NOT a per-step figure of the main mode: kernels of other modes are in this run ({', '.join(modes)})" if modes else ""))
     # matrix-pipe occupancy: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (32 per v_mfma_*_32x32x16);
     # against duration x 1024 SIMDs x the 2.4 GHz peak clock it is the fraction of the dense-MFMA peak the kernel used
     mfma = pmc_table(root, "pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
