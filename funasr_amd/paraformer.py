@@ -10,6 +10,7 @@ projection is fused with the arg-max, and there is exactly one device->host copy
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, List, Optional
 
@@ -125,7 +126,7 @@ class Paraformer(nn.Module):
     #      ParaformerSANMDecoder with its own output layer -- hands the whole chain to the library; subclasses with other predictors /
     #      decoders and callers that want the intermediate tensors keep the module-by-module chain below (bitwise the same ids)
     def _one_call_ok(self) -> bool:
-        return (getattr(self, "_one_call", True) and type(self).__name__ in ("Paraformer", "ParaformerHip") and type(self.predictor).__name__ == "CifPredictorV2"
+        return (getattr(self, "_one_call", True) and os.environ.get("PF_ONE_CALL", "1") != "0" and type(self).__name__ in ("Paraformer", "ParaformerHip") and type(self.predictor).__name__ == "CifPredictorV2"
                 and type(self.decoder).__name__ == "ParaformerSANMDecoder" and hasattr(self.encoder, "_apply_settings"))
 
     def _pipeline(self):
