@@ -205,16 +205,22 @@ __global__ __launch_bounds__(512, 2) void attention_f16x2_kernel(Attn2Args p) {
     }
 
     float s[16];
+    const bool active = qblk * QB + wave * 32 < Tq;          // (wave-uniform)
     if constexpr (PIPE == 0) {
         stage(0);
         for (int kt = 0; kt < ntiles; ++kt) {
             glds_wait_all();
             __syncthreads();                    // tile kt landed; every wave is done with tile kt-1 (the other buffer)
             if (kt + 1 < ntiles) stage(kt + 1);
-            floatx16 sa, sb;
-            PF_QK(kt, sa, sb)
-            PF_SOFTMAX(kt * KT, sa, sb)
-            PF_PV(kt)
+            // a wave whose 32 queries all lie behind the sequence's last query (T = 171 -> 176 rows in a 256-query block: waves 6, 7;
+            // the decoder's ~170 tokens per clip likewise) only stages tiles and keeps the barriers: its matrix-pipe time goes to the
+            // other workgroup of the CU
+            if (active) {
+                floatx16 sa, sb;
+                PF_QK(kt, sa, sb)
+                PF_SOFTMAX(kt * KT, sa, sb)
+                PF_PV(kt)
+            }
         }
     } else {
         floatx16 ca, cb, na, nb;
