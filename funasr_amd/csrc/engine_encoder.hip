@@ -215,7 +215,8 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             g.A = A; g.lda = lda; g.a_plane = (size_t)M * lda; g.W = W; g.ldw = K; g.w_plane = (size_t)N * K;
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2;
             g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = N; g.c_plane = (size_t)M * N; g.cscale = pow2f(ec);
-            g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = e->gemm_tile;
+            g.M = M; g.N = N; g.K = K; g.relu = relu; g.tile = (!C2 && K > D && e->w2_tile) ? e->w2_tile : e->gemm_tile;
+            if ((g.tile & 15) == 7 && !gemm_f16x2_w4_ok(g)) g.tile = 0;     // (shapes the four-wave kernel does not take: by shape)
             ProfScope ps(PROF_GEMM3, 2.0 * Mw * (double)N * K, s, C2 ? "enc.w_1 (planes out)" : (K > D ? "enc.w_2" : "enc.linear_out"));
             return launch_gemm_f16x2(g, s);
         };
@@ -528,6 +529,7 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     if (k == "ffn_fused") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: ffn_fused is 0, 1 or 2"); e->ffn_fused = value; return 0; }
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129 || value == 130, "encoder_set_option: row_bm is 0, 96, 128, 129 or 130"); e->row_bm = value; return 0; }
+    if (k == "w2_tile") { PF_REQUIRE(value == 0 || value == 2 || value == 7, "encoder_set_option: w2_tile is 0, 2 or 7"); e->w2_tile = value; return 0; }
     if (k == "w2_row") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: w2_row is 0, 1 or 2"); e->w2_row = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
     if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6 or 7"); e->gemm_tile = value; return 0; }

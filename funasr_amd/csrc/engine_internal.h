@@ -370,6 +370,10 @@ struct Encoder {
     // row block re-streams the 4-MB W panel for every 128 rows: 1.28 GB of L2 -> LDS per launch at M = 32768 against 1.0 GB; same-call
     // A/B 55.0 -> 53.8 ms per step, profiles/r05k_ab_w2_row.txt). Every choice gives the same bits (tested).
     int w2_row = 2;
+    // Gemm2Args.tile of w_2 in its tile form: 7 (default) = the four-wave shape (gemm_f16x2_w4.hip) for this projection only -- its fp32 +
+    // residual epilogue is where that shape wins (192.8 -> 180.5 us per launch, 53.6 -> 53.1 ms per step, profiles/r05q_ab_w2_tile.txt;
+    // for the plane / QKV forms it ties and its denser matrix code lowers the sustained clock); 0: gemm_tile
+    int w2_tile = 7;
     DevBuf fs_grp;                      // int32 [2][M / 16]: valid v rows [lo, hi) of the sequence owning each 16-row group
     std::vector<int32_t> h_fs;
     const int* cur_fs = nullptr; int cur_fs_groups = 0;

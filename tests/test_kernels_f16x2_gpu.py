@@ -341,10 +341,10 @@ def test_encoder_schedule_options_are_bitwise_equal(cuda, frames, packing):
         outs[(fuse_row, fsmn_fused, row_bm, ffn_fused)] = enc(feats, lens)[0].clone()
     # w_2 as a tile GEMM + its own LayerNorm launch (w2_row 0) against the full-row form (1), and the four-wave GEMM shape (gemm_tile 7)
     enc.set_option("fuse_row", 1).set_option("fsmn_fused", 1).set_option("row_bm", 0).set_option("ffn_fused", 0)
-    for w2_row, gemm_tile in ((0, 0), (1, 0), (0, 7), (1, 7), (2, 7)):
-        enc.set_option("w2_row", w2_row).set_option("gemm_tile", gemm_tile)
-        outs[("w2_row", w2_row, "gemm_tile", gemm_tile)] = enc(feats, lens)[0].clone()
-    enc.set_option("w2_row", 2).set_option("gemm_tile", 0)
+    for w2_row, gemm_tile, w2_tile in ((0, 0, 0), (1, 0, 0), (0, 7, 7), (1, 7, 7), (2, 7, 0), (0, 0, 7), (0, 0, 2)):
+        enc.set_option("w2_row", w2_row).set_option("gemm_tile", gemm_tile).set_option("w2_tile", w2_tile)
+        outs[("w2_row", w2_row, "gemm_tile", gemm_tile, "w2_tile", w2_tile)] = enc(feats, lens)[0].clone()
+    enc.set_option("w2_row", 2).set_option("gemm_tile", 0).set_option("w2_tile", 7)
     base = outs[(0, 0, 0, 0)]
     assert torch.isfinite(base).all() and base.abs().max().item() > 0.1
     for key, out in outs.items():
@@ -604,12 +604,12 @@ def test_optional_kernel_schedules_are_bitwise_inside_the_full_depth_encoder(cud
     feats = (torch.randn(64, 500, 560, generator=g) * 0.8).to(cuda)
     lens = torch.full((64,), 500, dtype=torch.int32)
     def run(**opts):
-        for k, v in {**dict(ffn_fused=0, gemm_tile=0, w2_row=2, row_bm=0), **opts}.items():
+        for k, v in {**dict(ffn_fused=0, gemm_tile=0, w2_row=2, row_bm=0, w2_tile=7), **opts}.items():
             model.encoder.set_option(k, v)
         return model.encode(feats, lens, all_rows=True)[0].clone()
     base = run()
     assert torch.isfinite(base).all()
     for opts in (dict(ffn_fused=2), dict(gemm_tile=6), dict(ffn_fused=2), dict(gemm_tile=6), dict(w2_row=1), dict(gemm_tile=7, row_bm=130),
-                 dict(gemm_tile=7, w2_row=1, row_bm=130)):
+                 dict(gemm_tile=7, w2_row=1, row_bm=130), dict(w2_tile=0)):
         assert torch.equal(run(**opts), base), f"{opts} changes the encoder's bits at full depth"
     run()
