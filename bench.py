@@ -78,11 +78,16 @@ def parse():
                     "f16x2 mode (pf_encoder_set_option), e.g. fuse_row=0, attn_variant=1; results are bitwise / fp32-class equal")
     ap.add_argument("--random-output-layer", action="store_true", help="keep the random-init output layer for the headline run "
                     "(default: the calibrated confident layer, synth.confident_output_layer; arithmetic and cost are identical)")
+    ap.add_argument("--weights-route", default="arena", choices=["arena", "device"], help="N > 1: how rank 0's weights reach the other ranks -- "
+                    "arena: one packed fp32 tensor through torch.distributed (RCCL broadcast), each rank re-uploads into its handles; "
+                    "device: the C ABI's pf_dp_broadcast_* straight into the module handles' HBM (funasr_amd.dp.broadcast_model_device; "
+                    "falls back to the arena if any rank fails). The arena is the default because no multi-GPU box has ever run either "
+                    "route (DESIGN 6) and a first contact that hangs inside a never-exercised communicator would lose the whole line")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cap on host threads for the CPU baseline (0 = all usable)")
     return ap.parse_args()
 
 
-def build_model(cfg, rank, world, device):
+def build_model(cfg, rank, world, device, route="arena"):
     """rank 0 draws the synthetic checkpoint; with world > 1 it is shipped as one packed arena (RCCL broadcast)."""
     from funasr_amd import synth
     from funasr_amd.paraformer import Paraformer
@@ -98,10 +103,26 @@ def build_model(cfg, rank, world, device):
         from funasr_amd import dp
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        arena_bytes = dp.broadcast_model(model, src=0)          # ONE packed fp32 arena over RCCL (~880 MB)
+        done = False
+        if route == "device":
+            import torch.distributed as dist
+            ok = 1
+            try:
+                comm = dp.DeviceComm.from_process_group(device)
+                arena_bytes = dp.broadcast_model_device(model, comm, src=0)     # grouped in-place broadcasts into the handles
+            except Exception as e:                               # noqa: BLE001
+                trace(f"rank {rank}: device route failed ({e!r})")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item())
+            if not done:
+                trace(f"rank {rank}: some rank could not take the device route: every rank falls back to the arena")
+        if not done:
+            arena_bytes = dp.broadcast_model(model, src=0)      # ONE packed fp32 arena over RCCL (~880 MB)
         torch.cuda.synchronize()
         bcast_s = time.perf_counter() - tb
-        trace(f"rank {rank}: weight arena broadcast, {arena_bytes / 1e6:.0f} MB in {bcast_s:.2f} s")
+        trace(f"rank {rank}: weights broadcast ({'C ABI, in place' if done else 'packed arena'}), {arena_bytes / 1e6:.0f} MB in {bcast_s:.2f} s")
     return model, arena_bytes, bcast_s
 
 
@@ -197,7 +218,7 @@ def main():
     lib = _lib.load()
     cfg = synth.PARAFORMER_LARGE
     trace("library loaded, building model")
-    model, arena_bytes, bcast_s = build_model(cfg, rank, world, device)
+    model, arena_bytes, bcast_s = build_model(cfg, rank, world, device, args.weights_route)
     trace("model on device")
     shift, scale = synth.synthetic_cmvn(560)
     frontend = WavFrontend(cmvn=torch.stack([shift, scale]), lfr_m=7, lfr_n=6, dither=0.0, device=device)
