@@ -232,7 +232,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             g.oscale = pow2f(-(ea + ew)); g.bias = bias; g.R1 = R1; g.ldr1 = D; g.R2 = R2; g.ldr2 = ldr2; g.C = x; g.ldc = D;
             g.ln_g = lg; g.ln_b = lb; g.ln_eps = c.ln_eps;
             if (lg) { g.Y2 = xn2; g.ldy2 = D; g.y_plane = (size_t)M * D; g.yscale = pow2f(ey); }
-            g.M = M; g.N = D; g.K = K; g.a_nt = e->row_nt >= (K == D ? 1 : 2); g.block_rows = e->row_bm;
+            g.M = M; g.N = D; g.K = K; g.a_nt = (e->row_nt >= (K == D ? 1 : 2) ? 1 : 0) | (e->row_sched ? 0 : 2); g.block_rows = e->row_bm;
             ProfScope ps(PROF_GEMM3, 2.0 * Mw * (double)D * K, s, K > D ? "enc.w_2 row (+res +LN)" : "enc.linear_out row (+fsmn +res +LN)");
             return launch_gemm_f16x2_row(g, s);
         };
@@ -529,10 +529,11 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     if (k == "ffn_fused") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: ffn_fused is 0, 1 or 2"); e->ffn_fused = value; return 0; }
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129 || value == 130, "encoder_set_option: row_bm is 0, 96, 128, 129 or 130"); e->row_bm = value; return 0; }
-    if (k == "w2_tile") { PF_REQUIRE(value == 0 || value == 2 || value == 7, "encoder_set_option: w2_tile is 0, 2 or 7"); e->w2_tile = value; return 0; }
+    if (k == "row_sched") { PF_REQUIRE(value == 0 || value == 2, "encoder_set_option: row_sched is 0 or 2"); e->row_sched = value; return 0; }
+    if (k == "w2_tile") { PF_REQUIRE(value == 0 || value == 2 || value == 7 || value == 8, "encoder_set_option: w2_tile is 0, 2, 7 or 8"); e->w2_tile = value; return 0; }
     if (k == "w2_row") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: w2_row is 0, 1 or 2"); e->w2_row = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
-    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6 or 7"); e->gemm_tile = value; return 0; }
+    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7 || value == 8, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6, 7 or 8"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
     set_error("encoder_set_option: unknown key " + k);
     return -1;

@@ -369,6 +369,7 @@ struct Encoder {
     // its own launch, 2 (default) = the tile form where its 256-row blocks fill whole rounds of the CUs to >= 85 % (the 128 x 512
     // row block re-streams the 4-MB W panel for every 128 rows: 1.28 GB of L2 -> LDS per launch at M = 32768 against 1.0 GB; same-call
     // A/B 55.0 -> 53.8 ms per step, profiles/r05k_ab_w2_row.txt). Every choice gives the same bits (tested).
+    int row_sched = 0;                  // k-step order of the eight-wave full-row kernel: 0 plain (default since round 5: FSMN form 108 -> 103 us, profiles/r05t), 2 both k-steps' fragments up front
     int w2_row = 2;
     // Gemm2Args.tile of w_2 in its tile form: 7 (default) = the four-wave shape (gemm_f16x2_w4.hip) for this projection only -- its fp32 +
     // residual epilogue is where that shape wins (192.8 -> 180.5 us per launch, 53.6 -> 53.1 ms per step, profiles/r05q_ab_w2_tile.txt;

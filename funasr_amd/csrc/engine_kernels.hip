@@ -194,7 +194,7 @@ int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void
     g.bias = bias; g.R1 = R1; g.ldr1 = ldr1; g.R2 = R2; g.ldr2 = ldr2; g.C = C; g.ldc = ldc;
     g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
     g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K; g.relu = relu;
-    g.a_nt = a_nt & 1; g.block_rows = a_nt >> 8;          // bits 8..: GemmRowArgs.block_rows (0 by row count, 96, 128, 129)
+    g.a_nt = a_nt & 3; g.block_rows = a_nt >> 8;          // bit 1: k-step order (A/B); bits 8..: GemmRowArgs.block_rows (0 by row count, 96, 128, 129, 130)
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
     return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
 }
@@ -232,7 +232,7 @@ int pf_k_gemm_f16x2_row_fsmn(const void* A2, int32_t lda, int64_t a_plane, const
     g.bias = bias; g.fs_v = fs_v; g.ldfv = ldfv; g.fs_w = fs_w; g.fs_lo = fs_lo; g.fs_hi = fs_hi; g.R2 = R2; g.ldr2 = ldr2;
     g.C = C; g.ldc = ldc; g.ln_g = ln_g; g.ln_b = ln_b; g.ln_eps = ln_eps; g.Y2 = reinterpret_cast<unsigned short*>(Y2); g.ldy2 = 512;
     g.y_plane = (size_t)y_plane; g.yscale = yscale; g.Yf = Yf; g.ldyf = 512; g.M = M; g.N = 512; g.K = K;
-    g.a_nt = a_nt & 1; g.block_rows = a_nt >> 8;
+    g.a_nt = a_nt & 3; g.block_rows = a_nt >> 8;
     if (iters <= 0 || !ms_out) return launch_gemm_f16x2_row(g, s);
     return time_launches([&] { return launch_gemm_f16x2_row(g, s); }, iters, ms_out, s);
 }

@@ -67,6 +67,14 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
     if (mblk >= nM) return;
     const int m0 = mblk * BM, n0 = nblk * BN;
+    if constexpr (ABL == 5) {
+        // TIMING EXPERIMENT (round 5): every second group of eight first-round workgroups starts ~half a tile late, so that the two
+        // halves of the chip run out of phase from then on -- how much of the epilogue's store burst (all CUs at once, every matrix
+        // pipe idle) goes away when only half the CUs burst at a time? (the delay itself is pure loss: total = base + delay - gain)
+        if (L < 256 && ((L >> 3) & 1)) {
+            for (int i = 0; i < p.relu; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     if constexpr (OUT == 0 && MODE == 0) {
         // split-K form: slice blockIdx.y multiplies columns [y K, (y + 1) K) of both operands (p.K is the slice length, the row
         // strides are the full ones) into its own [M, N] partial
@@ -467,6 +475,7 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
                 case 1: return launch_tile<2, 4, 0, 0, 1>(a, stream);
                 case 2: return launch_tile<2, 4, 0, 0, 2>(a, stream);
                 case 3: return launch_tile<2, 4, 0, 0, 3>(a, stream);
+                case 5: return launch_tile<2, 4, 0, 0, 5>(a, stream);      // de-phasing experiment: Gemm2Args.relu = delay in s_sleep(127) units
                 default: return launch_tile<2, 4, 0, 0, 4>(a, stream);
             }
         }
@@ -485,7 +494,7 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     const long m_tiles = ceil_div(a.M, 256);
     const long wide_blocks = m_tiles * (a.N / 256), narrow_blocks = m_tiles * ceil_div(a.N, 128);
     const double cost_wide = (double)((wide_blocks + n_cu - 1) / n_cu), cost_narrow = 0.57 * (double)((narrow_blocks + n_cu - 1) / n_cu);
-    const bool wide = a.tile == 2 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
+    const bool wide = a.tile == 2 || a.tile == 8 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
     if constexpr (OUT == 0) {
         // fp32 output: the 128 x 128 four-wave shape (two workgroups per CU, 0.55 of a 256 x 256 block's time per round of
         // 2 n_cu blocks: tools/bench_r03.py `dec`) wins where the larger shapes leave CUs idle -- the decoder's token-side GEMMs
@@ -500,7 +509,13 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
         if (a.tile == 0 && 2 * narrow_blocks <= n_cu) return launch_tile<2, 2, MODE, 1, 0, 0, 2>(a, stream);
     }
     // SCHED 2 on the 256 x 256 shape (both k-steps' fragments requested up front, DMA pieces early): 0-10 % faster there
-    return wide ? launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
+    // The wide shape's schedule. Round 2 chose SCHED 2 (both k-steps' fragments requested before the first MFMA, the DMA pieces
+    // early: "0-10 % faster"); on round 5's tree and boxes the plain order (SCHED 0: a k-step's fragments, its three products with
+    // the pieces between them, then the next k-step's) is 6-15 % FASTER per launch and 1.4 % per step
+    // (profiles/r05s_ab_wide_tile_sched0.txt: w_1 planes 230 -> 211 us, QKV form 185.5 -> 174.5, w_2 212 -> 191; same bits).
+    // tile 8 = SCHED 2 stays reachable for A/B runs.
+    if (wide && a.tile == 8) return launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream);
+    return wide ? launch_tile<2, 4, MODE, OUT, 0, 0>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
 }
 
 }  // namespace
@@ -600,7 +615,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
                    "gemm_f16x2: the arg-max form takes bias only and needs amax_ld >= 2 ceil(N / 256)");
         PF_REQUIRE(a.K % 32 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0,
                    "gemm_f16x2: operand alignment");
-        return launch_tile<2, 4, 0, 3, 0, 2>(a, stream);
+        return launch_tile<2, 4, 0, 3, 0, 0>(a, stream);
     }
     PF_REQUIRE(a.K % 32 == 0, "gemm_f16x2: K must be a multiple of 32 (pad the planes with zeros)");
     PF_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_plane % 8 == 0 && a.w_plane % 8 == 0, "gemm_f16x2: operand strides % 8");
@@ -660,11 +675,12 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
                 if (a.Qp) t.Qp = a.Qp + r0 * a.qkv_D;
                 t.Kp = a.Kp + r0 * a.qkv_D;
                 t.VT = a.VT + r0;
-                const int rc = launch_tile<2, 4, 0, 2, 0, 2>(h, stream);
+                const int rc = launch_tile<2, 4, 0, 2, 0, 0>(h, stream);
                 return rc ? rc : launch_tile<2, 2, 0, 2, 0, 0, 2>(t, stream);
             }
         }
-        return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);
+        if (a.tile == 8) return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);       // (A/B: round 2's schedule)
+        return launch_tile<2, 4, 0, 2, 0, 0>(a, stream);
     }
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");

@@ -35,7 +35,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // MODE bit 0: R1 addend, bit 1: R2 addend (v = v + R1, then v = R2 + v, like gemm_f16x2_kernel), bit 2: the first addend is
 // the FSMN memory block of p.fs_v computed in place (excludes bit 0); LN: LayerNorm epilogue
-template <int MODE, bool LN, bool A_NT>
+template <int MODE, bool LN, bool A_NT, int SCHED = 2>
 __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
     constexpr int WM = 2, WN = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -111,15 +111,28 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
         // both k-steps' fragments are requested before the first MFMA (one LDS-latency bubble per stage), the next stage's
         // DMA pieces early; per k-step the two small products first, hi * hi last: the order of gemm_f16x2_kernel
         f16x8 a0[WM][2], b0[WN][2], a1[WM][2], b1[WN][2];
-        RW_LOAD(a0, b0, 0)
-        RW_LOAD(a1, b1, 1)
-        RW_PIECE(0); RW_PIECE(1); RW_PIECE(2); RW_PIECE(3);
-        RW_PROD(a0, b0, 1, 0); RW_PIECE(4); RW_PIECE(5);
-        RW_PROD(a0, b0, 0, 1); RW_PIECE(6); RW_PIECE(7);
-        RW_PROD(a0, b0, 0, 0); RW_PIECE(8); RW_PIECE(9);
-        RW_PROD(a1, b1, 1, 0);
-        RW_PROD(a1, b1, 0, 1);
-        RW_PROD(a1, b1, 0, 0);
+        if constexpr (SCHED == 2) {
+            RW_LOAD(a0, b0, 0)
+            RW_LOAD(a1, b1, 1)
+            RW_PIECE(0); RW_PIECE(1); RW_PIECE(2); RW_PIECE(3);
+            RW_PROD(a0, b0, 1, 0); RW_PIECE(4); RW_PIECE(5);
+            RW_PROD(a0, b0, 0, 1); RW_PIECE(6); RW_PIECE(7);
+            RW_PROD(a0, b0, 0, 0); RW_PIECE(8); RW_PIECE(9);
+            RW_PROD(a1, b1, 1, 0);
+            RW_PROD(a1, b1, 0, 1);
+            RW_PROD(a1, b1, 0, 0);
+        } else {
+            // the plain order (round 5: what the wide tile GEMM now runs, profiles/r05s): a k-step's fragments, its products with
+            // the next stage's pieces between them, then the next k-step's fragments
+            RW_LOAD(a0, b0, 0)
+            RW_PROD(a0, b0, 1, 0); RW_PIECE(0); RW_PIECE(1); RW_PIECE(2);
+            RW_PROD(a0, b0, 0, 1); RW_PIECE(3); RW_PIECE(4); RW_PIECE(5);
+            RW_PROD(a0, b0, 0, 0); RW_PIECE(6); RW_PIECE(7);
+            RW_LOAD(a1, b1, 1)
+            RW_PROD(a1, b1, 1, 0); RW_PIECE(8); RW_PIECE(9);
+            RW_PROD(a1, b1, 0, 1);
+            RW_PROD(a1, b1, 0, 0);
+        }
 #undef RW_PROD
 #undef RW_LOAD
 #undef RW_PIECE
@@ -128,21 +141,23 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
     gemm2_row_epilogue<MODE, LN, 512, WM, 0>(p, acc, smem, m0, tid, wave, wr, wc, lane, true);
 }
 
-template <int MODE, bool LN, bool A_NT>
+template <int MODE, bool LN, bool A_NT, int SCHED = 2>
 int launch_row_t(const GemmRowArgs& a, hipStream_t stream) {
     static bool configured = false;
     if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_row_kernel<MODE, LN, A_NT>),
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_row_kernel<MODE, LN, A_NT, SCHED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RW_LDS_B));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_f16x2_row_kernel<MODE, LN, A_NT>), dim3((unsigned)ceil_div(a.M, RW_BM)), dim3(512), RW_LDS_B, stream, a);
+    hipLaunchKernelGGL((gemm_f16x2_row_kernel<MODE, LN, A_NT, SCHED>), dim3((unsigned)ceil_div(a.M, RW_BM)), dim3(512), RW_LDS_B, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
 template <int MODE, bool LN>
 int launch_row_m(const GemmRowArgs& a, hipStream_t stream) {
-    return a.a_nt ? launch_row_t<MODE, LN, true>(a, stream) : launch_row_t<MODE, LN, false>(a, stream);
+    // a_nt bit 0: non-temporal A loads; bit 1 (A/B hook): the plain k-step order instead of both k-steps' fragments up front
+    if (a.a_nt & 2) return (a.a_nt & 1) ? launch_row_t<MODE, LN, true, 0>(a, stream) : launch_row_t<MODE, LN, false, 0>(a, stream);
+    return (a.a_nt & 1) ? launch_row_t<MODE, LN, true>(a, stream) : launch_row_t<MODE, LN, false>(a, stream);
 }
 
 }  // namespace

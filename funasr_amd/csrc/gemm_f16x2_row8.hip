@@ -339,7 +339,7 @@ int launch_row8_t(const GemmRowArgs& a, hipStream_t stream) {
 }
 template <int WM, int MODE, bool LN>
 int launch_row8_m(const GemmRowArgs& a, hipStream_t stream) {
-    return a.a_nt ? launch_row8_t<WM, MODE, LN, true>(a, stream) : launch_row8_t<WM, MODE, LN, false>(a, stream);
+    return (a.a_nt & 1) ? launch_row8_t<WM, MODE, LN, true>(a, stream) : launch_row8_t<WM, MODE, LN, false>(a, stream);
 }
 template <int WM>
 int launch_row8_w(const GemmRowArgs& a, hipStream_t stream) {

@@ -261,7 +261,7 @@ int launch_w4_row_t(const GemmRowArgs& a, hipStream_t stream) {
 }
 template <int MODE, bool LN>
 int launch_w4_row_m(const GemmRowArgs& a, hipStream_t stream) {
-    return a.a_nt ? launch_w4_row_t<MODE, LN, true>(a, stream) : launch_w4_row_t<MODE, LN, false>(a, stream);
+    return (a.a_nt & 1) ? launch_w4_row_t<MODE, LN, true>(a, stream) : launch_w4_row_t<MODE, LN, false>(a, stream);
 }
 
 }  // namespace

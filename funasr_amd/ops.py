@@ -382,7 +382,7 @@ def gemm_f16x2_row(a2: torch.Tensor, w2: torch.Tensor, bias=None, add1=None, add
                                        _ptr(add1), add1.stride(0) if add1 is not None else 0,
                                        _ptr(add2), add2.stride(0) if add2 is not None else 0,
                                        _ptr(c), 512, _ptr(g), _ptr(b), float(eps), _ptr(y2), M * 512, float(2.0 ** out_scale_exp),
-                                       _ptr(yf), M, K, int(relu), int(bool(a_nt)) | (int(block_rows) << 8), int(time_iters),
+                                       _ptr(yf), M, K, int(relu), (int(a_nt) & 3) | (int(block_rows) << 8), int(time_iters),
                                        C.byref(ms), _stream()),
                "pf_k_gemm_f16x2_row")
     y = y2 if y2 is not None else yf
@@ -447,7 +447,7 @@ def gemm_f16x2_row_fsmn(a2: torch.Tensor, w2: torch.Tensor, bias, v: torch.Tenso
                                             _ptr(v), v.stride(0), _ptr(taps), _ptr(lo), _ptr(hi),
                                             _ptr(add2), add2.stride(0) if add2 is not None else 0, _ptr(c), 512, _ptr(g), _ptr(b),
                                             float(eps), _ptr(y2), M * 512, float(2.0 ** out_scale_exp), _ptr(yf), M, K,
-                                            int(bool(a_nt)) | (int(block_rows) << 8), int(time_iters), C.byref(ms), _stream()),
+                                            (int(a_nt) & 3) | (int(block_rows) << 8), int(time_iters), C.byref(ms), _stream()),
                "pf_k_gemm_f16x2_row_fsmn")
     y = y2 if y2 is not None else yf
     return (c, y, float(ms.value)) if time_iters > 0 else (c, y)
