@@ -140,6 +140,9 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     for (int st = 0; st < 2; ++st) coff[st] = ((2 * st + hh) ^ f) * 16;
 
     const int nk = p.K / KS;
+    // SCHED 3 (A/B, round 5): the plain order + static priority for the second-dispatched half of the workgroup (waves 4-7 lose the
+    // issue arbitration against their older SIMD partners on every segment; MI355X guide, "two waves per SIMD", item 4)
+    if constexpr (SCHED == 3) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
     if constexpr (KS_ == 16 && WGM == 4) {
         // Deep ring with EXACT waits (round 4). Five 32-KB buffers of 16-deep stages; at step kt stage kt is in registers, stage
         // kt + 1 is read from LDS into the other fragment set, stages kt + 2 .. kt + 5 are in flight: four stages = 128 KB against
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
         _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                                                             \
             b[jj][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(sb + pl * B_PLANE_B + boff + jj * 32 * ROWB + coff[S])); \
     }
-        if constexpr (SCHED == 0) {
+        if constexpr (SCHED == 0 || SCHED == 3) {
             f16x8 a[WM][2], b[WN][2];
             // the two small products first, hi*hi last (fixed order: results do not depend on the block shape's schedule)
             PF_LOAD(0)
@@ -494,7 +497,7 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     const long m_tiles = ceil_div(a.M, 256);
     const long wide_blocks = m_tiles * (a.N / 256), narrow_blocks = m_tiles * ceil_div(a.N, 128);
     const double cost_wide = (double)((wide_blocks + n_cu - 1) / n_cu), cost_narrow = 0.57 * (double)((narrow_blocks + n_cu - 1) / n_cu);
-    const bool wide = a.tile == 2 || a.tile == 8 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
+    const bool wide = a.tile == 2 || a.tile == 8 || a.tile == 9 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
     if constexpr (OUT == 0) {
         // fp32 output: the 128 x 128 four-wave shape (two workgroups per CU, 0.55 of a 256 x 256 block's time per round of
         // 2 n_cu blocks: tools/bench_r03.py `dec`) wins where the larger shapes leave CUs idle -- the decoder's token-side GEMMs
@@ -515,6 +518,7 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // (profiles/r05s_ab_wide_tile_sched0.txt: w_1 planes 230 -> 211 us, QKV form 185.5 -> 174.5, w_2 212 -> 191; same bits).
     // tile 8 = SCHED 2 stays reachable for A/B runs.
     if (wide && a.tile == 8) return launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream);
+    if (wide && a.tile == 9) return launch_tile<2, 4, MODE, OUT, 0, 3>(a, stream);
     return wide ? launch_tile<2, 4, MODE, OUT, 0, 0>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
 }
 
@@ -680,6 +684,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
             }
         }
         if (a.tile == 8) return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);       // (A/B: round 2's schedule)
+        if (a.tile == 9) return launch_tile<2, 4, 0, 2, 0, 3>(a, stream);
         return launch_tile<2, 4, 0, 2, 0, 0>(a, stream);
     }
     if (a.C2) {
