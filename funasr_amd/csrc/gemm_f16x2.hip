@@ -348,29 +348,12 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     gemm2_tile_body<WM, WN, MODE, OUT, ABL, SCHED, WGM, KS_>(p, m0, n0, nblk, smem);
 }
 
-// De-phased block order for the 256-row shapes (round 5). With equal tiles every CU runs its K loop and its epilogue at the same
-// time as every other CU: the epilogues' stores are a chip-wide burst at the fabric's write rate with every matrix pipe idle
-// (268 MB in >= 41 us for w_1 at M = 32768), four times per launch. Here every second workgroup of the FIRST round computes a
-// 256 x 128 half of its panel's first column block (half the time), the other half of that block is the panel's LAST work
-// item: from the first round on half of the CUs are half a tile ahead of the other half, so only half of them burst at a time
-// while the rest multiply (profiles/r05r_dephase_experiment.jsonl: de-phasing by a DELAY recovers 12-15 us per launch; this
-// order gets it without the delay). Same products, same k order, same epilogue per output element as every other shape:
-// bitwise equal (tested). Per XCD (panels x, x + 8, ..: PX of them) the order is: [narrow half 0 of column block 0 | wide column
-// block 1] per panel, then column blocks 2 .. nN - 1 panel by panel (a panel's tiles stay neighbours: its A rows come from L2),
-// then the narrow halves 1 of column block 0. Needs nM % 8 == 0 and nN >= 2.
-template <int MODE, int OUT, int SCHED>
-__global__ __launch_bounds__(512, 2) void gemm_f16x2_dephased_kernel(Gemm2Args p, int nM, int nN) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int L = blockIdx.x, xcd = L & 7, e = L >> 3;
-    const int PX = nM >> 3;
-    int panel, col, half = -1;                       // half >= 0: the 256 x 128 half `half` of column block `col`
-    if (e < 2 * PX) { panel = e >> 1; if (e & 1) col = 1; else { col = 0; half = 0; } }
-    else if (e < 2 * PX + PX * (nN - 2)) { const int t = e - 2 * PX; panel = t / (nN - 2); col = 2 + t % (nN - 2); }
-    else { panel = e - (2 * PX + PX * (nN - 2)); col = 0; half = 1; }
-    const int m0 = (panel * 8 + xcd) * 256;
-    if (half >= 0) gemm2_tile_body<2, 2, MODE, OUT, 0, 0, 4, 32>(p, m0, col * 256 + half * 128, 2 * col + half, smem);
-    else gemm2_tile_body<2, 4, MODE, OUT, 0, SCHED, 4, 32>(p, m0, col * 256, col, smem);
-}
+// (Round 5 built a de-phased block order on top of gemm2_tile_body -- every second workgroup of the first round computes a
+// 256 x 128 half of its tile and the other halves close the list, so that only half of the CUs run their epilogue's store burst
+// at a time. Bitwise equal, and SLOWER in both of its forms: w_1 planes 205 -> 223 us, the step 51.0 -> 52.6 ms
+// (profiles/r05x_ab_dephased_first_order.txt, r05y_ab_dephased_second_order.txt), although de-phasing by a plain DELAY
+// recovers 12-15 us per launch (profiles/r05r_dephase_experiment.jsonl): the narrow tiles and the changed order cost more
+// than the bursts. Removed.)
 
 // fp32 [M, N] (row stride ldx) * scale -> two fp16 planes [M, ldy] (`plane` elements apart); columns N..ldy are zero
 __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ y,
@@ -478,28 +461,6 @@ int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
-static int g_dephase = 0;          // process-wide default of the de-phased order (pf_k / engine option; 0 until measured in the engine)
-
-template <int MODE, int OUT>
-int launch_dephased(const Gemm2Args& a, hipStream_t stream) {
-    typedef Geo2<2, 4, 4, 32> G;
-    static bool configured = false;
-    if (!configured) {
-        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_dephased_kernel<MODE, OUT, 0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
-        configured = true;
-    }
-    const int nM = a.M / 256, nN = a.N / 256;
-    hipLaunchKernelGGL((gemm_f16x2_dephased_kernel<MODE, OUT, 0>), dim3((unsigned)(nM * (nN + 1))), dim3(512), G::LDS_B, stream, a, nM, nN);
-    PF_HIP_TRY(hipGetLastError());
-    return 0;
-}
-// whether the de-phased order applies: whole 256-row panels in multiples of 8 (one per XCD and round), at least two column blocks,
-// at least two rounds of work over the CUs (with one round there is nothing to de-phase)
-static inline bool dephased_ok(const Gemm2Args& a, int n_cu) {
-    return a.M % 2048 == 0 && a.N % 256 == 0 && a.N >= 512 && a.kslices <= 1 && !a.amax_val && a.a_kstep <= 0 && a.w_kstep <= 0 &&
-           (long)(a.M / 256) * (a.N / 256) >= 2L * n_cu;
-}
 // NOTE (round 4): the 128 x 256 shape below (tile 5) stages its operands behind COUNTED vmcnt waits (glds_wait_but). LDS-DMA pieces of
 // one wave were found to retire out of issue order when their sources differ (gemm_f16x2_ffn.hip header): it passes the warm kernel
 // tests but is NOT safe inside a long pipeline -- a measurement hook only. The deep ring (tile 6) was rebuilt on exact waits with one
@@ -550,7 +511,7 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     const long m_tiles = ceil_div(a.M, 256);
     const long wide_blocks = m_tiles * (a.N / 256), narrow_blocks = m_tiles * ceil_div(a.N, 128);
     const double cost_wide = (double)((wide_blocks + n_cu - 1) / n_cu), cost_narrow = 0.57 * (double)((narrow_blocks + n_cu - 1) / n_cu);
-    const bool wide = a.tile == 2 || a.tile == 8 || a.tile == 9 || a.tile == 10 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
+    const bool wide = a.tile == 2 || a.tile == 8 || a.tile == 9 || (a.tile == 0 && a.N % 256 == 0 && cost_wide <= cost_narrow);
     if constexpr (OUT == 0) {
         // fp32 output: the 128 x 128 four-wave shape (two workgroups per CU, 0.55 of a 256 x 256 block's time per round of
         // 2 n_cu blocks: tools/bench_r03.py `dec`) wins where the larger shapes leave CUs idle -- the decoder's token-side GEMMs
@@ -572,9 +533,6 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // tile 8 = SCHED 2 stays reachable for A/B runs.
     if (wide && a.tile == 8) return launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream);
     if (wide && a.tile == 9) return launch_tile<2, 4, MODE, OUT, 0, 3>(a, stream);
-    if constexpr (OUT <= 1) {
-        if ((a.tile == 10 || (a.tile == 0 && wide && g_dephase)) && dephased_ok(a, n_cu)) return launch_dephased<MODE, OUT>(a, stream);
-    }
     return wide ? launch_tile<2, 4, MODE, OUT, 0, 0>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
 }
 
@@ -741,7 +699,6 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         }
         if (a.tile == 8) return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);       // (A/B: round 2's schedule)
         if (a.tile == 9) return launch_tile<2, 4, 0, 2, 0, 3>(a, stream);
-        if ((a.tile == 10 || (a.tile == 0 && g_dephase)) && dephased_ok(a, 256)) return launch_dephased<0, 2>(a, stream);
         return launch_tile<2, 4, 0, 2, 0, 0>(a, stream);
     }
     if (a.C2) {
