@@ -355,14 +355,6 @@ def main():
                     avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
                     launches_per_step=gemm["launches_per_step"],
                     share_of_step=round(gemm["ms_per_step"] / (dt / args.steps * 1e3), 3))
-    if args.precision == "f16x2":
-        # what the matrix pipe sustains for THIS instruction mix on random operand planes under the part's power / clock
-        # management (tools/micro/mfma_peak.hip: register-resident three-product chains, no LDS, no memory), measured now
-        plp = power_limited_peak()
-        if plp:
-            roofline.update(power_limited_peak=round(plp["TFLOPs"] / PRODUCTS["f16x2"], 1), power_limited_peak_executed_16bit=plp["TFLOPs"],
-                            frac_of_power_limited_peak=round(ach / (plp["TFLOPs"] / PRODUCTS["f16x2"]), 4), power_limited_peak_source=plp["source"],
-                            power_limited_peak_sclk_mhz=plp.get("sclk_mhz_mean"), power_limited_peak_power_w=plp.get("power_w_mean"))
     if args.precision in PRODUCTS:
         n = PRODUCTS[args.precision]
         roofline.update(peak_note=f"dense 16-bit MFMA peak 2500 TFLOP/s / {n} products per fp32-equivalent product",
@@ -471,6 +463,16 @@ def main():
             trace("streaming done")
         except Exception as e:
             line["streaming"] = {"error": repr(e)}
+    if args.precision == "f16x2":
+        # what the matrix pipe sustains for THIS instruction mix on random operand planes under the part's power / clock
+        # management (tools/micro/mfma_peak.hip: register-resident three-product chains, no LDS, no memory), measured now -- LAST,
+        # so that its 1.5 s at the power limit do not precede (and heat) any timed leg above
+        plp = power_limited_peak()
+        if plp:
+            ach = line["roofline"]["achieved"]
+            line["roofline"].update(power_limited_peak=round(plp["TFLOPs"] / PRODUCTS["f16x2"], 1), power_limited_peak_executed_16bit=plp["TFLOPs"],
+                                    frac_of_power_limited_peak=round(ach / (plp["TFLOPs"] / PRODUCTS["f16x2"]), 4), power_limited_peak_source=plp["source"],
+                                    power_limited_peak_sclk_mhz=plp.get("sclk_mhz_mean"), power_limited_peak_power_w=plp.get("power_w_mean"))
     print(json.dumps(line), flush=True)
 
 
@@ -500,12 +502,15 @@ def run_pcie_inclusive(frontend, model, wav_host, wav_dev, lens, args, B):
         return model.enqueue_features(feats, flens)
 
     def run(k):
+        # batch i + 1's copy is issued BEFORE batch i is enqueued: enqueue() ends with the step's one host synchronisation (the
+        # CIF token count), and a copy issued only after it -- the round-3 / round-4 order -- reached the compute stream's wait
+        # late: +3.3 ms per step, although copies and events alone cost nothing (same-call dissection, profiles/r05_pcie_loop.json)
         ev = h2d(0)
+        nxt_ev = h2d(1) if k > 1 else None
         pending = enqueue(0, ev)
-        ev = h2d(1) if k > 1 else None
         for i in range(1, k):
+            ev, nxt_ev = nxt_ev, (h2d(i + 1) if i + 1 < k else None)
             nxt = enqueue(i, ev)
-            ev = h2d(i + 1) if i + 1 < k else None
             model.collect(pending)
             pending = nxt
         return model.collect(pending)
