@@ -28,7 +28,7 @@ constexpr int SK_KW = 16;    // waves per workgroup = K slices (a constant: a ro
 // LNIN: C = W LayerNorm(A) + bias without a LayerNorm launch and without normalising A (GemmArgs.ln_stats_in; the algebra is at
 // the statistics' loads below). The row statistics come from the producing GEMM's per-16-column partial sums (ln_stats_out), so
 // no workgroup re-reads a row to recompute them -- round 2 folded the LayerNorm into the fetch WITH a recomputation per column
-// workgroup and lost 1 ms per step to it. mean = S / K, var = Q / K - mean^2 (one pass; the stand-alone kernel is two-pass:
+// workgroup and lost 1 ms per step to it. mean = S / K, var = merged M2 / K (centred block partials merged by Chan's formula since round 5; the stand-alone kernel is two-pass:
 // results differ in the last bits, fp32-class either way), and every order of summation depends on K only -- never on M, RM or
 // CN -- so a stream's bits stay independent of its neighbours.
 // NW = waves per workgroup. 16: one workgroup owns a tile and all sixteen K slices. 4 (GemmArgs.ws_part): FOUR workgroups share
@@ -168,12 +168,20 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
     if constexpr (LNIN) {
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            float sx = st0[i].x + st1[i].x, sq = st0[i].y + st1[i].y;
+            // block partials are (sum, M2 = sum of squared deviations from the BLOCK mean) of 16 columns; merged by Chan's formula:
+            // M2 = sum_b [M2_b + 16 (mean_b - mean)^2]. (Until round 5 the partials were (sum, sum of squares) and the variance
+            // Q / K - mean^2, which cancels catastrophically for rows with |mean| >> std)
+            const int nblk = p.K >> 4;
+            float sx = st0[i].x + st1[i].x;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sq += __shfl_xor(sq, o, 64); }
+            for (int o = 32; o > 0; o >>= 1) sx += __shfl_xor(sx, o, 64);
             const float mean = sx / (float)p.K;
-            float var = sq / (float)p.K - mean * mean;
-            var = var > 0.f ? var : 0.f;
+            float m2 = 0.f;
+            if (lane < nblk) { const float d = st0[i].x * 0.0625f - mean; m2 += st0[i].y + 16.f * d * d; }
+            if (lane + 64 < nblk) { const float d = st1[i].x * 0.0625f - mean; m2 += st1[i].y + 16.f * d * d; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+            const float var = m2 / (float)p.K;
             if (lane == 0) ln_ms[wv + NW * i] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
         }
         // (visible to the epilogue's threads through the barrier that also publishes the slice tiles)
@@ -198,11 +206,15 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p) {
             if (p.ln_stats_out) {
                 // (sum, sum of squares) over this row's 16-column block: the 16 threads of the block are 16 consecutive,
                 // 16-aligned lanes and all active (N % 16 == 0); xor butterfly 8, 4, 2, 1
-                float sx = v, sq = v * v;
+                float sx = v;
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 16); sq += __shfl_xor(sq, o, 16); }
+                for (int o = 8; o > 0; o >>= 1) sx += __shfl_xor(sx, o, 16);
+                const float dv = v - sx * 0.0625f;               // deviation from the block mean: (sum, M2) partials, merged by Chan's formula
+                float m2 = dv * dv;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 16);
                 if ((lc & 15) == 0)
-                    reinterpret_cast<float2*>(p.ln_stats_out)[(size_t)row * (p.N >> 4) + (cc >> 4)] = make_float2(sx, sq);
+                    reinterpret_cast<float2*>(p.ln_stats_out)[(size_t)row * (p.N >> 4) + (cc >> 4)] = make_float2(sx, m2);
             }
         }
     };

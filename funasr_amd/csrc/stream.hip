@@ -234,23 +234,27 @@ __global__ __launch_bounds__(512) void dec_fsmn_chunk24_kernel(DecFsmnChunkArgs 
             // (mean, rstd) per token row: wave w reduces rows w, w + 8, w + 16 (one load per lane and row), butterfly 32 .. 1 --
             // the reduction of gemm_skinny.hip's consumer
             const int nblk = p.C >> 4;
-            float sx[3], sq[3];
+            // (sum, M2 about the block mean) partials of 16 channels (C <= 512: at most 32 blocks, one per lane), Chan's merge -- as
+            // gemm_skinny.hip's consumer
+            float2 bp[3];
+            float sx[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int r = wave + 8 * i;
-                sx[i] = 0.f; sq[i] = 0.f;
-                if (r < p.N) {
-                    const float2* st = reinterpret_cast<const float2*>(p.ln_stats_in) + ((size_t)s * p.N + r) * nblk;
-                    for (int b = lane; b < nblk; b += 64) { const float2 t = st[b]; sx[i] += t.x; sq[i] += t.y; }
-                }
+                bp[i] = make_float2(0.f, 0.f);
+                if (r < p.N && lane < nblk) bp[i] = (reinterpret_cast<const float2*>(p.ln_stats_in) + ((size_t)s * p.N + r) * nblk)[lane];
+                sx[i] = bp[i].x;
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { sx[i] += __shfl_xor(sx[i], o, 64); sq[i] += __shfl_xor(sq[i], o, 64); }
+                for (int o = 32; o > 0; o >>= 1) sx[i] += __shfl_xor(sx[i], o, 64);
                 const float mean = sx[i] / (float)p.C;
-                float var = sq[i] / (float)p.C - mean * mean;
-                var = var > 0.f ? var : 0.f;
+                float m2 = 0.f;
+                if (lane < nblk) { const float d = bp[i].x * 0.0625f - mean; m2 = bp[i].y + 16.f * d * d; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+                const float var = m2 / (float)p.C;
                 if (lane == 0 && wave + 8 * i < p.N) ms[wave + 8 * i] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
             }
         }
@@ -330,11 +334,15 @@ __global__ __launch_bounds__(512) void dec_fsmn_chunk24_kernel(DecFsmnChunkArgs 
                 if (p.ln_stats_out) {
                     // block partials of the output row: 16 channels = 4 consecutive lanes (C % 16 == 0: all four active or none)
                     float sx = (o.x + o.y) + (o.z + o.w);
-                    float sq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-                    sx += __shfl_xor(sx, 1, 64); sq += __shfl_xor(sq, 1, 64);
-                    sx += __shfl_xor(sx, 2, 64); sq += __shfl_xor(sq, 2, 64);
+                    sx += __shfl_xor(sx, 1, 64);
+                    sx += __shfl_xor(sx, 2, 64);
+                    const float mb = sx * 0.0625f;                // block mean; partials = (sum, sum of squared deviations from it)
+                    const float dx = o.x - mb, dy = o.y - mb, dz = o.z - mb, dw = o.w - mb;
+                    float m2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                    m2 += __shfl_xor(m2, 1, 64);
+                    m2 += __shfl_xor(m2, 2, 64);
                     if (active && (c4 & 3) == 0)
-                        reinterpret_cast<float2*>(p.ln_stats_out)[((size_t)s * p.N + k) * (p.C >> 4) + (c4 >> 2)] = make_float2(sx, sq);
+                        reinterpret_cast<float2*>(p.ln_stats_out)[((size_t)s * p.N + k) * (p.C >> 4) + (c4 >> 2)] = make_float2(sx, m2);
                 }
             }
         }

@@ -47,7 +47,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add1=None, add
 def gemm_small_m_ln(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add2=None, stats_in=None, ln=None, want_stats=False,
                     four_workgroups=False, out_gamma=None, a_has_gamma=False):
     """The small-M GEMM with a LayerNorm carried between GEMMs (gemm_skinny.hip). want_stats returns the [M, N / 16, 2] block
-    partials (sum, sum of squares) of the finished outputs; out_gamma [N]: the stored outputs are out * out_gamma (the partials stay
+    partials (sum, sum of squared deviations from the block mean: merged by Chan's formula in the consumer) of the finished outputs; out_gamma [N]: the stored outputs are out * out_gamma (the partials stay
     those of out). With stats_in [M, K / 16, 2] and ln = (gamma, beta, eps): out = w LayerNorm(a) + bias, evaluated as
     rstd (w (gamma a) - mean c1) + c2 with c1 = w gamma, c2 = w beta + bias (pf_k_ln_consts); a_has_gamma: `a` holds gamma a already.
     four_workgroups (M <= 32): four workgroups share a tile's sixteen K slices, the same bits. Returns (out, stats or None)."""

@@ -68,10 +68,11 @@ def test_small_m_gemm_rows_do_not_depend_on_m(cuda):
 
 
 def test_small_m_gemm_carries_a_layernorm_between_two_gemms(cuda):
-    """gemm_skinny.hip, the streaming step's fused LayerNorms: the producer's epilogue leaves (sum, sum of squares) per row and
-    16-column block, the consumer normalises its A operand on the fetch from them. Against float64 LayerNorm + GEMM (fp32-class:
-    tolerance 2e-6 of the output range); the pair's rows are bitwise independent of M like the plain kernel's; and against the
-    stand-alone LayerNorm kernel + GEMM the difference is the last bits of a one-pass vs two-pass variance (< 2e-6)."""
+    """gemm_skinny.hip, the streaming step's fused LayerNorms: the producer's epilogue leaves (sum, sum of squared deviations from the
+    block mean) per row and 16-column block, the consumer merges them by Chan's formula and normalises its A operand on the fetch.
+    Against float64 LayerNorm + GEMM (fp32-class: tolerance 2e-6 of the output range); the pair's rows are bitwise independent of M
+    like the plain kernel's; against the stand-alone LayerNorm kernel + GEMM < 2e-6; and rows whose mean is a hundred times their
+    spread (the former Q / K - mean^2 variance lost three digits there) stay fp32-class in the statistics."""
     from funasr_amd import ops
     g = torch.Generator().manual_seed(5)
     D, F, eps = 512, 2048, 1e-12
@@ -95,7 +96,7 @@ def test_small_m_gemm_carries_a_layernorm_between_two_gemms(cuda):
             assert _rel(full[0], xr) < 2e-6
             blocks = full[0].double().view(200, D // 16, 16)
             assert (full[1][..., 0].double() - blocks.sum(-1)).abs().max() < 1e-4
-            assert (full[1][..., 1].double() - (blocks ** 2).sum(-1)).abs().max() < 2e-3
+            assert (full[1][..., 1].double() - ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1)).abs().max() < 2e-4
             xn = torch.nn.functional.layer_norm(full[0].double(), (D,), gam.double(), bet.double(), eps)
             hr = torch.relu(xn @ w1.double().T + b1.double())
             assert _rel(full[2], hr) < 2e-6
@@ -120,6 +121,23 @@ def test_small_m_gemm_carries_a_layernorm_between_two_gemms(cuda):
                                           four_workgroups=True)
             h4, _ = ops.gemm_small_m_ln(x4, dev(w1), dev(b1), relu=True, stats_in=st4, ln=(dev(gam), dev(bet), eps), four_workgroups=True)
             assert torch.equal(x4, x) and torch.equal(st4, st) and torch.equal(h4, h), M
+
+
+    # rows with |mean| >> std: residual stream offset by 300 with spread ~1. The merged variance must be the two-pass one to fp32
+    # rounding (the one-pass form's error here: eps * mean^2 / var ~ 5e-3 relative); the consumer's output keeps the cancellation of
+    # rstd (W (gamma a) - mean c1) + c2 (inherent to carrying the LayerNorm: ~ eps * |mean| / std of the output range)
+    xb = (torch.randn(64, D, generator=g) + 300.0)
+    zero_w, zero_b = torch.zeros(D, D), torch.zeros(D)
+    x, st = ops.gemm_small_m_ln(dev(ctx[:64].contiguous()), dev(zero_w), dev(zero_b), add2=dev(xb), want_stats=True)
+    assert torch.equal(x.cpu(), xb)
+    blocks = xb.double().view(64, D // 16, 16)
+    m2 = st.cpu()[..., 1].double().sum(-1) + (16.0 * (blocks.mean(-1) - xb.double().mean(-1, keepdim=True)) ** 2).sum(-1)
+    var_ref = xb.double().var(-1, unbiased=False)
+    assert ((m2 / D - var_ref).abs() / var_ref).max().item() < 1e-5, "merged block partials are not the two-pass variance"
+    h, _ = ops.gemm_small_m_ln(x, dev(w1), dev(b1), relu=True, stats_in=st, ln=(dev(gam), dev(bet), eps))
+    xn = torch.nn.functional.layer_norm(xb.double(), (D,), gam.double(), bet.double(), eps)
+    hr = torch.relu(xn @ w1.double().T + b1.double())
+    assert _rel(h.cpu(), hr) < 3e-4
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (500, 1536, 576), (333, 2048, 512), (1000, 512, 2048), (70, 130, 192)])
