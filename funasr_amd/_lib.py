@@ -11,7 +11,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparaformer_hip.so")
+# PF_LIB_PATH (environment): another build of the same library (A/B runs of compiler flags; tools/repro_pk_aggressors.py)
+LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libparaformer_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 2            # PF_ABI_VERSION of include/paraformer_hip.h

@@ -9,6 +9,9 @@ from funasr_amd import ops, _lib
 
 dev = torch.device("cuda:0")
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+# aggressor: "gemm" = the 128 x 128 f16x2 GEMM of rounds 3 / 4; "regs" (round 5) = f16 MFMAs on register operands with a barrier every 16
+# steps (tools/micro/pk_aggr.hip KIND 9), which disturbs a packed-fp32 fbank_kernel in ~90 % of its calls
+AGGR = sys.argv[2] if len(sys.argv) > 2 else "gemm"
 g = torch.Generator().manual_seed(0)
 side = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(side):
@@ -49,15 +52,27 @@ def flat(o):
     return [t for t in (o if isinstance(o, (tuple, list)) else [o]) if isinstance(t, torch.Tensor)]
 
 
-out = {}
+if AGGR == "regs":
+    import ctypes as C
+    pa = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "pk_aggr.so"))
+    pa.pk_aggr_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    srcbuf = (torch.rand(65536 // 2, device=dev) * 1.875 + 0.125).to(torch.float16)
+    sink = torch.zeros(16, device=dev)
+    def aggress():
+        for _ in range(40):
+            pa.pk_aggr_launch(C.c_void_p(side.cuda_stream), 9, 16, srcbuf.data_ptr(), 512, 400, sink.data_ptr())
+else:
+    def aggress():
+        for _ in range(40):
+            ops.gemm_f16x2(aa, aw, ab, scale_exp=20, tile=3)
+out = {"aggressor": AGGR}
 for name, fn in victims.items():
     ref = [t.clone() for t in flat(fn())]
     torch.cuda.synchronize()
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < secs:
         with torch.cuda.stream(side):
-            for _ in range(40):
-                ops.gemm_f16x2(aa, aw, ab, scale_exp=20, tile=3)
+            aggress()
         for _ in range(8):
             got = flat(fn())
             n += 1
