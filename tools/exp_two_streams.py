@@ -1,55 +1,74 @@
 #!/usr/bin/env python3
-"""Experiment: one full batch on one stream vs two half batches on two streams (two host threads, two model handles with
-the same weights) -- does overlapping MFMA-bound and HBM-bound kernels of independent sub-batches raise throughput?"""
-import os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Does a second model replica on its own HIP stream fill the CUs a kernel's last round leaves idle?
+SenseVoiceSmall at 128 x 10 s runs M = 22 528 rows = 88 x 256: every power-of-two tiling of its N = 512 / 1536 projections fills
+11/16 of the chip. R replicas (own handles and workspaces, own streams), each software-pipelined like bench.py's loop, batches dealt
+round-robin; ids compared with the one-replica run.   usage: exp_two_streams.py [sensevoice|paraformer] [steps]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 from funasr_amd import synth
-from funasr_amd.paraformer import Paraformer
 from funasr_amd.wav_frontend import WavFrontend
 
+which = sys.argv[1] if len(sys.argv) > 1 else "sensevoice"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
-cfg = synth.PARAFORMER_LARGE
-sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
-shift, scale = synth.synthetic_cmvn(560)
-B, n = 64, 480000
-base = [synth.speech_like(n, seed=i) for i in range(8)]
-wav = torch.stack([base[i % 8].roll(137 * (i // 8)) for i in range(B)]).to(dev)
-mode = sys.argv[1] if len(sys.argv) > 1 else "f16x2"
+sh, sc = synth.synthetic_cmvn(560)
+cmvn = torch.stack([sh, sc])
+if which == "sensevoice":
+    from funasr_amd.sense_voice import SenseVoiceSmall
+    cfg = synth.SENSEVOICE_SMALL
+    sd = synth.sensevoice_state_dict(cfg, seed=0)
+    B, secs = 128, 10.0
+    def make():
+        m = SenseVoiceSmall.from_config(cfg); m.load_state_dict(sd, strict=False); m = m.to(dev); m.set_precision("f16x2"); return m
+    call = lambda m, f, fl: m.enqueue_features(f, fl, "auto", "woitn")
+else:
+    from funasr_amd.paraformer import Paraformer
+    cfg = synth.PARAFORMER_LARGE
+    sd = synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS)
+    B, secs = 64, 30.0
+    def make():
+        m = Paraformer.from_config(cfg); m.load_state_dict(sd, strict=False); m = m.to(dev); m.set_precision("f16x2"); return m
+    call = lambda m, f, fl: m.enqueue_features(f, fl)
+n = int(secs * 16000)
+wav = torch.stack([synth.speech_like(n, seed=500 + i) for i in range(B)]).to(dev)
+lens = [n] * B
+R = 2
+models = [make() for _ in range(R)]
+fes = [WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0, device=dev) for _ in range(R)]
+streams = [torch.cuda.Stream(device=dev) for _ in range(R)]
+torch.cuda.synchronize()
 
-def make():
-    m = Paraformer.from_config(cfg); m.load_state_dict(sd, strict=False); m = m.to(dev); m.set_precision(mode)
-    fe = WavFrontend(cmvn=torch.stack([shift, scale]), lfr_m=7, lfr_n=6, dither=0.0, device=dev)
-    return m, fe
+def enqueue(r):
+    with torch.cuda.stream(streams[r]):
+        f, fl = fes[r](wav, lens)
+        return call(models[r], f, fl)
 
-def run(m, fe, w, steps):
-    lens = [n] * w.shape[0]
-    pend = m.enqueue_features(*fe(w, lens))
-    for _ in range(steps - 1):
-        nxt = m.enqueue_features(*fe(w, lens))
-        r = m.collect(pend); pend = nxt
-    return m.collect(pend)
+def run(k, reps):
+    """k batches over `reps` replicas; every replica keeps two batches in flight on its stream (bench.py's loop per replica)"""
+    pend = [[] for _ in range(reps)]
+    last = None
+    for i in range(k):
+        r = i % reps
+        pend[r].append(enqueue(r))
+        if len(pend[r]) > 1:
+            with torch.cuda.stream(streams[r]):
+                last = models[r].collect(pend[r].pop(0))
+    for r in range(reps):
+        for p in pend[r]:
+            with torch.cuda.stream(streams[r]):
+                last = models[r].collect(p)
+    return last
 
-K = 6
-m0, f0 = make()
-run(m0, f0, wav, 2); torch.cuda.synchronize()
-t0 = time.perf_counter(); r_full = run(m0, f0, wav, K); torch.cuda.synchronize(); t_full = (time.perf_counter() - t0) / K
-print(f"one stream, batch 64: {t_full*1e3:.1f} ms/step  {B*30/t_full:.0f} audio-s/s", flush=True)
-
-for nsplit in (2, 4):
-    models = [make() for _ in range(nsplit)]
-    streams = [torch.cuda.Stream() for _ in range(nsplit)]
-    hb = B // nsplit
-    res = [None] * nsplit
-    def worker(i, steps):
-        with torch.cuda.stream(streams[i]):
-            res[i] = run(models[i][0], models[i][1], wav[i * hb:(i + 1) * hb], steps)
-            streams[i].synchronize()
-    for steps in (2, K):
-        th = [threading.Thread(target=worker, args=(i, steps)) for i in range(nsplit)]
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        [t.start() for t in th]; [t.join() for t in th]
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    ids = sum((r["raw_ids"] for r in res), [])
-    print(f"{nsplit} streams x batch {hb}: {dt*1e3:.1f} ms/step  {B*30/dt:.0f} audio-s/s  ids equal full-batch: {ids == r_full['raw_ids']}", flush=True)
-    del models
+out = {"workload": which, "batch": B, "clip_s": secs, "steps": steps}
+ref = None
+for rep in range(2):
+    for reps in (1, 2):
+        run(2 * reps, reps); torch.cuda.synchronize()
+        t0 = time.perf_counter(); res = run(steps, reps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if ref is None:
+            ref = res["ids"]
+        out.setdefault(f"replicas_{reps}", []).append({"audio_s_per_s": round(B * secs * steps / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 2),
+                                                       "ids_equal_first_run": res["ids"] == ref})
+print(json.dumps(out))
