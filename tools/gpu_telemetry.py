@@ -20,7 +20,7 @@ class Sampler:
     def __init__(self, device: int = 0, period_s: float = 0.02):
         self.dev, self.period = device, period_s
         self.lib, self.err = None, None
-        self.clk, self.pw = [], []
+        self.clk, self.pw, self.mclk, self.temps = [], [], [], {}
         self._stop = threading.Event()
         self._thr = None
         try:
@@ -46,7 +46,27 @@ class Sampler:
             return f.frequency[min(f.current, 32)] / 1e6
         return None
 
+    def _mclk_mhz(self):
+        f = _Freqs()
+        if self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.dev), C.c_int(4), C.byref(f)) == 0 and f.num_supported:   # RSMI_CLK_TYPE_MEM
+            return f.frequency[min(f.current, 32)] / 1e6
+        return None
+
+    def _temps_c(self):
+        """junction (1), memory (2) and the hottest HBM stack (3 .. 6) in degrees C, whichever sensors the part reports"""
+        out = {}
+        for name, sensors in (("junction", (1,)), ("memory", (2,)), ("hbm_max", (3, 4, 5, 6))):
+            vals = []
+            for sn in sensors:
+                v = C.c_int64(0)
+                if self.lib.rsmi_dev_temp_metric_get(C.c_uint32(self.dev), C.c_uint32(sn), C.c_int(0), C.byref(v)) == 0 and v.value:
+                    vals.append(v.value / 1e3)
+            if vals:
+                out[name] = max(vals)
+        return out
+
     def _run(self):
+        k = 0
         while not self._stop.is_set():
             try:
                 c, p = self._sclk_mhz(), self._power_w()
@@ -54,13 +74,20 @@ class Sampler:
                     self.clk.append(c)
                 if p:
                     self.pw.append(p)
+                if k % 10 == 0:                           # memory clock and temperatures: a slow box of the pool is usually a hot
+                    m = self._mclk_mhz()                  # or memory-throttled one (memory-bound kernels +60 %)
+                    if m:
+                        self.mclk.append(m)
+                    for name, v in self._temps_c().items():
+                        self.temps.setdefault(name, []).append(v)
+                k += 1
             except Exception as e:                        # noqa: BLE001  (telemetry must never take the bench down)
                 self.err = repr(e)
                 return
             self._stop.wait(self.period)
 
     def start(self):
-        self.clk, self.pw = [], []
+        self.clk, self.pw, self.mclk, self.temps = [], [], [], {}
         self._stop.clear()
         if self.lib is not None:
             self._thr = threading.Thread(target=self._run, daemon=True)
@@ -82,7 +109,9 @@ class Sampler:
         return {"available": True, "source": "librocm_smi64 (rsmi_dev_gpu_clk_freq_get SYS, socket power), polled every "
                                              f"{self.period * 1e3:.0f} ms from a host thread",
                 "samples": max(len(self.clk), len(self.pw)), "sclk_mhz_mean": cm, "sclk_mhz_min": cl, "sclk_mhz_max": ch,
-                "power_w_mean": pm, "power_w_min": pl, "power_w_max": ph}
+                "power_w_mean": pm, "power_w_min": pl, "power_w_max": ph,
+                "mclk_mhz_mean": stats(self.mclk, 0)[0], "mclk_mhz_min": stats(self.mclk, 0)[1],
+                "temp_c_max": {k: round(max(v), 1) for k, v in self.temps.items()} or None}
 
 
 if __name__ == "__main__":
