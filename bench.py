@@ -170,23 +170,47 @@ def run_two_replicas(cfg, model, frontend, wav, lens, args, B, device, res_main)
 
 
 def hbm_copy_probe(device):
-    """State of the box's memory, outside the clock: a 1-GiB device-to-device copy, best of 20 (read + write bytes / time). Boxes of
-    the pool differ: on some the memory-bound kernels of the step run 60 % longer at a HIGHER shader clock and LOWER power than on
-    the others (profiles/r05zz_bench.json vs gpurun_out/b2: linear_out 112 vs 177 us); this figure lets a line say which kind it ran on."""
+    """State of the box's memory system, outside the clock: device-to-device copies, best of 20 (read + write bytes / time) -- 1 GiB
+    (beyond the 256-MB infinity cache: HBM) and 32 MiB (both buffers cache-resident: fabric / infinity cache). Boxes of the pool
+    differ: on some the memory-bound kernels of the step run 60 % longer at a HIGHER shader clock and LOWER power than on the
+    others (profiles/r05_box_variance.jsonl: linear_out 108 vs 177 us) although the matrix-pipe probe and the 1-GiB copy agree."""
+    out = {"kernel": "torch copy_ (d2d)", "best_of": 20}
     try:
-        n = 1 << 28
-        a = torch.empty(n, dtype=torch.float32, device=device).normal_()
-        b = torch.empty_like(a)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
-        ev[0].record()
-        for i in range(20):
-            b.copy_(a)
-            ev[i + 1].record()
-        torch.cuda.synchronize()
-        ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(20))
-        return {"GBps_read_plus_write": round(2 * 4 * n / ms / 1e6, 0), "bytes": 4 * n, "best_of": 20, "kernel": "torch copy_ (d2d)"}
+        for name, n in (("GBps_read_plus_write", 1 << 28), ("GBps_32MiB_cache_resident", 1 << 23)):
+            a = torch.empty(n, dtype=torch.float32, device=device).normal_()
+            b = torch.empty_like(a)
+            for _ in range(3):
+                b.copy_(a)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+            ev[0].record()
+            for i in range(20):
+                b.copy_(a)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(20))
+            out[name] = round(2 * 4 * n / ms / 1e6, 0)
+            del a, b
+        out["bytes"] = 4 * (1 << 28)
     except Exception as e:                              # noqa: BLE001
-        return {"error": repr(e)}
+        out["error"] = repr(e)
+    try:
+        # own probe kernels (tools/micro/mfma_peak.hip, mem_probe_kernel): streaming read / streaming write of 2 GiB, and 2048
+        # workgroups re-reading 1-MiB windows 32 times (L2-resident: the pattern of a GEMM workgroup re-streaming its W panel)
+        lib = C.CDLL(os.path.join(ROOT, "tools", "micro", "mfma_peak.so"))
+        lib.mem_probe_run.restype = C.c_float
+        lib.mem_probe_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        n16 = 1 << 27
+        buf = torch.empty(n16 * 4, dtype=torch.int32, device=device).random_(0, 1 << 30)
+        sink = torch.zeros(4, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()
+        for name, mode, blocks, reps, byts in (("own_read_GBps", 0, 8192, 1, 16.0 * n16), ("own_write_GBps", 1, 8192, 1, 16.0 * n16),
+                                                ("own_L2_reread_GBps", 2, 2048, 32, 2048 * 32 * float(1 << 20))):
+            ms = lib.mem_probe_run(buf.data_ptr(), buf.data_ptr(), n16, mode, blocks, reps, 10, sink.data_ptr())
+            out[name] = round(byts / ms / 1e6, 0) if ms > 0 else None
+        del buf
+    except Exception as e:                              # noqa: BLE001
+        out["own_probe_error"] = repr(e)
+    return out
 
 
 def power_limited_peak(seconds=1.5):

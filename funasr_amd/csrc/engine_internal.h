@@ -366,9 +366,11 @@ struct Encoder {
     int ffn_abl = 0;                    // debugging hook: FfnArgs.abl
     int row_bm = 0;                     // GemmRowArgs.block_rows of the full-row GEMMs (0: by the row count)
     // w_2: 1 = full-row form (residual + the next norm1 in the epilogue), 0 = a 256 x 256 tile GEMM (+ residual) and the next norm1 as
-    // its own launch, 2 (default) = the tile form where its 256-row blocks fill whole rounds of the CUs to >= 85 % (the 128 x 512
+    // its own launch, 2 (default) = the tile form where its 256-row blocks fill whole rounds of the CUs to >= 65 % (the 128 x 512
     // row block re-streams the 4-MB W panel for every 128 rows: 1.28 GB of L2 -> LDS per launch at M = 32768 against 1.0 GB; same-call
-    // A/B 55.0 -> 53.8 ms per step, profiles/r05k_ab_w2_row.txt). Every choice gives the same bits (tested).
+    // A/B 55.0 -> 53.8 ms per step, profiles/r05k_ab_w2_row.txt; the mark was 85 % until SenseVoice's M = 22 528 -- 11/16 of a round --
+    // measured 47.0 -> 45.8 ms per step in the tile form, profiles/r05_sensevoice_options.json: at the socket's power limit idle CUs
+    // cost little). Every choice gives the same bits (tested).
     int row_sched = 0;                  // k-step order of the eight-wave full-row kernel: 0 plain (default since round 5: FSMN form 108 -> 103 us, profiles/r05t), 2 both k-steps' fragments up front
     int w2_row = 2;
     // Gemm2Args.tile of w_2 in its tile form: 7 (default) = the four-wave shape (gemm_f16x2_w4.hip) for this projection only -- its fp32 +
@@ -407,7 +409,7 @@ static inline bool encoder_w2_row_form(const Encoder* e, int M) {
         return n;
     }();
     const int blocks = ceil_div(M, 256) * (e->cfg.d_model / 256), rounds = ceil_div(blocks, n_cu);
-    return !(e->cfg.d_model % 256 == 0 && blocks >= (int)(0.85 * rounds * n_cu));
+    return !(e->cfg.d_model % 256 == 0 && blocks >= (int)(0.65 * rounds * n_cu));
 }
 
 // engine_frontend.hip: from now on every frontend handle of the process cross-checks its fbank frames (another stream may share a CU)

@@ -20,7 +20,7 @@ class Sampler:
     def __init__(self, device: int = 0, period_s: float = 0.02):
         self.dev, self.period = device, period_s
         self.lib, self.err = None, None
-        self.clk, self.pw, self.mclk, self.temps = [], [], [], {}
+        self.clk, self.pw, self.mclk, self.temps, self.other = [], [], [], {}, {}
         self._stop = threading.Event()
         self._thr = None
         try:
@@ -46,11 +46,14 @@ class Sampler:
             return f.frequency[min(f.current, 32)] / 1e6
         return None
 
-    def _mclk_mhz(self):
+    def _clk_mhz(self, kind):
         f = _Freqs()
-        if self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.dev), C.c_int(4), C.byref(f)) == 0 and f.num_supported:   # RSMI_CLK_TYPE_MEM
+        if self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.dev), C.c_int(kind), C.byref(f)) == 0 and f.num_supported:
             return f.frequency[min(f.current, 32)] / 1e6
         return None
+
+    def _mclk_mhz(self):
+        return self._clk_mhz(4)                                                                                          # RSMI_CLK_TYPE_MEM
 
     def _temps_c(self):
         """junction (1), memory (2) and the hottest HBM stack (3 .. 6) in degrees C, whichever sensors the part reports"""
@@ -80,6 +83,10 @@ class Sampler:
                         self.mclk.append(m)
                     for name, v in self._temps_c().items():
                         self.temps.setdefault(name, []).append(v)
+                    for name, kind in (("df", 1), ("soc", 3)):             # data-fabric and SOC clocks (RSMI_CLK_TYPE_DF / _SOC)
+                        v = self._clk_mhz(kind)
+                        if v:
+                            self.other.setdefault(name, []).append(v)
                 k += 1
             except Exception as e:                        # noqa: BLE001  (telemetry must never take the bench down)
                 self.err = repr(e)
@@ -87,7 +94,7 @@ class Sampler:
             self._stop.wait(self.period)
 
     def start(self):
-        self.clk, self.pw, self.mclk, self.temps = [], [], [], {}
+        self.clk, self.pw, self.mclk, self.temps, self.other = [], [], [], {}, {}
         self._stop.clear()
         if self.lib is not None:
             self._thr = threading.Thread(target=self._run, daemon=True)
@@ -111,7 +118,8 @@ class Sampler:
                 "samples": max(len(self.clk), len(self.pw)), "sclk_mhz_mean": cm, "sclk_mhz_min": cl, "sclk_mhz_max": ch,
                 "power_w_mean": pm, "power_w_min": pl, "power_w_max": ph,
                 "mclk_mhz_mean": stats(self.mclk, 0)[0], "mclk_mhz_min": stats(self.mclk, 0)[1],
-                "temp_c_max": {k: round(max(v), 1) for k, v in self.temps.items()} or None}
+                "temp_c_max": {k: round(max(v), 1) for k, v in self.temps.items()} or None,
+                "fabric_soc_clk_mhz_mean": {k: round(sum(v) / len(v), 0) for k, v in self.other.items()} or None}
 
 
 if __name__ == "__main__":
