@@ -326,14 +326,6 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
     const int mblk = (j8 / nN) * 8 + xcd, nblk = j8 % nN;
     if (mblk >= nM) return;
     const int m0 = mblk * BM, n0 = nblk * BN;
-    if constexpr (ABL == 5) {
-        // TIMING EXPERIMENT (round 5): every second group of eight first-round workgroups starts ~half a tile late, so that the two
-        // halves of the chip run out of phase from then on -- how much of the epilogue's store burst (all CUs at once, every matrix
-        // pipe idle) goes away when only half the CUs burst at a time? (the delay itself is pure loss: total = base + delay - gain)
-        if (L < 256 && ((L >> 3) & 1)) {
-            for (int i = 0; i < p.relu; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     if constexpr (OUT == 0 && MODE == 0) {
         // split-K form: slice blockIdx.y multiplies columns [y K, (y + 1) K) of both operands (p.K is the slice length, the row
         // strides are the full ones) into its own [M, N] partial
@@ -352,8 +344,8 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16x2_kernel(Gemm2Args p, i
 // 256 x 128 half of its tile and the other halves close the list, so that only half of the CUs run their epilogue's store burst
 // at a time. Bitwise equal, and SLOWER in both of its forms: w_1 planes 205 -> 223 us, the step 51.0 -> 52.6 ms
 // (profiles/r05x_ab_dephased_first_order.txt, r05y_ab_dephased_second_order.txt), although de-phasing by a plain DELAY
-// recovers 12-15 us per launch (profiles/r05r_dephase_experiment.jsonl): the narrow tiles and the changed order cost more
-// than the bursts. Removed.)
+// recovers 12-15 us per launch (profiles/r05r_dephase_experiment.jsonl; that measurement build is gone too): the narrow tiles and
+// the changed order cost more than the bursts. Removed.)
 
 // fp32 [M, N] (row stride ldx) * scale -> two fp16 planes [M, ldy] (`plane` elements apart); columns N..ldy are zero
 __global__ __launch_bounds__(256) void split2_kernel(const float* __restrict__ x, int ldx, unsigned short* __restrict__ y,
@@ -492,7 +484,6 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
                 case 1: return launch_tile<2, 4, 0, 0, 1>(a, stream);
                 case 2: return launch_tile<2, 4, 0, 0, 2>(a, stream);
                 case 3: return launch_tile<2, 4, 0, 0, 3>(a, stream);
-                case 5: return launch_tile<2, 4, 0, 0, 5>(a, stream);      // de-phasing experiment: Gemm2Args.relu = delay in s_sleep(127) units
                 default: return launch_tile<2, 4, 0, 0, 4>(a, stream);
             }
         }

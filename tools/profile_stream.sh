@@ -12,5 +12,5 @@ cd /tmp
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o s -- $CMD > "$OUT/trace.log" 2>&1
 echo "rc=$?" >> "$OUT/trace.log"
 cd - > /dev/null
-python tools/summarize_stream_trace.py "$OUT" | tee "$OUT/summary.txt"
+python tools/analyze_stream_trace.py "$(find "$OUT/trace" -name '*kernel_trace.csv' | head -1)" --idle-us 100 | tee "$OUT/summary.json"
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
