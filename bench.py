@@ -949,16 +949,21 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu, args, confident=None, gpu_ra
             torch.set_num_threads(all_cores)
             rate1 = next(s["value"] for s in settings if s["cores"] == all_cores)
             secs8 = full if 8 * full / max(rate1, 1e-9) <= 2 * args.cpu_budget else max(3.0, min(full, args.cpu_budget * rate1 / 8))
-            ws = [clips[i % len(clips)][: int(secs8 * 16000)] for i in range(8)]
             t0 = time.perf_counter()
-            feats8, flens8 = O.wav_frontend(ws, cmvn)
-            if use_ref:
-                MG.run_reference(enc_m, pred_m, dec_m, feats8, flens8)
-            else:
-                O.paraformer_greedy(feats8, flens8, sd, cfg)
+            nb = 0
+            while True:                                      # batches of 8 different clips until the budget is used (>= 1 batch)
+                ws = [clips[(8 * nb + i) % len(clips)][: int(secs8 * 16000)] for i in range(8)]
+                feats8, flens8 = O.wav_frontend(ws, cmvn)
+                if use_ref:
+                    MG.run_reference(enc_m, pred_m, dec_m, feats8, flens8)
+                else:
+                    O.paraformer_greedy(feats8, flens8, sd, cfg)
+                nb += 1
+                if time.perf_counter() - t0 > args.cpu_budget:
+                    break
             dt8 = time.perf_counter() - t0
-            settings.append({"value": round(8 * secs8 / dt8, 2), "unit": "audio-s/s", "cores": all_cores, "batch_size": 8,
-                             "sample": f"one batch of 8 x {secs8:g} s clips of the same workload, {dt8:.1f} s of CPU work"})
+            settings.append({"value": round(nb * 8 * secs8 / dt8, 2), "unit": "audio-s/s", "cores": all_cores, "batch_size": 8,
+                             "sample": f"{nb} batch(es) of 8 x {secs8:g} s clips of the same workload, {dt8:.1f} s of CPU work"})
     except Exception as e:                                  # noqa: BLE001  (the extra setting must not lose the baseline)
         settings.append({"cores": all_cores, "batch_size": 8, "error": repr(e)})
     best = max((s for s in settings if "value" in s), key=lambda s: s["value"])
