@@ -75,8 +75,9 @@ namespace pf {
 // Process-wide fence (round 5): fbank_kernel's cross-check switches itself on for every frontend handle once the process has said
 // that other work may share a CU with the frontend -- pf_set_concurrency_guard(1) (funasr_amd.dp.guard_shared_gpu: ranks sharing a
 // GPU) or an asynchronous streaming step (pf_stream_step_begin: a second stream's kernels can meet the frontend on the chip). The
-// two-stream fault of rounds 3 / 4 has a mitigation (no packed-fp32 VALU in the non-matrix kernels, csrc/Makefile), not a root
-// cause: until a reproducer pins it, the 0.4 % of a step the second evaluation costs is paid wherever the trigger can exist.
+// two-stream fault of rounds 3 / 4 is a hardware interaction of packed-fp32 VALU instructions with MFMA waves on the same CU
+// (tools/micro/pk reproduces it); the library is built without such instructions, and this cross-check stays as the
+// second line of defence: the 0.4 % of a step the second evaluation costs is paid wherever kernels of two streams can meet.
 static std::atomic<int> g_concurrency_guard{0};
 void note_concurrent_streams() { g_concurrency_guard.store(1, std::memory_order_relaxed); }
 static int frontend_verify_on(Frontend* f) {

@@ -69,12 +69,13 @@ __device__ __forceinline__ void normal4(const unsigned (&u)[4], float (&z)[4]) {
 // only ever touches its own slice and its DS operations execute in order. Everything that does not change from frame to
 // frame lives in registers for the life of the wave: window coefficients, stage twiddles, and the weights of the (at
 // most two) mel-triangle pieces this lane accumulates.
-// BUILD NOTE (Makefile: FLAGS_frontend): this file is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 /
-// v_pk_fma_f32). On the MI355X boxes of this pool a wave's packed-fp32 results come back wrong in one 16-lane pass now and then
+// BUILD NOTE (Makefile: NOPK, since round 5 for EVERY source of the library): this file is compiled WITHOUT packed-fp32 VALU
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32). On the MI355X boxes of this pool a wave's packed-fp32 results come back wrong in one 16-lane pass now and then
 // when waves of the 128 x 128 f16x2 GEMM (v_mfma_f32_32x32x16_f16, two workgroups per CU) run on the same CU -- from another process
 // or another HIP stream; round 3's "two-process frontend fault". Round 4 traced it with the cross-check below (checkpoints after
 // every exchange: the inputs of the last radix-4 butterfly were identical, its outputs differed in exactly 16 lanes; identical
-// again with this build flag: 0 disagreements in 52 000 frontends next to that GEMM against 150 000 before). DESIGN 4.
+// again with this build flag: 0 disagreements in 52 000 frontends next to that GEMM against 150 000 before). Round 5 reproduced it
+// stand-alone (tools/micro/pk: CU-local, needs MFMA waves that also synchronise; profiles/r05_pk_reproducer.txt). DESIGN 4.
 template <bool DITHER>
 __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_frames) {
     __shared__ float2 zs[WAVES_PER_BLOCK][NFFT / 2];          // exchange buffer / spectrum Z in natural order
