@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-interleave", action="store_true", help="round 5's loop: whole batches enqueued one after the other (the host's wait for "
+                    "the CIF token count then sits between a batch's encoder and decoder); default: the two-phase loop (begin(i+1), finish(i), collect(i-1))")
     ap.add_argument("--no-bf16", action="store_true", help="skip the other arithmetic modes (fp32-MFMA, bf16x3, bf16 operands)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads (PCIe-inclusive, SenseVoiceSmall, streaming)")
     ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16", "bf16x3", "f16x2"], help="mode of the MAIN timed region: "
@@ -163,6 +165,7 @@ def run_two_replicas(cfg, model, frontend, wav, lens, args, B, device, res_main)
     last = run(k)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    m2.close()                              # the pipeline object owns device buffers (two encoder outputs, embeds, ids)
     del m2
     return {"value": round(B * args.seconds * k / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt / k * 1e3, 2), "steps": k, "replicas": 2,
             "ids_equal_main": all(r is not None and r["raw_ids"] == res_main["raw_ids"] for r in last),
@@ -301,6 +304,7 @@ def main():
     from funasr_amd import _lib, dp, synth
     from funasr_amd.wav_frontend import WavFrontend
     dp.guard_shared_gpu(world, all_on_one=args.dist_backend == "gloo")
+    host_pin = dp.pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", "0")), world) if world > 1 else None
 
     lib = _lib.load()
     cfg = synth.PARAFORMER_LARGE
@@ -318,6 +322,7 @@ def main():
     wav = wav_host.to(device)
     lens = [n_samples] * B
     N_PAD = 512
+    interleave = not args.no_interleave
     trace("workload resident in HBM")
 
     def enqueue(src=None):
@@ -333,16 +338,39 @@ def main():
     def step():
         return collect(enqueue())
 
-    def run_steps(k):
-        """k batches, software-pipelined like a serving loop: batch i+1 is enqueued (frontend .. fused arg-max) before
-        batch i's ids are brought to the host, so host-side post-processing never leaves the GPU idle. Every batch is
-        fully processed and collected inside the call."""
+    def begin(src=None):
+        feats, flens = frontend(wav if src is None else src, lens)
+        return model.begin_features(feats, flens)
+
+    def run_steps_sequential(k):
+        """round 5's loop (kept for the A/B figure `interleave.sequential_ms_per_step`): batch i+1 is enqueued whole -- frontend ..
+        fused arg-max, with the host's wait for the CIF token count in its middle -- before batch i's ids are collected."""
         pending = enqueue()
         for _ in range(k - 1):
             nxt = enqueue()
             collect(pending)
             pending = nxt
         return collect(pending)
+
+    def run_steps(k):
+        """k batches, software-pipelined like a serving loop, in the two phases of the forward (Paraformer.begin_features /
+        finish_features = pf_paraformer_begin / _finish): batch i+1's frontend + encoder + CIF scan are enqueued BEFORE the host waits
+        for batch i's token counts and launches its decoder, and batch i-1's ids are collected after that -- the stream always holds
+        a whole encoder while the host reads a count, so the GPU never waits for the host. Every batch is fully processed
+        and collected inside the call."""
+        if not interleave:
+            return run_steps_sequential(k)
+        ticket, pending, out = begin(), None, None
+        for _ in range(k - 1):
+            nxt = begin()
+            fin = model.finish_features(ticket)
+            if pending is not None:
+                collect(pending)
+            pending, ticket = fin, nxt
+        fin = model.finish_features(ticket)
+        if pending is not None:
+            collect(pending)
+        return collect(fin)
 
     def sync():
         torch.cuda.synchronize()
@@ -473,7 +501,8 @@ def main():
                    "tokens_max": max(res["token_num"]), "tokens_min": min(res["token_num"]),
                    "rccl_ranks": world, "weight_arena_bytes_broadcast": arena_bytes,
                    "hypothesis_gather_bytes_per_rank_per_step": (B * (N_PAD + 1) * 4) if world > 1 else 0,
-                   "per_rank_ms_per_step": per_rank_ms, "weight_broadcast_seconds_per_rank": bcast_all if world > 1 else None},
+                   "per_rank_ms_per_step": per_rank_ms, "weight_broadcast_seconds_per_rank": bcast_all if world > 1 else None,
+                   "weights_route": args.weights_route if world > 1 else None, "host_cores_rank0": host_pin},
         "roofline": roofline, "kernels": kernels,
         "sclk_mhz_mean": (telemetry or {}).get("sclk_mhz_mean"), "power_w_mean": (telemetry or {}).get("power_w_mean"),
         "telemetry": telemetry,
@@ -487,6 +516,16 @@ def main():
 
     # ------------------------------------------------------------------- everything below: N = 1 only, outside the timed region
     line["hbm_copy_probe"] = hbm_copy_probe(device)
+    if interleave:
+        # A/B in the same process: round 5's loop (the host's wait for the CIF count between a batch's encoder and its decoder)
+        run_steps_sequential(2)
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        run_steps_sequential(args.steps)
+        torch.cuda.synchronize()
+        seq_ms = (time.perf_counter() - t0s) / args.steps * 1e3
+        line["interleave"] = {"loop": "begin(i+1) -> finish(i) -> collect(i-1) (pf_paraformer_begin / _finish)",
+                              "sequential_ms_per_step": round(seq_ms, 2), "gain": round(seq_ms / (dt / args.steps * 1e3), 4)}
     if not args.no_secondary:
         line["pcie_inclusive"] = run_pcie_inclusive(frontend, model, wav_host, wav, lens, args, B)
         # SURVEY 8(d) counts the waveforms' H2D copy; this run's rules make `value` the HBM-resident rate -- both at the top level
@@ -586,27 +625,30 @@ def run_pcie_inclusive(frontend, model, wav_host, wav_dev, lens, args, B):
             ev.record(copy_stream)
         return ev
 
-    def enqueue(i, ev):
+    def begin(i, ev):
         main.wait_event(ev)
         feats, flens = frontend(bufs[i % 2], lens)
         fe = torch.cuda.Event()
         fe.record(main)
         free_ev[i % 2] = fe
-        return model.enqueue_features(feats, flens)
+        return model.begin_features(feats, flens)
 
     def run(k):
-        # batch i + 1's copy is issued BEFORE batch i is enqueued: enqueue() ends with the step's one host synchronisation (the
-        # CIF token count), and a copy issued only after it -- the round-3 / round-4 order -- reached the compute stream's wait
-        # late: +3.3 ms per step, although copies and events alone cost nothing (same-call dissection, profiles/r05_pcie_loop.json)
+        # the two-phase loop of the headline run with batch i + 1's copy issued one batch ahead on the side stream
         ev = h2d(0)
         nxt_ev = h2d(1) if k > 1 else None
-        pending = enqueue(0, ev)
+        ticket, pending = begin(0, ev), None
         for i in range(1, k):
             ev, nxt_ev = nxt_ev, (h2d(i + 1) if i + 1 < k else None)
-            nxt = enqueue(i, ev)
+            nxt = begin(i, ev)
+            fin = model.finish_features(ticket)
+            if pending is not None:
+                model.collect(pending)
+            pending, ticket = fin, nxt
+        fin = model.finish_features(ticket)
+        if pending is not None:
             model.collect(pending)
-            pending = nxt
-        return model.collect(pending)
+        return model.collect(fin)
 
     run(2)
     torch.cuda.synchronize()

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libparaformer_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2            # PF_ABI_VERSION of include/paraformer_hip.h
+ABI_VERSION = 3            # PF_ABI_VERSION of include/paraformer_hip.h
 
 _lock = threading.Lock()
 _lib = None
@@ -161,6 +161,7 @@ SIGNATURES = {
     "pf_frontend_fbank": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "pf_frontend_lfr_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "pf_set_skinny_max_m": (C.c_int, [_i32]),
+    "pf_k_conv1d_gemm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pf_k_gemm_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pf_k_gemm_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pf_k_gemm_bf16_time": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), _vp]),
@@ -210,6 +211,8 @@ SIGNATURES = {
     "pf_paraformer_create": (_vp, [_vp, _vp, _vp]),
     "pf_paraformer_destroy": (None, [_vp]),
     "pf_paraformer_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "pf_paraformer_begin": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "pf_paraformer_finish": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "pf_paraformer_encoder_out": (_vp, [_vp]),
     "pf_paraformer_embeds": (_vp, [_vp]),
     "pf_dp_gather_ids": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp]),

@@ -295,15 +295,15 @@ int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
                a.k_plane % 8 == 0 && a.vt_plane % 8 == 0 && a.o_plane % 8 == 0, "attention_f16x2: strides % 8");
     PF_REQUIRE(((uintptr_t)a.Q & 15) == 0 && ((uintptr_t)a.K & 15) == 0 && ((uintptr_t)a.VT & 15) == 0 && ((uintptr_t)a.O & 15) == 0,
                "attention_f16x2: 16-B alignment");
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        configured = true;
+        configured.mark();
     }
     const int rows = a.Tq > 0 ? a.Tq : a.Tp;
     Attn2Args k = a;

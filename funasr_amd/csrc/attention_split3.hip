@@ -241,11 +241,11 @@ int launch_attention_split3(const AttnArgs& a, hipStream_t stream) {
     PF_REQUIRE(a.K2 == nullptr, "attention_split3: the two-source (streaming) form uses the fp32 MFMA kernel");
     PF_REQUIRE(a.O || a.O3, "attention: null output");
     if (a.O3) PF_REQUIRE(a.o_plane % 4 == 0 && ((uintptr_t)a.O3 & 7) == 0, "attention: plane output alignment");
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_split3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        configured = true;
+        configured.mark();
     }
     dim3 grid(ceil_div(a.Tq, 256), a.H, a.B);
     hipLaunchKernelGGL(attention_split3_kernel, grid, dim3(512), LDS_BYTES, stream, a);

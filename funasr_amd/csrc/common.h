@@ -5,11 +5,39 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <atomic>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 namespace pf {
+
+// A process may drive more than one device (threads, replicas on different GPUs): function attributes are per device, and so is the
+// CU count a shape choice looks at -- neither may be cached in a plain function-local static (ADVICE, round 5).
+inline int current_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d & 63;
+}
+struct PerDeviceOnce {                       // `static PerDeviceOnce once; if (!once.done()) { ...configure...; once.mark(); }`
+    std::atomic<bool> flag[64];
+    PerDeviceOnce() { for (auto& f : flag) f.store(false, std::memory_order_relaxed); }
+    bool done() const { return flag[current_device_slot()].load(std::memory_order_acquire); }
+    void mark() { flag[current_device_slot()].store(true, std::memory_order_release); }
+};
+inline int device_cu_count() {               // multiProcessorCount of the CURRENT device (256 on an MI355X)
+    static std::atomic<int> n[64];
+    const int slot = current_device_slot();
+    int v = n[slot].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int dev = 0;
+    hipDeviceProp_t pr;
+    v = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) v = pr.multiProcessorCount;
+    n[slot].store(v, std::memory_order_relaxed);
+    return v;
+}
+
 
 // thread-local last error text, surfaced through pf_last_error()
 void set_error(const std::string& msg);
@@ -234,6 +262,12 @@ struct GemmArgs {
     float* ws_part; int* ws_count;
     float* ln_stats_out;
     const float* ln_stats_in; const float* ln_g; float ln_eps;
+    // ---- tile kernel only (gemm_f32.hip), fp32 operands: A is read as the im2col of a Conv1d over time WITHOUT materialising it
+    // (CifPredictorV2's cif_conv1d, funasr/models/paraformer/cif_predictor.py:275-278). conv_taps > 0: K = conv_taps * conv_D; column
+    // k = tap * conv_D + c of row (b, t) is A[(b, t + tap - conv_left), c], zero where t + tap - conv_left falls outside [0, conv_T);
+    // M = B * conv_T rows, conv_D % 32 == 0 (a K tile never straddles two taps). conv_zero: >= 128 B of zeros on the device. The k order
+    // per output element is that of the materialised GEMM: bitwise the same result.
+    int conv_taps, conv_D, conv_T, conv_left; const float* conv_zero;
 };
 int launch_gemm_f32(const GemmArgs& a, hipStream_t stream);
 // small-M weight-streaming variant (gemm_skinny.hip); same contract, no fused arg-max

@@ -348,37 +348,55 @@ int pf_predictor_missing(const pf_predictor* ph) {
     return p ? p->tt.missing() : -1;
 }
 
-int pf_predictor_alphas(pf_predictor* ph, const float* hidden, const int32_t* lens_host, int32_t B, int32_t T,
-                        float* alphas, float* peaks, int32_t* token_num, void* stream) {
-    Predictor* p = reinterpret_cast<Predictor*>(ph);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    PF_REQUIRE(p && hidden && lens_host && token_num && B > 0 && T > 0, "predictor_alphas: null/empty argument");
+}  // extern "C"
+
+// relu(Conv1d(D, D, l + r + 1)(pad(hidden))) (cif_predictor.py:275-278) as ONE exact-fp32 GEMM whose A operand is gathered from the
+// row-shifted views of `hidden` by the DMA sources (gemm_f32.hip, GemmArgs.conv_*): the k order per output element is that of the
+// im2col GEMM of rounds 1-5, so alphas are bitwise unchanged, and the [M, taps D] column matrix (197 MB written + 196 MB read per
+// headline step) is gone
+static int predictor_conv(Predictor* p, const float* hidden, int B, int T, hipStream_t s) {
+    const pf_predictor_config& c = p->cfg;
+    const int D = c.d_model, taps = c.l_order + c.r_order + 1;
+    const size_t M = (size_t)B * T;
+    if (p->conv.ensure(sizeof(float) * M * D)) return -2;
+    if (!p->zero_row.p) {
+        if (p->zero_row.ensure(256)) return -2;
+        PF_HIP_TRY(hipMemsetAsync(p->zero_row.p, 0, 256, s));
+    }
+    GemmArgs g{};
+    g.A = hidden; g.lda = D; g.W = p->tt.get("cif_conv1d.weight"); g.ldw = taps * D; g.bias = p->tt.get("cif_conv1d.bias");
+    g.C = p->conv.as<float>(); g.ldc = D; g.M = (int)M; g.N = D; g.K = taps * D; g.relu = 1;
+    g.conv_taps = taps; g.conv_D = D; g.conv_T = T; g.conv_left = c.l_order; g.conv_zero = p->zero_row.as<float>();
+    ProfScope ps(PROF_GEMM, 2.0 * (double)M * D * (double)(taps * D), s);
+    return launch_gemm_f32(g, s);
+}
+
+namespace pf {
+// everything of pf_predictor_alphas up to the scan, ENQUEUED into scan-state slot `slot`; the token counts stay on the device
+// (predictor_counts_dev)
+int predictor_alphas_enqueue(Predictor* p, int slot, const float* hidden, const int32_t* lens_host, int B, int T, hipStream_t s) {
+    PF_REQUIRE(p && hidden && lens_host && B > 0 && T > 0 && (slot == 0 || slot == 1), "predictor_alphas: null/empty argument");
     for (int b = 0; b < B; ++b) PF_REQUIRE(lens_host[b] >= 1 && lens_host[b] <= T, "predictor_alphas: lens out of range");
     std::string first;
     if (p->tt.missing(&first)) { set_error("predictor: tensor not set: " + first); return -3; }
     const pf_predictor_config& c = p->cfg;
-    const int D = c.d_model, taps = c.l_order + c.r_order + 1, Te = T + 1;
-    const size_t M = (size_t)B * T;
-    if (p->col.ensure(sizeof(float) * M * taps * D) || p->conv.ensure(sizeof(float) * M * D) ||
-        p->alphas.ensure(sizeof(float) * (size_t)B * Te) || p->peaks.ensure(sizeof(float) * (size_t)B * Te) ||
-        p->rems.ensure(sizeof(float) * (size_t)B * Te) || p->flags.ensure(sizeof(int) * (size_t)B * Te) ||
-        p->nfires.ensure(sizeof(int) * (size_t)B))
+    const int D = c.d_model, Te = T + 1;
+    Predictor::CifState& S = p->st[slot];
+    if (S.alphas.ensure(sizeof(float) * (size_t)B * Te) || S.peaks.ensure(sizeof(float) * (size_t)B * Te) ||
+        S.rems.ensure(sizeof(float) * (size_t)B * Te) || S.flags.ensure(sizeof(int) * (size_t)B * Te) ||
+        S.nfires.ensure(sizeof(int) * (size_t)B))
         return -2;
     int rc;
-    if ((rc = upload_lens(p->lens, lens_host, B, s))) return rc;
-    // relu(Conv1d(D, D, l+r+1)(pad(hidden))) as an im2col GEMM (cif_predictor.py:275-278)
-    if ((rc = launch_im2col(hidden, p->col.as<float>(), B, T, D, c.l_order, c.r_order, s))) return rc;
-    if ((rc = gemm_simple(p->col.as<float>(), taps * D, p->tt.get("cif_conv1d.weight"), taps * D,
-                          p->tt.get("cif_conv1d.bias"), p->conv.as<float>(), D, (int)M, D, taps * D, 1, nullptr, 0,
-                          nullptr, 0, s))) return rc;
+    if ((rc = upload_lens(S.lens, lens_host, B, s))) return rc;
+    if ((rc = predictor_conv(p, hidden, B, T, s))) return rc;
     AlphaArgs aa{};
     aa.conv = p->conv.as<float>(); aa.w = p->tt.get("cif_output.weight"); aa.bias = p->tt.get("cif_output.bias");
-    aa.lens = p->lens.as<int>(); aa.alphas = p->alphas.as<float>(); aa.B = B; aa.T = T; aa.D = D; aa.T_ext = Te;
+    aa.lens = S.lens.as<int>(); aa.alphas = S.alphas.as<float>(); aa.B = B; aa.T = T; aa.D = D; aa.T_ext = Te;
     aa.smooth = c.smooth_factor; aa.noise = c.noise_threshold;
     if ((rc = launch_alpha(aa, s))) return rc;
     CifScanArgs sa{};
-    sa.alphas = p->alphas.as<float>(); sa.peaks = p->peaks.as<float>(); sa.rems = p->rems.as<float>();
-    sa.fire_flag = p->flags.as<int>(); sa.n_fires = p->nfires.as<int>(); sa.lens = p->lens.as<int>(); sa.B = B;
+    sa.alphas = S.alphas.as<float>(); sa.peaks = S.peaks.as<float>(); sa.rems = S.rems.as<float>();
+    sa.fire_flag = S.flags.as<int>(); sa.n_fires = S.nfires.as<int>(); sa.lens = S.lens.as<int>(); sa.B = B;
     sa.T = T; sa.tail_threshold = c.tail_threshold; sa.tail_mask = c.tail_mask;
     if (p->v3) {
         if (p->curs.ensure(sizeof(float) * (size_t)B * Te) || p->ntok.ensure(sizeof(int) * (size_t)B)) return -2;
@@ -386,31 +404,51 @@ int pf_predictor_alphas(pf_predictor* ph, const float* hidden, const int32_t* le
     } else if ((rc = launch_cif_scan(sa, s))) {
         return rc;
     }
-    if (alphas) PF_HIP_TRY(hipMemcpyAsync(alphas, p->alphas.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
-    if (peaks) PF_HIP_TRY(hipMemcpyAsync(peaks, p->peaks.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
-    // V3 reports floor(sum alphas) (cif_predictor.py:383), V2's count of fires is the same number by construction
-    PF_HIP_TRY(hipMemcpyAsync(token_num, p->v3 ? p->ntok.p : p->nfires.p, sizeof(int32_t) * (size_t)B,
-                              hipMemcpyDeviceToHost, s));
-    PF_HIP_TRY(hipStreamSynchronize(s));
-    p->last_B = B; p->last_T = T;
+    S.B = B; S.T = T;
     return 0;
 }
-
-int pf_predictor_embeds(pf_predictor* ph, const float* hidden, int32_t B, int32_t T, int32_t N, float* embeds,
-                        void* stream) {
-    Predictor* p = reinterpret_cast<Predictor*>(ph);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    PF_REQUIRE(p && hidden && embeds && N >= 0, "predictor_embeds: null argument");
-    PF_REQUIRE(B == p->last_B && T == p->last_T, "predictor_embeds: call pf_predictor_alphas with the same batch first");
+// V3 reports floor(sum alphas) (cif_predictor.py:383), V2's count of fires is the same number by construction
+const int32_t* predictor_counts_dev(Predictor* p, int slot) {
+    return reinterpret_cast<const int32_t*>(p->v3 ? p->ntok.p : p->st[slot].nfires.p);
+}
+const float* predictor_alphas_dev(Predictor* p, int slot) { return p->st[slot].alphas.as<float>(); }
+const float* predictor_peaks_dev(Predictor* p, int slot) { return p->st[slot].peaks.as<float>(); }
+int predictor_embeds_slot(Predictor* p, int slot, const float* hidden, int B, int T, int N, float* embeds, hipStream_t s) {
+    PF_REQUIRE(p && hidden && embeds && N >= 0 && (slot == 0 || slot == 1), "predictor_embeds: null argument");
+    Predictor::CifState& S = p->st[slot];
+    PF_REQUIRE(B == S.B && T == S.T, "predictor_embeds: call pf_predictor_alphas with the same batch first");
     CifEmitArgs ea{};
-    ea.hidden = hidden; ea.alphas = p->alphas.as<float>(); ea.rems = p->rems.as<float>();
-    ea.fire_flag = p->flags.as<int>(); ea.embeds = embeds; ea.B = B; ea.T = T; ea.D = p->cfg.d_model; ea.N = N;
+    ea.hidden = hidden; ea.alphas = S.alphas.as<float>(); ea.rems = S.rems.as<float>();
+    ea.fire_flag = S.flags.as<int>(); ea.embeds = embeds; ea.B = B; ea.T = T; ea.D = p->cfg.d_model; ea.N = N;
     if (p->v3) {
         if (N <= 0) return 0;
         ea.alphas = p->curs.as<float>();
         return launch_cif_emit_loop(ea, s);
     }
     return launch_cif_emit(ea, s);
+}
+}  // namespace pf
+
+extern "C" {
+
+int pf_predictor_alphas(pf_predictor* ph, const float* hidden, const int32_t* lens_host, int32_t B, int32_t T,
+                        float* alphas, float* peaks, int32_t* token_num, void* stream) {
+    Predictor* p = reinterpret_cast<Predictor*>(ph);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(p && token_num, "predictor_alphas: null/empty argument");
+    int rc;
+    if ((rc = predictor_alphas_enqueue(p, 0, hidden, lens_host, B, T, s))) return rc;
+    const size_t Te = (size_t)T + 1;
+    if (alphas) PF_HIP_TRY(hipMemcpyAsync(alphas, p->st[0].alphas.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
+    if (peaks) PF_HIP_TRY(hipMemcpyAsync(peaks, p->st[0].peaks.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
+    PF_HIP_TRY(hipMemcpyAsync(token_num, predictor_counts_dev(p, 0), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    PF_HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int pf_predictor_embeds(pf_predictor* ph, const float* hidden, int32_t B, int32_t T, int32_t N, float* embeds,
+                        void* stream) {
+    return predictor_embeds_slot(reinterpret_cast<Predictor*>(ph), 0, hidden, B, T, N, embeds, reinterpret_cast<hipStream_t>(stream));
 }
 
 // one direction-pair of torch.nn.LSTM on a time-major input: gates-major input projections by the fp32 MFMA GEMM
@@ -452,16 +490,12 @@ int pf_predictor_timestamp(pf_predictor* ph, const float* hidden, const int32_t*
     const int D = c.d_model, U = p->c3.upsample_times, taps = c.l_order + c.r_order + 1, Tu = T * U;
     const size_t M = (size_t)B * T;
     int rc;
-    if ((rc = upload_lens(p->lens, lens_host, B, s))) return rc;
+    if ((rc = upload_lens(p->st[0].lens, lens_host, B, s))) return rc;
     if (p->tok_dev.ensure(sizeof(int) * (size_t)B)) return -2;
     if (upload_h2d(p->tok_dev.p, token_num_host, sizeof(int32_t) * (size_t)B, s)) return -2;
     const float* src = hidden;
     if (p->c3.use_cif1_cnn) {                                   // the head sees relu(cif_conv1d(hidden)) instead (:317-320)
-        if (p->col.ensure(sizeof(float) * M * taps * D) || p->conv.ensure(sizeof(float) * M * D)) return -2;
-        if ((rc = launch_im2col(hidden, p->col.as<float>(), B, T, D, c.l_order, c.r_order, s))) return rc;
-        if ((rc = gemm_simple(p->col.as<float>(), taps * D, p->tt.get("cif_conv1d.weight"), taps * D,
-                              p->tt.get("cif_conv1d.bias"), p->conv.as<float>(), D, (int)M, D, taps * D, 1, nullptr, 0,
-                              nullptr, 0, s))) return rc;
+        if ((rc = predictor_conv(p, hidden, B, T, s))) return rc;
         src = p->conv.as<float>();
     }
     // ConvTranspose1d(k = stride = U) == one GEMM: row (b, t) of the output holds frames U t .. U t + U - 1
@@ -495,7 +529,7 @@ int pf_predictor_timestamp(pf_predictor* ph, const float* hidden, const int32_t*
                                p->cell, s))) return rc;
         UsAlphaArgs ua{};
         ua.out_t = p->lstm_out.as<float>(); ua.w = p->tt.get("cif_output2.weight"); ua.bias = p->tt.get("cif_output2.bias");
-        ua.lens = p->lens.as<int>(); ua.alphas = us_alphas; ua.B = B; ua.Bs = Bs; ua.T = Tu; ua.C = 2 * D; ua.U = U;
+        ua.lens = p->st[0].lens.as<int>(); ua.alphas = us_alphas; ua.B = B; ua.Bs = Bs; ua.T = Tu; ua.C = 2 * D; ua.U = U;
         ua.smooth = p->c3.smooth_factor2; ua.noise = p->c3.noise_threshold2;
         if ((rc = launch_us_alpha_t(ua, s))) return rc;
     } else {

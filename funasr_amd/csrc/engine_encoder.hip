@@ -561,7 +561,8 @@ int pf_decoder_debug_poison(pf_decoder* dh, int32_t byte) {
 int pf_predictor_debug_poison(pf_predictor* ph, int32_t byte) {
     Predictor* p = reinterpret_cast<Predictor*>(ph);
     PF_REQUIRE(p, "predictor_debug_poison: null");
-    return poison({&p->col, &p->conv, &p->alphas, &p->peaks, &p->rems, &p->flags, &p->nfires}, byte);
+    return poison({&p->conv, &p->st[0].alphas, &p->st[0].peaks, &p->st[0].rems, &p->st[0].flags, &p->st[0].nfires, &p->st[1].alphas, &p->st[1].peaks,
+                   &p->st[1].rems, &p->st[1].flags, &p->st[1].nfires}, byte);
 }
 int pf_encoder_set_row_packing(pf_encoder* eh, int32_t extra_rows) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);

@@ -72,12 +72,7 @@ struct DevBuf {
 
 // the fused feed-forward runs ONE 128-row workgroup per CU: take it where the workgroups fill whole rounds of the CUs to >= 85 %
 static inline bool ffn_fills_rounds(int M) {
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
-        return n;
-    }();
+    const int n_cu = device_cu_count();
     const int blocks = ceil_div(M, 128), rounds = ceil_div(blocks, n_cu);
     return blocks >= (int)(0.85 * rounds * n_cu);
 }
@@ -402,12 +397,7 @@ static inline float pow2f(int e) { return ldexpf(1.f, e); }
 // the form of the block's w_2 projection (Encoder.w2_row): true = full-row kernel, false = tile GEMM + separate LayerNorm launch
 static inline bool encoder_w2_row_form(const Encoder* e, int M) {
     if (e->w2_row != 2) return e->w2_row == 1;
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
-        return n;
-    }();
+    const int n_cu = device_cu_count();
     const int blocks = ceil_div(M, 256) * (e->cfg.d_model / 256), rounds = ceil_div(blocks, n_cu);
     return !(e->cfg.d_model % 256 == 0 && blocks >= (int)(0.65 * rounds * n_cu));
 }
@@ -440,8 +430,11 @@ struct EncChunkCtx {
 struct Predictor {
     pf_predictor_config cfg;
     TensorTable tt;
-    DevBuf col, conv, lens, alphas, peaks, rems, flags, nfires;
-    int last_B = 0, last_T = 0;
+    DevBuf col, conv, zero_row;
+    // the scan state of one batch (what pf_predictor_embeds reads back). Two slots: the split-phase pipeline (engine_pipeline.hip)
+    // runs batch i + 1's encoder + scan before batch i's decoder, so batch i's state must survive that; the module-level entry
+    // points (pf_predictor_alphas / _embeds / _timestamp) use slot 0
+    struct CifState { DevBuf lens, alphas, peaks, rems, flags, nfires; int B = 0, T = 0; } st[2];
     // CifPredictorV3 (bicif_paraformer/cif_predictor.py:121-384): sequential fp32 CIF + the upsampled timestamp head
     bool v3 = false;
     pf_predictor_v3_config c3{};
@@ -449,6 +442,13 @@ struct Predictor {
     bool packed = false;                 // pack = both directions' re-laid weight_hh, then bias_ih, bias_hh back to back
     std::vector<int32_t> ul_host;
 };
+
+// the predictor's two phases without the host synchronisation between them (engine_decoder.hip; engine_pipeline.hip drives them)
+int predictor_alphas_enqueue(Predictor* p, int slot, const float* hidden, const int32_t* lens_host, int B, int T, hipStream_t s);
+const int32_t* predictor_counts_dev(Predictor* p, int slot);
+const float* predictor_alphas_dev(Predictor* p, int slot);
+const float* predictor_peaks_dev(Predictor* p, int slot);
+int predictor_embeds_slot(Predictor* p, int slot, const float* hidden, int B, int T, int N, float* embeds, hipStream_t s);
 
 // ================================================================================================= decoder
 struct DecLayerW {

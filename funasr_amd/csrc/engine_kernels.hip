@@ -33,6 +33,17 @@ int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, cons
     return gemm_simple(A, lda, W, ldw, bias, C, ldc, M, N, K, relu, R1, ldr1, R2, ldr2,
                        reinterpret_cast<hipStream_t>(stream));
 }
+/* Conv1d over time as ONE exact-fp32 GEMM with the im2col gathered by the operand loads (gemm_f32.hip, GemmArgs.conv_*; the
+ * predictor's cif_conv1d, cif_predictor.py:275-278): C [B T, N] = relu?(col(hidden) W^T + bias), hidden [B, T, D], W [N, taps D]
+ * with column tap * D + c = torch's weight[n, c, tap]; zero_dev: >= 128 B of zeros. Bitwise pf_k_gemm_f32 on the materialised
+ * column matrix. */
+int pf_k_conv1d_gemm_f32(const float* hidden, const float* W, const float* bias, float* C, int32_t B, int32_t T, int32_t D,
+                         int32_t N, int32_t taps, int32_t left, int32_t relu, const float* zero_dev, void* stream) {
+    GemmArgs g{};
+    g.A = hidden; g.lda = D; g.W = W; g.ldw = taps * D; g.bias = bias; g.C = C; g.ldc = N; g.M = B * T; g.N = N; g.K = taps * D;
+    g.relu = relu; g.conv_taps = taps; g.conv_D = D; g.conv_T = T; g.conv_left = left; g.conv_zero = zero_dev;
+    return launch_gemm_f32(g, reinterpret_cast<hipStream_t>(stream));
+}
 /* bf16-operand GEMM (throughput mode): A [M,K] bf16, W [N,K] bf16, fp32 accumulate, fp32 bias/residuals, C fp32 or
  * bf16 (c_bf16); strides in elements */
 int pf_k_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const float* R1,

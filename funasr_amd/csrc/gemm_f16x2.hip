@@ -440,11 +440,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int WM, int WN, int MODE, int OUT, int ABL = 0, int SCHED = 0, int WGM = 4, int KS_ = 32>
 int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     typedef Geo2<WM, WN, WGM, KS_> G;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<WM, WN, MODE, OUT, ABL, SCHED, WGM, KS_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
-        configured = true;
+        configured.mark();
     }
     const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
     const int nMpad = (nM + 7) / 8 * 8;
@@ -492,13 +492,7 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // time in whole rounds over the CUs: 290 wide blocks on 256 CUs are two rounds, 580 narrow ones three half-rounds.
     // The choice moves no result: both shapes issue the same products in the same k order per output element (bitwise
     // equal, tested), so a clip's result still does not depend on what else is in the batch.
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
-            n = pr.multiProcessorCount;
-        return n;
-    }();
+    const int n_cu = device_cu_count();
     const long m_tiles = ceil_div(a.M, 256);
     const long wide_blocks = m_tiles * (a.N / 256), narrow_blocks = m_tiles * ceil_div(a.N, 128);
     const double cost_wide = (double)((wide_blocks + n_cu - 1) / n_cu), cost_narrow = 0.57 * (double)((narrow_blocks + n_cu - 1) / n_cu);
@@ -644,7 +638,12 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
                    "gemm_f16x2: QKV outputs");
     }
     // the four-wave 256 x 256 shape (gemm_f16x2_w4.hip): tile 7; bits 4.. = its measurement builds
-    if ((a.tile & 15) == 7) return launch_gemm_f16x2_w4(a, a.tile >> 4, stream);
+    if ((a.tile & 15) == 7) {
+        if (gemm_f16x2_w4_ok(a)) return launch_gemm_f16x2_w4(a, a.tile >> 4, stream);
+        Gemm2Args b = a;                    // a shape the four-wave block does not take (N % 256 != 0, K < 64): chosen by shape instead
+        b.tile = 0;
+        return launch_gemm_f16x2(b, stream);
+    }
     if (a.qkv_D > 0) {
         if (a.tile == 5) return launch_pair<0, 2>(a, stream);
         if (a.tile == 6) return launch_ring<0, 2>(a, stream);
@@ -657,13 +656,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
             //   head / tail split: the whole rounds as 256 x 256 blocks, the rows behind them as 128 x 128 blocks in a second
             //     launch (+0.65: a launch boundary and one small round) -- 198 us instead of 218 at M = 33 536.
             // Row ranges are independent and all shapes give the same bits (tested), so the choice may depend on M.
-            static const int n_cu = [] {
-                int dev = 0, n = 256;
-                hipDeviceProp_t pr;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
-                    n = pr.multiProcessorCount;
-                return n;
-            }();
+            const int n_cu = device_cu_count();
             const int nN = a.N / 256, m_tiles = ceil_div(a.M, 256);
             const long blocks = (long)m_tiles * nN, full = blocks / n_cu, rem = blocks % n_cu;
             const double cost_wide = (double)(full + (rem ? 1 : 0));

@@ -143,11 +143,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
 
 template <int MODE, bool LN, bool A_NT, int SCHED = 2>
 int launch_row_t(const GemmRowArgs& a, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_row_kernel<MODE, LN, A_NT, SCHED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RW_LDS_B));
-        configured = true;
+        configured.mark();
     }
     hipLaunchKernelGGL((gemm_f16x2_row_kernel<MODE, LN, A_NT, SCHED>), dim3((unsigned)ceil_div(a.M, RW_BM)), dim3(512), RW_LDS_B, stream, a);
     PF_HIP_TRY(hipGetLastError());
@@ -189,13 +189,7 @@ int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream) {
     // (tools/bench_r03.py `row8`). Both kernels give the same bits, so the choice may depend on the batch's row count.
     int bm = a.block_rows;
     if (bm == 0) {
-        static const int n_cu = [] {
-            int dev = 0, n = 256;
-            hipDeviceProp_t pr;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
-                n = pr.multiProcessorCount;
-            return n;
-        }();
+        const int n_cu = device_cu_count();
         const double cost128 = (double)ceil_div(ceil_div(a.M, 128), n_cu), cost96 = 0.80 * (double)ceil_div(ceil_div(a.M, 96), n_cu);
         bm = cost96 < cost128 - 0.02 ? 96 : 128;
     }

@@ -327,11 +327,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row8_kernel(GemmRowArgs p) 
 template <int WM, int MODE, bool LN, bool A_NT>
 int launch_row8_t(const GemmRowArgs& a, hipStream_t stream) {
     typedef R8Geo<WM> G;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_row8_kernel<WM, MODE, LN, A_NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
-        configured = true;
+        configured.mark();
     }
     hipLaunchKernelGGL((gemm_f16x2_row8_kernel<WM, MODE, LN, A_NT>), dim3((unsigned)ceil_div(a.M, G::BM)), dim3(512), G::LDS_B, stream, a);
     PF_HIP_TRY(hipGetLastError());

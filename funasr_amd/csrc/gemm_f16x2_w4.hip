@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_row_kernel(GemmRowArgs p
 template <int MODE, int OUT, int EABL = 0, int NODMA = 0>
 int launch_w4(const Gemm2Args& a, hipStream_t stream) {
     typedef W4Geo<2, 2> G;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_w4_kernel<MODE, OUT, EABL, NODMA>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
-        configured = true;
+        configured.mark();
     }
     const int nM = ceil_div(a.M, G::BM), nN = ceil_div(a.N, G::BN);
     const int nMpad = (nM + 7) / 8 * 8;
@@ -249,11 +249,11 @@ int launch_w4(const Gemm2Args& a, hipStream_t stream) {
 template <int MODE, bool LN, bool A_NT>
 int launch_w4_row_t(const GemmRowArgs& a, hipStream_t stream) {
     typedef W4Geo<1, 4> G;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_w4_row_kernel<MODE, LN, A_NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_B));
-        configured = true;
+        configured.mark();
     }
     hipLaunchKernelGGL((gemm_f16x2_w4_row_kernel<MODE, LN, A_NT>), dim3((unsigned)ceil_div(a.M, G::BM)), dim3(256), G::LDS_B, stream, a);
     PF_HIP_TRY(hipGetLastError());

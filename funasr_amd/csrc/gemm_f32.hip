@@ -52,7 +52,8 @@ constexpr int MODE_ARGMAX = 4;   // MODE bit 0: + R1, bit 1: + R2; 4: fused arg-
 // TM = 32-row MFMA tiles per wave in M: 2 -> the 128 x 128 block tile; 1 -> a 64 x 128 block tile, chosen by the
 // launcher when the 128-row grid would leave most CUs idle (decoder-sized problems: twice the workgroups, same
 // per-element fma chain, so the choice never changes a bit of the result)
-template <int MODE, bool BF16, int TM>
+// CONV: the A operand is the im2col of a Conv1d over time, gathered by the DMA sources (GemmArgs.conv_*)
+template <int MODE, bool BF16, int TM, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int nM, int nN) {
     constexpr int BM = 64 * TM;
     constexpr int ES = BF16 ? 2 : 4;                  // operand element size
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
     //      lane l of a piece lands at row (l >> 3), physical chunk (l & 7)
     const char* asrc[2 * TM];
     const char* wsrc[4];
+    const char* zsrc[2 * TM];   // CONV: this lane's chunk of the zero row
+    int at[2 * TM];             // CONV: the row's time index inside its sequence
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = wave * 32 + i * 8 + (lane >> 3);
@@ -91,6 +94,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
         int row = m0 + r;
         row = row < p.M ? row : p.M - 1;
         asrc[i] = reinterpret_cast<const char*>(p.A) + ((size_t)row * p.lda) * ES + c * 16;
+        if constexpr (CONV) {
+            at[i] = row % p.conv_T;
+            zsrc[i] = reinterpret_cast<const char*>(p.conv_zero) + c * 16;
+        }
     }
     const int nk = p.K / BK;
 
@@ -100,8 +107,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p, int n
         // issued from inline asm (common.h: glds16) so that the prefetch really stays in flight under the MFMAs of
         // the current tile
         const unsigned off = (unsigned)buf * (BUF_FLOATS * 4);
+        if constexpr (CONV) {
+            // K tile kt lies inside tap `tap`: the rows `shift` frames away, columns kin .. kin + 31 (zeros outside the sequence)
+            const int k0 = kt * BK, tap = k0 / p.conv_D, kin = k0 - tap * p.conv_D, shift = tap - p.conv_left;
+            const ptrdiff_t delta = ((ptrdiff_t)shift * p.lda + kin) * ES;
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i) {
+                const int ts = at[i] + shift;
+                glds16((ts >= 0 && ts < p.conv_T) ? asrc[i] + delta : zsrc[i], lds_a + off + i * 8 * ROW_BYTES);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 2 * TM; ++i) glds16(asrc[i] + kt * ROW_BYTES, lds_a + off + i * 8 * ROW_BYTES);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(wsrc[i] + kt * ROW_BYTES, lds_b + off + i * 8 * ROW_BYTES);
     };
@@ -310,6 +328,15 @@ int launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
     }
     const dim3 grid((unsigned)nMpad * nN), block(256);
     const int mode = a.amax_val ? MODE_ARGMAX : ((a.R1 ? 1 : 0) | (a.R2 ? 2 : 0));
+    if (a.conv_taps > 0) {
+        PF_REQUIRE(!a.ab_bf16 && mode == 0 && a.conv_zero && a.conv_D % 32 == 0 && a.K == a.conv_taps * a.conv_D && a.conv_T > 0 &&
+                   a.M % a.conv_T == 0 && a.conv_left >= 0 && a.conv_left < a.conv_taps && ((uintptr_t)a.conv_zero & 15) == 0,
+                   "gemm: the im2col form needs fp32 operands, no addends, conv_D % 32 == 0, K == taps * conv_D, M == B * conv_T");
+        if (half_tile) hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, false, 1, true>), grid, block, 0, stream, g, nM, nN);
+        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<0, false, 2, true>), grid, block, 0, stream, g, nM, nN);
+        PF_HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #define PF_LAUNCH_GEMM(MODE_)                                                                                          \
     do {                                                                                                               \
         if (a.ab_bf16) {                                                                                               \

@@ -280,11 +280,11 @@ __global__ __launch_bounds__(SK_KW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
 template <int RM, int CN>
 int launch_skinny_batch_t(const GemmArgs& a, const GemmBatch& t, hipStream_t stream) {
     constexpr int lds = SK_KW * RM * 16 * (CN * 16 + 1) * (int)sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_batch_kernel<RM, CN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
+        configured.mark();
     }
     dim3 grid(ceil_div(a.N, 16 * CN), ceil_div(a.M, 16 * RM), t.n), block(SK_KW * 64);
     hipLaunchKernelGGL((gemm_skinny_batch_kernel<RM, CN>), grid, block, lds, stream, a, t);
@@ -295,11 +295,11 @@ int launch_skinny_batch_t(const GemmArgs& a, const GemmBatch& t, hipStream_t str
 template <int RM, int CN, int LNIN>
 int launch_skinny_t(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = SK_KW * RM * 16 * (CN * 16 + 1) * (int)sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<RM, CN, LNIN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
+        configured.mark();
     }
     dim3 grid(ceil_div(a.N, 16 * CN), ceil_div(a.M, 16 * RM)), block(SK_KW * 64);
     hipLaunchKernelGGL((gemm_skinny_kernel<RM, CN, LNIN>), grid, block, lds, stream, a);

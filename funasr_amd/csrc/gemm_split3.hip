@@ -223,11 +223,11 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
 template <int MODE, bool OUT3, int KS>
 int launch_ks(const Gemm3Args& a, int nM, int nN, hipStream_t stream) {
     constexpr int LDS_B = 2 * Geo<KS>::STAGE_B;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split3_kernel<MODE, OUT3, KS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-        configured = true;
+        configured.mark();
     }
     const int nMpad = (nM + 7) / 8 * 8;
     hipLaunchKernelGGL((gemm_split3_kernel<MODE, OUT3, KS>), dim3((unsigned)nMpad * nN), dim3(512), LDS_B, stream, a, nM, nN);

@@ -44,6 +44,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add1=None, add
     return out
 
 
+def conv1d_gemm(hidden: torch.Tensor, w: torch.Tensor, bias=None, left: int = 1, relu=False):
+    """Conv1d over time as one exact-fp32 GEMM, im2col gathered by the operand loads (pf_k_conv1d_gemm_f32): hidden [B, T, D],
+    w [N, taps * D] (column tap * D + c) -> [B * T, N]."""
+    lib = _lib.load()
+    _f32c(hidden, "hidden"), _f32c(w, "w")
+    B, T, D = hidden.shape
+    N, taps = w.shape[0], w.shape[1] // D
+    out = torch.empty(B * T, N, device=hidden.device, dtype=torch.float32)
+    zero = torch.zeros(64, device=hidden.device, dtype=torch.float32)
+    _lib.check(lib.pf_k_conv1d_gemm_f32(_ptr(hidden), _ptr(w), _ptr(bias), _ptr(out), B, T, D, N, taps, left, int(relu), _ptr(zero),
+                                        _stream()), "pf_k_conv1d_gemm_f32")
+    return out
+
+
 def gemm_small_m_ln(a: torch.Tensor, w: torch.Tensor, bias=None, relu=False, add2=None, stats_in=None, ln=None, want_stats=False,
                     four_workgroups=False, out_gamma=None, a_has_gamma=False):
     """The small-M GEMM with a LayerNorm carried between GEMMs (gemm_skinny.hip). want_stats returns the [M, N / 16, 2] block

@@ -142,36 +142,75 @@ class Paraformer(nn.Module):
             self.__dict__["_pipe"] = cur = (key, h)
         return lib, cur[1]
 
+    def close(self):
+        """Frees the pipeline object's device buffers (encoder outputs of two batches, embeds, ids). The module handles stay."""
+        cur = self.__dict__.pop("_pipe", None)
+        if cur is not None:
+            try:
+                _lib.load().pf_paraformer_destroy(cur[1])
+            except Exception:
+                pass
+
+    def __del__(self):
+        self.close()
+
+    # the pipeline handle is a raw pointer into this process's library: never copied or pickled with the module
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ("_pipe", "_host_ring"):
+            st.pop(k, None)
+        return st
+
+    def begin_features(self, speech: torch.Tensor, speech_lengths):
+        """Phase 1 of the offline forward (include/paraformer_hip.h pf_paraformer_begin): encoder + predictor scan ENQUEUED on the
+        current HIP stream, no host synchronisation; returns a ticket for `finish_features`. A serving loop issues
+        begin(batch i + 1) BEFORE finish(batch i): the CIF token count (the .item() of cif_predictor.py:311) still sizes the
+        decoder exactly, but while the host reads it the GPU already holds the next batch's encoder."""
+        if not self._one_call_ok():
+            raise RuntimeError("begin_features: the split-phase forward exists for the plain offline model (CifPredictorV2 + ParaformerSANMDecoder)")
+        lib, h = self._pipeline()
+        enc_m = self.encoder
+        enc_m.set_row_packing(max(1, int(self.predictor.r_order)))
+        lib_e, he = enc_m._ensure_handle()
+        enc_m._apply_settings(lib_e, he)
+        self.decoder._apply_settings()
+        dev = enc_m._handle_device
+        xs = speech.to(device=dev, dtype=torch.float32).contiguous()
+        B, T, Din = xs.shape
+        if Din != enc_m._input_size:
+            raise ValueError(f"expected feature dim {enc_m._input_size}, got {Din}")
+        lens_c, _ = host_i32(speech_lengths, B)
+        pe = enc_m._pe_table(T, dev)
+        with torch.cuda.device(dev):
+            t = lib.pf_paraformer_begin(h, xs.data_ptr(), lens_c, B, T, pe.data_ptr(), stream_ptr())
+        if t < 0:
+            _lib.check(t, "pf_paraformer_begin")
+        return dict(ticket=t, B=B, T=T, dev=dev, keep=(xs, lens_c, pe))
+
+    def finish_features(self, ticket: dict):
+        """Phase 2 (pf_paraformer_finish): waits for the ticket's token counts only, enqueues embeds + decoder + fused arg-max and
+        the ids' D2H copy; returns what `enqueue_features` returns (`collect()` brings the ids to the host)."""
+        lib, h = self._pipeline()
+        B, T, dev = ticket["B"], ticket["T"], ticket["dev"]
+        tok_c = (C.c_int32 * B)()
+        ids = torch.empty(B, T + 1, device=dev, dtype=torch.int32)          # a CIF fires at most once per frame (+ the tail)
+        with torch.cuda.device(dev):
+            n = lib.pf_paraformer_finish(h, ticket["ticket"], ids.data_ptr(), T + 1, tok_c, None, None, stream_ptr())
+        if n < 0:
+            _lib.check(n, "pf_paraformer_finish")
+        tok = [int(v) for v in tok_c]
+        pending = dict(tok=tok, ids=ids if n >= 1 else None, B=B, keep=ticket["keep"])
+        if n >= 1:
+            pending["ids_host"] = (ids, self.__dict__.setdefault("_host_ring", HostCopyRing()).start(ids))
+        return pending
+
     def enqueue_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
-        """[B, T, 560] features -> everything up to the fused arg-max ENQUEUED on the current HIP stream. The only host
-        synchronisation inside is the CIF token count (it sizes the decoder, like the .item() at cif_predictor.py:311).
-        `collect()` brings the ids to the host; a serving loop enqueues batch i+1 before collecting batch i, so the
-        GPU never waits for the host-side post-processing."""
+        """[B, T, 560] features -> everything up to the fused arg-max ENQUEUED on the current HIP stream. The only host wait
+        inside is for the CIF token count (it sizes the decoder, like the .item() at cif_predictor.py:311); `begin_features` /
+        `finish_features` are its two halves for loops that interleave batches. `collect()` brings the ids to the host; a serving
+        loop enqueues batch i+1 before collecting batch i, so the GPU never waits for the host-side post-processing."""
         if not return_intermediate and self._one_call_ok():
-            lib, h = self._pipeline()
-            enc_m = self.encoder
-            enc_m.set_row_packing(max(1, int(self.predictor.r_order)))
-            lib_e, he = enc_m._ensure_handle()
-            enc_m._apply_settings(lib_e, he)
-            self.decoder._apply_settings()
-            dev = enc_m._handle_device
-            xs = speech.to(device=dev, dtype=torch.float32).contiguous()
-            B, T, Din = xs.shape
-            if Din != enc_m._input_size:
-                raise ValueError(f"expected feature dim {enc_m._input_size}, got {Din}")
-            lens_c, _ = host_i32(speech_lengths, B)
-            tok_c = (C.c_int32 * B)()
-            ids = torch.empty(B, T + 1, device=dev, dtype=torch.int32)          # a CIF fires at most once per frame (+ the tail)
-            pe = enc_m._pe_table(T, dev)
-            with torch.cuda.device(dev):
-                n = lib.pf_paraformer_forward(h, xs.data_ptr(), lens_c, B, T, pe.data_ptr(), ids.data_ptr(), T + 1, tok_c, None, None, stream_ptr())
-            if n < 0:
-                _lib.check(n, "pf_paraformer_forward")
-            tok = [int(v) for v in tok_c]
-            pending = dict(tok=tok, ids=ids if n >= 1 else None, B=B, keep=(xs, lens_c))
-            if n >= 1:
-                pending["ids_host"] = (ids, self.__dict__.setdefault("_host_ring", HostCopyRing()).start(ids))
-            return pending
+            return self.finish_features(self.begin_features(speech, speech_lengths))
         enc, olens = self.encode(speech, speech_lengths, all_rows=return_intermediate)
         embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
         tok = [int(round(v)) for v in token_num.tolist()]           # pre_token_length.round().long(), model.py:614

@@ -51,8 +51,9 @@ extern "C" {
 
 /* 2 (round 5): everything added since the first release is covered by one number a dlsym-binding host can test -- pf_dp_*
  * (incl. pf_dp_broadcast_raw), pf_stream_step_begin / _end, pf_frontend_set_dither / _verify, pf_paraformer_forward, the
- * pf_k_* measurement entries. A library reporting 1 has none of them. */
-#define PF_ABI_VERSION 2
+ * pf_k_* measurement entries. A library reporting 1 has none of them.
+ * 3 (round 6): + pf_paraformer_begin / pf_paraformer_finish (the split-phase offline forward). */
+#define PF_ABI_VERSION 3
 
 const char* pf_last_error(void);
 int pf_abi_version(void);
@@ -270,8 +271,19 @@ void pf_paraformer_destroy(pf_paraformer* m);
 int pf_paraformer_forward(pf_paraformer* m, const float* feats_dev, const int32_t* lens_host, int32_t B, int32_t T,
                           const float* pe_dev, int32_t* ids_dev, int32_t ids_ld, int32_t* token_num_host,
                           float* alphas_dev, float* peaks_dev, void* stream);
-/* the last forward's encoder output [B, T, d_model] / acoustic embeddings [B, N, d_model] (library-owned; valid until the
- * next forward of this object) */
+/* The same forward in its two phases, for serving loops (round 6). pf_paraformer_begin ENQUEUES encoder + predictor (alphas, scan)
+ * and the token counts' copy to a pinned host buffer, and returns a ticket (0 / 1) without any host synchronisation;
+ * pf_paraformer_finish(ticket) waits for THAT copy (an event of this batch, not the stream), fills token_num_host, enqueues
+ * embeds + decoder + arg-max and returns N like pf_paraformer_forward. Two batches may be in flight: issue begin(i + 1) BEFORE
+ * finish(i) and the stream holds batch i + 1's encoder while the host reads batch i's counts -- the decoder is still sized by the
+ * exact CIF count (cif_predictor.py:311), but the GPU never waits for the host. Tickets are finished in the order they were begun;
+ * lens_host is copied by begin. (A V3 predictor keeps one scan state: one batch in flight.) pf_paraformer_forward == begin + finish. */
+int pf_paraformer_begin(pf_paraformer* m, const float* feats_dev, const int32_t* lens_host, int32_t B, int32_t T,
+                        const float* pe_dev, void* stream);
+int pf_paraformer_finish(pf_paraformer* m, int32_t ticket, int32_t* ids_dev, int32_t ids_ld, int32_t* token_num_host,
+                         float* alphas_dev, float* peaks_dev, void* stream);
+/* the last finished forward's encoder output [B, T, d_model] / acoustic embeddings [B, N, d_model] (library-owned; valid until
+ * the next begin into the same slot / the next finish of this object) */
 const float* pf_paraformer_encoder_out(const pf_paraformer* m);
 const float* pf_paraformer_embeds(const pf_paraformer* m);
 
@@ -469,6 +481,12 @@ int pf_set_skinny_max_m(int32_t m);
 int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R1,
                   int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc, int32_t M, int32_t N,
                   int32_t K, int32_t relu, void* stream);
+/* Conv1d over time as one exact-fp32 GEMM whose im2col is gathered by the operand loads (the predictor's cif_conv1d,
+ * funasr/models/paraformer/cif_predictor.py:275-278): hidden [B, T, D], W [N, taps * D] (column tap * D + c = weight[n, c, tap]),
+ * C [B * T, N]; rows t + tap - left outside [0, T) read as zero; zero_dev: >= 128 B of zeros; D % 32 == 0. Bitwise pf_k_gemm_f32
+ * on the materialised column matrix. */
+int pf_k_conv1d_gemm_f32(const float* hidden, const float* W, const float* bias, float* C, int32_t B, int32_t T, int32_t D,
+                         int32_t N, int32_t taps, int32_t left, int32_t relu, const float* zero_dev, void* stream);
 /* bf16-operand GEMM of the throughput mode: A [M,K] bf16, W [N,K] bf16 (strides in elements), fp32 accumulate on
  * v_mfma_f32_32x32x16_bf16, fp32 bias / residuals, C fp32 (c_bf16 = 0) or bf16 (1). K % 64 == 0. */
 int pf_k_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const float* R1,

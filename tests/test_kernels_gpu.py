@@ -26,6 +26,25 @@ def gemm_path(request):
     lib.pf_set_skinny_max_m(0)
 
 
+@pytest.mark.parametrize("B,T,D,taps,left", [(3, 37, 512, 3, 1), (64, 500, 512, 3, 1), (2, 5, 64, 5, 2), (1, 1, 32, 3, 1), (5, 130, 96, 2, 0)])
+def test_conv1d_gathered_by_the_gemm_loads_is_bitwise_the_im2col_gemm(cuda, B, T, D, taps, left):
+    """cif_conv1d (funasr/models/paraformer/cif_predictor.py:275-278) without the materialised column matrix: the same k order per
+    output element, so the same bits as the im2col GEMM of rounds 1-5 -- and fp32-close to torch's conv1d."""
+    from funasr_amd import ops
+    g = torch.Generator().manual_seed(B * 31 + T)
+    h = torch.randn(B, T, D, generator=g)
+    weight = torch.randn(D, D, taps, generator=g) / math.sqrt(D * taps)                  # torch Conv1d layout [out, in, tap]
+    bias = torch.randn(D, generator=g)
+    w = weight.permute(0, 2, 1).reshape(D, taps * D).contiguous()                        # column tap * D + c
+    pad = torch.nn.functional.pad(h, (0, 0, left, taps - 1 - left))
+    col = torch.cat([pad[:, k:k + T] for k in range(taps)], dim=-1).reshape(B * T, taps * D).contiguous()
+    got = ops.conv1d_gemm(h.cuda(), w.cuda(), bias.cuda(), left=left, relu=True)
+    want = ops.gemm(col.cuda(), w.cuda(), bias.cuda(), relu=True)
+    assert torch.equal(got, want)
+    ref = torch.relu(torch.nn.functional.conv1d(pad.transpose(1, 2).double(), weight.double(), bias.double())).transpose(1, 2).reshape(B * T, D)
+    assert _rel(got.cpu(), ref) < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 512, 512), (500, 1536, 576), (333, 8404, 512),
                                    (1000, 512, 2048), (64, 1, 64), (7, 130, 96), (15, 1536, 576), (20, 8404, 512),
                                    (960, 2048, 512)])

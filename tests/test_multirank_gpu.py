@@ -79,6 +79,28 @@ def test_bench_two_ranks_prints_one_whole_job_line(cuda):
     assert "roofline" in d and d["roofline"]["frac"] > 0
 
 
+@pytest.mark.timeout(1500)
+def test_bench_eight_ranks_dry_run_on_one_gpu(cuda):
+    """The driver's 8-GPU command with every rank on the one visible GPU (gloo): what an 8 x MI355X node will run first
+    (BASELINE configs[3]; the reference's recipe is one process per GPU, examples/aishell/paraformer/run.sh:135-190). One
+    whole-job line from rank 0, eight per-rank times, the 880-MB weight arena broadcast once, every rank pinned to its own
+    host cores, no CPU-baseline leg at N > 1. Smaller batches than the headline (eight replicas share one GPU's memory and time)."""
+    out = _run(_torchrun(8, ["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "16", "--dist-backend", "gloo"]), 1400)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["rccl_ranks"] == 8 and c["parallelism"] == "utterance-dp8" and d["scaling"] == "weak"
+    assert len(c["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in c["per_rank_ms_per_step"])
+    assert max(c["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=1e-2)
+    assert 8.0e8 < c["weight_arena_bytes_broadcast"] < 9.6e8 and c["weights_route"] == "arena"
+    assert len(c["weight_broadcast_seconds_per_rank"]) == 8
+    assert c["hypothesis_gather_bytes_per_rank_per_step"] == 16 * 513 * 4
+    assert c["host_cores_rank0"] is not None and c["host_cores_rank0"]["threads"] >= 1
+    assert abs(d["value"] - 8 * 16 * 30.0 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01
+    assert "cpu_baseline" not in d                      # N = 1 only (and only rank 0 would run it)
+
+
 @pytest.mark.timeout(900)
 def test_bench_bare_command_launches_its_own_ranks(cuda):
     """the driver's literal command, NO torchrun wrapper: `python bench.py --gpus 2 ...` must itself become a 2-rank job

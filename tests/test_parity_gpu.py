@@ -306,6 +306,55 @@ def test_one_call_forward_is_bitwise_the_module_chain(cuda, f32_mode):
     assert (rc < 0 and "ids_ld" in _lib.last_error()) or max(tok) <= 1
 
 
+def test_two_phase_forward_interleaved_across_batches_is_bitwise_the_one_call_forward(cuda, f32_mode):
+    """include/paraformer_hip.h pf_paraformer_begin / _finish: batch i + 1's encoder + CIF scan are enqueued BEFORE batch i's token
+    counts are read and its decoder launched (the serving loop of bench.py). The decoder is still sized by the exact count (the
+    .item() at funasr/models/paraformer/cif_predictor.py:311), so ids and counts are those of the one-call forward, whatever the
+    interleaving -- batches of different shapes, a batch in which nothing fires in the middle; misuse is an error, not a corruption."""
+    from funasr_amd import _lib
+    from funasr_amd.paraformer import Paraformer
+    cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=3, dec_blocks=2, vocab=97)
+    model = Paraformer.from_config(cfg)
+    model.load_state_dict(synth.paraformer_state_dict(cfg, seed=5, cif_bias=-0.3), strict=False)
+    model = model.to(cuda).set_precision(f32_mode)
+    g = torch.Generator().manual_seed(21)
+    shapes = [(5, 77, [77, 60, 33, 77, 9]), (2, 120, [120, 64]), (3, 4, [1, 1, 1]), (7, 50, [50, 49, 48, 10, 50, 3, 25]), (1, 200, [200])]
+    batches = []
+    for B, T, lens in shapes:
+        f = torch.randn(B, T, 560, generator=g) * 0.7
+        if T == 4:
+            f = torch.full((B, T, 560), -50.0)             # far below the threshold: nothing fires (model.py:615-616)
+        batches.append((f.to(cuda), torch.tensor(lens, dtype=torch.int32)))
+    want = [model.recognize_features(f, l) for f, l in batches]
+    assert max(want[0]["token_num"]) >= 1
+    # the loop of bench.py: begin(i + 1), finish(i), collect(i - 1)
+    got, ticket, pending = [], model.begin_features(*batches[0]), None
+    for i in range(1, len(batches)):
+        nxt = model.begin_features(*batches[i])
+        fin = model.finish_features(ticket)
+        if pending is not None:
+            got.append(model.collect(pending))
+        pending, ticket = fin, nxt
+    fin = model.finish_features(ticket)
+    got.append(model.collect(pending))
+    got.append(model.collect(fin))
+    for w, r in zip(want, got):
+        assert r["token_num"] == w["token_num"] and r["raw_ids"] == w["raw_ids"] and r["ids"] == w["ids"]
+    # three batches in flight: refused; the two begun ones still finish correctly
+    t0 = model.begin_features(*batches[0])
+    t1 = model.begin_features(*batches[1])
+    with pytest.raises(RuntimeError, match="both slots are in flight"):
+        model.begin_features(*batches[3])
+    r0 = model.collect(model.finish_features(t0))
+    r1 = model.collect(model.finish_features(t1))
+    assert r0["raw_ids"] == want[0]["raw_ids"] and r1["raw_ids"] == want[1]["raw_ids"]
+    with pytest.raises(RuntimeError, match="not in flight"):
+        model.finish_features(t1)
+    model.close()                                            # and the object can be dropped and rebuilt
+    again = model.recognize_features(*batches[0])
+    assert again["raw_ids"] == want[0]["raw_ids"]
+
+
 def test_pred_timestamp_follows_the_reference_call(cuda):
     """Paraformer.inference(pred_timestamp=True) (paraformer/model.py:668-681): per utterance the reference calls
     ts_prediction_lfr6_standard(pre_peak_index[i], alphas[i], tokens, vad_offset=begin_time, upsample_rate=1) -- cif_peak
