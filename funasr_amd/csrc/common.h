@@ -354,6 +354,9 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream);
 // abl (measurement only): 0 product, 1 no global stores, 2 no epilogue, 3 no epilogue and no operand DMA
 bool gemm_f16x2_w4_ok(const Gemm2Args& a);
 int launch_gemm_f16x2_w4(const Gemm2Args& a, int abl, hipStream_t stream);
+// the persistent, wave-specialised 256 x 128 shape (gemm_f16x2_ps.hip; Gemm2Args.tile 10): bitwise the results of the other shapes
+bool gemm_f16x2_ps_ok(const Gemm2Args& a);
+int launch_gemm_f16x2_ps(const Gemm2Args& a, hipStream_t stream);
 struct GemmRowArgs;
 bool gemm_f16x2_w4_row_ok(const GemmRowArgs& a);
 int launch_gemm_f16x2_w4_row(const GemmRowArgs& a, hipStream_t stream);

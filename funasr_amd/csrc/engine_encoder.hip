@@ -530,10 +530,10 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129 || value == 130, "encoder_set_option: row_bm is 0, 96, 128, 129 or 130"); e->row_bm = value; return 0; }
     if (k == "row_sched") { PF_REQUIRE(value == 0 || value == 2, "encoder_set_option: row_sched is 0 or 2"); e->row_sched = value; return 0; }
-    if (k == "w2_tile") { PF_REQUIRE(value == 0 || value == 2 || value == 7 || value == 8, "encoder_set_option: w2_tile is 0, 2, 7 or 8"); e->w2_tile = value; return 0; }
+    if (k == "w2_tile") { PF_REQUIRE(value == 0 || value == 2 || value == 7 || value == 8 || value == 10, "encoder_set_option: w2_tile is 0, 2, 7, 8 or 10"); e->w2_tile = value; return 0; }
     if (k == "w2_row") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: w2_row is 0, 1 or 2"); e->w2_row = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
-    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7 || value == 8 || value == 9, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6, 7, 8 or 9"); e->gemm_tile = value; return 0; }
+    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7 || value == 8 || value == 9 || value == 10, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6, 7, 8, 9 or 10"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
     set_error("encoder_set_option: unknown key " + k);
     return -1;

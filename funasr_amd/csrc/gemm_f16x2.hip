@@ -638,6 +638,13 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
                    "gemm_f16x2: QKV outputs");
     }
     // the four-wave 256 x 256 shape (gemm_f16x2_w4.hip): tile 7; bits 4.. = its measurement builds
+    // the persistent wave-specialised shape (gemm_f16x2_ps.hip): tile 10; shapes it does not take are chosen by shape instead
+    if (a.tile == 10) {
+        if (gemm_f16x2_ps_ok(a)) return launch_gemm_f16x2_ps(a, stream);
+        Gemm2Args b = a;
+        b.tile = 0;
+        return launch_gemm_f16x2(b, stream);
+    }
     if ((a.tile & 15) == 7) {
         if (gemm_f16x2_w4_ok(a)) return launch_gemm_f16x2_w4(a, a.tile >> 4, stream);
         Gemm2Args b = a;                    // a shape the four-wave block does not take (N % 256 != 0, K < 64): chosen by shape instead
