@@ -250,8 +250,66 @@ def power_limited_peak(seconds=1.5):
         return {"TFLOPs": round(flops / m / 1e9, 1), "source": f"tools/micro/mfma_peak.so, live, {seconds:g} s on random planes",
                 "sclk_mhz_mean": tel.get("sclk_mhz_mean"), "power_w_mean": tel.get("power_w_mean")}
     except Exception as e:                              # noqa: BLE001  (an auxiliary measurement must not lose the line)
-        trace(f"power-limited peak not measured live ({e!r}); using the recorded run")
-        return {"TFLOPs": 1647.0, "source": "profiles/r05a_w4_first_run.jsonl (recorded: 1647 TFLOP/s at 1782 MHz, 1237 W)"}
+        trace(f"power-limited peak not measured live ({e!r}); the line carries the recorded figure, flagged, and no live fraction")
+        return {"TFLOPs": None, "recorded_TFLOPs": 1647.0,
+                "source": "NOT measured in this run; recorded: profiles/r05a_w4_first_run.jsonl (1647 TFLOP/s at 1782 MHz, 1237 W on another box)"}
+
+
+def apply_power_limited_peak(roofline: dict, plp: dict, products: int) -> dict:
+    """`roofline` + the power-limited ceiling of the matrix pipe (power_limited_peak()). A figure that was not measured in this run
+    never turns into a fraction of this run: `frac_of_power_limited_peak` is then null and the recorded number is labelled as such."""
+    live = plp.get("TFLOPs")
+    if live:
+        roofline.update(power_limited_peak=round(live / products, 1), power_limited_peak_executed_16bit=live,
+                        frac_of_power_limited_peak=round(roofline["achieved"] / (live / products), 4), power_limited_peak_source=plp["source"],
+                        power_limited_peak_sclk_mhz=plp.get("sclk_mhz_mean"), power_limited_peak_power_w=plp.get("power_w_mean"))
+    else:
+        roofline.update(power_limited_peak=None, frac_of_power_limited_peak=None, power_limited_peak_source=plp["source"],
+                        power_limited_peak_recorded=round(plp["recorded_TFLOPs"] / products, 1))
+    return roofline
+
+
+def assemble_roofline(gemm: dict, kname: str, peak: float, step_ms: float, pmc, products=None) -> dict:
+    """The `roofline` object of the line from the instrumented pass's figures for the dominant kernel family: `gemm` =
+    {work_per_step (algorithmic flops), ms_per_step (hipEvent time on the launch stream), launches_per_step}."""
+    ach = gemm["work_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12 if gemm["ms_per_step"] > 0 else 0.0
+    roofline = dict(bound="mfma", kernel=("gemm_f16x2_kernel + gemm_f16x2_row_kernel" if kname == "gemm_f16x2_" else kname), achieved=round(ach, 2), peak=round(peak, 1),
+                    unit="TFLOP/s", frac=round(ach / peak, 4), traffic=pmc[0] if pmc else None,
+                    traffic_unit="HBM bytes per launch (PMC)", traffic_source=pmc[1] if pmc else None,
+                    flops_per_launch=gemm["work_per_step"] / max(gemm["launches_per_step"], 1),
+                    avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
+                    launches_per_step=gemm["launches_per_step"],
+                    share_of_step=round(gemm["ms_per_step"] / step_ms, 3))
+    if products:
+        roofline.update(peak_note=f"dense 16-bit MFMA peak 2500 TFLOP/s / {products} products per fp32-equivalent product",
+                        executed_16bit_tflops=round(ach * products, 1), fp32_mfma_peak_for_comparison=PEAK_F32_MFMA_TFLOPS)
+    return roofline
+
+
+def assemble_line(*, value, dt, steps, warmup, world, dtype, B, seconds, token_num, arena_bytes, n_pad, per_rank_ms, bcast_all, weights_route,
+                  host_pin, roofline, kernels, telemetry, output_layer) -> dict:
+    """The contract part of the JSON line (what the driver reads) from plain values; tests/test_bench_contract.py checks its schema on
+    synthetic inputs. `value` = whole-job audio-seconds per second with the waveforms resident in HBM when the clock starts."""
+    return {
+        "metric": "audio-seconds/sec (RTF^-1) Paraformer-large 30s@bs64", "value": round(value, 1),
+        "unit": "audio-s/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"Paraformer-large (50 enc + 16 dec blocks, vocab 8404, random-init), "
+                               f"{B} x {seconds:g} s distinct 16 kHz clips per GPU, wav in HBM -> token ids on host",
+                   "h2d": "excluded (waveforms resident in HBM when the clock starts; the PCIe-inclusive rate is `pcie_inclusive`)",
+                   "clips_per_gpu": B, "clip_seconds": seconds, "parallelism": f"utterance-dp{world}",
+                   "tokens_per_clip": round(sum(token_num) / len(token_num), 1),
+                   "tokens_max": max(token_num), "tokens_min": min(token_num),
+                   "rccl_ranks": world, "weight_arena_bytes_broadcast": arena_bytes,
+                   "hypothesis_gather_bytes_per_rank_per_step": (B * (n_pad + 1) * 4) if world > 1 else 0,
+                   "per_rank_ms_per_step": per_rank_ms, "weight_broadcast_seconds_per_rank": bcast_all if world > 1 else None,
+                   "weights_route": weights_route if world > 1 else None, "host_cores_rank0": host_pin,
+                   "output_layer": output_layer},
+        "roofline": roofline, "kernels": kernels,
+        "sclk_mhz_mean": (telemetry or {}).get("sclk_mhz_mean"), "power_w_mean": (telemetry or {}).get("power_w_mean"),
+        "telemetry": telemetry,
+    }
 
 
 def read_prof(lib, steps):
@@ -461,19 +519,7 @@ def main():
     else:
         gemm, kname = prof["gemm_f32_mfma"], "gemm_f32_mfma_kernel"
         peak = PEAK_16BIT_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-    ach = gemm["work_per_step"] / (gemm["ms_per_step"] * 1e-3) / 1e12 if gemm["ms_per_step"] > 0 else 0.0
-    pmc = pmc_traffic(kname)
-    roofline = dict(bound="mfma", kernel=("gemm_f16x2_kernel + gemm_f16x2_row_kernel" if kname == "gemm_f16x2_" else kname), achieved=round(ach, 2), peak=round(peak, 1),
-                    unit="TFLOP/s", frac=round(ach / peak, 4), traffic=pmc[0] if pmc else None,
-                    traffic_unit="HBM bytes per launch (PMC)", traffic_source=pmc[1] if pmc else None,
-                    flops_per_launch=gemm["work_per_step"] / max(gemm["launches_per_step"], 1),
-                    avg_launch_ms=gemm["ms_per_step"] / max(gemm["launches_per_step"], 1),
-                    launches_per_step=gemm["launches_per_step"],
-                    share_of_step=round(gemm["ms_per_step"] / (dt / args.steps * 1e3), 3))
-    if args.precision in PRODUCTS:
-        n = PRODUCTS[args.precision]
-        roofline.update(peak_note=f"dense 16-bit MFMA peak 2500 TFLOP/s / {n} products per fp32-equivalent product",
-                        executed_16bit_tflops=round(ach * n, 1), fp32_mfma_peak_for_comparison=PEAK_F32_MFMA_TFLOPS)
+    roofline = assemble_roofline(gemm, kname, peak, dt / args.steps * 1e3, pmc_traffic(kname), PRODUCTS.get(args.precision))
     kernels = {k: dict(ms_per_step=round(v["ms_per_step"], 3), launches=v["launches_per_step"]) for k, v in prof.items()}
     for nm in ("gemm_f32_mfma", "gemm_split", "attention"):
         if prof[nm]["ms_per_step"] > 0:
@@ -488,27 +534,12 @@ def main():
                                                  - prof["attention"]["ms_per_step"], 2)
     trace("instrumented pass done")
 
-    line = {
-        "metric": "audio-seconds/sec (RTF^-1) Paraformer-large 30s@bs64", "value": round(value, 1),
-        "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": MODE_DTYPE[args.precision], "data": "synthetic",
-        "config": {"workload": f"Paraformer-large (50 enc + 16 dec blocks, vocab 8404, random-init), "
-                               f"{B} x {args.seconds:g} s distinct 16 kHz clips per GPU, wav in HBM -> token ids on host",
-                   "h2d": "excluded (waveforms resident in HBM when the clock starts; the PCIe-inclusive rate is `pcie_inclusive`)",
-                   "clips_per_gpu": B, "clip_seconds": args.seconds, "parallelism": f"utterance-dp{world}",
-                   "tokens_per_clip": round(sum(res["token_num"]) / len(res["token_num"]), 1),
-                   "tokens_max": max(res["token_num"]), "tokens_min": min(res["token_num"]),
-                   "rccl_ranks": world, "weight_arena_bytes_broadcast": arena_bytes,
-                   "hypothesis_gather_bytes_per_rank_per_step": (B * (N_PAD + 1) * 4) if world > 1 else 0,
-                   "per_rank_ms_per_step": per_rank_ms, "weight_broadcast_seconds_per_rank": bcast_all if world > 1 else None,
-                   "weights_route": args.weights_route if world > 1 else None, "host_cores_rank0": host_pin},
-        "roofline": roofline, "kernels": kernels,
-        "sclk_mhz_mean": (telemetry or {}).get("sclk_mhz_mean"), "power_w_mean": (telemetry or {}).get("power_w_mean"),
-        "telemetry": telemetry,
-    }
-    line["config"]["output_layer"] = ("random-init" if confident is None else
-                                      {"kind": "confident (synth.confident_output_layer, calibrated on the batch)", **conf_stats})
+    line = assemble_line(value=value, dt=dt, steps=args.steps, warmup=args.warmup, world=world, dtype=MODE_DTYPE[args.precision], B=B,
+                         seconds=args.seconds, token_num=res["token_num"], arena_bytes=arena_bytes, n_pad=N_PAD, per_rank_ms=per_rank_ms,
+                         bcast_all=bcast_all if world > 1 else None, weights_route=args.weights_route, host_pin=host_pin, roofline=roofline,
+                         kernels=kernels, telemetry=telemetry,
+                         output_layer=("random-init" if confident is None else
+                                       {"kind": "confident (synth.confident_output_layer, calibrated on the batch)", **conf_stats}))
     if world > 1:
         print(json.dumps(line), flush=True)
         dist.destroy_process_group()
@@ -599,12 +630,7 @@ def main():
         # what the matrix pipe sustains for THIS instruction mix on random operand planes under the part's power / clock
         # management (tools/micro/mfma_peak.hip: register-resident three-product chains, no LDS, no memory), measured now -- LAST,
         # so that its 1.5 s at the power limit do not precede (and heat) any timed leg above
-        plp = power_limited_peak()
-        if plp:
-            ach = line["roofline"]["achieved"]
-            line["roofline"].update(power_limited_peak=round(plp["TFLOPs"] / PRODUCTS["f16x2"], 1), power_limited_peak_executed_16bit=plp["TFLOPs"],
-                                    frac_of_power_limited_peak=round(ach / (plp["TFLOPs"] / PRODUCTS["f16x2"]), 4), power_limited_peak_source=plp["source"],
-                                    power_limited_peak_sclk_mhz=plp.get("sclk_mhz_mean"), power_limited_peak_power_w=plp.get("power_w_mean"))
+        apply_power_limited_peak(line["roofline"], power_limited_peak(), PRODUCTS["f16x2"])
     print(json.dumps(line), flush=True)
 
 

@@ -1,6 +1,7 @@
-"""The bench line's contract, checked offline on the committed line of the round (profiles/r05_final_bench.json): every key the driver
-reads, the roofline and cpu_baseline objects, and the rule that `value` is the HBM-resident one-stream rate (the PCIe-inclusive and
-two-replica figures sit beside it). Also: the profile / trace condensers run on synthetic rocprofv3 CSVs."""
+"""The bench line's contract: (i) the functions bench.py assembles the line with, on synthetic measurements (schema, value and roofline
+arithmetic, the flagged fallback of the power-limited peak); (ii) as a separate sanity check, a committed line of an earlier round
+(profiles/r05_final_bench.json): every key the driver reads, the roofline and cpu_baseline objects, `value` as the HBM-resident one-stream
+rate with the PCIe-inclusive and two-replica figures beside it. Also: the profile / trace condensers run on synthetic rocprofv3 CSVs."""
 import csv
 import json
 import os
@@ -17,7 +18,51 @@ def _line():
     return json.loads(rows[0])
 
 
-def test_committed_line_has_every_contract_key():
+def _import_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_line_assembly_schema_on_synthetic_inputs():
+    """what bench.py EMITS (bench.assemble_roofline / assemble_line / apply_power_limited_peak), on made-up measurements: every key
+    the driver reads, `value` = clips x seconds x steps / time, frac = achieved / peak, and a power-limited peak that was not measured
+    in the run never becomes a fraction of the run"""
+    b = _import_bench()
+    gemm = {"work_per_step": 11.67e12, "ms_per_step": 41.2, "launches_per_step": 283}
+    roof = b.assemble_roofline(gemm, "gemm_f16x2_", 2500.0 / 3, 52.4, (4.0e8, "profiles/x_traffic.json"), 3)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["achieved"] - 11.67e12 / 41.2e-3 / 1e12) < 0.01
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["traffic"] == 4.0e8 and roof["launches_per_step"] == 283
+    steps, dt = 20, 1.048
+    line = b.assemble_line(value=64 * 30.0 * steps / dt, dt=dt, steps=steps, warmup=5, world=1, dtype="f32 (...)", B=64, seconds=30.0,
+                           token_num=[170, 168, 171], arena_bytes=0, n_pad=512, per_rank_ms=None, bcast_all=None, weights_route="arena",
+                           host_pin=None, roofline=roof, kernels={}, telemetry={"sclk_mhz_mean": 2000.0, "power_w_mean": 1200.0},
+                           output_layer="random-init")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - 64 * 30.0 / (line["ms_per_step"] * 1e-3)) / line["value"] < 2e-3
+    assert line["config"]["hypothesis_gather_bytes_per_rank_per_step"] == 0 and line["config"]["weights_route"] is None
+    json.dumps(line)                                            # serialisable as it stands
+    multi = b.assemble_line(value=1.0, dt=1.0, steps=2, warmup=1, world=8, dtype="x", B=16, seconds=10.0, token_num=[5], arena_bytes=880_000_000,
+                            n_pad=512, per_rank_ms=[1.0] * 8, bcast_all=[0.5] * 8, weights_route="arena", host_pin={"cores": [0, 1], "threads": 2},
+                            roofline=roof, kernels={}, telemetry=None, output_layer="random-init")
+    assert multi["config"]["rccl_ranks"] == 8 and multi["config"]["hypothesis_gather_bytes_per_rank_per_step"] == 16 * 513 * 4
+    assert multi["config"]["weights_route"] == "arena" and multi["sclk_mhz_mean"] is None
+    live = b.apply_power_limited_peak(dict(roof), {"TFLOPs": 1650.0, "source": "live"}, 3)
+    assert abs(live["frac_of_power_limited_peak"] - roof["achieved"] / 550.0) < 1e-3 and live["frac_of_power_limited_peak"] > roof["frac"]
+    rec = b.apply_power_limited_peak(dict(roof), {"TFLOPs": None, "recorded_TFLOPs": 1647.0, "source": "NOT measured in this run; recorded: ..."}, 3)
+    assert rec["frac_of_power_limited_peak"] is None and rec["power_limited_peak"] is None and rec["power_limited_peak_recorded"] == 549.0
+
+
+def test_committed_line_sanity_of_the_recorded_artefact():
+    """a sanity check of a RECORDED artefact (not of bench.py: the schema test above is that)"""
     d = _line()
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)

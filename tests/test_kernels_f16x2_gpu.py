@@ -89,6 +89,14 @@ def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
             if K >= 64:
                 four = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=7, **kw)
                 assert torch.equal(four, narrow), f"four-wave 256x256 shape (gemm_f16x2_w4.hip) differs {sorted(kw)}"
+        # the persistent wave-specialised shape (gemm_f16x2_ps.hip; transposed product, stores straight from the accumulators);
+        # shapes it does not take (M % 16, N % 128, both residuals) fall back by themselves: equal either way
+        ps = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=10, **kw)
+        assert torch.equal(ps, narrow), f"persistent 256x128 shape (gemm_f16x2_ps.hip) differs {sorted(kw)}"
+        if kw.get("add2") is not None and kw.get("add1") is None:
+            x = kw["add2"].clone()                  # in place, C == R2: the encoder's x = x + w_2(...)
+            ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=10, relu=kw.get("relu", False), add2=x, out=x)
+            assert torch.equal(x, narrow), "persistent shape, in place"
 
 
 @pytest.mark.parametrize("M", [15, 960, 3840])
@@ -130,6 +138,9 @@ def test_gemm_f16x2_plane_output(cuda, M):
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=0), p_w)
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=6), p_w)
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=7), p_w), "four-wave shape"
+    assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=10), p_w), "persistent shape"
+    assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=False, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=10),
+                       ops.gemm_f16x2(a2, w2, bias, relu=False, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=2)), "persistent shape, no ReLU"
     assert torch.isfinite(p_w.float()).all()
     val = _planes_value(p_w) * 2.0 ** -eo
     # the split adds <= 2^-22 of the element (+ the subnormal floor 2^-25 in the scaled domain)
@@ -159,8 +170,10 @@ def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
             assert (out[key] is None and one[key] is None) or torch.equal(out[key], one[key]), f"tile {tile}: {key} differs"
     ring = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=6)
     four = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=7)
+    pers = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=10)
     for key in ("q2", "k2", "v", "vt"):
         assert (out[key] is None and four[key] is None) or torch.equal(out[key], four[key]), f"four-wave shape: {key} differs"
+        assert (out[key] is None and pers[key] is None) or torch.equal(out[key], pers[key]), f"persistent shape: {key} differs"
         assert (out[key] is None and pair[key] is None) or torch.equal(out[key], pair[key]), f"128x256 shape: {key} differs"
         assert (out[key] is None and ring[key] is None) or torch.equal(out[key], ring[key]), f"deep-ring shape: {key} differs"
     ref, mag = _gemm_ref(a2, w2, se, bias)
@@ -341,7 +354,7 @@ def test_encoder_schedule_options_are_bitwise_equal(cuda, frames, packing):
         outs[(fuse_row, fsmn_fused, row_bm, ffn_fused)] = enc(feats, lens)[0].clone()
     # w_2 as a tile GEMM + its own LayerNorm launch (w2_row 0) against the full-row form (1), and the four-wave GEMM shape (gemm_tile 7)
     enc.set_option("fuse_row", 1).set_option("fsmn_fused", 1).set_option("row_bm", 0).set_option("ffn_fused", 0)
-    for w2_row, gemm_tile, w2_tile in ((0, 0, 0), (1, 0, 0), (0, 7, 7), (1, 7, 7), (2, 7, 0), (0, 0, 7), (0, 0, 2)):
+    for w2_row, gemm_tile, w2_tile in ((0, 0, 0), (1, 0, 0), (0, 7, 7), (1, 7, 7), (2, 7, 0), (0, 0, 7), (0, 0, 2), (0, 10, 10), (2, 10, 7), (0, 0, 10)):
         enc.set_option("w2_row", w2_row).set_option("gemm_tile", gemm_tile).set_option("w2_tile", w2_tile)
         outs[("w2_row", w2_row, "gemm_tile", gemm_tile, "w2_tile", w2_tile)] = enc(feats, lens)[0].clone()
     enc.set_option("w2_row", 2).set_option("gemm_tile", 0).set_option("w2_tile", 7)

@@ -85,7 +85,10 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(cuda):
     (BASELINE configs[3]; the reference's recipe is one process per GPU, examples/aishell/paraformer/run.sh:135-190). One
     whole-job line from rank 0, eight per-rank times, the 880-MB weight arena broadcast once, every rank pinned to its own
     host cores, no CPU-baseline leg at N > 1. Smaller batches than the headline (eight replicas share one GPU's memory and time)."""
-    out = _run(_torchrun(8, ["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "16", "--dist-backend", "gloo"]), 1400)
+    # (kept cheap: eight Python ranks import torch, build the 220 M-parameter mirror and take the arena through gloo on the box's
+    # few host cores -- small batches, short clips, no calibration of the output layer)
+    out = _run(_torchrun(8, ["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "16", "--seconds", "10",
+                             "--random-output-layer", "--dist-backend", "gloo"]), 1400)
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     d = json.loads(lines[0])
@@ -97,7 +100,7 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(cuda):
     assert len(c["weight_broadcast_seconds_per_rank"]) == 8
     assert c["hypothesis_gather_bytes_per_rank_per_step"] == 16 * 513 * 4
     assert c["host_cores_rank0"] is not None and c["host_cores_rank0"]["threads"] >= 1
-    assert abs(d["value"] - 8 * 16 * 30.0 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01
+    assert abs(d["value"] - 8 * 16 * 10.0 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.01
     assert "cpu_baseline" not in d                      # N = 1 only (and only rank 0 would run it)
 
 
