@@ -13,13 +13,15 @@
 //   * the MFMA waves never issue an LDS-DMA piece and never wait on vmcnt: their matrix pipe sees MFMAs, fragment ds_reads and,
 //     between tiles, the epilogue -- whose global stores go out straight from the accumulator registers and are left in flight
 //     while the next tile's K loop runs (nothing ever waits for them; a wave's 32 stores per tile fit the 6-bit counter);
-//   * the product is computed TRANSPOSED (W fragment as the first MFMA operand), so a lane holds 4 consecutive output COLUMNS of
-//     one row per accumulator quad: fp32 output = 16-B pieces, plane output = 16-B pieces after one v_permlane32_swap per dword
-//     with the lane that holds the neighbouring 4 columns -- no LDS slab, so the stage ring is never interrupted;
-//   * the loader waves own the ring of three 48-KB stages: stage x is issued whole (48 one-KB pieces) by loader x & 3 right after
-//     the barrier that frees its buffer and waited for with vmcnt(0) -- exact, it is the only thing that wave has in flight --
-//     before the barrier that publishes it. Two stages (96 KB) in flight against the one 64-KB stage of the other shapes, and
-//     the next tile's first stages are in flight during the current tile's epilogue;
+//   * no LDS slab: a store instruction's 32 lanes are 32 consecutive columns of a row (the C/D layout of the 32 x 32 MFMA with the A
+//     fragment as first operand), fp32 output = dword stores of 128 contiguous bytes per row, plane output = one DPP exchange
+//     between neighbouring lanes and dword stores of two fp16 (64 contiguous bytes per row and plane) -- the stage ring is never
+//     interrupted by an epilogue;
+//   * the loader waves own the ring of three 48-KB stages: loaders 0 / 1 the even stages, 2 / 3 the odd ones, one operand plane
+//     each (24 one-KB pieces per loader and stage), issued right after the barrier that frees the stage's buffer and waited for
+//     with vmcnt(0) -- exact, it is the only thing that wave has in flight -- before the barrier that publishes it. Two stages
+//     (96 KB) in flight against the one 64-KB stage of the other shapes, and the next tile's first stages are in flight during the
+//     current tile's epilogue;
 //   * ONE s_barrier per stage for all eight waves, in the middle of the stage (it publishes stage g + 1 and frees buffer g % 3).
 // Price: 256 x 128 tiles move 1.5x the L2 -> LDS bytes per flop of a 256 x 256 tile, and a wave's 64 x 128 quadrant needs 12
 // ds_read_b128 per 24 MFMAs (the eight-wave shape's ratio), placed by hand one per two MFMAs like gemm_f16x2_w4.hip.
@@ -66,9 +68,19 @@ __device__ __forceinline__ void ps_settle(floatx16 (&acc)[4][2]) {
                  : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[3][0]), "+a"(acc[3][1]));
 }
 
+// one 1-KB LDS-DMA piece: uniform 64-bit base + 32-bit per-lane byte offset, destination lds_buf + LOFF (m0 is reserved: the
+// compiler keeps nothing in it). Three instructions.
+template <int LOFF> __device__ __forceinline__ void ps_piece(const char* sbase, unsigned voff, unsigned lds_buf) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_buf), "n"(LOFF) : "memory", "scc");
+}
+
 // v_permlane32_swap: swaps the upper 32 lanes of `a` with the lower 32 lanes of `b` (gfx950)
+// (the builtin, not inline asm: the instruction needs wait states after a VALU write of its operands, which the compiler's hazard
+// recogniser only inserts for instructions it can see -- the asm form returned garbage right behind v_accvgpr_read)
 __device__ __forceinline__ void ps_swap32(unsigned& a, unsigned& b) {
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
 }
 
 // the static tile list of workgroup `wg` of `nwg` (nwg % 8 == 0): XCD x = wg & 7 owns the row blocks x, x + 8, ... and walks
@@ -104,51 +116,70 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
     if (tiles.count == 0) return;
     const int nk = p.K / 32;
     const int total_stages = tiles.count * nk;
+    // measurement switches (tools/bench_ps.py; Gemm2Args.tile = 10 + 16 abl): bit 0 no operand DMA, bit 1 no epilogue, bit 2 no stores,
+    // bit 3 stores into an L2-resident window, bit 4 staggered workgroup starts
+    const int abl = p.tile >> 4;
+    if (abl & 16) {
+        // measurement: workgroups start up to one tile time apart (16 phases), so that their epilogues' store phases do not coincide
+        const long long t0 = __builtin_readcyclecounter();
+        const long long d = (long long)(((int)blockIdx.x >> 3) & 15) * (p.K / 32) * 140;     // 16 x 140 cycles ~ one 32-deep stage
+        while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(16);
+    }
 
     if (wave >= 4) {
         // ======================================================================================== loader waves
-        const int L = wave - 4;
+        // Loaders 0 / 1 own the EVEN stages, 2 / 3 the ODD ones; inside a pair, loader (L & 1) moves plane (L & 1) of both operands:
+        // 16 A pieces + 8 W pieces = 24 KB per loader and stage. A stage is issued right after the barrier that frees its buffer and
+        // waited for with vmcnt(0) before the barrier that publishes it -- exact: a loader never has more than that one stage in
+        // flight (its previous one was published two barriers earlier). Issue is three instructions per piece (m0, wait state,
+        // load): uniform 64-bit base per (plane, stage) in SGPRs, the piece's rows in a per-lane byte offset that is computed
+        // once per tile (A) / once per launch (W) and kept in this wave's otherwise idle registers. (The first form of this
+        // loader -- one wave per stage, address arithmetic per piece -- needed 2.3 us to issue a 48-KB stage and made the whole
+        // kernel DMA-issue bound: w_1 316 us, profiles/r06b_ps_first_run.jsonl.)
+        const int L = wave - 4, par = L >> 1, pl = L & 1;
         const int prow = lane >> 2;
         const unsigned chunkb = (unsigned)(((lane & 3) ^ ((prow >> 2) & 3)) * 16);
-        const unsigned voff_a = (unsigned)prow * (unsigned)p.lda * 2u + chunkb;
-        const unsigned voff_w = (unsigned)prow * (unsigned)p.ldw * 2u + chunkb;
-        const char* const a_hi = reinterpret_cast<const char*>(p.A);
-        const char* const w_hi = reinterpret_cast<const char*>(p.W);
-        const size_t a_plane_b = p.a_plane * 2, w_plane_b = p.w_plane * 2;
-        const int last_piece_row = p.M - 16;                                         // M % 16 == 0: a piece is valid or wholly past M
-        // stage x (global index over this workgroup's tiles) -> buffer x % 3
-        auto issue = [&](int x) {
-            const int ti = x / nk, s = x - ti * nk;
-            int m0, n0;
-            tiles.at(ti, m0, n0);
-            const unsigned dst = lds0 + (unsigned)(x % G::NSTG) * G::STAGE_B;
-            const size_t ko = (size_t)s * 64;
+        const char* const a_pl = reinterpret_cast<const char*>(p.A) + (size_t)pl * p.a_plane * 2;
+        const char* const w_pl = reinterpret_cast<const char*>(p.W) + (size_t)pl * p.w_plane * 2;
+        unsigned va[G::A_PIECES], vw[G::W_PIECES];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll 4
-                for (int q = 0; q < G::A_PIECES; ++q) {
-                    int r0 = m0 + 16 * q;
-                    r0 = r0 <= last_piece_row ? r0 : last_piece_row;
-                    glds16s(a_hi + pl * a_plane_b + (size_t)r0 * p.lda * 2 + ko, voff_a, dst + pl * G::A_PLANE_B + q * 1024);
-                }
-            }
+        for (int q = 0; q < G::W_PIECES; ++q) vw[q] = (unsigned)(16 * q + prow) * (unsigned)p.ldw * 2u + chunkb;
+        const unsigned lds_a = lds0 + (unsigned)pl * G::A_PLANE_B, lds_w = lds0 + 2 * G::A_PLANE_B + (unsigned)pl * G::W_PLANE_B;
+        // my next stage: global index x = tile ti, stage s of the tile; (m0, n0) and the A offsets follow the tile
+        int x = par, ti = 0, s = par;
+        while (s >= nk) { s -= nk; ++ti; }
+        int cur_ti = -1;
+        const char* a_tile = a_pl;
+        const char* w_tile = w_pl;
+        auto issue = [&]() {
+            if (ti != cur_ti) {
+                int m0, n0;
+                tiles.at(ti, m0, n0);
+                cur_ti = ti;
+                a_tile = a_pl + (size_t)m0 * p.lda * 2;
+                w_tile = w_pl + (size_t)n0 * p.ldw * 2;
+                // rows past M (M % 16 == 0: a piece is valid or wholly past M) re-read the last valid piece; their products are never stored
+                const int last = p.M - 16 - m0;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll 4
-                for (int q = 0; q < G::W_PIECES; ++q)
-                    glds16s(w_hi + pl * w_plane_b + (size_t)(n0 + 16 * q) * p.ldw * 2 + ko, voff_w,
-                            dst + 2 * G::A_PLANE_B + pl * G::W_PLANE_B + q * 1024);
+                for (int q = 0; q < G::A_PIECES; ++q) va[q] = (unsigned)((16 * q <= last ? 16 * q : last) + prow) * (unsigned)p.lda * 2u + chunkb;
             }
+            const unsigned buf = (unsigned)(x % G::NSTG) * G::STAGE_B;
+            const char* const ab = a_tile + (size_t)s * 64;
+            const char* const wb = w_tile + (size_t)s * 64;
+            [&]<int... Q>(std::integer_sequence<int, Q...>) { (ps_piece<Q * 1024>(ab, va[Q], lds_a + buf), ...); }(std::make_integer_sequence<int, G::A_PIECES>{});
+            [&]<int... Q>(std::integer_sequence<int, Q...>) { (ps_piece<Q * 1024>(wb, vw[Q], lds_w + buf), ...); }(std::make_integer_sequence<int, G::W_PIECES>{});
+            x += 2; s += 2;
+            while (s >= nk) { s -= nk; ++ti; }
         };
-        // stages 0 and 1 before the first barrier; then, around barrier g (g = -1 .. total - 1): the owner of stage g + 1 waits
-        // for it before the barrier (the only thing it has in flight), the owner of stage g + 3 issues it after the barrier
-        // (buffer g % 3 was read for the last time before it)
-        if (L == 0) issue(0);
-        if (L == 1 && total_stages > 1) issue(1);
+        // stages 0 (pair 0) and 1 (pair 1) before the first barrier; then, around barrier g (g = -1 .. total - 1): the pair of stage
+        // g + 1 waits for it before the barrier, the pair of stage g + 3 issues it after the barrier (buffer g % 3 was read for
+        // the last time before it)
+        const bool dma = (abl & 1) == 0;
+        if (x < total_stages && dma) issue();
         for (int g = -1; g < total_stages; ++g) {
-            if (((g + 1) & 3) == L) glds_wait_all();
+            if (((g + 1) & 1) == par) glds_wait_all();
             __builtin_amdgcn_s_barrier();
-            if (g + 3 < total_stages && ((g + 3) & 3) == L) issue(g + 3);
+            if (((g + 3) & 1) == par && g + 3 < total_stages && dma) issue();
         }
         return;
     }
@@ -172,14 +203,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
     __builtin_amdgcn_s_barrier();                   // barrier -1: stage 0 has landed
     int buf = 0;
     const float oscale = p.oscale_dev ? p.oscale * *p.oscale_dev : p.oscale;
-    // one tile, start to finish. A generic lambda instantiated per operand order: the accumulators are LOCAL to an instantiation
-    // (a tile's first products write them with C = 0, nothing is carried between tiles), so the two orders never meet in a phi
-    // and neither epilogue's registers leak into the other's K loop.
-    // Swap (the V tiles of the QKV form): the A fragment is the first MFMA operand -- lane idx = column, registers = rows, the
-    // layout whose register octets ARE the V^T pieces attention_f16x2.hip reads; same products, same sums
-    auto run_tile = [&](auto Swap, const int m0, const int n0, const int seg) {
-        constexpr bool SW = decltype(Swap)::value;
-        floatx16 acc[4][2];                         // [column tile][row tile]; !SW: lane idx = row, registers = columns (D^T); SW: the reverse
+    constexpr bool HAS_R1 = OUT == 0 && (MODE & 1) != 0, HAS_R2 = OUT == 0 && (MODE & 2) != 0;
+    for (int ti = 0; ti < tiles.count; ++ti) {
+        int m0, n0;
+        tiles.at(ti, m0, n0);
+        // accumulators [column tile][row tile], local to the tile (its first products write them with C = 0). The A fragment is the
+        // FIRST MFMA operand: lane idx = output COLUMN n0 + 32 tn + idx, registers = rows 32 tm + 8 (r >> 2) + 4 hh + (r & 3)
+        floatx16 acc[4][2];
         // one 16-deep k-step: 24 MFMAs on `x`; the next k-step's fragments are read into `y`, one read per two MFMAs
         auto kstep = [&](auto First, PsFrags& x, PsFrags& y, unsigned fa, unsigned fw) {
             [&]<int... Gp>(std::integer_sequence<int, Gp...>) {
@@ -188,8 +218,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
                     // the two small products first, hi * hi last -- the order of every other shape
                     const f16x8& w = P == 1 ? x.wl[tn] : x.wh[tn];
                     const f16x8& a = P == 0 ? x.al[tm] : x.ah[tm];
-                    if constexpr (P == 0 && decltype(First)::value) { if constexpr (SW) ps_mfma0(acc[tn][tm], a, w); else ps_mfma0(acc[tn][tm], w, a); }
-                    else { if constexpr (SW) ps_mfma(acc[tn][tm], a, w); else ps_mfma(acc[tn][tm], w, a); }
+                    if constexpr (P == 0 && decltype(First)::value) ps_mfma0(acc[tn][tm], a, w);
+                    else ps_mfma(acc[tn][tm], a, w);
                     if constexpr ((g & 1) == 0) frag_read(std::integral_constant<int, (g >> 1)>{}, y, fa, fw);
                 }(), ...);
             }(std::make_integer_sequence<int, 24>{});
@@ -214,69 +244,75 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
         stage(std::true_type{});                    // the tile's first products write the accumulators (C = 0)
         for (int s = 1; s < nk; ++s) stage(std::false_type{});
         ps_settle(acc);
-        if constexpr (SW) {
-                // ---- V tile. acc[tn][tm][r]: column d = n0 + 32 tn + idx, row m0 + 64 wave + 32 tm + 8 (r >> 2) + 4 hh + (r & 3).
-            //      Registers 8 G .. 8 G + 7 = rows {0..3, 8..11} + 4 hh of the 16-row group G: one 16-B V^T piece per plane
-            //      (the piece layout of gemm_f16x2_epilogue.h / attention_f16x2.hip). fp32 V (the FSMN memory block reads it):
-            //      one dword per register, 32 lanes = 128 contiguous bytes of a row.
-            float v_mul = p.v_mul;
-            if (p.kv_mul_dev) v_mul *= p.kv_mul_dev[1];
-            // (opaque copies: everything derived from them is recomputed per tile instead of being hoisted out of the tile loop
-            // into ~200 registers that live across the K loop)
-            int ldc_ = p.ldc, ldvt_ = p.ldvt, idx_ = idx, hh_ = hh;
-            asm volatile("" : "+s"(ldc_), "+s"(ldvt_), "+v"(idx_), "+v"(hh_));
-            const int vc0 = n0 - (p.kv_form ? 1 : 2) * p.qkv_D;                 // first column of the tile inside v
-            const int mw = m0 + wave * 64;
-            unsigned short* const vt0 = p.VT + (size_t)(vc0 + idx_) * ldvt_ + mw + 8 * hh_;
-            float* const c0 = p.C ? p.C + (size_t)(mw + 4 * hh_) * ldc_ + vc0 + idx_ : nullptr;
-            float bv[4];
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) bv[tn] = p.bias ? p.bias[n0 + 32 * tn + idx_] : 0.f;
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const floatx16& a = acc[tn][tm];
-#pragma unroll
-                    for (int Gq = 0; Gq < 2; ++Gq) {
-                        if (mw + 32 * tm + 16 * Gq >= p.M) continue;                // M % 16 == 0: a 16-row group is valid or wholly past M
-                        float t[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) t[j] = (a[8 * Gq + j] * oscale + bv[tn]) * v_mul;
-                        uint4 h, l;
-                        split2_pk(t[0], t[1], h.x, l.x);
-                        split2_pk(t[2], t[3], h.y, l.y);
-                        split2_pk(t[4], t[5], h.z, l.z);
-                        split2_pk(t[6], t[7], h.w, l.w);
-                        unsigned short* vp = vt0 + (size_t)(32 * tn) * ldvt_ + 32 * tm + 16 * Gq;
-                        *reinterpret_cast<uint4*>(vp) = h;
-                        *reinterpret_cast<uint4*>(vp + p.vt_plane) = l;
-                        if (c0) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                c0[(size_t)(32 * tm + 16 * Gq + 8 * (j >> 2) + (j & 3)) * ldc_ + 32 * tn] = a[8 * Gq + j] * oscale + bv[tn];
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);      // one accumulator tile at a time (16 registers out of the accumulator file, not 128)
-                }
-            }
-        } else {
+        if (abl & 2) {                              // (the accumulators still count as used: the products are volatile asm)
+            if (acc[0][0][0] == 123.456f && p.C) p.C[0] = acc[3][1][15];
+            continue;
+        }
 
-        // ---- epilogue, straight from the accumulators. acc[tn][tm][r]: row m0 + 64 wave + 32 tm + idx,
-        //      column n0 + 32 tn + 8 (r >> 2) + 4 hh + (r & 3): four consecutive columns per quad q = r >> 2.
-        //      Two phases. Phase 1 finishes every value IN REGISTERS (bias, scale, ReLU, residual loads, plane split); phase 2 is
-        //      32 stores and nothing else. vmcnt completes in issue order, so a load issued behind a store would wait for that
-        //      store's acknowledgement: with all loads of a tile ahead of all of its stores the only thing a load ever waits
-        //      behind is the PREVIOUS tile's stores, a whole K loop old.
+        // ---- epilogue, straight from the accumulators: no LDS slab, so the stage ring is never interrupted and the loaders keep
+        //      filling it under the epilogue. A store instruction's 32 lanes are 32 consecutive COLUMNS of a row (the two half-waves:
+        //      rows 4 apart): fp32 = 128 contiguous bytes per row and instruction; planes: lanes 2k / 2k + 1 trade one value (a DPP
+        //      quad permute) so that the even lane holds columns (c, c + 1) of row r and the odd lane those of row r + 1 -- one dword
+        //      of two fp16 per plane, 64 contiguous bytes per row and instruction. (The first form of this kernel computed the
+        //      TRANSPOSED product, lane = row, and stored 16-B pieces of 32 different rows per instruction: one cache line per lane,
+        //      and the loaders' LDS-DMA queued behind it -- profiles/r06c_ps_fast_loaders.jsonl: epilogue 69 us of a 279-us w_1.)
+        //      Phase 1 finishes every value IN REGISTERS (the finished words overwrite the accumulator elements they came from);
+        //      phase 2 is stores and nothing else, left in flight under the next tile's K loop: vmcnt completes in issue order, so
+        //      with all loads of a tile ahead of all of its stores a load only ever waits behind the PREVIOUS tile's stores.
         // (opaque per-tile copies of the lane coordinates: what is derived from them is recomputed per tile, not hoisted out of the
         // tile loop into registers that live across the K loop)
         int idx_ = idx, hh_ = hh;
         asm volatile("" : "+v"(idx_), "+v"(hh_));
-        const int rbase = m0 + wave * 64 + idx_;
-        // (results overwrite the accumulator elements they came from: 128 live registers, not 256)
-        constexpr bool HAS_R1 = OUT == 0 && (MODE & 1) != 0, HAS_R2 = OUT == 0 && (MODE & 2) != 0;
-        // units u = 0..7 of (column tile u >> 1, quads 2 (u & 1), 2 (u & 1) + 1): unit u + 1's loads are in flight under unit u's arithmetic
-        float4 bias4[2][2], r1[2][2][2], r2[2][2][2];
+        const int odd = idx_ & 1;
+        const int rowl = wave * 64 + 4 * hh_;                                  // + 32 tm + 8 (r >> 2) + (r & 3): row inside the tile
+        const int seg = OUT == 2 ? n0 / p.qkv_D + (p.kv_form ? 1 : 0) : 0;     // QKV / KV form: 0 q, 1 k, 2 v (qkv_D % 128 == 0)
+        if constexpr (OUT == 2) {
+            if (seg == 2) {
+                // ---- V tile: registers 8 G .. 8 G + 7 = rows {0..3, 8..11} + 4 hh of the 16-row group G: one 16-B V^T piece per plane
+                //      (the piece layout of gemm_f16x2_epilogue.h / attention_f16x2.hip); fp32 V (the FSMN memory block reads it): one
+                //      dword per register
+                float v_mul = p.v_mul;
+                if (p.kv_mul_dev) v_mul *= p.kv_mul_dev[1];
+                int ldc_ = p.ldc, ldvt_ = p.ldvt;
+                asm volatile("" : "+s"(ldc_), "+s"(ldvt_));
+                const int vc0 = n0 - (p.kv_form ? 1 : 2) * p.qkv_D;             // first column of the tile inside v
+                const int mw = m0 + wave * 64;
+                unsigned short* const vt0 = p.VT + (size_t)(vc0 + idx_) * ldvt_ + mw + 8 * hh_;
+                float* const c0 = p.C ? p.C + (size_t)(mw + 4 * hh_) * ldc_ + vc0 + idx_ : nullptr;
+                float bv[4];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) bv[tn] = p.bias ? p.bias[n0 + 32 * tn + idx_] : 0.f;
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) {
+                        const floatx16& a = acc[tn][tm];
+#pragma unroll
+                        for (int Gq = 0; Gq < 2; ++Gq) {
+                            if (mw + 32 * tm + 16 * Gq >= p.M) continue;        // M % 16 == 0: a 16-row group is valid or wholly past M
+                            float t[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) t[j] = (a[8 * Gq + j] * oscale + bv[tn]) * v_mul;
+                            uint4 h, l;
+                            split2_pk(t[0], t[1], h.x, l.x);
+                            split2_pk(t[2], t[3], h.y, l.y);
+                            split2_pk(t[4], t[5], h.z, l.z);
+                            split2_pk(t[6], t[7], h.w, l.w);
+                            unsigned short* vp = vt0 + (size_t)(32 * tn) * ldvt_ + 32 * tm + 16 * Gq;
+                            *reinterpret_cast<uint4*>(vp) = h;
+                            *reinterpret_cast<uint4*>(vp + p.vt_plane) = l;
+                            if (c0) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    c0[(size_t)(32 * tm + 16 * Gq + 8 * (j >> 2) + (j & 3)) * ldc_ + 32 * tn] = a[8 * Gq + j] * oscale + bv[tn];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // one accumulator tile at a time (16 registers out of the accumulator file, not 128)
+                    }
+                }
+                continue;
+            }
+        }
         // plane outputs: the multiplier of the planes and where they go (QKV form: q / k planes, row stride qkv_D)
         float pscale = p.cscale;
         unsigned short* pdst = p.C2;
@@ -288,94 +324,119 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
             pld = p.qkv_D; pplane = p.qk_plane;
             pcol0 = n0 - (n0 / p.qkv_D) * p.qkv_D;
         }
+        // Units = PAIRS of column tiles: u = 2 p + tm holds acc[2 p][tm] and acc[2 p + 1][tm] (64 columns x 32 rows). One
+        // v_permlane32_swap per register pair turns (columns 32 x rows {hh = 0 | hh = 1}) x 2 tiles into
+        //     A'[r] = rows 8 (r >> 2) + (r & 3)     , lower half-wave: tile 2 p, upper half-wave: tile 2 p + 1   (64 consecutive columns)
+        //     B'[r] = rows 8 (r >> 2) + (r & 3) + 4 , the same columns
+        // so that a store instruction covers ONE row: 256 contiguous bytes of fp32, or (after the DPP exchange between neighbouring
+        // lanes) two rows x 128 contiguous bytes per plane -- whole cache lines instead of 64-B halves of four of them.
+        // Unit u + 1's residual loads are in flight under unit u's arithmetic.
+        const int h2 = hh_;                                                     // half-wave = which tile of the pair
+        const int lc = 32 * h2 + idx_;                                          // this lane's column inside the pair's 64
+        float bv[2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) bv[pp] = p.bias ? p.bias[n0 + 64 * pp + lc] : 0.f;
+        float r1[2][32], r2[2][32];
+        // (uniform 64-bit bases in SGPRs + ONE per-lane offset: 128 per-lane addresses would cost 256 registers. M % 16 == 0 and the
+        // rows of a register octet lie in one 16-row group, so row validity is uniform too)
+        int ldr1_ = p.ldr1, ldr2_ = p.ldr2;
+        asm volatile("" : "+s"(ldr1_), "+s"(ldr2_));
+        const int mw = m0 + wave * 64;
+        const int mws = (abl & 8) ? wave * 64 : mw;                             // measurement: every tile stores into the first 256 rows (an L2-resident window)
         auto load_unit = [&](auto U) {
-            constexpr int u = decltype(U)::value, tn = u >> 1;
+            constexpr int u = decltype(U)::value, pp = u >> 1, tm = u & 1;
+            if constexpr (HAS_R1 || HAS_R2) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int q = 2 * (u & 1) + k;
-                const int col = n0 + 32 * tn + 8 * q + 4 * hh_;
-                bias4[u & 1][k] = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const int row = rbase + 32 * tm;
-                    const int rr = row < p.M ? row : p.M - 1;
-                    if constexpr (HAS_R1) r1[u & 1][k][tm] = *reinterpret_cast<const float4*>(p.R1 + (size_t)rr * p.ldr1 + col);
-                    if constexpr (HAS_R2) r2[u & 1][k][tm] = *reinterpret_cast<const float4*>(p.R2 + (size_t)rr * p.ldr2 + col);
+                for (int k = 0; k < 32; ++k) {
+                    const int r = k & 15, rl = 32 * tm + 8 * (r >> 2) + (r & 3) + 4 * (k >> 4);
+                    const bool ok = mw + 32 * tm + 16 * (r >> 3) < p.M;
+                    if constexpr (HAS_R1) r1[u & 1][k] = ok ? (p.R1 + (size_t)(mws + rl) * ldr1_ + n0 + 64 * pp)[lc] : 0.f;
+                    if constexpr (HAS_R2) r2[u & 1][k] = ok ? (p.R2 + (size_t)(mws + rl) * ldr2_ + n0 + 64 * pp)[lc] : 0.f;
                 }
             }
         };
         auto finish_unit = [&](auto U) {
-            constexpr int u = decltype(U)::value, tn = u >> 1;
+            constexpr int u = decltype(U)::value, pp = u >> 1, tm = u & 1;
+            floatx16& A = acc[2 * pp][tm];
+            floatx16& B = acc[2 * pp + 1][tm];
+            float o[32];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int q = 2 * (u & 1) + k;
+            for (int r = 0; r < 16; ++r) {
+                const float fa = A[r], fb = B[r];   // (copies: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0)
+                unsigned x = __builtin_bit_cast(unsigned, fa), y = __builtin_bit_cast(unsigned, fb);
+                ps_swap32(x, y);                    // x = A'[r], y = B'[r]
+                o[r] = __builtin_bit_cast(float, x);
+                o[16 + r] = __builtin_bit_cast(float, y);
+            }
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    floatx16& a = acc[tn][tm];
-                    const float4 b4 = bias4[u & 1][k];
-                    float o[4] = {a[4 * q + 0] * oscale + b4.x, a[4 * q + 1] * oscale + b4.y, a[4 * q + 2] * oscale + b4.z, a[4 * q + 3] * oscale + b4.w};
-                    if constexpr (RELU) {
+            for (int k = 0; k < 32; ++k) {
+                o[k] = o[k] * oscale + bv[pp];
+                if constexpr (RELU) o[k] = fmaxf(o[k], 0.f);
+                if constexpr (HAS_R1) o[k] = o[k] + r1[u & 1][k];
+                if constexpr (HAS_R2) o[k] = r2[u & 1][k] + o[k];
+            }
+            if constexpr (OUT == 0) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-                    }
-                    if constexpr (OUT == 0) {
-                        if constexpr (HAS_R1) { const float4 r = r1[u & 1][k][tm]; o[0] = o[0] + r.x; o[1] = o[1] + r.y; o[2] = o[2] + r.z; o[3] = o[3] + r.w; }
-                        if constexpr (HAS_R2) { const float4 r = r2[u & 1][k][tm]; o[0] = r.x + o[0]; o[1] = r.y + o[1]; o[2] = r.z + o[2]; o[3] = r.w + o[3]; }
-                        a[4 * q + 0] = o[0]; a[4 * q + 1] = o[1]; a[4 * q + 2] = o[2]; a[4 * q + 3] = o[3];
-                    } else {
-                        // two planes of o * cscale: this lane's 4 columns and the 4 of the lane 32 away (the other half of the same
-                        // row's 8-column group): the lower lane ends up with the hi plane's 8 columns, the upper lane with the lo plane's
-                        unsigned h0, l0, h1, l1;
-                        split2_pk(o[0] * pscale, o[1] * pscale, h0, l0);
-                        split2_pk(o[2] * pscale, o[3] * pscale, h1, l1);
-                        ps_swap32(h0, l0);      // lower lanes: l0 <- the partner's h0; upper lanes: h0 <- the partner's l0
-                        ps_swap32(h1, l1);
-                        a[4 * q + 0] = __builtin_bit_cast(float, h0); a[4 * q + 1] = __builtin_bit_cast(float, h1);
-                        a[4 * q + 2] = __builtin_bit_cast(float, l0); a[4 * q + 3] = __builtin_bit_cast(float, l1);
-                    }
+                for (int r = 0; r < 16; ++r) { A[r] = o[r]; B[r] = o[16 + r]; }
+            } else {
+                // rows (r, r + 1), r even: the even lane keeps row r and gets the odd lane's value of it (column c + 1); the odd lane keeps
+                // row r + 1 and gets the even lane's (column c - 1): (hi, lo) words of two adjacent columns of ONE row per lane
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float x0 = o[2 * k] * pscale, x1 = o[2 * k + 1] * pscale;
+                    const float got = __builtin_bit_cast(float, dpp_swap1(__builtin_bit_cast(unsigned, odd ? x0 : x1)));
+                    unsigned h, l;
+                    split2_pk(odd ? got : x0, odd ? x1 : got, h, l);
+                    floatx16& D = k < 8 ? A : B;
+                    D[2 * (k & 7)] = __builtin_bit_cast(float, h);
+                    D[2 * (k & 7) + 1] = __builtin_bit_cast(float, l);
                 }
             }
         };
         load_unit(std::integral_constant<int, 0>{});
         [&]<int... U>(std::integer_sequence<int, U...>) {
             ([&] {
-                if constexpr (U + 1 < 8) load_unit(std::integral_constant<int, U + 1>{});
+                if constexpr (U + 1 < 4) load_unit(std::integral_constant<int, U + 1>{});
                 __builtin_amdgcn_sched_barrier(0);
                 finish_unit(std::integral_constant<int, U>{});
-                // the finished values go back to the accumulator file, not to 32 more VGPRs
-                if constexpr ((U & 1) == 1) asm volatile("" : "+a"(acc[U >> 1][0]), "+a"(acc[U >> 1][1]));
+                // the finished words go back to the accumulator file, not to 32 more VGPRs
+                asm volatile("" : "+a"(acc[2 * (U >> 1)][U & 1]), "+a"(acc[2 * (U >> 1) + 1][U & 1]));
                 __builtin_amdgcn_sched_barrier(0);
             }(), ...);
-        }(std::make_integer_sequence<int, 8>{});
+        }(std::make_integer_sequence<int, 4>{});
+        if (abl & 4) {                              // measurement: everything but the stores
+            if (acc[0][0][0] == 123.456f && p.C) p.C[0] = acc[3][1][15];
+            continue;
+        }
+        int ldo_ = OUT == 0 ? p.ldc : pld;
+        asm volatile("" : "+s"(ldo_));
+        const size_t so = OUT == 0 ? (size_t)lc : (size_t)odd * ldo_ + (lc & ~1);   // this lane inside a register's row (pair)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    const int row = rbase + 32 * tm;
-                    if (row >= p.M) continue;
-                    const floatx16& a = acc[tn][tm];
-                    const float4 v4 = make_float4(a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+                for (int half = 0; half < 2; ++half) {                           // A' (rows + 0), B' (rows + 4)
+                    const floatx16& a = acc[2 * pp + half][tm];
                     if constexpr (OUT == 0) {
-                        *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + n0 + 32 * tn + 8 * q + 4 * hh_) = v4;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = 32 * tm + 8 * (r >> 2) + (r & 3) + 4 * half;
+                            if (mw + 32 * tm + 16 * (r >> 3) < p.M) (p.C + (size_t)(mws + rl) * ldo_ + n0 + 64 * pp)[so] = a[r];
+                        }
                     } else {
-                        // hh = 0: hi plane, columns c8 .. c8 + 7; hh = 1: lo plane, the same columns
-                        unsigned short* dst = pdst + (size_t)row * pld + pcol0 + 32 * tn + 8 * q + (hh_ ? pplane : (size_t)0);
-                        *reinterpret_cast<float4*>(dst) = v4;
+                        // this lane's row of the pair (r, r + 1) is r + odd; its two columns start at the even one
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int rl = 32 * tm + 8 * (k >> 1) + 2 * (k & 1) + 4 * half;   // rows 0, 2, 8, 10, 16, 18, 24, 26 of the tile (+ 4 half + odd)
+                            if (mw + 32 * tm + 16 * (k >> 2) < p.M) {
+                                unsigned short* const d = pdst + (size_t)(mws + rl) * ldo_ + pcol0 + 64 * pp;
+                                *reinterpret_cast<float*>(d + so) = a[2 * k];
+                                *reinterpret_cast<float*>(d + pplane + so) = a[2 * k + 1];
+                            }
+                        }
                     }
                 }
-        }
-    };
-    for (int ti = 0; ti < tiles.count; ++ti) {
-        int m0, n0;
-        tiles.at(ti, m0, n0);
-        // QKV / KV form: this tile's 128 columns lie inside one of q | k | v (qkv_D % 128 == 0): 0 q, 1 k, 2 v
-        const int seg = OUT == 2 ? n0 / p.qkv_D + (p.kv_form ? 1 : 0) : 0;
-        if constexpr (OUT == 2) {
-            if (seg == 2) { run_tile(std::true_type{}, m0, n0, seg); continue; }
-        }
-        run_tile(std::false_type{}, m0, n0, seg);
     }
 }
 

@@ -82,6 +82,9 @@ def timing():
             a2, w2, b = operands(N, K, data=data)
             r2 = torch.randn(M, N, device=dev)
             row = {"shape": name, "data": data, "M": M}
+            for label, tile in (("ps_nodma", PS + 16), ("ps_noepi", PS + 32), ("ps_loop", PS + 48), ("ps_nostore", PS + 64), ("ps_l2window", PS + 128), ("ps_stagger", PS + 256)):
+                row[label + "_planes"] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, relu=True, out_planes=True,
+                                                                         out_scale_exp=9, time_iters=20)[1]), 1)
             for label, tile in (("t2", 2), ("t7", 7), ("ps", PS)):
                 row[label + "_fp32"] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, time_iters=20)[1]), 1)
                 row[label + "_fp32_res"] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, add2=r2, out=r2, time_iters=20)[1]), 1)
