@@ -1049,13 +1049,21 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu, args, confident=None, gpu_ra
     # prefix sums straddle an integer): the committed 512-clip, 30-s statistic (GPU alphas from a gpurun box, the oracle on the
     # build host; tools/cif_margin_stats.py --dump / --compare) next to this run's clips
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_cif_margins_512x30s.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_cif_margins_512x30s_ids.json")) as f:
             cm = json.load(f)
         parity["cif_margin_statistic"] = {k: cm.get(k) for k in (
             "clips", "clip_seconds", "mode", "frames_compared", "tokens", "clips_with_different_fire_indices", "clips_with_different_token_count",
             "alpha_max_abs_diff", "prefix_sum_abs_diff", "margin_to_integer", "frames_with_margin_below_4x_prefix_sum_diff",
             "min_margin_over_diff_ratio", "expected_frames_within_diff_of_an_integer")}
-        parity["cif_margin_statistic"]["source"] = "profiles/r05_cif_margins_512x30s.json"
+        # round 6: the consequence at token-id level -- both paths decoded, with the random-init output layer and with a confident one
+        # calibrated once on the GPU's first batch (clips with different ids, token error rate, and whether they are the clips whose
+        # fire indices differ)
+        ids = cm.get("token_ids") or {}
+        parity["cif_margin_statistic"]["token_ids"] = {
+            kind: {k: v.get(k) for k in ("clips_with_different_ids", "token_errors", "ref_tokens", "token_error_rate",
+                                         "different_ids_among_fire_mismatch_clips", "different_ids_among_fire_equal_clips")}
+            for kind, v in ids.items()}
+        parity["cif_margin_statistic"]["source"] = "profiles/r06_cif_margins_512x30s_ids.json (tools/cif_margin_stats.py --ids)"
     except (OSError, ValueError):
         pass
     return {"value": best["value"], "unit": "audio-s/s", "cores": best["cores"], "kind": kind,

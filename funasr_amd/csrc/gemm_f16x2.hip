@@ -639,7 +639,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
     }
     // the four-wave 256 x 256 shape (gemm_f16x2_w4.hip): tile 7; bits 4.. = its measurement builds
     // the persistent wave-specialised shape (gemm_f16x2_ps.hip): tile 10; shapes it does not take are chosen by shape instead
-    if ((a.tile & 15) == 10) {
+    if ((a.tile & 15) == 10 || (a.tile & 15) == 11) {         // 10: finisher form for plane / QKV outputs; 11: the first form everywhere (A/B)
         if (gemm_f16x2_ps_ok(a)) return launch_gemm_f16x2_ps(a, stream);
         Gemm2Args b = a;
         b.tile = 0;

@@ -32,6 +32,7 @@ namespace pf {
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float ps_f4 __attribute__((ext_vector_type(4)));           // (a native vector: HIP's float4 is a struct, no register constraint takes it)
 
 struct PsGeo {
     static constexpr int BM = 256, BN = 128;
@@ -440,6 +441,359 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
     }
 }
 
+// ================================================================================================ finisher form (planes / QKV)
+// Round 6, second step. The dissection of the kernel above (profiles/r06g_ps_dissection.jsonl; w_1, M = 32768, random planes):
+// K loop 132 us; + operand DMA by the loader waves 156; + epilogue arithmetic in the MFMA waves 175; + their stores 236 -- the
+// store phase is the chip's write bandwidth (268 MB at 4.4 TB/s) with every MFMA wave blocked behind it, because a wave's stores
+// are accepted at the rate the memory system drains them and all workgroups reach their epilogue together. What can absorb a
+// tile's 128 KB of results while the NEXT tile is multiplied is the register file of the four auxiliary waves (256 registers each,
+// ~40 used). So here the MFMA waves do no epilogue at all:
+//   * at the end of a tile an MFMA wave dumps its RAW accumulators (128 registers) into LDS -- the stage buffer its last barrier
+//     freed (48 KB) plus the 16 KB behind the ring: 64 KB = half a tile, so two rounds with a barrier pair each -- and starts the
+//     next tile; its SIMD partner (wave + 4) reads the image back lane for lane into its own accumulator file;
+//   * the partner finishes the tile while the next one is multiplied: one quarter (scale, bias, ReLU, plane split, 32 stores)
+//     per stage interval, its VALU work in the shadow of the MFMA wave's matrix instructions;
+//   * the auxiliary waves still own the stage ring, now ONE wave per stage (stage x: aux x & 3, all 48 pieces, three instructions
+//     each): a wave has a stage in flight during two of every four intervals and finishes results only in the other two, so the
+//     vmcnt(0) that publishes a stage never waits for a store younger than two intervals (stores and LDS-DMA share the counter).
+// Same products, same k order, same epilogue expressions: bitwise the results of every other shape.
+template <int OUT, bool RELU>   // OUT: 1 two fp16 planes of result * cscale, 2 the QKV / KV form
+__global__ __launch_bounds__(512, 1) void gemm_f16x2_psf_kernel(Gemm2Args p) {
+    typedef PsGeo G;
+    constexpr unsigned SPARE = G::NSTG * G::STAGE_B;                        // 16 KB behind the ring
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    PsTiles tiles;
+    tiles.init(p.M, p.N, (int)blockIdx.x, (int)gridDim.x);
+    if (tiles.count == 0) return;
+    const int nk = p.K / 32;
+    const int total_stages = tiles.count * nk;
+    const int abl = p.tile >> 4;            // measurement switches: bit 0 no operand DMA, bit 1 no hand-over / epilogue, bit 2 no stores
+    // this lane's 16 bytes of a 1-KB dump row; MFMA wave w (and its partner w + 4) use 12 KB of the freed stage buffer + 4 KB of the spare
+    const int pw = wave & 3;
+    const unsigned dump_ring = (unsigned)pw * 12288u + (unsigned)lane * 16u, dump_spare = lds0 + SPARE + (unsigned)pw * 4096u + (unsigned)lane * 16u;
+
+    if (wave >= 4) {
+        // ======================================================================================== auxiliary waves
+        const int L = wave - 4;
+        const int prow = lane >> 2;
+        const unsigned chunkb = (unsigned)(((lane & 3) ^ ((prow >> 2) & 3)) * 16);
+        const char* const a_base = reinterpret_cast<const char*>(p.A);
+        const char* const w_base = reinterpret_cast<const char*>(p.W);
+        const size_t a_plane_b = p.a_plane * 2, w_plane_b = p.w_plane * 2;
+        unsigned va[G::A_PIECES], vw[G::W_PIECES];
+#pragma unroll
+        for (int q = 0; q < G::W_PIECES; ++q) vw[q] = (unsigned)(16 * q + prow) * (unsigned)p.ldw * 2u + chunkb;
+        // ---- loader state: my next stage (global index x = tile dti, stage ds)
+        int x = L, dti = 0, ds = L;
+        while (ds >= nk) { ds -= nk; ++dti; }
+        int cur_ti = -1;
+        const char* a_tile = a_base;
+        const char* w_tile = w_base;
+        bool inflight = false;
+        const bool dma = (abl & 1) == 0;
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            if (dma) {
+                if (dti != cur_ti) {
+                    int m0, n0;
+                    tiles.at(dti, m0, n0);
+                    cur_ti = dti;
+                    a_tile = a_base + (size_t)m0 * p.lda * 2;
+                    w_tile = w_base + (size_t)n0 * p.ldw * 2;
+                    const int last = p.M - 16 - m0;                 // rows past M re-read the last valid piece (never stored)
+#pragma unroll
+                    for (int q = 0; q < G::A_PIECES; ++q) va[q] = (unsigned)((16 * q <= last ? 16 * q : last) + prow) * (unsigned)p.lda * 2u + chunkb;
+                }
+                const unsigned buf = lds0 + (unsigned)(x % G::NSTG) * G::STAGE_B;
+                const char* const ab = a_tile + (size_t)ds * 64;
+                const char* const wb = w_tile + (size_t)ds * 64;
+                [&]<int... Q>(std::integer_sequence<int, Q...>) { (ps_piece<Q * 1024>(ab, va[Q], buf), ...); }(std::make_integer_sequence<int, G::A_PIECES>{});
+                [&]<int... Q>(std::integer_sequence<int, Q...>) { (ps_piece<G::A_PLANE_B + Q * 1024>(ab + a_plane_b, va[Q], buf), ...); }(std::make_integer_sequence<int, G::A_PIECES>{});
+                [&]<int... Q>(std::integer_sequence<int, Q...>) { (ps_piece<2 * G::A_PLANE_B + Q * 1024>(wb, vw[Q], buf), ...); }(std::make_integer_sequence<int, G::W_PIECES>{});
+                [&]<int... Q>(std::integer_sequence<int, Q...>) { (ps_piece<2 * G::A_PLANE_B + G::W_PLANE_B + Q * 1024>(wb + w_plane_b, vw[Q], buf), ...); }(std::make_integer_sequence<int, G::W_PIECES>{});
+            }
+            inflight = true;
+            x += 4; ds += 4;
+            while (ds >= nk) { ds -= nk; ++dti; }
+        };
+
+        // ---- finisher state: the partner's raw accumulators of one tile (accumulator file), its coordinates, how much is left to do
+        floatx16 img[4][2];
+        int fm0 = 0, fn0 = 0, units_left = 0;
+        const float oscale = p.oscale_dev ? p.oscale * *p.oscale_dev : p.oscale;
+        const int hh = lane >> 5, idx = lane & 31, odd = lane & 1;
+        // one quarter of a tile: arithmetic + stores. Plane tiles: unit U = 2 pp + tm = the column-tile pair (2 pp, 2 pp + 1) of row tile tm,
+        // half-waves swapped so that a store covers whole rows (see the kernel above); V tiles: unit U = column tile U, both row tiles
+        // (the argument struct through an opaque pointer: its fields are s_loaded where a quarter needs them instead of ~40 of them
+        // living in SGPRs across the whole kernel -- the K-loop side needs the scalar file too)
+        // (not &p: taking the parameter's address makes the compiler keep a private copy of the whole struct)
+        typedef const Gemm2Args __attribute__((address_space(4)))* KernArgs;
+#if defined(__HIP_DEVICE_COMPILE__)
+        KernArgs pq = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+        KernArgs pq = nullptr;
+#endif
+        asm volatile("" : "+s"(pq));
+        auto unit = [&](auto Uc) __attribute__((always_inline)) {
+            constexpr int U = decltype(Uc)::value;
+            const auto& q = *pq;
+            const int m0 = fm0, n0 = fn0;
+            const int mw = m0 + L * 64;
+            const int seg = OUT == 2 ? n0 / q.qkv_D + (q.kv_form ? 1 : 0) : 0;
+            const bool stores = (abl & 4) == 0;
+            if constexpr (OUT == 2) {
+                if (seg == 2) {
+                    constexpr int tn = U;
+                    float v_mul = q.v_mul;
+                    if (q.kv_mul_dev) v_mul *= q.kv_mul_dev[1];
+                    const int vc0 = n0 - (q.kv_form ? 1 : 2) * q.qkv_D;
+                    const int ldvt = q.ldvt, ldc = q.ldc;
+                    unsigned short* const vt0 = q.VT + (size_t)(vc0 + 32 * tn + idx) * ldvt + mw + 8 * hh;
+                    float* const c0 = q.C ? q.C + (size_t)(mw + 4 * hh) * ldc + vc0 + 32 * tn + idx : nullptr;
+                    const size_t vt_plane = q.vt_plane;
+                    const float bv = q.bias ? q.bias[n0 + 32 * tn + idx] : 0.f;
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) {
+                        const floatx16& a = img[tn][tm];
+#pragma unroll
+                        for (int Gq = 0; Gq < 2; ++Gq) {
+                            if (mw + 32 * tm + 16 * Gq >= q.M) continue;
+                            float t[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) t[j] = (a[8 * Gq + j] * oscale + bv) * v_mul;
+                            uint4 h, l;
+                            split2_pk(t[0], t[1], h.x, l.x);
+                            split2_pk(t[2], t[3], h.y, l.y);
+                            split2_pk(t[4], t[5], h.z, l.z);
+                            split2_pk(t[6], t[7], h.w, l.w);
+                            if (stores) {
+                                unsigned short* vp = vt0 + 32 * tm + 16 * Gq;
+                                *reinterpret_cast<uint4*>(vp) = h;
+                                *reinterpret_cast<uint4*>(vp + vt_plane) = l;
+                                if (c0) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j)
+                                        c0[(size_t)(32 * tm + 16 * Gq + 8 * (j >> 2) + (j & 3)) * ldc] = a[8 * Gq + j] * oscale + bv;
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    return;
+                }
+            }
+            constexpr int pp = U >> 1, tm = U & 1;
+            float pscale = q.cscale;
+            unsigned short* pdst = q.C2;
+            int pld = q.ldc2, pcol0 = n0;
+            size_t pplane = q.c_plane;
+            if constexpr (OUT == 2) {
+                pscale = seg == 0 ? q.q_mul : (q.kv_mul_dev ? q.k_mul * q.kv_mul_dev[0] : q.k_mul);
+                pdst = seg == 0 ? q.Qp : q.Kp;
+                pld = q.qkv_D; pplane = q.qk_plane;
+                pcol0 = n0 - (n0 / q.qkv_D) * q.qkv_D;
+            }
+            const int lc = 32 * hh + idx;                                   // this lane's column inside the pair's 64
+            const float bv = q.bias ? q.bias[n0 + 64 * pp + lc] : 0.f;
+            const floatx16& A = img[2 * pp][tm];
+            const floatx16& B = img[2 * pp + 1][tm];
+            // this lane's first element: row (mw + 32 tm + odd), its even column of the pair; rows advance by 2 pld elements
+            unsigned short* const d0 = pdst + (size_t)(mw + 32 * tm + odd) * pld + pcol0 + 64 * pp + (lc & ~1);
+            const size_t row2 = (size_t)2 * pld;
+            const int M = q.M;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                                   // register pair (2 k, 2 k + 1): rows rl, rl + 1 (A') and + 4 (B')
+                float lo_[2], hi_[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float fa = A[2 * k + e], fb = B[2 * k + e];
+                    unsigned xx = __builtin_bit_cast(unsigned, fa), yy = __builtin_bit_cast(unsigned, fb);
+                    ps_swap32(xx, yy);                                       // xx = A'[r] (rows + 0), yy = B'[r] (rows + 4)
+                    lo_[e] = __builtin_bit_cast(float, xx) * oscale + bv;
+                    hi_[e] = __builtin_bit_cast(float, yy) * oscale + bv;
+                    if constexpr (RELU) { lo_[e] = fmaxf(lo_[e], 0.f); hi_[e] = fmaxf(hi_[e], 0.f); }
+                }
+                if (mw + 32 * tm + 16 * (k >> 2) < M) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const float x0 = (half ? hi_[0] : lo_[0]) * pscale, x1 = (half ? hi_[1] : lo_[1]) * pscale;
+                        const float got = __builtin_bit_cast(float, dpp_swap1(__builtin_bit_cast(unsigned, odd ? x0 : x1)));
+                        unsigned h, l;
+                        split2_pk(odd ? got : x0, odd ? x1 : got, h, l);
+                        if (stores) {
+                            const int rl2 = 4 * (k >> 1) + (k & 1);          // (rows 0, 2, 8, 10, 16, 18, 24, 26) / 2
+                            unsigned short* const d = d0 + (size_t)(rl2 + 2 * half) * row2;
+                            *reinterpret_cast<unsigned*>(d) = h;
+                            *reinterpret_cast<unsigned*>(d + pplane) = l;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto do_unit = [&](int u) __attribute__((always_inline)) {
+            if (u == 0) unit(std::integral_constant<int, 0>{});
+            else if (u == 1) unit(std::integral_constant<int, 1>{});
+            else if (u == 2) unit(std::integral_constant<int, 2>{});
+            else unit(std::integral_constant<int, 3>{});
+        };
+        // the partner's dump -> my accumulator file, lane for lane: round R = accumulator tiles 4 R .. 4 R + 3, 16 reads of 16 B
+        auto take = [&](auto Rc, unsigned ring) __attribute__((always_inline)) {
+            constexpr int R = decltype(Rc)::value;
+            const unsigned ring_ = ring, spare_ = dump_spare;
+            [&, ring_, spare_]<int... J>(std::integer_sequence<int, J...>) {
+                ([&, ring_, spare_] {
+                    constexpr int tt = 4 * R + (J >> 2), r0 = 4 * (J & 3);
+                    ps_f4 v;
+                    if constexpr (J < 12) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(ring_), "n"(J * 1024));
+                    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(spare_), "n"((J - 12) * 1024));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+                    floatx16& a = img[tt >> 1][tt & 1];
+                    a[r0] = v[0]; a[r0 + 1] = v[1]; a[r0 + 2] = v[2]; a[r0 + 3] = v[3];
+                }(), ...);
+            }(std::make_integer_sequence<int, 16>{});
+        };
+
+        // stages 0 and 1 before the first barrier, stage 2 right after it; then around barrier g (the one in the middle of stage g):
+        // the owner of stage g + 1 waits for it before the barrier, the owner of stage g + 3 issues it after the barrier -- except
+        // behind a tile's LAST stage, whose buffer is the hand-over window first.
+        // (ONE lexical call site of the quarter-tile code: it is ~400 instructions per quarter, and an un-inlined copy would force the
+        // whole argument struct into memory. The loop runs one virtual tile past the end -- no barriers, no DMA -- to finish the last
+        // tile's results.)
+        if (L < 2 && x < total_stages) issue_next();
+        if (L == 0) { glds_wait_all(); inflight = false; }
+        __builtin_amdgcn_s_barrier();                                       // barrier -1
+        if (L == 2 && x < total_stages) issue_next();
+        int g = 0;
+        for (int ti = 0; ti <= tiles.count; ++ti) {
+            const bool real = ti < tiles.count;
+            bool deferred = false;
+            for (int s = 0; s < nk; ++s) {
+                if (real) {
+                    if (inflight && ((g + 1) & 3) == L) { glds_wait_all(); inflight = false; }
+                    __builtin_amdgcn_s_barrier();                           // barrier g
+                    if (((g + 3) & 3) == L && g + 3 < total_stages) {
+                        if (s != nk - 1) issue_next(); else deferred = true;
+                    }
+                    ++g;
+                }
+                // a quarter of the previous tile, in an interval without a stage of mine in flight (or, running out of intervals, anyway:
+                // the image must be free at the hand-over)
+                if (units_left > 0 && (!inflight || nk - 1 - s < units_left)) { do_unit(4 - units_left); --units_left; }
+            }
+            if (!real || (abl & 2)) { if (deferred) issue_next(); continue; }
+            const unsigned ring = lds0 + (unsigned)((g - 1) % G::NSTG) * G::STAGE_B + dump_ring;
+            __builtin_amdgcn_s_barrier();                                   // X1: the partner has dumped accumulator tiles 0..3
+            take(std::integral_constant<int, 0>{}, ring);
+            __builtin_amdgcn_s_barrier();                                   // X2
+            __builtin_amdgcn_s_barrier();                                   // X3: tiles 4..7 are in the window
+            take(std::integral_constant<int, 1>{}, ring);
+            __builtin_amdgcn_s_barrier();                                   // X4: the window is a stage buffer again
+            if (deferred) issue_next();
+            tiles.at(ti, fm0, fn0);
+            units_left = 4;
+        }
+        return;
+    }
+
+    // ============================================================================================ MFMA waves
+    const int hh = lane >> 5, idx = lane & 31;
+    const unsigned fsw = (unsigned)((idx >> 2) & 3);
+    const unsigned fa0 = lds0 + (unsigned)((wave * 64 + idx) * 64);
+    const unsigned fw0 = lds0 + 2 * G::A_PLANE_B + (unsigned)(idx * 64);
+    auto coff = [&](int st) { return (unsigned)(((2 * st + hh) ^ fsw) * 16); };
+    auto frag_read = [&](auto Rr, PsFrags& f, unsigned fa, unsigned fw) {
+        constexpr int r = decltype(Rr)::value;
+        if constexpr (r < 2) ps_read<G::A_PLANE_B + r * 2048>(f.al[r], fa);
+        else if constexpr (r < 6) ps_read<(r - 2) * 2048>(f.wh[r - 2], fw);
+        else if constexpr (r < 8) ps_read<(r - 6) * 2048>(f.ah[r - 6], fa);
+        else ps_read<G::W_PLANE_B + (r - 8) * 2048>(f.wl[r - 8], fw);
+    };
+    PsFrags f0, f1;
+    __builtin_amdgcn_s_barrier();                   // barrier -1: stage 0 has landed
+    int buf = 0;
+    for (int ti = 0; ti < tiles.count; ++ti) {
+        floatx16 acc[4][2];
+        auto kstep = [&](auto First, PsFrags& x, PsFrags& y, unsigned fa, unsigned fw) {
+            [&]<int... Gp>(std::integer_sequence<int, Gp...>) {
+                ([&] {
+                    constexpr int g = Gp, P = g >> 3, t = g & 7, tn = t >> 1, tm = t & 1;
+                    const f16x8& w = P == 1 ? x.wl[tn] : x.wh[tn];
+                    const f16x8& a = P == 0 ? x.al[tm] : x.ah[tm];
+                    if constexpr (P == 0 && decltype(First)::value) ps_mfma0(acc[tn][tm], a, w);
+                    else ps_mfma(acc[tn][tm], a, w);
+                    if constexpr ((g & 1) == 0) frag_read(std::integral_constant<int, (g >> 1)>{}, y, fa, fw);
+                }(), ...);
+            }(std::make_integer_sequence<int, 24>{});
+            ps_reads_done(y);
+        };
+        {
+            const unsigned cur0 = (unsigned)buf * G::STAGE_B;
+            [&]<int... I>(std::integer_sequence<int, I...>) { (frag_read(std::integral_constant<int, I>{}, f0, fa0 + cur0 + coff(0), fw0 + cur0 + coff(0)), ...); }(std::make_integer_sequence<int, 12>{});
+            ps_reads_done(f0);
+        }
+        auto stage = [&](auto First) {
+            const unsigned cur = (unsigned)buf * G::STAGE_B;
+            const int nb = buf + 1 == G::NSTG ? 0 : buf + 1;
+            const unsigned nxt = (unsigned)nb * G::STAGE_B;
+            kstep(First, f0, f1, fa0 + cur + coff(1), fw0 + cur + coff(1));
+            __builtin_amdgcn_s_barrier();
+            kstep(std::false_type{}, f1, f0, fa0 + nxt + coff(0), fw0 + nxt + coff(0));
+            buf = nb;
+        };
+        stage(std::true_type{});
+        for (int s = 1; s < nk; ++s) stage(std::false_type{});
+        ps_settle(acc);
+        if (abl & 2) {
+            if (acc[0][0][0] == 123.456f && p.C) p.C[0] = acc[3][1][15];
+            continue;
+        }
+        // ---- hand the raw accumulators to the partner: the buffer of the tile's last stage (read for the last time before its
+        //      barrier; nothing is issued into it before X4) + the spare 16 KB, two rounds of four accumulator tiles
+        const unsigned ring = lds0 + (unsigned)(buf == 0 ? G::NSTG - 1 : buf - 1) * G::STAGE_B + dump_ring;
+        auto dump = [&](auto Rc) {
+            constexpr int R = decltype(Rc)::value;
+            const unsigned ring_ = ring, spare_ = dump_spare;
+            [&, ring_, spare_]<int... J>(std::integer_sequence<int, J...>) {
+                ([&, ring_, spare_] {
+                    constexpr int tt = 4 * R + (J >> 2), r0 = 4 * (J & 3);
+                    const floatx16& a = acc[tt >> 1][tt & 1];
+                    const ps_f4 v = {a[r0], a[r0 + 1], a[r0 + 2], a[r0 + 3]};
+                    if constexpr (J < 12) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(ring_), "v"(v), "n"(J * 1024) : "memory");
+                    else asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(spare_), "v"(v), "n"((J - 12) * 1024) : "memory");
+                }(), ...);
+            }(std::make_integer_sequence<int, 16>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        dump(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_s_barrier();               // X1
+        __builtin_amdgcn_s_barrier();               // X2: the partner has read round 0
+        dump(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_s_barrier();               // X3
+        __builtin_amdgcn_s_barrier();               // X4
+    }
+}
+
+template <int OUT, bool RELU>
+int launch_psf(const Gemm2Args& a, hipStream_t stream) {
+    constexpr int LDS = PsGeo::LDS_B + 16384;       // the ring + the spare 16 KB = the CU's whole LDS
+    static PerDeviceOnce configured;
+    if (!configured.done()) {
+        PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_psf_kernel<OUT, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        configured.mark();
+    }
+    const int n_cu = device_cu_count() / 8 * 8;
+    const long tiles = (long)ceil_div(a.M, PsGeo::BM) * (a.N / PsGeo::BN);
+    int grid = n_cu;
+    if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((gemm_f16x2_psf_kernel<OUT, RELU>), dim3((unsigned)grid), dim3(512), LDS, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int MODE, int OUT, bool RELU>
 int launch_ps_r(const Gemm2Args& a, hipStream_t stream) {
     static PerDeviceOnce configured;
@@ -472,8 +826,12 @@ bool gemm_f16x2_ps_ok(const Gemm2Args& a) {
 
 int launch_gemm_f16x2_ps(const Gemm2Args& a, hipStream_t stream) {
     PF_REQUIRE(gemm_f16x2_ps_ok(a), "gemm_f16x2 (persistent shape): needs K % 32 == 0, K >= 64, N % 128 == 0, M % 16 == 0, fp32 or plane output");
-    if (a.qkv_D > 0) return launch_ps_r<0, 2, false>(a, stream);
-    if (a.C2) return launch_ps<0, 1>(a, stream);
+    const bool fin = (a.tile & 15) == 10 && a.K % 128 == 0;       // (the finisher form wants >= 4 stage intervals per quarter-tile round: K % 128 == 0)
+    if (a.qkv_D > 0) return fin ? launch_psf<2, false>(a, stream) : launch_ps_r<0, 2, false>(a, stream);
+    if (a.C2) {
+        if (fin) return a.relu ? launch_psf<1, true>(a, stream) : launch_psf<1, false>(a, stream);
+        return launch_ps<0, 1>(a, stream);
+    }
     const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
     switch (mode) {
         case 0: return launch_ps<0, 0>(a, stream);

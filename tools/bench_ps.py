@@ -82,7 +82,7 @@ def timing():
             a2, w2, b = operands(N, K, data=data)
             r2 = torch.randn(M, N, device=dev)
             row = {"shape": name, "data": data, "M": M}
-            for label, tile in (("ps_nodma", PS + 16), ("ps_noepi", PS + 32), ("ps_loop", PS + 48), ("ps_nostore", PS + 64), ("ps_l2window", PS + 128), ("ps_stagger", PS + 256)):
+            for label, tile in (("ps_nodma", PS + 16), ("ps_noepi", PS + 32), ("ps_loop", PS + 48), ("ps_nostore", PS + 64), ("ps1", 11), ("ps1_nostore", 11 + 64)):
                 row[label + "_planes"] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, relu=True, out_planes=True,
                                                                          out_scale_exp=9, time_iters=20)[1]), 1)
             for label, tile in (("t2", 2), ("t7", 7), ("ps", PS)):
@@ -91,7 +91,7 @@ def timing():
                 row[label + "_planes"] = round(best(lambda: ops.gemm_f16x2(a2, w2, b, scale_exp=20, tile=tile, relu=True, out_planes=True,
                                                                          out_scale_exp=9, time_iters=20)[1]), 1)
             if name == "qkv":
-                for label, tile in (("t2", 2), ("t7", 7), ("ps", PS)):
+                for label, tile in (("t2", 2), ("t7", 7), ("ps", PS), ("ps1", 11), ("ps_nostore", PS + 64), ("ps_noepi", PS + 32)):
                     row[label + "_qkvform"] = round(best(lambda: ops.gemm_f16x2_qkv(a2, w2, b, 512, 20, 8.0, 16.0, 32.0, tile=tile, time_iters=20)["ms"]), 1)
             fl = 2.0 * M * N * K * 3
             row["exec_TFLOPs_ps_planes"] = round(fl / row["ps_planes"] / 1e6)
