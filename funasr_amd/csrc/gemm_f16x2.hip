@@ -17,6 +17,7 @@
 //   256 x 256 (wave = 2 x 4 MFMA tiles): 12 ds_read_b128 + 24 MFMA per 16-deep step, 64-KB stages, 2/3 of the L2 -> LDS
 //                                         bytes per flop: the shape for N >= 1024
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 #include "gemm_f16x2_epilogue.h"
 
@@ -581,6 +582,22 @@ int launch_rowl1_bound(const float* W, int rows, int cols, int ld, const float* 
     return 0;
 }
 
+// QKV / KV form: the persistent 256 x 128 shape (gemm_f16x2_ps.hip) takes it where whole rounds of 256 x 256 blocks fit the row count
+// badly (the last round less than ~ half full: SenseVoice's 128 x 10 s batch, M = 22 528 -> 528 blocks = 2.06 rounds): its 256 x 128
+// tiles quantise twice as finely. Same-call A/B inside the engine (profiles/r06i_ab_qkv_on_ps.txt): SenseVoiceSmall 29 412 -> 29 852
+// audio-s/s; the headline shape (768 blocks = 3 whole rounds) is left alone (50.59 / 50.68 ms with the form forced on). Same bits either
+// way. PF_QKV_PS=0 / 1 (environment) forces never / always for A/B runs.
+static bool qkv_form_prefers_ps(const Gemm2Args& a) {
+    static const int mode = [] { const char* e = getenv("PF_QKV_PS"); return e ? atoi(e) : 2; }();
+    if (mode == 0 || !gemm_f16x2_ps_ok(a)) return false;
+    if (mode == 1) return true;
+    const int n_cu = device_cu_count();
+    const long blocks = (long)ceil_div(a.M, 256) * (a.N / 256);
+    if (blocks < n_cu) return false;            // (small problems: the 128 x 128 shapes below)
+    const double rounds = (double)blocks / n_cu, whole = (double)((blocks + n_cu - 1) / n_cu);
+    return whole / rounds > 1.15;
+}
+
 int gemm_f16x2_argmax_parts(int M, int N) { (void)M; return 2 * ceil_div(N, 256); }
 
 int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
@@ -639,7 +656,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
     }
     // the four-wave 256 x 256 shape (gemm_f16x2_w4.hip): tile 7; bits 4.. = its measurement builds
     // the persistent wave-specialised shape (gemm_f16x2_ps.hip): tile 10; shapes it does not take are chosen by shape instead
-    if ((a.tile & 15) == 10 || (a.tile & 15) == 11) {         // 10: finisher form for plane / QKV outputs; 11: the first form everywhere (A/B)
+    if ((a.tile & 15) == 10 || (a.tile & 15) == 12) {         // 10: the persistent shape; 12: its finisher form (measurement library only)
         if (gemm_f16x2_ps_ok(a)) return launch_gemm_f16x2_ps(a, stream);
         Gemm2Args b = a;
         b.tile = 0;
@@ -655,6 +672,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         if (a.tile == 5) return launch_pair<0, 2>(a, stream);
         if (a.tile == 6) return launch_ring<0, 2>(a, stream);
         if (a.tile == 3) return launch_tile<2, 2, 0, 2, 0, 0, 2>(a, stream);     // 128 x 128, four waves, two workgroups per CU
+        if (a.tile == 0 && qkv_form_prefers_ps(a)) return launch_gemm_f16x2_ps(a, stream);
         if (a.tile == 0) {
             // Shape by the row count, in units of one round of 256 x 256 blocks (tools/bench_r03.py `qkvsplit`, N = 1536):
             //   256 x 256 only: whole rounds -- 528 blocks (M = 22 528) cost 3, not 2.06;

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
     }
 }
 
+#if defined(PF_MEASUREMENT_KERNELS)
 // ================================================================================================ finisher form (planes / QKV)
 // Round 6, second step. The dissection of the kernel above (profiles/r06g_ps_dissection.jsonl; w_1, M = 32768, random planes):
 // K loop 132 us; + operand DMA by the loader waves 156; + epilogue arithmetic in the MFMA waves 175; + their stores 236 -- the
@@ -794,6 +795,8 @@ int launch_psf(const Gemm2Args& a, hipStream_t stream) {
     return 0;
 }
 
+#endif  // PF_MEASUREMENT_KERNELS
+
 template <int MODE, int OUT, bool RELU>
 int launch_ps_r(const Gemm2Args& a, hipStream_t stream) {
     static PerDeviceOnce configured;
@@ -826,12 +829,15 @@ bool gemm_f16x2_ps_ok(const Gemm2Args& a) {
 
 int launch_gemm_f16x2_ps(const Gemm2Args& a, hipStream_t stream) {
     PF_REQUIRE(gemm_f16x2_ps_ok(a), "gemm_f16x2 (persistent shape): needs K % 32 == 0, K >= 64, N % 128 == 0, M % 16 == 0, fp32 or plane output");
-    const bool fin = (a.tile & 15) == 10 && a.K % 128 == 0;       // (the finisher form wants >= 4 stage intervals per quarter-tile round: K % 128 == 0)
-    if (a.qkv_D > 0) return fin ? launch_psf<2, false>(a, stream) : launch_ps_r<0, 2, false>(a, stream);
-    if (a.C2) {
-        if (fin) return a.relu ? launch_psf<1, true>(a, stream) : launch_psf<1, false>(a, stream);
-        return launch_ps<0, 1>(a, stream);
-    }
+#if defined(PF_MEASUREMENT_KERNELS)
+    // tile 12 (measurement library only, `make measure`): the finisher form for plane / QKV outputs -- measured and off
+    // (profiles/r06h_ps_finisher_form.jsonl: w_1 330 us against 251 for the form above and 211 for the eight-wave 256 x 256 shape)
+    const bool fin = (a.tile & 15) == 12 && a.K % 128 == 0;       // (>= 4 stage intervals per quarter-tile round)
+    if (fin && a.qkv_D > 0) return launch_psf<2, false>(a, stream);
+    if (fin && a.C2) return a.relu ? launch_psf<1, true>(a, stream) : launch_psf<1, false>(a, stream);
+#endif
+    if (a.qkv_D > 0) return launch_ps_r<0, 2, false>(a, stream);
+    if (a.C2) return launch_ps<0, 1>(a, stream);
     const int mode = (a.R1 ? 1 : 0) | (a.R2 ? 2 : 0);
     switch (mode) {
         case 0: return launch_ps<0, 0>(a, stream);
