@@ -161,6 +161,7 @@ SIGNATURES = {
     "pf_frontend_fbank": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "pf_frontend_lfr_cmvn": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "pf_set_skinny_max_m": (C.c_int, [_i32]),
+    "pf_measurement_build": (C.c_int, []),
     "pf_k_conv1d_gemm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pf_k_gemm_f32": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pf_k_gemm_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -297,17 +297,24 @@ int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
                "attention_f16x2: 16-B alignment");
     static PerDeviceOnce configured;
     if (!configured.done()) {
+#if defined(PF_MEASUREMENT_KERNELS)
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+#endif
         PF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<0, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         configured.mark();
     }
     const int rows = a.Tq > 0 ? a.Tq : a.Tp;
     Attn2Args k = a;
+    // variant 3 (lazy rescale) is the product's schedule; 0 / 1 are in the measurement library only (`make measure`; profiles/r02l_bench_attn2.json)
+#if defined(PF_MEASUREMENT_KERNELS)
     PF_REQUIRE(a.variant == 0 || a.variant == 1 || a.variant == 3, "attention_f16x2: variant must be 0, 1 or 3");
+#else
+    PF_REQUIRE(a.variant == 3, "attention_f16x2: variant must be 3 (variants 0 / 1: the measurement library, make measure)");
+#endif
     const int nqb = ceil_div(rows, 256);
     dim3 grid(nqb, a.H, a.B);
     // more than one query block per (sequence, head): XCD-aware 1-D order (xcd_nqb < 0 keeps the plain order: measurement hook)
@@ -315,10 +322,12 @@ int launch_attention_f16x2(const Attn2Args& a, hipStream_t stream) {
     if (k.xcd_nqb > 0) grid = dim3((unsigned)(ceil_div(a.B * a.H, 8) * 8 * nqb), 1, 1);
     if (a.variant == 3)
         hipLaunchKernelGGL((attention_f16x2_kernel<0, true>), grid, dim3(512), LDS_BYTES, stream, k);
+#if defined(PF_MEASUREMENT_KERNELS)
     else if (a.variant == 1)
         hipLaunchKernelGGL(attention_f16x2_kernel<1>, grid, dim3(512), LDS_BYTES, stream, k);
     else
         hipLaunchKernelGGL(attention_f16x2_kernel<0>, grid, dim3(512), LDS_BYTES, stream, k);
+#endif
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

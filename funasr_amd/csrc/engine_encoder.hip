@@ -284,6 +284,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             if ((rc = launch_layernorm(x, D, w.n2g, w.n2b, reinterpret_cast<float*>(xn2), D, M, D, D, c.ln_eps, s, 3, 0,
                                        (size_t)M * D, pow2f(w.e_x2)))) return rc;
         }
+#if defined(PF_MEASUREMENT_KERNELS)      // the one-launch feed-forward (gemm_f16x2_ffn.hip): a tie with the pair at best, measurement library only
         if (fuse && e->ffn_fused && ffn_f16x2_applicable(D, F) && (e->ffn_fused == 2 || ffn_fills_rounds(M))) {
             const bool ln = next && next->in_dim == D;
             FfnArgs g{};
@@ -299,6 +300,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
             ProfScope ps(PROF_GEMM3, 2.0 * Mw * 2.0 * (double)D * F, s, "enc.ffn fused (w_1 +relu +w_2 +res +LN)");
             return launch_ffn_f16x2(g, s);
         }
+#endif
         if ((rc = gemm2(xn2, D, w.e_x2, w.w1_2, w.ew_1, w.b1, nullptr, 0, ffn2, w.e_h, F, D, 1, nullptr, 0, nullptr, 0))) return rc;
         if (fuse && encoder_w2_row_form(e, M)) {
             // w_2 + residual -> x, and (when a block follows directly) its norm1(x) -> the planes its QKV projection reads
@@ -524,17 +526,28 @@ int pf_encoder_set_option(pf_encoder* eh, const char* key, int32_t value) {
     Encoder* e = reinterpret_cast<Encoder*>(eh);
     PF_REQUIRE(e && key, "encoder_set_option: null");
     const std::string k = key;
+    // the product's keys: fuse_row, fsmn_fused (the unfused chains are the bitwise references of the fused kernels), w2_row (which form
+    // w_2 takes), gemm_tile (0 by shape; 2 / 7 / 10 pin a shape for A/B runs). Everything else selects measured-and-off shapes and exists
+    // in the measurement library only (`make measure`): DESIGN 3 lists each with the file that holds its numbers.
     if (k == "fuse_row") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fuse_row is 0 or 1"); e->fuse_row = value; return 0; }
+    if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
+    if (k == "w2_row") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: w2_row is 0, 1 or 2"); e->w2_row = value; return 0; }
+#if defined(PF_MEASUREMENT_KERNELS)
+    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7 || value == 8 || value == 9 || value == 10 || value == 12, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6, 7, 8, 9, 10 or 12"); e->gemm_tile = value; return 0; }
     if (k == "ffn_abl") { e->ffn_abl = value; return 0; }
     if (k == "ffn_fused") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: ffn_fused is 0, 1 or 2"); e->ffn_fused = value; return 0; }
-    if (k == "fsmn_fused") { PF_REQUIRE(value == 0 || value == 1, "encoder_set_option: fsmn_fused is 0 or 1"); e->fsmn_fused = value; return 0; }
     if (k == "row_bm") { PF_REQUIRE(value == 0 || value == 96 || value == 128 || value == 129 || value == 130, "encoder_set_option: row_bm is 0, 96, 128, 129 or 130"); e->row_bm = value; return 0; }
     if (k == "row_sched") { PF_REQUIRE(value == 0 || value == 2, "encoder_set_option: row_sched is 0 or 2"); e->row_sched = value; return 0; }
     if (k == "w2_tile") { PF_REQUIRE(value == 0 || value == 2 || value == 7 || value == 8 || value == 10, "encoder_set_option: w2_tile is 0, 2, 7, 8 or 10"); e->w2_tile = value; return 0; }
-    if (k == "w2_row") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: w2_row is 0, 1 or 2"); e->w2_row = value; return 0; }
     if (k == "row_nt") { PF_REQUIRE(value >= 0 && value <= 2, "encoder_set_option: row_nt is 0, 1 or 2"); e->row_nt = value; return 0; }
-    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 5 || value == 6 || value == 7 || value == 8 || value == 9 || value == 10, "encoder_set_option: gemm_tile is 0, 1, 2, 5, 6, 7, 8, 9 or 10"); e->gemm_tile = value; return 0; }
     if (k == "attn_variant") { PF_REQUIRE(value == 0 || value == 1 || value == 3, "encoder_set_option: attn_variant is 0, 1 or 3"); e->attn_variant = value; return 0; }
+#else
+    if (k == "gemm_tile") { PF_REQUIRE(value == 0 || value == 2 || value == 7 || value == 10, "encoder_set_option: gemm_tile is 0, 2, 7 or 10"); e->gemm_tile = value; return 0; }
+    if (k == "ffn_abl" || k == "ffn_fused" || k == "row_bm" || k == "row_sched" || k == "w2_tile" || k == "row_nt" || k == "attn_variant") {
+        set_error("encoder_set_option: " + k + " selects a measured-and-off shape: build and load the measurement library (make -C funasr_amd/csrc measure; PF_LIB_PATH)");
+        return -1;
+    }
+#endif
     set_error("encoder_set_option: unknown key " + k);
     return -1;
 }

@@ -44,6 +44,14 @@ int pf_k_conv1d_gemm_f32(const float* hidden, const float* W, const float* bias,
     g.relu = relu; g.conv_taps = taps; g.conv_D = D; g.conv_T = T; g.conv_left = left; g.conv_zero = zero_dev;
     return launch_gemm_f32(g, reinterpret_cast<hipStream_t>(stream));
 }
+/* 1: this library was built with the measured-and-off kernel shapes and ablation builds (make measure); 0: the product */
+int pf_measurement_build(void) {
+#if defined(PF_MEASUREMENT_KERNELS)
+    return 1;
+#else
+    return 0;
+#endif
+}
 /* bf16-operand GEMM (throughput mode): A [M,K] bf16, W [N,K] bf16, fp32 accumulate, fp32 bias/residuals, C fp32 or
  * bf16 (c_bf16); strides in elements */
 int pf_k_gemm_bf16(const void* A, int32_t lda, const void* W, int32_t ldw, const float* bias, const float* R1,
@@ -211,6 +219,7 @@ int pf_k_gemm_f16x2_row(const void* A2, int32_t lda, int64_t a_plane, const void
 }
 /* the encoder block's feed-forward in one launch (gemm_f16x2_ffn.hip): C = R + (relu(X W1^T + b1) W2^T + b2) [+ LayerNorm -> planes Y2
  * or fp32 Yf]; operands are two-plane fp16 tensors ([2][M, 512], [2][F, 512], [2][512, F]), plane strides M 512 / F 512 / 512 F */
+#if defined(PF_MEASUREMENT_KERNELS)
 int pf_k_ffn_f16x2(const void* X2, const void* W1, const void* W2, const float* b1, const float* b2, float oscale1, float hscale,
                    float oscale2, const float* R, float* Cout, const float* ln_g, const float* ln_b, float ln_eps, void* Y2,
                    float yscale, float* Yf, int32_t M, int32_t F, int32_t iters, float* ms_out, void* stream) {
@@ -229,6 +238,14 @@ int pf_k_ffn_f16x2(const void* X2, const void* W1, const void* W2, const float* 
     if (iters <= 0 || !ms_out) return launch_ffn_f16x2(g, s);
     return time_launches([&] { return launch_ffn_f16x2(g, s); }, iters, ms_out, s);
 }
+#else
+int pf_k_ffn_f16x2(const void* X2, const void* W1, const void* W2, const float* b1, const float* b2, float oscale1, float hscale,
+                   float oscale2, const float* R, float* Cout, const float* ln_g, const float* ln_b, float ln_eps, void* Y2,
+                   float yscale, float* Yf, int32_t M, int32_t F, int32_t iters, float* ms_out, void* stream) {
+    set_error("pf_k_ffn_f16x2: the one-launch feed-forward is in the measurement library only (make -C funasr_amd/csrc measure)");
+    return -1;
+}
+#endif
 /* the FSMN form of the full-row kernel: the first addend is the FSMN memory block (11 taps, left padding 5) of fs_v [M, 512],
  * valid input rows [fs_lo[g], fs_hi[g]) per 16-row group g; M % 16 == 0, LayerNorm epilogue required */
 int pf_k_gemm_f16x2_row_fsmn(const void* A2, int32_t lda, int64_t a_plane, const void* W2, int32_t ldw, int64_t w_plane, float oscale,

@@ -454,6 +454,7 @@ int launch_tile(const Gemm2Args& a, hipStream_t stream) {
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }
+#if defined(PF_MEASUREMENT_KERNELS)
 // NOTE (round 4): the 128 x 256 shape below (tile 5) stages its operands behind COUNTED vmcnt waits (glds_wait_but). LDS-DMA pieces of
 // one wave were found to retire out of issue order when their sources differ (gemm_f16x2_ffn.hip header): it passes the warm kernel
 // tests but is NOT safe inside a long pipeline -- a measurement hook only. The deep ring (tile 6) was rebuilt on exact waits with one
@@ -464,6 +465,7 @@ int launch_pair(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 
 // the 256 x 256 eight-wave shape over a deep ring of 16-deep stages (tile 6; N % 256 == 0)
 template <int MODE, int OUT>
 int launch_ring(const Gemm2Args& a, hipStream_t stream) { return launch_tile<2, 4, MODE, OUT, 0, 0, 4, 16>(a, stream); }
+#endif
 template <int MODE, int OUT>
 int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // block shape by N only (never by the batch's M: a clip's result must not depend on what else is in the batch --
@@ -471,8 +473,11 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     if constexpr (OUT == 1) {
         if (a.tile == 3) return launch_tile<2, 2, MODE, 1, 0, 0, 2>(a, stream);   // 128 x 128, 4 waves (plane output)
     }
-    if constexpr (OUT == 0) {              // measurement hooks (tools/abl_gemm2.py)
+    if constexpr (OUT == 0) {
         if (a.tile == 3) return launch_tile<2, 2, MODE, 0, 0, 0, 2>(a, stream);   // 128 x 128, 4 waves, two workgroups per CU
+    }
+#if defined(PF_MEASUREMENT_KERNELS)
+    if constexpr (OUT == 0) {              // measurement hooks (tools/abl_gemm2.py)
         if (a.tile >= 256) return (a.tile >> 8) == 1 ? launch_tile<2, 4, MODE, 0, 0, 1>(a, stream) : launch_tile<2, 4, MODE, 0, 0, 2>(a, stream);
     }
     if constexpr (MODE == 0 && OUT == 0) {
@@ -489,6 +494,7 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
             }
         }
     }
+#endif
     // 256 x 256 blocks or 256 x 128 ones (twice as many, each 0.57 of the time: tools/abl_gemm2.py), whichever needs less
     // time in whole rounds over the CUs: 290 wide blocks on 256 CUs are two rounds, 580 narrow ones three half-rounds.
     // The choice moves no result: both shapes issue the same products in the same k order per output element (bitwise
@@ -517,8 +523,10 @@ int launch_one(const Gemm2Args& a, hipStream_t stream) {
     // the pieces between them, then the next k-step's) is 6-15 % FASTER per launch and 1.4 % per step
     // (profiles/r05s_ab_wide_tile_sched0.txt: w_1 planes 230 -> 211 us, QKV form 185.5 -> 174.5, w_2 212 -> 191; same bits).
     // tile 8 = SCHED 2 stays reachable for A/B runs.
+#if defined(PF_MEASUREMENT_KERNELS)
     if (wide && a.tile == 8) return launch_tile<2, 4, MODE, OUT, 0, 2>(a, stream);
     if (wide && a.tile == 9) return launch_tile<2, 4, MODE, OUT, 0, 3>(a, stream);
+#endif
     return wide ? launch_tile<2, 4, MODE, OUT, 0, 0>(a, stream) : launch_tile<2, 2, MODE, OUT>(a, stream);
 }
 
@@ -668,9 +676,19 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
         b.tile = 0;
         return launch_gemm_f16x2(b, stream);
     }
+    // Tile ids of the product: 0 by shape, 1 / 2 the eight-wave 256 x 128 / 256 x 256 shapes, 3 the four-wave 128 x 128 shape, 7 the
+    // four-wave 256 x 256 shape, 10 the persistent 256 x 128 shape. The measured-and-off shapes -- 5 (128 x 256, two workgroups per CU,
+    // counted waits), 6 (deep ring), 8 / 9 (round 2's k-step order, static priorities), the ablation builds -- are in the measurement
+    // library only (`make measure`; their numbers: profiles/r03y*, r04_ffn*, r05s, r05w, docs/history).
+#if !defined(PF_MEASUREMENT_KERNELS)
+    PF_REQUIRE(a.tile == 0 || a.tile == 1 || a.tile == 2 || a.tile == 3 || a.tile == 7 || (a.tile & 15) == 10,
+               "gemm_f16x2: this tile id is a measurement shape (libparaformer_hip_measure.so, make measure)");
+#endif
     if (a.qkv_D > 0) {
+#if defined(PF_MEASUREMENT_KERNELS)
         if (a.tile == 5) return launch_pair<0, 2>(a, stream);
         if (a.tile == 6) return launch_ring<0, 2>(a, stream);
+#endif
         if (a.tile == 3) return launch_tile<2, 2, 0, 2, 0, 0, 2>(a, stream);     // 128 x 128, four waves, two workgroups per CU
         if (a.tile == 0 && qkv_form_prefers_ps(a)) return launch_gemm_f16x2_ps(a, stream);
         if (a.tile == 0) {
@@ -706,16 +724,21 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
                 return rc ? rc : launch_tile<2, 2, 0, 2, 0, 0, 2>(t, stream);
             }
         }
+#if defined(PF_MEASUREMENT_KERNELS)
         if (a.tile == 8) return launch_tile<2, 4, 0, 2, 0, 2>(a, stream);       // (A/B: round 2's schedule)
         if (a.tile == 9) return launch_tile<2, 4, 0, 2, 0, 3>(a, stream);
+#endif
         return launch_tile<2, 4, 0, 2, 0, 0>(a, stream);
     }
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");
+#if defined(PF_MEASUREMENT_KERNELS)
         if (a.tile == 5 && a.N % 256 == 0) return launch_pair<0, 1>(a, stream);
         if (a.tile == 6 && a.N % 256 == 0) return launch_ring<0, 1>(a, stream);
+#endif
         return launch_one<0, 1>(a, stream);
     }
+#if defined(PF_MEASUREMENT_KERNELS)
     if (a.tile == 5 && a.N % 256 == 0) {
         switch (mode) {
             case 0: return launch_pair<0, 0>(a, stream);
@@ -732,6 +755,7 @@ int launch_gemm_f16x2(const Gemm2Args& a, hipStream_t stream) {
             default: return launch_ring<3, 0>(a, stream);
         }
     }
+#endif
     switch (mode) {
         case 0: return launch_one<0, 0>(a, stream);
         case 1: return launch_one<1, 0>(a, stream);

@@ -155,9 +155,12 @@ int launch_row_t(const GemmRowArgs& a, hipStream_t stream) {
 }
 template <int MODE, bool LN>
 int launch_row_m(const GemmRowArgs& a, hipStream_t stream) {
-    // a_nt bit 0: non-temporal A loads; bit 1 (A/B hook): the plain k-step order instead of both k-steps' fragments up front
-    if (a.a_nt & 2) return (a.a_nt & 1) ? launch_row_t<MODE, LN, true, 0>(a, stream) : launch_row_t<MODE, LN, false, 0>(a, stream);
-    return (a.a_nt & 1) ? launch_row_t<MODE, LN, true>(a, stream) : launch_row_t<MODE, LN, false>(a, stream);
+    // a_nt bit 0: non-temporal A loads; bit 1: the plain k-step order (the product's since round 5, profiles/r05t); without it both
+    // k-steps' fragments up front -- the measurement library only
+#if defined(PF_MEASUREMENT_KERNELS)
+    if (!(a.a_nt & 2)) return (a.a_nt & 1) ? launch_row_t<MODE, LN, true>(a, stream) : launch_row_t<MODE, LN, false>(a, stream);
+#endif
+    return (a.a_nt & 1) ? launch_row_t<MODE, LN, true, 0>(a, stream) : launch_row_t<MODE, LN, false, 0>(a, stream);
 }
 
 }  // namespace
@@ -193,9 +196,14 @@ int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream) {
         const double cost128 = (double)ceil_div(ceil_div(a.M, 128), n_cu), cost96 = 0.80 * (double)ceil_div(ceil_div(a.M, 96), n_cu);
         bm = cost96 < cost128 - 0.02 ? 96 : 128;
     }
-    if (bm == 130) return launch_gemm_f16x2_w4_row(a, stream);       // the four-wave 1 x 4 grid (gemm_f16x2_w4.hip)
+#if defined(PF_MEASUREMENT_KERNELS)
+    if (bm == 130) return launch_gemm_f16x2_w4_row(a, stream);       // the four-wave 1 x 4 grid (gemm_f16x2_w4.hip): measured and off
     if (bm != 128) {
         PF_REQUIRE(bm == 96 || bm == 129, "gemm_f16x2_row: block_rows is 0, 96, 128, 129 or 130");
+#else
+    if (bm != 128) {
+        PF_REQUIRE(bm == 96, "gemm_f16x2_row: block_rows is 0, 96 or 128 (129 / 130: the measurement library, make measure)");
+#endif
         const int rc = launch_gemm_f16x2_row8(a, bm == 96 ? 96 : 128, stream);
         if (rc != -3) return rc;                      // -3: form not built in that height
     }

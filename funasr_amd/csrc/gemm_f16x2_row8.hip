@@ -363,7 +363,9 @@ int launch_row8_w(const GemmRowArgs& a, hipStream_t stream) {
 /* rows per block 96 or 128 (bm); -3: this form is not built in that height. Argument checks are launch_gemm_f16x2_row's. */
 int launch_gemm_f16x2_row8(const GemmRowArgs& a, int bm, hipStream_t stream) {
     if (bm == 96) return launch_row8_w<3>(a, stream);
-    if (bm == 128) return launch_row8_w<4>(a, stream);
+#if defined(PF_MEASUREMENT_KERNELS)
+    if (bm == 128) return launch_row8_w<4>(a, stream);               // (the 128-row height of this wave grid: measured and off)
+#endif
     return -3;
 }
 

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_kernel(Gemm2Args p, int 
     gemm2_epilogue<4, 4, 4, MODE, OUT, EABL>(p, acc, smem, m0, n0, nblk, wave, wr, wc, lane);
 }
 
+#if defined(PF_MEASUREMENT_KERNELS)
 // full-row form (N == 512): one workgroup = 128 complete rows, wave w = columns 128 w ..; the row epilogue runs once per 64-row half
 template <int MODE, bool LN, bool A_NT>
 __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_row_kernel(GemmRowArgs p) {
@@ -229,6 +230,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w4_row_kernel(GemmRowArgs p
     gemm2_row_epilogue<MODE, LN, 256, 4, 0>(p, acc, smem, m0, tid, wave, 0, wave, lane, true);
     gemm2_row_epilogue<MODE, LN, 256, 4, 2>(p, acc, smem, m0, tid, wave, 1, wave, lane, false);
 }
+
+#endif
 
 template <int MODE, int OUT, int EABL = 0, int NODMA = 0>
 int launch_w4(const Gemm2Args& a, hipStream_t stream) {
@@ -246,6 +249,7 @@ int launch_w4(const Gemm2Args& a, hipStream_t stream) {
     return 0;
 }
 
+#if defined(PF_MEASUREMENT_KERNELS)
 template <int MODE, bool LN, bool A_NT>
 int launch_w4_row_t(const GemmRowArgs& a, hipStream_t stream) {
     typedef W4Geo<1, 4> G;
@@ -264,6 +268,8 @@ int launch_w4_row_m(const GemmRowArgs& a, hipStream_t stream) {
     return (a.a_nt & 1) ? launch_w4_row_t<MODE, LN, true>(a, stream) : launch_w4_row_t<MODE, LN, false>(a, stream);
 }
 
+#endif
+
 }  // namespace
 
 bool gemm_f16x2_w4_ok(const Gemm2Args& a) {
@@ -279,12 +285,18 @@ int launch_gemm_f16x2_w4(const Gemm2Args& a, int abl, hipStream_t stream) {
     if (a.qkv_D > 0) return launch_w4<0, 2>(a, stream);
     if (a.C2) {
         PF_REQUIRE(mode == 0, "gemm_f16x2: the plane output has no residual form");
+#if defined(PF_MEASUREMENT_KERNELS)
         if (abl == 1) return launch_w4<0, 1, 1>(a, stream);
+#endif
         return launch_w4<0, 1>(a, stream);
     }
+#if defined(PF_MEASUREMENT_KERNELS)
     if (abl == 1) return launch_w4<0, 0, 1>(a, stream);
     if (abl == 2) return launch_w4<0, 0, 2>(a, stream);
     if (abl == 3) return launch_w4<0, 0, 2, 1>(a, stream);
+#else
+    PF_REQUIRE(abl == 0, "gemm_f16x2 (four-wave shape): the ablation builds are in the measurement library (make measure)");
+#endif
     switch (mode) {
         case 0: return launch_w4<0, 0>(a, stream);
         case 1: return launch_w4<1, 0>(a, stream);
@@ -297,7 +309,8 @@ bool gemm_f16x2_w4_row_ok(const GemmRowArgs& a) {
     return a.N == 512 && a.K % 32 == 0 && a.K >= 64 && (size_t)a.M * (size_t)a.lda * 2 < (1ull << 32) && (size_t)a.ldw * 1024 < (1ull << 32);
 }
 
-// the four-wave full-row form; the caller (launch_gemm_f16x2_row) has checked the arguments
+// the four-wave full-row form (measurement library only); the caller (launch_gemm_f16x2_row) has checked the arguments
+#if defined(PF_MEASUREMENT_KERNELS)
 int launch_gemm_f16x2_w4_row(const GemmRowArgs& a, hipStream_t stream) {
     PF_REQUIRE(gemm_f16x2_w4_row_ok(a), "gemm_f16x2_row (four-wave shape): needs N == 512, K % 32 == 0, K >= 64 and operands below 4 GB");
     const bool ln = a.ln_g != nullptr;
@@ -314,5 +327,12 @@ int launch_gemm_f16x2_w4_row(const GemmRowArgs& a, hipStream_t stream) {
         default: return launch_w4_row_m<3, true>(a, stream);
     }
 }
+
+#else
+int launch_gemm_f16x2_w4_row(const GemmRowArgs&, hipStream_t) {
+    set_error("gemm_f16x2_row (four-wave shape): measured and off -- in the measurement library only (make measure)");
+    return -1;
+}
+#endif
 
 }  // namespace pf

@@ -481,6 +481,10 @@ int pf_set_skinny_max_m(int32_t m);
 int pf_k_gemm_f32(const float* A, int32_t lda, const float* W, int32_t ldw, const float* bias, const float* R1,
                   int32_t ldr1, const float* R2, int32_t ldr2, float* C, int32_t ldc, int32_t M, int32_t N,
                   int32_t K, int32_t relu, void* stream);
+/* 1 if the library holds the measured-and-off kernel shapes and ablation builds (libparaformer_hip_measure.so, `make -C funasr_amd/csrc
+ * measure`: what tools/bench_*.py and the records under profiles/ were made with); 0 for the product library, in which the option keys
+ * and tile ids of those shapes return an error. */
+int pf_measurement_build(void);
 /* Conv1d over time as one exact-fp32 GEMM whose im2col is gathered by the operand loads (the predictor's cif_conv1d,
  * funasr/models/paraformer/cif_predictor.py:275-278): hidden [B, T, D], W [N, taps * D] (column tap * D + c = weight[n, c, tap]),
  * C [B * T, N]; rows t + tap - left outside [0, T) read as zero; zero_dev: >= 128 B of zeros; D % 32 == 0. Bitwise pf_k_gemm_f32

@@ -22,6 +22,18 @@ from funasr_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+def _measure():
+    """the measured-and-off kernel shapes (tiles 5 / 6 / 8 / 9 / 12, row heights 129 / 130, attention variants 0 / 1, the one-launch
+    feed-forward, ...) exist in the measurement library only (make -C funasr_amd/csrc measure; PF_LIB_PATH=.../libparaformer_hip_measure.so):
+    with it loaded these tests also check that every such shape returns the product's bits"""
+    from funasr_amd import _lib
+    return bool(_lib.load().pf_measurement_build())
+
+
+need_measure = pytest.mark.skipif("not __import__('torch').cuda.is_available() or not __import__('funasr_amd._lib', fromlist=['x']).load().pf_measurement_build()",
+                                  reason="kernel shape of the measurement library (make measure) -- not in the product")
+
+
 def _planes_value(p2: torch.Tensor) -> torch.Tensor:
     """float64 value of a two-plane tensor [2, ...] (still times its power-of-two scale)"""
     return p2[0].double() + p2[1].double()
@@ -82,10 +94,11 @@ def test_gemm_f16x2_fp32_forms_vs_float64(cuda, M, N, K):
             assert torch.equal(wide, narrow), f"256x256 and 256x128 tiles differ {sorted(kw)}"
             auto = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=0, **kw)
             assert torch.equal(auto, narrow)
-            pair = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=5, **kw)
-            assert torch.equal(pair, narrow), f"128x256 two-workgroups-per-CU shape differs {sorted(kw)}"
-            ring = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=6, **kw)
-            assert torch.equal(ring, narrow), f"256x256 deep-ring shape differs {sorted(kw)}"
+            if _measure():
+                pair = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=5, **kw)
+                assert torch.equal(pair, narrow), f"128x256 two-workgroups-per-CU shape differs {sorted(kw)}"
+                ring = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=6, **kw)
+                assert torch.equal(ring, narrow), f"256x256 deep-ring shape differs {sorted(kw)}"
             if K >= 64:
                 four = ops.gemm_f16x2(a2, w2, bias, scale_exp=se, tile=7, **kw)
                 assert torch.equal(four, narrow), f"four-wave 256x256 shape (gemm_f16x2_w4.hip) differs {sorted(kw)}"
@@ -131,12 +144,14 @@ def test_gemm_f16x2_plane_output(cuda, M):
     eo = 9
     p_n = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=1)
     p_w = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=2)
-    p_p = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=5)
+    p_p = ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=5 if _measure() else 2)
     assert torch.equal(p_n, p_w) and torch.equal(p_p, p_w)
     # 128 x 128 four-wave shape (tile 0's pick where the 256-row shapes would leave most CUs idle, e.g. M = 70) and tile 0 itself
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=3), p_w)
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=0), p_w)
-    assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=6), p_w)
+    if _measure():
+        assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=6), p_w)
+        assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=12), p_w), "finisher form"
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=7), p_w), "four-wave shape"
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=True, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=10), p_w), "persistent shape"
     assert torch.equal(ops.gemm_f16x2(a2, w2, bias, relu=False, scale_exp=se, out_planes=True, out_scale_exp=eo, tile=10),
@@ -162,13 +177,13 @@ def test_gemm_f16x2_qkv_and_kv_forms(cuda, M, K, kv_form):
     bias = torch.randn(nseg * D, generator=g).to(cuda)
     q_mul, k_mul, v_mul = 128 ** -0.5 * 2.0 ** 7, 2.0 ** 6, 2.0 ** 5
     out = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form)
-    pair = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=5)
+    pair = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=5 if _measure() else 2)
     # tile 0 (above) picks by the row count: 128 x 128 blocks at M = 22 528, whole rounds of 256 x 256 blocks + a 128 x 128 tail at M = 33 536; 2: 256 x 256 only; 3: 128 x 128 only
     for tile in (2, 3):
         one = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=tile)
         for key in ("q2", "k2", "v", "vt"):
             assert (out[key] is None and one[key] is None) or torch.equal(out[key], one[key]), f"tile {tile}: {key} differs"
-    ring = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=6)
+    ring = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=6 if _measure() else 3)
     four = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=7)
     pers = ops.gemm_f16x2_qkv(a2, w2, bias, D, se, q_mul, k_mul, v_mul, kv_form=kv_form, tile=10)
     for key in ("q2", "k2", "v", "vt"):
@@ -256,12 +271,12 @@ def test_row_form_is_bitwise_gemm_then_layernorm(cuda, M, K, r1, r2):
     c_only, none = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se)
     assert none is None and torch.equal(c_only, c_ref)
     # every block height (0: chosen by the row count; 128: the 2 x 4-wave kernel; 96 / 129: the 1 x 8-wave kernel) gives the same bits
-    for br in (0, 128, 96, 129, 130):             # 130: the four-wave 1 x 4 grid (gemm_f16x2_w4.hip)
+    for br in ((0, 128, 96, 129, 130) if _measure() else (0, 128, 96)):             # 129 / 130 (measurement library): the 1 x 8 grid at 128 rows, the four-wave 1 x 4 grid
         c, y = ops.gemm_f16x2_row(a2, w2, bias, add1=add1, add2=add2, scale_exp=se, ln=(gamma, beta, eps), out_scale_exp=ey,
                                   block_rows=br, a_nt=(br == 96))
         assert torch.equal(c, c_ref) and torch.equal(y, y_ref), f"block_rows {br}"
     if r2 and not r1:
-        for br in (96, 129, 130):
+        for br in ((96, 129, 130) if _measure() else (96,)):
             c, none = ops.gemm_f16x2_row(a2, w2, bias, add2=add2, scale_exp=se, block_rows=br)
             assert none is None and torch.equal(c, c_ref), f"block_rows {br} without LayerNorm"
             nc, yf = ops.gemm_f16x2_row(a2, w2, bias, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False, want_c=False,
@@ -324,7 +339,7 @@ def test_row_form_with_fsmn_in_the_epilogue_is_bitwise_fsmn_then_row(cuda, slots
     nc, yf = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps), ln_planes=False,
                                      want_c=False)
     assert nc is None and torch.equal(yf, ops.layernorm(c_ref, gamma, beta, eps))
-    for br in (0, 128, 96, 129, 130):
+    for br in ((0, 128, 96, 129, 130) if _measure() else (0, 128, 96)):
         c, y = ops.gemm_f16x2_row_fsmn(a2, w2, bias, v, taps, lo, hi, add2=add2, scale_exp=se, ln=(gamma, beta, eps),
                                        out_scale_exp=ey, block_rows=br)
         assert torch.equal(c, c_ref) and torch.equal(y, y_ref), f"FSMN form, block_rows {br}"
@@ -348,16 +363,29 @@ def test_encoder_schedule_options_are_bitwise_equal(cuda, frames, packing):
     outs = {}
     # ffn_fused: 0 the w_1 -> w_2 pair, 2 the one-launch feed-forward (gemm_f16x2_ffn.hip) whatever the row count, 1 by the row count
     # (the test model's few rows always take w_2's full-row form: w2_row = 2 is the default choice by row count)
-    for fuse_row, fsmn_fused, row_bm, ffn_fused in ((0, 0, 0, 0), (1, 0, 128, 0), (1, 1, 128, 0), (1, 1, 96, 0), (1, 0, 96, 0), (1, 1, 129, 0),
-                                                    (1, 1, 0, 0), (1, 1, 0, 2), (1, 0, 128, 2), (1, 1, 0, 1), (1, 1, 130, 0), (1, 0, 130, 0)):
-        enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused).set_option("row_bm", row_bm).set_option("ffn_fused", ffn_fused)
+    measure = _measure()                  # row_bm / ffn_fused / w2_tile select shapes of the measurement library (make measure)
+    combos = ((0, 0, 0, 0), (1, 0, 128, 0), (1, 1, 128, 0), (1, 1, 96, 0), (1, 0, 96, 0), (1, 1, 129, 0), (1, 1, 0, 0), (1, 1, 0, 2), (1, 0, 128, 2),
+              (1, 1, 0, 1), (1, 1, 130, 0), (1, 0, 130, 0)) if measure else ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0), (0, 1, 0, 0))
+    for fuse_row, fsmn_fused, row_bm, ffn_fused in combos:
+        enc.set_option("fuse_row", fuse_row).set_option("fsmn_fused", fsmn_fused)
+        if measure:
+            enc.set_option("row_bm", row_bm).set_option("ffn_fused", ffn_fused)
         outs[(fuse_row, fsmn_fused, row_bm, ffn_fused)] = enc(feats, lens)[0].clone()
-    # w_2 as a tile GEMM + its own LayerNorm launch (w2_row 0) against the full-row form (1), and the four-wave GEMM shape (gemm_tile 7)
-    enc.set_option("fuse_row", 1).set_option("fsmn_fused", 1).set_option("row_bm", 0).set_option("ffn_fused", 0)
-    for w2_row, gemm_tile, w2_tile in ((0, 0, 0), (1, 0, 0), (0, 7, 7), (1, 7, 7), (2, 7, 0), (0, 0, 7), (0, 0, 2), (0, 10, 10), (2, 10, 7), (0, 0, 10)):
-        enc.set_option("w2_row", w2_row).set_option("gemm_tile", gemm_tile).set_option("w2_tile", w2_tile)
+    # w_2 as a tile GEMM + its own LayerNorm launch (w2_row 0) against the full-row form (1), the four-wave (gemm_tile 7) and the
+    # persistent (10) GEMM shapes
+    enc.set_option("fuse_row", 1).set_option("fsmn_fused", 1)
+    if measure:
+        enc.set_option("row_bm", 0).set_option("ffn_fused", 0)
+    for w2_row, gemm_tile, w2_tile in ((0, 0, 0), (1, 0, 0), (0, 7, 7), (1, 7, 7), (2, 7, 0), (0, 0, 7), (0, 0, 2), (0, 10, 10), (2, 10, 7), (0, 0, 10), (0, 2, 7), (2, 2, 7)):
+        if not measure and w2_tile != 7:
+            continue                               # (w2_tile: measurement library; the product runs w_2's tile form on the four-wave shape)
+        enc.set_option("w2_row", w2_row).set_option("gemm_tile", gemm_tile)
+        if measure:
+            enc.set_option("w2_tile", w2_tile)
         outs[("w2_row", w2_row, "gemm_tile", gemm_tile, "w2_tile", w2_tile)] = enc(feats, lens)[0].clone()
-    enc.set_option("w2_row", 2).set_option("gemm_tile", 0).set_option("w2_tile", 7)
+    enc.set_option("w2_row", 2).set_option("gemm_tile", 0)
+    if measure:
+        enc.set_option("w2_tile", 7)
     base = outs[(0, 0, 0, 0)]
     assert torch.isfinite(base).all() and base.abs().max().item() > 0.1
     for key, out in outs.items():
@@ -412,7 +440,7 @@ def test_attention_f16x2_variants_vs_float64(cuda, B, Tq, Tk, H):
     # operand ranges: |q scale| * 2^eq < 2^15 etc.
     eq, ek, ev = 9, 10, 11
     outs = {}
-    for variant in (0, 1, 3):
+    for variant in ((0, 1, 3) if _measure() else (3,)):      # 3 (lazy rescale) is the product's schedule; 0 / 1: measurement library
         for plain in (0, 16):
             o = ops.attention_f16x2(q, k, v, klens, H, scale, eq=eq, ek=ek, ev=ev, variant=variant + plain)
             assert torch.isfinite(o).all()
@@ -537,6 +565,7 @@ def _ffn_case(M, F, cuda, seed=0):
     return t
 
 
+@need_measure
 @pytest.mark.parametrize("M", [70, 128, 500, 4000, 32768])
 @pytest.mark.parametrize("F", [2048, 1024])
 def test_fused_ffn_vs_the_two_kernel_pair_and_float64(cuda, M, F):
@@ -587,6 +616,7 @@ def test_fused_ffn_vs_the_two_kernel_pair_and_float64(cuda, M, F):
     assert ((c5.double() + t["b2"].double() - ref).abs() <= tol + 1e-6).all()
 
 
+@need_measure
 def test_fused_ffn_rows_are_independent_and_deterministic(cuda):
     """a row's result does not depend on the batch around it (the utterance-DP premise) and repeats bit for bit"""
     from funasr_amd import ops
@@ -616,13 +646,20 @@ def test_optional_kernel_schedules_are_bitwise_inside_the_full_depth_encoder(cud
     g = torch.Generator().manual_seed(4)
     feats = (torch.randn(64, 500, 560, generator=g) * 0.8).to(cuda)
     lens = torch.full((64,), 500, dtype=torch.int32)
+    measure = _measure()
+    defaults = dict(ffn_fused=0, gemm_tile=0, w2_row=2, row_bm=0, w2_tile=7) if measure else dict(gemm_tile=0, w2_row=2)
     def run(**opts):
-        for k, v in {**dict(ffn_fused=0, gemm_tile=0, w2_row=2, row_bm=0, w2_tile=7), **opts}.items():
+        for k, v in {**defaults, **opts}.items():
             model.encoder.set_option(k, v)
         return model.encode(feats, lens, all_rows=True)[0].clone()
     base = run()
     assert torch.isfinite(base).all()
-    for opts in (dict(ffn_fused=2), dict(gemm_tile=6), dict(ffn_fused=2), dict(gemm_tile=6), dict(w2_row=1), dict(gemm_tile=7, row_bm=130),
-                 dict(gemm_tile=7, w2_row=1, row_bm=130), dict(w2_tile=0)):
+    # the product's alternatives: w_2's full-row form, the four-wave and the persistent GEMM shapes for every tile GEMM; with the
+    # measurement library also the one-launch feed-forward, the deep ring, the four-wave row form and the persistent shape's finisher form
+    cases = [dict(w2_row=1), dict(gemm_tile=7), dict(gemm_tile=10), dict(gemm_tile=10), dict(gemm_tile=2, w2_row=0)]
+    if measure:
+        cases += [dict(ffn_fused=2), dict(gemm_tile=6), dict(ffn_fused=2), dict(gemm_tile=6), dict(gemm_tile=7, row_bm=130),
+                  dict(gemm_tile=7, w2_row=1, row_bm=130), dict(w2_tile=0), dict(gemm_tile=12), dict(gemm_tile=12, w2_tile=10)]
+    for opts in cases:
         assert torch.equal(run(**opts), base), f"{opts} changes the encoder's bits at full depth"
     run()
