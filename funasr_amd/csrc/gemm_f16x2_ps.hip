@@ -384,10 +384,14 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_ps_kernel(Gemm2Args p) {
                 // row r + 1 and gets the even lane's (column c - 1): (hi, lo) words of two adjacent columns of ONE row per lane
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const float x0 = o[2 * k] * pscale, x1 = o[2 * k + 1] * pscale;
-                    const float got = __builtin_bit_cast(float, dpp_swap1(__builtin_bit_cast(unsigned, odd ? x0 : x1)));
+                    // (the UNSCALED values are exchanged and the plane multiplier is applied inside the split, the expression of
+                    // store_split2x4_pair: the compiler fuses `o * scale - hi` into one fma there, so with a multiplier that is not a
+                    // power of two -- q's d_k^-1/2 -- scaling before the exchange gives other low-plane bits than the other shapes)
+                    const float y0 = o[2 * k], y1 = o[2 * k + 1];
+                    const float got = __builtin_bit_cast(float, dpp_swap1(__builtin_bit_cast(unsigned, odd ? y0 : y1)));
+                    const float ca = odd ? got : y0, cb = odd ? y1 : got;
                     unsigned h, l;
-                    split2_pk(odd ? got : x0, odd ? x1 : got, h, l);
+                    split2_pk(ca * pscale, cb * pscale, h, l);
                     floatx16& D = k < 8 ? A : B;
                     D[2 * (k & 7)] = __builtin_bit_cast(float, h);
                     D[2 * (k & 7) + 1] = __builtin_bit_cast(float, l);
@@ -620,10 +624,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_psf_kernel(Gemm2Args p) {
                 if (mw + 32 * tm + 16 * (k >> 2) < M) {
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
-                        const float x0 = (half ? hi_[0] : lo_[0]) * pscale, x1 = (half ? hi_[1] : lo_[1]) * pscale;
-                        const float got = __builtin_bit_cast(float, dpp_swap1(__builtin_bit_cast(unsigned, odd ? x0 : x1)));
+                        const float y0 = half ? hi_[0] : lo_[0], y1 = half ? hi_[1] : lo_[1];
+                        const float got = __builtin_bit_cast(float, dpp_swap1(__builtin_bit_cast(unsigned, odd ? y0 : y1)));
+                        const float ca = odd ? got : y0, cb = odd ? y1 : got;
                         unsigned h, l;
-                        split2_pk(odd ? got : x0, odd ? x1 : got, h, l);
+                        split2_pk(ca * pscale, cb * pscale, h, l);                  // (multiplier inside the split: see the kernel above)
                         if (stores) {
                             const int rl2 = 4 * (k >> 1) + (k & 1);          // (rows 0, 2, 8, 10, 16, 18, 24, 26) / 2
                             unsigned short* const d = d0 + (size_t)(rl2 + 2 * half) * row2;
