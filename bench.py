@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--seconds", type=float, default=30.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decoder-stream", action="store_true", help="the two-phase loop with both phases on ONE stream (default: batch i's decoder on a "
+                    "second HIP stream, beside batch i+1's encoder; one model replica, one set of weights)")
     ap.add_argument("--no-interleave", action="store_true", help="round 5's loop: whole batches enqueued one after the other (the host's wait for "
                     "the CIF token count then sits between a batch's encoder and decoder); default: the two-phase loop (begin(i+1), finish(i), collect(i-1))")
     ap.add_argument("--no-bf16", action="store_true", help="skip the other arithmetic modes (fp32-MFMA, bf16x3, bf16 operands)")
@@ -381,6 +383,9 @@ def main():
     lens = [n_samples] * B
     N_PAD = 512
     interleave = not args.no_interleave
+    dec_stream = torch.cuda.Stream(device=device) if (interleave and not args.no_decoder_stream) else None
+    if dec_stream is not None:
+        lib.pf_set_concurrency_guard(1)        # kernels of two streams may share a CU: the frontend's cross-check on (0.4 % of a step)
     trace("workload resident in HBM")
 
     def enqueue(src=None):
@@ -389,6 +394,8 @@ def main():
 
     def collect(pending):
         if world > 1 and pending["ids"] is not None:
+            if pending.get("ready") is not None:
+                torch.cuda.current_stream().wait_event(pending["ready"])     # the ids were produced on the decoder stream
             # gather hypotheses on rank 0 (fixed-stride int32 ids + counts packed on the device), the path's only exchange
             dp.gather_packed(dp.pack_hypotheses_device(pending["ids"], pending["tok"], N_PAD), dst=0)
         return model.collect(pending)
@@ -410,22 +417,24 @@ def main():
             pending = nxt
         return collect(pending)
 
-    def run_steps(k):
+    def run_steps(k, stream="default"):
         """k batches, software-pipelined like a serving loop, in the two phases of the forward (Paraformer.begin_features /
         finish_features = pf_paraformer_begin / _finish): batch i+1's frontend + encoder + CIF scan are enqueued BEFORE the host waits
         for batch i's token counts and launches its decoder, and batch i-1's ids are collected after that -- the stream always holds
         a whole encoder while the host reads a count, so the GPU never waits for the host. Every batch is fully processed
-        and collected inside the call."""
+        and collected inside the call. With `dec_stream` the second phase runs on its own HIP stream: batch i's decoder (few rows per
+        kernel, launch- and latency-bound) beside batch i+1's encoder GEMMs -- ONE model replica, one set of weights."""
         if not interleave:
             return run_steps_sequential(k)
+        stream = dec_stream if stream == "default" else stream
         ticket, pending, out = begin(), None, None
         for _ in range(k - 1):
             nxt = begin()
-            fin = model.finish_features(ticket)
+            fin = model.finish_features(ticket, stream=stream)
             if pending is not None:
                 collect(pending)
             pending, ticket = fin, nxt
-        fin = model.finish_features(ticket)
+        fin = model.finish_features(ticket, stream=stream)
         if pending is not None:
             collect(pending)
         return collect(fin)
@@ -555,10 +564,18 @@ def main():
         run_steps_sequential(args.steps)
         torch.cuda.synchronize()
         seq_ms = (time.perf_counter() - t0s) / args.steps * 1e3
-        line["interleave"] = {"loop": "begin(i+1) -> finish(i) -> collect(i-1) (pf_paraformer_begin / _finish)",
+        line["interleave"] = {"loop": "begin(i+1) -> finish(i) -> collect(i-1) (pf_paraformer_begin / _finish)" +
+                                      ("; finish on a second HIP stream (the decoder beside the next encoder)" if dec_stream is not None else ""),
                               "sequential_ms_per_step": round(seq_ms, 2), "gain": round(seq_ms / (dt / args.steps * 1e3), 4)}
+        if dec_stream is not None:          # and the two-phase loop with both phases on one stream
+            run_steps(2, stream=None)
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            run_steps(args.steps, stream=None)
+            torch.cuda.synchronize()
+            line["interleave"]["one_stream_ms_per_step"] = round((time.perf_counter() - t0s) / args.steps * 1e3, 2)
     if not args.no_secondary:
-        line["pcie_inclusive"] = run_pcie_inclusive(frontend, model, wav_host, wav, lens, args, B)
+        line["pcie_inclusive"] = run_pcie_inclusive(frontend, model, wav_host, wav, lens, args, B, dec_stream)
         # SURVEY 8(d) counts the waveforms' H2D copy; this run's rules make `value` the HBM-resident rate -- both at the top level
         line["value_pcie_inclusive"] = line["pcie_inclusive"]["value"]
         trace(f"PCIe-inclusive: {line['pcie_inclusive']['value']} audio-s/s")
@@ -634,7 +651,7 @@ def main():
     print(json.dumps(line), flush=True)
 
 
-def run_pcie_inclusive(frontend, model, wav_host, wav_dev, lens, args, B):
+def run_pcie_inclusive(frontend, model, wav_host, wav_dev, lens, args, B, dec_stream=None):
     """The same steps with every batch's waveforms starting in PINNED HOST memory: H2D copies on a side stream into two
     device buffers, one batch ahead of the compute stream (an event each way). Never `value` -- reported beside it."""
     copy_stream = torch.cuda.Stream()
@@ -667,11 +684,11 @@ def run_pcie_inclusive(frontend, model, wav_host, wav_dev, lens, args, B):
         for i in range(1, k):
             ev, nxt_ev = nxt_ev, (h2d(i + 1) if i + 1 < k else None)
             nxt = begin(i, ev)
-            fin = model.finish_features(ticket)
+            fin = model.finish_features(ticket, stream=dec_stream)
             if pending is not None:
                 model.collect(pending)
             pending, ticket = fin, nxt
-        fin = model.finish_features(ticket)
+        fin = model.finish_features(ticket, stream=dec_stream)
         if pending is not None:
             model.collect(pending)
         return model.collect(fin)

@@ -18,7 +18,9 @@
 // The CIF token count still sizes the decoder exactly (the .item() of cif_predictor.py:311; no padded N_max, no speculative row
 // budget, no re-launch path), but the wait no longer drains the GPU: with `begin(i + 1)` issued before `finish(i)` the stream holds
 // batch i + 1's encoder while the host reads batch i's counts and launches its decoder behind it. Two slots (encoder output +
-// scan state) make that legal. pf_paraformer_forward = begin + finish back to back: bitwise the module chain, as before.
+// scan state) make that legal, and `finish` may be given another stream than `begin`: the decoder of batch i then runs BESIDE the
+// encoder of batch i + 1 (its few-row kernels fill what the big GEMMs leave idle; an event orders the slot's reuse).
+// pf_paraformer_forward = begin + finish back to back: bitwise the module chain, as before.
 namespace pf {
 namespace {
 struct Slot {
@@ -27,6 +29,8 @@ struct Slot {
     int32_t* counts_host = nullptr;      // pinned, [cap_B]
     int cap_B = 0;
     hipEvent_t ev = nullptr;
+    hipEvent_t done = nullptr;           // recorded behind the decoder of the batch that last used this slot
+    bool done_pending = false;
     int B = 0, T = 0;
     bool open = false;                   // begun, not finished
 };
@@ -43,6 +47,7 @@ struct Pipeline {
         for (Slot& s : slot) {
             if (s.counts_host) (void)hipHostFree(s.counts_host);
             if (s.ev) (void)hipEventDestroy(s.ev);
+            if (s.done) (void)hipEventDestroy(s.done);
         }
     }
 };
@@ -87,6 +92,10 @@ int pf_paraformer_begin(pf_paraformer* mh, const float* feats_dev, const int32_t
         S.cap_B = B;
     }
     if (!S.ev) PF_HIP_TRY(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+    if (!S.done) PF_HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+    // pf_paraformer_finish may run on ANOTHER stream (the decoder of batch i beside the encoder of batch i + 1): what this slot held
+    // -- encoder output and scan state of batch i - 1 -- must have been consumed before the encoder writes it again
+    if (S.done_pending) { PF_HIP_TRY(hipStreamWaitEvent(s, S.done, 0)); S.done_pending = false; }
     S.lens.assign(lens_host, lens_host + B);
     int rc;
     if ((rc = pf_encoder_forward(m->e, feats_dev, lens_host, B, T, pe_dev, S.enc.as<float>(), -1, stream))) return rc;
@@ -116,6 +125,10 @@ int pf_paraformer_finish(pf_paraformer* mh, int32_t ticket, int32_t* ids_dev, in
     if (alphas_dev) PF_HIP_TRY(hipMemcpyAsync(alphas_dev, predictor_alphas_dev(P, ticket), sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
     if (peaks_dev) PF_HIP_TRY(hipMemcpyAsync(peaks_dev, predictor_peaks_dev(P, ticket), sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
     m->last_slot = ticket; m->last_N = N;
+    struct DoneMark {                                        // whatever the exit, the slot's consumers end here on `s`
+        Slot& S; hipStream_t s;
+        ~DoneMark() { if (S.done && hipEventRecord(S.done, s) == hipSuccess) S.done_pending = true; }
+    } done_mark{S, s};
     if (N == 0) return 0;                                    // model.py:615-616: nothing fired anywhere in the batch
     PF_REQUIRE(!ids_dev || N <= ids_ld, "paraformer_finish: ids_ld is smaller than the batch's largest token count");
     if (m->embeds.ensure(sizeof(float) * (size_t)B * N * D)) return -2;

@@ -187,21 +187,26 @@ class Paraformer(nn.Module):
             _lib.check(t, "pf_paraformer_begin")
         return dict(ticket=t, B=B, T=T, dev=dev, keep=(xs, lens_c, pe))
 
-    def finish_features(self, ticket: dict):
+    def finish_features(self, ticket: dict, stream: "torch.cuda.Stream" = None):
         """Phase 2 (pf_paraformer_finish): waits for the ticket's token counts only, enqueues embeds + decoder + fused arg-max and
-        the ids' D2H copy; returns what `enqueue_features` returns (`collect()` brings the ids to the host)."""
+        the ids' D2H copy; returns what `enqueue_features` returns (`collect()` brings the ids to the host). `stream`: another HIP
+        stream for this phase -- batch i's decoder then runs BESIDE batch i + 1's encoder (the library orders the reuse of its
+        buffers with an event); `pending["ready"]` is the event behind the phase's last kernel."""
         lib, h = self._pipeline()
         B, T, dev = ticket["B"], ticket["T"], ticket["dev"]
         tok_c = (C.c_int32 * B)()
-        ids = torch.empty(B, T + 1, device=dev, dtype=torch.int32)          # a CIF fires at most once per frame (+ the tail)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(dev)):
+            ids = torch.empty(B, T + 1, device=dev, dtype=torch.int32)      # a CIF fires at most once per frame (+ the tail)
             n = lib.pf_paraformer_finish(h, ticket["ticket"], ids.data_ptr(), T + 1, tok_c, None, None, stream_ptr())
-        if n < 0:
-            _lib.check(n, "pf_paraformer_finish")
-        tok = [int(v) for v in tok_c]
-        pending = dict(tok=tok, ids=ids if n >= 1 else None, B=B, keep=ticket["keep"])
-        if n >= 1:
-            pending["ids_host"] = (ids, self.__dict__.setdefault("_host_ring", HostCopyRing()).start(ids))
+            if n < 0:
+                _lib.check(n, "pf_paraformer_finish")
+            tok = [int(v) for v in tok_c]
+            pending = dict(tok=tok, ids=ids if n >= 1 else None, B=B, keep=ticket["keep"])
+            if n >= 1:
+                pending["ids_host"] = (ids, self.__dict__.setdefault("_host_ring", HostCopyRing()).start(ids))
+            if stream is not None:
+                pending["ready"] = torch.cuda.Event()
+                pending["ready"].record(stream)
         return pending
 
     def enqueue_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):

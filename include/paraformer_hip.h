@@ -277,7 +277,10 @@ int pf_paraformer_forward(pf_paraformer* m, const float* feats_dev, const int32_
  * embeds + decoder + arg-max and returns N like pf_paraformer_forward. Two batches may be in flight: issue begin(i + 1) BEFORE
  * finish(i) and the stream holds batch i + 1's encoder while the host reads batch i's counts -- the decoder is still sized by the
  * exact CIF count (cif_predictor.py:311), but the GPU never waits for the host. Tickets are finished in the order they were begun;
- * lens_host is copied by begin. (A V3 predictor keeps one scan state: one batch in flight.) pf_paraformer_forward == begin + finish. */
+ * lens_host is copied by begin. (A V3 predictor keeps one scan state: one batch in flight.) pf_paraformer_forward == begin + finish.
+ * `finish` may be given another stream than `begin` (the host has already waited for the batch's scan; the library orders the reuse of
+ * the slot with an event): batch i's decoder then runs beside batch i + 1's encoder. ids_dev is valid once finish's stream has reached
+ * the end of the call's work. */
 int pf_paraformer_begin(pf_paraformer* m, const float* feats_dev, const int32_t* lens_host, int32_t B, int32_t T,
                         const float* pe_dev, void* stream);
 int pf_paraformer_finish(pf_paraformer* m, int32_t ticket, int32_t* ids_dev, int32_t ids_ld, int32_t* token_num_host,

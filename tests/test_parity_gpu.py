@@ -340,6 +340,21 @@ def test_two_phase_forward_interleaved_across_batches_is_bitwise_the_one_call_fo
     got.append(model.collect(fin))
     for w, r in zip(want, got):
         assert r["token_num"] == w["token_num"] and r["raw_ids"] == w["raw_ids"] and r["ids"] == w["ids"]
+    # the second phase on ANOTHER stream (the decoder of batch i beside the encoder of batch i + 1): same results
+    side = torch.cuda.Stream(device=cuda)
+    got, ticket, pending = [], model.begin_features(*batches[0]), None
+    for i in range(1, len(batches)):
+        nxt = model.begin_features(*batches[i])
+        fin = model.finish_features(ticket, stream=side)
+        if pending is not None:
+            got.append(model.collect(pending))
+        pending, ticket = fin, nxt
+    fin = model.finish_features(ticket, stream=side)
+    got.append(model.collect(pending))
+    got.append(model.collect(fin))
+    torch.cuda.synchronize()
+    for w, r in zip(want, got):
+        assert r["token_num"] == w["token_num"] and r["raw_ids"] == w["raw_ids"], "decoder on a second stream"
     # three batches in flight: refused; the two begun ones still finish correctly
     t0 = model.begin_features(*batches[0])
     t1 = model.begin_features(*batches[1])
