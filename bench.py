@@ -507,10 +507,13 @@ def main():
     # ---- per-kernel numbers: the same steps again with a hipEvent pair around every launch of the dominant kernels, on the
     #      launch stream (the events cost ~5 ms per step, which is why this pass is not the timed one). Every rank runs it
     #      (the steps contain the hypothesis gather); only rank 0's numbers are reported
+    #      ONE stream here even when the timed loop runs the decoder on a second stream: a kernel's duration beside another stream's
+    #      kernels is not the kernel's (w_1 reads 261 us instead of 211 with the decoder next to it) -- the roofline fraction is quoted
+    #      for the kernel running alone, as in every earlier round, and tools/profile.sh runs rocprofv3 on the same one-stream loop
     torch.cuda.synchronize()
     lib.pf_prof_reset()
     lib.pf_prof_enable(1)
-    run_steps(args.steps)
+    run_steps(args.steps, stream=None)
     sync()
     lib.pf_prof_enable(0)
     if rank != 0:
@@ -528,7 +531,9 @@ def main():
     else:
         gemm, kname = prof["gemm_f32_mfma"], "gemm_f32_mfma_kernel"
         peak = PEAK_16BIT_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-    roofline = assemble_roofline(gemm, kname, peak, dt / args.steps * 1e3, pmc_traffic(kname), PRODUCTS.get(args.precision))
+    roofline = assemble_roofline(gemm, kname, peak, sum(v["ms_per_step"] for v in prof.values()), pmc_traffic(kname), PRODUCTS.get(args.precision))
+    roofline["measured_in"] = ("instrumented pass on ONE stream (hipEvent pairs on the launch stream); share_of_step = this family's share of the "
+                               "instrumented kernel time of a step")
     kernels = {k: dict(ms_per_step=round(v["ms_per_step"], 3), launches=v["launches_per_step"]) for k, v in prof.items()}
     for nm in ("gemm_f32_mfma", "gemm_split", "attention"):
         if prof[nm]["ms_per_step"] > 0:
@@ -904,7 +909,7 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu, args, confident=None, gpu_ra
     full = clips[0].numel() / 16000.0
 
     # The reference's OWN nn.Modules where its checkout exists (the build container), the port elsewhere (the GPU box has no
-    # /root/reference): profiles/r04_cpu_port_vs_reference.json holds both timed on one host (tools/cpu_port_vs_reference.py)
+    # /root/reference): profiles/r06_cpu_port_vs_reference.json holds both timed on one host (tools/cpu_port_vs_reference.py)
     kind, ref_note = "port", None
     try:
         from oracle import ref_import
@@ -927,9 +932,9 @@ def run_cpu_baseline(cfg, clips, shift, scale, gpu, args, confident=None, gpu_ra
             feats, flens = O.wav_frontend([w], cmvn)
             return O.paraformer_greedy(feats, flens, sd, cfg)
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_cpu_port_vs_reference.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r06_cpu_port_vs_reference.json")) as f:
                 pr = json.load(f)
-            ref_note = {"source": "profiles/r04_cpu_port_vs_reference.json (same host, same clips, build container)",
+            ref_note = {"source": "profiles/r06_cpu_port_vs_reference.json (same host, same clips, build container)",
                         "port_over_reference_rate": [dict(threads=x["threads"], ratio=x["port_over_reference"]) for x in pr["settings"]],
                         "outputs_bit_equal": pr["outputs"]}
         except (OSError, KeyError, ValueError):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """CPU baseline: is the oracle ("port") as fast as the reference's own nn.Modules on the same host?  Build container only
-(needs /root/reference); writes profiles/r04_cpu_port_vs_reference.json.
+(needs /root/reference); writes profiles/r06_cpu_port_vs_reference.json.
 
 bench.py's `cpu_baseline` runs on the GPU box, where /root/reference does not exist, so it times the oracle
 (oracle/paraformer_oracle.py, `"kind": "port"`). This tool times, on ONE host and the SAME clips / thread counts,
@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--threads", default="4,8")
     ap.add_argument("--repeats", type=int, default=2)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_cpu_port_vs_reference.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_cpu_port_vs_reference.json"))
     args = ap.parse_args()
     from funasr_amd import synth
     from oracle import paraformer_oracle as O
