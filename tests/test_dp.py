@@ -154,3 +154,41 @@ def test_ensure_ranks_relaunches_a_bare_command_and_refuses_mismatches(tmp_path)
     r = subprocess.run([sys.executable, str(script), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_rank_thread_count_follows_the_cpu_quota(monkeypatch, tmp_path):
+    """dp.pin_rank_to_cores: a rank takes its slice of the usable cores, and never more threads than its share of the container's CPU
+    quota (a 2-rank dry run with 128 threads per rank on a 16-CPU quota took 7 minutes for 12 s of work)"""
+    import builtins
+    import os
+    import torch
+    from funasr_amd import dp
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity on this platform")
+    before_aff, before_thr, before_env = os.sched_getaffinity(0), torch.get_num_threads(), os.environ.get("OMP_NUM_THREADS")
+    pinned = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: pinned.update(cores=list(cores)))
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            f = tmp_path / "cpu.max"
+            f.write_text("1600000 100000\n")
+            return real_open(f, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    try:
+        out2 = dp.pin_rank_to_cores(1, 2)
+        assert pinned["cores"] == list(range(128, 256)) and out2 == {"cores": [128, 255], "threads": 8}
+        out8 = dp.pin_rank_to_cores(3, 8)
+        assert pinned["cores"] == list(range(96, 128)) and out8["threads"] == 2
+        assert dp.pin_rank_to_cores(0, 64)["threads"] == 1
+    finally:
+        monkeypatch.undo()
+        os.sched_setaffinity(0, before_aff)
+        torch.set_num_threads(before_thr)
+        if before_env is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = before_env
