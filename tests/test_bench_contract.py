@@ -1,6 +1,6 @@
 """The bench line's contract: (i) the functions bench.py assembles the line with, on synthetic measurements (schema, value and roofline
 arithmetic, the flagged fallback of the power-limited peak); (ii) as a separate sanity check, a committed line of an earlier round
-(profiles/r05_final_bench.json): every key the driver reads, the roofline and cpu_baseline objects, `value` as the HBM-resident one-stream
+(profiles/r06_final_bench.json): every key the driver reads, the roofline and cpu_baseline objects, `value` as the HBM-resident one-stream
 rate with the PCIe-inclusive and two-replica figures beside it. Also: the profile / trace condensers run on synthetic rocprofv3 CSVs."""
 import csv
 import json
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r05_final_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r06_final_bench.json")) as f:
         rows = [ln for ln in f if ln.startswith("{")]
     assert len(rows) == 1, "bench.py prints ONE JSON line"
     return json.loads(rows[0])
@@ -98,6 +98,12 @@ def test_value_is_the_resident_one_stream_rate_and_the_variants_sit_beside_it():
     assert p["GBps_read_plus_write"] > 1000 and p["own_read_GBps"] > 1000 and p["own_L2_reread_GBps"] > p["own_read_GBps"]
     st = d["cpu_baseline"]["full_config_parity"]["cif_margin_statistic"]
     assert st["clips"] >= 512 and st["clips_with_different_token_count"] == 0
+    # round 6: the statistic goes down to token ids, and the line says how its loop ran
+    ids = st["token_ids"]
+    assert ids["confident_output_layer"]["clips_with_different_ids"] == 0 and ids["random_output_layer"]["different_ids_among_fire_mismatch_clips"] == 0
+    il = d["interleave"]
+    assert "second HIP stream" in il["loop"] and il["sequential_ms_per_step"] > d["ms_per_step"] and il["one_stream_ms_per_step"] > d["ms_per_step"]
+    assert "ONE stream" in d["roofline"]["measured_in"]
 
 
 def _trace_csv(path, rows):
