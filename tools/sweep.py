@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--dump", default=None, help="rank 0 writes the hypotheses in CORPUS order to this JSON file")
     ap.add_argument("--no-pack", action="store_true", help="A/B: plan batches for the padded layout (no encoder row packing)")
     ap.add_argument("--no-overlap", action="store_true", help="assemble, decode and collect one batch at a time")
+    ap.add_argument("--no-decoder-stream", action="store_true", help="Paraformer: whole batches enqueued one after the other on one stream (round 5's loop) "
+                    "instead of the two-phase loop with batch i's decoder on a second stream beside batch i+1's encoder")
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--serialize-gpu", action="store_true", help="single-GPU dry run of the N > 1 path (every rank on cuda:0): the "
@@ -130,6 +132,13 @@ def main():
     trace_rows = []
     gpu_events = []
     paraformer = hasattr(model, "enqueue_features")
+    # the bench's loop: begin(i+1) -> finish(i) on a second stream -> collect(i-1); ids are those of enqueue_features
+    two_phase = (paraformer and hasattr(model, "begin_features") and model._one_call_ok() and not args.no_overlap and not args.no_decoder_stream
+                 and args.trace_hash is None)
+    dec_stream = torch.cuda.Stream(device=dev) if two_phase else None
+    if two_phase:
+        from funasr_amd import _lib
+        _lib.load().pf_set_concurrency_guard(1)
 
     def launch(batch):
         t = time.perf_counter()
@@ -147,7 +156,9 @@ def main():
             r = model.recognize_features(feats, flens, return_intermediate=True)
             trace_rows.append({"clips": list(batch), "wav": hb(wav), "feats": hb(feats), "enc": hb(r["enc"]), "alphas": hb(r["alphas"]),
                                "embeds": hb(r["embeds"]), "tok": r["token_num"], "ids": r["raw_ids"]})
-        if paraformer:
+        if two_phase:
+            pending = model.begin_features(feats, flens)
+        elif paraformer:
             pending = model.enqueue_features(feats, flens)
         elif args.model == "sensevoice":
             pending = model.recognize_features(feats, flens, "auto", "woitn")
@@ -160,6 +171,8 @@ def main():
 
     def finish(pending):
         t = time.perf_counter()
+        if two_phase and "ticket" in pending:
+            pending = model.finish_features(pending, stream=dec_stream)
         ids = model.collect(pending)["ids"] if paraformer else pending["ids"]
         timing["collect"] += time.perf_counter() - t
         return ids
@@ -177,7 +190,31 @@ def main():
     t0 = time.perf_counter()
     hyps = {}
 
+    def decode_all_two_phase():
+        ticket = pend = None                      # (batch, ticket of begin) / (batch, pending of finish)
+        for b in batches:
+            nxt = launch(b)
+            if ticket is not None:
+                t = time.perf_counter()
+                fin = model.finish_features(ticket[1], stream=dec_stream)
+                timing["enqueue"] += time.perf_counter() - t
+                if pend is not None:
+                    for i, ids in zip(pend[0], finish(pend[1])):
+                        hyps[i] = ids
+                pend = (ticket[0], fin)
+            ticket = (b, nxt)
+        if ticket is not None:
+            fin = model.finish_features(ticket[1], stream=dec_stream)
+            if pend is not None:
+                for i, ids in zip(pend[0], finish(pend[1])):
+                    hyps[i] = ids
+            for i, ids in zip(ticket[0], finish(fin)):
+                hyps[i] = ids
+        torch.cuda.synchronize()
+
     def decode_all():
+        if two_phase:
+            return decode_all_two_phase()
         inflight = None
         for b in batches:
             pending = launch(b)
@@ -227,6 +264,7 @@ def main():
         padded = sum(len(b) * max(lens[i] for i in b) for b in batches) / 16000.0
         mine_s = sum(lens[i] for i in mine) / 16000.0
         print(json.dumps({"metric": f"corpus sweep audio-seconds/s ({args.model}, {args.precision})", "value": round(total_s / dt, 1),
+                          "loop": ("two-phase, decoder on a second stream" if two_phase else "one batch at a time" if args.no_overlap else "whole batches, one stream"),
                           "n_gpus": world, "clips": args.clips, "audio_hours": round(total_s / 3600, 2), "wall_s": round(dt, 3),
                           "batches_rank0": len(batches), "batch_budget": (f"{args.batch_seconds} s" if args.batch_seconds > 0 else f"{args.batch_rows} rows"),
                           "padding_efficiency_rank0": round(mine_s / padded, 3),
