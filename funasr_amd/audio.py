@@ -202,3 +202,36 @@ def load_audio_list(data_in, fs: int = 16000, audio_fs: int = 16000) -> List[tor
     if isinstance(data_in, torch.Tensor) and data_in.dim() == 2:
         return [row for row in data_in]
     return [load_audio(data_in, fs, audio_fs)]
+
+
+def batch_to_features(data_in, data_lengths, frontend, kwargs, uploader=None):
+    """The head of every model's `inference` (funasr/models/paraformer/model.py:576-595, sense_voice/model.py:948-975): waveforms
+    (paths / arrays / tensors / bytes) or ready features -> (speech, speech_lengths, meta_data). `uploader`
+    (hip_module.StagedUpload): the padded batch goes to the device through pinned memory on an upload stream -- the form of
+    `.to(device)` for loops that overlap batches."""
+    import time
+    meta_data = {}
+    device = kwargs.get("device", None)
+    if isinstance(data_in, torch.Tensor) and kwargs.get("data_type", "sound") == "fbank":
+        speech, speech_lengths = data_in, data_lengths
+        if speech.dim() < 3:
+            speech = speech[None]
+        if speech_lengths is None:
+            speech_lengths = [speech.shape[1]] * speech.shape[0]
+        return speech, speech_lengths, meta_data
+    t1 = time.perf_counter()
+    audio = load_audio_list(data_in, fs=frontend.fs, audio_fs=kwargs.get("fs", 16000))
+    t2 = time.perf_counter()
+    meta_data["load_data"] = f"{t2 - t1:0.3f}"
+    if uploader is not None and device is not None and str(device).startswith("cuda") and all(a.device.type == "cpu" for a in audio):
+        wav, lens = uploader(audio, device)
+    else:
+        lens = [int(a.shape[0]) for a in audio]
+        wav = torch.nn.utils.rnn.pad_sequence(audio, batch_first=True)      # load_utils.py:413
+        if device is not None:
+            wav = wav.to(device)
+    speech, speech_lengths = frontend(wav, lens)
+    t3 = time.perf_counter()
+    meta_data["extract_feat"] = f"{t3 - t2:0.3f}"
+    meta_data["batch_data_time"] = (int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000)
+    return speech, speech_lengths, meta_data

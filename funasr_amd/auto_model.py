@@ -26,6 +26,7 @@ When the real package is importable, use `funasr.AutoModel` itself after `funasr
 """
 from __future__ import annotations
 
+import collections
 import copy
 import json
 import logging
@@ -362,17 +363,10 @@ class AutoModel:
         time_speech_total, time_escape_total = 0.0, 0.0
         call_kwargs = {k: v for k, v in kwargs.items() if k not in ("model", "key", "data_in")}
         n = len(data_list)
-        for beg in range(0, n, batch_size):
-            end = min(n, beg + batch_size)
-            batch = {"data_in": data_list[beg:end], "key": key_list[beg:end]}
-            if end - beg == 1 and kwargs.get("data_type") == "fbank":
-                batch["data_in"] = data_list[beg]
-                batch["data_lengths"] = input_len
-            t1 = time.perf_counter()
-            with torch.no_grad():
-                res = model.inference(**batch, **call_kwargs)
+
+        def account(res, dt, end):
+            nonlocal time_speech_total, time_escape_total
             results, meta = (res[0] if len(res) > 0 else [{"text": ""}]), (res[1] if len(res) > 1 else {})
-            dt = time.perf_counter() - t1
             results_all.extend(results)
             batch_data_time = meta.get("batch_data_time", -1)
             speed_stats.update(load_data=meta.get("load_data", 0.0), extract_feat=meta.get("extract_feat", 0.0),
@@ -385,6 +379,67 @@ class AutoModel:
                     logging.error("progress_callback error: %s", e)
             time_speech_total += batch_data_time
             time_escape_total += dt
+
+        def make_batch(beg, end):
+            batch = {"data_in": data_list[beg:end], "key": key_list[beg:end]}
+            if end - beg == 1 and kwargs.get("data_type") == "fbank":
+                batch["data_in"] = data_list[beg]
+                batch["data_lengths"] = input_len
+            return batch
+
+        # More than one batch and a model that offers its `inference` in three parts (paraformer.py inference_begin / _launch /
+        # _end): the loop of auto_model.py:790-840 with the batches overlapped -- host work of batch i + 1 and of batch i - 1
+        # beside the GPU work of batch i. Same records in the same order; `pipeline=False` keeps the plain loop.
+        bounds = [(beg, min(n, beg + batch_size)) for beg in range(0, n, batch_size)]
+        done = 0
+        if len(bounds) > 1 and kwargs.get("pipeline", True) and hasattr(model, "inference_begin"):
+            inflight = collections.deque()                                    # [pending, end, host seconds so far, launched]
+
+            def launch(e):
+                t1 = time.perf_counter()
+                with torch.no_grad():
+                    model.inference_launch(e[0])
+                e[2] += time.perf_counter() - t1
+                e[3] = True
+
+            def finish(e):
+                nonlocal done
+                if not e[3]:
+                    launch(e)
+                t1 = time.perf_counter()
+                with torch.no_grad():
+                    res = model.inference_end(e[0])
+                account(res, e[2] + time.perf_counter() - t1, e[1])
+                done += 1
+
+            try:
+                for beg, end in bounds:
+                    t1 = time.perf_counter()
+                    with torch.no_grad():
+                        pending = model.inference_begin(**make_batch(beg, end), **call_kwargs)
+                    if pending is None:                                       # this configuration has no split form
+                        break
+                    if inflight and not inflight[-1][3]:
+                        launch(inflight[-1])                                  # batch i's decoder, behind ITS encoder, beside batch i + 1's
+                    inflight.append([pending, end, time.perf_counter() - t1, False])
+                    while len(inflight) > 2:
+                        finish(inflight.popleft())
+                if inflight and not inflight[-1][3]:
+                    launch(inflight[-1])                                      # the last batch's decoder under the text of the one before
+                while inflight:
+                    finish(inflight.popleft())
+            except BaseException:
+                for e in inflight:                                            # no ticket stays open in the library
+                    try:
+                        model.inference_end(e[0])
+                    except Exception:  # noqa: BLE001
+                        pass
+                raise
+        for beg, end in bounds[done:]:
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                res = model.inference(**make_batch(beg, end), **call_kwargs)
+            account(res, time.perf_counter() - t1, end)
         self.speed_stats = dict(speed_stats, rtf_avg=(time_escape_total / time_speech_total) if time_speech_total else None)
         try:
             device = next(model.parameters()).device

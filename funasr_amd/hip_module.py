@@ -206,3 +206,31 @@ class HostCopyRing:
         ev.synchronize()
         slot.outstanding = False
         return slot.buf
+
+
+class StagedUpload:
+    """Host -> device copies of padded waveform batches for PIPELINED callers (AutoModel.inference's loop over batches): the batch is
+    padded straight into pinned memory and copied on an UPLOAD stream, and the caller's stream waits for that copy only. A plain
+    `wav.to(device)` from pageable memory is ordered behind everything already enqueued on the caller's stream -- the previous
+    batch's encoder -- and blocks the host until then, which is exactly the wait a pipelined loop exists to remove. The pinned
+    buffers come from torch's caching host allocator (it keeps a block busy until the copy's event has passed)."""
+
+    def __init__(self):
+        self._streams = {}
+
+    def __call__(self, audio, device) -> "tuple[torch.Tensor, list]":
+        dev = torch.device(device)
+        lens = [int(a.shape[0]) for a in audio]
+        host = torch.empty(len(audio), max(lens), dtype=torch.float32, pin_memory=True)
+        for j, a in enumerate(audio):                               # pad_sequence(batch_first=True) of load_utils.py:413
+            host[j, : lens[j]].copy_(a)
+            host[j, lens[j]:].zero_()
+        up = self._streams.get(dev)
+        if up is None:
+            up = self._streams[dev] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(up):
+            wav = host.to(dev, non_blocking=True)
+        main.wait_stream(up)
+        wav.record_stream(main)
+        return wav, lens

@@ -17,11 +17,11 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from .audio import load_audio_list
+from .audio import batch_to_features, load_audio_list
 import ctypes as C
 
 from . import _lib
-from .hip_module import HostCopyRing, host_i32, stream_ptr
+from .hip_module import HostCopyRing, StagedUpload, host_i32, stream_ptr
 from .register import tables
 from .timestamps import cif_token_spans
 from .tokenizer import sentence_postprocess
@@ -157,7 +157,7 @@ class Paraformer(nn.Module):
     # the pipeline handle is a raw pointer into this process's library: never copied or pickled with the module
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ("_pipe", "_host_ring"):
+        for k in ("_pipe", "_host_ring", "_upload", "_dec_stream"):
             st.pop(k, None)
         return st
 
@@ -284,37 +284,59 @@ class Paraformer(nn.Module):
         return out
 
     # ---------------------------------------------------------------------------------------------- AutoModel API
-    def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
+    def _wants_beam(self, kwargs) -> None:
         is_use_ctc = kwargs.get("decoding_ctc_weight", 0.0) > 0.00001 and self.ctc is not None        # model.py:554-562
         is_use_lm = kwargs.get("lm_weight", 0.0) > 0.00001 and kwargs.get("lm_file", None) is not None
         if self.beam_search is None and (is_use_lm or is_use_ctc):
             self.init_beam_search(**kwargs)
             self.nbest = kwargs.get("nbest", 1)
-        meta_data = {}
-        device = kwargs.get("device", None)
-        if isinstance(data_in, torch.Tensor) and kwargs.get("data_type", "sound") == "fbank":
-            speech, speech_lengths = data_in, data_lengths
-            if speech.dim() < 3:
-                speech = speech[None]
-            if speech_lengths is None:
-                speech_lengths = [speech.shape[1]] * speech.shape[0]
-        else:
-            t1 = time.perf_counter()
-            audio = load_audio_list(data_in, fs=frontend.fs, audio_fs=kwargs.get("fs", 16000))
-            t2 = time.perf_counter()
-            meta_data["load_data"] = f"{t2 - t1:0.3f}"
-            lens = [int(a.shape[0]) for a in audio]
-            wav = torch.nn.utils.rnn.pad_sequence(audio, batch_first=True)      # load_utils.py:413
-            if device is not None:
-                wav = wav.to(device)
-            speech, speech_lengths = frontend(wav, lens)
-            t3 = time.perf_counter()
-            meta_data["extract_feat"] = f"{t3 - t2:0.3f}"
-            meta_data["batch_data_time"] = (int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000)
+
+    def _prepare(self, data_in, data_lengths, frontend, kwargs, staged: bool = False):
+        """model.py:576-595: waveforms / features -> (speech, speech_lengths, meta_data); `staged`: pinned upload on its own stream"""
+        return batch_to_features(data_in, data_lengths, frontend, kwargs,
+                                 uploader=self.__dict__.setdefault("_upload", StagedUpload()) if staged else None)
+
+    def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
+        self._wants_beam(kwargs)
+        speech, speech_lengths, meta_data = self._prepare(data_in, data_lengths, frontend, kwargs)
         want_stamps = self._always_timestamps or kwargs.get("pred_timestamp", False)
         if self.beam_search is not None and not self._always_timestamps:
             return self._inference_beam(speech, speech_lengths, key, tokenizer, want_stamps, meta_data, **kwargs)
         res = self.recognize_features(speech, speech_lengths, return_intermediate=want_stamps)
+        return self._assemble(res, key, tokenizer, want_stamps, meta_data, kwargs)
+
+    # ---- the same call in three parts, for AutoModel.inference's loop over batches (auto_model.py:790-840 runs them one after the
+    #      other: load, features, forward, text -- the GPU idles through every host part). begin(i + 1) | launch(i) | end(i - 1):
+    #      the host loads and uploads batch i + 1 and enqueues its encoder while batch i's decoder runs on a second stream and batch
+    #      i - 1's ids become text. Records, their order and the ids are those of `inference` (tests/test_parity_gpu.py).
+    def inference_begin(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
+        """-> a pending object for `inference_launch` / `inference_end`, or None when this call has to take `inference` itself
+        (beam search, timestamps, feature input, a model that is not the plain offline one)."""
+        self._wants_beam(kwargs)
+        want_stamps = self._always_timestamps or kwargs.get("pred_timestamp", False)
+        if (self.beam_search is not None or want_stamps or not self._one_call_ok() or kwargs.get("data_type", "sound") == "fbank"
+                or not str(kwargs.get("device", "")).startswith("cuda")):
+            return None
+        speech, speech_lengths, meta_data = self._prepare(data_in, data_lengths, frontend, kwargs, staged=True)
+        ticket = self.begin_features(speech, speech_lengths)
+        return dict(ticket=ticket, key=key, tokenizer=tokenizer, meta_data=meta_data, kwargs=kwargs)
+
+    def inference_launch(self, pending: dict) -> None:
+        dev = pending["ticket"]["dev"]
+        side = self.__dict__.get("_dec_stream")
+        if side is None or side.device != dev:
+            side = self.__dict__["_dec_stream"] = torch.cuda.Stream(device=dev)
+            _lib.load().pf_set_concurrency_guard(1)
+        pending["fin"] = self.finish_features(pending.pop("ticket"), stream=side)
+
+    def inference_end(self, pending: dict):
+        if "fin" not in pending:
+            self.inference_launch(pending)
+        res = self.collect(pending.pop("fin"))
+        return self._assemble(res, pending["key"], pending["tokenizer"], False, pending["meta_data"], pending["kwargs"])
+
+    def _assemble(self, res, key, tokenizer, want_stamps, meta_data, kwargs):
+        """model.py:639-697: ids -> records"""
         B = len(res["ids"])
         if key is None:
             key = [f"utt_{i}" for i in range(B)]

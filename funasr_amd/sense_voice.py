@@ -16,9 +16,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .audio import load_audio_list
+from .audio import batch_to_features
 from .ctc import CTC
-from .hip_module import HostCopyRing
+from .hip_module import HostCopyRing, StagedUpload
 from .register import tables
 from . import sanm_encoder as _sanm_encoder  # noqa: F401
 from . import wav_frontend as _wav_frontend  # noqa: F401
@@ -203,35 +203,35 @@ class SenseVoiceSmall(nn.Module):
 
     def inference(self, data_in, data_lengths=None, key: list = ["wav_file_tmp_name"], tokenizer=None, frontend=None,
                   **kwargs):
+        pending = self._inference_enqueue(data_in, data_lengths, key, tokenizer, frontend, kwargs, staged=False)
+        return self.inference_end(pending)
+
+    # ---- the same call in parts for AutoModel.inference's loop over batches (see paraformer.py inference_begin): the encoder +
+    #      CTC arg-max of batch i + 1 are enqueued before batch i's frame ids are read and turned into text
+    def inference_begin(self, data_in, data_lengths=None, key: list = ["wav_file_tmp_name"], tokenizer=None, frontend=None, **kwargs):
+        if (kwargs.get("output_timestamp", False) or kwargs.get("data_type", "sound") == "fbank"
+                or not str(kwargs.get("device", "")).startswith("cuda")):
+            return None
+        return self._inference_enqueue(data_in, data_lengths, key, tokenizer, frontend, kwargs, staged=True)
+
+    def inference_launch(self, pending: dict) -> None:
+        return None                                              # nothing waits for the host between the encoder and the ids
+
+    def _inference_enqueue(self, data_in, data_lengths, key, tokenizer, frontend, kwargs, staged):
         output_timestamp = kwargs.get("output_timestamp", False)
         if output_timestamp and tokenizer is None:
             raise ValueError("output_timestamp needs the tokenizer (text2tokens / tokens2ids)")
-        meta_data = {}
-        device = kwargs.get("device", None)
-        if isinstance(data_in, torch.Tensor) and kwargs.get("data_type", "sound") == "fbank":
-            speech, speech_lengths = data_in, data_lengths
-            if speech.dim() < 3:
-                speech = speech[None]
-            if speech_lengths is None:
-                speech_lengths = [speech.shape[1]] * speech.shape[0]
-        else:
-            t1 = time.perf_counter()
-            audio = load_audio_list(data_in, fs=frontend.fs, audio_fs=kwargs.get("fs", 16000))
-            t2 = time.perf_counter()
-            meta_data["load_data"] = f"{t2 - t1:0.3f}"
-            lens = [int(a.shape[0]) for a in audio]
-            wav = torch.nn.utils.rnn.pad_sequence(audio, batch_first=True)
-            if device is not None:
-                wav = wav.to(device)
-            speech, speech_lengths = frontend(wav, lens)
-            t3 = time.perf_counter()
-            meta_data["extract_feat"] = f"{t3 - t2:0.3f}"
-            meta_data["batch_data_time"] = int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000
+        speech, speech_lengths, meta_data = batch_to_features(
+            data_in, data_lengths, frontend, kwargs, uploader=self.__dict__.setdefault("_upload", StagedUpload()) if staged else None)
         use_itn = kwargs.get("use_itn", False)
         textnorm = kwargs.get("text_norm", None) or ("withitn" if use_itn else "woitn")
         ban = [self.emo_dict["unk"]] if kwargs.get("ban_emo_unk", False) else None          # model.py:1004-1005
-        res = self.recognize_features(speech, speech_lengths, kwargs.get("language", "auto"), textnorm, ban_ids=ban,
-                                      return_intermediate=output_timestamp)
+        enq = self.enqueue_features(speech, speech_lengths, kwargs.get("language", "auto"), textnorm, output_timestamp, ban)
+        return dict(enq=enq, key=key, tokenizer=tokenizer, meta_data=meta_data, output_timestamp=output_timestamp)
+
+    def inference_end(self, pending: dict):
+        res = self.collect(pending.pop("enq"))
+        key, tokenizer, meta_data, output_timestamp = pending["key"], pending["tokenizer"], pending["meta_data"], pending["output_timestamp"]
         B = len(res["ids"])
         logp = None
         if output_timestamp:                                     # one D2H copy of the batch's log-probabilities (:1045)

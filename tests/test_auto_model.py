@@ -121,6 +121,53 @@ def test_generate_matches_oracle_text(model_dir, cuda):
 
 
 @pytest.mark.gpu
+def test_generate_over_many_batches_overlapped_equals_the_plain_loop(model_dir, cuda, tmp_path):
+    """`generate` over a list longer than the batch: the loop of auto_model.py:790-840 with the batches overlapped (pinned upload on
+    its own stream, the decoder of batch i on a second stream beside the encoder of batch i + 1, text of batch i - 1 on the host
+    meanwhile) returns the plain loop's records, in order, for ragged batches, a 50-ms clip and a last short batch."""
+    am = AutoModel(model=model_dir["dir"], device="cuda:0", batch_size=3)
+    paths = []
+    for i, n in enumerate((40000, 9000, 56000, 31000, 16000, 47000, 52000, 23000, 800, 38000, 61000)):
+        p = str(tmp_path / f"clip{i}.wav")
+        write_wav(p, synth.speech_like(n, seed=70 + i))
+        paths.append(p)
+    plain = am.generate(input=paths, pipeline=False)
+    over = am.generate(input=paths)
+    assert over == plain and len(over) == len(paths)
+    assert am.speed_stats["rtf_avg"] is not None
+    assert am.model.__dict__.get("_dec_stream") is not None, "the overlapped loop did not run"
+    # keys, another batch size, again (the pinned buffers and both library slots are reused)
+    keys = [f"k{i}" for i in range(len(paths))]
+    assert am.generate(input=paths, key=keys, batch_size=4) == am.generate(input=paths, key=keys, batch_size=4, pipeline=False)
+    # a file that cannot be read in the middle: the error surfaces, and the next call works (no ticket left open in the library)
+    bad = paths[:5] + [str(tmp_path / "missing.wav")] + paths[5:]
+    with pytest.raises(Exception):
+        am.generate(input=bad)
+    assert am.generate(input=paths) == plain
+
+
+@pytest.mark.gpu
+def test_sensevoice_batches_overlapped_equal_the_plain_loop(cuda):
+    from funasr_amd.sense_voice import SenseVoiceSmall
+    from funasr_amd.wav_frontend import WavFrontend
+    cfg = synth.tiny(synth.SENSEVOICE_SMALL, enc_blocks=2, tp_blocks=1, vocab=997)
+    model = SenseVoiceSmall.from_config(cfg)
+    model.load_state_dict(synth.sensevoice_state_dict(cfg, seed=3), strict=False)
+    model = model.to("cuda:0").eval()
+    sh, sc = synth.synthetic_cmvn(560)
+    fe = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0, device="cuda:0")
+    am = _bare_auto_model(model, batch_size=3, device="cuda:0", frontend=fe, tokenizer=None)
+    am._base_kwargs = {k: v for k, v in am.kwargs.items() if k not in ("frontend", "tokenizer")}
+    clips = [synth.speech_like(n, seed=90 + i) for i, n in enumerate((30000, 12000, 44000, 21000, 16000, 52000, 9000, 38000))]
+    plain = AutoModel.inference(am, clips, pipeline=False)
+    over = AutoModel.inference(am, clips)
+    ids = lambda res: [r["token_int"] for r in res]              # (keys are random per call for tensor inputs, like the reference's)
+    assert ids(over) == ids(plain) and len(over) == len(clips)
+    assert len({tuple(t) for t in ids(over)}) > 1
+    assert model.__dict__.get("_upload") is not None, "the overlapped loop did not run"
+
+
+@pytest.mark.gpu
 def test_generate_with_vad_segments_on_the_hip_path(model_dir, cuda):
     """inference_with_vad (auto_model.py:852-1254) with a stand-in VAD model: a long recording is cut at the VAD's
     segments, decoded in length-sorted batches by the HIP path and merged; every segment's text and (shifted)
@@ -287,3 +334,74 @@ def test_progress_callback_called_like_the_reference_spec():
     res = AutoModel.inference(am, ["a", "b", "c"], progress_callback=lambda idx, total: progress.append((idx, total)))
     assert progress == [(2, 3), (3, 3)]
     assert [r["text"] for r in res] == ["a", "b", "c"]
+
+
+class _SplitDummy:
+    """a model that offers `inference` in three parts (funasr_amd/paraformer.py inference_begin / _launch / _end) and logs the calls"""
+
+    def __init__(self, split=True, fail_at=None):
+        self.param = torch.nn.Parameter(torch.zeros(1))
+        self.log, self.split, self.fail_at, self.open = [], split, fail_at, set()
+
+    def parameters(self):
+        return iter([self.param])
+
+    def eval(self):
+        pass
+
+    def inference(self, data_in=None, **kwargs):
+        self.log.append(("whole", tuple(data_in)))
+        return [{"text": str(d)} for d in data_in], {"batch_data_time": 1}
+
+    def inference_begin(self, data_in=None, **kwargs):
+        if not self.split:
+            return None
+        if self.fail_at is not None and data_in[0] == self.fail_at:
+            raise RuntimeError("cannot load " + str(data_in[0]))
+        self.log.append(("begin", tuple(data_in)))
+        self.open.add(tuple(data_in))
+        return {"data": tuple(data_in)}
+
+    def inference_launch(self, pending):
+        self.log.append(("launch", pending["data"]))
+        pending["launched"] = True
+
+    def inference_end(self, pending):
+        if not pending.get("launched"):
+            self.inference_launch(pending)
+        self.log.append(("end", pending["data"]))
+        self.open.discard(pending["data"])
+        return [{"text": str(d)} for d in pending["data"]], {"batch_data_time": 1}
+
+
+def _bare_auto_model(model, **kw):
+    am = AutoModel.__new__(AutoModel)
+    am.model = model
+    am.kwargs = dict({"batch_size": 2, "disable_pbar": True}, **kw)
+    am._base_kwargs = dict(am.kwargs)
+    return am
+
+
+def test_batches_overlap_in_three_stages_when_the_model_offers_them():
+    """AutoModel.inference over several batches: begin(i + 1) | launch(i) | end(i - 1), records and progress as the plain loop's"""
+    m = _SplitDummy()
+    progress = []
+    res = AutoModel.inference(_bare_auto_model(m), list("abcdefg"), progress_callback=lambda i, n: progress.append((i, n)))
+    assert [r["text"] for r in res] == list("abcdefg")
+    assert progress == [(2, 7), (4, 7), (6, 7), (7, 7)]
+    b = [("a", "b"), ("c", "d"), ("e", "f"), ("g",)]
+    assert m.log == [("begin", b[0]), ("begin", b[1]), ("launch", b[0]), ("begin", b[2]), ("launch", b[1]), ("end", b[0]),
+                     ("begin", b[3]), ("launch", b[2]), ("end", b[1]), ("launch", b[3]), ("end", b[2]), ("end", b[3])]
+    # pipeline=False, a single batch, and a model whose configuration has no split form: the plain loop
+    for am, items in ((_bare_auto_model(_SplitDummy(), pipeline=False), "abc"), (_bare_auto_model(_SplitDummy()), "ab"),
+                      (_bare_auto_model(_SplitDummy(split=False)), "abc")):
+        res = AutoModel.inference(am, list(items))
+        assert [r["text"] for r in res] == list(items)
+        assert all(kind == "whole" for kind, _ in am.model.log) and len(am.model.log) == (len(items) + 1) // 2
+
+
+def test_a_failing_batch_leaves_no_batch_open():
+    m = _SplitDummy(fail_at="e")
+    with pytest.raises(RuntimeError, match="cannot load e"):
+        AutoModel.inference(_bare_auto_model(m), list("abcdefg"))
+    assert not m.open and ("end", ("c", "d")) in m.log
