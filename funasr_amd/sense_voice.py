@@ -203,8 +203,9 @@ class SenseVoiceSmall(nn.Module):
 
     def inference(self, data_in, data_lengths=None, key: list = ["wav_file_tmp_name"], tokenizer=None, frontend=None,
                   **kwargs):
-        pending = self._inference_enqueue(data_in, data_lengths, key, tokenizer, frontend, kwargs, staged=False)
-        return self.inference_end(pending)
+        args, ban, meta_data, output_timestamp = self._inference_inputs(data_in, data_lengths, tokenizer, frontend, kwargs, staged=False)
+        res = self.recognize_features(*args, ban_ids=ban, return_intermediate=output_timestamp)
+        return self._records(res, key, tokenizer, meta_data, output_timestamp)
 
     # ---- the same call in parts for AutoModel.inference's loop over batches (see paraformer.py inference_begin): the encoder +
     #      CTC arg-max of batch i + 1 are enqueued before batch i's frame ids are read and turned into text
@@ -212,12 +213,17 @@ class SenseVoiceSmall(nn.Module):
         if (kwargs.get("output_timestamp", False) or kwargs.get("data_type", "sound") == "fbank"
                 or not str(kwargs.get("device", "")).startswith("cuda")):
             return None
-        return self._inference_enqueue(data_in, data_lengths, key, tokenizer, frontend, kwargs, staged=True)
+        args, ban, meta_data, _ = self._inference_inputs(data_in, data_lengths, tokenizer, frontend, kwargs, staged=True)
+        return dict(enq=self.enqueue_features(*args, ban_ids=ban), key=key, tokenizer=tokenizer, meta_data=meta_data)
 
     def inference_launch(self, pending: dict) -> None:
         return None                                              # nothing waits for the host between the encoder and the ids
 
-    def _inference_enqueue(self, data_in, data_lengths, key, tokenizer, frontend, kwargs, staged):
+    def inference_end(self, pending: dict):
+        return self._records(self.collect(pending.pop("enq")), pending["key"], pending["tokenizer"], pending["meta_data"], False)
+
+    def _inference_inputs(self, data_in, data_lengths, tokenizer, frontend, kwargs, staged):
+        """-> ((speech, speech_lengths, language, textnorm) and ban_ids of recognize_features / enqueue_features, meta_data, output_timestamp)"""
         output_timestamp = kwargs.get("output_timestamp", False)
         if output_timestamp and tokenizer is None:
             raise ValueError("output_timestamp needs the tokenizer (text2tokens / tokens2ids)")
@@ -226,12 +232,9 @@ class SenseVoiceSmall(nn.Module):
         use_itn = kwargs.get("use_itn", False)
         textnorm = kwargs.get("text_norm", None) or ("withitn" if use_itn else "woitn")
         ban = [self.emo_dict["unk"]] if kwargs.get("ban_emo_unk", False) else None          # model.py:1004-1005
-        enq = self.enqueue_features(speech, speech_lengths, kwargs.get("language", "auto"), textnorm, output_timestamp, ban)
-        return dict(enq=enq, key=key, tokenizer=tokenizer, meta_data=meta_data, output_timestamp=output_timestamp)
+        return (speech, speech_lengths, kwargs.get("language", "auto"), textnorm), ban, meta_data, output_timestamp
 
-    def inference_end(self, pending: dict):
-        res = self.collect(pending.pop("enq"))
-        key, tokenizer, meta_data, output_timestamp = pending["key"], pending["tokenizer"], pending["meta_data"], pending["output_timestamp"]
+    def _records(self, res, key, tokenizer, meta_data, output_timestamp):
         B = len(res["ids"])
         logp = None
         if output_timestamp:                                     # one D2H copy of the batch's log-probabilities (:1045)
