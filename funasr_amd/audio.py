@@ -223,7 +223,8 @@ def batch_to_features(data_in, data_lengths, frontend, kwargs, uploader=None):
     audio = load_audio_list(data_in, fs=frontend.fs, audio_fs=kwargs.get("fs", 16000))
     t2 = time.perf_counter()
     meta_data["load_data"] = f"{t2 - t1:0.3f}"
-    if uploader is not None and device is not None and str(device).startswith("cuda") and all(a.device.type == "cpu" for a in audio):
+    if (uploader is not None and device is not None and str(device).startswith("cuda") and torch.cuda.is_available()
+            and all(a.device.type == "cpu" for a in audio)):
         wav, lens = uploader(audio, device)
     else:
         lens = [int(a.shape[0]) for a in audio]

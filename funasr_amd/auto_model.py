@@ -348,7 +348,10 @@ class AutoModel:
             return apply_postprocess_hotwords_to_results(results, cfg)      # text-level hotword correction (:742,:748)
         return apply_postprocess_hotwords_to_results(self.inference_with_vad(input, input_len=input_len, **cfg), cfg)
 
-    def inference(self, input, input_len=None, model=None, kwargs=None, key=None, progress_callback=None, **cfg):
+    def inference(self, input, input_len=None, model=None, kwargs=None, key=None, progress_callback=None, batch_bounds=None, **cfg):
+        """auto_model.py:750-850. `batch_bounds` (this package's own): [begin, end) index ranges into the input list that replace the
+        count-based batches of `batch_size` -- inference_with_vad hands a recording's planned segment batches over in ONE call, so
+        that they overlap like any other list of batches."""
         if kwargs is None:                                                   # _reset_runtime_configs (:1318-1359)
             keep = {k: self.kwargs[k] for k in ("tokenizer", "frontend") if k in self.kwargs}
             self.kwargs = dict(copy.deepcopy(self._base_kwargs), **keep)
@@ -390,7 +393,7 @@ class AutoModel:
         # More than one batch and a model that offers its `inference` in three parts (paraformer.py inference_begin / _launch /
         # _end): the loop of auto_model.py:790-840 with the batches overlapped -- host work of batch i + 1 and of batch i - 1
         # beside the GPU work of batch i. Same records in the same order; `pipeline=False` keeps the plain loop.
-        bounds = [(beg, min(n, beg + batch_size)) for beg in range(0, n, batch_size)]
+        bounds = [(beg, min(n, beg + batch_size)) for beg in range(0, n, batch_size)] if batch_bounds is None else [(int(b), int(e)) for b, e in batch_bounds]
         done = 0
         if len(bounds) > 1 and kwargs.get("pipeline", True) and hasattr(model, "inference_begin"):
             inflight = collections.deque()                                    # [pending, end, host seconds so far, launched]
@@ -495,6 +498,10 @@ class AutoModel:
             key, segments = vad_res["key"], vad_res["value"]
             speech = load_audio_list([data_list[i]], fs=fs, audio_fs=kwargs.get("fs", 16000))[0]
             n = len(segments)
+            if n > 0 and str(kwargs.get("device", "")).startswith("cuda") and speech.device.type == "cpu" and kwargs.get("fs", 16000) == fs and torch.cuda.is_available():
+                # one upload of the recording: the segment slices below are device views, a batch is padded on the device
+                # (load_utils.py:413's pad_sequence, same samples) and nothing is padded or copied per batch on the host
+                speech = speech.to(kwargs["device"])
             order = sorted(range(n), key=lambda j: segments[j][1] - segments[j][0])       # stable, ascending duration
             if n == 0:
                 out.append({"key": key, "text": "", "timestamp": []})
@@ -517,14 +524,19 @@ class AutoModel:
                 frames = [fe.num_frames(int(d * 16)) if hasattr(fe, "num_frames") else max(1, int(d) // 60) for d in durs]
                 plan = dp.plan_batches_by_rows(frames, int(kwargs["batch_size_rows"]), extra_rows=1,
                                                packed=getattr(getattr(self.model, "encoder", None), "_mode", lambda: "fp32")() == "f16x2")
-            for beg, end in plan:
-                idx = order[beg:end]
-                # slice_padding_audio_samples (funasr/utils/vad_utils.py:28-51): 16 samples per millisecond
-                clips = [speech[int(segments[j][0] * 16): min(int(segments[j][1] * 16), len(speech))] for j in idx]
-                results = self.inference(clips, input_len=None, model=self.model, kwargs=kwargs, **cfg)
-                if len(results) < 1:
-                    continue
-                decoded.extend(results)
+            # slice_padding_audio_samples (funasr/utils/vad_utils.py:28-51): 16 samples per millisecond. The reference decodes the
+            # planned batches with one self.inference call each (:967-985); here the whole plan goes over in one call, so that the
+            # recording's batches overlap (a batch that decodes nothing still yields ONE record, i.e. the count check below fails
+            # for the recording exactly as there)
+            clips = [speech[int(segments[j][0] * 16): min(int(segments[j][1] * 16), len(speech))] for j in order]
+            if len(plan) > 1 and kwargs.get("pipeline", True) and hasattr(self.model, "inference_begin"):
+                decoded = self.inference(clips, input_len=None, model=self.model, kwargs=kwargs, batch_bounds=plan, **cfg)
+            else:
+                for beg, end in plan:
+                    results = self.inference(clips[beg:end], input_len=None, model=self.model, kwargs=kwargs, **cfg)
+                    if len(results) < 1:
+                        continue
+                    decoded.extend(results)
             if len(decoded) != n:
                 out.append({"key": key, "text": "", "timestamp": []})
                 continue

@@ -298,7 +298,7 @@ class Paraformer(nn.Module):
 
     def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
         self._wants_beam(kwargs)
-        speech, speech_lengths, meta_data = self._prepare(data_in, data_lengths, frontend, kwargs)
+        speech, speech_lengths, meta_data = self._prepare(data_in, data_lengths, frontend, kwargs, staged=True)
         want_stamps = self._always_timestamps or kwargs.get("pred_timestamp", False)
         if self.beam_search is not None and not self._always_timestamps:
             return self._inference_beam(speech, speech_lengths, key, tokenizer, want_stamps, meta_data, **kwargs)

@@ -203,7 +203,7 @@ class SenseVoiceSmall(nn.Module):
 
     def inference(self, data_in, data_lengths=None, key: list = ["wav_file_tmp_name"], tokenizer=None, frontend=None,
                   **kwargs):
-        args, ban, meta_data, output_timestamp = self._inference_inputs(data_in, data_lengths, tokenizer, frontend, kwargs, staged=False)
+        args, ban, meta_data, output_timestamp = self._inference_inputs(data_in, data_lengths, tokenizer, frontend, kwargs, staged=True)
         res = self.recognize_features(*args, ban_ids=ban, return_intermediate=output_timestamp)
         return self._records(res, key, tokenizer, meta_data, output_timestamp)
 

@@ -235,6 +235,11 @@ def test_vad_model_directory_end_to_end(model_dir, cuda, tmp_path):
     single = AutoModel(model=model_dir["dir"], device="cuda:0")
     texts = [single.generate(input=long[b * 16: min(e * 16, long.numel())])[0]["text"] for b, e in segs]
     assert len(out) == 1 and out[0]["text"] == " ".join(texts)
+    # several segments per batch plan, overlapped (the default) against the plain loop: the same record
+    long2 = torch.cat([long, long.roll(4000), long.roll(9000)])
+    many = am.generate(input=long2, batch_size_s=6)
+    assert many[0]["text"] == am.generate(input=long2, batch_size_s=6, pipeline=False)[0]["text"] and len(many[0]["text"]) > len(out[0]["text"])
+    assert am.model.__dict__.get("_dec_stream") is not None, "the segment batches did not overlap"
     # the whole long-form chain from three model directories: VAD -> ASR (with token timestamps) -> CT-Transformer.
     # The text is what the punctuation model makes of the joined segment texts, the sentence records are cut at its marks
     from funasr_amd.timestamps import timestamp_sentence

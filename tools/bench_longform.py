@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Long-form decoding, the reference's `inference_with_vad` (funasr/auto/auto_model.py:852-1254): FSMN-VAD cuts recordings into segments,
+the segments are decoded in length-sorted dynamic batches (`batch_size_s` / this package's `batch_size_rows`) by full-size Paraformer-large
+(random-init weights; an energy-tracking VAD so that the synthetic bursts are found), texts are merged per recording. Measures audio-seconds
+per second of the whole call, the overlapped batches (default) against `pipeline=False`, records compared.
+
+    python tools/bench_longform.py --recordings 4 --minutes 20
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def recording(minutes, seed, pool):
+    """speech-like bursts of 2-14 s separated by 1-2 s of near silence"""
+    g = torch.Generator().manual_seed(seed)
+    n = int(minutes * 60 * 16000)
+    x = 1e-4 * torch.randn(n, generator=g)
+    t, k = 8000, 0
+    while True:
+        d = int((2.0 + 12.0 * float(torch.rand(1, generator=g))) * 16000)
+        if t + d + 16000 > n:
+            break
+        x[t: t + d] += pool[(seed + k) % len(pool)].roll(977 * k)[:d]
+        t += d + int((1.0 + float(torch.rand(1, generator=g))) * 16000)
+        k += 1
+    return x, k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--recordings", type=int, default=4)
+    ap.add_argument("--minutes", type=float, default=20.0)
+    ap.add_argument("--batch-size-s", type=int, default=300, help="the reference's default budget (padded seconds per batch)")
+    ap.add_argument("--batch-size-rows", type=int, default=0, help="> 0: budget in encoder rows instead (INTEGRATION 2: 32768 fills the chip)")
+    ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--profile", action="store_true", help="cProfile of one overlapped call (by own time and by cumulative time) to stderr")
+    args = ap.parse_args()
+
+    from funasr_amd import synth
+    from funasr_amd.auto_model import AutoModel
+    from bench_generate import model_dir
+    sys.path.insert(0, ROOT)
+    from tests._model_dir import VAD_ENCODER_CONF, make_vad_model_dir
+    from tests.test_vad_gpu import _energy_tracking_weights
+
+    work = tempfile.mkdtemp(prefix="pf_longform_")
+    mdir, vdir = os.path.join(work, "asr"), os.path.join(work, "vad")
+    cfg = synth.PARAFORMER_LARGE
+    model_dir(mdir, cfg)
+    make_vad_model_dir(vdir, _energy_tracking_weights(VAD_ENCODER_CONF))
+    pool = [synth.speech_like(int(14.7 * 16000) + 1, seed=1000 + i) for i in range(16)]
+    recs, bursts = [], 0
+    for r in range(args.recordings):
+        x, k = recording(args.minutes, 50 + r, pool)
+        recs.append(x)
+        bursts += k
+    total_s = sum(x.numel() for x in recs) / 16000.0
+    am = AutoModel(model=mdir, device="cuda:0", vad_model=vdir, disable_pbar=True)
+    am.model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
+    am.model.to("cuda:0")
+    kw = {"batch_size_s": args.batch_size_s}
+    if args.batch_size_rows > 0:
+        kw["batch_size_rows"] = args.batch_size_rows
+    am.generate(input=recs[:1], **kw)
+    am.generate(input=recs[:1], pipeline=False, **kw)
+    out = {"metric": "inference_with_vad audio-seconds/s (FSMN-VAD + Paraformer-large f16x2, texts merged per recording)",
+           "recordings": args.recordings, "minutes_each": args.minutes, "bursts": bursts, "budget": kw, "runs": []}
+    ref = None
+    for _ in range(args.repeats):
+        for name, extra in (("overlapped", {}), ("plain loop", {"pipeline": False})):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            res = am.generate(input=recs, **kw, **extra)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            ref = ref if ref is not None else res
+            same = [a.get("text") for a in res] == [a.get("text") for a in ref]
+            out["runs"].append({"loop": name, "wall_s": round(dt, 3), "audio_s_per_s": round(total_s / dt, 1), "texts_equal_first_run": same})
+    if args.profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        am.generate(input=recs, **kw)
+        pr.disable()
+        st = pstats.Stats(pr, stream=sys.stderr)
+        st.sort_stats("tottime").print_stats(22)
+        st.sort_stats("cumulative").print_stats(40)
+    best = {n: max(x["audio_s_per_s"] for x in out["runs"] if x["loop"] == n) for n in ("overlapped", "plain loop")}
+    out.update(value=best["overlapped"], plain_loop=best["plain loop"], gain=round(best["overlapped"] / best["plain loop"], 3),
+               characters=sum(len(r.get("text", "")) for r in ref))
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
