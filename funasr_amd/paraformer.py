@@ -310,18 +310,27 @@ class Paraformer(nn.Module):
     #      the host loads and uploads batch i + 1 and enqueues its encoder while batch i's decoder runs on a second stream and batch
     #      i - 1's ids become text. Records, their order and the ids are those of `inference` (tests/test_parity_gpu.py).
     def inference_begin(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, **kwargs):
-        """-> a pending object for `inference_launch` / `inference_end`, or None when this call has to take `inference` itself
-        (beam search, timestamps, feature input, a model that is not the plain offline one)."""
+        """-> a pending object for `inference_launch` / `inference_end`, or None when this call has to take `inference` itself (beam
+        search, feature input, no GPU). The plain offline model without timestamps goes in three parts (pf_paraformer_begin /
+        _finish: nothing waits for the host before `inference_launch`); timestamps and the other model classes (BiCif / SeACo /
+        contextual: module-by-module chains that read the CIF token counts on the way) go in two -- everything enqueued here, text
+        in `inference_end` -- which still puts the next batch's loading and upload and the previous batch's text beside GPU work."""
         self._wants_beam(kwargs)
         want_stamps = self._always_timestamps or kwargs.get("pred_timestamp", False)
-        if (self.beam_search is not None or want_stamps or not self._one_call_ok() or kwargs.get("data_type", "sound") == "fbank"
-                or not str(kwargs.get("device", "")).startswith("cuda")):
+        if (self.beam_search is not None or kwargs.get("data_type", "sound") == "fbank" or not str(kwargs.get("device", "")).startswith("cuda")
+                or not torch.cuda.is_available()):
             return None
         speech, speech_lengths, meta_data = self._prepare(data_in, data_lengths, frontend, kwargs, staged=True)
-        ticket = self.begin_features(speech, speech_lengths)
-        return dict(ticket=ticket, key=key, tokenizer=tokenizer, meta_data=meta_data, kwargs=kwargs)
+        pending = dict(key=key, tokenizer=tokenizer, meta_data=meta_data, kwargs=kwargs, want_stamps=want_stamps)
+        if self._one_call_ok() and not want_stamps:
+            pending["ticket"] = self.begin_features(speech, speech_lengths)
+        else:
+            pending["fin"] = self.enqueue_features(speech, speech_lengths, return_intermediate=want_stamps)
+        return pending
 
     def inference_launch(self, pending: dict) -> None:
+        if "ticket" not in pending:
+            return
         dev = pending["ticket"]["dev"]
         side = self.__dict__.get("_dec_stream")
         if side is None or side.device != dev:
@@ -333,7 +342,7 @@ class Paraformer(nn.Module):
         if "fin" not in pending:
             self.inference_launch(pending)
         res = self.collect(pending.pop("fin"))
-        return self._assemble(res, pending["key"], pending["tokenizer"], False, pending["meta_data"], pending["kwargs"])
+        return self._assemble(res, pending["key"], pending["tokenizer"], pending["want_stamps"], pending["meta_data"], pending["kwargs"])
 
     def _assemble(self, res, key, tokenizer, want_stamps, meta_data, kwargs):
         """model.py:639-697: ids -> records"""

@@ -136,6 +136,9 @@ def test_generate_over_many_batches_overlapped_equals_the_plain_loop(model_dir, 
     assert over == plain and len(over) == len(paths)
     assert am.speed_stats["rtf_avg"] is not None
     assert am.model.__dict__.get("_dec_stream") is not None, "the overlapped loop did not run"
+    # token timestamps: the two-part form (everything enqueued in `inference_begin`, text and spans in `inference_end`)
+    stamped = am.generate(input=paths, pred_timestamp=True)
+    assert stamped == am.generate(input=paths, pred_timestamp=True, pipeline=False) and all("timestamp" in r for r in stamped)
     # keys, another batch size, again (the pinned buffers and both library slots are reused)
     keys = [f"k{i}" for i in range(len(paths))]
     assert am.generate(input=paths, key=keys, batch_size=4) == am.generate(input=paths, key=keys, batch_size=4, pipeline=False)

@@ -190,3 +190,7 @@ def test_automodel_wav_to_text_with_hotwords_equals_the_oracle(cuda, tmp_path):
         for r, (text, stamps) in zip(out, want):
             assert r["text"] == text and r["timestamp"] == stamps
     assert [r["text"] for r in res] != [r["text"] for r in plain]
+    # more inputs than one batch: the overlapped loop (two parts for this class: everything enqueued, text later) == the plain loop
+    many = [w.numpy() for w in waves] + [waves[0][:20000].numpy(), waves[1][:27000].numpy()]
+    strip = lambda out: [(r["text"], r["timestamp"]) for r in out]
+    assert strip(am.generate(input=many, batch_size=2, hotword=hot)) == strip(am.generate(input=many, batch_size=2, hotword=hot, pipeline=False))
