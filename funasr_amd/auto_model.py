@@ -470,6 +470,96 @@ class AutoModel:
             beg, end, longest = end, end + 1, d
         return plan
 
+    def _rows_plan(self, durations_ms, kwargs):
+        """MI355X-native alternative to batch_size_s: a budget of encoder ROWS per batch (funasr_amd/dp.py; 32 768 = one round of
+        GEMM blocks over the chip). frames = LFR frames of the segment, 60 ms each; the list is length-sorted."""
+        from . import dp
+        fe = kwargs.get("frontend")
+        frames = [fe.num_frames(int(d * 16)) if hasattr(fe, "num_frames") else max(1, int(d) // 60) for d in durations_ms]
+        return dp.plan_batches_by_rows(frames, int(kwargs["batch_size_rows"]), extra_rows=1,
+                                       packed=getattr(getattr(self.model, "encoder", None), "_mode", lambda: "fp32")() == "f16x2")
+
+    @staticmethod
+    def _recording_on_device(speech, kwargs, fs):
+        """one upload of the recording: the segment slices are device views, a batch is padded on the device (load_utils.py:413's
+        pad_sequence, same samples) and nothing is padded or copied per batch on the host"""
+        if (str(kwargs.get("device", "")).startswith("cuda") and speech.device.type == "cpu" and kwargs.get("fs", 16000) == fs
+                and torch.cuda.is_available()):
+            return speech.to(kwargs["device"])
+        return speech
+
+    def _decode_one_recording(self, speech, segments, kwargs, cfg, budget, threshold_ms) -> List[dict]:
+        """auto_model.py:905-985: the recording's segments, shortest first, in dynamic batches -> their records in THAT order"""
+        order = sorted(range(len(segments)), key=lambda j: segments[j][1] - segments[j][0])
+        durs = [segments[j][1] - segments[j][0] for j in order]
+        # the reference updates the budget IN PLACE (auto_model.py:924-928): once a recording's shortest segment exceeds
+        # it, the raised budget -- or the 0 of device="cpu" -- also applies to the recordings after it in the same call
+        # (found by tests/test_reference_vad_pipeline_differential.py against the reference's own loop)
+        budget[0] = max(budget[0], durs[0])
+        if kwargs["device"] == "cpu":
+            budget[0] = 0
+        plan = self.plan_vad_batches(durs, budget[0], threshold_ms)
+        if kwargs.get("batch_size_rows") and kwargs["device"] != "cpu":
+            plan = self._rows_plan(durs, kwargs)
+        # slice_padding_audio_samples (funasr/utils/vad_utils.py:28-51): 16 samples per millisecond. The reference decodes the
+        # planned batches with one self.inference call each (:967-985); where batches can overlap the whole plan goes over in one
+        # call (a batch that decodes nothing still yields ONE record, i.e. the caller's count check fails exactly as there)
+        clips = [speech[int(segments[j][0] * 16): min(int(segments[j][1] * 16), len(speech))] for j in order]
+        if len(plan) > 1 and kwargs.get("pipeline", True) and hasattr(self.model, "inference_begin"):
+            return self.inference(clips, input_len=None, model=self.model, kwargs=kwargs, batch_bounds=plan, **cfg)
+        decoded: List[dict] = []
+        for beg, end in plan:
+            results = self.inference(clips[beg:end], input_len=None, model=self.model, kwargs=kwargs, **cfg)
+            if len(results) < 1:
+                continue
+            decoded.extend(results)
+        return decoded
+
+    def _decode_across_recordings(self, res, data_list, kwargs, cfg, fs, group_samples: int = 1 << 28) -> Dict[int, List[dict]]:
+        """-> {recording index: its segments' records in SEGMENT order} for the recordings decoded here; {} when the mode does not
+        apply (no `batch_size_rows`, `batch_across_recordings=False`, one recording, cpu, a model without the split inference).
+        Recordings are taken in groups of at most `group_samples` samples (4.7 h at 16 kHz: 1 GiB on the device); a group's segments,
+        longest first, are cut into batches by the rows budget and decoded in ONE overlapped `inference` call. What a segment's
+        record can owe to its batch is what it owes to it in the reference: the LONGEST clip of a batch has no frame behind its last
+        one, every other clip has the encoder's row for a padding frame there, and CifPredictorV2's conv reads that row
+        (cif_predictor.py:196-205,275-277) -- the last token of a batch's longest clip may differ from the one it gets as a shorter
+        member of another batch, exactly as when `batch_size_s` is changed there (200 one-minute calls: 200 of 87 108 characters
+        against per-recording batches, profiles/r06u_*); CifPredictorV3's timestamp head runs over the padded batch."""
+        if not (kwargs.get("batch_size_rows") and kwargs.get("batch_across_recordings", True)
+                and str(kwargs.get("device", "")).startswith("cuda") and torch.cuda.is_available()
+                and hasattr(self.model, "inference_begin") and sum(1 for r in res if len(r["value"]) > 0) > 1):
+            return {}
+        from .audio import load_audio_list
+        done: Dict[int, List[dict]] = {}
+        group: List[tuple] = []
+
+        def flush():
+            flat = [(seg[1] - seg[0], i, j) for i, _, segs in group for j, seg in enumerate(segs)]
+            flat.sort(key=lambda t: -t[0])                                            # stable: longest first
+            speech_of = {i: sp for i, sp, _ in group}
+            segs_of = {i: segs for i, _, segs in group}
+            clips = [speech_of[i][int(segs_of[i][j][0] * 16): min(int(segs_of[i][j][1] * 16), len(speech_of[i]))] for _, i, j in flat]
+            decoded = self.inference(clips, input_len=None, model=self.model, kwargs=kwargs,
+                                     batch_bounds=self._rows_plan([d for d, _, _ in flat], kwargs), **cfg)
+            if len(decoded) == len(flat):                                             # else: the per-recording path decides
+                for (_, i, j), rec in zip(flat, decoded):
+                    done.setdefault(i, [None] * len(segs_of[i]))[j] = rec
+            group.clear()
+
+        total = 0
+        for i, vad_res in enumerate(res):
+            if len(vad_res["value"]) == 0:
+                continue
+            speech = self._recording_on_device(load_audio_list([data_list[i]], fs=fs, audio_fs=kwargs.get("fs", 16000))[0], kwargs, fs)
+            if total > 0 and total + speech.numel() > group_samples:
+                flush()
+                total = 0
+            group.append((i, speech, vad_res["value"]))
+            total += speech.numel()
+        if group:
+            flush()
+        return done
+
     def inference_with_vad(self, input, input_len=None, **cfg):
         """VAD -> length-sorted dynamic batches -> ASR -> merge -> punctuation -> sentence records
         (funasr/auto/auto_model.py:852-1254 without the speaker branch). Returns one dict per recording: key, text,
@@ -494,49 +584,22 @@ class AutoModel:
         key_list, data_list = prepare_data_iterator(input, input_len=input_len, data_type=kwargs.get("data_type"))
         fs = getattr(kwargs.get("frontend"), "fs", 16000)
         out: List[dict] = []
+        budget = [batch_size]                                       # updated in place across recordings, like the reference's
+        # MI355X-native: with a rows budget the segments of SEVERAL recordings share batches (the reference batches inside one
+        # recording only, :905-985 -- a one-minute call is a sixth of a 300-s batch and a thirtieth of a round of GEMM blocks)
+        across = self._decode_across_recordings(res, data_list, kwargs, cfg, fs)
         for i, vad_res in enumerate(res):
             key, segments = vad_res["key"], vad_res["value"]
-            speech = load_audio_list([data_list[i]], fs=fs, audio_fs=kwargs.get("fs", 16000))[0]
             n = len(segments)
-            if n > 0 and str(kwargs.get("device", "")).startswith("cuda") and speech.device.type == "cpu" and kwargs.get("fs", 16000) == fs and torch.cuda.is_available():
-                # one upload of the recording: the segment slices below are device views, a batch is padded on the device
-                # (load_utils.py:413's pad_sequence, same samples) and nothing is padded or copied per batch on the host
-                speech = speech.to(kwargs["device"])
-            order = sorted(range(n), key=lambda j: segments[j][1] - segments[j][0])       # stable, ascending duration
             if n == 0:
                 out.append({"key": key, "text": "", "timestamp": []})
                 continue
-            durs = [segments[j][1] - segments[j][0] for j in order]
-            # the reference updates the budget IN PLACE (auto_model.py:924-928): once a recording's shortest segment exceeds
-            # it, the raised budget -- or the 0 of device="cpu" -- also applies to the recordings after it in the same call
-            # (found by tests/test_reference_vad_pipeline_differential.py against the reference's own loop)
-            batch_size = max(batch_size, durs[0])
-            if kwargs["device"] == "cpu":
-                batch_size = 0
-            bs = batch_size
-            decoded: List[dict] = []
-            plan = self.plan_vad_batches(durs, bs, threshold_ms)
-            if kwargs.get("batch_size_rows") and kwargs["device"] != "cpu":
-                # MI355X-native alternative to batch_size_s: a budget of encoder ROWS per batch (funasr_amd/dp.py; 32 768 =
-                # one round of GEMM blocks over the chip). frames = LFR frames of the segment, 60 ms each
-                from . import dp
-                fe = kwargs.get("frontend")
-                frames = [fe.num_frames(int(d * 16)) if hasattr(fe, "num_frames") else max(1, int(d) // 60) for d in durs]
-                plan = dp.plan_batches_by_rows(frames, int(kwargs["batch_size_rows"]), extra_rows=1,
-                                               packed=getattr(getattr(self.model, "encoder", None), "_mode", lambda: "fp32")() == "f16x2")
-            # slice_padding_audio_samples (funasr/utils/vad_utils.py:28-51): 16 samples per millisecond. The reference decodes the
-            # planned batches with one self.inference call each (:967-985); here the whole plan goes over in one call, so that the
-            # recording's batches overlap (a batch that decodes nothing still yields ONE record, i.e. the count check below fails
-            # for the recording exactly as there)
-            clips = [speech[int(segments[j][0] * 16): min(int(segments[j][1] * 16), len(speech))] for j in order]
-            if len(plan) > 1 and kwargs.get("pipeline", True) and hasattr(self.model, "inference_begin"):
-                decoded = self.inference(clips, input_len=None, model=self.model, kwargs=kwargs, batch_bounds=plan, **cfg)
+            if i in across:
+                order, decoded = list(range(n)), across[i]
             else:
-                for beg, end in plan:
-                    results = self.inference(clips[beg:end], input_len=None, model=self.model, kwargs=kwargs, **cfg)
-                    if len(results) < 1:
-                        continue
-                    decoded.extend(results)
+                speech = load_audio_list([data_list[i]], fs=fs, audio_fs=kwargs.get("fs", 16000))[0]
+                decoded = self._decode_one_recording(self._recording_on_device(speech, kwargs, fs), segments, kwargs, cfg, budget, threshold_ms)
+                order = sorted(range(n), key=lambda j: segments[j][1] - segments[j][0])   # stable, ascending duration
             if len(decoded) != n:
                 out.append({"key": key, "text": "", "timestamp": []})
                 continue

@@ -243,6 +243,19 @@ def test_vad_model_directory_end_to_end(model_dir, cuda, tmp_path):
     many = am.generate(input=long2, batch_size_s=6)
     assert many[0]["text"] == am.generate(input=long2, batch_size_s=6, pipeline=False)[0]["text"] and len(many[0]["text"]) > len(out[0]["text"])
     assert am.model.__dict__.get("_dec_stream") is not None, "the segment batches did not overlap"
+    # several recordings with a rows budget: their segments share batches (this package's own mode) -- the texts per recording are
+    # those of the per-recording batches and of the plain loop
+    recs = [long, long.roll(4000)[: 20 * fs], long2, 1e-4 * torch.randn(3 * fs, generator=torch.Generator().manual_seed(9)), long.roll(9000)]
+    shared = am.generate(input=recs, batch_size_rows=512)
+    txt = lambda res: [r["text"] for r in res]
+    assert txt(shared) == txt(am.generate(input=recs, batch_size_rows=512, pipeline=False))          # the same batches, one after the other
+    # against per-recording batches: the same texts up to the last token of a clip that is the longest of its batch in one plan and
+    # not in the other (CifPredictorV2 reads the row behind the last frame: a property of the reference's padded batches)
+    apart = am.generate(input=recs, batch_size_rows=512, batch_across_recordings=False)
+    assert len(shared) == len(apart) == 5 and shared[3]["text"] == apart[3]["text"] == ""
+    import difflib
+    for a, b in zip(txt(shared), txt(apart)):
+        assert a == b or difflib.SequenceMatcher(None, a, b, autojunk=False).ratio() > 0.95, (a, b)
     # the whole long-form chain from three model directories: VAD -> ASR (with token timestamps) -> CT-Transformer.
     # The text is what the punctuation model makes of the joined segment texts, the sentence records are cut at its marks
     from funasr_amd.timestamps import timestamp_sentence
