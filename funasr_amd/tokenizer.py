@@ -18,6 +18,8 @@ _DROP = ("<s>", "</s>", "<unk>", "<OOV>")
 
 
 def _strip(tok: str) -> str:
+    if " " not in tok and "<" not in tok:          # nothing to remove (every dropped symbol has a "<"): the common case
+        return tok
     for d in (" ",) + _DROP:
         tok = tok.replace(d, "")
     return tok
@@ -45,13 +47,16 @@ def _all_alpha(tokens: Sequence[str]) -> bool:
 
 
 def _is_letter(tok: str) -> bool:
-    return len(tok) == 1 and tok.encode("utf-8").isalpha()
+    # one ASCII letter (the reference tests `len(word) == 1 and word.encode("utf-8").isalpha()`: bytes.isalpha is ASCII-only)
+    return len(tok) == 1 and ("a" <= tok <= "z" or "A" <= tok <= "Z")
 
 
 def _merge_abbreviations(words: List[str], spans: Optional[List[List[int]]] = None):
     """'a', ' ', 'b', ' ', 'c' -> 'ABC' (abbr_dispose, postprocess_utils.py:68-163). With `spans` (one [begin, end] per
     non-blank word) the merged word runs from its first letter's begin to its last letter's end and the merged span
     list is returned as well."""
+    if spans is None and not any(len(w) == 1 and ("a" <= w <= "z" or "A" <= w <= "Z") for w in words):
+        return list(words)                         # no single letters: nothing to merge
     out: List[str] = []
     out_spans: List[List[int]] = []
     # span index of every position: a blank shares the index of the word that follows it
