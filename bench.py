@@ -639,6 +639,11 @@ def main():
 
     if not args.no_secondary:
         try:
+            line["generate_wav_files"] = run_generate(model, frontend, cfg, device)
+            trace(f"AutoModel.generate over wav files: {line['generate_wav_files']['value']} audio-s/s")
+        except Exception as e:                                   # noqa: BLE001
+            line["generate_wav_files"] = {"error": repr(e)}
+        try:
             line["sensevoice"] = run_sensevoice(device, args)
             trace(f"SenseVoiceSmall: {line['sensevoice']['value']} audio-s/s")
         except Exception as e:                                   # a secondary workload must not lose the headline line
@@ -654,6 +659,57 @@ def main():
         # so that its 1.5 s at the power limit do not precede (and heat) any timed leg above
         apply_power_limited_peak(line["roofline"], power_limited_peak(), PRODUCTS["f16x2"])
     print(json.dumps(line), flush=True)
+
+
+def run_generate(model, frontend, cfg, device, clips=2000, batch_size=256):
+    """The caller's side of the path (SURVEY 8 f3 / INTEGRATION 1): `AutoModel.generate` over wav FILES -- read, decode, pad, upload,
+    features, forward, ids -> text -- with this run's model: the batches overlapped (funasr_amd/auto_model.py) against the reference's
+    one-batch-after-the-other loop (funasr/auto/auto_model.py:790-840), records compared. AISHELL-like durations, sorted by length."""
+    import shutil
+    import tempfile
+    import wave
+    from funasr_amd import synth
+    from funasr_amd.auto_model import AutoModel
+    from funasr_amd.tokenizer import CharTokenizer
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sweep import durations
+    work = tempfile.mkdtemp(prefix="pf_bench_generate_")
+    try:
+        durs = sorted(durations(clips), reverse=True)
+        pool = [synth.speech_like(int(14.7 * 16000) + 1, seed=1000 + i) for i in range(16)]
+        paths = []
+        for i, d in enumerate(durs):
+            p = os.path.join(work, f"clip{i:05d}.wav")
+            pcm = (pool[i % 16].roll(31 * i)[: int(d * 16000)].clamp(-1, 1) * 32767.0).round().to(torch.int16).numpy()
+            with wave.open(p, "wb") as f:
+                f.setnchannels(1)
+                f.setsampwidth(2)
+                f.setframerate(16000)
+                f.writeframes(pcm.tobytes())
+            paths.append(p)
+        V = cfg["decoder"]["vocab_size"]
+        am = AutoModel.__new__(AutoModel)
+        am.model, am.vad_model, am.punc_model = model, None, None
+        am.kwargs = {"batch_size": batch_size, "device": str(device), "disable_pbar": True, "frontend": frontend,
+                     "tokenizer": CharTokenizer(token_list=["<blank>", "<s>", "</s>"] + [chr(0x4E00 + i) for i in range(V - 4)] + ["<unk>"])}
+        am._base_kwargs = {k: v for k, v in am.kwargs.items() if k not in ("frontend", "tokenizer")}
+        total = float(sum(durs))
+        am.generate(input=paths[: 2 * batch_size])
+        am.generate(input=paths[-2 * batch_size:], pipeline=False)
+        out = {}
+        for name, kw in (("overlapped", {}), ("plain_loop", {"pipeline": False})):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = am.generate(input=paths, **kw)
+            torch.cuda.synchronize()
+            out[name] = (res, total / (time.perf_counter() - t0))
+        same = sum(1 for a, b in zip(out["overlapped"][0], out["plain_loop"][0]) if a["text"] == b["text"])
+        return {"value": round(out["overlapped"][1], 1), "unit": "audio-s/s", "plain_loop": round(out["plain_loop"][1], 1),
+                "gain": round(out["overlapped"][1] / out["plain_loop"][1], 3), "records_with_identical_text": f"{same}/{clips}",
+                "workload": f"{clips} wav files, {total / 3600:.2f} h (AISHELL-like durations, longest first), batch_size {batch_size}, "
+                            "file reading, padding, H2D, features and text included; the larger corpus: profiles/r06q_generate_10k_wav_files.json"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def run_pcie_inclusive(frontend, model, wav_host, wav_dev, lens, args, B, dec_stream=None):
