@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libparaformer_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 3            # PF_ABI_VERSION of include/paraformer_hip.h
+ABI_VERSION = 4            # PF_ABI_VERSION of include/paraformer_hip.h
 
 _lock = threading.Lock()
 _lib = None
@@ -121,6 +121,8 @@ SIGNATURES = {
     "pf_predictor_missing": (C.c_int, [_vp]),
     "pf_predictor_alphas": (C.c_int, [_vp, _vp, _pi32, _i32, _i32, _vp, _vp, _pi32, _vp]),
     "pf_predictor_embeds": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pf_predictor_alphas_begin": (C.c_int, [_vp, _i32, _vp, _pi32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pf_predictor_embeds_slot": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pf_predictor_create_v3": (_vp, [C.POINTER(pf_predictor_config), C.POINTER(pf_predictor_v3_config)]),
     "pf_predictor_timestamp": (C.c_int, [_vp, _vp, _pi32, _pi32, _i32, _i32, _vp, _vp, _vp]),
     "pf_decoder_create": (_vp, [C.POINTER(pf_decoder_config)]),

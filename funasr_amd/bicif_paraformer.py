@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import torch
 
+from .hip_module import HostCopyRing, host_i32
 from .paraformer import Paraformer
 from .register import tables
 from .timestamps import cif_token_spans
@@ -41,24 +42,48 @@ class BiCifParaformer(Paraformer):
     def calc_predictor_timestamp(self, encoder_out, encoder_out_lens, token_num):
         return self.predictor.get_upsample_timestamp(encoder_out, None, token_num, lengths=encoder_out_lens)
 
-    def enqueue_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
+    # The chain in two halves around its one host wait (the CIF token counts size the decoder and the timestamp scan, like the
+    # .item() at cif_predictor.py:311): `enqueue_begin` puts encoder + predictor and the counts' D2H copy on the stream and returns
+    # at once, `enqueue_finish` waits for the counts and enqueues the rest. A loop over batches calls begin(i + 1) before finish(i)
+    # (AutoModel.inference through inference_begin / inference_launch): the host then never sits in that wait with nothing queued.
+    def enqueue_begin(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False) -> dict:
         enc, olens = self.encode(speech, speech_lengths)
-        embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
+        return dict(enc=enc, olens=olens, want=return_intermediate, pred=self.predictor.forward_begin(enc, olens))
+
+    def enqueue_finish(self, half: dict) -> dict:
+        enc, olens = half["enc"], half["olens"]
+        embeds, token_num, alphas, peaks = self.predictor.forward_finish(half["pred"])
+        half.update(alphas=alphas, peaks=peaks)
         tok = [int(round(v)) for v in token_num.tolist()]
         ids, us_alphas, us_peaks = None, None, None
         if max(tok) >= 1:                                            # model.py:343-344
             ids, _ = self.decoder.greedy(enc, olens, embeds, tok)
             _, _, us_alphas, us_peaks = self.calc_predictor_timestamp(enc, olens, tok)
         pending = dict(tok=tok, ids=ids, B=enc.shape[0], extra=dict(us_alphas=us_alphas, us_peaks=us_peaks, olens=olens))
-        if return_intermediate:
-            pending["extra"].update(enc=enc, embeds=embeds, alphas=alphas, peaks=peaks)
+        if ids is not None:
+            # the batch's D2H copies go on the stream NOW, into pinned memory: collect() then waits for THIS batch only (a .cpu()
+            # at collect time is ordered behind everything enqueued since -- the next batches of an overlapped loop)
+            ring = self.__dict__.setdefault("_host_ring", HostCopyRing())
+            pending["ids_host"] = (ids, ring.start(ids))
+            pending["us_host"] = (ring.start(us_alphas), ring.start(us_peaks))
+        if half["want"]:
+            pending["extra"].update(enc=enc, embeds=embeds, alphas=half["alphas"], peaks=half["peaks"])
         return pending
+
+    def enqueue_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
+        return self.enqueue_finish(self.enqueue_begin(speech, speech_lengths, return_intermediate))
+
+    _split_enqueue_features = enqueue_features      # inference_begin uses the halves only while no subclass overrides the chain
 
     def collect(self, pending: dict) -> dict:
         out = super().collect(pending)
         if out.get("us_alphas") is not None:                         # one more small D2H pair per batch
-            out["us_alphas_host"], out["us_peaks_host"] = out["us_alphas"].cpu(), out["us_peaks"].cpu()
-            out["olens_host"] = [int(v) for v in (out["olens"].tolist() if isinstance(out["olens"], torch.Tensor) else out["olens"])]
+            early = pending.get("us_host")
+            if early is not None:
+                out["us_alphas_host"], out["us_peaks_host"] = HostCopyRing.wait(early[0]).clone(), HostCopyRing.wait(early[1]).clone()
+            else:
+                out["us_alphas_host"], out["us_peaks_host"] = out["us_alphas"].cpu(), out["us_peaks"].cpu()
+            out["olens_host"] = host_i32(out["olens"])[1]
         return out
 
     def _token_timestamps(self, res: dict, i: int, token, kwargs):

@@ -69,6 +69,46 @@ class CifPredictorV2(HipModule):
             alphas, peaks = alphas[:, :T], peaks[:, :T]
         return embeds, token_num_t, alphas, peaks
 
+    # ---- `forward` in two halves around its host wait (include/paraformer_hip.h pf_predictor_alphas_begin / _embeds_slot): a loop
+    #      over batches calls forward_begin(batch i + 1) before forward_finish(batch i); two batches may be in flight (slots 0 / 1)
+    def forward_begin(self, hidden, lengths) -> dict:
+        lib, h = self._ensure_handle()
+        dev = self._handle_device
+        hid = hidden.to(device=dev, dtype=torch.float32).contiguous()
+        B, T, D = hid.shape
+        lens_c, _ = host_i32(lengths, B)
+        slot = self.__dict__["_slot"] = 1 - self.__dict__.get("_slot", 1)
+        alphas = torch.empty(B, T + 1, device=dev, dtype=torch.float32)
+        peaks = torch.empty(B, T + 1, device=dev, dtype=torch.float32)
+        counts = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pf_predictor_alphas_begin(h, slot, hid.data_ptr(), lens_c, B, T, alphas.data_ptr(), peaks.data_ptr(),
+                                                     counts.data_ptr(), stream_ptr()), "pf_predictor_alphas_begin")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        return dict(hid=hid, lens_c=lens_c, slot=slot, alphas=alphas, peaks=peaks, counts=counts, ev=ev)
+
+    def forward_finish(self, st: dict):
+        """-> what `forward` returns (embeds, token_num -- a HOST tensor here --, alphas, peaks) for the batch of `forward_begin`"""
+        lib, h = self._ensure_handle()
+        hid, dev = st["hid"], self._handle_device
+        B, T, D = hid.shape
+        st["ev"].synchronize()
+        token_num = st["counts"].tolist()
+        N = max(token_num)
+        with torch.cuda.device(dev):
+            embeds = torch.empty(B, N, D, device=dev, dtype=torch.float32)
+            if N > 0:
+                _lib.check(lib.pf_predictor_embeds_slot(h, st["slot"], hid.data_ptr(), B, T, N, embeds.data_ptr(), stream_ptr()),
+                           "pf_predictor_embeds_slot")
+        # the counts stay on the HOST here (a device tensor would cost a pageable H2D copy ordered behind everything already queued
+        # on the stream -- the next batch's encoder -- which is the wait these halves exist to avoid)
+        token_num_t = torch.tensor(token_num, dtype=torch.float32)
+        alphas, peaks = st["alphas"], st["peaks"]
+        if self.tail_threshold <= 0.0:
+            alphas, peaks = alphas[:, :T], peaks[:, :T]
+        return embeds, token_num_t, alphas, peaks
+
 
 @tables.register("predictor_classes", "CifPredictorV3")
 class CifPredictorV3(CifPredictorV2):

@@ -399,8 +399,8 @@ int predictor_alphas_enqueue(Predictor* p, int slot, const float* hidden, const 
     sa.fire_flag = S.flags.as<int>(); sa.n_fires = S.nfires.as<int>(); sa.lens = S.lens.as<int>(); sa.B = B;
     sa.T = T; sa.tail_threshold = c.tail_threshold; sa.tail_mask = c.tail_mask;
     if (p->v3) {
-        if (p->curs.ensure(sizeof(float) * (size_t)B * Te) || p->ntok.ensure(sizeof(int) * (size_t)B)) return -2;
-        if ((rc = launch_cif_scan_loop(sa, p->curs.as<float>(), p->ntok.as<int>(), s))) return rc;
+        if (S.curs.ensure(sizeof(float) * (size_t)B * Te) || S.ntok.ensure(sizeof(int) * (size_t)B)) return -2;
+        if ((rc = launch_cif_scan_loop(sa, S.curs.as<float>(), S.ntok.as<int>(), s))) return rc;
     } else if ((rc = launch_cif_scan(sa, s))) {
         return rc;
     }
@@ -409,7 +409,7 @@ int predictor_alphas_enqueue(Predictor* p, int slot, const float* hidden, const 
 }
 // V3 reports floor(sum alphas) (cif_predictor.py:383), V2's count of fires is the same number by construction
 const int32_t* predictor_counts_dev(Predictor* p, int slot) {
-    return reinterpret_cast<const int32_t*>(p->v3 ? p->ntok.p : p->st[slot].nfires.p);
+    return reinterpret_cast<const int32_t*>(p->v3 ? p->st[slot].ntok.p : p->st[slot].nfires.p);
 }
 const float* predictor_alphas_dev(Predictor* p, int slot) { return p->st[slot].alphas.as<float>(); }
 const float* predictor_peaks_dev(Predictor* p, int slot) { return p->st[slot].peaks.as<float>(); }
@@ -422,7 +422,7 @@ int predictor_embeds_slot(Predictor* p, int slot, const float* hidden, int B, in
     ea.fire_flag = S.flags.as<int>(); ea.embeds = embeds; ea.B = B; ea.T = T; ea.D = p->cfg.d_model; ea.N = N;
     if (p->v3) {
         if (N <= 0) return 0;
-        ea.alphas = p->curs.as<float>();
+        ea.alphas = S.curs.as<float>();
         return launch_cif_emit_loop(ea, s);
     }
     return launch_cif_emit(ea, s);
@@ -449,6 +449,26 @@ int pf_predictor_alphas(pf_predictor* ph, const float* hidden, const int32_t* le
 int pf_predictor_embeds(pf_predictor* ph, const float* hidden, int32_t B, int32_t T, int32_t N, float* embeds,
                         void* stream) {
     return predictor_embeds_slot(reinterpret_cast<Predictor*>(ph), 0, hidden, B, T, N, embeds, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The two steps without the synchronisation between them, for callers that keep two batches in flight (include/paraformer_hip.h)
+int pf_predictor_alphas_begin(pf_predictor* ph, int32_t slot, const float* hidden, const int32_t* lens_host, int32_t B, int32_t T,
+                              float* alphas, float* peaks, int32_t* counts_pinned_host, void* stream) {
+    Predictor* p = reinterpret_cast<Predictor*>(ph);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PF_REQUIRE(p && counts_pinned_host && (slot == 0 || slot == 1), "predictor_alphas_begin: null argument or slot not 0 / 1");
+    int rc;
+    if ((rc = predictor_alphas_enqueue(p, slot, hidden, lens_host, B, T, s))) return rc;
+    const size_t Te = (size_t)T + 1;
+    if (alphas) PF_HIP_TRY(hipMemcpyAsync(alphas, p->st[slot].alphas.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
+    if (peaks) PF_HIP_TRY(hipMemcpyAsync(peaks, p->st[slot].peaks.p, sizeof(float) * (size_t)B * Te, hipMemcpyDeviceToDevice, s));
+    PF_HIP_TRY(hipMemcpyAsync(counts_pinned_host, predictor_counts_dev(p, slot), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+int pf_predictor_embeds_slot(pf_predictor* ph, int32_t slot, const float* hidden, int32_t B, int32_t T, int32_t N, float* embeds,
+                             void* stream) {
+    return predictor_embeds_slot(reinterpret_cast<Predictor*>(ph), slot, hidden, B, T, N, embeds, reinterpret_cast<hipStream_t>(stream));
 }
 
 // one direction-pair of torch.nn.LSTM on a time-major input: gates-major input projections by the fp32 MFMA GEMM
@@ -490,7 +510,7 @@ int pf_predictor_timestamp(pf_predictor* ph, const float* hidden, const int32_t*
     const int D = c.d_model, U = p->c3.upsample_times, taps = c.l_order + c.r_order + 1, Tu = T * U;
     const size_t M = (size_t)B * T;
     int rc;
-    if ((rc = upload_lens(p->st[0].lens, lens_host, B, s))) return rc;
+    if ((rc = upload_lens(p->ts_lens, lens_host, B, s))) return rc;        // (its own buffer: both scan-state slots may be in flight)
     if (p->tok_dev.ensure(sizeof(int) * (size_t)B)) return -2;
     if (upload_h2d(p->tok_dev.p, token_num_host, sizeof(int32_t) * (size_t)B, s)) return -2;
     const float* src = hidden;
@@ -529,7 +549,7 @@ int pf_predictor_timestamp(pf_predictor* ph, const float* hidden, const int32_t*
                                p->cell, s))) return rc;
         UsAlphaArgs ua{};
         ua.out_t = p->lstm_out.as<float>(); ua.w = p->tt.get("cif_output2.weight"); ua.bias = p->tt.get("cif_output2.bias");
-        ua.lens = p->st[0].lens.as<int>(); ua.alphas = us_alphas; ua.B = B; ua.Bs = Bs; ua.T = Tu; ua.C = 2 * D; ua.U = U;
+        ua.lens = p->ts_lens.as<int>(); ua.alphas = us_alphas; ua.B = B; ua.Bs = Bs; ua.T = Tu; ua.C = 2 * D; ua.U = U;
         ua.smooth = p->c3.smooth_factor2; ua.noise = p->c3.noise_threshold2;
         if ((rc = launch_us_alpha_t(ua, s))) return rc;
     } else {

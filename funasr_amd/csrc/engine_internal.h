@@ -434,11 +434,12 @@ struct Predictor {
     // the scan state of one batch (what pf_predictor_embeds reads back). Two slots: the split-phase pipeline (engine_pipeline.hip)
     // runs batch i + 1's encoder + scan before batch i's decoder, so batch i's state must survive that; the module-level entry
     // points (pf_predictor_alphas / _embeds / _timestamp) use slot 0
-    struct CifState { DevBuf lens, alphas, peaks, rems, flags, nfires; int B = 0, T = 0; } st[2];
+    // (curs / ntok: V3's sequential scan -- per slot too since round 6: pf_predictor_alphas_begin keeps two batches in flight)
+    struct CifState { DevBuf lens, alphas, peaks, rems, flags, nfires, curs, ntok; int B = 0, T = 0; } st[2];
     // CifPredictorV3 (bicif_paraformer/cif_predictor.py:121-384): sequential fp32 CIF + the upsampled timestamp head
     bool v3 = false;
     pf_predictor_v3_config c3{};
-    DevBuf curs, ntok, up, x_tm, pre, lstm_out, h_a, h_b, cell, tok_dev, ulens, pack;
+    DevBuf up, x_tm, pre, lstm_out, h_a, h_b, cell, tok_dev, ulens, pack, ts_lens;
     bool packed = false;                 // pack = both directions' re-laid weight_hh, then bias_ih, bias_hh back to back
     std::vector<int32_t> ul_host;
 };

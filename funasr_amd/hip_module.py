@@ -144,10 +144,28 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def device_lens(vals, device, dtype=torch.int32) -> torch.Tensor:
+    """A lengths tensor on the device made WITHOUT waiting for the stream: `torch.tensor(list, device=cuda)` copies from pageable
+    memory and synchronises behind everything already enqueued -- the kernel launch this tensor usually follows -- which turns every
+    module's forward into a blocking call. Here: pinned staging, asynchronous copy, and the host values kept on the tensor
+    (`_pf_host`) so that `host_i32` hands them back without a D2H copy (which would synchronise again)."""
+    vals = [int(v) for v in vals]
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        t = torch.tensor(vals, dtype=dtype, device=dev)
+    else:
+        host = torch.empty(len(vals), dtype=dtype, pin_memory=True)
+        host.copy_(torch.tensor(vals, dtype=dtype))
+        t = host.to(dev, non_blocking=True)
+    t._pf_host = vals
+    return t
+
+
 def host_i32(x, n=None):
     """lengths -> (ctypes int32 array, python list). Accepts tensors (any device), lists, numpy."""
     if isinstance(x, torch.Tensor):
-        vals = [int(v) for v in x.detach().cpu().reshape(-1).tolist()]
+        known = getattr(x, "_pf_host", None)                         # device_lens: the values never left the host
+        vals = list(known) if known is not None and len(known) == x.numel() else [int(v) for v in x.detach().cpu().reshape(-1).tolist()]
     else:
         vals = [int(v) for v in list(x)]
     if n is not None and len(vals) != n:

@@ -324,11 +324,16 @@ class Paraformer(nn.Module):
         pending = dict(key=key, tokenizer=tokenizer, meta_data=meta_data, kwargs=kwargs, want_stamps=want_stamps)
         if self._one_call_ok() and not want_stamps:
             pending["ticket"] = self.begin_features(speech, speech_lengths)
+        elif type(self).enqueue_features is getattr(type(self), "_split_enqueue_features", None):
+            pending["half"] = self.enqueue_begin(speech, speech_lengths, want_stamps)        # (BiCif: the chain up to its host wait)
         else:
             pending["fin"] = self.enqueue_features(speech, speech_lengths, return_intermediate=want_stamps)
         return pending
 
     def inference_launch(self, pending: dict) -> None:
+        if "half" in pending:
+            pending["fin"] = self.enqueue_finish(pending.pop("half"))
+            return
         if "ticket" not in pending:
             return
         dev = pending["ticket"]["dev"]

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .hip_module import Holder, HipModule, ParamHolder, depthwise, host_i32, layer_norm, linear, stream_ptr
+from .hip_module import Holder, HipModule, ParamHolder, depthwise, device_lens, host_i32, layer_norm, linear, stream_ptr
 from .register import tables
 
 
@@ -118,7 +118,7 @@ class ParaformerSANMDecoder(HipModule):
                                               ids.data_ptr() if want_ids else None,
                                               hid.data_ptr() if want_hidden else None, stream_ptr()),
                        "pf_decoder_forward")
-        olens = torch.tensor(tlens, dtype=torch.int64, device=dev)
+        olens = device_lens(tlens, dev, torch.int64)
         return logits, ids, hid, olens
 
     def forward_asf6(self, hs_pad, hlens, ys_in_pad, ys_in_lens, n_blocks_before: int = 5) -> torch.Tensor:

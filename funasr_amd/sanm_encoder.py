@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .hip_module import Holder, HipModule, depthwise, host_i32, layer_norm, linear, stream_ptr
+from .hip_module import Holder, HipModule, depthwise, device_lens, host_i32, layer_norm, linear, stream_ptr
 from .register import tables
 
 
@@ -154,7 +154,7 @@ class _SANMEncoderBase(HipModule):
         with torch.cuda.device(dev):
             _lib.check(lib.pf_encoder_forward(h, xs.data_ptr(), lens_c, B, T, pe.data_ptr(), out.data_ptr(),
                                               run_blocks, stream_ptr()), "pf_encoder_forward")
-        olens = torch.tensor(lens, dtype=torch.int32, device=dev)
+        olens = device_lens(lens, dev)                               # (no synchronisation: hip_module.device_lens)
         return out, olens
 
 

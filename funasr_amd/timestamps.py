@@ -96,6 +96,11 @@ def cif_token_spans(us_alphas, us_peaks, char_list: Sequence[str], vad_offset: f
     peaks = us_peaks[0] if getattr(us_peaks, "ndim", 1) == 2 else us_peaks
     p = peaks.detach().cpu().numpy() if isinstance(peaks, torch.Tensor) else np.asarray(peaks)
     fires = np.nonzero(p >= np.float32(_FIRE))[0] + force_time_shift
+    if n_tok > 0 and len(fires) != n_tok + 1:
+        # the reference's repair (timestamp_tools.py:60-63): alphas rescaled to n_tok + 1 fires and integrated again, once
+        alphas = us_alphas[0] if getattr(us_alphas, "ndim", 1) == 2 else us_alphas
+        p = _refire(alphas if isinstance(alphas, torch.Tensor) else torch.as_tensor(np.asarray(alphas)), n_tok + 1).numpy()
+        fires = np.nonzero(p >= np.float32(_FIRE))[0] + force_time_shift
     if n_tok == 0 or len(fires) != n_tok + 1:
         return cif_timestamps(us_alphas, us_peaks, char_list, vad_offset, force_time_shift, True, upsample_rate)[1]
     frame_s = 10.0 * 6 / 1000 / upsample_rate

@@ -53,7 +53,7 @@ extern "C" {
  * (incl. pf_dp_broadcast_raw), pf_stream_step_begin / _end, pf_frontend_set_dither / _verify, pf_paraformer_forward, the
  * pf_k_* measurement entries. A library reporting 1 has none of them.
  * 3 (round 6): + pf_paraformer_begin / pf_paraformer_finish (the split-phase offline forward). */
-#define PF_ABI_VERSION 3
+#define PF_ABI_VERSION 4
 
 const char* pf_last_error(void);
 int pf_abi_version(void);
@@ -200,6 +200,17 @@ int pf_predictor_alphas(pf_predictor* p, const float* hidden_dev, const int32_t*
  * rows >= token_num[b] are zero. No sync. */
 int pf_predictor_embeds(pf_predictor* p, const float* hidden_dev, int32_t B, int32_t T, int32_t N,
                         float* embeds_dev, void* stream);
+/* The same two steps WITHOUT the synchronisation between them, for callers that keep two batches in flight (round 6; the
+ * module-level counterpart of pf_paraformer_begin / _finish, used by the classes whose chain is not the plain offline one --
+ * BiCifParaformer: funasr/models/bicif_paraformer/model.py:327-345 reads the counts between predictor and decoder).
+ * pf_predictor_alphas_begin: everything of step 1 ENQUEUED into scan state `slot` (0 or 1); the token counts are copied by the
+ * stream into counts_pinned_host (B int32 of PINNED host memory that stays alive until the caller has synchronised, e.g. on an
+ * event recorded behind this call). pf_predictor_embeds_slot: step 2 for that slot -- before the slot's next _begin.
+ * pf_predictor_alphas / _embeds are slot 0 of the same state. */
+int pf_predictor_alphas_begin(pf_predictor* p, int32_t slot, const float* hidden_dev, const int32_t* lens_host, int32_t B, int32_t T,
+                              float* alphas_dev, float* peaks_dev, int32_t* counts_pinned_host, void* stream);
+int pf_predictor_embeds_slot(pf_predictor* p, int32_t slot, const float* hidden_dev, int32_t B, int32_t T, int32_t N,
+                             float* embeds_dev, void* stream);
 
 /* CifPredictorV3 (funasr/models/bicif_paraformer/cif_predictor.py:121-384), the predictor of BiCifParaformer and
  * SeACo-Paraformer ("paraformer-zh"): the same first head as V2 but integrated by the sequential fp32 loop `cif`

@@ -129,6 +129,36 @@ def test_predictor_v3_on_the_gpu_equals_reference_golden(cuda):
 
 
 @pytest.mark.gpu
+def test_predictor_halves_with_two_batches_in_flight_are_bitwise_forward(cuda):
+    """pf_predictor_alphas_begin / pf_predictor_embeds_slot (CifPredictorV2.forward_begin / forward_finish, V3 through the same
+    entry points): begin(A), begin(B), finish(A), finish(B) -- both scan states alive at once -- give what forward(A), forward(B) give"""
+    from funasr_amd.cif_predictor import CifPredictorV2, CifPredictorV3
+    from oracle import bicif_oracle as BO
+    g = _gold()
+    name = json.loads(str(g["variants"]))[0]
+    cfg = json.loads(str(g[f"{name}_cfg"]))
+    sd = BO.predictor_v3_state_dict(cfg, seed=int(g[f"{name}_seed"]), cif_bias=-0.6)
+    v3 = CifPredictorV3(**cfg)
+    v3.load_state_dict(sd, strict=True)
+    v2 = CifPredictorV2(idim=cfg["idim"], l_order=cfg["l_order"], r_order=cfg["r_order"], threshold=cfg.get("threshold", 1.0),
+                        tail_threshold=cfg.get("tail_threshold", 0.0))
+    v2.load_state_dict({k: v for k, v in sd.items() if k.startswith(("cif_conv1d", "cif_output."))}, strict=True)
+    hidden, lens = _t(g, f"{name}_hidden").to(cuda), _t(g, f"{name}_lens")
+    A = (hidden, lens)
+    Bh = torch.cat([hidden.flip(0) * 1.25, hidden[:1]], 0)[:, : hidden.shape[1] - 2].contiguous()
+    Bb = (Bh, [max(1, min(int(n), Bh.shape[1])) for n in list(lens.flip(0).tolist()) + [int(lens[0])]])
+    for pred in (v2.to(cuda), v3.to(cuda)):
+        want = [pred(h, lengths=n)[:4] for h, n in (A, Bb)]
+        for rounds in range(2):                                      # twice: the slots alternate, buffers are reused
+            sa, sb = pred.forward_begin(*A), pred.forward_begin(*Bb)
+            got = [pred.forward_finish(sa), pred.forward_finish(sb)]
+            for w, o in zip(want, got):
+                assert w[1].tolist() == o[1].tolist() and o[1].device.type == "cpu"
+                for x, y in ((w[0], o[0]), (w[2], o[2]), (w[3], o[3])):
+                    assert torch.equal(x, y), type(pred).__name__
+
+
+@pytest.mark.gpu
 def test_bicif_paraformer_text_and_timestamps_equal_reference_inference(cuda):
     """the HIP BiCifParaformer on the features the reference model decoded (oracle/make_golden_bicif.py): same text, same
     token timestamps, in fp32 and in the bf16x3 mode; a single utterance decodes like its row of the batch"""
@@ -147,6 +177,14 @@ def test_bicif_paraformer_text_and_timestamps_equal_reference_inference(cuda):
         res, _ = model.inference(feats, data_lengths=lens, key=[w["key"] for w in want], tokenizer=tok, data_type="fbank")
         for r, w in zip(res, want):
             assert r["key"] == w["key"] and r["text"] == w["text"] and r["timestamp"] == w["timestamp"], (mode, r, w)
+    # the chain's halves interleaved across two batches (what AutoModel.inference does with them) == one batch after the other
+    model.set_precision("f16x2")
+    fa, la, fb, lb = feats, lens, feats[:2].flip(0).contiguous(), lens[:2].flip(0)
+    seq = [model.collect(model.enqueue_features(fa, la)), model.collect(model.enqueue_features(fb, lb))]
+    ha, hb = model.enqueue_begin(fa, la), model.enqueue_begin(fb, lb)
+    pa, pb = model.enqueue_finish(ha), model.enqueue_finish(hb)
+    for w, o in zip(seq, (model.collect(pa), model.collect(pb))):
+        assert w["ids"] == o["ids"] and torch.equal(w["us_alphas"], o["us_alphas"]) and torch.equal(w["us_peaks"], o["us_peaks"])
     model.set_precision("fp32")
     one, _ = model.inference(feats[:1], data_lengths=lens[:1], key=["utt0"], tokenizer=tok, data_type="fbank")
     assert one[0]["text"] == want[0]["text"] and one[0]["timestamp"] == want[0]["timestamp"]

@@ -23,11 +23,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def model_dir(path, cfg):
+def model_dir(path, cfg, model="Paraformer"):
     ec, dc, pc = cfg["encoder"], cfg["decoder"], cfg["predictor"]
     vocab = ["<blank>", "<s>", "</s>"] + [chr(0x4E00 + i) for i in range(dc["vocab_size"] - 4)] + ["<unk>"]
     conf = {
-        "model": "Paraformer",
+        "model": model,
         "model_conf": {"ctc_weight": 0.0, "predictor_weight": 1.0, "predictor_bias": 1},
         "encoder": "SANMEncoder",
         "encoder_conf": {"output_size": ec["output_size"], "attention_heads": ec["attention_heads"], "linear_units": ec["linear_units"],
@@ -37,8 +37,9 @@ def model_dir(path, cfg):
         "decoder": "ParaformerSANMDecoder",
         "decoder_conf": {"attention_heads": dc["attention_heads"], "linear_units": dc["linear_units"], "num_blocks": dc["num_blocks"],
                          "att_layer_num": dc["att_layer_num"], "kernel_size": dc["kernel_size"], "sanm_shfit": dc["sanm_shfit"]},
-        "predictor": "CifPredictorV2",
-        "predictor_conf": {"idim": pc["idim"], "threshold": 1.0, "l_order": 1, "r_order": 1, "tail_threshold": 0.45},
+        "predictor": "CifPredictorV2" if model == "Paraformer" else "CifPredictorV3",
+        "predictor_conf": dict({"idim": pc["idim"], "threshold": 1.0, "l_order": 1, "r_order": 1, "tail_threshold": 0.45},
+                               **({} if model == "Paraformer" else {"upsample_times": 3, "use_cif1_cnn": False, "upsample_type": "cnn_blstm"})),
         "frontend": "WavFrontend",
         "frontend_conf": {"fs": 16000, "window": "hamming", "n_mels": 80, "frame_length": 25, "frame_shift": 10, "lfr_m": 7, "lfr_n": 6},
         "tokenizer": "CharTokenizer",
@@ -58,6 +59,8 @@ def main():
     ap.add_argument("--batch-size", type=int, default=64, help="clips per batch (AutoModel batch_size)")
     ap.add_argument("--dir", default=None)
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--model", default="Paraformer", choices=["Paraformer", "BiCifParaformer"], help="BiCifParaformer: text + token timestamps "
+                    "on every call (the model behind the paraformer-zh alias), CifPredictorV3 with random timestamp-head weights")
     ap.add_argument("--profile", action="store_true", help="cProfile of one overlapped pass (top functions by own time) to stderr")
     args = ap.parse_args()
 
@@ -70,7 +73,7 @@ def main():
     work = args.dir or tempfile.mkdtemp(prefix="pf_generate_")
     mdir = os.path.join(work, "model")
     cfg = synth.PARAFORMER_LARGE
-    model_dir(mdir, cfg)
+    model_dir(mdir, cfg, args.model)
     durs = durations(args.clips)
     pool = [synth.speech_like(int(14.7 * 16000) + 1, seed=1000 + i) for i in range(16)]
     paths = []
@@ -87,11 +90,17 @@ def main():
     print(f"[generate] {args.clips} wav files, {total_s / 3600:.2f} h, written in {time.perf_counter() - t0:.1f} s under {work}", file=sys.stderr)
 
     am = AutoModel(model=mdir, device="cuda:0", batch_size=args.batch_size, disable_pbar=True)
-    am.model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
+    missing, _ = am.model.load_state_dict(synth.paraformer_state_dict(cfg, seed=0, cif_bias=synth.BENCH_CIF_BIAS), strict=False)
+    if args.model != "Paraformer":
+        g = torch.Generator().manual_seed(5)
+        sd = am.model.state_dict()
+        for k in missing:
+            if k.startswith("predictor."):
+                sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.05)
     am.model.to("cuda:0")
     am.generate(input=paths[: 2 * args.batch_size])                  # warm-up: buffers at their final size, files in the page cache
     am.generate(input=paths[-2 * args.batch_size:], pipeline=False)
-    out = {"metric": "AutoModel.generate over wav files, audio-seconds/s (Paraformer-large, f16x2)", "clips": args.clips,
+    out = {"metric": f"AutoModel.generate over wav files, audio-seconds/s ({args.model}-large, f16x2)", "clips": args.clips,
            "audio_hours": round(total_s / 3600, 2), "batch_size": args.batch_size, "runs": []}
     ref = None
     for r in range(args.repeats):
