@@ -21,21 +21,51 @@ import numpy as np
 import torch
 
 
+def _decode_wav_fast(path: str):
+    """The canonical RIFF layout -- 'RIFF' size 'WAVE' 'fmt ' 16 <PCM, channels, rate, ..., bits> 'data' size samples, 44 header
+    bytes -- read with one file read and no chunk walking (a corpus of short clips spends as long in the stdlib's chunk parser as
+    in reading the samples). -> (raw bytes, rate, channels, sample width) or None for anything else (`wave` then decides)."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 44 or data[:4] != b"RIFF" or data[8:16] != b"WAVEfmt " or data[36:40] != b"data":
+        return None
+    fmt_size, tag, ch, fs, _, align, bits = struct.unpack_from("<IHHIIHH", data, 16)
+    n = struct.unpack_from("<I", data, 40)[0]
+    if fmt_size != 16 or tag != 1 or ch < 1 or bits not in (8, 16, 32) or align != ch * bits // 8:
+        return None
+    n = min(n, len(data) - 44) // align * align                      # like wave.readframes: whole frames that are really there
+    return data[44: 44 + n], fs, ch, bits // 8
+
+
 def _decode_wav(src) -> tuple[torch.Tensor, int]:
+    fast = _decode_wav_fast(src) if isinstance(src, str) else None
+    if fast is not None:
+        raw, fs, ch, width = fast
+        return _pcm_to_float(raw, ch, width), fs
     with wave.open(src, "rb") as f:
         fs, ch, width, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
         raw = f.readframes(n)
+    return _pcm_to_float(raw, ch, width), fs
+
+
+def _pcm_to_float(raw: bytes, ch: int, width: int) -> torch.Tensor:
+    # (scaled in place by the power of two: bit for bit the division, one pass and one allocation less per clip)
     if width == 2:
-        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32)
+        x *= np.float32(2.0 ** -15)
     elif width == 4:
-        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32)
+        x *= np.float32(2.0 ** -31)
     elif width == 1:
-        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        x = np.frombuffer(raw, dtype=np.uint8).astype(np.float32)
+        x -= np.float32(128.0)
+        x *= np.float32(2.0 ** -7)
     else:
         raise ValueError(f"unsupported PCM sample width {width}")
     if ch > 1:
         x = x.reshape(-1, ch).mean(axis=1)      # reduce_channels (load_utils.py:126-127)
-    return torch.from_numpy(np.ascontiguousarray(x)), fs
+    return torch.from_numpy(x if x.flags.c_contiguous else np.ascontiguousarray(x))
 
 
 # ------------------------------------------------------------------------------------------- container sniffing

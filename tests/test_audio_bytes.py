@@ -94,3 +94,58 @@ def test_int16_arrays_are_scaled_before_resampling_and_channels_are_averaged():
     import pytest
     with pytest.raises(ValueError):
         load_audio(np.zeros((100, 100), np.float32))
+
+
+def test_canonical_wav_fast_reader_equals_the_wave_module(tmp_path):
+    """funasr_amd/audio.py _decode_wav_fast (one read, no chunk walking) against the stdlib path it short-cuts: mono / stereo,
+    8 / 16 / 32 bit, a data chunk that announces more than the file holds, and the layouts it must hand back to `wave`"""
+    import struct
+    import wave
+
+    import numpy as np
+    import torch
+
+    from funasr_amd import audio
+
+    def via_wave(path):
+        with wave.open(path, "rb") as f:
+            return audio._pcm_to_float(f.readframes(f.getnframes()), f.getnchannels(), f.getsampwidth()), f.getframerate()
+
+    rng = np.random.default_rng(3)
+    k = 0
+    for ch in (1, 2):
+        for width, dtype in ((1, np.uint8), (2, "<i2"), (4, "<i4")):
+            for n in (0, 1, 1601):
+                p = str(tmp_path / f"a{k}.wav")
+                k += 1
+                info = np.iinfo(dtype)
+                pcm = rng.integers(info.min, info.max, size=n * ch, endpoint=True).astype(dtype)
+                with wave.open(p, "wb") as f:
+                    f.setnchannels(ch)
+                    f.setsampwidth(width)
+                    f.setframerate(8000 if n == 1 else 16000)
+                    f.writeframes(pcm.tobytes())
+                assert audio._decode_wav_fast(p) is not None
+                x, fs = audio._decode_wav(p)
+                y, fs2 = via_wave(p)
+                assert fs == fs2 and x.dtype == torch.float32 and torch.equal(x, y), (ch, width, n)
+    # truncated file: the data chunk announces 4000 bytes, 1001 are there -> whole frames only, like wave.readframes
+    p = str(tmp_path / "cut.wav")
+    body = rng.integers(-3000, 3000, size=2000).astype("<i2").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + 4000) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"data" + struct.pack("<I", 4000)
+    open(p, "wb").write(hdr + body[:1001])
+    assert audio._decode_wav(p)[0].numel() == 500
+    # a LIST chunk before the data, a 24-bit file, an extensible fmt chunk: not the canonical layout -> the stdlib decides
+    p2 = str(tmp_path / "list.wav")
+    open(p2, "wb").write(b"RIFF" + struct.pack("<I", 36 + 12 + 8 + 200) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+                         + b"LIST" + struct.pack("<I", 4) + b"INFO" + b"data" + struct.pack("<I", 200) + body[:200])
+    assert audio._decode_wav_fast(p2) is None
+    x, fs = audio._decode_wav(p2)
+    assert fs == 16000 and x.numel() == 100 and torch.equal(x, torch.from_numpy(np.frombuffer(body[:200], dtype="<i2").astype(np.float32) / 32768.0))
+    p3 = str(tmp_path / "w24.wav")
+    with wave.open(p3, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(3)
+        f.setframerate(16000)
+        f.writeframes(b"\x00" * 30)
+    assert audio._decode_wav_fast(p3) is None
