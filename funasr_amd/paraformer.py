@@ -216,8 +216,22 @@ class Paraformer(nn.Module):
         loop enqueues batch i+1 before collecting batch i, so the GPU never waits for the host-side post-processing."""
         if not return_intermediate and self._one_call_ok():
             return self.finish_features(self.begin_features(speech, speech_lengths))
+        return self.enqueue_finish(self.enqueue_begin(speech, speech_lengths, return_intermediate))
+
+    # The module-by-module chain in two halves around its one host wait (the CIF token counts size the decoder, like the .item() at
+    # cif_predictor.py:311): `enqueue_begin` puts encoder + predictor and the counts' D2H copy on the stream and returns at once
+    # (pf_predictor_alphas_begin), `enqueue_finish` waits for the counts and enqueues the rest. A loop over batches calls
+    # begin(i + 1) before finish(i) (AutoModel.inference through inference_begin / inference_launch). Subclasses that change the
+    # chain override `enqueue_features` (and are then driven in two parts) or the halves themselves (BiCifParaformer).
+    def enqueue_begin(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False) -> dict:
         enc, olens = self.encode(speech, speech_lengths, all_rows=return_intermediate)
-        embeds, token_num, alphas, peaks = self.calc_predictor(enc, olens)
+        if not hasattr(self.predictor, "forward_begin") or type(self).calc_predictor is not Paraformer.calc_predictor:
+            return dict(enc=enc, olens=olens, want=return_intermediate, done=self.calc_predictor(enc, olens))   # (another predictor: its own wait)
+        return dict(enc=enc, olens=olens, want=return_intermediate, pred=self.predictor.forward_begin(enc, olens))
+
+    def enqueue_finish(self, half: dict) -> dict:
+        enc, olens = half["enc"], half["olens"]
+        embeds, token_num, alphas, peaks = half["done"] if "done" in half else self.predictor.forward_finish(half["pred"])
         tok = [int(round(v)) for v in token_num.tolist()]           # pre_token_length.round().long(), model.py:614
         ids = None
         if max(tok) >= 1:                                            # model.py:615-616
@@ -226,9 +240,14 @@ class Paraformer(nn.Module):
         if ids is not None:
             # the batch's single D2H copy goes on the stream now: collect() then waits for THIS batch only
             pending["ids_host"] = (ids, self.__dict__.setdefault("_host_ring", HostCopyRing()).start(ids))
-        if return_intermediate:
+        if half["want"]:
             pending["extra"] = dict(enc=enc, olens=olens, embeds=embeds, alphas=alphas, peaks=peaks)
+            if ids is not None:                                      # what the token timestamps read on the host (_token_timestamps)
+                ring = self.__dict__.setdefault("_host_ring", HostCopyRing())
+                pending["stamps_host"] = (ring.start(peaks.contiguous()), ring.start(alphas.contiguous()))
         return pending
+
+    _split_enqueue_features = enqueue_features      # inference_begin uses the halves only while no subclass overrides the chain
 
     def collect(self, pending: dict) -> dict:
         tok, B = pending["tok"], pending["B"]
@@ -241,6 +260,8 @@ class Paraformer(nn.Module):
         drop = (self.sos, self.eos, self.blank_id)
         out = dict(token_num=tok, raw_ids=raw, ids=[[t for t in r if t not in drop] for r in raw])
         out.update(pending.get("extra", {}))
+        if "stamps_host" in pending:
+            out["peaks_host"], out["alphas_host"] = (HostCopyRing.wait(h).clone() for h in pending["stamps_host"])
         return out
 
     def recognize_features(self, speech: torch.Tensor, speech_lengths, return_intermediate: bool = False):
@@ -325,7 +346,7 @@ class Paraformer(nn.Module):
         if self._one_call_ok() and not want_stamps:
             pending["ticket"] = self.begin_features(speech, speech_lengths)
         elif type(self).enqueue_features is getattr(type(self), "_split_enqueue_features", None):
-            pending["half"] = self.enqueue_begin(speech, speech_lengths, want_stamps)        # (BiCif: the chain up to its host wait)
+            pending["half"] = self.enqueue_begin(speech, speech_lengths, want_stamps)        # the chain up to its host wait
         else:
             pending["fin"] = self.enqueue_features(speech, speech_lengths, return_intermediate=want_stamps)
         return pending
