@@ -88,12 +88,52 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) coff[st] = ((2 * st + hh) ^ f) * 16;
 
+#if defined(PF_MEASUREMENT_KERNELS)
+    const int nk = (p.a_nt & 128) ? 0 : p.K / RW_KS;                      // bit 7: no K loop (the epilogue alone)
+#else
     const int nk = p.K / RW_KS;
+#endif
+    // MEASURED AND OFF (round 6, review item 3; profiles/r06aa_row_prefetch_ab.txt: 113 -> 121 (either half) / 128 us (both)):
+    // epilogue operands pulled towards the chip DURING the K loop (a_nt bits 2 / 3; FSMN form): the loop reads 1 MB of A / W per stage
+    // from L2 and leaves HBM idle, the epilogue then asks for 544 KB of fp32 rows per workgroup -- the residual rows and the v rows
+    // with their halo -- all at once, on every CU at the same moment. One dword load per cache line (128 B), spread over the first
+    // nk - 1 stages, result unused: the line lands in L2 / the 256-MB memory-side cache and the epilogue's float4 loads find it
+    // there. Pure data movement: the bits of the result cannot change. (`pf_sink` stays live until the wait behind the load.)
+    constexpr int PF_R2_LINES = RW_BM * 16, PF_V_LINES = (RW_BM + RW_FS_KS - 1) * 16;      // 2-KB rows = 16 lines
+#if defined(PF_MEASUREMENT_KERNELS)
+    const bool pf_on = (MODE & 4) && (p.a_nt & 12) && nk > 1;            // bit 2: the residual rows, bit 3: the v rows
+#else
+    constexpr bool pf_on = false;                                        // measured and off (profiles/r06aa): the product has no such loads
+#endif
+    const int pf_first = (p.a_nt & 4) ? 0 : PF_R2_LINES, pf_last = (p.a_nt & 8) ? PF_R2_LINES + PF_V_LINES : PF_R2_LINES;
+    const int pf_per_stage = pf_on ? (pf_last - pf_first + nk - 2) / (nk - 1) : 0;
+    unsigned pf_sink = 0;
+    if (nk > 0) {
 #pragma unroll
-    for (int i = 0; i < RW_PPW; ++i) piece(i, 0, 0);
+        for (int i = 0; i < RW_PPW; ++i) piece(i, 0, 0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         glds_wait_all();
+        asm volatile("" : : "v"(pf_sink));
         __syncthreads();
+        if (pf_on && kt + 1 < nk) {
+            for (int l = tid; l < pf_per_stage; l += 512) {
+                const int idx = pf_first + kt * pf_per_stage + l;
+                const float* src_line = nullptr;
+                if (idx >= pf_last) {
+                } else if (idx < PF_R2_LINES) {
+                    int row = m0 + (idx >> 4);
+                    row = row < p.M ? row : p.M - 1;
+                    src_line = p.R2 + (size_t)row * p.ldr2 + (idx & 15) * 32;
+                } else if (idx < PF_R2_LINES + PF_V_LINES) {
+                    const int j = idx - PF_R2_LINES;
+                    int row = m0 - RW_FS_LP + (j >> 4);
+                    row = row < 0 ? 0 : (row < p.M ? row : p.M - 1);
+                    src_line = p.fs_v + (size_t)row * p.ldfv + (j & 15) * 32;
+                }
+                if (src_line) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(src_line) : "memory");
+            }
+        }
         const bool nxt = kt + 1 < nk;
         const int nb = (kt + 1) & 1;
         const unsigned char* sb = smem + (kt & 1) * RW_STAGE_B;
@@ -136,6 +176,23 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
 #undef RW_PROD
 #undef RW_LOAD
 #undef RW_PIECE
+    }
+#if defined(PF_MEASUREMENT_KERNELS)
+    if (p.a_nt & 256) {                                    // bit 8: the K loop alone (one store so that the accumulators stay live)
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][jj][r];
+        if (sacc == 12345.678f && p.C) p.C[tid] = sacc;
+        return;
+    }
+#endif
+    if (pf_on) {                                           // (nothing of the asm-issued loads is in flight when compiler-counted loads start)
+        glds_wait_all();
+        asm volatile("" : : "v"(pf_sink));
     }
 
     gemm2_row_epilogue<MODE, LN, 512, WM, 0>(p, acc, smem, m0, tid, wave, wr, wc, lane, true);
@@ -190,6 +247,16 @@ int launch_gemm_f16x2_row(const GemmRowArgs& a, hipStream_t stream) {
     // block height by the time the block count costs in WHOLE rounds over the CUs (one block per CU): 22 528 rows are 176
     // blocks of 128 rows = one round with 80 CUs idle, or 235 blocks of 96 rows = one round of 0.78 the time
     // (tools/bench_r03.py `row8`). Both kernels give the same bits, so the choice may depend on the batch's row count.
+#if defined(PF_MEASUREMENT_KERNELS)
+    static const int env_prefetch = [] { const char* e = getenv("PF_ROW_PREFETCH"); return e ? atoi(e) : -1; }();
+    // A/B switches: PF_ROW_PREFETCH 1 both / 2 residual / 3 v rows; + 16 / 32 / 64 / 128: the epilogue's ablation bits as they are
+    const int env_bits = (env_prefetch & ~3) | ((env_prefetch & 3) == 1 ? 12 : (env_prefetch & 3) == 2 ? 4 : (env_prefetch & 3) == 3 ? 8 : 0);
+    if (env_prefetch >= 0 && a.fs_v && a.R2 && (a.a_nt & ~3) != env_bits) {
+        GemmRowArgs b = a;
+        b.a_nt = (a.a_nt & 3) | env_bits;
+        return launch_gemm_f16x2_row(b, stream);
+    }
+#endif
     int bm = a.block_rows;
     if (bm == 0) {
         const int n_cu = device_cu_count();

@@ -32,6 +32,13 @@ __device__ __forceinline__ void gemm2_row_epilogue(const GemmRowArgs& p, floatx1
     constexpr int WM = 2, WN = 4;
     const int hh = lane >> 5, idx = lane & 31;
     floatx16 (&acc_)[AM][4] = accf;
+    // measurement switches of the FSMN form (a_nt bits 4..6, measurement library only; profiles/r06ab): 16 no v-row loads, 32 no
+    // residual loads, 64 no global stores -- the results are then wrong by construction
+#if defined(PF_MEASUREMENT_KERNELS)
+    const int abl = p.a_nt;
+#else
+    constexpr int abl = 0;
+#endif
 #define acc(i, jj) acc_[I0 + (i)][jj]
     // ---- epilogue, part 1: accumulators (C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) +
     //      4 (lane >> 5)) -> wave-private slab -> float4 pieces of rows: half-wave h takes rows 16 h .. 16 h + 15 of the
@@ -78,7 +85,8 @@ __device__ __forceinline__ void gemm2_row_epilogue(const GemmRowArgs& p, floatx1
             auto load_row = [&](int k) {
                 const int vr = row0 - RW_FS_LP + k;
                 const bool ok = vr >= lo && vr < hi;
-                const float4 t = *reinterpret_cast<const float4*>(p.fs_v + (size_t)(ok ? vr : (lo < hi ? lo : 0)) * p.ldfv + col);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(abl & 16)) t = *reinterpret_cast<const float4*>(p.fs_v + (size_t)(ok ? vr : (lo < hi ? lo : 0)) * p.ldfv + col);
                 win[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             };
 #pragma unroll
@@ -92,7 +100,8 @@ __device__ __forceinline__ void gemm2_row_epilogue(const GemmRowArgs& p, floatx1
                     fa[t] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if constexpr (HAS_R2) {
                         const int row = row0 + h4 * 4 + t;
-                        r2[t] = *reinterpret_cast<const float4*>(p.R2 + (size_t)(row < p.M ? row : p.M - 1) * p.ldr2 + col);
+                        r2[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (!(abl & 32)) r2[t] = *reinterpret_cast<const float4*>(p.R2 + (size_t)(row < p.M ? row : p.M - 1) * p.ldr2 + col);
                     }
                 }
 #pragma unroll
@@ -122,7 +131,7 @@ __device__ __forceinline__ void gemm2_row_epilogue(const GemmRowArgs& p, floatx1
                     if constexpr (HAS_R2) { o[0] = r2[t].x + o[0]; o[1] = r2[t].y + o[1]; o[2] = r2[t].z + o[2]; o[3] = r2[t].w + o[3]; }
                     const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
                     ov[i][h4 * 4 + t] = o4;
-                    if (p.C && row < p.M) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = o4;
+                    if (p.C && row < p.M && !(abl & 64)) *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + col) = o4;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -209,7 +218,7 @@ __device__ __forceinline__ void gemm2_row_epilogue(const GemmRowArgs& p, floatx1
         for (int it = 0; it < 16; ++it) {
             const int rl = lrow0 + 32 * i + it;
             const int row = m0 + rl;
-            if (row >= p.M) continue;
+            if (row >= p.M || (abl & 64)) continue;
             const float4 y = ln_apply4(ov[i][it], ST[rl], ST[RW_BM + rl], g4, b4);
             if (p.Y2) {
                 const float yv[4] = {y.x, y.y, y.z, y.w};
