@@ -137,7 +137,16 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x2_row_kernel(GemmRowArgs p) {
         const bool nxt = kt + 1 < nk;
         const int nb = (kt + 1) & 1;
         const unsigned char* sb = smem + (kt & 1) * RW_STAGE_B;
-#define RW_PIECE(I) do { if (nxt) piece(I, nb, kt + 1); } while (0)
+#if defined(PF_MEASUREMENT_KERNELS)
+        const bool early = (p.a_nt & 512) != 0;            // bit 9: the next stage's pieces all at the top of the stage (A/B, r06ac)
+        if (early && nxt) {
+#pragma unroll
+            for (int i = 0; i < RW_PPW; ++i) piece(i, nb, kt + 1);
+        }
+#else
+        constexpr bool early = false;
+#endif
+#define RW_PIECE(I) do { if (nxt && !early) piece(I, nb, kt + 1); } while (0)
 #define RW_PROD(AF, BF, PA, PB)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < WM; ++i) _Pragma("unroll") for (int jj = 0; jj < WN; ++jj)                  \
         acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i][PA], BF[jj][PB], acc[i][jj], 0, 0, 0)

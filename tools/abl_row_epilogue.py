@@ -16,6 +16,7 @@ SETTINGS = [(0, "the kernel"), (16, "no v-row loads"), (32, "no residual loads")
             (128 + 64, "no K loop, no stores (epilogue's reads alone)"), (128 + 48, "no K loop, no epilogue loads (epilogue's stores alone)"),
             (128 + 112, "no K loop, no epilogue loads, no stores (the epilogue's on-chip work alone: slab, taps, statistics)"),
             (256, "K loop alone (no epilogue)"),
+            (512, "the kernel, next stage's DMA pieces all at the top of the stage"), (512 + 256, "K loop alone, pieces at the top of the stage"),
             (1, "prefetch residual + v rows"), (2, "prefetch residual rows"), (3, "prefetch v rows")]
 
 
