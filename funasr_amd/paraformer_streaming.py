@@ -309,6 +309,11 @@ class ParaformerStreaming(Paraformer):
         ids = [t for t in raw if t not in (self.sos, self.eos, self.blank_id)]
         return tokenizer.ids2tokens(ids) if tokenizer is not None else ids
 
+    def inference_begin(self, *args, **kwargs):
+        """the streaming model decodes chunk by chunk against a session cache: its calls cannot be taken apart and overlapped like
+        the offline model's (Paraformer.inference_begin) -- AutoModel.inference then runs the plain loop"""
+        return None
+
     def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, cache: dict = None,
                   **kwargs):
         if kwargs.get("decoding_ctc_weight", 0.0) > 1e-5 or (kwargs.get("lm_weight", 0.0) > 1e-5 and kwargs.get("lm_file")):
