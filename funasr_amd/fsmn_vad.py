@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .audio import load_audio_list
-from .hip_module import Holder, HipModule, ParamHolder, linear, stream_ptr
+from .hip_module import Holder, HipModule, HostCopyRing, ParamHolder, StagedUpload, linear, stream_ptr
 from .register import tables
 from .vad_decision import IN_SPEECH, NativeVadDecision, VadOptions
 
@@ -172,6 +172,34 @@ class FsmnVADStreaming(torch.nn.Module):
         db = frame_decibel(w, T, int(o.frame_length_ms * o.sample_rate / 1000), int(o.frame_in_ms * o.sample_rate / 1000))
         return p_sil.cpu().numpy(), db.cpu().numpy()
 
+    def _scores_enqueue(self, frontend, wav: torch.Tensor):
+        """`_scores` without its wait: upload (pinned, on the upload stream), features, network and frame energies ENQUEUED, the two
+        score vectors on their way to pinned host memory -> handles for `_scores_wait`, or None for a recording without a frame"""
+        dev = next(self.encoder.parameters()).device
+        if wav.device.type == "cpu":
+            w = self.__dict__.setdefault("_upload", StagedUpload())([wav], dev)[0][0]
+        else:
+            w = wav.to(dev)
+        if hasattr(frontend, "init_cache"):
+            feats, flens = frontend(w[None], [int(w.numel())], cache={}, is_final=True)
+        else:
+            feats, flens = frontend(w[None], [int(w.numel())])
+        T = int(flens[0]) if feats.numel() else 0
+        if T <= 0:
+            return None
+        p_sil = self.encoder.silence_posterior(feats[:, :T], None, self.vad_opts.sil_pdf_ids)[0]
+        o = self.vad_opts
+        db = frame_decibel(w, T, int(o.frame_length_ms * o.sample_rate / 1000), int(o.frame_in_ms * o.sample_rate / 1000))
+        ring = self.__dict__.setdefault("_host_ring", HostCopyRing())
+        return ring.start(p_sil.contiguous()), ring.start(db.contiguous())
+
+    @staticmethod
+    def _scores_wait(handles):
+        import numpy as np
+        if handles is None:
+            return np.zeros(0, np.float32), np.zeros(0, np.float32)
+        return tuple(np.array(HostCopyRing.wait(h).numpy(), copy=True) for h in handles)
+
     def inference(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, cache: dict = None,
                   **kwargs):
         if frontend is None:
@@ -203,6 +231,40 @@ class FsmnVADStreaming(torch.nn.Module):
         t2 = time.perf_counter()
         p_sil, db = self._scores(frontend, wav, None)
         meta["extract_feat"] = f"{time.perf_counter() - t2:0.3f}"
+        return self._decide(p_sil, db, int(wav.numel()), k0, frontend, cache, chunk_ms, meta, kwargs)
+
+    # ---- the whole-recording call in two parts for AutoModel.inference's loop over recordings (paraformer.py inference_begin): the
+    #      scores of recording i + 1 are enqueued before those of recording i are read and cut into segments on the host
+    def inference_begin(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, cache: dict = None, **kwargs):
+        if (cache or frontend is None or frontend.lfr_n != 1 or not torch.cuda.is_available()
+                or next(self.encoder.parameters()).device.type != "cuda"):
+            return None
+        chunk_ms = kwargs.get("chunk_size", 60000)
+        streaming_input = kwargs.get("is_streaming_input", False) if chunk_ms >= 15000 else kwargs.get("is_streaming_input", True)
+        is_final = kwargs.get("is_final", False) if streaming_input else kwargs.get("is_final", True)
+        t1 = time.perf_counter()
+        audio = load_audio_list(data_in if isinstance(data_in, (list, tuple)) else [data_in], fs=frontend.fs, audio_fs=kwargs.get("fs", 16000))
+        if isinstance(data_in, (list, tuple)) and len(data_in) and isinstance(data_in[0], str):
+            is_final, streaming_input = True, False
+        if len(audio) != 1 or audio[0].numel() == 0 or streaming_input or not is_final:
+            return None                                            # (the plain call decides: empty input, batch > 1, streaming input)
+        meta: Dict[str, Any] = {"load_data": f"{time.perf_counter() - t1:0.3f}"}
+        t2 = time.perf_counter()
+        handles = self._scores_enqueue(frontend, audio[0])
+        meta["extract_feat"] = f"{time.perf_counter() - t2:0.3f}"
+        return dict(handles=handles, n=int(audio[0].numel()), key=key[0] if key else "", frontend=frontend, chunk_ms=chunk_ms, meta=meta,
+                    kwargs=kwargs)
+
+    def inference_launch(self, pending: dict) -> None:
+        return None
+
+    def inference_end(self, pending: dict):
+        p_sil, db = self._scores_wait(pending["handles"])
+        return self._decide(p_sil, db, pending["n"], pending["key"], pending["frontend"], self.init_cache({}, **pending["kwargs"]),
+                            pending["chunk_ms"], pending["meta"], pending["kwargs"])
+
+    def _decide(self, p_sil, db, n_samples: int, k0: str, frontend, cache: dict, chunk_ms: int, meta: dict, kwargs: dict):
+        """scores of a whole recording -> segments (the block loop of model.py:985-1087 over the frame counts its online frontend emits)"""
         meta["batch_data_time"] = len(p_sil) * frontend.frame_shift * frontend.lfr_n / 1000
         dec: NativeVadDecision = cache["decision"]
         dynamic = kwargs.get("dynamic_silence", kwargs.get("max_end_silence_time") is None)
@@ -214,7 +276,7 @@ class FsmnVADStreaming(torch.nn.Module):
         # (two frames of look-ahead), the final block the rest: the frame counts below reproduce that
         n_total = len(p_sil)
         stride = int(chunk_ms * frontend.fs / 1000)
-        n_blocks = int(wav.numel() // stride + 1)
+        n_blocks = int(n_samples // stride + 1)
         hop = int(self.vad_opts.frame_in_ms * self.vad_opts.sample_rate / 1000)
         flen = int(self.vad_opts.frame_length_ms * self.vad_opts.sample_rate / 1000)
         segments: List[List[int]] = []
@@ -230,7 +292,7 @@ class FsmnVADStreaming(torch.nn.Module):
                         dec.max_end_sil_ms = max(silence_ms - to_sil, 0)
                         dec.speech_noise_thres = 0.5
                         break
-            seen = min((b + 1) * stride, wav.numel())
+            seen = min((b + 1) * stride, n_samples)
             fb = max((seen - flen) // hop + 1, 0) if seen >= flen else 0        # fbank frames available so far
             upto = n_total if last else max(min(fb - 2, n_total), done)          # LFR(5,1): two frames of look-ahead
             if upto > done or last:

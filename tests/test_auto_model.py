@@ -253,6 +253,10 @@ def test_vad_model_directory_end_to_end(model_dir, cuda, tmp_path):
     # not in the other (CifPredictorV2 reads the row behind the last frame: a property of the reference's padded batches)
     apart = am.generate(input=recs, batch_size_rows=512, batch_across_recordings=False)
     assert len(shared) == len(apart) == 5 and shared[3]["text"] == apart[3]["text"] == ""
+    # the VAD alone over several recordings: the recordings' score passes overlap (FsmnVADStreaming.inference_begin / _end), same segments
+    vals = lambda res: [r["value"] for r in res]
+    assert vals(vad.generate(input=recs)) == vals(vad.generate(input=recs, pipeline=False)) and vals(vad.generate(input=recs))[0] == segs
+    assert vad.model.__dict__.get("_host_ring") is not None, "the VAD's overlapped form did not run"
     import difflib
     for a, b in zip(txt(shared), txt(apart)):
         assert a == b or difflib.SequenceMatcher(None, a, b, autojunk=False).ratio() > 0.95, (a, b)
