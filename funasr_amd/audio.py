@@ -266,3 +266,28 @@ def batch_to_features(data_in, data_lengths, frontend, kwargs, uploader=None):
     meta_data["extract_feat"] = f"{t3 - t2:0.3f}"
     meta_data["batch_data_time"] = (int(speech_lengths.sum().item()) * frontend.frame_shift * frontend.lfr_n / 1000)
     return speech, speech_lengths, meta_data
+
+
+def peek_num_samples(item, fs: int = 16000):
+    """How many samples `load_audio(item, fs)` will return, WITHOUT decoding: canonical RIFF header of a path, length of a 1-D array
+    or tensor; None where only decoding can tell (other containers, bytes, multi-channel arrays). For planning batches by length."""
+    import struct
+    if isinstance(item, str):
+        try:
+            with open(item, "rb") as f:
+                h = f.read(44)
+        except OSError:
+            return None
+        if len(h) < 44 or h[:4] != b"RIFF" or h[8:16] != b"WAVEfmt " or h[36:40] != b"data":
+            return None
+        fmt_size, tag, ch, rate, _, align, bits = struct.unpack_from("<IHHIIHH", h, 16)
+        if fmt_size != 16 or tag != 1 or ch < 1 or align != ch * bits // 8 or align == 0 or rate <= 0:
+            return None
+        try:
+            n = min(struct.unpack_from("<I", h, 40)[0], max(os.path.getsize(item) - 44, 0)) // align
+        except OSError:
+            return None
+        return n if rate == fs else int(round(n * fs / rate))
+    if isinstance(item, (np.ndarray, torch.Tensor)) and item.ndim == 1:
+        return int(item.shape[0])
+    return None

@@ -393,6 +393,21 @@ class AutoModel:
         # More than one batch and a model that offers its `inference` in three parts (paraformer.py inference_begin / _launch /
         # _end): the loop of auto_model.py:790-840 with the batches overlapped -- host work of batch i + 1 and of batch i - 1
         # beside the GPU work of batch i. Same records in the same order; `pipeline=False` keeps the plain loop.
+        # MI355X-native batching of a plain list (this package's own option, like inference_with_vad's): `batch_size_rows` = a budget
+        # of encoder rows per batch. The inputs are taken longest first (lengths from the WAV headers / array sizes, nothing is
+        # decoded for the plan), cut into batches by funasr_amd.dp.plan_batches_by_rows, and the records returned in INPUT order.
+        restore = None
+        if (batch_bounds is None and kwargs.get("batch_size_rows") and n > 1 and model is getattr(self, "model", None)
+                and hasattr(model, "inference_begin") and kwargs.get("data_type", "sound") != "fbank" and kwargs.get("frontend") is not None):
+            from .audio import peek_num_samples
+            fe = kwargs["frontend"]
+            lens = [peek_num_samples(d, getattr(fe, "fs", 16000)) for d in data_list]
+            if all(v is not None and v > 0 for v in lens) and hasattr(fe, "num_frames"):
+                restore = sorted(range(n), key=lambda i: -lens[i])
+                data_list, key_list = [data_list[i] for i in restore], [key_list[i] for i in restore]
+                from . import dp
+                batch_bounds = dp.plan_batches_by_rows([fe.num_frames(lens[i]) for i in restore], int(kwargs["batch_size_rows"]), extra_rows=1,
+                                                       packed=getattr(getattr(model, "encoder", None), "_mode", lambda: "fp32")() == "f16x2")
         bounds = [(beg, min(n, beg + batch_size)) for beg in range(0, n, batch_size)] if batch_bounds is None else [(int(b), int(e)) for b, e in batch_bounds]
         done = 0
         if len(bounds) > 1 and kwargs.get("pipeline", True) and hasattr(model, "inference_begin"):
@@ -451,6 +466,11 @@ class AutoModel:
                     torch.cuda.empty_cache()                                   # :846-849
         except StopIteration:
             pass
+        if restore is not None and len(results_all) == n:          # (a batch that decoded nothing leaves the count off: as decoded)
+            ordered: List[Any] = [None] * n
+            for pos, i in enumerate(restore):
+                ordered[i] = results_all[pos]
+            results_all = ordered
         return results_all
 
     # --------------------------------------------------------------------------------------- inference_with_vad

@@ -149,3 +149,9 @@ def test_canonical_wav_fast_reader_equals_the_wave_module(tmp_path):
         f.setframerate(16000)
         f.writeframes(b"\x00" * 30)
     assert audio._decode_wav_fast(p3) is None
+    # the header peek used for planning batches by length agrees with what decoding returns
+    for q in sorted(tmp_path.glob("a*.wav")):
+        x, fs = audio._decode_wav(str(q))
+        assert audio.peek_num_samples(str(q), fs) == x.numel()
+    assert audio.peek_num_samples(p2, 16000) is None and audio.peek_num_samples(torch.zeros(7), 16000) == 7
+    assert audio.peek_num_samples(torch.zeros(2, 7), 16000) is None and audio.peek_num_samples(b"1234", 16000) is None

@@ -139,6 +139,12 @@ def test_generate_over_many_batches_overlapped_equals_the_plain_loop(model_dir, 
     # token timestamps: the two-part form (everything enqueued in `inference_begin`, text and spans in `inference_end`)
     stamped = am.generate(input=paths, pred_timestamp=True)
     assert stamped == am.generate(input=paths, pred_timestamp=True, pipeline=False) and all("timestamp" in r for r in stamped)
+    # a rows budget instead of a count (this package's option): inputs taken longest first, batches cut by encoder rows, records back
+    # in INPUT order with their own keys; a clip's text as in any other batch plan (up to the longest-clip property)
+    by_rows = am.generate(input=paths, batch_size_rows=256)
+    assert [r["key"] for r in by_rows] == [r["key"] for r in plain] and len(by_rows) == len(plain)
+    assert sum(a["text"] == b["text"] for a, b in zip(by_rows, plain)) >= len(plain) - 4
+    assert by_rows == am.generate(input=paths, batch_size_rows=256, pipeline=False)
     # keys, another batch size, again (the pinned buffers and both library slots are reused)
     keys = [f"k{i}" for i in range(len(paths))]
     assert am.generate(input=paths, key=keys, batch_size=4) == am.generate(input=paths, key=keys, batch_size=4, pipeline=False)

@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--batch-size", type=int, default=64, help="clips per batch (AutoModel batch_size)")
     ap.add_argument("--dir", default=None)
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--batch-size-rows", type=int, default=0, help="> 0: generate(batch_size_rows=N) over the list in its ORIGINAL (unsorted) "
+                    "order -- this package's own option: batches planned by encoder rows from the WAV headers, records back in input order")
     ap.add_argument("--model", default="Paraformer", choices=["Paraformer", "BiCifParaformer"], help="BiCifParaformer: text + token timestamps "
                     "on every call (the model behind the paraformer-zh alias), CifPredictorV3 with random timestamp-head weights")
     ap.add_argument("--profile", action="store_true", help="cProfile of one overlapped pass (top functions by own time) to stderr")
@@ -84,8 +86,9 @@ def main():
         paths.append(p)
     # the reference sorts nothing here: generate() takes the list in its order; sorted by duration so that a batch pads little
     # (what examples/aishell's data preparation achieves with its length-sorted jsonl)
-    order = sorted(range(len(paths)), key=lambda i: -durs[i])
-    paths = [paths[i] for i in order]
+    if args.batch_size_rows <= 0:
+        order = sorted(range(len(paths)), key=lambda i: -durs[i])
+        paths = [paths[i] for i in order]
     total_s = float(sum(durs))
     print(f"[generate] {args.clips} wav files, {total_s / 3600:.2f} h, written in {time.perf_counter() - t0:.1f} s under {work}", file=sys.stderr)
 
@@ -104,14 +107,16 @@ def main():
            "audio_hours": round(total_s / 3600, 2), "batch_size": args.batch_size, "runs": []}
     ref = None
     for r in range(args.repeats):
-        for name, kw in (("overlapped", {}), ("plain loop", {"pipeline": False})):
+        rows_kw = {"batch_size_rows": args.batch_size_rows} if args.batch_size_rows > 0 else {}
+        for name, kw in (("overlapped", dict(rows_kw)), ("plain loop", dict(rows_kw, pipeline=False))) + (
+                (("count batches, unsorted list", {}),) if rows_kw else ()):
             torch.cuda.synchronize()
             t = time.perf_counter()
             res = am.generate(input=paths, **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t
             ref = ref if ref is not None else res
-            out["runs"].append({"loop": name, "wall_s": round(dt, 3), "audio_s_per_s": round(total_s / dt, 1), "records_equal_first_run": res == ref,
+            out["runs"].append({"loop": name, "wall_s": round(dt, 3), "audio_s_per_s": round(total_s / dt, 1), "records_equal_first_run": res == ref, "texts_equal_first_run": sum(a.get("text") == b.get("text") for a, b in zip(res, ref)),
                                 "last_batch": {k: am.speed_stats.get(k) for k in ("load_data", "extract_feat", "forward")}})
     if args.profile:
         import cProfile
@@ -121,7 +126,9 @@ def main():
         am.generate(input=paths)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(28)
-    best = {n: max(x["audio_s_per_s"] for x in out["runs"] if x["loop"] == n) for n in ("overlapped", "plain loop")}
+    best = {n: max(x["audio_s_per_s"] for x in out["runs"] if x["loop"] == n) for n in {x["loop"] for x in out["runs"]}}
+    out["batch_size_rows"] = args.batch_size_rows or None
+    out["count_batches_unsorted"] = best.get("count batches, unsorted list")
     out["value"] = best["overlapped"]
     out["plain_loop"] = best["plain loop"]
     out["gain"] = round(best["overlapped"] / best["plain loop"], 3)
