@@ -60,8 +60,14 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
+        const size_t had = cap;
         if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+        // Growing costs a device-wide synchronisation (the old block may be in use by queued kernels), i.e. it stalls a loop that
+        // keeps batches in flight -- so grow rarely: at least 64 KB (the per-clip arrays of a batch: a ragged corpus taken longest
+        // first raises the clip count batch after batch) and geometrically (x 1.5) beyond what was there; 288 GB of HBM pay for it
         size_t want = bytes + bytes / 8;
+        if (want < had + had / 2) want = had + had / 2;
+        if (want < 65536) want = 65536;
         PF_HIP_TRY(hipMalloc(&p, want));
         cap = want;
         ++g_ws_epoch;
