@@ -235,6 +235,13 @@ class FsmnVADStreaming(torch.nn.Module):
 
     # ---- the whole-recording call in two parts for AutoModel.inference's loop over recordings (paraformer.py inference_begin): the
     #      scores of recording i + 1 are enqueued before those of recording i are read and cut into segments on the host
+    # per-process staging objects (HIP streams, pinned buffers) are never copied or pickled with the module
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ("_upload", "_host_ring"):
+            st.pop(k, None)
+        return st
+
     def inference_begin(self, data_in, data_lengths=None, key: list = None, tokenizer=None, frontend=None, cache: dict = None, **kwargs):
         if (cache or frontend is None or frontend.lfr_n != 1 or not torch.cuda.is_available()
                 or next(self.encoder.parameters()).device.type != "cuda"):

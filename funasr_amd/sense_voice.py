@@ -201,6 +201,13 @@ class SenseVoiceSmall(nn.Module):
             start = end
         return self.post(timestamp)
 
+    # per-process staging objects (HIP streams, pinned buffers) are never copied or pickled with the module
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ("_upload", "_host_ring"):
+            st.pop(k, None)
+        return st
+
     def inference(self, data_in, data_lengths=None, key: list = ["wav_file_tmp_name"], tokenizer=None, frontend=None,
                   **kwargs):
         args, ban, meta_data, output_timestamp = self._inference_inputs(data_in, data_lengths, tokenizer, frontend, kwargs, staged=True)
