@@ -390,9 +390,6 @@ class AutoModel:
                 batch["data_lengths"] = input_len
             return batch
 
-        # More than one batch and a model that offers its `inference` in three parts (paraformer.py inference_begin / _launch /
-        # _end): the loop of auto_model.py:790-840 with the batches overlapped -- host work of batch i + 1 and of batch i - 1
-        # beside the GPU work of batch i. Same records in the same order; `pipeline=False` keeps the plain loop.
         # MI355X-native batching of a plain list (this package's own option, like inference_with_vad's): `batch_size_rows` = a budget
         # of encoder rows per batch. The inputs are taken longest first (lengths from the WAV headers / array sizes, nothing is
         # decoded for the plan), cut into batches by funasr_amd.dp.plan_batches_by_rows, and the records returned in INPUT order.
@@ -409,6 +406,9 @@ class AutoModel:
                 batch_bounds = dp.plan_batches_by_rows([fe.num_frames(lens[i]) for i in restore], int(kwargs["batch_size_rows"]), extra_rows=1,
                                                        packed=getattr(getattr(model, "encoder", None), "_mode", lambda: "fp32")() == "f16x2")
         bounds = [(beg, min(n, beg + batch_size)) for beg in range(0, n, batch_size)] if batch_bounds is None else [(int(b), int(e)) for b, e in batch_bounds]
+        # More than one batch and a model that offers its `inference` in three parts (paraformer.py inference_begin / _launch /
+        # _end): the loop of auto_model.py:790-840 with the batches overlapped -- host work of batch i + 1 and of batch i - 1
+        # beside the GPU work of batch i. Same records in the same order; `pipeline=False` keeps the plain loop.
         done = 0
         if len(bounds) > 1 and kwargs.get("pipeline", True) and hasattr(model, "inference_begin"):
             inflight = collections.deque()                                    # [pending, end, host seconds so far, launched]
