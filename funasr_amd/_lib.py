@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libparaformer_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4            # PF_ABI_VERSION of include/paraformer_hip.h
+ABI_VERSION = 5            # PF_ABI_VERSION of include/paraformer_hip.h
 
 _lock = threading.Lock()
 _lib = None
@@ -100,6 +100,8 @@ SIGNATURES = {
     "pf_frontend_faults": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "pf_frontend_fault_log": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "pf_frontend_set_tables": (C.c_int, [_vp, _vp, _vp]),
+    "pf_frontend_set_window": (C.c_int, [_vp, C.c_char_p, _f32]),
+    "pf_frontend_set_snip_edges": (C.c_int, [_vp, _i32]),
     "pf_frontend_num_fbank_frames": (_i32, [_vp, _i64]),
     "pf_frontend_num_frames": (_i32, [_vp, _i64]),
     "pf_frontend_forward": (C.c_int, [_vp, _vp, _i64, _pi32, _i32, _vp, _i32, _pi32, _vp, _vp]),
@@ -127,6 +129,7 @@ SIGNATURES = {
     "pf_predictor_timestamp": (C.c_int, [_vp, _vp, _pi32, _pi32, _i32, _i32, _vp, _vp, _vp]),
     "pf_decoder_create": (_vp, [C.POINTER(pf_decoder_config)]),
     "pf_decoder_destroy": (None, [_vp]),
+    "pf_decoder_set_decoders2": (C.c_int, [_vp, _i32]),
     "pf_decoder_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "pf_decoder_missing": (C.c_int, [_vp]),
     "pf_decoder_set_precision": (C.c_int, [_vp, _i32]),

@@ -29,6 +29,18 @@ int decoder_resolve(Decoder* d) {
         w.o_w = d->tt.get(p + "src_attn.linear_out.weight"); w.o_b = d->tt.get(p + "src_attn.linear_out.bias");
         d->layers.push_back(w);
     }
+    d->layers2.clear();
+    for (int i = 0; i < d->n_blocks2; ++i) {
+        const std::string p = "decoders2." + std::to_string(i) + ".";
+        DecLayerW w{};
+        w.n1g = d->tt.get(p + "norm1.weight"); w.n1b = d->tt.get(p + "norm1.bias");
+        w.w1 = d->tt.get(p + "feed_forward.w_1.weight"); w.b1 = d->tt.get(p + "feed_forward.w_1.bias");
+        w.fng = d->tt.get(p + "feed_forward.norm.weight"); w.fnb = d->tt.get(p + "feed_forward.norm.bias");
+        w.w2 = d->tt.get(p + "feed_forward.w_2.weight");
+        w.n2g = d->tt.get(p + "norm2.weight"); w.n2b = d->tt.get(p + "norm2.bias");
+        w.fsmn_w = d->tt.get(p + "self_attn.fsmn_block.weight");
+        d->layers2.push_back(w);
+    }
     {
         const std::string p = "decoders3.0.";
         DecLayerW w{};
@@ -248,6 +260,15 @@ int decoder_forward_bf16(Decoder* d, const float* memory, int B, int T, int N, i
             if ((rc = launch_attention_bf16(aa, s))) return rc;
         }
         if ((rc = gemm16(ctx16, D, w16(p + "src_attn.linear_out.weight"), D, w.o_b, x, D, Mq, D, D, 0, x, D, 0))) return rc;
+    }
+    for (int l = 0; l < d->n_blocks2; ++l) {                       // decoders2 (decoder.py:363-380): no cross-attention, taps centred
+        const DecLayerW& w = d->layers2[l];
+        if ((rc = ffn_bf16("decoders2." + std::to_string(l) + ".", w, x, t2))) return rc;
+        if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;
+        FsmnArgs fa{};
+        fa.in = t1; fa.ldin = D; fa.w = w.fsmn_w; fa.R = x; fa.ldr = D; fa.out = x; fa.ldo = D;
+        fa.lens = d->tok_lens.as<int>(); fa.B = B; fa.T = N; fa.C = D; fa.K = c.kernel_size; fa.left_pad = (c.kernel_size - 1) / 2;
+        if ((rc = fsmn(fa, s))) return rc;
     }
     if ((rc = ffn_bf16("decoders3.0.", d->last, x, t2))) return rc;
     u16* hid16 = d->hid16.as<u16>();
@@ -637,6 +658,34 @@ static pf_decoder* decoder_create_impl(const pf_decoder_config* cfg, bool contex
     return reinterpret_cast<pf_decoder*>(d.release());
 }
 void pf_decoder_destroy(pf_decoder* d) { delete reinterpret_cast<Decoder*>(d); }
+/* decoders2 (paraformer/decoder.py:363-380, :436-437): n_layers = num_blocks - att_layer_num blocks of FFN + FSMN memory (built with
+ * sanm_shfit 0: the taps centred) and NO cross-attention, run between `decoders` and `decoders3`. Tensors "decoders2.<i>.norm1|norm2.*",
+ * "decoders2.<i>.feed_forward.*", "decoders2.<i>.self_attn.fsmn_block.weight". Call once, before the first set_tensor. */
+int pf_decoder_set_decoders2(pf_decoder* dh, int32_t n_layers) {
+    Decoder* d = reinterpret_cast<Decoder*>(dh);
+    PF_REQUIRE(d && n_layers >= 0 && n_layers <= 64, "decoder_set_decoders2: null handle or layer count out of range");
+    PF_REQUIRE(d->n_blocks2 == 0 || d->n_blocks2 == n_layers, "decoder_set_decoders2: already set");
+    if (d->n_blocks2 == n_layers) return 0;
+    const int D = d->cfg.d_model, F = d->cfg.ffn_dim;
+    int rc = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const std::string p = "decoders2." + std::to_string(i) + ".";
+        rc |= d->tt.add(p + "norm1.weight", D);
+        rc |= d->tt.add(p + "norm1.bias", D);
+        rc |= d->tt.add(p + "feed_forward.w_1.weight", (int64_t)F * D);
+        rc |= d->tt.add(p + "feed_forward.w_1.bias", F);
+        rc |= d->tt.add(p + "feed_forward.norm.weight", F);
+        rc |= d->tt.add(p + "feed_forward.norm.bias", F);
+        rc |= d->tt.add(p + "feed_forward.w_2.weight", (int64_t)D * F);
+        rc |= d->tt.add(p + "norm2.weight", D);
+        rc |= d->tt.add(p + "norm2.bias", D);
+        rc |= d->tt.add(p + "self_attn.fsmn_block.weight", (int64_t)D * d->cfg.kernel_size);
+    }
+    if (rc) return -2;
+    d->n_blocks2 = n_layers;
+    d->resolved = false;
+    return 0;
+}
 int pf_decoder_set_tensor(pf_decoder* dh, const char* name, const float* data, int64_t numel) {
     Decoder* d = reinterpret_cast<Decoder*>(dh);
     PF_REQUIRE(d && name && data, "decoder_set_tensor: null");
@@ -753,6 +802,8 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
         if (d->vt2.cap != cap_v) PF_HIP_TRY(hipMemsetAsync(d->vt2.p, 0, d->vt2.cap, s));
         for (int l = 0; l < c.n_blocks; ++l)
             if ((rc = dec_layer_x2(d, d->layers[l], dec_layer_prefix(d->contextual, c.n_blocks, l), true, s))) return rc;
+        for (int l = 0; l < d->n_blocks2; ++l)
+            if ((rc = dec_layer_x2(d, d->layers2[l], "decoders2." + std::to_string(l) + ".", false, s))) return rc;
         if ((rc = dec_layer_x2(d, d->last, "decoders3.0.", false, s))) return rc;
         if (!d->lb_uploaded) {
             std::vector<float> lb((size_t)4 * c.n_blocks);
@@ -919,6 +970,22 @@ static int decoder_forward_impl(Decoder* d, const float* memory, const int32_t* 
         }
         if ((rc = gemm_simple(d->ctx.as<float>(), D, w.o_w, D, w.o_b, x, D, Mq, D, D, 0, nullptr, 0, x, D, s)))
             return rc;                                                                        // x = residual + att
+    }
+    // decoders2: FFN -> norm2 -> FSMN memory + residual, no cross-attention; the blocks are built with sanm_shfit 0 whatever the
+    // attention blocks use (decoder.py:363-380, DecoderLayerSANM.forward :97-107 with src_attn None)
+    for (int l = 0; l < d->n_blocks2; ++l) {
+        const DecLayerW& w = d->layers2[l];
+        const unsigned short* w1_3 = w3("decoders2." + std::to_string(l) + ".feed_forward.w_1.weight", F, D);
+        if (x3 && !w1_3) return -2;
+        if (x2) rc = dec_ffn_x2(d, w, x, t2, Mq, s);
+        else rc = dec_ffn(d, w, x, t2, Mq, s, w1_3);
+        if (rc) return rc;
+        if ((rc = layernorm(t2, D, w.n2g, w.n2b, t1, D, Mq, D, D, c.ln_eps, s))) return rc;
+        FsmnArgs fa{};
+        fa.in = t1; fa.ldin = D; fa.w = w.fsmn_w; fa.R = x; fa.ldr = D; fa.out = x; fa.ldo = D;
+        fa.lens = d->tok_lens.as<int>(); fa.B = B; fa.T = N; fa.C = D; fa.K = c.kernel_size; fa.left_pad = (c.kernel_size - 1) / 2;
+        fa.offs = offs_dev;
+        if ((rc = fsmn(fa, s))) return rc;
     }
     // decoders3: FFN only, no residual (decoder.py:438, DecoderLayerSANM with self_attn = src_attn = None)
     {

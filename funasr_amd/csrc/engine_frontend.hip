@@ -172,10 +172,43 @@ int pf_frontend_set_tables(pf_frontend* fh, const float* window, const float* me
     return frontend_upload_tables(f, w, m);
 }
 
+// The window by name, with kaldi-native-fbank's float64 arithmetic (feature-window.cc:25-55; FrameExtractionOptions.window_type,
+// blackman_coeff 0.42 by default). Callers that want torchaudio's float32 tables pass them through pf_frontend_set_tables.
+int pf_frontend_set_window(pf_frontend* fh, const char* window_type, float blackman_coeff) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    PF_REQUIRE(f && window_type, "frontend_set_window: null");
+    const std::string t(window_type);
+    const int n = f->cfg.frame_length;
+    std::vector<float> w(n);
+    const double a = 6.283185307179586476925286766559005 / (n - 1);
+    for (int i = 0; i < n; ++i) {
+        const double x = (double)i;
+        if (t == "hanning") w[i] = (float)(0.5 - 0.5 * cos(a * x));
+        else if (t == "sine") w[i] = (float)sin(0.5 * a * x);
+        else if (t == "hamming") w[i] = (float)(0.54 - 0.46 * cos(a * x));
+        else if (t == "povey") w[i] = (float)pow(0.5 - 0.5 * cos(a * x), 0.85);
+        else if (t == "rectangular") w[i] = 1.f;
+        else if (t == "blackman") w[i] = (float)(blackman_coeff - 0.5 * cos(a * x) + (0.5 - blackman_coeff) * cos(2 * a * x));
+        else { set_error("frontend_set_window: window_type must be hamming | hanning | povey | rectangular | blackman | sine"); return -1; }
+    }
+    PF_HIP_TRY(hipMemcpy(f->window.p, w.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+// snip_edges = false: (n + shift / 2) / shift frames centred on multiples of the shift, the waveform mirrored at both ends
+// (kaldi FrameExtractionOptions.snip_edges; the reference passes WavFrontend's `snip_edges` through, wav_frontend.py:180)
+int pf_frontend_set_snip_edges(pf_frontend* fh, int32_t on) {
+    Frontend* f = reinterpret_cast<Frontend*>(fh);
+    PF_REQUIRE(f, "frontend_set_snip_edges: null handle");
+    f->snip_edges = on ? 1 : 0;
+    return 0;
+}
+
 int32_t pf_frontend_num_fbank_frames(const pf_frontend* fh, int64_t n) {
     const Frontend* f = reinterpret_cast<const Frontend*>(fh);
-    if (!f || n < f->cfg.frame_length) return 0;
-    return (int32_t)(1 + (n - f->cfg.frame_length) / f->cfg.frame_shift);   // feature-window.cc:76-90 (snip_edges)
+    if (!f) return 0;
+    if (!f->snip_edges) return (int32_t)((n + f->cfg.frame_shift / 2) / f->cfg.frame_shift);   // feature-window.cc:87-89
+    if (n < f->cfg.frame_length) return 0;
+    return (int32_t)(1 + (n - f->cfg.frame_length) / f->cfg.frame_shift);   // feature-window.cc:76-86 (snip_edges)
 }
 int32_t pf_frontend_num_frames(const pf_frontend* fh, int64_t n) {
     const Frontend* f = reinterpret_cast<const Frontend*>(fh);
@@ -194,7 +227,7 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     for (int b = 0; b < B; ++b) {
         PF_REQUIRE(n_samples[b] <= wav_stride, "frontend_forward: n_samples exceeds wav_stride");
         nfr[b] = pf_frontend_num_fbank_frames(fh, n_samples[b]);
-        PF_REQUIRE(nfr[b] > 0, "frontend_forward: utterance shorter than one 25 ms window");
+        PF_REQUIRE(nfr[b] > 0, "frontend_forward: utterance shorter than one analysis window");
         const int t = (nfr[b] + f->cfg.lfr_n - 1) / f->cfg.lfr_n;
         PF_REQUIRE(t <= T_out, "frontend_forward: T_out too small");
         if (feat_lens) feat_lens[b] = t;
@@ -202,6 +235,10 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     }
     if (f->nfr.ensure(sizeof(int32_t) * B)) return -2;
     if (upload_h2d(f->nfr.p, nfr.data(), sizeof(int32_t) * B, s)) return -2;
+    if (!f->snip_edges) {
+        if (f->nsamp.ensure(sizeof(int32_t) * B)) return -2;
+        if (upload_h2d(f->nsamp.p, n_samples, sizeof(int32_t) * B, s)) return -2;
+    }
     float* fb = fbank_out;
     if (!fb) {
         if (f->fbank.ensure(sizeof(float) * (size_t)B * max_fr * f->cfg.n_mels)) return -2;
@@ -215,6 +252,8 @@ int pf_frontend_forward(pf_frontend* fh, const float* wav, int64_t wav_stride, c
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
     a.verify = frontend_verify_on(f); a.faults = a.verify ? f->faults.as<unsigned int>() : nullptr;
+    a.n_samples = f->snip_edges ? nullptr : f->nsamp.as<int>();
+    a.first_offset = f->cfg.frame_length / 2 - f->cfg.frame_shift / 2;
     int rc;
     {
         double bytes = 0;
@@ -268,6 +307,13 @@ int pf_frontend_fbank(pf_frontend* fh, const float* wav_dev, int64_t n_samples, 
     a.mel_first = f->mel_first.as<int>(); a.mel_count = f->mel_count.as<int>(); a.n_pieces = f->n_pieces;
     a.dither = f->dither; a.seed = f->dither_seed; a.call = f->dither != 0.f ? f->dither_calls++ : 0;
     a.verify = frontend_verify_on(f); a.faults = a.verify ? f->faults.as<unsigned int>() : nullptr;
+    if (!f->snip_edges) {
+        PF_REQUIRE(n_samples < (1ll << 31), "frontend_fbank: waveform too long");
+        if (f->nsamp.ensure(sizeof(int32_t))) return -2;
+        if ((rc = launch_fill_int(f->nsamp.as<int>(), 1, (int)n_samples, s))) return rc;
+        a.n_samples = f->nsamp.as<int>();
+        a.first_offset = f->cfg.frame_length / 2 - f->cfg.frame_shift / 2;
+    }
     return launch_fbank(a, 1, nfr, s);
 }
 

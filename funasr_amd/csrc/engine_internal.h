@@ -311,6 +311,7 @@ struct Frontend {
     int feat_dim() const { return cfg.n_mels * cfg.lfr_m; }
     float dither = 0.f; unsigned long long dither_seed = 0; unsigned dither_calls = 0;   // pf_frontend_set_dither
     int verify = 0; DevBuf faults;                                                       // pf_frontend_set_verify (FbankArgs.verify)
+    int snip_edges = 1; DevBuf nsamp;                                                    // pf_frontend_set_snip_edges (FbankArgs.n_samples)
 };
 // =============================================================================================== encoder
 struct EncLayerW {
@@ -475,6 +476,8 @@ struct Decoder {
     DevBuf xself, xcat, ctx_lens;     // contextual: x after the FSMN residual, [x_src_attn | cx] rows, hotword counts
     TensorTable tt;
     std::vector<DecLayerW> layers;
+    int n_blocks2 = 0;       // decoders2: num_blocks - att_layer_num blocks of FFN + FSMN without cross-attention (decoder.py:363-380)
+    std::vector<DecLayerW> layers2;
     DecLayerW last;          // decoders3.0 (FFN only)
     bool resolved = false;
     DevBuf x, t1, t2, ffn, ffn2, q, kv, ctx, mem_lens, tok_lens, pval, pidx, hid;

@@ -475,8 +475,8 @@ pf_stream* pf_stream_create(pf_encoder* eh, pf_predictor* ph, pf_decoder* dh, co
     if (c.n_streams < 1 || c.chunk_left < 0 || c.chunk_cur < 1 || c.chunk_right < 0 || c.enc_look_back < 0 ||
         c.dec_look_back < 0 || c.max_frames < c.chunk_cur || c.max_tokens < 1 || c.max_tokens > 96 ||
         e->cfg.tp_blocks != 0 || e->cfg.d_model != 512 || d->cfg.d_model != 512 || p->cfg.d_model != 512 ||
-        dec_left != K - 1) {
-        set_error("stream: unsupported config (d_model 512, look_back >= 0 (finite), max_tokens <= 96, causal decoder "
+        dec_left != K - 1 || d->n_blocks2 != 0) {
+        set_error("stream: unsupported config (d_model 512, look_back >= 0 (finite), max_tokens <= 96, no decoders2, causal decoder "
                   "FSMN i.e. sanm_shfit == (kernel_size-1)/2 as in paraformer_streaming/template.yaml:62)");
         return nullptr;
     }

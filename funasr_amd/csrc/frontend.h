@@ -32,6 +32,10 @@ struct FbankArgs {
     // results agree; disagreements are counted in *faults (device, may be null). For GPUs shared with another process that runs
     // LDS-DMA-heavy kernels: there a frame's LDS exchange is disturbed about once per 10^4 frames (open issue).
     int verify; unsigned int* faults;
+    // snip_edges = false (feature-window.cc:66-90): n_samples != null, frame f starts at f * frame_shift - first_offset with
+    // first_offset = frame_len / 2 - frame_shift / 2, and samples outside [0, n) are mirrored at the ends (feature-window.cc:152-171)
+    const int* n_samples;        // device int32 [B]; null = snip_edges (every frame lies inside the waveform)
+    int first_offset;
 };
 int launch_fbank(const FbankArgs& a, int B, int max_frames_in_batch, hipStream_t stream);
 

@@ -132,6 +132,21 @@ __global__ __launch_bounds__(256, 4) void fbank_kernel(FbankArgs p, int total_fr
         if (g >= total_frames) return;
         const int b = g / p.max_frames, f = g - b * p.max_frames;
         if (f >= p.n_frames[b]) return;
+        if (p.n_samples) {                                     // snip_edges = false: mirrored ends (wave-uniform branch)
+            const float* w = p.wav + (size_t)b * p.wav_stride;
+            const int n = p.n_samples[b], start = f * p.frame_shift - p.first_offset;
+            auto mirrored = [&](int s) {
+                while (s < 0 || s >= n) s = s < 0 ? -s - 1 : 2 * n - 1 - s;
+                return w[s];
+            };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i0 = 2 * (lane + 64 * j);
+                if (i0 < p.frame_len) re[j] = mirrored(start + i0);
+                if (i0 + 1 < p.frame_len) ro[j] = mirrored(start + i0 + 1);
+            }
+            return;
+        }
         const float* w = p.wav + (size_t)b * p.wav_stride + (size_t)f * p.frame_shift;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

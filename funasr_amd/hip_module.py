@@ -85,6 +85,7 @@ class HipModule(nn.Module):
                 create = getattr(lib, getattr(self, "_create_name", None) or self._prefix + "_create")
                 h = create(C.byref(cfg)) if cfg is not None else create(*self._create_args())
                 self._handle = _lib.check_handle(h, self._prefix + "_create")
+                self._after_create(lib, self._handle)
             self._handle_device = dev
             self._dirty = True
         if self._dirty:
@@ -94,6 +95,9 @@ class HipModule(nn.Module):
 
     def _create_args(self):  # for handles created from scalars instead of a config struct
         return ()
+
+    def _after_create(self, lib, handle):  # settings that register further tensors, before the first set_tensor
+        pass
 
     def _push_weights(self, lib):
         set_tensor = getattr(lib, self._prefix + "_set_tensor")

@@ -27,6 +27,17 @@ def _ffn(block, d_model, ffn):
     block.feed_forward.w_2 = linear(d_model, ffn, bias=False)
 
 
+def _block2(d_model, ffn, kernel_size):
+    """decoders2 block: DecoderLayerSANM(self_attn=MultiHeadedAttentionSANMDecoder(sanm_shfit=0), src_attn=None) -- norm1 / FFN / norm2 /
+    FSMN, no norm3, no cross-attention (decoder.py:363-380, :65-68)"""
+    b = Holder()
+    _ffn(b, d_model, ffn)
+    b.norm2 = layer_norm(d_model)
+    b.self_attn = Holder()
+    b.self_attn.fsmn_block = depthwise(d_model, kernel_size)
+    return b
+
+
 def _block(d_model, ffn, kernel_size):
     b = Holder()
     _ffn(b, d_model, ffn)
@@ -56,9 +67,8 @@ class ParaformerSANMDecoder(HipModule):
                  chunk_multiply_factor: tuple = (1,), tf2torch_tensor_name_prefix_torch: str = "decoder",
                  tf2torch_tensor_name_prefix_tf: str = "seq2seq/decoder", **kwargs):
         super().__init__()
-        if num_blocks - att_layer_num > 0 or not normalize_before or concat_after or lora_list:
-            raise NotImplementedError("ParaformerSANMDecoder(HIP): only att_layer_num >= num_blocks (no decoders2), "
-                                      "normalize_before, no LoRA is built")
+        if not normalize_before or concat_after or lora_list:
+            raise NotImplementedError("ParaformerSANMDecoder(HIP): normalize_before, no concat_after, no LoRA is built")
         if sanm_shfit is None:
             sanm_shfit = (kernel_size - 1) // 2
         D = encoder_output_size
@@ -67,6 +77,9 @@ class ParaformerSANMDecoder(HipModule):
         if not wo_input_layer and input_layer == "embed":
             self.embed = nn.ModuleList([ParamHolder((vocab_size, D), None)])
         self.decoders = nn.ModuleList([_block(D, linear_units, kernel_size) for _ in range(att_layer_num)])
+        # decoder.py:363-380: num_blocks - att_layer_num blocks without cross-attention (None when there are none)
+        self.decoders2 = (nn.ModuleList([_block2(D, linear_units, kernel_size) for _ in range(num_blocks - att_layer_num)])
+                          if num_blocks - att_layer_num > 0 else None)
         last = Holder()
         _ffn(last, D, linear_units)
         self.decoders3 = nn.ModuleList([last])
@@ -93,6 +106,10 @@ class ParaformerSANMDecoder(HipModule):
     def _make_config(self):
         return _lib.pf_decoder_config(self.vocab_size if self.output_layer is not None else 0, self.d_model, self.attention_heads, self.linear_units,
                                       self.att_layer_num, self.kernel_size, self.sanm_shfit, 1e-12)
+
+    def _after_create(self, lib, handle):
+        if self.decoders2 is not None:
+            _lib.check(lib.pf_decoder_set_decoders2(handle, len(self.decoders2)), "pf_decoder_set_decoders2")
 
     def _apply_settings(self):
         lib, h = self._ensure_handle()

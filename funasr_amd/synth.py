@@ -133,6 +133,11 @@ def decoder_state_dict(cfg: dict, seed: int = 2, prefix: str = "", with_embed: b
         _linear(sd, rng, p + ".src_attn.linear_q", D, D)
         _linear(sd, rng, p + ".src_attn.linear_k_v", 2 * D, D)
         _linear(sd, rng, p + ".src_attn.linear_out", D, D, gain=0.5)
+    for i in range(max(cfg.get("num_blocks", cfg["att_layer_num"]) - cfg["att_layer_num"], 0)):   # decoders2 (decoder.py:363-380)
+        p = prefix + f"decoders2.{i}"
+        ffn(p)
+        _ln(sd, rng, p + ".norm2", D)
+        sd[p + ".self_attn.fsmn_block.weight"] = rng.normal(D, 1, K, std=0.15)
     ffn(prefix + "decoders3.0")
     _ln(sd, rng, prefix + "after_norm", D)
     _linear(sd, rng, prefix + "output_layer", V, D)

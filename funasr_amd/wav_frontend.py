@@ -44,14 +44,39 @@ def load_cmvn(cmvn_file: str) -> torch.Tensor:
     return torch.from_numpy(np.stack([shift, scale]))
 
 
-def kaldi_tables(n_mels: int, window_size: int, fs: float, low_freq: float = 20.0, high_freq: float = 0.0):
+WINDOW_TYPES = ("hamming", "hanning", "povey", "rectangular", "blackman")
+
+
+def kaldi_window(window_type: str, window_size: int, blackman_coeff: float = 0.42) -> torch.Tensor:
+    """The analysis window as torchaudio.compliance.kaldi._feature_window_function builds it in float32 (what the reference's
+    kaldi.fbank(window_type=self.window) evaluates, wav_frontend.py:171-181); Kaldi's definitions are
+    kaldi-native-fbank/csrc/feature-window.cc:25-55."""
+    import math
+
+    if window_type == "hamming":
+        return torch.hamming_window(window_size, periodic=False, alpha=0.54, beta=0.46, dtype=torch.float32)
+    if window_type == "hanning":
+        return torch.hann_window(window_size, periodic=False, dtype=torch.float32)
+    if window_type == "povey":
+        return torch.hann_window(window_size, periodic=False, dtype=torch.float32).pow(0.85)
+    if window_type == "rectangular":
+        return torch.ones(window_size, dtype=torch.float32)
+    if window_type == "blackman":
+        a = 2 * math.pi / (window_size - 1)
+        i = torch.arange(window_size, dtype=torch.float32)
+        return (blackman_coeff - 0.5 * torch.cos(a * i) + (0.5 - blackman_coeff) * torch.cos(2 * a * i)).to(torch.float32)
+    raise ValueError(f"Invalid window type {window_type!r} (one of {WINDOW_TYPES})")
+
+
+def kaldi_tables(n_mels: int, window_size: int, fs: float, low_freq: float = 20.0, high_freq: float = 0.0,
+                 window_type: str = "hamming"):
     """Window and dense mel matrix in the float32 arithmetic torchaudio.compliance.kaldi uses, so that the device
     frontend matches the reference's Python path to float32 round-off (the library's built-in tables follow
     kaldi-native-fbank's float64-cosine / float-scalar construction instead)."""
     import math
 
     padded = 1 << (window_size - 1).bit_length()
-    window = torch.hamming_window(window_size, periodic=False, alpha=0.54, beta=0.46, dtype=torch.float32)
+    window = kaldi_window(window_type, window_size)
     nyq = 0.5 * fs
     hf = high_freq + nyq if high_freq <= 0.0 else high_freq
     mlo = 1127.0 * math.log(1.0 + low_freq / 700.0)
@@ -76,10 +101,8 @@ class WavFrontend(nn.Module):
         # verify: the fbank kernel evaluates every frame twice and repeats until two runs agree (pf_frontend_set_verify): for a GPU
         # this process SHARES with another one. None = on exactly when the launcher says so (PF_FRONTEND_VERIFY=1)
         self.verify = bool(int(os.environ.get("PF_FRONTEND_VERIFY", "0"))) if verify is None else bool(verify)
-        if window != "hamming":
-            raise NotImplementedError("only the hamming window of the Paraformer/SenseVoice recipes is built")
-        if not snip_edges:
-            raise NotImplementedError("snip_edges=False is not built")
+        if window not in WINDOW_TYPES:
+            raise ValueError(f"Invalid window type {window!r} (one of {WINDOW_TYPES})")
         if float(dither) < 0.0:
             raise ValueError("dither must be >= 0")
         self.dither_seed = int(torch.initial_seed() if dither_seed is None else dither_seed) & 0xFFFFFFFFFFFFFFFF
@@ -125,8 +148,10 @@ class WavFrontend(nn.Module):
                                       self.lfr_n, 20.0, 0.0, 0.97, float(1 << 15) if self.upsacle_samples else 1.0)
         with torch.cuda.device(dev):
             h = _lib.check_handle(lib.pf_frontend_create(C.byref(cfg)), "pf_frontend_create")
-            w, mel = kaldi_tables(self.n_mels, win, float(self.fs))
+            w, mel = kaldi_tables(self.n_mels, win, float(self.fs), window_type=self.window)
             _lib.check(lib.pf_frontend_set_tables(h, w.data_ptr(), mel.data_ptr()), "pf_frontend_set_tables")
+            if not self.snip_edges:
+                _lib.check(lib.pf_frontend_set_snip_edges(h, 0), "pf_frontend_set_snip_edges")
             if float(self.dither) != 0.0:
                 _lib.check(lib.pf_frontend_set_dither(h, float(self.dither), self.dither_seed), "pf_frontend_set_dither")
             if self.verify:
@@ -163,10 +188,16 @@ class WavFrontend(nn.Module):
             raise RuntimeError("WavFrontend: no GPU visible; the HIP frontend is the only implementation")
         return torch.device("cuda", torch.cuda.current_device())
 
-    def num_frames(self, n_samples: int) -> int:
+    def num_fbank_frames(self, n_samples: int) -> int:
+        """Kaldi's NumFrames (feature-window.cc:66-90): whole windows inside the waveform, or with snip_edges=False one frame per
+        shift, centred, the ends mirrored"""
         win, hop = int(self.fs * self.frame_length * 0.001), int(self.fs * self.frame_shift * 0.001)
-        tf = 0 if n_samples < win else 1 + (n_samples - win) // hop
-        return (tf + self.lfr_n - 1) // self.lfr_n
+        if not self.snip_edges:
+            return (n_samples + hop // 2) // hop
+        return 0 if n_samples < win else 1 + (n_samples - win) // hop
+
+    def num_frames(self, n_samples: int) -> int:
+        return (self.num_fbank_frames(n_samples) + self.lfr_n - 1) // self.lfr_n
 
     def forward(self, input: torch.Tensor, input_lengths, return_fbank: bool = False, **kwargs):
         if input.dim() == 1:
@@ -183,8 +214,7 @@ class WavFrontend(nn.Module):
         out_lens = (C.c_int32 * B)()
         fb = None
         if return_fbank:
-            win, hop = int(self.fs * self.frame_length * 0.001), int(self.fs * self.frame_shift * 0.001)
-            tfb = max(1 + (n - win) // hop for n in lens)
+            tfb = max(self.num_fbank_frames(n) for n in lens)
             fb = torch.zeros(B, tfb, self.n_mels, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(lib.pf_frontend_forward(h, wav.data_ptr(), wav.stride(0), lens_c, B, feats.data_ptr(), T,

@@ -52,8 +52,10 @@ extern "C" {
 /* 2 (round 5): everything added since the first release is covered by one number a dlsym-binding host can test -- pf_dp_*
  * (incl. pf_dp_broadcast_raw), pf_stream_step_begin / _end, pf_frontend_set_dither / _verify, pf_paraformer_forward, the
  * pf_k_* measurement entries. A library reporting 1 has none of them.
- * 3 (round 6): + pf_paraformer_begin / pf_paraformer_finish (the split-phase offline forward). */
-#define PF_ABI_VERSION 4
+ * 3 (round 6): + pf_paraformer_begin / pf_paraformer_finish (the split-phase offline forward).
+ * 4: + pf_predictor_alphas_begin / pf_predictor_embeds_slot.
+ * 5: + pf_frontend_set_window / pf_frontend_set_snip_edges, pf_decoder_set_decoders2. */
+#define PF_ABI_VERSION 5
 
 const char* pf_last_error(void);
 int pf_abi_version(void);
@@ -104,7 +106,14 @@ int pf_frontend_fault_log(pf_frontend* f, uint32_t* log_host_64);
  * kaldi-native-fbank feature-window.cc:25-47, mel-computations.cc:118-210) with caller-computed ones, e.g. the
  * float32 tables torchaudio.compliance.kaldi builds. window: [frame_length]; mel: dense [n_mels, 257]. */
 int pf_frontend_set_tables(pf_frontend* f, const float* window_host, const float* mel_host);
-/* frames after fbank (snip_edges) and after LFR for an utterance of n_samples */
+/* The analysis window by name: hamming (default) | hanning | povey | rectangular | blackman | sine, evaluated as kaldi-native-fbank
+ * does (float64 cosines, feature-window.cc:25-55; blackman_coeff 0.42 is Kaldi's default). The reference passes WavFrontend's
+ * `window` to kaldi.fbank(window_type=...) (funasr/frontends/wav_frontend.py:178). */
+int pf_frontend_set_window(pf_frontend* f, const char* window_type, float blackman_coeff);
+/* snip_edges = 0: (n + shift / 2) / shift frames, frame i centred on sample i * shift + shift / 2, the waveform mirrored at both
+ * ends (kaldi FrameExtractionOptions.snip_edges, feature-window.cc:66-90,152-171; funasr/frontends/wav_frontend.py:180). Default 1. */
+int pf_frontend_set_snip_edges(pf_frontend* f, int32_t on);
+/* frames after fbank and after LFR for an utterance of n_samples (by the handle's snip_edges setting) */
 int32_t pf_frontend_num_fbank_frames(const pf_frontend* f, int64_t n_samples);
 int32_t pf_frontend_num_frames(const pf_frontend* f, int64_t n_samples);
 /* wav_dev: [B, wav_stride] float32 in [-1, 1]; n_samples_host: [B]; feats_dev: [B, T_out, n_mels*lfr_m] with
@@ -244,7 +253,7 @@ typedef struct pf_decoder_config {
     int32_t d_model;          /* 512 */
     int32_t n_heads;          /* 4 */
     int32_t ffn_dim;          /* 2048 */
-    int32_t n_blocks;         /* 16 = att_layer_num = num_blocks (decoders2 absent, decoder.py:363-364) */
+    int32_t n_blocks;         /* 16 = att_layer_num (blocks with cross-attention; decoders2: pf_decoder_set_decoders2) */
     int32_t kernel_size;      /* 11; 21 (with sanm_shift 0) for SeACo's bias decoder */
     int32_t sanm_shift;       /* 0 offline / 5 streaming model */
     float ln_eps;             /* 1e-12 */
@@ -252,6 +261,11 @@ typedef struct pf_decoder_config {
 
 pf_decoder* pf_decoder_create(const pf_decoder_config* cfg);
 void pf_decoder_destroy(pf_decoder* d);
+/* decoders2 (funasr/models/paraformer/decoder.py:363-380,436-437): n_layers = num_blocks - att_layer_num further blocks of
+ * FFN + FSMN memory (sanm_shfit 0) WITHOUT cross-attention between `decoders` and `decoders3`. Registers the tensors
+ * "decoders2.<i>.{norm1,norm2}.{weight,bias}", "decoders2.<i>.feed_forward.*", "decoders2.<i>.self_attn.fsmn_block.weight";
+ * call once, right after create. The published recipes have none (att_layer_num == num_blocks). */
+int pf_decoder_set_decoders2(pf_decoder* d, int32_t n_layers);
 int pf_decoder_set_tensor(pf_decoder* d, const char* name, const float* data, int64_t numel);
 int pf_decoder_missing(const pf_decoder* d);
 /* 0 = fp32 (default), 1 = bf16 operands for the GEMMs and the cross-attention (see pf_encoder_set_precision; applies

@@ -54,24 +54,55 @@ def kaldi_mel_banks(num_bins: int, padded_window: int, sample_freq: float, low_f
     return torch.max(torch.zeros(1), torch.min(up, down))
 
 
+def kaldi_window(window_type: str, window_size: int, blackman_coeff: float = 0.42) -> Tensor:
+    """torchaudio.compliance.kaldi._feature_window_function in float32 (hamming | hanning | povey | rectangular | blackman);
+    Kaldi's definitions: kaldi-native-fbank/csrc/feature-window.cc:25-55."""
+    if window_type == "hamming":
+        return torch.hamming_window(window_size, periodic=False, alpha=0.54, beta=0.46, dtype=torch.float32)
+    if window_type == "hanning":
+        return torch.hann_window(window_size, periodic=False, dtype=torch.float32)
+    if window_type == "povey":
+        return torch.hann_window(window_size, periodic=False, dtype=torch.float32).pow(0.85)
+    if window_type == "rectangular":
+        return torch.ones(window_size, dtype=torch.float32)
+    if window_type == "blackman":
+        a = 2 * math.pi / (window_size - 1)
+        i = torch.arange(window_size, dtype=torch.float32)
+        return (blackman_coeff - 0.5 * torch.cos(a * i) + (0.5 - blackman_coeff) * torch.cos(2 * a * i)).to(torch.float32)
+    raise ValueError("Invalid window type " + window_type)
+
+
 def kaldi_fbank(waveform: Tensor, num_mel_bins: int = 80, frame_length_ms: float = 25.0, frame_shift_ms: float = 10.0,
                 sample_frequency: float = 16000.0, preemphasis: float = 0.97, low_freq: float = 20.0,
-                high_freq: float = 0.0, dither: float = 0.0, generator=None) -> Tensor:
-    """Kaldi `compute-fbank-feats` for a [n] float32 waveform (already scaled by 32768), options fixed to what
-    WavFrontend passes (funasr/frontends/wav_frontend.py:171-181): dither 0, snip_edges, remove_dc_offset,
-    hamming, power spectrum, log, energy_floor 0, no energy column. Evaluated the way
+                high_freq: float = 0.0, dither: float = 0.0, generator=None, window_type: str = "hamming",
+                snip_edges: bool = True) -> Tensor:
+    """Kaldi `compute-fbank-feats` for a [n] float32 waveform (already scaled by 32768), options as WavFrontend passes
+    them (funasr/frontends/wav_frontend.py:171-181): dither, window_type and snip_edges from the constructor,
+    remove_dc_offset, power spectrum, log, energy_floor 0, no energy column. Evaluated the way
     torchaudio.compliance.kaldi.fbank does it (float32 torch ops); Kaldi semantics per
-    kaldi-native-fbank/csrc/feature-window.cc:76-90,186-244 and feature-fbank.cc:75-106.
+    kaldi-native-fbank/csrc/feature-window.cc:66-90,152-171,186-244 and feature-fbank.cc:75-106.
     Returns [T_fb, num_mel_bins] float32."""
     wave = waveform.to(torch.float32)
     window_shift = int(sample_frequency * frame_shift_ms * 0.001)
     window_size = int(sample_frequency * frame_length_ms * 0.001)
     padded = _next_pow2(window_size)
     n = wave.numel()
-    if n < window_size:
-        return torch.zeros(0, num_mel_bins)
-    m = 1 + (n - window_size) // window_shift                      # snip_edges (feature-window.cc:76-90)
-    frames = wave.as_strided((m, window_size), (window_shift, 1)).clone()
+    if snip_edges:
+        if n < window_size:
+            return torch.zeros(0, num_mel_bins)
+        m = 1 + (n - window_size) // window_shift                  # feature-window.cc:76-86
+        frames = wave.as_strided((m, window_size), (window_shift, 1)).clone()
+    else:
+        # (n + shift / 2) / shift frames, frame f starts at f * shift + shift / 2 - window / 2 (feature-window.cc:55-64,87-89);
+        # samples outside [0, n) are mirrored: s < 0 -> -s - 1, s >= n -> 2 n - 1 - s (feature-window.cc:152-171)
+        m = (n + window_shift // 2) // window_shift
+        if m == 0:
+            return torch.zeros(0, num_mel_bins)
+        idx = (torch.arange(m)[:, None] * window_shift + (window_shift // 2 - window_size // 2) + torch.arange(window_size)[None, :])
+        while bool(((idx < 0) | (idx >= n)).any()):
+            idx = torch.where(idx < 0, -idx - 1, idx)
+            idx = torch.where(idx >= n, 2 * n - 1 - idx, idx)
+        frames = wave[idx]
     if dither != 0.0:
         # torchaudio.compliance.kaldi._get_window: strided_input + randn(strided_input.shape) * dither -- one draw per
         # (frame, sample), before the DC removal (the reference default, wav_frontend.py:106; statistical parity only)
@@ -79,7 +110,7 @@ def kaldi_fbank(waveform: Tensor, num_mel_bins: int = 80, frame_length_ms: float
     frames = frames - frames.mean(dim=1, keepdim=True)              # remove_dc_offset (:186-196)
     prev = torch.cat([frames[:, :1], frames[:, :-1]], dim=1)        # x[-1] := x[0]  (:204-215)
     frames = frames - preemphasis * prev
-    window = torch.hamming_window(window_size, periodic=False, alpha=0.54, beta=0.46, dtype=torch.float32)
+    window = kaldi_window(window_type, window_size)
     frames = frames * window.unsqueeze(0)
     if padded != window_size:
         frames = F.pad(frames, (0, padded - window_size))
@@ -350,6 +381,11 @@ def paraformer_decoder(memory: Tensor, mem_lens: Tensor, embeds: Tensor, tok_len
         k, v = torch.split(kv, D, dim=-1)
         x = x + F.linear(_mha(q, k, v, mem_mask, H), sd[p + "src_attn.linear_out.weight"],
                          sd[p + "src_attn.linear_out.bias"])
+    # decoders2 (decoder.py:363-380, :436-437): num_blocks - att_layer_num blocks with the FSMN built at sanm_shfit 0, no cross-attention
+    for i in range(max(cfg.get("num_blocks", cfg["att_layer_num"]) - cfg["att_layer_num"], 0)):
+        p = prefix + f"decoders2.{i}."
+        t = _dec_ffn(_ln(x, sd, p + "norm1", eps), sd, p, eps)
+        x = x + _fsmn(_ln(t, sd, p + "norm2", eps), sd[p + "self_attn.fsmn_block.weight"], tgt_mask, (cfg["kernel_size"] - 1) // 2)
     p = prefix + "decoders3.0."
     x = _dec_ffn(_ln(x, sd, p + "norm1", eps), sd, p, eps)
     hidden = _ln(x, sd, prefix + "after_norm", eps)

@@ -41,7 +41,7 @@ def test_ctypes_prototypes_cover_the_header():
 
 def test_load_and_version_and_no_cpu_fallback():
     lib = _lib.load()
-    assert lib.pf_abi_version() == 4
+    assert lib.pf_abi_version() == 5
     if lib.pf_device_count() == 0:
         cfg = _lib.pf_encoder_config(560, 512, 4, 2048, 2, 0, 11, 0, 1e-12)
         h = lib.pf_encoder_create(ctypes.byref(cfg))

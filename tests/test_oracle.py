@@ -55,6 +55,34 @@ def test_fbank_matches_kaldi_native_fbank():
         assert d.mean().item() <= 2e-5, d.mean().item()
 
 
+FBANK_OPTION_CASES = [(w, snip) for w in ("hamming", "hanning", "povey", "rectangular", "blackman") for snip in (True, False)
+                      if not (w == "hamming" and snip)]
+
+
+@pytest.mark.parametrize("window,snip", FBANK_OPTION_CASES)
+def test_fbank_window_and_snip_edges_options_match_kaldi_native_fbank(window, snip):
+    """WavFrontend's `window` / `snip_edges` (wav_frontend.py:178-180) against the reference-vendored kaldi-native-fbank with the same
+    FrameExtractionOptions (oracle/make_golden_fbank_options.py). Same bar as the default options; the rectangular window leaks the
+    residual DC / pre-emphasis edge into every bin, so its near-cancelled mel energies sit at a looser maximum (5e-3)."""
+    g, go = gold("frontend"), gold("fbank_options")
+    for k in ("a", "b"):
+        wave = t(g[f"pcm_{k}"].astype(np.float32) / 32768.0) * 32768.0
+        fb = O.kaldi_fbank(wave, window_type=window, snip_edges=snip)
+        ref = t(go[f"{k}_{window}_{'snip' if snip else 'nosnip'}"])
+        assert fb.shape == ref.shape
+        d = (fb - ref).abs()
+        assert d.max().item() <= (5e-3 if window == "rectangular" else 2e-3), d.max().item()
+        assert d.mean().item() <= 3e-5, d.mean().item()
+
+
+def test_fbank_snip_edges_false_on_less_than_one_window_mirrors_repeatedly():
+    go = gold("fbank_options")
+    fb = O.kaldi_fbank(t(go["short_pcm"].astype(np.float32)), snip_edges=False)
+    ref = t(go["short_hamming_nosnip"])
+    assert fb.shape == ref.shape == (2, 80)
+    assert (fb - ref).abs().max().item() <= 2e-3
+
+
 def test_frontend_lfr_cmvn_on_reference_fbank_bit_exact():
     g = gold("frontend")
     cmvn = t(g["cmvn"])
@@ -125,6 +153,19 @@ def test_decoder_matches_reference():
     sd = synth.decoder_state_dict(cfg, seed=int(g["seed"]))
     logits = O.paraformer_decoder(t(g["memory"]), t(g["mem_lens"]), t(g["embeds"]), t(g["tok_lens"]), sd, cfg)
     assert (logits - t(g["logits"])).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_decoder_with_decoders2_matches_reference(tag):
+    """att_layer_num < num_blocks: the blocks without cross-attention (decoder.py:363-380, :436-437; their FSMN is built at
+    sanm_shfit 0 even when the attention blocks are shifted, case b) against the reference's own class."""
+    g = gold("decoders2")
+    cfg = json.loads(str(g[f"{tag}_cfg"]))
+    sd = synth.decoder_state_dict(cfg, seed=int(g[f"{tag}_seed"]))
+    logits, hidden = O.paraformer_decoder(t(g[f"{tag}_memory"]), t(g[f"{tag}_mem_lens"]), t(g[f"{tag}_embeds"]), t(g[f"{tag}_tok_lens"]),
+                                          sd, cfg, return_hidden=True)
+    assert (logits - t(g[f"{tag}_logits"])).abs().max().item() < 2e-5
+    assert (hidden - t(g[f"{tag}_hidden"])).abs().max().item() < 2e-5
 
 
 def test_pipeline_token_ids_equal_reference():

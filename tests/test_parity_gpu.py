@@ -69,6 +69,69 @@ def test_frontend_vs_reference_features_and_oracle(cuda):
         assert (feats[i, : ol[i]] - of[i, : ol[i]]).abs().max().item() < 5e-4
 
 
+@pytest.mark.parametrize("window,snip", [("povey", True), ("hanning", False), ("rectangular", True), ("blackman", False),
+                                         ("hamming", False)])
+def test_frontend_window_and_snip_edges_options(cuda, window, snip):
+    """WavFrontend(window=, snip_edges=) -> kaldi.fbank(window_type=, snip_edges=) (wav_frontend.py:178-180): frame counts, the
+    mirrored ends and the window against the reference-vendored kaldi-native-fbank run with the same options
+    (tests/golden/fbank_options.npz) and against the oracle; a ragged batch, so the mirror uses each clip's own length."""
+    from funasr_amd.wav_frontend import WavFrontend
+    from oracle import paraformer_oracle as O
+    g, go = gold("frontend"), gold("fbank_options")
+    fe = WavFrontend(cmvn=None, lfr_m=1, lfr_n=1, dither=0.0, window=window, snip_edges=snip)
+    waves = [t(g["pcm_a"].astype(np.float32) / 32768.0), t(g["pcm_b"].astype(np.float32) / 32768.0)]
+    lens = [w.numel() for w in waves]
+    batch = torch.zeros(2, max(lens))
+    for i, w in enumerate(waves):
+        batch[i, : lens[i]] = w
+    feats, flens, fb = fe(batch.to(cuda), lens, return_fbank=True)
+    fb = fb.cpu()
+    bar = 5e-3 if window == "rectangular" else 2e-3
+    for i, k in enumerate("ab"):
+        ref = t(go[f"{k}_{window}_{'snip' if snip else 'nosnip'}"])
+        assert int(flens[i]) == ref.shape[0] == fe.num_fbank_frames(lens[i])
+        d = (fb[i, : ref.shape[0]] - ref).abs()
+        assert d.max().item() <= bar and d.mean().item() <= 3e-5, (d.max().item(), d.mean().item())
+        ofb = O.kaldi_fbank(waves[i] * 32768.0, window_type=window, snip_edges=snip)
+        assert (fb[i, : ref.shape[0]] - ofb).abs().max().item() <= bar
+        assert torch.equal(feats[i, : ref.shape[0]].cpu(), fb[i, : ref.shape[0]])          # lfr 1 / 1, no CMVN: the log-mel itself
+    if not snip:        # fewer samples than one window: the ends mirror more than once (feature-window.cc:152-171)
+        short = t(go["short_pcm"].astype(np.float32) / 32768.0)
+        _, sl, sfb = fe(short[None].to(cuda), [short.numel()], return_fbank=True)
+        if window == "hamming":
+            assert int(sl[0]) == 2 and (sfb[0].cpu() - t(go["short_hamming_nosnip"])).abs().max().item() <= 2e-3
+        ofb = O.kaldi_fbank(short * 32768.0, window_type=window, snip_edges=False)
+        assert (sfb[0].cpu() - ofb).abs().max().item() <= bar
+
+
+def test_frontend_window_by_name_at_the_c_abi(cuda):
+    """pf_frontend_set_window evaluates the named window as kaldi-native-fbank does (float64 cosines): against the same goldens."""
+    import ctypes as C
+    from funasr_amd import _lib
+    g, go = gold("frontend"), gold("fbank_options")
+    lib = _lib.load()
+    cfg = _lib.pf_frontend_config(16000, 400, 160, 80, 1, 1, 20.0, 0.0, 0.97, 32768.0)
+    wave = t(g["pcm_b"].astype(np.float32) / 32768.0).to(cuda)
+    with torch.cuda.device(cuda):
+        h = _lib.check_handle(lib.pf_frontend_create(C.byref(cfg)), "pf_frontend_create")
+        try:
+            assert lib.pf_frontend_set_window(h, b"triangle", 0.42) != 0
+            for window in ("povey", "blackman", "hanning", "rectangular", "hamming"):
+                _lib.check(lib.pf_frontend_set_window(h, window.encode(), 0.42), "pf_frontend_set_window")
+                for snip in (1, 0):
+                    _lib.check(lib.pf_frontend_set_snip_edges(h, snip), "pf_frontend_set_snip_edges")
+                    n = lib.pf_frontend_num_fbank_frames(h, wave.numel())
+                    ref = t(g["fbank_knf_b"]) if (window == "hamming" and snip) else t(go[f"b_{window}_{'snip' if snip else 'nosnip'}"])
+                    assert n == ref.shape[0]
+                    out = torch.empty(n, 80, device=cuda)
+                    _lib.check(lib.pf_frontend_fbank(h, wave.data_ptr(), wave.numel(), out.data_ptr(), None), "pf_frontend_fbank")
+                    torch.cuda.synchronize()
+                    d = (out.cpu() - ref).abs()
+                    assert d.max().item() <= (5e-3 if window == "rectangular" else 2e-3), (window, snip, d.max().item())
+        finally:
+            lib.pf_frontend_destroy(h)
+
+
 def test_frontend_ragged_batch_equals_single_utterance_bitwise(cuda):
     """Utterance-level data parallelism: a clip's features do not depend on its batch neighbours."""
     from funasr_amd.wav_frontend import WavFrontend
@@ -233,6 +296,49 @@ def test_decoder_vs_reference_golden(cuda, f32_mode):
     for b in range(ids.shape[0]):
         n = int(g["tok_lens"][b])
         assert ids[b, :n].cpu().tolist() == ref_ids[b, :n].tolist()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_decoder_with_decoders2_vs_reference_golden(cuda, f32_mode, tag):
+    """att_layer_num < num_blocks (decoder.py:363-380, :436-437): pf_decoder_set_decoders2 -- blocks of FFN + FSMN without
+    cross-attention after the attention blocks, their taps centred whatever sanm_shfit says (case b) -- against the reference's own
+    ParaformerSANMDecoder (tests/golden/decoders2.npz), logits, hidden states and the fused arg-max route."""
+    from funasr_amd.paraformer_decoder import ParaformerSANMDecoder
+    g = gold("decoders2")
+    cfg = json.loads(str(g[f"{tag}_cfg"]))
+    d = ParaformerSANMDecoder(**cfg)
+    assert d.decoders2 is not None and len(d.decoders2) == cfg["num_blocks"] - cfg["att_layer_num"]
+    d.load_state_dict(synth.decoder_state_dict(cfg, seed=int(g[f"{tag}_seed"]), with_embed=True), strict=True)
+    d = d.to(cuda).set_precision(f32_mode)
+    args = (t(g[f"{tag}_memory"]).to(cuda), t(g[f"{tag}_mem_lens"]), t(g[f"{tag}_embeds"]).to(cuda), t(g[f"{tag}_tok_lens"]))
+    logits, hidden, olens = d(*args, return_both=True)
+    assert olens.tolist() == g[f"{tag}_tok_lens"].tolist()
+    ref_logits, ref_hidden = t(g[f"{tag}_logits"]), t(g[f"{tag}_hidden"])
+    for b in range(logits.shape[0]):
+        n = int(g[f"{tag}_tok_lens"][b])                         # rows past a sequence's length are masked garbage on both sides
+        assert (logits[b, :n].cpu() - ref_logits[b, :n]).abs().max().item() < 2e-4
+        assert (hidden[b, :n].cpu() - ref_hidden[b, :n]).abs().max().item() < 2e-4
+    ids, _ = d.greedy(*args)
+    ref_ids = ref_logits.argmax(-1)
+    for b in range(ids.shape[0]):
+        n = int(g[f"{tag}_tok_lens"][b])
+        assert ids[b, :n].cpu().tolist() == ref_ids[b, :n].tolist()
+
+
+def test_decoder_with_decoders2_bf16_mode_close_to_reference(cuda):
+    from funasr_amd.paraformer_decoder import ParaformerSANMDecoder
+    g = gold("decoders2")
+    cfg = json.loads(str(g["a_cfg"]))
+    d = ParaformerSANMDecoder(**cfg)
+    d.load_state_dict(synth.decoder_state_dict(cfg, seed=int(g["a_seed"]), with_embed=True), strict=True)
+    d = d.to(cuda).set_precision("bf16")
+    args = (t(g["a_memory"]).to(cuda), t(g["a_mem_lens"]), t(g["a_embeds"]).to(cuda), t(g["a_tok_lens"]))
+    hid, _ = d(*args, return_hidden=True)
+    ref = t(g["a_hidden"])
+    for b in range(hid.shape[0]):
+        n = int(g["a_tok_lens"][b])
+        dd = (hid[b, :n].cpu() - ref[b, :n]).abs()
+        assert dd.mean().item() < 0.03 * ref[b, :n].abs().mean().item()       # bf16 operands: the bar of the other bf16-mode tests
 
 
 # ---------------------------------------------------------------------------------------------------- pipeline
