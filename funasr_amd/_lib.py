@@ -100,6 +100,8 @@ SIGNATURES = {
     "pf_frontend_faults": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "pf_frontend_fault_log": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "pf_frontend_set_tables": (C.c_int, [_vp, _vp, _vp]),
+    "pf_utterance_mvn": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "pf_global_mvn": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "pf_frontend_set_window": (C.c_int, [_vp, C.c_char_p, _f32]),
     "pf_frontend_set_snip_edges": (C.c_int, [_vp, _i32]),
     "pf_frontend_num_fbank_frames": (_i32, [_vp, _i64]),

@@ -16,8 +16,8 @@ def hip_classes():
     (funasr_amd.register.tables) holds after its modules are imported -- frontends, encoders, predictors (V2, V3), decoder,
     the model classes (Paraformer, BiCifParaformer, SeacoParaformer, ParaformerStreaming, SenseVoiceSmall,
     FsmnVADStreaming, CTTransformer, CTTransformerStreaming) and the tokenizers."""
-    from . import (bicif_paraformer, cif_predictor, contextual_paraformer, ct_transformer, fsmn_vad, paraformer, paraformer_decoder,  # noqa: F401
-                   paraformer_streaming, sanm_encoder, seaco_paraformer, sense_voice, tokenizer, wav_frontend)
+    from . import (bicif_paraformer, cif_predictor, contextual_paraformer, ct_transformer, fsmn_vad, normalize, paraformer,  # noqa: F401
+                   paraformer_decoder, paraformer_streaming, sanm_encoder, seaco_paraformer, sense_voice, tokenizer, wav_frontend)
     from .register import TABLE_NAMES, tables as own
 
     out = []

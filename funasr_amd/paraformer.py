@@ -50,8 +50,6 @@ class Paraformer(nn.Module):
                  sampling_ratio: float = 0.2, share_embedding: bool = False, use_1st_decoder_loss: bool = False,
                  **kwargs):
         super().__init__()
-        if normalize is not None:
-            raise NotImplementedError("Paraformer(HIP): utterance-MVN `normalize` is not part of the published recipes")
         enc_conf = dict(encoder_conf or {})
         enc_conf.pop("input_size", None)
         self.encoder = tables.encoder_classes.get(encoder)(input_size=input_size, **enc_conf)
@@ -65,6 +63,9 @@ class Paraformer(nn.Module):
         self.sos = sos if sos is not None else vocab_size - 1
         self.eos = eos if eos is not None else vocab_size - 1
         self.ctc, self.specaug, self.normalize = None, None, None
+        if normalize is not None:                            # model.py:128-130: UtteranceMVN / GlobalMVN (funasr_amd/normalize.py)
+            from . import normalize as _normalize  # noqa: F401  (registers normalize_classes)
+            self.normalize = tables.normalize_classes.get(normalize)(**(normalize_conf or {}))
         if ctc_weight > 0.0:                                 # model.py:109-111: the CTC head exists only then
             from .ctc import CTC
             self.ctc = CTC(odim=vocab_size, encoder_output_size=d, **(ctc_conf or {}))
@@ -110,8 +111,16 @@ class Paraformer(nn.Module):
         if hasattr(self.encoder, "set_row_packing"):
             v2_only = type(self.predictor).__name__ == "CifPredictorV2"
             self.encoder.set_row_packing(max(1, int(self.predictor.r_order)) if (v2_only and not all_rows) else self.encoder.ALL_ROWS)
+        speech, speech_lengths = self._normalized(speech, speech_lengths)
         out, olens, _ = self.encoder(speech, speech_lengths)
         return out, olens
+
+    def _normalized(self, speech: torch.Tensor, speech_lengths):
+        """model.py:304-306: feature normalisation (Global-CMVN / Utterance-CMVN) in front of the encoder, in place like the reference"""
+        if self.normalize is None:
+            return speech, speech_lengths
+        dev = self.encoder._device() if hasattr(self.encoder, "_device") else speech.device
+        return self.normalize(speech.to(device=dev, dtype=torch.float32).contiguous(), speech_lengths)
 
     # what `inference` returns when no utterance of the batch predicts a token: the reference returns a BARE empty list there
     # (model.py:615-616; bicif_paraformer/model.py:342-343, contextual_paraformer/model.py:460-461), which AutoModel.inference
@@ -176,6 +185,8 @@ class Paraformer(nn.Module):
         self.decoder._apply_settings()
         dev = enc_m._handle_device
         xs = speech.to(device=dev, dtype=torch.float32).contiguous()
+        if self.normalize is not None:
+            xs, speech_lengths = self.normalize(xs, speech_lengths)
         B, T, Din = xs.shape
         if Din != enc_m._input_size:
             raise ValueError(f"expected feature dim {enc_m._input_size}, got {Din}")

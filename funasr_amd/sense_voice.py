@@ -62,8 +62,12 @@ class SenseVoiceSmall(nn.Module):
                  input_size: int = 80, vocab_size: int = -1, ignore_id: int = -1, blank_id: int = 0, sos: int = 1,
                  eos: int = 2, length_normalized_loss: bool = False, **kwargs):
         super().__init__()
+        # built like the reference (sense_voice/model.py:705-707,722) -- and like there used by the training `encode` only: `inference`
+        # goes from the frontend straight to the encoder (model.py:998), so no feature normalisation is applied on this path
+        self.normalize = None
         if normalize is not None:
-            raise NotImplementedError("SenseVoiceSmall(HIP): `normalize` is not part of the published recipe")
+            from . import normalize as _normalize  # noqa: F401  (registers normalize_classes)
+            self.normalize = tables.normalize_classes.get(normalize)(**(normalize_conf or {}))
         enc_conf = dict(encoder_conf or {})
         enc_conf.pop("input_size", None)
         self.encoder = tables.encoder_classes.get(encoder)(input_size=input_size, **enc_conf)

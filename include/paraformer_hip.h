@@ -54,7 +54,8 @@ extern "C" {
  * pf_k_* measurement entries. A library reporting 1 has none of them.
  * 3 (round 6): + pf_paraformer_begin / pf_paraformer_finish (the split-phase offline forward).
  * 4: + pf_predictor_alphas_begin / pf_predictor_embeds_slot.
- * 5: + pf_frontend_set_window / pf_frontend_set_snip_edges, pf_decoder_set_decoders2. */
+ * 5: + pf_frontend_set_window / pf_frontend_set_snip_edges, pf_decoder_set_decoders2,
+ *    pf_utterance_mvn / pf_global_mvn. */
 #define PF_ABI_VERSION 5
 
 const char* pf_last_error(void);
@@ -123,6 +124,18 @@ int32_t pf_frontend_num_frames(const pf_frontend* f, int64_t n_samples);
 int pf_frontend_forward(pf_frontend* f, const float* wav_dev, int64_t wav_stride, const int32_t* n_samples_host,
                         int32_t B, float* feats_dev, int32_t T_out, int32_t* feat_lens_host, float* fbank_dev,
                         void* stream);
+
+/* ---------------------------------------------------------------------------------- feature normalisation (normalize_classes)
+ * The reference's `normalize` modules, applied between the frontend and the encoder (funasr/models/paraformer/model.py:305-306,
+ * sense_voice/model.py:836-837). In place on x_dev [B, T, D]; lens_dev: device int32 [B]. No sync.
+ * pf_utterance_mvn = UtteranceMVN (funasr/models/normalize/utterance_mvn.py:51-96), its arithmetic step by step -- including that
+ * with norm_means the padded rows come out as -mean and, with norm_vars as well, take part in the variance and the divisor is
+ * sqrt(std). pf_global_mvn = GlobalMVN.forward (global_mvn.py:66-92) with the mean / std vectors [D] the class derives from its
+ * stats file: (x - mean), padded rows zero, / std -- bit-exact. */
+int pf_utterance_mvn(float* x_dev, const int32_t* lens_dev, int32_t B, int32_t T, int32_t D, int32_t norm_means, int32_t norm_vars,
+                     float eps, void* stream);
+int pf_global_mvn(float* x_dev, const int32_t* lens_dev, int32_t B, int32_t T, int32_t D, const float* mean_dev, const float* std_dev,
+                  int32_t norm_means, int32_t norm_vars, void* stream);
 
 /* ------------------------------------------------------------------------------------------------- encoder */
 typedef struct pf_encoder pf_encoder;

@@ -166,6 +166,49 @@ def apply_cmvn(feats: Tensor, cmvn: Tensor) -> Tensor:
     return ((feats + cmvn[0:1, :d]) * cmvn[1:2, :d]).to(torch.float32)
 
 
+def utterance_mvn(x: Tensor, ilens: Optional[Tensor] = None, norm_means: bool = True, norm_vars: bool = False,
+                  eps: float = 1.0e-20) -> Tensor:
+    """UtteranceMVN at inference, funasr/models/normalize/utterance_mvn.py:51-96, step by step -- including that with norm_means
+    the padded rows come out as -mean and (with norm_vars too) take part in the variance, whose divisor is sqrt(std) (:85-87).
+    x [B, T, D] -> a new tensor (the reference works in place)."""
+    x = x.clone()
+    B, T = x.shape[:2]
+    if ilens is None:
+        ilens = torch.full((B,), T)
+    lens_f = ilens.to(x.dtype).view(-1, 1, 1)
+    pad = torch.arange(T)[None, :, None] >= ilens.to(torch.int64).view(-1, 1, 1)
+    x = x.masked_fill(pad, 0.0)
+    mean = x.sum(dim=1, keepdim=True) / lens_f
+    if norm_means:
+        x = x - mean
+        if norm_vars:
+            var = x.pow(2).sum(dim=1, keepdim=True) / lens_f
+            std = torch.clamp(var.sqrt(), min=eps)
+            x = x / std.sqrt()
+        return x
+    if norm_vars:
+        y = (x - mean).masked_fill(pad, 0.0)
+        var = y.pow(2).sum(dim=1, keepdim=True) / lens_f
+        x = x / torch.clamp(var.sqrt(), min=eps)
+    return x
+
+
+def global_mvn(x: Tensor, ilens: Optional[Tensor], mean: Tensor, std: Tensor, norm_means: bool = True,
+               norm_vars: bool = True) -> Tensor:
+    """GlobalMVN.forward, funasr/models/normalize/global_mvn.py:66-92: x - mean, padded rows zero, / std (mean / std in x's dtype)."""
+    x = x.clone()
+    B, T = x.shape[:2]
+    if ilens is None:
+        ilens = torch.full((B,), T)
+    pad = torch.arange(T)[None, :, None] >= ilens.to(torch.int64).view(-1, 1, 1)
+    if norm_means:
+        x = x - mean.to(x.dtype)
+    x = x.masked_fill(pad, 0.0)
+    if norm_vars:
+        x = x / std.to(x.dtype)
+    return x
+
+
 def wav_frontend(waves: Sequence[Tensor], cmvn: Optional[Tensor], n_mels: int = 80, frame_length: int = 25,
                  frame_shift: int = 10, lfr_m: int = 7, lfr_n: int = 6, fs: int = 16000,
                  return_fbank: bool = False):
