@@ -112,14 +112,11 @@ class ContextualParaformer(Paraformer):
         self._hw_cache = {}
 
     # --------------------------------------------------------------------------------------------------- hotwords
-    def init_beam_search(self, **kwargs):
-        """The reference passes the hotword list to the decoder on the beam-search route too (contextual_paraformer/model.py);
-        here that route is not built for the contextual decoder: refuse at configuration time instead of failing inside the
-        decoder call of the first utterance."""
-        if kwargs.get("decoding_ctc_weight", 0.0) > 0.0 and getattr(self, "ctc", None) is not None:
-            raise NotImplementedError("ContextualParaformer(HIP): beam search with CTC rescoring (decoding_ctc_weight > 0) is not "
-                                      "built for the contextual decoder; use greedy decoding (decoding_ctc_weight = 0)")
-        return super().init_beam_search(**kwargs)
+    def _decoder_logits(self, enc, olens, embeds, tok) -> torch.Tensor:
+        """The beam-search route ranks the hotword-biased scores too: the reference hands hw_list / clas_scale to
+        cal_decoder_with_predictor before either branch (contextual_paraformer/model.py:467-494)."""
+        hw = self._hotword_embeddings(self.hotword_list)
+        return self.decoder(enc, olens, embeds, tok, contextual_info=hw[None], clas_scale=self.clas_scale)[0]
 
     def generate_hotwords_list(self, hotword_list_or_file, tokenizer=None, frontend=None) -> Optional[List[List[int]]]:
         """model.py:534-657: a local .txt file (one hotword per line) or a space-separated string; every entry is tokenised

@@ -305,7 +305,7 @@ class Paraformer(nn.Module):
             out.update(enc=enc, olens=olens, embeds=embeds, alphas=alphas, peaks=peaks)
         if max(tok) < 1:
             return out
-        logits, _ = self.decoder(enc, olens, embeds, torch.tensor(tok))
+        logits = self._decoder_logits(enc, olens, embeds, tok)
         am = ops.log_softmax(logits.contiguous(), inplace=True).cpu()          # one D2H copy of the batch's scores
         ctc_logp = self.ctc.log_softmax(enc).cpu().numpy() if (self.ctc is not None and self.beam_search.w_ctc != 0) else None
         for i in range(B):
@@ -314,6 +314,11 @@ class Paraformer(nn.Module):
             lp = ctc_logp[i, : int(olens[i])] if ctc_logp is not None else None
             out["nbest"][i] = self.beam_search(am[i, : tok[i]], lp, maxlenratio=maxlenratio, minlenratio=minlenratio)[: self.nbest]
         return out
+
+    def _decoder_logits(self, enc, olens, embeds, tok) -> torch.Tensor:
+        """the decoder scores the beam search ranks (cal_decoder_with_predictor, model.py:326-346); subclasses with other decoder
+        inputs (ContextualParaformer: the hotword embeddings) override"""
+        return self.decoder(enc, olens, embeds, torch.tensor(tok))[0]
 
     # ---------------------------------------------------------------------------------------------- AutoModel API
     def _wants_beam(self, kwargs) -> None:

@@ -74,3 +74,40 @@ def test_contextual_paraformer_on_the_gpu_equals_reference_inference(cuda, tmp_p
         want = json.loads(str(g[name]))
         assert [r["text"] for r in res] == [w["text"] for w in want], (name, res, want)
         assert [r["key"] for r in res] == [w["key"] for w in want]
+
+
+@pytest.mark.gpu
+def test_contextual_beam_search_on_the_gpu_equals_reference_inference(cuda, tmp_path):
+    """The CTC-rescored beam search over the hotword-biased decoder scores (contextual_paraformer/model.py:408-415,467-494;
+    init_beam_search paraformer/model.py:482-532) against the n-best texts the REFERENCE classes' own `inference` produced
+    (tests/golden/contextual_beam.npz, oracle/make_golden_contextual_beam.py): with and without hotwords, 2-best of beam 3."""
+    from funasr_amd.contextual_paraformer import ContextualParaformer
+    from funasr_amd.tokenizer import CharTokenizer
+    from oracle.make_golden_contextual import contextual_state_dict
+    from oracle.make_golden_contextual_beam import ctc_state_dict
+    g = np.load(os.path.join(os.path.dirname(GOLD), "contextual_beam.npz"), allow_pickle=False)
+    cfg, vocab = json.loads(str(g["cfg"])), json.loads(str(g["vocab"]))
+    sd = contextual_state_dict(cfg, int(g["seed"]))
+    sd.update(ctc_state_dict(cfg, int(g["seed"])))
+    ec = dict(cfg["encoder"]); input_size = ec.pop("input_size")
+    dc = dict(cfg["decoder"]); V = dc.pop("vocab_size"); dc.pop("encoder_output_size", None)
+    tok = CharTokenizer(token_list=vocab, unk_symbol="<unk>")
+    feats, lens = torch.from_numpy(g["feats"]).to(cuda), torch.from_numpy(g["lens"])
+    seg = {ch: ch for ch in vocab[3:-10]}
+    seg.update({"hello": "hel@@ lo", "world": "wor@@ ld", "the": "the"})
+    with open(tmp_path / "seg_dict", "w", encoding="utf-8") as f:
+        f.write("".join(f"{k} {v}\n" for k, v in seg.items()))
+    fe = _Frontend()
+    fe.cmvn_file = str(tmp_path / "am.mvn")
+    keys = [f"utt{b}" for b in range(3)]
+    beam_kw = json.loads(str(g["beam_kw"]))
+    for name, kw in (("beam_hot", dict(hotword=str(g["hotwords"]))), ("beam_plain", dict())):
+        model = ContextualParaformer(encoder="SANMEncoder", encoder_conf=dict(ec, input_layer="pe"), decoder="ContextualParaformerDecoder",
+                                     decoder_conf=dc, predictor="CifPredictorV2", predictor_conf=dict(cfg["predictor"]), ctc_weight=0.3,
+                                     input_size=input_size, vocab_size=V, inner_dim=512, bias_encoder_type="lstm")
+        model.load_state_dict(sd, strict=True)
+        model = model.to(cuda)
+        res, _ = model.inference(feats, data_lengths=lens, key=keys, tokenizer=tok, frontend=fe, data_type="fbank", token_list=vocab,
+                                 **beam_kw, **kw)
+        want = json.loads(str(g[name]))
+        assert [(r["key"], r["text"]) for r in res] == [(w["key"], w["text"]) for w in want], (name, res, want)
