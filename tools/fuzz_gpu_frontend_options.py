@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Frontend fuzz on the GPU: random ragged batches (1 .. 50 000 samples per clip, down to fewer samples than one window with
+snip_edges=False), every window type, snip_edges either way, LFR on and off, against the CPU oracle's kaldi_fbank / apply_lfr / apply_cmvn
+(itself pinned to the reference-vendored kaldi-native-fbank in tests/test_oracle.py). Not part of the test run.
+usage: fuzz_gpu_frontend_options.py [seed] [cases]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from funasr_amd import synth                           # noqa: E402
+from funasr_amd.wav_frontend import WINDOW_TYPES, WavFrontend   # noqa: E402
+from oracle import paraformer_oracle as O              # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+sh, sc = synth.synthetic_cmvn()
+worst, bad = 0.0, 0
+for ci in range(n_cases):
+    window = WINDOW_TYPES[int(torch.randint(0, len(WINDOW_TYPES), (1,), generator=g))]
+    snip = bool(torch.randint(0, 2, (1,), generator=g))
+    lfr = bool(torch.randint(0, 2, (1,), generator=g))
+    B = int(torch.randint(1, 7, (1,), generator=g))
+    lo = 400 if snip else 81                            # snip_edges=False: at least one frame needs (n + 80) // 160 >= 1
+    lens = [int(torch.randint(lo, 50001 if ci % 3 else 1200, (1,), generator=g)) for _ in range(B)]
+    waves = [synth.speech_like(n, seed=1000 * ci + i) for i, n in enumerate(lens)]
+    batch = torch.zeros(B, max(lens))
+    for i, w in enumerate(waves):
+        batch[i, : lens[i]] = w
+    fe = WavFrontend(cmvn=torch.stack([sh, sc]) if lfr else None, lfr_m=7 if lfr else 1, lfr_n=6 if lfr else 1, dither=0.0,
+                     window=window, snip_edges=snip)
+    feats, flens, fb = fe(batch.to(dev), lens, return_fbank=True)
+    feats, fb = feats.cpu(), fb.cpu()
+    ok = True
+    for i, w in enumerate(waves):
+        ofb = O.kaldi_fbank(w * 32768.0, window_type=window, snip_edges=snip)
+        ok = ok and ofb.shape[0] == fe.num_fbank_frames(lens[i])
+        d = (fb[i, : ofb.shape[0]] - ofb).abs().max().item() if ofb.shape[0] else 0.0
+        of = O.apply_cmvn(O.apply_lfr(ofb, 7, 6), torch.stack([sh, sc])) if lfr else ofb
+        ok = ok and int(flens[i]) == of.shape[0]
+        d2 = (feats[i, : of.shape[0]] - of).abs().max().item()
+        ok = ok and bool((feats[i, of.shape[0]:] == 0).all())
+        worst = max(worst, d)
+        # near-cancelled mel energies of the rectangular window: the looser bar of tests/test_oracle.py
+        if d > (2e-2 if window == "rectangular" else 4e-3) or d2 > (2e-2 if window == "rectangular" else 4e-3):
+            ok = False
+    if not ok:
+        bad += 1
+        print(f"case {ci} window={window} snip={snip} lfr={lfr} lens={lens}: MISMATCH (worst so far {worst:.2e})")
+print(json.dumps(dict(tool="fuzz_gpu_frontend_options", cases=n_cases, bad=bad, worst_logmel_abs_diff=worst)))
+sys.exit(1 if bad else 0)

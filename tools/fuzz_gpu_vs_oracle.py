@@ -19,6 +19,7 @@ worst, bad, n_packed, near_ties = {"fp32": 0.0, "bf16x3": 0.0, "f16x2": 0.0}, 0,
 for ci in range(n_cases):
     cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=int(torch.randint(1, 4, (1,), generator=g)),
                      dec_blocks=int(torch.randint(1, 3, (1,), generator=g)), vocab=int(torch.randint(30, 300, (1,), generator=g)))
+    cfg["decoder"]["num_blocks"] += int(torch.randint(0, 3, (1,), generator=g))        # 0..2 decoders2 blocks (no cross-attention)
     sd = synth.paraformer_state_dict(cfg, seed=500 + ci, cif_bias=float(torch.rand(1, generator=g)) * 0.8 - 0.2)
     model = Paraformer.from_config(cfg)
     model.load_state_dict(sd, strict=False)
