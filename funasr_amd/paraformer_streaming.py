@@ -43,6 +43,12 @@ from .wav_frontend import WavFrontend
 class WavFrontendOnline(WavFrontend):
     """forward(input [1, n], input_lengths, cache=<dict>, is_final=bool) -> (feats [1, t, n_mels*lfr_m] | empty, lens)"""
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # the online class stores `snip_edges` and never passes it to kaldi.fbank (wav_frontend.py:316,441-450): frames always lie
+        # inside the samples seen so far (compute_frame_num, :393-399), whatever the option says; `window` IS passed (:449)
+        self.snip_edges_option, self.snip_edges = self.snip_edges, True
+
     def init_cache(self, cache: dict = None):
         if cache is None:
             cache = {}
