@@ -89,6 +89,18 @@ def kaldi_tables(n_mels: int, window_size: int, fs: float, low_freq: float = 20.
     return window.contiguous(), torch.nn.functional.pad(bins, (0, 1)).contiguous()
 
 
+def mel_on_the_512_grid(mel: torch.Tensor) -> torch.Tensor:
+    """[n_mels, P/2 + 1] weights over the bins of a P-point FFT (P = 2 .. 512) as a dense [n_mels, 257] matrix over the bins of the
+    kernel's 512-point FFT: the zero-padded 512-point transform of a frame holds the P-point one at every (512 / P)-th bin exactly
+    (X_512[k 512/P] = X_P[k]), so a shorter window's mel energies are the same sums with the weights placed at those bins."""
+    P = 2 * (mel.shape[1] - 1)
+    if P == 512:
+        return mel.contiguous()
+    out = torch.zeros(mel.shape[0], 257, dtype=mel.dtype)
+    out[:, :: 512 // P] = mel
+    return out
+
+
 @tables.register("frontend_classes", "wav_frontend")
 @tables.register("frontend_classes", "WavFrontend")
 class WavFrontend(nn.Module):
@@ -96,8 +108,12 @@ class WavFrontend(nn.Module):
                  frame_length: int = 25, frame_shift: int = 10, filter_length_min: int = -1,
                  filter_length_max: int = -1, lfr_m: int = 1, lfr_n: int = 1, dither: float = 0.0,
                  snip_edges: bool = True, upsacle_samples: bool = True, cmvn: torch.Tensor = None,
-                 device=None, dither_seed: int = None, verify: bool = None, **kwargs):
+                 device=None, dither_seed: int = None, verify: bool = None, window_samples: int = None, **kwargs):
         super().__init__()
+        # window_samples: the analysis window in samples instead of frame_length ms -- the per-clip window of clips shorter than
+        # frame_length (wav_frontend.py:176); used by this class for its own short-clip children
+        self._win_override = None if window_samples is None else int(window_samples)
+        self._short = {}
         # verify: the fbank kernel evaluates every frame twice and repeats until two runs agree (pf_frontend_set_verify): for a GPU
         # this process SHARES with another one. None = on exactly when the launcher says so (PF_FRONTEND_VERIFY=1)
         self.verify = bool(int(os.environ.get("PF_FRONTEND_VERIFY", "0"))) if verify is None else bool(verify)
@@ -143,12 +159,13 @@ class WavFrontend(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("WavFrontend runs only on an AMD GPU through libparaformer_hip.so (no CPU fallback)")
         self.close()
-        win = int(self.fs * self.frame_length * 0.001)
+        win = self._win_override or int(self.fs * self.frame_length * 0.001)
         cfg = _lib.pf_frontend_config(self.fs, win, int(self.fs * self.frame_shift * 0.001), self.n_mels, self.lfr_m,
                                       self.lfr_n, 20.0, 0.0, 0.97, float(1 << 15) if self.upsacle_samples else 1.0)
         with torch.cuda.device(dev):
             h = _lib.check_handle(lib.pf_frontend_create(C.byref(cfg)), "pf_frontend_create")
             w, mel = kaldi_tables(self.n_mels, win, float(self.fs), window_type=self.window)
+            mel = mel_on_the_512_grid(mel)
             _lib.check(lib.pf_frontend_set_tables(h, w.data_ptr(), mel.data_ptr()), "pf_frontend_set_tables")
             if not self.snip_edges:
                 _lib.check(lib.pf_frontend_set_snip_edges(h, 0), "pf_frontend_set_snip_edges")
@@ -179,6 +196,12 @@ class WavFrontend(nn.Module):
         except Exception:
             pass
 
+    def __getstate__(self):
+        # device handles (this object's and the short-clip children's) are not part of a pickle or a deep copy: the copy makes its own
+        st = dict(self.__dict__)
+        st["_handle"], st["_handle_device"], st["_short"] = None, None, {}
+        return st
+
     def _target_device(self, x: torch.Tensor) -> torch.device:
         if x.is_cuda:
             return x.device
@@ -191,10 +214,23 @@ class WavFrontend(nn.Module):
     def num_fbank_frames(self, n_samples: int) -> int:
         """Kaldi's NumFrames (feature-window.cc:66-90): whole windows inside the waveform, or with snip_edges=False one frame per
         shift, centred, the ends mirrored"""
-        win, hop = int(self.fs * self.frame_length * 0.001), int(self.fs * self.frame_shift * 0.001)
+        win, hop = self.window_samples(n_samples), int(self.fs * self.frame_shift * 0.001)
         if not self.snip_edges:
             return (n_samples + hop // 2) // hop
         return 0 if n_samples < win else 1 + (n_samples - win) // hop
+
+    def window_samples(self, n_samples: int) -> int:
+        """The analysis window of a clip of n_samples: `frame_length=min(self.frame_length, waveform_length / self.fs * 1000)`
+        (wav_frontend.py:176; waveform_length is a 0-dim integer tensor there, so the right-hand side is float32 tensor arithmetic and
+        torchaudio's int(sample_frequency * frame_length * 0.001) truncates a float32 product) -- a clip shorter than frame_length
+        ms is analysed with one window of its own length, and the FFT size follows."""
+        win = int(self.fs * self.frame_length * 0.001)
+        if self._win_override is not None:
+            return self._win_override
+        if n_samples >= win:
+            return win
+        ms = torch.tensor(int(n_samples)) / self.fs * 1000
+        return win if not bool(ms < self.frame_length) else int(float(self.fs) * ms * 0.001)
 
     def num_frames(self, n_samples: int) -> int:
         return (self.num_fbank_frames(n_samples) + self.lfr_n - 1) // self.lfr_n
@@ -207,9 +243,12 @@ class WavFrontend(nn.Module):
         wav = input.to(device=dev, dtype=torch.float32).contiguous()
         B, n_max = wav.shape
         lens_c, lens = host_i32(input_lengths, B)
+        win = self._win_override or int(self.fs * self.frame_length * 0.001)
+        if any(self.window_samples(n) != win for n in lens):
+            return self._forward_with_short_clips(wav, lens, win, return_fbank)
         T = max(self.num_frames(n) for n in lens)
         if T <= 0:
-            raise ValueError("WavFrontend: every utterance must be at least one analysis window (25 ms) long")
+            raise ValueError("WavFrontend: every utterance must hold at least one frame")
         feats = torch.empty(B, T, self.output_size(), device=dev, dtype=torch.float32)
         out_lens = (C.c_int32 * B)()
         fb = None
@@ -224,3 +263,49 @@ class WavFrontend(nn.Module):
         if return_fbank:
             return feats, feats_lens, fb
         return feats, feats_lens
+
+    def _forward_with_short_clips(self, wav: torch.Tensor, lens, win: int, return_fbank: bool):
+        """A batch that holds clips shorter than frame_length ms (a VAD segment of a few milliseconds): the reference's loop gives
+        each of them its own window (`window_samples`); here the other clips go through the batched launch and every short one through
+        a child frontend built for its window length (cached per length), and the rows are put together like pad_sequence does."""
+        B = wav.shape[0]
+        dev = wav.device
+        for n in lens:
+            if self.window_samples(n) < 2:                          # torchaudio: assert 2 <= window_size
+                raise ValueError(f"WavFrontend: a clip of {n} sample(s) has no analysis window (window size must be >= 2)")
+        T = max(self.num_frames(n) for n in lens)
+        if T <= 0:
+            raise ValueError("WavFrontend: every utterance must hold at least one frame")
+        feats = torch.zeros(B, T, self.output_size(), device=dev, dtype=torch.float32)
+        flens = [0] * B
+        fb = torch.zeros(B, max(self.num_fbank_frames(n) for n in lens), self.n_mels, device=dev, dtype=torch.float32) if return_fbank else None
+        groups = {}
+        for i, n in enumerate(lens):
+            groups.setdefault(self.window_samples(n), []).append(i)
+        for ws, idx in groups.items():
+            fe = self if ws == win else self._short_clip_frontend(ws)
+            sub_lens = [lens[i] for i in idx]
+            sub = wav[idx][:, : max(sub_lens)].contiguous()
+            out = fe.forward(sub, sub_lens, return_fbank=return_fbank)
+            for j, i in enumerate(idx):
+                t = int(out[1][j])
+                feats[i, :t] = out[0][j, :t]
+                flens[i] = t
+                if return_fbank:
+                    tf = fe.num_fbank_frames(lens[i])
+                    fb[i, :tf] = out[2][j, :tf]
+        feats_lens = torch.tensor(flens, dtype=torch.int32)
+        if return_fbank:
+            return feats, feats_lens, fb
+        return feats, feats_lens
+
+    def _short_clip_frontend(self, ws: int) -> "WavFrontend":
+        fe = self._short.get(ws)
+        if fe is None:
+            if len(self._short) >= 32:                              # one handle per distinct length: keep the set small
+                self._short.pop(next(iter(self._short))).close()
+            fe = self._short[ws] = WavFrontend(cmvn=self.cmvn, fs=self.fs, window=self.window, n_mels=self.n_mels, frame_length=self.frame_length,
+                                               frame_shift=self.frame_shift, lfr_m=self.lfr_m, lfr_n=self.lfr_n, dither=self.dither,
+                                               snip_edges=self.snip_edges, upsacle_samples=self.upsacle_samples, device=self._device_arg,
+                                               dither_seed=self.dither_seed, verify=self.verify, window_samples=ws)
+        return fe

@@ -9,7 +9,8 @@
 
 // window_type / snip_edges: the FrameExtractionOptions fields kaldi.fbank(window_type=, snip_edges=) stands for
 // (funasr/frontends/wav_frontend.py:178-180); InputFinished() releases the mirrored last frames of snip_edges = false
-extern "C" int knf_fbank_opts(const float* wave_scaled, int64_t n, int n_mels, int frame_length_ms, int frame_shift_ms,
+// frame_length_ms is a float: WavFrontend shrinks the window of a clip shorter than 25 ms to the clip itself (wav_frontend.py:176)
+extern "C" int knf_fbank_opts(const float* wave_scaled, int64_t n, int n_mels, float frame_length_ms, int frame_shift_ms,
                               float sample_rate, const char* window_type, int snip_edges, float* out, int64_t max_frames) {
     knf::FbankOptions opts;
     opts.frame_opts.dither = 0.0f;
@@ -17,7 +18,7 @@ extern "C" int knf_fbank_opts(const float* wave_scaled, int64_t n, int n_mels, i
     opts.frame_opts.samp_freq = sample_rate;
     opts.frame_opts.window_type = window_type;
     opts.frame_opts.frame_shift_ms = (float)frame_shift_ms;
-    opts.frame_opts.frame_length_ms = (float)frame_length_ms;
+    opts.frame_opts.frame_length_ms = frame_length_ms;
     opts.mel_opts.num_bins = n_mels;
     opts.energy_floor = 0.0f;
     opts.mel_opts.debug_mel = false;

@@ -18,15 +18,15 @@ GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
 WINDOWS = ("hamming", "hanning", "povey", "rectangular", "blackman")
 
 
-def knf_fbank_opts(wave_scaled: np.ndarray, window_type: str, snip_edges: bool, n_mels: int = 80) -> np.ndarray:
+def knf_fbank_opts(wave_scaled: np.ndarray, window_type: str, snip_edges: bool, n_mels: int = 80, frame_length_ms: float = 25.0) -> np.ndarray:
     lib = ctypes.CDLL(os.path.join(HERE, "_ref", "libknf_ref.so"))
     lib.knf_fbank_opts.restype = ctypes.c_int
-    lib.knf_fbank_opts.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+    lib.knf_fbank_opts.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_float,
                                    ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
     w = np.ascontiguousarray(wave_scaled, dtype=np.float32)
     max_frames = len(w) // 160 + 2
     out = np.zeros((max_frames, n_mels), dtype=np.float32)
-    n = lib.knf_fbank_opts(w.ctypes.data, len(w), n_mels, 25, 10, 16000.0, window_type.encode(), int(snip_edges),
+    n = lib.knf_fbank_opts(w.ctypes.data, len(w), n_mels, frame_length_ms, 10, 16000.0, window_type.encode(), int(snip_edges),
                            out.ctypes.data, max_frames)
     return out[:n]
 
@@ -44,6 +44,14 @@ def main():
     # short inputs of snip_edges = False: fewer samples than a window (frames mirror several times)
     arrs["short_pcm"] = g["pcm_a"][3000:3000 + 250]
     arrs["short_hamming_nosnip"] = knf_fbank_opts(arrs["short_pcm"].astype(np.float32), "hamming", False)
+    # clips shorter than one 25-ms window: WavFrontend analyses them with ONE window of their own length (wav_frontend.py:176,
+    # frame_length = n / 16 ms; the FFT size follows: 512 down to 64 points here)
+    for n in (399, 300, 257, 256, 200, 129, 100, 64, 33):
+        pcm = g["pcm_a"][5000:5000 + n]
+        arrs[f"tiny_{n}_pcm"] = pcm
+        arrs[f"tiny_{n}_hamming_snip"] = knf_fbank_opts(pcm.astype(np.float32), "hamming", True, frame_length_ms=n / 16.0)
+        assert arrs[f"tiny_{n}_hamming_snip"].shape == (1, 80), arrs[f"tiny_{n}_hamming_snip"].shape
+    arrs["tiny_300_povey_snip"] = knf_fbank_opts(arrs["tiny_300_pcm"].astype(np.float32), "povey", True, frame_length_ms=300 / 16.0)
     path = os.path.join(GOLD, "fbank_options.npz")
     np.savez_compressed(path, **arrs)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB): " + ", ".join(f"{k}{v.shape}" for k, v in arrs.items()))

@@ -84,6 +84,8 @@ def kaldi_fbank(waveform: Tensor, num_mel_bins: int = 80, frame_length_ms: float
     Returns [T_fb, num_mel_bins] float32."""
     wave = waveform.to(torch.float32)
     window_shift = int(sample_frequency * frame_shift_ms * 0.001)
+    # (frame_length_ms may be the 0-dim float32 tensor of short_clip_frame_length_ms: the product is then float32 tensor arithmetic,
+    #  as in torchaudio's _get_waveform_and_window_properties when WavFrontend hands it a tensor)
     window_size = int(sample_frequency * frame_length_ms * 0.001)
     padded = _next_pow2(window_size)
     n = wave.numel()
@@ -119,6 +121,19 @@ def kaldi_fbank(waveform: Tensor, num_mel_bins: int = 80, frame_length_ms: float
     mel = F.pad(mel, (0, 1))                                        # Nyquist bin carries zero weight
     e = spectrum @ mel.T
     return torch.max(e, torch.tensor(torch.finfo(torch.float32).eps)).log()   # feature-fbank.cc:102-106
+
+
+def short_clip_frame_length_ms(n_samples: int, fs: int = 16000, frame_length: int = 25):
+    """WavFrontend.forward's per-utterance window, funasr/frontends/wav_frontend.py:176:
+    `frame_length=min(self.frame_length, waveform_length / self.fs * 1000)` with waveform_length = input_lengths[i], a 0-dim integer
+    TENSOR (extract_fbank hands tensors): the quotient and product are float32 tensor arithmetic, and `min` keeps the int 25 unless
+    the tensor is smaller. A clip shorter than 25 ms is analysed with ONE window of (about) its own length."""
+    return min(frame_length, torch.tensor(int(n_samples)) / fs * 1000)
+
+
+def short_clip_window_size(n_samples: int, fs: int = 16000, frame_length: int = 25) -> int:
+    """samples of the analysis window for a clip of n_samples (torchaudio: int(sample_frequency * frame_length * 0.001))"""
+    return int(float(fs) * short_clip_frame_length_ms(n_samples, fs, frame_length) * 0.001)
 
 
 def fbank_tables(num_mel_bins: int = 80, window_size: int = 400, sample_frequency: float = 16000.0,
@@ -211,15 +226,15 @@ def global_mvn(x: Tensor, ilens: Optional[Tensor], mean: Tensor, std: Tensor, no
 
 def wav_frontend(waves: Sequence[Tensor], cmvn: Optional[Tensor], n_mels: int = 80, frame_length: int = 25,
                  frame_shift: int = 10, lfr_m: int = 7, lfr_n: int = 6, fs: int = 16000,
-                 return_fbank: bool = False):
+                 return_fbank: bool = False, window_type: str = "hamming", snip_edges: bool = True):
     """WavFrontend.forward (funasr/frontends/wav_frontend.py:149-196) with dither = 0: per utterance
     wave * 2^15 -> fbank -> LFR -> CMVN, then zero padding to the longest utterance.
     Returns (feats [B, T, n_mels*lfr_m], lens int32 [B])."""
     feats, lens, fbs = [], [], []
     for w in waves:
         w = w.to(torch.float32) * (1 << 15)
-        ms = min(frame_length, w.numel() / fs * 1000)             # wav_frontend.py:174
-        mat = kaldi_fbank(w, n_mels, ms, frame_shift, float(fs))
+        ms = short_clip_frame_length_ms(w.numel(), fs, frame_length)     # wav_frontend.py:176
+        mat = kaldi_fbank(w, n_mels, ms, frame_shift, float(fs), window_type=window_type, snip_edges=snip_edges)
         fbs.append(mat)
         if lfr_m != 1 or lfr_n != 1:
             mat = apply_lfr(mat, lfr_m, lfr_n)

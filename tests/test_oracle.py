@@ -83,6 +83,29 @@ def test_fbank_snip_edges_false_on_less_than_one_window_mirrors_repeatedly():
     assert (fb - ref).abs().max().item() <= 2e-3
 
 
+TINY_CLIPS = (399, 300, 257, 256, 200, 129, 100, 64, 33)
+
+
+def test_fbank_of_clips_shorter_than_one_window_matches_kaldi_native_fbank():
+    """wav_frontend.py:176: `frame_length=min(self.frame_length, waveform_length / self.fs * 1000)` -- a clip shorter than 25 ms gets ONE
+    window of its own length (float32 tensor arithmetic: n samples for every n in 2..399 at 16 kHz), and the FFT size follows (512 down to
+    64 points here). Against the reference-vendored kaldi-native-fbank with frame_length_ms = n / 16."""
+    for n in range(2, 401):
+        assert O.short_clip_window_size(n) == n
+    assert O.short_clip_frame_length_ms(400) == 25 and O.short_clip_frame_length_ms(16000) == 25
+    go = gold("fbank_options")
+    for n in TINY_CLIPS:
+        fb = O.kaldi_fbank(t(go[f"tiny_{n}_pcm"].astype(np.float32)), 80, O.short_clip_frame_length_ms(n))
+        ref = t(go[f"tiny_{n}_hamming_snip"])
+        assert fb.shape == ref.shape == (1, 80)
+        assert (fb - ref).abs().max().item() <= 2e-3, n
+    fb = O.kaldi_fbank(t(go["tiny_300_pcm"].astype(np.float32)), 80, O.short_clip_frame_length_ms(300), window_type="povey")
+    assert (fb - t(go["tiny_300_povey_snip"])).abs().max().item() <= 2e-3
+    # through the batch-level restatement: one LFR row of seven copies of the single frame
+    feats, lens = O.wav_frontend([t(go["tiny_200_pcm"].astype(np.float32) / 32768.0)], None)
+    assert lens.tolist() == [1] and feats.shape == (1, 1, 560) and torch.equal(feats[0, 0, :80], feats[0, 0, 480:])
+
+
 def test_frontend_lfr_cmvn_on_reference_fbank_bit_exact():
     g = gold("frontend")
     cmvn = t(g["cmvn"])

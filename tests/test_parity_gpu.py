@@ -95,13 +95,43 @@ def test_frontend_window_and_snip_edges_options(cuda, window, snip):
         ofb = O.kaldi_fbank(waves[i] * 32768.0, window_type=window, snip_edges=snip)
         assert (fb[i, : ref.shape[0]] - ofb).abs().max().item() <= bar
         assert torch.equal(feats[i, : ref.shape[0]].cpu(), fb[i, : ref.shape[0]])          # lfr 1 / 1, no CMVN: the log-mel itself
-    if not snip:        # fewer samples than one window: the ends mirror more than once (feature-window.cc:152-171)
+    if not snip:        # fewer samples than 25 ms: the CLASS shrinks the window to the clip (wav_frontend.py:176), two mirrored frames
         short = t(go["short_pcm"].astype(np.float32) / 32768.0)
         _, sl, sfb = fe(short[None].to(cuda), [short.numel()], return_fbank=True)
-        if window == "hamming":
-            assert int(sl[0]) == 2 and (sfb[0].cpu() - t(go["short_hamming_nosnip"])).abs().max().item() <= 2e-3
-        ofb = O.kaldi_fbank(short * 32768.0, window_type=window, snip_edges=False)
-        assert (sfb[0].cpu() - ofb).abs().max().item() <= bar
+        ofb = O.kaldi_fbank(short * 32768.0, 80, O.short_clip_frame_length_ms(short.numel()), window_type=window, snip_edges=False)
+        assert int(sl[0]) == ofb.shape[0] == 2 and (sfb[0].cpu() - ofb).abs().max().item() <= bar
+
+
+def test_frontend_clips_shorter_than_one_window(cuda):
+    """wav_frontend.py:176: a clip shorter than 25 ms (a few-millisecond VAD segment) is analysed with one window of its own length, the
+    FFT size following the window; in a batch only that clip is affected. Against the reference-vendored kaldi-native-fbank run with
+    frame_length_ms = n / 16 (tests/golden/fbank_options.npz) and against the oracle's batch-level restatement, LFR + CMVN included."""
+    from funasr_amd.wav_frontend import WavFrontend
+    from oracle import paraformer_oracle as O
+    g, go = gold("frontend"), gold("fbank_options")
+    cmvn = t(g["cmvn"])
+    fe = WavFrontend(cmvn=cmvn, lfr_m=7, lfr_n=6, dither=0.0)
+    tiny = (399, 300, 257, 256, 200, 129, 100, 64, 33)
+    waves = [t(go[f"tiny_{n}_pcm"].astype(np.float32) / 32768.0) for n in tiny] + [t(g["pcm_b"].astype(np.float32) / 32768.0)]
+    lens = [w.numel() for w in waves]
+    batch = torch.zeros(len(waves), max(lens))
+    for i, w in enumerate(waves):
+        batch[i, : lens[i]] = w
+    feats, flens, fb = fe(batch.to(cuda), lens, return_fbank=True)
+    feats, fb = feats.cpu(), fb.cpu()
+    of, ol, ofb = O.wav_frontend(waves, cmvn, return_fbank=True)
+    assert flens.tolist() == ol.tolist() == [1] * len(tiny) + [g["feats_b"].shape[0]]
+    for i, n in enumerate(tiny):
+        assert (fb[i, :1] - t(go[f"tiny_{n}_hamming_snip"])).abs().max().item() <= 2e-3, n
+        assert (fb[i, 1:] == 0).all() and (feats[i, 1:] == 0).all()
+    for i in range(len(waves)):
+        assert (feats[i, : ol[i]] - of[i, : ol[i]]).abs().max().item() < 5e-4, lens[i]
+    # the long clip of the mixed batch == the same clip alone, bitwise (utterance-level independence)
+    alone, al = fe(waves[-1][None].to(cuda), [lens[-1]])
+    assert torch.equal(alone[0, : al[0]].cpu(), feats[-1, : flens[-1]])
+    assert (feats[-1, : flens[-1]] - t(g["feats_b"])).abs().max().item() < 5e-4
+    with pytest.raises(ValueError, match="no analysis window"):
+        fe(torch.zeros(1, 8).to(cuda), [1])
 
 
 def test_frontend_window_by_name_at_the_c_abi(cuda):
@@ -128,6 +158,13 @@ def test_frontend_window_by_name_at_the_c_abi(cuda):
                     torch.cuda.synchronize()
                     d = (out.cpu() - ref).abs()
                     assert d.max().item() <= (5e-3 if window == "rectangular" else 2e-3), (window, snip, d.max().item())
+            # fewer samples than the handle's window, snip_edges = 0: the ends mirror more than once (feature-window.cc:152-171)
+            short = t(go["short_pcm"].astype(np.float32) / 32768.0).to(cuda)
+            assert lib.pf_frontend_num_fbank_frames(h, short.numel()) == 2
+            out = torch.empty(2, 80, device=cuda)
+            _lib.check(lib.pf_frontend_fbank(h, short.data_ptr(), short.numel(), out.data_ptr(), None), "pf_frontend_fbank")
+            torch.cuda.synchronize()
+            assert (out.cpu() - t(go["short_hamming_nosnip"])).abs().max().item() <= 2e-3
         finally:
             lib.pf_frontend_destroy(h)
 
@@ -789,8 +826,8 @@ def test_bf16_operand_mode_stays_close_to_fp32_mode(cuda):
 
 
 def test_edge_cases_short_silent_and_zero_token_utterances(cuda, f32_mode):
-    """Edge cases of the offline path: (1) an utterance shorter than one 25 ms window is rejected like the reference's
-    fbank would produce no frame; (2) one-frame utterances and a batch where some clips fire no token at all: those
+    """Edge cases of the offline path: (1) an utterance shorter than one 25 ms window gets one window of its own length
+    (wav_frontend.py:176; test_frontend_clips_shorter_than_one_window), a one-sample clip has none; (2) one-frame utterances and a batch where some clips fire no token at all: those
     clips come back empty, their neighbours are unaffected (bitwise) -- where the reference raises IndexError for a
     zero-token LAST utterance (cif_predictor.py:887) this path returns an empty hypothesis; (3) a 60 s clip (T = 1000)."""
     from funasr_amd.paraformer import Paraformer
@@ -798,8 +835,10 @@ def test_edge_cases_short_silent_and_zero_token_utterances(cuda, f32_mode):
     from oracle import paraformer_oracle as O
     sh, sc = synth.synthetic_cmvn()
     fe = WavFrontend(cmvn=torch.stack([sh, sc]), lfr_m=7, lfr_n=6, dither=0.0)
-    with pytest.raises(Exception, match="25 ms|window"):
-        fe(torch.zeros(1, 399).to(cuda), [399])
+    feats, flens = fe(torch.zeros(1, 399).to(cuda), [399])
+    assert flens.tolist() == [1] and feats.shape == (1, 1, 560)
+    with pytest.raises(Exception, match="window"):
+        fe(torch.zeros(1, 399).to(cuda), [1])
     feats, flens = fe(torch.zeros(2, 400).to(cuda), [400, 400])           # exactly one window -> one LFR frame
     assert flens.tolist() == [1, 1] and feats.shape[1] == 1
     cfg = synth.tiny(synth.PARAFORMER_LARGE, enc_blocks=2, dec_blocks=1, vocab=97)
