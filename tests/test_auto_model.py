@@ -156,6 +156,38 @@ def test_generate_over_many_batches_overlapped_equals_the_plain_loop(model_dir, 
 
 
 @pytest.mark.gpu
+def test_generate_with_clips_of_a_few_milliseconds(model_dir, cuda, tmp_path):
+    """Files shorter than one 25-ms analysis window in the list (5 ms, 19 ms): the reference's frontend gives each ONE frame from a window of
+    its own length (wav_frontend.py:176) and decodes on; `generate` used to fail the whole call. Same records from the plain loop, the
+    overlapped loop and the rows-budget plan; the tiny clips' text equals the CPU oracle's."""
+    from funasr_amd.tokenizer import CharTokenizer, sentence_postprocess
+    from oracle import paraformer_oracle as O
+    am = AutoModel(model=model_dir["dir"], device="cuda:0", batch_size=2)
+    paths, pcm = [], {}
+    for i, n in enumerate((40000, 300, 9000, 80, 16000)):
+        p = str(tmp_path / f"tiny{i}.wav")
+        pcm[p] = write_wav(p, synth.speech_like(n, seed=40 + i))
+        paths.append(p)
+    plain = am.generate(input=paths, pipeline=False)
+    assert len(plain) == len(paths) and am.generate(input=paths) == plain
+    by_rows = am.generate(input=paths, batch_size_rows=128)
+    assert [r["key"] for r in by_rows] == [r["key"] for r in plain]
+    cmvn = am.kwargs["frontend"].cmvn
+    tok = CharTokenizer(token_list=VOCAB)
+    # the oracle on the plain loop's own batches (two files each, in input order): what a clip's last frame sees behind it depends on
+    # its batch (the predictor's conv reads one encoder row past the clip, a reference property), so the comparison keeps the batches
+    for b0 in (0, 2):
+        ws = [torch.from_numpy(pcm[p].astype(np.float32) / 32768.0) for p in paths[b0:b0 + 2]]
+        feats, flens = O.wav_frontend(ws, cmvn)
+        assert flens.tolist()[1] == 1                              # the tiny clip: one LFR row from its one frame
+        ref = O.paraformer_greedy(feats, flens, model_dir["sd"], model_dir["cfg"])
+        for j in range(2):
+            ids = [t for t in ref["raw_ids"][j] if t not in (0, 1, 2)]
+            text, _ = sentence_postprocess(tok.ids2tokens(ids)) if ids else ("", None)
+            assert plain[b0 + j]["text"] == text, (b0 + j, plain[b0 + j], text)
+
+
+@pytest.mark.gpu
 def test_sensevoice_batches_overlapped_equal_the_plain_loop(cuda):
     from funasr_amd.sense_voice import SenseVoiceSmall
     from funasr_amd.wav_frontend import WavFrontend
