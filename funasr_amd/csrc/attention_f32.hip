@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
 
     // the ring append (below) copies rows of (K2, V2) that nothing in this kernel produces: fetch them now, store them at the end
     const bool do_app = p.app_rows > 0 && gridDim.x == 1 && p.K2;
-    const int app_skip = p.app_rows > p.Tk ? p.app_rows - p.Tk : 0;   // only the newest `cap` rows can survive
+    const int app_cap = (p.app_mod > 0 && n1 > 0) ? p.app_mod : p.Tk;  // (AttnArgs.app_mod: an encoder ring after its first append)
+    const int app_skip = p.app_rows > app_cap ? p.app_rows - app_cap : 0;   // only the newest `cap` rows can survive
     const int app_n = (p.app_rows - app_skip) * 64;                    // 32 float4 of K and 32 of V per row
     float4 appv[4];
     if (do_app) {
@@ -479,14 +480,14 @@ __global__ __launch_bounds__(256) void attention_f32_fewq_kernel(AttnArgs p) {
     // ring append (attention.py:343-361: the cache keeps the last rows): every wave of this -- the only -- workgroup of
     // (stream, head) passed the barrier above, i.e. has its ring rows in registers; other heads own other columns
     if (do_app && (!p.app_gate || p.app_gate[b] >= 1)) {
-        const int cap = p.Tk;
+        const int cap = app_cap;
         const int wp = p.app_wp[b * p.app_wp_stride];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = tid + 256 * e;
             if (i < app_n) {
                 const int r = i >> 6, c = i & 63, c4 = (c & 31) * 4;
-                const size_t dst = (size_t)b * cap + (wp + app_skip + r) % cap;
+                const size_t dst = (size_t)b * p.Tk + (wp + app_skip + r) % cap;
                 float* base = c < 32 ? const_cast<float*>(p.K) + dst * p.ldk : const_cast<float*>(p.V) + dst * p.ldv;
                 *reinterpret_cast<float4*>(base + head * DK + c4) = appv[e];
             }

@@ -487,6 +487,10 @@ struct AttnArgs {
     // the workgroup appends rows [app_r0, app_r0 + app_rows) of (K2, V2) -- its head's columns -- to the ring (K, V; Tk =
     // capacity) at write pointer app_wp[b * app_wp_stride], like ring_append_kernel (stream.hip); app_gate[b] < 1 skips
     int app_rows, app_r0; const int* app_wp; int app_wp_stride; const int* app_gate;
+    // app_mod > 0 (the ENCODER's ring when chunk_left + max_frames > look_back * chunk_cur): the reference leaves the FIRST chunk's cache
+    // untrimmed (sanm/attention.py:356-361) and trims to look_back * chunk_size[1] rows from the second chunk on (:353-355). The ring
+    // then holds Tk >= app_mod rows: the first append (n1 == 0) is written linearly, later ones modulo app_mod; rows [0, n1) are valid
+    int app_mod;
     // launch_attention_small only (SANMVadEncoder, ct_transformer_streaming/encoder.py:372-418): 0 = key padding only,
     // 1 = also causal (key <= query), 2 = also the VAD corner (transformer/utils/mask.py:38-52): queries before
     // vad_pos[b] - 1 do not see keys from vad_pos[b] on (when 0 < vad_pos[b] < Tk)

@@ -405,6 +405,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     bool appended = false;
     if (cc && cc->cap > 0 && cc->append_rows > 0) {
         aa.app_rows = cc->append_rows; aa.app_r0 = 0; aa.app_wp = &cc->st->enc_wp; aa.app_wp_stride = 0; aa.app_gate = nullptr;
+        aa.app_mod = cc->mod;
     }
     // f16x2 step: the attention writes the out-projection's operand planes itself (no split2 launch)
     const bool o2 = x2c && cc->x2_attn_planes && g_stream_mode && T <= 32 && D / c.n_heads == 128;
@@ -413,7 +414,7 @@ int encoder_block(Encoder* e, const EncLayerW& w, float* x_in, int ld_in, float*
     if (cc && cc->cap > 0 && cc->append_rows > 0 && !appended) {
         RingAppendArgs ra{};
         ra.src = qkv + D; ra.ldsrc = 3 * D; ra.src_T = T; ra.r0 = 0; ra.rows = cc->append_rows; ra.cols = 2 * D;
-        ra.ring = cc->ring; ra.cap = cc->cap; ra.S = B; ra.st = cc->st;
+        ra.ring = cc->ring; ra.cap = cc->cap; ra.S = B; ra.st = cc->st; ra.mod = cc->mod;
         if ((rc = launch_ring_append(ra, s))) return rc;
     }
     // out projection + fsmn memory (+ residual when in == out, encoder.py:120-137)

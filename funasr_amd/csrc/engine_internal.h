@@ -415,6 +415,7 @@ void note_concurrent_streams();
 struct EncChunkCtx {
     float* ring; int cap; const StreamDev* st; int append_rows;
     const int* lens;     // device [B]: every window row is valid in a chunk
+    int mod = 0;         // > 0: the ring's trim size when its first, untrimmed append needs more rows than that (AttnArgs.app_mod)
     bool x2 = false;     // the block's four GEMMs on the fp16 matrix cores (two-plane operands, gemm_f16x2.hip), fp32 results
     // fp32 step: the LayerNorms ride in the small-M GEMMs on either side (gemm_skinny.hip: the producer's epilogue leaves per-row
     // partial sums, the consumer normalises on the fetch). ln_stats = [rows][d_model / 16][2] scratch; ln_in_ready = the block that
@@ -512,6 +513,7 @@ struct Stream {
     Encoder* e = nullptr; Predictor* p = nullptr; Decoder* d = nullptr;
     pf_stream_config cfg{};
     int S = 1, keep = 5, Wmax = 0, Nmax = 0, enc_cap = 0, dec_cap = 0, pe_rows = 0;
+    int enc_mod = 0;     // > 0: enc_cap rows hold an untrimmed first chunk (chunk_left + max_frames > look_back * chunk_cur); trim size
     DevBuf dev_state, cache_feats, feats_in, win, enc_ring, dec_ring, dec_fsmn, cif_hidden, cif_alpha, dec_valid, dec_wp,
         n_fired, pe, lensW, enc_out, embeds, ids, alphas;
     int32_t* h_ids = nullptr; int32_t* h_n = nullptr;       // pinned

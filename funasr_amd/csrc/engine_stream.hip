@@ -175,6 +175,7 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
     for (size_t l = 0; l < e->layers.size(); ++l) {
         EncChunkCtx cc{st->enc_cap > 0 ? st->enc_ring.as<float>() + l * ring_layer : nullptr, st->enc_cap, dev, append_rows,
                        st->lensW.as<int>(), st->x2};
+        cc.mod = st->enc_mod;
         cc.fsmn_rides = st->fsmn_rides;
         cc.x2_attn_planes = st->x2 && st->ln_folded;
         cc.x2_short_k = (st->x2 && stream_short_k(st)) ? (st->short_k >= 3 ? 1 : 2) : 0;
@@ -196,9 +197,13 @@ static int stream_enqueue(Stream* st, int n, int is_final, int tail, hipStream_t
         else rc = encoder_block(e, e->layers[l], x, D, x, S, W, s, &cc);
         if (rc) return rc;
     }
+    if (st->enc_mod > 0 && append_rows > 0) {
+        RingFoldArgs rf{st->enc_ring.as<float>(), ring_layer, (int)e->layers.size(), S, st->enc_cap, st->enc_mod, 2 * D, append_rows, dev};
+        if ((rc = launch_ring_fold(rf, s))) return rc;
+    }
     StreamAdvanceArgs adv{};
     adv.st = st->dev_state.as<StreamDev>(); adv.n_frames = tail ? st->keep : n;   // the tail chunk re-feeds `keep` rows (embedding.py:478)
-    adv.enc_rows = append_rows; adv.enc_cap = st->enc_cap;
+    adv.enc_rows = append_rows; adv.enc_cap = st->enc_cap; adv.enc_mod = st->enc_mod;
     if ((rc = launch_stream_advance_enc(adv, s))) return rc;
     float* enc_out = st->enc_out.as<float>();
     if ((rc = layernorm(x, D, e->tt.get("after_norm.weight"), e->tt.get("after_norm.bias"), enc_out, D, M, D, D,
@@ -504,6 +509,14 @@ pf_stream* pf_stream_create(pf_encoder* eh, pf_predictor* ph, pf_decoder* dh, co
     st->e = e; st->p = p; st->d = d; st->cfg = c;
     st->S = c.n_streams; st->keep = c.chunk_left + c.chunk_right; st->Wmax = st->keep + c.max_frames;
     st->Nmax = c.max_tokens; st->enc_cap = c.enc_look_back * c.chunk_cur; st->dec_cap = c.dec_look_back * c.chunk_cur;
+    // The reference trims the encoder's K / V cache to look_back * chunk_size[1] rows from the SECOND chunk on and leaves the first
+    // chunk's cache -- chunk_left + n rows -- as it is (sanm/attention.py:353-361). Where that is more than the trim size (chunk_left >
+    // (look_back - 1) * chunk_cur: e.g. [5, 10, 5] with look-back 1) the ring holds the larger count and trims from its second append
+    // on (RingAppendArgs.mod); found by tools/fuzz_gpu_streaming_vs_oracle.py, profiles/r06ak_streaming_fuzz.json
+    if (st->enc_cap > 0 && c.chunk_right > 0 && c.chunk_left + c.max_frames > st->enc_cap) {
+        st->enc_mod = st->enc_cap;
+        st->enc_cap = c.chunk_left + c.max_frames;
+    }
     st->use_graph = c.use_graph != 0;
     const int S = st->S, D = 512, Din = e->cfg.input_dim;
     const size_t L = e->layers.size(), Ld = (size_t)d->cfg.n_blocks;

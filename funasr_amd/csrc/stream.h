@@ -35,11 +35,24 @@ struct RingAppendArgs {
     // the same append for n_layers (src, ring) pairs src_layer / ring_layer floats apart (0 / 1: one pair): the decoder's sixteen
     // rings share the write pointers, and with the batched key/value projection every layer's rows outlive the token chain
     int n_layers = 0; size_t src_layer = 0, ring_layer = 0;
+    // uniform mode, mod > 0: an encoder ring of `cap` rows whose first append (st->enc_valid == 0) is linear and untrimmed and whose
+    // later appends run modulo `mod` = look_back * chunk_cur (AttnArgs.app_mod; sanm/attention.py:353-361)
+    int mod = 0;
 };
 int launch_ring_append(const RingAppendArgs& a, hipStream_t stream);
 
+// The one step after an untrimmed first append (st->enc_valid > mod): the rows of the first chunk that survive this step's trim and sit
+// behind position `mod` move to their ring positions (global row index modulo `mod`), so that rows [0, mod) are again exactly the last
+// `mod` rows appended. new_rows = this step's append. Does nothing in every other step.
+struct RingFoldArgs {
+    float* ring; size_t ring_layer; int n_layers, S, cap, mod, cols, new_rows;
+    const StreamDev* st;
+};
+int launch_ring_fold(const RingFoldArgs& a, hipStream_t stream);
+
 struct StreamAdvanceArgs {
     StreamDev* st; int n_frames, enc_rows, enc_cap;
+    int enc_mod = 0;           // > 0: the ring's trim size (RingAppendArgs.mod); enc_cap is then its row count
     int* dec_valid; int* dec_wp; const int* gate; int S, dec_rows, dec_cap;
 };
 int launch_stream_advance_enc(const StreamAdvanceArgs& a, hipStream_t stream);

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void stream_keep_kernel(const float* win, floa
 // ---------------------------------------------------------------------------------------------------- K/V rings
 __global__ __launch_bounds__(256) void ring_append_kernel(RingAppendArgs p) {
     const int C4 = p.cols >> 2;
-    const int skip = p.rows > p.cap ? p.rows - p.cap : 0;      // only the newest `cap` rows can survive
+    const int cap = (p.mod > 0 && p.st && p.st->enc_valid > 0) ? p.mod : p.cap;   // (RingAppendArgs.mod: after the first append)
+    const int skip = p.rows > cap ? p.rows - cap : 0;          // only the newest `cap` rows can survive
     const int rows = p.rows - skip;
     const int total = p.S * rows * C4;
     const float* src_l = p.src + (size_t)blockIdx.y * p.src_layer;
@@ -68,9 +69,30 @@ __global__ __launch_bounds__(256) void ring_append_kernel(RingAppendArgs p) {
             if (p.gate_dev[s] < 1) continue;
             wp = p.wp_dev[s];
         }
-        const int dst = (wp + skip + r) % p.cap;
+        const int dst = (wp + skip + r) % cap;
         const float4 v = *reinterpret_cast<const float4*>(src_l + (size_t)(s * p.src_T + p.r0 + skip + r) * p.ldsrc + c4 * 4);
         reinterpret_cast<float4*>(ring_l)[((size_t)s * p.cap + dst) * C4 + c4] = v;
+    }
+}
+
+// RingFoldArgs: runs after a step's appends and before its advance. R0 = rows of the untrimmed first append (global indices 0 .. R0-1,
+// stored linearly); this step appended new_rows more at (R0 + r) mod `mod`. Of the old rows the last max(0, mod - new_rows) survive the
+// trim; those with index >= mod move to index % mod (their targets hold rows that the trim drops, never this step's new rows)
+__global__ __launch_bounds__(256) void ring_fold_kernel(RingFoldArgs p) {
+    const int R0 = p.st->enc_valid;
+    if (R0 <= p.mod) return;
+    const int lo_keep = R0 + p.new_rows - p.mod;
+    const int lo = lo_keep > p.mod ? lo_keep : p.mod;
+    const int rows = R0 - lo;
+    if (rows <= 0) return;
+    const int C4 = p.cols >> 2;
+    float* ring_l = p.ring + (size_t)blockIdx.y * p.ring_layer;
+    const int total = p.S * rows * C4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = i % C4, r = (i / C4) % rows, s = i / (C4 * rows);
+        const int src = lo + r, dst = src % p.mod;
+        reinterpret_cast<float4*>(ring_l)[((size_t)s * p.cap + dst) * C4 + c4] =
+            reinterpret_cast<const float4*>(ring_l)[((size_t)s * p.cap + src) * C4 + c4];
     }
 }
 
@@ -78,7 +100,13 @@ __global__ void stream_advance_enc_kernel(StreamAdvanceArgs p) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         StreamDev s = *p.st;
         s.start_idx += p.n_frames;
-        if (p.enc_cap > 0) {
+        if (p.enc_cap > 0 && p.enc_mod > 0) {
+            // the first chunk's cache stays untrimmed, every later one is trimmed to enc_mod rows (sanm/attention.py:353-361)
+            const bool first = s.enc_valid == 0;
+            const int v = s.enc_valid + p.enc_rows;
+            s.enc_valid = first ? (p.enc_rows < p.enc_cap ? p.enc_rows : p.enc_cap) : (v < p.enc_mod ? v : p.enc_mod);
+            s.enc_wp = first ? p.enc_rows % p.enc_mod : (s.enc_wp + p.enc_rows) % p.enc_mod;
+        } else if (p.enc_cap > 0) {
             const int v = s.enc_valid + p.enc_rows;
             s.enc_valid = v < p.enc_cap ? v : p.enc_cap;
             s.enc_wp = (s.enc_wp + p.enc_rows) % p.enc_cap;
@@ -383,6 +411,15 @@ int launch_ring_append(const RingAppendArgs& a, hipStream_t stream) {
     const int rows = a.rows > a.cap ? a.cap : a.rows;
     const int total = a.S * rows * (a.cols / 4);
     hipLaunchKernelGGL(ring_append_kernel, dim3(ceil_div(total, 256), a.n_layers > 1 ? a.n_layers : 1), dim3(256), 0, stream, a);
+    PF_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_ring_fold(const RingFoldArgs& a, hipStream_t stream) {
+    if (a.mod <= 0 || a.cap <= a.mod) return 0;
+    PF_REQUIRE(a.cols % 4 == 0, "ring_fold: cols % 4");
+    const int total = a.S * (a.cap - a.mod) * (a.cols / 4);
+    hipLaunchKernelGGL(ring_fold_kernel, dim3(ceil_div(total, 256), a.n_layers > 1 ? a.n_layers : 1), dim3(256), 0, stream, a);
     PF_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -204,6 +204,35 @@ def test_stream_other_chunk_geometries_vs_streaming_oracle(cuda, chunk, enc_lb, 
     sb.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
+@pytest.mark.parametrize("chunk,enc_lb,sizes", [([5, 10, 5], 1, [10, 10, 10, 10, 7]),      # the first cache (15 rows) exceeds the trim (10)
+                                                ([5, 10, 5], 1, [10, 3, 10, 2, 10, 12]),   # ... and short chunks follow it (API-level session)
+                                                ([6, 4, 2], 1, [4, 4, 1, 4, 3]),           # the first cache is more than twice the trim
+                                                ([3, 8, 4], 2, [8, 8, 8, 5])])             # fits: the plain ring
+def test_stream_first_chunk_cache_is_not_trimmed(cuda, precision, chunk, enc_lb, sizes):
+    """The reference trims the encoder's K / V cache to look_back * chunk_size[1] rows from the SECOND chunk on and leaves the first
+    chunk's cache (chunk_size[0] + n rows) untrimmed (sanm/attention.py:353-361): with chunk_size[0] > (look_back - 1) * chunk_size[1]
+    the second chunk attends to more cached rows than any later one. Found by tools/fuzz_gpu_streaming_vs_oracle.py (the ring used to drop
+    those rows: encoder window off by 0.2 in the second chunk); against the reference-pinned streaming oracle."""
+    from funasr_amd.paraformer_streaming import StreamBatch
+    from oracle import streaming_oracle as S
+    g, cfg, sd, wav = load()
+    model = build(cfg, sd, cuda)
+    sb = StreamBatch(model, 1, chunk, enc_lb, 1, precision=precision)
+    st = S.model_init(cfg, tuple(chunk), enc_lb, 1)
+    gen = torch.Generator().manual_seed(sum(sizes) + enc_lb)
+    for i, n in enumerate(sizes):
+        fin = i == len(sizes) - 1
+        feats = torch.randn(1, n, 560, generator=gen) * 0.7
+        trace = []
+        with torch.no_grad():
+            oids = S.generate_chunk(feats.clone(), st, sd, cfg, fin, trace)
+        ids, enc = sb.step(feats.to(cuda), is_final=fin, return_enc=True)
+        assert (enc.cpu() - trace[0]["enc"]).abs().max().item() < 1e-3, (i, n)
+        assert [t for t in ids[0] if t not in (0, 1, 2)] == oids and len(ids[0]) == trace[0]["n"], (i, ids[0], oids)
+    sb.close()
+
+
 def test_graphs_survive_workspace_growth_by_an_offline_batch(cuda):
     """The captured step holds raw workspace pointers of the shared encoder/decoder handles; an offline batch that grows
     those workspaces in between must not leave the graph with stale pointers (it is re-captured)."""
