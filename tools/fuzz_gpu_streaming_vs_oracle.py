@@ -38,38 +38,40 @@ for si in range(n_sessions):
     chunk = [ri(0, 1) * ri(1, 6), cur, ri(1, max(1, cur // 2))]
     enc_lb, dec_lb = ri(0, 4), ri(0, 2)
     precision = ("fp32", "f16x2")[ri(0, 1)]
+    n_str = 1 if si % 2 == 0 else ri(2, 5)           # lock-step streams: own features and oracle state each, same chunk sizes
     try:
-        sb = StreamBatch(model, 1, chunk, enc_lb, dec_lb, precision=precision)
+        sb = StreamBatch(model, n_str, chunk, enc_lb, dec_lb, precision=precision)
     except (ValueError, RuntimeError) as e:          # geometries the step refuses loudly (token rows per step capped, ...)
         skipped += 1
         print(f"session {si}: chunk={chunk} lb=({enc_lb},{dec_lb}) refused: {str(e)[:100]}")
         continue
-    st = S.model_init(cfg, tuple(chunk), enc_lb, dec_lb)
+    sts = [S.model_init(cfg, tuple(chunk), enc_lb, dec_lb) for _ in range(n_str)]
+    quiet = [n_str > 1 and ri(0, 2) == 0 for _ in range(n_str)]      # features near zero: such a stream fires (almost) nothing in a step
     n_chunks = ri(2, 9)
     ragged = si % 3 == 2          # API-level sessions: non-final chunks of any size (the reference's own loop always brings chunk_cur frames)
     ok = True
     for i in range(n_chunks):
         fin = i == n_chunks - 1
         n = (ri(1, cur) if ragged else cur) if not fin else ri(1, cur + 2)
-        feats = torch.randn(1, n, 560, generator=gen) * 0.7
-        trace = []
-        with torch.no_grad():
-            oids = S.generate_chunk(feats.clone(), st, sd, cfg, fin, trace)
+        feats = torch.randn(n_str, n, 560, generator=gen) * 0.7
+        for k in range(n_str):
+            if quiet[k]:
+                feats[k] *= 0.02
         ids, enc = sb.step(feats.to(dev), is_final=fin, return_enc=True)
         steps += 1
-        if trace:
-            d = (enc.cpu() - trace[0]["enc"]).abs().max().item()
+        for k in range(n_str):
+            trace = []
+            with torch.no_grad():
+                oids = S.generate_chunk(feats[k:k + 1].clone(), sts[k], sd, cfg, fin, trace)
+            d = (enc[k:k + 1].cpu() - trace[0]["enc"]).abs().max().item()
             worst = max(worst, d)
-            same = [t for t in ids[0] if t not in (0, 1, 2)] == oids and len(ids[0]) == trace[0]["n"] and d < 1e-3
-        else:
-            same = [t for t in ids[0] if t not in (0, 1, 2)] == oids
-        if not same:
-            ok = False
-            if trace:
-                print(f"   enc window |d| {d:.3e}, counts {len(ids[0])} / {trace[0]['n']}")
-            print(f"session {si} chunk {i}: geometry={chunk} lb=({enc_lb},{dec_lb}) {precision} fin={fin} n={n}: ids {ids[0]} oracle {oids}")
+            same = [t for t in ids[k] if t not in (0, 1, 2)] == oids and len(ids[k]) == trace[0]["n"] and d < 1e-3
+            if not same:
+                ok = False
+                print(f"   enc window |d| {d:.3e}, counts {len(ids[k])} / {trace[0]['n']}")
+                print(f"session {si} chunk {i} stream {k}/{n_str}: geometry={chunk} lb=({enc_lb},{dec_lb}) {precision} fin={fin} n={n}: ids {ids[k]} oracle {oids}")
     bad += 0 if ok else 1
-    print(f"session {si}: chunk={chunk} lb=({enc_lb},{dec_lb}) {precision} chunks={n_chunks}{' ragged' if ragged else ''} -> {'ok' if ok else 'MISMATCH'}")
+    print(f"session {si}: chunk={chunk} lb=({enc_lb},{dec_lb}) {precision} streams={n_str} chunks={n_chunks}{' ragged' if ragged else ''} -> {'ok' if ok else 'MISMATCH'}")
     sb.close()
 print(json.dumps(dict(tool="fuzz_gpu_streaming_vs_oracle", seed=seed, sessions=n_sessions, refused=skipped, steps=steps, bad_sessions=bad,
                       worst_encoder_window_abs_diff=worst)))
