@@ -92,7 +92,33 @@ for ci in range(n_cases):
     if d > 1e-3 or not same:
         pc_bad += 1
         print(f"punctuation case {ci} B={B} N={N} lens={lens.tolist()} blocks={e['num_blocks']}: |d| {d:.2e} argmax equal {same}")
-print(json.dumps(dict(tool="fuzz_gpu_sensevoice_punc_vs_oracle", seed=seed, cases=n_cases,
+# --------------------------------------------------------- realtime punctuation: causal mask + VAD corner in the last block
+from funasr_amd.ct_transformer import CTTransformerStreaming      # noqa: E402
+ps_bad, ps_worst = 0, 0.0
+for ci in range(n_cases):
+    vocab = ri(50, 500)
+    e = dict(enc, num_blocks=ri(1, 4))
+    sd = punc_oracle.synthetic_state_dict(vocab, e, seed=1100 + ci)
+    model = CTTransformerStreaming(encoder="SANMVadEncoder", encoder_conf=dict(e, input_layer="pe"), vocab_size=vocab,
+                                   punc_list=punc_oracle.PUNC_LIST, embed_unit=256, att_unit=256, ignore_id=0, sentence_end_id=3)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    B, N = ri(1, 6), ri(1, 90)
+    lens = torch.randint(1, N + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = N
+    ids = torch.randint(1, vocab, (B, N), generator=g, dtype=torch.int64)
+    for b in range(B):
+        ids[b, lens[b]:] = 0
+    vad = torch.tensor([ri(0, N + 2) for _ in range(B)], dtype=torch.int32)      # 0 / >= T: no corner (mask.py:38-52)
+    want = punc_oracle.punc_forward_vad(ids, lens, vad, sd, e)
+    got, _ = model.punc_forward(ids, lens, vad)
+    d = max((got[b, : lens[b]].cpu() - want[b, : lens[b]]).abs().max().item() for b in range(B))
+    ps_worst = max(ps_worst, d)
+    if d > 1e-3:
+        ps_bad += 1
+        print(f"realtime punctuation case {ci} B={B} N={N} lens={lens.tolist()} vad={vad.tolist()} blocks={e['num_blocks']}: |d| {d:.2e}")
+pc_bad += ps_bad
+print(json.dumps(dict(tool="fuzz_gpu_sensevoice_punc_vs_oracle", seed=seed, cases=n_cases, punctuation_realtime=dict(bad=ps_bad, worst_logit_abs_diff=ps_worst),
                       sensevoice=dict(bad=sv_bad, worst_encoder_abs_diff=sv_worst, frames=sv_frames, near_tie_frame_flips=sv_ties),
                       punctuation=dict(bad=pc_bad, worst_logit_abs_diff=pc_worst))))
 sys.exit(1 if (sv_bad or pc_bad) else 0)
