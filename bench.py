@@ -383,7 +383,12 @@ def main():
     lens = [n_samples] * B
     N_PAD = 512
     interleave = not args.no_interleave
-    dec_stream = torch.cuda.Stream(device=device) if (interleave and not args.no_decoder_stream) else None
+    # PF_DEC_STREAM_PRIORITY: measurement switch (-1 = high priority for the decoder stream; profiles/r06ao_ab_stream_priorities.txt)
+    dec_stream = (torch.cuda.Stream(device=device, priority=int(os.environ.get("PF_DEC_STREAM_PRIORITY", "0")))
+                  if (interleave and not args.no_decoder_stream) else None)
+    if os.environ.get("PF_MAIN_STREAM_PRIORITY") is not None:     # measurement switch: the loop's own stream with a HIP priority (same record)
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ["PF_MAIN_STREAM_PRIORITY"])))
     if dec_stream is not None:
         lib.pf_set_concurrency_guard(1)        # kernels of two streams may share a CU: the frontend's cross-check on (0.4 % of a step)
     trace("workload resident in HBM")
