@@ -453,6 +453,53 @@ def paraformer_decoder(memory: Tensor, mem_lens: Tensor, embeds: Tensor, tok_len
     return (logits, hidden) if return_hidden else logits
 
 
+def contextual_decoder(memory: Tensor, mem_lens: Tensor, embeds: Tensor, tok_lens: Tensor, contextual_info: Tensor, sd: SD, cfg: dict,
+                       clas_scale: float = 1.0, prefix: str = "", eps: float = 1e-12, return_hidden: bool = False):
+    """ContextualParaformerDecoder.forward, funasr/models/contextual_paraformer/decoder.py:293-352: att_layer_num - 1 standard blocks
+    (`decoders`), then `last_decoder` (ContextualDecoderLayer :53-96: x_self_attn = x + FSMN(LN2 FFN(LN1 x)); x_src_attn = CrossAtt(LN3
+    x_self_attn, memory) WITHOUT its residual), the hotword branch cx = CrossAtt_bias(LN3_bias x_self_attn, contextual_info) (ContextualBiasDecoder
+    :114-130, every hotword row valid), x = x_self_attn + bias_output([x_src_attn | cx * clas_scale]) (Conv1d(2D, D, 1, bias=False), :335-338),
+    decoders2 if any, decoders3, after_norm, output_layer. contextual_info [B or 1, n_hot, D]. Returns logits [B, N, V]."""
+    B, N, D = embeds.shape
+    T = memory.shape[1]
+    H = cfg["attention_heads"]
+    left_pad = (cfg["kernel_size"] - 1) // 2 + max(cfg.get("sanm_shfit", 0), 0)
+    tgt_mask = (torch.arange(N)[None, :] < tok_lens[:, None].to(torch.int64)).float()[:, :, None]
+    mem_mask = torch.arange(T)[None, :] < mem_lens[:, None].to(torch.int64)
+    L = cfg["att_layer_num"]
+
+    def cross(xn, mem, mask, p):
+        q = F.linear(xn, sd[p + "linear_q.weight"], sd[p + "linear_q.bias"])
+        kv = F.linear(mem, sd[p + "linear_k_v.weight"], sd[p + "linear_k_v.bias"])
+        k, v = torch.split(kv, D, dim=-1)
+        return F.linear(_mha(q, k, v, mask, H), sd[p + "linear_out.weight"], sd[p + "linear_out.bias"])
+
+    x = embeds
+    for i in range(L - 1):
+        p = prefix + f"decoders.{i}."
+        t = _dec_ffn(_ln(x, sd, p + "norm1", eps), sd, p, eps)
+        x = x + _fsmn(_ln(t, sd, p + "norm2", eps), sd[p + "self_attn.fsmn_block.weight"], tgt_mask, left_pad)
+        x = x + cross(_ln(x, sd, p + "norm3", eps), memory, mem_mask, p + "src_attn.")
+    p = prefix + "last_decoder."
+    t = _dec_ffn(_ln(x, sd, p + "norm1", eps), sd, p, eps)
+    x_self = x + _fsmn(_ln(t, sd, p + "norm2", eps), sd[p + "self_attn.fsmn_block.weight"], tgt_mask, left_pad)
+    x_src = cross(_ln(x_self, sd, p + "norm3", eps), memory, mem_mask, p + "src_attn.")
+    ctx = contextual_info.expand(B, -1, -1) if contextual_info.shape[0] != B else contextual_info
+    hot_mask = torch.ones(B, ctx.shape[1], dtype=torch.bool)
+    cx = cross(_ln(x_self, sd, prefix + "bias_decoder.norm3", eps), ctx, hot_mask, prefix + "bias_decoder.src_attn.")
+    cat = torch.cat([x_src, cx * clas_scale], dim=2)
+    x = x_self + F.conv1d(cat.transpose(1, 2), sd[prefix + "bias_output.weight"]).transpose(1, 2)
+    for i in range(max(cfg.get("num_blocks", L) - L, 0)):
+        p = prefix + f"decoders2.{i}."
+        t = _dec_ffn(_ln(x, sd, p + "norm1", eps), sd, p, eps)
+        x = x + _fsmn(_ln(t, sd, p + "norm2", eps), sd[p + "self_attn.fsmn_block.weight"], tgt_mask, (cfg["kernel_size"] - 1) // 2)
+    p = prefix + "decoders3.0."
+    x = _dec_ffn(_ln(x, sd, p + "norm1", eps), sd, p, eps)
+    hidden = _ln(x, sd, prefix + "after_norm", eps)
+    logits = F.linear(hidden, sd[prefix + "output_layer.weight"], sd[prefix + "output_layer.bias"])
+    return (logits, hidden) if return_hidden else logits
+
+
 def paraformer_greedy(feats: Tensor, lens: Tensor, sd: SD, cfg: dict, sos: int = 1, eos: int = 2, blank: int = 0):
     """Device half of Paraformer.inference, funasr/models/paraformer/model.py:596-666: encode -> predictor ->
     round().long() -> decoder -> log_softmax -> argmax per valid token -> drop sos/eos/blank.

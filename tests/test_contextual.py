@@ -111,3 +111,45 @@ def test_contextual_beam_search_on_the_gpu_equals_reference_inference(cuda, tmp_
                                  **beam_kw, **kw)
         want = json.loads(str(g[name]))
         assert [(r["key"], r["text"]) for r in res] == [(w["key"], w["text"]) for w in want], (name, res, want)
+
+
+def _decoder_case(tag):
+    from oracle.make_golden_contextual_decoder import decoder_weights
+    g = np.load(os.path.join(os.path.dirname(GOLD), "contextual_decoder.npz"), allow_pickle=False)
+    dc = json.loads(str(g[f"{tag}_cfg"]))
+    t = lambda k: torch.from_numpy(g[f"{tag}_{k}"])                                  # noqa: E731
+    return dc, decoder_weights(dc, int(g[f"{tag}_seed"])), t, float(g[f"{tag}_scale"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_oracle_contextual_decoder_equals_reference_logits(tag):
+    """oracle/paraformer_oracle.py contextual_decoder against logits of the reference's own ContextualParaformerDecoder
+    (contextual_paraformer/decoder.py:293-352; oracle/make_golden_contextual_decoder.py): hotword rows, clas_scale 0.6, decoders2 behind the fusion."""
+    from oracle import paraformer_oracle as O
+    dc, sd, t, scale = _decoder_case(tag)
+    logits = O.contextual_decoder(t("memory"), t("mem_lens"), t("embeds"), t("tok_lens"), t("hot"), sd, dc, clas_scale=scale)
+    ref = t("logits")
+    for b, n in enumerate(t("tok_lens").tolist()):
+        assert (logits[b, :n] - ref[b, :n]).abs().max().item() < 2e-5, (tag, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_contextual_decoder_on_the_gpu_equals_reference_logits(cuda, tag):
+    """pf_decoder_forward_contextual (last_decoder without its cross-attention residual, hotword branch, 1 x 1 fusion, decoders2 behind it
+    in case c) against the same reference logits, and the fused arg-max route against their arg-max."""
+    from funasr_amd.contextual_paraformer import ContextualParaformerDecoder
+    dc, sd, t, scale = _decoder_case(tag)
+    d = ContextualParaformerDecoder(**dc)
+    missing, unexpected = d.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    d = d.to(cuda)
+    args = (t("memory").to(cuda), t("mem_lens"), t("embeds").to(cuda), t("tok_lens"))
+    logits, olens = d(*args, contextual_info=t("hot").to(cuda), clas_scale=scale)
+    ref = t("logits")
+    assert olens.tolist() == t("tok_lens").tolist()
+    for b, n in enumerate(t("tok_lens").tolist()):
+        assert (logits[b, :n].cpu() - ref[b, :n]).abs().max().item() < 2e-4, (tag, b)
+    ids, _ = d.greedy(*args, contextual_info=t("hot").to(cuda), clas_scale=scale)
+    for b, n in enumerate(t("tok_lens").tolist()):
+        assert ids[b, :n].cpu().tolist() == ref[b, :n].argmax(-1).tolist()
